@@ -1,0 +1,231 @@
+"""Synthetic molecules and a seeded synthetic checkpoint (SURVEY.md §8 d).
+
+No real datasets or published checkpoints are reachable offline, so benchmarks
+and parity tests run on (a) self-avoiding random chains with the reference's
+per-atom integer encodings and (b) a randomly initialised checkpoint that uses
+the reference's state-dict names and tensor shapes
+(``/root/reference/src/jamun/model/arch/e3conv.py:15-85``), so that the same
+loader path serves real Lightning checkpoints.
+"""
+
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+import torch
+
+
+def default_arch(**over) -> dict:
+    """Hyper-parameters of ``src/jamun/hydra_config/model/arch/e3conv.yaml:3-14``."""
+    a = dict(
+        irreps_out="1x1e",
+        irreps_hidden="120x0e + 32x1e",
+        irreps_sh="1x0e + 1x1e",
+        n_layers=5,
+        edge_attr_dim=64,
+        atom_type_embedding_dim=8,
+        atom_code_embedding_dim=8,
+        residue_code_embedding_dim=32,
+        residue_index_embedding_dim=8,
+        use_residue_information=True,
+        use_residue_sequence_index=False,
+    )
+    a.update(over)
+    return a
+
+
+def random_chain(n_atoms: int, seed: int = 0, bond: float = 0.15, min_dist: float = 0.24) -> dict:
+    """Self-avoiding random chain: bonds (i-1, i), with every 4th atom branching off i-2.
+
+    Returns a molecule dict: ``pos [n,3] f32`` (nm), the four per-atom int32 index tensors, ``bonds [2,B] i64``
+    (each bond once, ``parent -> child``, as ``src/jamun/data/_mdtraj.py:73``).
+    """
+    rng = np.random.RandomState(seed)
+    pos = np.zeros((n_atoms, 3), dtype=np.float64)
+    parents = [-1]
+    for i in range(1, n_atoms):
+        p = i - 2 if (i % 4 == 3 and i >= 2) else i - 1
+        parents.append(p)
+        for _attempt in range(10000):
+            d = rng.normal(size=3)
+            d /= np.linalg.norm(d)
+            cand = pos[p] + bond * d
+            others = [j for j in range(i) if j != p]
+            if not others or np.min(np.linalg.norm(pos[others] - cand, axis=1)) >= min_dist:
+                pos[i] = cand
+                break
+        else:  # pragma: no cover
+            raise RuntimeError("could not place atom")
+    bonds = np.array([[parents[i], i] for i in range(1, n_atoms)], dtype=np.int64).T.reshape(2, -1)
+    idx = np.arange(n_atoms)
+    return dict(
+        pos=torch.tensor(pos, dtype=torch.float32),
+        atom_type_index=torch.tensor(rng.randint(0, 3, size=n_atoms), dtype=torch.int32),
+        atom_code_index=torch.tensor(rng.randint(0, 7, size=n_atoms), dtype=torch.int32),
+        residue_code_index=torch.tensor((idx // 5) % 20, dtype=torch.int32),
+        residue_sequence_index=torch.tensor(idx // 5, dtype=torch.int32),
+        bonds=torch.tensor(bonds, dtype=torch.long),
+    )
+
+
+def ag_dipeptide() -> dict:
+    """Hand-built uncapped Ala-Gly heavy-atom graph: N CA CB C O | N CA C O OXT.
+
+    Encodings follow ``src/jamun/utils/residue_metadata.py:7-32,62-83``; coordinates (nm) are an extended
+    conformation from ideal bond lengths/angles.
+    """
+    # atom names, elements, residue
+    names = ["N", "CA", "CB", "C", "O", "N", "CA", "C", "O", "OXT"]
+    elems = ["N", "C", "C", "C", "O", "N", "C", "C", "O", "O"]
+    res = ["ALA"] * 5 + ["GLY"] * 5
+    ATOM_TYPES = ["C", "O", "N", "F", "S"]
+    ATOM_CODES = ["C", "O", "N", "S", "CA", "CB"]
+    RES = ["ALA", "ARG", "ASN", "ASP", "CYS", "GLU", "GLN", "GLY"]
+    enc = lambda x, table: table.index(x) if x in table else len(table)
+    # extended backbone built in the xy plane with CB / O / OXT off-axis (Angstrom)
+    A = np.array(
+        [
+            [0.000, 0.000, 0.000],  # N
+            [1.458, 0.000, 0.000],  # CA
+            [1.994, 1.204, -0.773],  # CB
+            [2.009, -0.105, 1.419],  # C
+            [1.251, -0.332, 2.362],  # O
+            [3.326, 0.060, 1.557],  # N
+            [4.002, 0.000, 2.848],  # CA
+            [5.510, 0.150, 2.690],  # C
+            [6.020, 0.310, 1.560],  # O
+            [6.200, 0.100, 3.740],  # OXT
+        ]
+    )
+    bonds = [[0, 1], [1, 2], [1, 3], [3, 4], [3, 5], [5, 6], [6, 7], [7, 8], [7, 9]]
+    return dict(
+        pos=torch.tensor(A / 10.0, dtype=torch.float32),
+        atom_type_index=torch.tensor([enc(e, ATOM_TYPES) for e in elems], dtype=torch.int32),
+        atom_code_index=torch.tensor([enc(n, ATOM_CODES) for n in names], dtype=torch.int32),
+        residue_code_index=torch.tensor([enc(r, RES) for r in res], dtype=torch.int32),
+        residue_sequence_index=torch.tensor([0] * 5 + [1] * 5, dtype=torch.int32),
+        bonds=torch.tensor(bonds, dtype=torch.long).T.contiguous(),
+        atom_names=names,
+        residues=res,
+    )
+
+
+def _irreps_muls(s: str):
+    m0 = m1 = 0
+    for part in s.split("+"):
+        part = part.strip()
+        mul, ir = part.split("x")
+        if ir.strip() == "0e":
+            m0 += int(mul)
+        elif ir.strip() == "1e":
+            m1 += int(mul)
+        else:
+            raise NotImplementedError(part)
+    return m0, m1
+
+
+def synthetic_state_dict(arch: Optional[dict] = None, seed: int = 0, output_gain: float = 0.5, tp_weight_scale: float = 13.0) -> Dict[str, torch.Tensor]:
+    """Random-init parameters with the reference's names/shapes (no ``g.`` prefix).
+
+    ``o3.Linear`` weights ~ N(0,1) (e3nn default); ``nn.Linear`` / ``nn.Embedding`` use torch's default
+    init; the radial net's output layer is scaled by ``tp_weight_scale`` so messages are O(1);
+    noise-scaling last layers are ``(0, 1) + N(0, 0.1)`` (``noise_conditioning.py:39-42`` initialises to
+    exactly (0, 1)); ``output_gain`` is non-zero (the reference initialises it to 0, ``e3conv.py:85``).
+    """
+    arch = arch or default_arch()
+    g = torch.Generator().manual_seed(seed)
+    m0, m1 = _irreps_muls(arch["irreps_hidden"])
+    E = arch["edge_attr_dim"]
+    emb_dims = [
+        arch["atom_type_embedding_dim"],
+        arch["atom_code_embedding_dim"],
+        arch["residue_code_embedding_dim"],
+        arch["residue_index_embedding_dim"],
+    ]
+    # src/jamun/model/atom_embedding.py:54-56 uses atom_type dim twice for irreps bookkeeping
+    emb_irreps_muls = [emb_dims[0], emb_dims[0], emb_dims[2], emb_dims[3]]
+    n_emb = sum(emb_irreps_muls)
+    assert n_emb == sum(emb_dims), "atom_type/atom_code embedding dims must match (reference quirk, atom_embedding.py:54-56)"
+
+    def randn(*shape):
+        return torch.randn(*shape, generator=g)
+
+    def lin(out_f, in_f, scale=1.0):
+        bound = 1.0 / math.sqrt(in_f)
+        w = (torch.rand(out_f, in_f, generator=g) * 2 - 1) * bound * scale
+        b = (torch.rand(out_f, generator=g) * 2 - 1) * bound * scale
+        return w, b
+
+    sd: Dict[str, torch.Tensor] = {}
+    sd["embed_bondedness.weight"] = randn(2, E // 2)
+    sd["atom_embedder.atom_type_embedding.weight"] = randn(20, emb_dims[0])
+    sd["atom_embedder.atom_code_embedding.weight"] = randn(10, emb_dims[1])
+    sd["atom_embedder.residue_code_embedding.weight"] = randn(25, emb_dims[2])
+    sd["atom_embedder.residue_index_embedding.weight"] = randn(10, emb_dims[3])
+
+    def noise_mlp(prefix, k):
+        w, b = lin(k, 1)
+        sd[prefix + ".0.weight"], sd[prefix + ".0.bias"] = w, b
+        sd[prefix + ".2.weight"] = 0.1 * randn(k, k) / math.sqrt(k)
+        sd[prefix + ".2.bias"] = 1.0 + 0.1 * randn(k)
+
+    def conv_block(prefix, mul_in_scalar_blocks: Sequence[int], mul1_in: int):
+        n0_in = sum(mul_in_scalar_blocks)
+        # skip: Linear(in -> hidden); self: Linear(hidden -> hidden)
+        sd[prefix + ".gated_conv.skip_connection.weight"] = randn(n0_in * m0 + mul1_in * m1)
+        sd[prefix + ".gated_conv.self_interaction.weight"] = randn(m0 * m0 + m1 * m1)
+        # FCTP(in, 1x0e+1x1e, (m0+m1)x0e + m1x1e) weight count
+        g0, g1 = m0 + m1, m1
+        numel = 0
+        for mul in mul_in_scalar_blocks:
+            numel += mul * g0 + mul * g1
+        if mul1_in:
+            numel += mul1_in * g1 + mul1_in * g0 + mul1_in * g1
+        w0, b0 = lin(E, E)
+        w3, b3 = lin(numel, E, scale=tp_weight_scale)
+        sd[prefix + ".gated_conv.f.f.radial_nn.0.weight"], sd[prefix + ".gated_conv.f.f.radial_nn.0.bias"] = w0, b0
+        sd[prefix + ".gated_conv.f.f.radial_nn.3.weight"], sd[prefix + ".gated_conv.f.f.radial_nn.3.bias"] = w3, b3
+
+    noise_mlp("initial_noise_scaling.scale_predictor", n_emb)
+    conv_block("initial_projector", emb_irreps_muls, 0)
+    for i in range(arch["n_layers"]):
+        conv_block(f"layers.{i}", [m0], m1)
+        noise_mlp(f"noise_scalings.{i}.scale_predictor", m0 + m1)
+        noise_mlp(f"skip_connections.{i}.weights.scale_predictor", m0 + m1)
+        # skip weights go through a sigmoid: centre them at 0 instead of 1 for a balanced mix
+        sd[f"skip_connections.{i}.weights.scale_predictor.2.bias"] -= 1.0
+    sd["output_head.0.lin.weight"] = randn(m0 * (m0 + m1) + m1 * m1)
+    sd["output_head.1.weight"] = randn(m1)
+    sd["output_gain"] = torch.tensor(float(output_gain))
+    return sd
+
+
+def synthetic_checkpoint(
+    arch: Optional[dict] = None,
+    seed: int = 0,
+    max_radius: float = 1.0,
+    average_squared_distance: float = 0.332,
+    output_gain: float = 0.5,
+    prefix: str = "g.",
+) -> dict:
+    """A Lightning-shaped checkpoint dict: ``{"state_dict": {"g.<name>": ...}, "hyper_parameters": {...}}``."""
+    arch = arch or default_arch()
+    sd = synthetic_state_dict(arch, seed=seed, output_gain=output_gain)
+    return {
+        "state_dict": {prefix + k: v for k, v in sd.items()},
+        "hyper_parameters": dict(
+            arch=dict(arch),
+            max_radius=max_radius,
+            average_squared_distance=average_squared_distance,
+            mean_center=True,
+            use_torch_compile=(prefix != "g."),
+        ),
+        "pytorch-lightning_version": "2.4.0",
+    }
+
+
+def replicate(mol: dict, walkers: int) -> List[dict]:
+    """``repeat_init_samples`` walkers of the same molecule, consecutive (``src/jamun/cmdline/sample.py:35-37``)."""
+    return [mol for _ in range(walkers)]

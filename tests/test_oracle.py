@@ -1,0 +1,194 @@
+"""CPU tests: the oracle against the reference-generated golden vectors and analytic known answers."""
+import json
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import denoiser as od
+from oracle import e3
+from oracle import graph as og
+from oracle import walk as ow
+from jamun_amd import synth
+
+
+def _score_fn(d):
+    mu = torch.tensor(d["mu"])
+    s, a, b = [float(x) for x in d["score_params"]]
+    return lambda y: -(y - mu) / (s * s) + a * torch.sin(b * y)
+
+
+@pytest.mark.parametrize("name", ["baoab_default", "baoab_clip_mass", "baoab_noclip_notraj", "aboba_default", "aboba_clip_mass"])
+def test_integrators_match_reference_golden(golden_dir, name):
+    d = np.load(os.path.join(golden_dir, name + ".npz"))
+    meta = json.load(open(os.path.join(golden_dir, name + ".json")))
+    fn = getattr(ow, meta["integrator"])
+    noise = ow.RecordedNoise(torch.tensor(d["noise"]))
+    y, v, y_traj, score_traj = fn(torch.tensor(d["y0"]), _score_fn(d), noise=noise, **meta["kwargs"])
+    # same arithmetic, same order -> bit-exact on CPU
+    assert torch.equal(y, torch.tensor(d["y"]))
+    assert torch.equal(v, torch.tensor(d["v"]))
+    if "y_traj" in d:
+        assert torch.equal(y_traj, torch.tensor(d["y_traj"]))
+    else:
+        assert y_traj is None
+    assert torch.equal(score_traj, torch.tensor(d["score_traj"]))
+
+
+def test_torchnoise_reproduces_recorded_stream(golden_dir):
+    d = np.load(os.path.join(golden_dir, "baoab_default.npz"))
+    n = ow.TorchNoise(42)
+    like = torch.zeros(40, 3)
+    for i in range(5):
+        assert torch.equal(n(like), torch.tensor(d["noise"][i]))
+
+
+def test_aboba_without_trajectory_raises_like_reference():
+    with pytest.raises(RuntimeError):
+        ow.aboba(torch.zeros(4, 3), lambda y: -y, steps=3, noise=ow.TorchNoise(0), save_trajectory=False)
+
+
+def test_walk_jump_matches_reference_golden(golden_dir):
+    d = np.load(os.path.join(golden_dir, "walkjump_baoab.npz"))
+    meta = json.load(open(os.path.join(golden_dir, "walkjump_baoab.json")))
+    sigma = meta["sigma"]
+    sfn = _score_fn(d)
+    kw = dict(meta["kwargs"])
+    kw.pop("v_init")  # Sampler's v_init="gaussian" overrides the config's "zero" (mcmc/_splitting.py:57)
+    out = ow.walk_jump(sfn, lambda y: y + sigma**2 * sfn(y), ow.baoab, torch.tensor(d["y0"]), "gaussian", ow.RecordedNoise(torch.tensor(d["noise"])), **kw)
+    for k in ["xhat", "y", "v", "xhat_traj", "y_traj", "score_traj", "sample", "t_traj"]:
+        assert torch.equal(out[k], torch.tensor(d[k])), k
+    # BAOAB: the jump equals y_t + sigma^2 * score_t
+    assert torch.allclose(out["xhat_traj"], out["y_traj"] + sigma**2 * out["score_traj"], atol=1e-6)
+
+
+def test_encodings_golden(golden_dir):
+    enc = json.load(open(os.path.join(golden_dir, "encodings.json")))
+    from jamun_amd.data import encode_atom_type, encode_atom_code, encode_residue
+
+    for k, v in enc["atom_type"].items():
+        assert encode_atom_type(k) == v
+    for k, v in enc["atom_code"].items():
+        assert encode_atom_code(k) == v
+    for k, v in enc["residue"].items():
+        assert encode_residue(k) == v
+
+
+# ---- e3nn restatement: derived constants and known answers -------------------------------------
+
+
+def test_wigner_constants():
+    assert torch.allclose(e3.wigner_3j(0, 0, 0, torch.float64), torch.ones(1, 1, 1, dtype=torch.float64))
+    d = torch.eye(3, dtype=torch.float64) / math.sqrt(3)
+    assert torch.allclose(e3.wigner_3j(1, 1, 0, torch.float64)[:, :, 0], d)
+    assert torch.allclose(e3.wigner_3j(0, 1, 1, torch.float64)[0], d)
+    assert torch.allclose(e3.wigner_3j(1, 0, 1, torch.float64)[:, 0, :], d)
+    C = e3.wigner_3j(1, 1, 1, torch.float64)
+    eps = torch.zeros(3, 3, 3, dtype=torch.float64)
+    for i, j, k in [(0, 1, 2), (1, 2, 0), (2, 0, 1)]:
+        eps[i, j, k] = 1
+        eps[i, k, j] = -1
+    assert torch.allclose(C, eps / math.sqrt(6))
+
+
+def test_weight_counts_match_reference_shapes():
+    hid = e3.parse_irreps("120x0e + 32x1e")
+    sh = e3.parse_irreps("1x0e + 1x1e")
+    gin = od.gate_in_irreps(hid)
+    assert gin == [(152, 0), (32, 1)]
+    assert e3.fctp_weight_numel(hid, sh, gin) == 28992
+    assert e3.fctp_weight_numel([(8, 0), (8, 0), (32, 0), (8, 0)], sh, gin) == 10304
+    assert e3.linear_weight_numel([(8, 0), (8, 0), (32, 0), (8, 0)], hid) == 6720
+    assert e3.linear_weight_numel(hid, hid) == 15424
+    assert e3.linear_weight_numel(hid, gin) == 19264
+    offs = [i[3] for i in e3.fctp_instructions(hid, sh, gin)[0]]
+    assert offs == [0, 18240, 22080, 23104, 27968]
+
+
+def test_normalize2mom_constants():
+    assert abs(e3.normalize2mom_const("leaky_relu") - 1.4162684) < 1e-6
+    assert abs(e3.normalize2mom_const("sigmoid") - 1.8467055) < 1e-6
+
+
+def test_fctp_variance_preservation():
+    """e3nn's normalisation: unit-variance inputs and weights give ~unit second moment per output component."""
+    torch.manual_seed(0)
+    hid = e3.parse_irreps("120x0e + 32x1e")
+    sh = e3.parse_irreps("1x0e + 1x1e")
+    out = [(152, 0), (32, 1)]
+    Z = 512
+    x = torch.randn(Z, 216)
+    v = torch.randn(Z, 3)
+    y = e3.spherical_harmonics_01(v)
+    w = torch.randn(Z, 28992)
+    o = e3.fctp(x, y, w, hid, sh, out)
+    assert abs(o[:, :152].pow(2).mean().item() - 1.0) < 0.1
+    assert abs(o[:, 152:].pow(2).mean().item() - 1.0) < 0.1
+    lin = e3.linear(x, torch.randn(15424), hid, hid)
+    assert abs(lin.pow(2).mean().item() - 1.0) < 0.1
+
+
+def _setup(n_walkers=2, mol=None):
+    mol = mol or {k: v for k, v in synth.ag_dipeptide().items() if torch.is_tensor(v)}
+    topo = og.collate([mol] * n_walkers)
+    return topo
+
+
+def test_zero_gain_closed_form():
+    """output_gain = 0 (reference init, e3conv.py:85) => xhat = mean_center(c_skip * mean_center(y))."""
+    topo = _setup()
+    sd = synth.synthetic_state_dict(output_gain=0.0)
+    hp = od.default_hparams()
+    torch.manual_seed(0)
+    y = topo["pos"] + 0.04 * torch.randn_like(topo["pos"])
+    x = od.xhat(y, topo, 0.04, sd, hp)
+    A, B = 0.332, 6 * 0.04**2
+    yc = og.mean_center(y, topo["batch"], 2)
+    assert torch.allclose(x, og.mean_center(A / (A + B) * yc, topo["batch"], 2), atol=1e-7)
+
+
+def test_se3_equivariance_and_reflection():
+    from scipy.spatial.transform import Rotation
+
+    topo = _setup()
+    sd = synth.synthetic_state_dict()
+    hp = od.default_hparams()
+    torch.manual_seed(0)
+    y = (topo["pos"] + 0.04 * torch.randn_like(topo["pos"])).double()
+    sd64 = {k: v.double() for k, v in sd.items()}
+    x = od.xhat(y, topo, 0.04, sd64, hp)
+    R = torch.tensor(Rotation.random(random_state=1).as_matrix())
+    x2 = od.xhat(y @ R.T + torch.tensor([0.1, -0.3, 0.2], dtype=torch.float64), topo, 0.04, sd64, hp)
+    assert torch.allclose(x2, x @ R.T, atol=1e-10)
+    # all irreps are even parity: the 1e x 1e -> 1e (cross product) path breaks reflection equivariance
+    x3 = od.xhat(-y, topo, 0.04, sd64, hp)
+    assert (x3 + x).abs().max() > 1e-6
+
+
+def test_radius_graph_cap_and_order():
+    torch.manual_seed(0)
+    pos = torch.rand(50, 3) * 0.5  # dense: everyone within r
+    batch = torch.zeros(50, dtype=torch.long)
+    ei = og.radius_graph(pos, 10.0, batch)
+    src, dst = ei
+    for i in range(50):
+        nb = src[dst == i].tolist()
+        hits = list(range(50))[:33]
+        expect = [j for j in hits if j != i]
+        assert nb == expect
+    # two graphs never connect
+    batch2 = torch.cat([torch.zeros(25), torch.ones(25)]).long()
+    ei2 = og.radius_graph(pos, 10.0, batch2)
+    assert ((ei2[0] < 25) == (ei2[1] < 25)).all()
+    assert ei2.shape[1] == 2 * 25 * 24
+    # strict inequality
+    p3 = torch.tensor([[0.0, 0, 0], [1.0, 0, 0]])
+    assert og.radius_graph(p3, 1.0, torch.zeros(2, dtype=torch.long)).shape[1] == 0
+
+
+def test_scatter_mean_empty_rows_are_zero():
+    src = torch.ones(3, 2)
+    out = og.scatter_mean(src, torch.tensor([0, 0, 2]), 4)
+    assert torch.equal(out, torch.tensor([[1.0, 1], [0, 0], [1, 1], [0, 0]]))
