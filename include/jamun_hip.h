@@ -1,0 +1,197 @@
+/*
+ * jamun_hip.h — C ABI of the MI355X-native JAMUN walk-jump sampling path.
+ *
+ * The reference (prescient-design/jamun) is pure Python and has no FFI of its own; its
+ * extension points for this path are duck-typed Python protocols.  This header is the C ABI
+ * that sits UNDER those protocols: each entry point names the reference interface it
+ * replaces (paths relative to /root/reference).  Plain pointers and sizes only — no torch
+ * types.  All device pointers are HIP device memory owned by the caller; all work is
+ * enqueued on the `hipStream_t` passed in (as `void*`), with no internal synchronisation
+ * unless stated.  Every function returns 0 on success or a negative error code; the message
+ * is available from jamun_last_error() (thread-local).
+ *
+ * Build: hipcc --offload-arch=gfx950 -shared -fPIC (see jamun_amd/csrc/build.py).
+ */
+#ifndef JAMUN_HIP_H
+#define JAMUN_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define JAMUN_OK 0
+#define JAMUN_ERR_INVALID -1   /* bad argument / unsupported configuration */
+#define JAMUN_ERR_MISSING -2   /* a required checkpoint tensor is missing  */
+#define JAMUN_ERR_HIP -3       /* a HIP runtime call failed                */
+
+/* A named host tensor in the reference's state-dict layout (fp32, contiguous).
+ * Names are the reference's parameter names WITHOUT the "g." / "g._orig_mod." prefix,
+ * e.g. "layers.3.gated_conv.f.f.radial_nn.3.weight"  (src/jamun/model/arch/e3conv.py:15-85,
+ * src/jamun/e3tools/nn/_conv.py:76-92). */
+typedef struct jamun_tensor {
+  const char* name;
+  const float* data; /* host pointer */
+  int64_t numel;
+} jamun_tensor;
+
+/* Architecture + denoiser hyper-parameters
+ * (src/jamun/hydra_config/model/arch/e3conv.yaml:3-14, src/jamun/model/denoiser.py:16-33). */
+typedef struct jamun_hparams {
+  int32_t n_layers;               /* hidden ConvBlocks (5)                       */
+  int32_t mul0, mul1;             /* irreps_hidden = mul0 x0e + mul1 x1e (120,32) */
+  int32_t edge_attr_dim;          /* 64: 32 bonded-embedding + 32 radial          */
+  int32_t emb_dim[4];             /* atom_type, atom_code, residue_code, residue_index (8,8,32,8) */
+  int32_t emb_rows[4];            /* embedding table rows (20,10,25,10)           */
+  int32_t use_residue_sequence_index; /* 0: index zeroed (atom_embedding.py:69-71) */
+  int32_t mean_center;            /* Denoiser.mean_center                         */
+  float max_radius;               /* Denoiser.max_radius                          */
+  float average_squared_distance; /* Denoiser.average_squared_distance            */
+  float act_scalar_const;         /* e3nn normalize2mom(LeakyReLU(0.01))  = 1.4162684 */
+  float act_gate_const;           /* e3nn normalize2mom(sigmoid)          = 1.8467055 */
+  float w3j_111_sign;             /* +1: wigner_3j(1,1,1) = +eps/sqrt(6) (e3nn 0.5.4)   */
+} jamun_hparams;
+
+/* Static description of the walker batch — what torch_geometric's Batch.from_data_list gives the
+ * reference (src/jamun/cmdline/sample.py:27-38, src/jamun/utils/data_with_residue_info.py:17-33).
+ * All host pointers.  bonds are directed pairs (src,dst) already offset into the batch. */
+typedef struct jamun_topology {
+  int32_t n_atoms;
+  int32_t n_graphs;
+  const int32_t* ptr;                    /* [n_graphs+1] first atom of each walker */
+  const int32_t* atom_type_index;        /* [n_atoms] */
+  const int32_t* atom_code_index;        /* [n_atoms] */
+  const int32_t* residue_code_index;     /* [n_atoms] */
+  const int32_t* residue_sequence_index; /* [n_atoms] */
+  int32_t n_bonds;
+  const int64_t* bond_src;               /* [n_bonds] edge_index[0] of the dataset's bonded edges */
+  const int64_t* bond_dst;               /* [n_bonds] edge_index[1]                               */
+} jamun_topology;
+
+/* Langevin splitting-integrator parameters — the fields of the BAOAB/ABOBA dataclasses
+ * (src/jamun/sampling/mcmc/_splitting.py:11-58) consumed by
+ * src/jamun/sampling/mcmc/functional/_splitting.py:44-178. */
+typedef struct jamun_mcmc_params {
+  int32_t steps;              /* range(1, steps): steps-1 integrator iterations     */
+  int32_t save_every_n_steps; /* >= 1                                               */
+  int32_t burn_in_steps;
+  int32_t has_clip;           /* 0: score_fn_clip = None                            */
+  float delta, friction, M, inverse_temperature, score_fn_clip;
+} jamun_mcmc_params;
+
+typedef struct jamun_model jamun_model;     /* raw checkpoint tensors kept on the host          */
+typedef struct jamun_sampler jamun_sampler; /* sigma- and topology-specific device state        */
+
+const char* jamun_last_error(void);
+int jamun_version(void);
+
+/* Replaces Denoiser.load_from_checkpoint's module construction + load_state_dict
+ * (src/jamun/hydra_config/model/denoiser_pretrained.yaml:1-2, src/jamun/model/denoiser.py:16-42). */
+int jamun_model_create(const jamun_hparams* hp, const jamun_tensor* tensors, int32_t n_tensors, jamun_model** out);
+void jamun_model_destroy(jamun_model* m);
+
+/* Binds a model to one noise level and one walker batch: folds the noise-conditioning constants
+ * (src/jamun/model/noise_conditioning.py:50-73), path normalisations and Clebsch-Gordan factors into
+ * MFMA-ordered packed weights, uploads them, and allocates every work buffer.  Replaces
+ * ModelSamplingWrapper.__init__ + the per-call graph clone (src/jamun/utils/sampling_wrapper.py:12-47).
+ * Synchronous (uploads weights). */
+int jamun_sampler_create(const jamun_model* m, float sigma, const jamun_topology* topo, jamun_sampler** out);
+void jamun_sampler_destroy(jamun_sampler* s);
+
+/* Denoiser.xhat (src/jamun/model/denoiser.py:203-217): y_dev [n_atoms,3] -> xhat_dev [n_atoms,3]. */
+int jamun_xhat(jamun_sampler* s, const float* y_dev, float* xhat_dev, void* stream);
+/* Denoiser.score (src/jamun/model/denoiser.py:111-114). */
+int jamun_score(jamun_sampler* s, const float* y_dev, float* score_dev, void* stream);
+
+/* baoab() (src/jamun/sampling/mcmc/functional/_splitting.py:112-178) with the model's score, fused with the
+ * jump of SingleMeasurementSampler.walk_jump (src/jamun/sampling/walkjump/_single_measurement.py:49-79).
+ *   y_dev, v_dev  [n_atoms,3]  in: y_init, v_init (already initialised) ; out: final y, v
+ *   noise_dev     [steps-1, n_atoms, 3] standard-normal draws, one per iteration (reference RNG call order),
+ *                 or NULL to draw them in-kernel from Philox4x32-10 keyed by (seed, iteration, atom)
+ *   y_traj_dev, score_traj_dev, xhat_traj_dev  [T, n_atoms, 3] or NULL (save_trajectory=False);
+ *                 T = jamun_num_frames(params, 0).  xhat_traj[t] = y_traj[t] + sigma^2 * score_traj[t]
+ *                 (identical to the reference's extra forward per frame, in exact arithmetic)
+ *   xhat_dev      [n_atoms,3] xhat(y_final) or NULL
+ * No host synchronisation; all steps are enqueued on `stream`. */
+int jamun_walk_baoab(jamun_sampler* s, float* y_dev, float* v_dev, const jamun_mcmc_params* p, const float* noise_dev,
+                     uint64_t seed, float* y_traj_dev, float* score_traj_dev, float* xhat_traj_dev, float* xhat_dev,
+                     void* stream);
+/* aboba() (src/jamun/sampling/mcmc/functional/_splitting.py:44-109).  score_traj has T-1 frames (scores at the
+ * half-step positions, :90,99-101); xhat_traj (if requested) costs one extra forward per saved frame, as the
+ * reference (the half-step score cannot be reused). */
+int jamun_walk_aboba(jamun_sampler* s, float* y_dev, float* v_dev, const jamun_mcmc_params* p, const float* noise_dev,
+                     uint64_t seed, float* y_traj_dev, float* score_traj_dev, float* xhat_traj_dev, float* xhat_dev,
+                     void* stream);
+/* Number of saved y frames for (steps, save_every_n_steps, burn_in_steps); aboba's score_traj has one fewer
+ * when burn_in_steps == 0.  */
+int jamun_num_frames(const jamun_mcmc_params* p, int32_t* n_y_frames, int32_t* n_score_frames_baoab,
+                     int32_t* n_score_frames_aboba);
+
+/* ---- stand-alone operators of the path (also used for unit-level parity tests) -------------------------- */
+
+/* mean_center (src/jamun/utils/mean_center.py:7-12): out = pos - centroid(graph).  ptr_dev [n_graphs+1] int32. */
+int jamun_mean_center(const float* pos_dev, const int32_t* ptr_dev, int32_t n_graphs, float* out_dev, void* stream);
+
+/* torch_geometric.nn.radius_graph(pos, r, batch) with torch_cluster CUDA semantics, call site
+ * src/jamun/model/denoiser.py:149: per centre, scan its graph in index order, keep while d^2 < r^2 until 33 hits,
+ * drop self.  Output is a fixed-stride neighbour table: nbr_dev [n_atoms, stride] (src indices, ascending),
+ * deg_dev [n_atoms].  stride >= 33. */
+int jamun_radius_graph(const float* pos_dev, const int32_t* ptr_dev, int32_t n_graphs, int32_t n_atoms, float r,
+                       int32_t stride, int32_t* nbr_dev, int32_t* deg_dev, void* stream);
+
+/* torch_scatter.scatter(src, index, dim=0, dim_size, reduce="mean"), call site src/jamun/e3tools/nn/_conv.py:117,
+ * for a destination-sorted index given as CSR: rows seg_ptr[d]..seg_ptr[d+1] of src are averaged into out[d]
+ * (empty segment -> 0).  Fixed summation order (row order), no atomics.  src_dev [E, width], out_dev [n_out, width]. */
+int jamun_scatter_mean(const float* src_dev, const int32_t* seg_ptr_dev, int32_t n_out, int32_t width, float* out_dev,
+                       void* stream);
+
+/* One BAOAB iteration's state update around the score evaluation
+ * (src/jamun/sampling/mcmc/functional/_splitting.py:158-166):
+ *   pre : v += u*(delta/2)*psi ; y += (delta/2)*v ; vhat = exp(-gamma)*v + zeta*sqrt(u)*R ; y += (delta/2)*vhat
+ *   post: psi = clip(score)*beta ; v = vhat + (delta/2)*psi          (no u, as the reference :166)
+ * n = number of atoms; arrays are [n,3]. */
+int jamun_baoab_pre(float* y_dev, float* v_dev, const float* psi_dev, const float* noise_dev, int32_t n,
+                    const jamun_mcmc_params* p, void* stream);
+int jamun_baoab_post(float* v_dev, float* psi_dev, const float* score_dev, int32_t n, const jamun_mcmc_params* p,
+                     void* stream);
+
+/* Introspection for tests / benchmarks. */
+typedef struct jamun_stats {
+  int64_t n_edges;        /* directed edges (radial + bonded) in the last forward             */
+  int64_t flop_ref_assoc; /* FLOPs of one forward in the reference association (SURVEY §8 d)  */
+  int64_t flop_executed;  /* FLOPs actually issued on MFMA/VALU by this implementation         */
+  int64_t conv_k0, conv_k1; /* padded contraction depth of the scalar / vector conv GEMMs (hidden layer) */
+  int64_t conv0_flop_alg;   /* useful FLOPs of ONE hidden-layer scalar-row conv launch: 2*n_atoms*65*(mul0+mul1)*(mul0+mul1) */
+  int64_t conv1_flop_alg;   /* useful FLOPs of ONE hidden-layer vector-row conv launch: 2*3*n_atoms*65*(mul0+2*mul1)*mul1   */
+  int32_t edge_stride;
+  int32_t n_slices;
+} jamun_stats;
+/* Synchronises `stream`. */
+int jamun_sampler_stats(jamun_sampler* s, jamun_stats* out, void* stream);
+
+/* Per-kernel-class timing with HIP events recorded on the launch stream around each launch of the forward
+ * (bench.py's roofline leg).  enable(1) starts collecting; read() synchronises `stream`, returns the summed
+ * elapsed milliseconds and launch count per class (arrays of JAMUN_PROF_NCLASS) and clears the collection. */
+#define JAMUN_PROF_GEOM 0        /* centring + radius graph + edge geometry                         */
+#define JAMUN_PROF_EDGE_H 1      /* radial-MLP hidden layer per edge                                */
+#define JAMUN_PROF_CONV0_INIT 2  /* conv contraction, scalar-output rows, initial projector          */
+#define JAMUN_PROF_CONV1_INIT 3  /* conv contraction, vector-output rows, initial projector          */
+#define JAMUN_PROF_CONV0 4       /* conv contraction, scalar-output rows, hidden layers (dominant)   */
+#define JAMUN_PROF_CONV1 5       /* conv contraction, vector-output rows, hidden layers              */
+#define JAMUN_PROF_NODE 6        /* partial-slab reduce + gate + self/skip Linear + noise skip mix   */
+#define JAMUN_PROF_HEAD 7        /* output head + xhat/score finalize                                */
+#define JAMUN_PROF_NCLASS 8
+int jamun_profile_enable(jamun_sampler* s, int32_t on);
+int jamun_profile_read(jamun_sampler* s, double* ms_total, int64_t* launches, void* stream);
+
+/* Copy internal buffers out for layer-level parity tests (device->device on `stream`):
+ *   what = 0: node features after block `layer` (0 = initial projector) [n_atoms, mul0+3*mul1]
+ *   what = 1: in-degree (radial + bonded) as float [n_atoms]
+ *   what = 2: network output g [n_atoms,3] (before c_skip/c_out)                          */
+int jamun_debug_read(jamun_sampler* s, int32_t what, int32_t layer, float* out_dev, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* JAMUN_HIP_H */

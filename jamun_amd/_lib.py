@@ -1,0 +1,137 @@
+"""ctypes binding of ``libjamun_hip.so`` (C ABI declared in ``include/jamun_hip.h``).
+
+The product path has no CPU fallback: if the shared library is missing or does not load, every
+operator raises ``RuntimeError`` (build it with ``python jamun_amd/csrc/build.py``).
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libjamun_hip.so")
+
+
+class jamun_tensor(C.Structure):
+    _fields_ = [("name", C.c_char_p), ("data", C.POINTER(C.c_float)), ("numel", C.c_int64)]
+
+
+class jamun_hparams(C.Structure):
+    _fields_ = [
+        ("n_layers", C.c_int32),
+        ("mul0", C.c_int32),
+        ("mul1", C.c_int32),
+        ("edge_attr_dim", C.c_int32),
+        ("emb_dim", C.c_int32 * 4),
+        ("emb_rows", C.c_int32 * 4),
+        ("use_residue_sequence_index", C.c_int32),
+        ("mean_center", C.c_int32),
+        ("max_radius", C.c_float),
+        ("average_squared_distance", C.c_float),
+        ("act_scalar_const", C.c_float),
+        ("act_gate_const", C.c_float),
+        ("w3j_111_sign", C.c_float),
+    ]
+
+
+class jamun_topology(C.Structure):
+    _fields_ = [
+        ("n_atoms", C.c_int32),
+        ("n_graphs", C.c_int32),
+        ("ptr", C.POINTER(C.c_int32)),
+        ("atom_type_index", C.POINTER(C.c_int32)),
+        ("atom_code_index", C.POINTER(C.c_int32)),
+        ("residue_code_index", C.POINTER(C.c_int32)),
+        ("residue_sequence_index", C.POINTER(C.c_int32)),
+        ("n_bonds", C.c_int32),
+        ("bond_src", C.POINTER(C.c_int64)),
+        ("bond_dst", C.POINTER(C.c_int64)),
+    ]
+
+
+class jamun_mcmc_params(C.Structure):
+    _fields_ = [
+        ("steps", C.c_int32),
+        ("save_every_n_steps", C.c_int32),
+        ("burn_in_steps", C.c_int32),
+        ("has_clip", C.c_int32),
+        ("delta", C.c_float),
+        ("friction", C.c_float),
+        ("M", C.c_float),
+        ("inverse_temperature", C.c_float),
+        ("score_fn_clip", C.c_float),
+    ]
+
+
+class jamun_stats(C.Structure):
+    _fields_ = [
+        ("n_edges", C.c_int64),
+        ("flop_ref_assoc", C.c_int64),
+        ("flop_executed", C.c_int64),
+        ("conv_k0", C.c_int64),
+        ("conv_k1", C.c_int64),
+        ("conv0_flop_alg", C.c_int64),
+        ("conv1_flop_alg", C.c_int64),
+        ("edge_stride", C.c_int32),
+        ("n_slices", C.c_int32),
+    ]
+
+
+# every symbol include/jamun_hip.h declares: name -> (restype, argtypes)
+_P = C.c_void_p
+SYMBOLS = {
+    "jamun_last_error": (C.c_char_p, []),
+    "jamun_version": (C.c_int, []),
+    "jamun_model_create": (C.c_int, [C.POINTER(jamun_hparams), C.POINTER(jamun_tensor), C.c_int32, C.POINTER(_P)]),
+    "jamun_model_destroy": (None, [_P]),
+    "jamun_sampler_create": (C.c_int, [_P, C.c_float, C.POINTER(jamun_topology), C.POINTER(_P)]),
+    "jamun_sampler_destroy": (None, [_P]),
+    "jamun_xhat": (C.c_int, [_P, _P, _P, _P]),
+    "jamun_score": (C.c_int, [_P, _P, _P, _P]),
+    "jamun_walk_baoab": (C.c_int, [_P, _P, _P, C.POINTER(jamun_mcmc_params), _P, C.c_uint64, _P, _P, _P, _P, _P]),
+    "jamun_walk_aboba": (C.c_int, [_P, _P, _P, C.POINTER(jamun_mcmc_params), _P, C.c_uint64, _P, _P, _P, _P, _P]),
+    "jamun_num_frames": (C.c_int, [C.POINTER(jamun_mcmc_params), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "jamun_mean_center": (C.c_int, [_P, _P, C.c_int32, _P, _P]),
+    "jamun_radius_graph": (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_float, C.c_int32, _P, _P, _P]),
+    "jamun_scatter_mean": (C.c_int, [_P, _P, C.c_int32, C.c_int32, _P, _P]),
+    "jamun_baoab_pre": (C.c_int, [_P, _P, _P, _P, C.c_int32, C.POINTER(jamun_mcmc_params), _P]),
+    "jamun_baoab_post": (C.c_int, [_P, _P, _P, C.c_int32, C.POINTER(jamun_mcmc_params), _P]),
+    "jamun_sampler_stats": (C.c_int, [_P, C.POINTER(jamun_stats), _P]),
+    "jamun_profile_enable": (C.c_int, [_P, C.c_int32]),
+    "jamun_profile_read": (C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(C.c_int64), _P]),
+    "jamun_debug_read": (C.c_int, [_P, C.c_int32, C.c_int32, _P, _P]),
+}
+
+PROF_CLASSES = ["geom", "edge_h", "conv0_init", "conv1_init", "conv0", "conv1", "node_update", "head_finalize"]
+
+_lib: Optional[C.CDLL] = None
+
+
+def load() -> C.CDLL:
+    """Load the HIP library or raise.  There is deliberately no fallback."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} not found: the HIP extension is not built. Run `python jamun_amd/csrc/build.py` "
+            "(hipcc --offload-arch=gfx950). jamun_amd has no CPU fallback."
+        )
+    try:
+        lib = C.CDLL(LIB_PATH)
+    except OSError as e:  # pragma: no cover
+        raise RuntimeError(f"could not load {LIB_PATH}: {e}") from e
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)  # AttributeError if the library does not export a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(code: int) -> None:
+    if code != 0:
+        msg = load().jamun_last_error()
+        raise RuntimeError(f"jamun_hip error {code}: {msg.decode() if msg else '?'}")

@@ -1,0 +1,98 @@
+"""Checkpoint location and loading for the sampling path.
+
+``find_checkpoint`` keeps the ``checkpoint_dir`` / ``checkpoint_type`` semantics of
+``/root/reference/src/jamun/utils/checkpoint.py:25-68`` (the wandb lookup is out of scope offline).
+``load_checkpoint_file`` reads a Lightning ``.ckpt`` (a ``torch.save``d dict with ``state_dict`` and
+``hyper_parameters``).  Real JAMUN checkpoints pickle ``functools.partial`` / ``omegaconf`` objects that reference
+modules which are not installed here (hydra, omegaconf, e3nn, lightning, jamun.*); those are resolved by a tolerant
+unpickler that substitutes inert stand-ins and keeps only plain keyword data.
+"""
+
+from __future__ import annotations
+
+import os
+import pickle
+import re
+from typing import Optional
+
+import torch
+
+
+def find_checkpoint_in_directory(checkpoint_dir: str, checkpoint_type: str) -> str:
+    """``utils/checkpoint.py:25-50``: 'last' -> last.ckpt, 'best_so_far' -> highest ``epoch=N-...ckpt``, or a file name."""
+    if checkpoint_type.endswith(".ckpt"):
+        path = os.path.join(checkpoint_dir, checkpoint_type)
+        if not os.path.exists(path):
+            raise ValueError(f"Checkpoint {path} not found")
+        return path
+    if checkpoint_type == "last":
+        path = os.path.join(checkpoint_dir, "last.ckpt")
+        if not os.path.exists(path):
+            raise ValueError(f"Checkpoint {path} not found")
+        return path
+    if checkpoint_type == "best_so_far":
+        best_epoch, best = -1, None
+        for f in sorted(os.listdir(checkpoint_dir)):
+            m = re.match(r"epoch=(\d+)-.*\.ckpt$", f)
+            if m and int(m.group(1)) > best_epoch:
+                best_epoch, best = int(m.group(1)), f
+        if best is None:
+            raise ValueError(f"No epoch=*.ckpt checkpoint found in {checkpoint_dir}")
+        return os.path.join(checkpoint_dir, best)
+    raise ValueError(f"Invalid checkpoint type: {checkpoint_type}")
+
+
+def find_checkpoint(wandb_train_run_path: Optional[str] = None, checkpoint_dir: Optional[str] = None, checkpoint_type: Optional[str] = None) -> str:
+    """``utils/checkpoint.py:53-68``: exactly one of ``wandb_train_run_path`` / ``checkpoint_dir``."""
+    if wandb_train_run_path and checkpoint_dir:
+        raise ValueError("Exactly one of wandb_train_run_path or checkpoint_dir must be provided.")
+    if not wandb_train_run_path and not checkpoint_dir:
+        raise ValueError("Must provide one of wandb_train_run_path or checkpoint_dir")
+    if wandb_train_run_path:
+        raise NotImplementedError("wandb run lookup is not available offline; pass checkpoint_dir=... wandb_train_run_path=null")
+    return find_checkpoint_in_directory(checkpoint_dir, checkpoint_type or "last")
+
+
+class _Inert:
+    """Stand-in for a class from a module that is not installed: keeps constructor/state data, does nothing."""
+
+    def __init__(self, *args, **kwargs):
+        self._args, self._kwargs = args, kwargs
+
+    def __setstate__(self, state):
+        self.__dict__["_state"] = state
+
+    def items(self):
+        st = self.__dict__.get("_state") or {}
+        content = st.get("_content", st) if isinstance(st, dict) else {}
+        return content.items() if isinstance(content, dict) else []
+
+
+class _TolerantUnpickler(pickle.Unpickler):
+    def find_class(self, module, name):
+        try:
+            return super().find_class(module, name)
+        except Exception:
+            return type(name, (_Inert,), {"__module__": module})
+
+
+class _TolerantPickle:
+    """``pickle_module`` for ``torch.load``: unknown classes become inert stand-ins instead of import errors."""
+
+    __name__ = "pickle"
+    Unpickler = _TolerantUnpickler
+    Pickler = pickle.Pickler
+
+    @staticmethod
+    def load(f, **kw):
+        return _TolerantUnpickler(f, **kw).load()
+
+
+def load_checkpoint_file(path: str) -> dict:
+    try:
+        ckpt = torch.load(path, map_location="cpu", weights_only=False)
+    except (ModuleNotFoundError, AttributeError, ImportError):
+        ckpt = torch.load(path, map_location="cpu", weights_only=False, pickle_module=_TolerantPickle)
+    if not isinstance(ckpt, dict) or "state_dict" not in ckpt or "hyper_parameters" not in ckpt:
+        raise RuntimeError(f"{path} is not a Lightning checkpoint with state_dict + hyper_parameters")
+    return ckpt

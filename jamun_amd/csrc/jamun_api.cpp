@@ -1,0 +1,865 @@
+// jamun_api.cpp — host runtime behind include/jamun_hip.h: checkpoint-tensor lookup, constant folding and
+// MFMA-ordered weight packing, work-buffer management, and the per-step launch sequence.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/jamun_hip.h"
+#include "jamun_internal.h"
+
+namespace {
+
+thread_local std::string g_err;
+
+struct Err : std::runtime_error {
+  int code;
+  Err(int c, const std::string& m) : std::runtime_error(m), code(c) {}
+};
+
+#define HIPCHECK(expr)                                                                                 \
+  do {                                                                                                 \
+    hipError_t _e = (expr);                                                                            \
+    if (_e != hipSuccess) throw Err(JAMUN_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e)); \
+  } while (0)
+
+template <typename F>
+int guarded(F&& f) {
+  try {
+    f();
+    return JAMUN_OK;
+  } catch (const Err& e) {
+    g_err = e.what();
+    return e.code;
+  } catch (const std::exception& e) {
+    g_err = e.what();
+    return JAMUN_ERR_INVALID;
+  }
+}
+
+template <typename T>
+T* dev_alloc(size_t n) {
+  T* p = nullptr;
+  HIPCHECK(hipMalloc((void**)&p, std::max<size_t>(n, 1) * sizeof(T)));
+  return p;
+}
+template <typename T>
+T* dev_upload(const std::vector<T>& v) {
+  T* p = dev_alloc<T>(v.size());
+  if (!v.empty()) HIPCHECK(hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+  return p;
+}
+
+}  // namespace
+
+struct jamun_model {
+  jamun_hparams hp;
+  std::map<std::string, std::vector<float>> t;
+  const std::vector<float>& get(const std::string& name, int64_t numel = -1) const {
+    auto it = t.find(name);
+    if (it == t.end()) throw Err(JAMUN_ERR_MISSING, "missing checkpoint tensor: " + name);
+    if (numel >= 0 && (int64_t)it->second.size() != numel)
+      throw Err(JAMUN_ERR_INVALID, "tensor " + name + " has " + std::to_string(it->second.size()) +
+                                       " elements, expected " + std::to_string(numel));
+    return it->second;
+  }
+};
+
+namespace {
+
+// ---- packed conv problem ------------------------------------------------------------------------
+struct UEntry {
+  int type;      // JAMUN_T_*
+  int cross;     // 1 for the cross-product half of an X1C block
+  int xoff;      // offset of the channel's first float inside a node feature row
+  int64_t wbase; // offset of W row (u, :) inside the flat tensor-product weight vector
+  double scale;  // path coefficient * CG factor * input noise scaling
+};
+struct UBlock {
+  int type;
+  std::vector<UEntry> e;  // nu entries (even)
+};
+struct ConvProblemDev {
+  float* wpack = nullptr;
+  int4* chunks = nullptr;
+  int* slice_ptr = nullptr;
+  int4* ublk = nullptr;
+  int* lane_xoff = nullptr;
+  int rc = 0, nt = 0, nk = 0;
+  int64_t K = 0;  // padded contraction depth
+};
+struct LayerDev {
+  ConvProblemDev p0, p1;
+  float *w1r = nullptr, *cmask = nullptr;
+  float *w_self0 = nullptr, *w_self1 = nullptr, *w_skip0 = nullptr, *w_skip1 = nullptr, *mix = nullptr;
+  int in0 = 0, in1 = 0, XSin = 0;
+  int64_t tp_numel = 0;
+};
+
+void free_problem(ConvProblemDev& p) {
+  hipFree(p.wpack); hipFree(p.chunks); hipFree(p.slice_ptr); hipFree(p.ublk); hipFree(p.lane_xoff);
+}
+
+std::vector<double> noise_mlp(const jamun_model& m, const std::string& prefix, int k, double c_noise) {
+  // Linear(1->k) . SELU . Linear(k->k)   (src/jamun/model/noise_conditioning.py:33-37)
+  const auto& w0 = m.get(prefix + ".0.weight", k);
+  const auto& b0 = m.get(prefix + ".0.bias", k);
+  const auto& w2 = m.get(prefix + ".2.weight", (int64_t)k * k);
+  const auto& b2 = m.get(prefix + ".2.bias", k);
+  const double alpha = 1.6732632423543772848170429916717, scale = 1.0507009873554804934193349852946;
+  std::vector<double> h(k), out(k);
+  for (int i = 0; i < k; ++i) {
+    double z = (double)w0[i] * c_noise + (double)b0[i];
+    h[i] = scale * (z > 0 ? z : alpha * (std::exp(z) - 1.0));
+  }
+  for (int o = 0; o < k; ++o) {
+    double s = b2[o];
+    for (int i = 0; i < k; ++i) s += (double)w2[(size_t)o * k + i] * h[i];
+    out[o] = s;
+  }
+  return out;
+}
+
+struct InBlock { int mul, l, xoff, ch0; };
+
+ConvProblemDev pack_problem(const std::vector<UBlock>& blocks, int rc, int G, int nk, int n_slices,
+                            const std::vector<float>& W3, const std::vector<float>& b3, int hidden) {
+  ConvProblemDev P;
+  P.rc = rc;
+  P.nk = nk;
+  P.nt = (G + 31) / 32;
+  const int NT = P.nt;
+  const int kp = ((hidden + 1 + nk - 1) / nk) * nk;  // hidden units + bias row, padded to the k-group size
+  std::vector<int4> chunks;
+  std::vector<int> steps;
+  int64_t wofs = 0;  // in units of 64 floats
+  for (int k0 = 0; k0 < kp; k0 += nk)
+    for (size_t b = 0; b < blocks.size(); ++b) {
+      const int nu = (int)blocks[b].e.size();
+      const int ns = nk * nu / 2;
+      chunks.push_back(make_int4((int)b, k0, (int)wofs, 0));
+      steps.push_back(ns);
+      wofs += (int64_t)ns * NT;
+    }
+  if (wofs * 64 > (int64_t)1 << 31) throw Err(JAMUN_ERR_INVALID, "packed conv weights exceed 2^31 floats");
+  std::vector<float> wp((size_t)wofs * 64, 0.f);
+  int64_t Ktot = 0;
+  for (size_t ci = 0; ci < chunks.size(); ++ci) {
+    const UBlock& B = blocks[chunks[ci].x];
+    const int nu = (int)B.e.size(), k0 = chunks[ci].y;
+    float* dst = wp.data() + (size_t)chunks[ci].z * 64;
+    Ktot += (int64_t)nk * nu;
+    for (int q = 0; q < steps[ci]; ++q)
+      for (int nt = 0; nt < NT; ++nt)
+        for (int lane = 0; lane < 64; ++lane) {
+          const int hh = lane >> 5, c = lane & 31;
+          const int kidx = 2 * q + hh, kl = kidx / nu, ul = kidx % nu;
+          const int k = k0 + kl, col = nt * 32 + c;
+          const UEntry& ue = B.e[ul];
+          float v = 0.f;
+          if (k <= hidden && col < G && ue.scale != 0.0) {
+            const int64_t p = ue.wbase + col;
+            const double w = (k < hidden) ? (double)W3[(size_t)p * hidden + k] : (double)b3[p];
+            v = (float)(w * ue.scale);
+          }
+          dst[((size_t)q * NT + nt) * 64 + lane] = v;
+        }
+  }
+  P.K = Ktot;
+  // contiguous slices balanced by K-steps
+  int64_t total = 0;
+  for (int s : steps) total += s;
+  std::vector<int> sp(n_slices + 1, 0);
+  {
+    int64_t cum = 0;
+    int s = 0;
+    for (size_t ci = 0; ci < chunks.size(); ++ci) {
+      while (s <= n_slices && cum * n_slices >= total * (int64_t)s) sp[s++] = (int)ci;
+      cum += steps[ci];
+    }
+    while (s <= n_slices) sp[s++] = (int)chunks.size();
+    sp[n_slices] = (int)chunks.size();
+  }
+  std::vector<int4> ub;
+  std::vector<int> lx;
+  for (const UBlock& B : blocks) {
+    ub.push_back(make_int4(B.type, (int)B.e.size(), 0, 0));
+    for (int lane = 0; lane < 64; ++lane) {
+      int v = 0;
+      if (lane < (int)B.e.size()) v = B.e[lane].xoff | (B.e[lane].cross ? JAMUN_XOFF_CROSS : 0);
+      lx.push_back(v);
+    }
+  }
+  P.wpack = dev_upload(wp);
+  P.chunks = dev_upload(chunks);
+  P.slice_ptr = dev_upload(sp);
+  P.ublk = dev_upload(ub);
+  P.lane_xoff = dev_upload(lx);
+  return P;
+}
+
+void pad_even(UBlock& b) {
+  if (b.e.size() % 2) b.e.push_back(UEntry{b.type, 0, 0, 0, 0.0});
+}
+
+}  // namespace
+
+struct jamun_sampler {
+  jamun_hparams hp;
+  float sigma = 0;
+  int n_atoms = 0, n_graphs = 0, n_pad = 0, S = 0, n_slices = 8;
+  int XS = 0, n_emb = 0;
+  float c_in = 0, c_skip = 0, c_out = 0, r_cut = 0, r2 = 0, rb_step = 0;
+  // static device data
+  int *ptr = nullptr, *bond_in_ptr = nullptr, *bond_in_src = nullptr;
+  float *x_emb = nullptr, *mu = nullptr;
+  std::vector<LayerDev> layers;
+  float *w_gate = nullptr, *w_vec = nullptr, *w_out = nullptr;
+  // work buffers
+  float *yc = nullptr, *h = nullptr, *partial0 = nullptr, *partial1 = nullptr, *g = nullptr, *tmp = nullptr;
+  float *xhat_buf = nullptr, *score_buf = nullptr, *psi = nullptr;
+  int *deg = nullptr, *esrc = nullptr;
+  float4* egeo = nullptr;
+  std::vector<float*> x;  // per block output [n_atoms][XS]
+  unsigned long long* counter = nullptr;
+  int64_t flop_ref_per_edge = 0, flop_exec = 0;
+  // optional per-kernel-class timing with HIP events on the launch stream (jamun_profile_*)
+  bool prof = false;
+  std::vector<hipEvent_t> ev_pool;
+  std::vector<std::pair<int, std::pair<int, int>>> ev_used;  // (class, (begin, end))
+  size_t ev_next = 0;
+
+  ~jamun_sampler() {
+    hipFree(ptr); hipFree(bond_in_ptr); hipFree(bond_in_src); hipFree(x_emb); hipFree(mu);
+    for (auto& L : layers) {
+      free_problem(L.p0); free_problem(L.p1);
+      hipFree(L.w1r); hipFree(L.cmask); hipFree(L.w_self0); hipFree(L.w_self1); hipFree(L.w_skip0);
+      hipFree(L.w_skip1); hipFree(L.mix);
+    }
+    hipFree(w_gate); hipFree(w_vec); hipFree(w_out);
+    hipFree(yc); hipFree(h); hipFree(partial0); hipFree(partial1); hipFree(g); hipFree(tmp);
+    hipFree(xhat_buf); hipFree(score_buf); hipFree(psi); hipFree(deg); hipFree(esrc); hipFree(egeo);
+    for (float* p : x) hipFree(p);
+    hipFree(counter);
+    for (hipEvent_t e : ev_pool) hipEventDestroy(e);
+  }
+};
+
+namespace {
+
+LayerDev build_layer(const jamun_model& m, const std::string& prefix, const std::vector<InBlock>& in_blocks,
+                     const std::vector<double>& s_in, int n_slices) {
+  const jamun_hparams& hp = m.hp;
+  const int mul0 = hp.mul0, mul1 = hp.mul1, G0 = mul0 + mul1, G1 = mul1, H = hp.edge_attr_dim;
+  LayerDev L;
+  // ---- FullyConnectedTensorProduct instruction table (e3nn order: for i1, for i2 in (0e,1e), for i_out in (0e,1e))
+  struct Ins { int b, l2, lo; int64_t off; };
+  std::vector<Ins> ins;
+  int64_t off = 0;
+  double sum0 = 0, sum1 = 0;  // sum over instructions of mul1*mul2 feeding each output irrep
+  for (size_t b = 0; b < in_blocks.size(); ++b)
+    for (int l2 = 0; l2 <= 1; ++l2)
+      for (int lo = 0; lo <= 1; ++lo) {
+        const int l1 = in_blocks[b].l;
+        if (lo < std::abs(l1 - l2) || lo > l1 + l2) continue;
+        const int gout = lo == 0 ? G0 : G1;
+        if (gout == 0) continue;
+        ins.push_back({(int)b, l2, lo, off});
+        off += (int64_t)in_blocks[b].mul * gout;
+        (lo == 0 ? sum0 : sum1) += in_blocks[b].mul;
+      }
+  L.tp_numel = off;
+  const auto& W3 = m.get(prefix + ".gated_conv.f.f.radial_nn.3.weight", off * H);
+  const auto& b3 = m.get(prefix + ".gated_conv.f.f.radial_nn.3.bias", off);
+  const double c0 = std::sqrt(1.0 / sum0), c1 = sum1 > 0 ? std::sqrt(3.0 / sum1) : 0.0;
+  auto find = [&](int b, int l2, int lo) -> int64_t {
+    for (auto& i : ins)
+      if (i.b == b && i.l2 == l2 && i.lo == lo) return i.off;
+    throw Err(JAMUN_ERR_INVALID, "internal: missing tensor-product instruction");
+  };
+  std::vector<UEntry> x0e, dote, x0ve, x1e, crosse;
+  int in0 = 0, in1 = 0;
+  for (size_t b = 0; b < in_blocks.size(); ++b) {
+    const InBlock& ib = in_blocks[b];
+    for (int u = 0; u < ib.mul; ++u) {
+      const double s = s_in[ib.ch0 + u];
+      if (ib.l == 0) {
+        x0e.push_back({JAMUN_T_X0, 0, ib.xoff + u, find(b, 0, 0) + (int64_t)u * G0, c0 * s});
+        if (G1) x0ve.push_back({JAMUN_T_X0V, 0, ib.xoff + u, find(b, 1, 1) + (int64_t)u * G1, c1 * s});
+      } else {
+        dote.push_back({JAMUN_T_DOT, 0, ib.xoff + 3 * u, find(b, 1, 0) + (int64_t)u * G0, c0 * s});
+        x1e.push_back({JAMUN_T_X1C, 0, ib.xoff + 3 * u, find(b, 0, 1) + (int64_t)u * G1, c1 / std::sqrt(3.0) * s});
+        crosse.push_back({JAMUN_T_X1C, 1, ib.xoff + 3 * u, find(b, 1, 1) + (int64_t)u * G1,
+                          c1 * (double)hp.w3j_111_sign / std::sqrt(2.0) * s});
+      }
+    }
+    if (ib.l == 0) in0 += ib.mul; else in1 += ib.mul;
+  }
+  L.in0 = in0; L.in1 = in1; L.XSin = in0 + 3 * in1;
+  auto chunked = [](const std::vector<UEntry>& v, int type, std::vector<UBlock>& out) {
+    for (size_t i = 0; i < v.size(); i += 64) {
+      UBlock b; b.type = type;
+      b.e.assign(v.begin() + i, v.begin() + std::min(v.size(), i + 64));
+      pad_even(b);
+      out.push_back(b);
+    }
+  };
+  std::vector<UBlock> blocks0, blocks1;
+  chunked(x0e, JAMUN_T_X0, blocks0);
+  chunked(dote, JAMUN_T_DOT, blocks0);
+  chunked(x0ve, JAMUN_T_X0V, blocks1);
+  for (size_t i = 0; i < x1e.size(); i += 32) {
+    UBlock b; b.type = JAMUN_T_X1C;
+    const size_t hi = std::min(x1e.size(), i + 32);
+    b.e.assign(x1e.begin() + i, x1e.begin() + hi);
+    b.e.insert(b.e.end(), crosse.begin() + i, crosse.begin() + hi);
+    pad_even(b);
+    blocks1.push_back(b);
+  }
+  L.p0 = pack_problem(blocks0, 1, G0, JAMUN_NK0, n_slices, W3, b3, H);
+  L.p1 = pack_problem(blocks1, 3, G1, JAMUN_NK1, n_slices, W3, b3, H);
+
+  // ---- radial MLP first layer: split into the constant bonded part and the radial part
+  const auto& W1 = m.get(prefix + ".gated_conv.f.f.radial_nn.0.weight", (int64_t)H * H);
+  const auto& b1 = m.get(prefix + ".gated_conv.f.f.radial_nn.0.bias", H);
+  const int nb = H / 2, nr = (H + 1) / 2;
+  const auto& Eb = m.get("embed_bondedness.weight", 2 * nb);
+  std::vector<float> w1r((size_t)H * nr), cmask(2 * (size_t)H);
+  for (int k = 0; k < H; ++k) {
+    for (int r = 0; r < nr; ++r) w1r[(size_t)k * nr + r] = W1[(size_t)k * H + nb + r];
+    for (int mk = 0; mk < 2; ++mk) {
+      double s = b1[k];
+      for (int c = 0; c < nb; ++c) s += (double)W1[(size_t)k * H + c] * Eb[(size_t)mk * nb + c];
+      cmask[(size_t)mk * H + k] = (float)s;
+    }
+  }
+  L.w1r = dev_upload(w1r);
+  L.cmask = dev_upload(cmask);
+
+  // ---- o3.Linear skip (in -> hidden) and self-interaction (hidden -> hidden)  (_interaction.py:23-30)
+  int64_t n_skip = 0;
+  for (auto& ib : in_blocks) n_skip += (int64_t)ib.mul * (ib.l == 0 ? mul0 : mul1);
+  const auto& Wskip = m.get(prefix + ".gated_conv.skip_connection.weight", n_skip);
+  const auto& Wself = m.get(prefix + ".gated_conv.self_interaction.weight", (int64_t)mul0 * mul0 + (int64_t)mul1 * mul1);
+  std::vector<float> ws0((size_t)std::max(in0, 1) * mul0, 0.f), ws1((size_t)std::max(in1, 1) * std::max(mul1, 1), 0.f);
+  {
+    int64_t o = 0;
+    int u0 = 0, u1 = 0;
+    for (auto& ib : in_blocks) {
+      if (ib.l == 0) {
+        for (int u = 0; u < ib.mul; ++u, ++u0)
+          for (int w = 0; w < mul0; ++w)
+            ws0[(size_t)u0 * mul0 + w] = (float)((double)Wskip[o + (int64_t)u * mul0 + w] / std::sqrt((double)in0) * s_in[ib.ch0 + u]);
+        o += (int64_t)ib.mul * mul0;
+      } else {
+        for (int u = 0; u < ib.mul; ++u, ++u1)
+          for (int w = 0; w < mul1; ++w)
+            ws1[(size_t)u1 * mul1 + w] = (float)((double)Wskip[o + (int64_t)u * mul1 + w] / std::sqrt((double)in1) * s_in[ib.ch0 + u]);
+        o += (int64_t)ib.mul * mul1;
+      }
+    }
+  }
+  std::vector<float> wf0((size_t)mul0 * mul0), wf1((size_t)std::max(mul1 * mul1, 1));
+  for (int i = 0; i < mul0 * mul0; ++i) wf0[i] = (float)((double)Wself[i] / std::sqrt((double)mul0));
+  for (int i = 0; i < mul1 * mul1; ++i) wf1[i] = (float)((double)Wself[(size_t)mul0 * mul0 + i] / std::sqrt((double)mul1));
+  L.w_skip0 = dev_upload(ws0);
+  L.w_skip1 = dev_upload(ws1);
+  L.w_self0 = dev_upload(wf0);
+  L.w_self1 = dev_upload(wf1);
+  return L;
+}
+
+struct ProfScope {
+  jamun_sampler* s; int cls; hipStream_t st; int b = -1;
+  ProfScope(jamun_sampler* s_, int cls_, hipStream_t st_) : s(s_), cls(cls_), st(st_) {
+    if (!s->prof) return;
+    while (s->ev_pool.size() < s->ev_next + 2) {
+      hipEvent_t e;
+      HIPCHECK(hipEventCreate(&e));
+      s->ev_pool.push_back(e);
+    }
+    b = (int)s->ev_next;
+    s->ev_next += 2;
+    HIPCHECK(hipEventRecord(s->ev_pool[b], st));
+  }
+  ~ProfScope() {
+    if (b < 0) return;
+    (void)hipEventRecord(s->ev_pool[b + 1], st);
+    s->ev_used.push_back({cls, {b, b + 1}});
+  }
+};
+
+void forward(jamun_sampler* s, const float* y, float* xhat, float* score, hipStream_t st) {
+  {
+    ProfScope ps(s, JAMUN_PROF_GEOM, st);
+    launch_geom(y, s->ptr, s->n_graphs, s->c_in, s->r2, s->S, s->bond_in_ptr, s->bond_in_src, s->hp.mean_center, s->yc,
+                s->deg, s->esrc, s->egeo, st);
+  }
+  const float* x_in = s->x_emb;
+  int XSin = s->n_emb;
+  for (size_t l = 0; l < s->layers.size(); ++l) {
+    LayerDev& L = s->layers[l];
+    {
+      ProfScope ps(s, JAMUN_PROF_EDGE_H, st);
+      launch_edge_h(s->deg, s->esrc, s->egeo, s->n_atoms, s->S, L.w1r, L.cmask, s->mu, s->rb_step, s->h, st);
+    }
+    ConvArgs a{};
+    a.deg = s->deg; a.esrc = s->esrc; a.egeo = s->egeo; a.h = s->h; a.x = x_in;
+    a.n_atoms = s->n_atoms; a.n_pad = s->n_pad; a.S = s->S; a.XS = XSin; a.n_slices = s->n_slices;
+    for (int pi = 0; pi < 2; ++pi) {
+      ConvProblemDev& P = pi == 0 ? L.p0 : L.p1;
+      if (P.nt == 0) continue;
+      a.wpack = P.wpack; a.chunks = P.chunks; a.slice_ptr = P.slice_ptr; a.ublk = P.ublk; a.lane_xoff = P.lane_xoff;
+      a.partial = pi == 0 ? s->partial0 : s->partial1;
+      ProfScope ps(s, l == 0 ? (pi == 0 ? JAMUN_PROF_CONV0_INIT : JAMUN_PROF_CONV1_INIT) : (pi == 0 ? JAMUN_PROF_CONV0 : JAMUN_PROF_CONV1), st);
+      if (launch_conv(a, P.rc, P.nt, P.nk, st) != 0) throw Err(JAMUN_ERR_INVALID, "unsupported conv tile configuration");
+    }
+    NodeArgs n{};
+    n.partial0 = s->partial0; n.partial1 = s->partial1; n.deg = s->deg; n.x_in = x_in; n.x_out = s->x[l];
+    n.w_self0 = L.w_self0; n.w_self1 = L.w_self1; n.w_skip0 = L.w_skip0; n.w_skip1 = L.w_skip1; n.mix = L.mix;
+    n.cL = s->hp.act_scalar_const; n.cS = s->hp.act_gate_const;
+    n.n_atoms = s->n_atoms; n.n_pad = s->n_pad; n.n_slices = s->n_slices; n.nt0 = L.p0.nt; n.nt1 = L.p1.nt;
+    n.mul0 = s->hp.mul0; n.mul1 = s->hp.mul1; n.in0 = L.in0; n.in1 = L.in1; n.XSin = XSin;
+    {
+      ProfScope ps(s, JAMUN_PROF_NODE, st);
+      launch_node_update(n, st);
+    }
+    x_in = s->x[l];
+    XSin = s->XS;
+  }
+  HeadArgs hd{};
+  hd.x = x_in; hd.w_gate = s->w_gate; hd.w_vec = s->w_vec; hd.w_out = s->w_out; hd.g = s->g;
+  hd.cS = s->hp.act_gate_const; hd.n_atoms = s->n_atoms; hd.mul0 = s->hp.mul0; hd.mul1 = s->hp.mul1;
+  {
+    ProfScope ps(s, JAMUN_PROF_HEAD, st);
+    launch_head(hd, st);
+    launch_finalize(y, s->yc, s->g, s->ptr, s->n_graphs, s->c_skip, s->c_out, s->sigma * s->sigma, s->hp.mean_center,
+                    s->tmp, xhat, score, st);
+  }
+  HIPCHECK(hipGetLastError());
+}
+
+LangevinConsts make_consts(const jamun_mcmc_params* p) {
+  if (p->M <= 0) throw Err(JAMUN_ERR_INVALID, "M must be positive");
+  const double u = 1.0 / (double)p->M;  // pow(M, -1)
+  const double zeta2 = std::sqrt(1.0 - std::exp(-2.0 * (double)p->friction));
+  LangevinConsts k;
+  k.u_half_delta = (float)(u * ((double)p->delta / 2));
+  k.half_delta = (float)((double)p->delta / 2);
+  k.exp_mg = (float)std::exp(-(double)p->friction);
+  k.zeta_sqrt_u = (float)(zeta2 * std::sqrt(u));
+  k.beta = p->inverse_temperature;
+  k.clip = p->score_fn_clip;
+  k.has_clip = p->has_clip;
+  return k;
+}
+
+void check_mcmc(const jamun_mcmc_params* p) {
+  if (!p) throw Err(JAMUN_ERR_INVALID, "null mcmc params");
+  if (p->steps < 1) throw Err(JAMUN_ERR_INVALID, "steps must be >= 1");
+  if (p->save_every_n_steps < 1) throw Err(JAMUN_ERR_INVALID, "save_every_n_steps must be >= 1");
+}
+
+bool saves(const jamun_mcmc_params* p, int i) { return (i % p->save_every_n_steps) == 0 && i >= p->burn_in_steps; }
+
+}  // namespace
+
+extern "C" {
+
+const char* jamun_last_error(void) { return g_err.c_str(); }
+int jamun_version(void) { return 1; }
+
+int jamun_model_create(const jamun_hparams* hp, const jamun_tensor* tensors, int32_t n_tensors, jamun_model** out) {
+  return guarded([&] {
+    if (!hp || !out || (!tensors && n_tensors > 0)) throw Err(JAMUN_ERR_INVALID, "null argument");
+    if (hp->edge_attr_dim != 64) throw Err(JAMUN_ERR_INVALID, "only edge_attr_dim = 64 is supported");
+    if (hp->mul0 < 1 || hp->mul1 < 0 || hp->n_layers < 0) throw Err(JAMUN_ERR_INVALID, "bad irreps_hidden / n_layers");
+    if ((hp->mul0 + hp->mul1 + 31) / 32 > 5 || (hp->mul1 + 31) / 32 > 5)
+      throw Err(JAMUN_ERR_INVALID, "irreps_hidden too wide for the compiled conv tiles (mul0 + mul1 <= 160)");
+    if (hp->mul1 == 0) throw Err(JAMUN_ERR_INVALID, "irreps_hidden needs at least one 1e channel (output is 1x1e)");
+    if (hp->emb_dim[0] != hp->emb_dim[1])
+      throw Err(JAMUN_ERR_INVALID, "atom_type and atom_code embedding dims must match (reference atom_embedding.py:54-56)");
+    auto* m = new jamun_model();
+    m->hp = *hp;
+    for (int i = 0; i < n_tensors; ++i) {
+      if (!tensors[i].name || (!tensors[i].data && tensors[i].numel > 0)) {
+        delete m;
+        throw Err(JAMUN_ERR_INVALID, "tensor table entry with null name/data");
+      }
+      m->t[tensors[i].name] = std::vector<float>(tensors[i].data, tensors[i].data + tensors[i].numel);
+    }
+    *out = m;
+  });
+}
+void jamun_model_destroy(jamun_model* m) { delete m; }
+
+int jamun_sampler_create(const jamun_model* m, float sigma, const jamun_topology* topo, jamun_sampler** out) {
+  return guarded([&] {
+    if (!m || !topo || !out) throw Err(JAMUN_ERR_INVALID, "null argument");
+    if (!(sigma > 0)) throw Err(JAMUN_ERR_INVALID, "sigma must be positive");
+    if (topo->n_atoms < 1 || topo->n_graphs < 1) throw Err(JAMUN_ERR_INVALID, "empty walker batch");
+    const jamun_hparams& hp = m->hp;
+    std::unique_ptr<jamun_sampler> s(new jamun_sampler());
+    s->hp = hp;
+    s->sigma = sigma;
+    s->n_atoms = topo->n_atoms;
+    s->n_graphs = topo->n_graphs;
+    s->n_pad = ((topo->n_atoms + 31) / 32) * 32;
+    s->XS = hp.mul0 + 3 * hp.mul1;
+    s->n_emb = hp.emb_dim[0] + hp.emb_dim[1] + hp.emb_dim[2] + hp.emb_dim[3];
+    const int N = topo->n_atoms, W = topo->n_graphs;
+    // ---- normalisation factors in fp32, op for op as Denoiser.normalization_factors (denoiser.py:116-136,177-178)
+    {
+      const float A = hp.average_squared_distance;
+      const float B = 6.0f * (sigma * sigma);
+      s->c_in = 1.0f / sqrtf(A + B);
+      s->c_skip = A / (A + B);
+      s->c_out = sqrtf((A * B) / (A + B));
+      const float mr2 = (float)((double)hp.max_radius * (double)hp.max_radius);
+      s->r_cut = sqrtf(mr2 + 6.0f * (sigma * sigma)) / s->c_in;
+      s->r2 = s->r_cut * s->r_cut;
+    }
+    const double c_noise = std::log((double)sigma) / 4.0;
+    // ---- graph structure
+    int nmax = 0;
+    for (int g = 0; g < W; ++g) {
+      if (topo->ptr[g + 1] < topo->ptr[g]) throw Err(JAMUN_ERR_INVALID, "ptr must be non-decreasing");
+      nmax = std::max(nmax, topo->ptr[g + 1] - topo->ptr[g]);
+    }
+    if (topo->ptr[0] != 0 || topo->ptr[W] != N) throw Err(JAMUN_ERR_INVALID, "ptr must span [0, n_atoms]");
+    std::vector<int> graph_of(N);
+    for (int g = 0; g < W; ++g)
+      for (int a = topo->ptr[g]; a < topo->ptr[g + 1]; ++a) graph_of[a] = g;
+    std::vector<int> bip(N + 1, 0), bis(topo->n_bonds);
+    for (int b = 0; b < topo->n_bonds; ++b) {
+      const int64_t sa = topo->bond_src[b], da = topo->bond_dst[b];
+      if (sa < 0 || sa >= N || da < 0 || da >= N) throw Err(JAMUN_ERR_INVALID, "bond index out of range");
+      if (graph_of[sa] != graph_of[da]) throw Err(JAMUN_ERR_INVALID, "bond connects two different walkers");
+      bip[da + 1]++;
+    }
+    int max_in = 0;
+    for (int i = 0; i < N; ++i) { max_in = std::max(max_in, bip[i + 1]); bip[i + 1] += bip[i]; }
+    {
+      std::vector<int> fill(bip.begin(), bip.end() - 1);
+      for (int b = 0; b < topo->n_bonds; ++b) bis[fill[topo->bond_dst[b]]++] = (int)topo->bond_src[b];  // stable: list order
+    }
+    s->S = std::min(std::max(nmax - 1, 0), JAMUN_MAX_NEIGHBORS + 1) + max_in;
+    if (s->S < 1) s->S = 1;
+    std::vector<int> ptr_h(topo->ptr, topo->ptr + W + 1);
+    s->ptr = dev_upload(ptr_h);
+    s->bond_in_ptr = dev_upload(bip);
+    s->bond_in_src = dev_upload(bis);
+    // ---- radial basis centres: torch.linspace(0, r_cut, 34)[1:-1] in fp32 (e3nn soft_one_hot_linspace)
+    {
+      const int nr = (hp.edge_attr_dim + 1) / 2, steps = nr + 2;
+      const float start = 0.f, end = s->r_cut;
+      const float step = (end - start) / (float)(steps - 1);
+      std::vector<float> vals(steps);
+      for (int i = 0; i < steps; ++i) vals[i] = (i < steps / 2) ? start + step * (float)i : end - step * (float)(steps - i - 1);
+      s->rb_step = vals[1] - vals[0];
+      std::vector<float> mu(vals.begin() + 1, vals.end() - 1);
+      s->mu = dev_upload(mu);
+    }
+    // ---- scaled atom embeddings (constant per topology and sigma): atom_embedding.py:58-76, noise_conditioning.py:50-54
+    {
+      const char* names[4] = {"atom_embedder.atom_type_embedding.weight", "atom_embedder.atom_code_embedding.weight",
+                              "atom_embedder.residue_code_embedding.weight", "atom_embedder.residue_index_embedding.weight"};
+      const int32_t* idx[4] = {topo->atom_type_index, topo->atom_code_index, topo->residue_code_index,
+                               topo->residue_sequence_index};
+      std::vector<double> s0 = noise_mlp(*m, "initial_noise_scaling.scale_predictor", s->n_emb, c_noise);
+      std::vector<float> xe((size_t)N * s->n_emb);
+      int col = 0;
+      for (int tb = 0; tb < 4; ++tb) {
+        const auto& T = m->get(names[tb], (int64_t)hp.emb_rows[tb] * hp.emb_dim[tb]);
+        for (int i = 0; i < N; ++i) {
+          int row = idx[tb][i];
+          if (tb == 3 && !hp.use_residue_sequence_index) row = 0;
+          if (row < 0 || row >= hp.emb_rows[tb]) throw Err(JAMUN_ERR_INVALID, std::string("index out of range for ") + names[tb]);
+          for (int c = 0; c < hp.emb_dim[tb]; ++c)
+            xe[(size_t)i * s->n_emb + col + c] = (float)((double)T[(size_t)row * hp.emb_dim[tb] + c] * s0[col + c]);
+        }
+        col += hp.emb_dim[tb];
+      }
+      s->x_emb = dev_upload(xe);
+    }
+    // ---- layers
+    {
+      // initial projector: four scalar blocks (irreps not simplified, atom_embedding.py:54-56); scaling already in x_emb
+      std::vector<InBlock> ib;
+      int xo = 0;
+      const int muls[4] = {hp.emb_dim[0], hp.emb_dim[0], hp.emb_dim[2], hp.emb_dim[3]};
+      for (int b = 0; b < 4; ++b) { ib.push_back({muls[b], 0, xo, xo}); xo += muls[b]; }
+      std::vector<double> ones(s->n_emb, 1.0);
+      s->layers.push_back(build_layer(*m, "initial_projector", ib, ones, s->n_slices));
+    }
+    for (int l = 0; l < hp.n_layers; ++l) {
+      std::vector<InBlock> ib = {{hp.mul0, 0, 0, 0}, {hp.mul1, 1, hp.mul0, hp.mul0}};
+      const std::string li = std::to_string(l);
+      std::vector<double> sc = noise_mlp(*m, "noise_scalings." + li + ".scale_predictor", hp.mul0 + hp.mul1, c_noise);
+      LayerDev L = build_layer(*m, "layers." + li, ib, sc, s->n_slices);
+      std::vector<double> wm = noise_mlp(*m, "skip_connections." + li + ".weights.scale_predictor", hp.mul0 + hp.mul1, c_noise);
+      std::vector<float> mix(wm.size());
+      for (size_t i = 0; i < wm.size(); ++i) mix[i] = (float)(1.0 / (1.0 + std::exp(-wm[i])));
+      L.mix = dev_upload(mix);
+      s->layers.push_back(L);
+    }
+    // ---- head (EquivariantMLP, _mlp.py:84-114) and output gain (e3conv.py:134-135)
+    {
+      const int mul0 = hp.mul0, mul1 = hp.mul1, G0 = mul0 + mul1;
+      const auto& Wl = m->get("output_head.0.lin.weight", (int64_t)mul0 * G0 + (int64_t)mul1 * mul1);
+      const auto& Wo = m->get("output_head.1.weight", mul1);
+      const auto& gain = m->get("output_gain", 1);
+      std::vector<float> wg((size_t)mul0 * mul1), wv((size_t)mul1 * mul1), wo(mul1);
+      for (int u = 0; u < mul0; ++u)
+        for (int w = 0; w < mul1; ++w) wg[(size_t)u * mul1 + w] = (float)((double)Wl[(size_t)u * G0 + mul0 + w] / std::sqrt((double)mul0));
+      for (int i = 0; i < mul1 * mul1; ++i) wv[i] = (float)((double)Wl[(size_t)mul0 * G0 + i] / std::sqrt((double)mul1));
+      for (int w = 0; w < mul1; ++w) wo[w] = (float)((double)Wo[w] / std::sqrt((double)mul1) * (double)gain[0]);
+      s->w_gate = dev_upload(wg);
+      s->w_vec = dev_upload(wv);
+      s->w_out = dev_upload(wo);
+    }
+    // ---- work buffers
+    const size_t NS = (size_t)N * s->S;
+    s->yc = dev_alloc<float>((size_t)N * 3);
+    s->deg = dev_alloc<int>(N);
+    s->esrc = dev_alloc<int>(NS);
+    s->egeo = dev_alloc<float4>(NS);
+    s->h = dev_alloc<float>(NS * JAMUN_HS);
+    int nt0 = 0, nt1 = 0;
+    for (auto& L : s->layers) { nt0 = std::max(nt0, L.p0.nt); nt1 = std::max(nt1, L.p1.nt); }
+    s->partial0 = dev_alloc<float>((size_t)s->n_slices * s->n_pad * nt0 * 32);
+    s->partial1 = dev_alloc<float>((size_t)s->n_slices * s->n_pad * 3 * nt1 * 32);
+    s->g = dev_alloc<float>((size_t)N * 3);
+    s->tmp = dev_alloc<float>((size_t)N * 3);
+    s->xhat_buf = dev_alloc<float>((size_t)N * 3);
+    s->score_buf = dev_alloc<float>((size_t)N * 3);
+    s->psi = dev_alloc<float>((size_t)N * 3);
+    for (size_t l = 0; l < s->layers.size(); ++l) s->x.push_back(dev_alloc<float>((size_t)N * s->XS));
+    s->counter = dev_alloc<unsigned long long>(1);
+    // ---- FLOP bookkeeping
+    s->flop_ref_per_edge = 0;
+    s->flop_exec = 0;
+    for (auto& L : s->layers) {
+      s->flop_ref_per_edge += 2LL * 64 * 64 + 130LL * L.tp_numel;  // SURVEY.md §8 d
+      s->flop_exec += 2LL * s->n_pad * (1LL * L.p0.K * L.p0.nt * 32 + 3LL * L.p1.K * L.p1.nt * 32);
+    }
+    HIPCHECK(hipDeviceSynchronize());
+    *out = s.release();
+  });
+}
+void jamun_sampler_destroy(jamun_sampler* s) { delete s; }
+
+int jamun_xhat(jamun_sampler* s, const float* y_dev, float* xhat_dev, void* stream) {
+  return guarded([&] {
+    if (!s || !y_dev || !xhat_dev) throw Err(JAMUN_ERR_INVALID, "null argument");
+    forward(s, y_dev, xhat_dev, nullptr, (hipStream_t)stream);
+  });
+}
+int jamun_score(jamun_sampler* s, const float* y_dev, float* score_dev, void* stream) {
+  return guarded([&] {
+    if (!s || !y_dev || !score_dev) throw Err(JAMUN_ERR_INVALID, "null argument");
+    forward(s, y_dev, nullptr, score_dev, (hipStream_t)stream);
+  });
+}
+
+int jamun_num_frames(const jamun_mcmc_params* p, int32_t* n_y, int32_t* n_s_baoab, int32_t* n_s_aboba) {
+  return guarded([&] {
+    check_mcmc(p);
+    int ny = saves(p, 0) ? 1 : 0, extra = 0;
+    for (int i = 1; i < p->steps; ++i) extra += saves(p, i) ? 1 : 0;
+    if (n_y) *n_y = ny + extra;
+    if (n_s_baoab) *n_s_baoab = 1 + extra;
+    if (n_s_aboba) *n_s_aboba = extra;
+  });
+}
+
+int jamun_walk_baoab(jamun_sampler* s, float* y, float* v, const jamun_mcmc_params* p, const float* noise,
+                     uint64_t seed, float* y_traj, float* score_traj, float* xhat_traj, float* xhat_out, void* stream) {
+  return guarded([&] {
+    if (!s || !y || !v) throw Err(JAMUN_ERR_INVALID, "null argument");
+    check_mcmc(p);
+    hipStream_t st = (hipStream_t)stream;
+    const LangevinConsts k = make_consts(p);
+    const int n = s->n_atoms;
+    const size_t fr = (size_t)n * 3;
+    int fy = 0, fs = 0;
+    // i = 0: initial frame + initial score (_splitting.py:136-155)
+    forward(s, y, s->xhat_buf, s->score_buf, st);
+    {
+      const bool sv = saves(p, 0);
+      float* yf = (y_traj && sv) ? y_traj + fr * fy : nullptr;
+      float* xf = (xhat_traj && sv) ? xhat_traj + fr * fy : nullptr;
+      float* sf = score_traj ? score_traj + fr * fs : nullptr;
+      launch_baoab_post(v, s->psi, s->score_buf, y, s->xhat_buf, n, k, /*update_v=*/0, yf, sf, xf, st);
+      if (sv) ++fy;
+      ++fs;
+    }
+    for (int i = 1; i < p->steps; ++i) {
+      launch_baoab_pre(y, v, s->psi, noise ? noise + fr * (size_t)(i - 1) : nullptr, seed, (uint32_t)i, n, k, st);
+      forward(s, y, s->xhat_buf, s->score_buf, st);
+      const bool sv = saves(p, i);
+      float* yf = (y_traj && sv) ? y_traj + fr * fy : nullptr;
+      float* xf = (xhat_traj && sv) ? xhat_traj + fr * fy : nullptr;
+      float* sf = (score_traj && sv) ? score_traj + fr * fs : nullptr;
+      launch_baoab_post(v, s->psi, s->score_buf, y, s->xhat_buf, n, k, /*update_v=*/1, yf, sf, xf, st);
+      if (sv) { ++fy; ++fs; }
+    }
+    if (xhat_out) launch_copy(s->xhat_buf, xhat_out, n * 3, st);  // last forward was evaluated at the final y
+    HIPCHECK(hipGetLastError());
+  });
+}
+
+int jamun_walk_aboba(jamun_sampler* s, float* y, float* v, const jamun_mcmc_params* p, const float* noise,
+                     uint64_t seed, float* y_traj, float* score_traj, float* xhat_traj, float* xhat_out, void* stream) {
+  return guarded([&] {
+    if (!s || !y || !v) throw Err(JAMUN_ERR_INVALID, "null argument");
+    check_mcmc(p);
+    hipStream_t st = (hipStream_t)stream;
+    const LangevinConsts k = make_consts(p);
+    const int n = s->n_atoms;
+    const size_t fr = (size_t)n * 3;
+    int fy = 0, fs = 0;
+    if (saves(p, 0)) {
+      if (y_traj) launch_copy(y, y_traj, n * 3, st);
+      if (xhat_traj) forward(s, y, xhat_traj, nullptr, st);
+      ++fy;
+    }
+    for (int i = 1; i < p->steps; ++i) {
+      launch_aboba_a(y, v, n, k.half_delta, st);
+      forward(s, y, nullptr, s->score_buf, st);
+      const bool sv = saves(p, i);
+      float* yf = (y_traj && sv) ? y_traj + fr * fy : nullptr;
+      float* sf = (score_traj && sv) ? score_traj + fr * fs : nullptr;
+      launch_aboba_b(y, v, s->score_buf, noise ? noise + fr * (size_t)(i - 1) : nullptr, seed, (uint32_t)i, n, k, yf, sf, st);
+      if (sv) {
+        if (xhat_traj) forward(s, y, xhat_traj + fr * fy, nullptr, st);  // one extra forward per saved frame, as the reference
+        ++fy; ++fs;
+      }
+    }
+    if (xhat_out) forward(s, y, xhat_out, nullptr, st);
+    HIPCHECK(hipGetLastError());
+  });
+}
+
+int jamun_mean_center(const float* pos, const int32_t* ptr, int32_t n_graphs, float* out, void* stream) {
+  return guarded([&] {
+    if (!pos || !ptr || !out || n_graphs < 0) throw Err(JAMUN_ERR_INVALID, "bad argument");
+    if (n_graphs == 0) return;
+    launch_mean_center(pos, ptr, n_graphs, out, (hipStream_t)stream);
+    HIPCHECK(hipGetLastError());
+  });
+}
+
+int jamun_radius_graph(const float* pos, const int32_t* ptr, int32_t n_graphs, int32_t n_atoms, float r, int32_t stride,
+                       int32_t* nbr, int32_t* deg, void* stream) {
+  return guarded([&] {
+    if (!pos || !ptr || !nbr || !deg || n_graphs < 0 || n_atoms < 0) throw Err(JAMUN_ERR_INVALID, "bad argument");
+    if (stride < JAMUN_MAX_NEIGHBORS + 1) throw Err(JAMUN_ERR_INVALID, "stride must be >= 33");
+    if (n_graphs == 0) return;
+    launch_radius_graph(pos, ptr, n_graphs, r * r, stride, nbr, deg, (hipStream_t)stream);
+    HIPCHECK(hipGetLastError());
+  });
+}
+
+int jamun_scatter_mean(const float* src, const int32_t* seg_ptr, int32_t n_out, int32_t width, float* out, void* stream) {
+  return guarded([&] {
+    if (!seg_ptr || !out || n_out < 0 || width < 1) throw Err(JAMUN_ERR_INVALID, "bad argument");
+    if (n_out == 0) return;
+    launch_scatter_mean(src, seg_ptr, n_out, width, out, (hipStream_t)stream);
+    HIPCHECK(hipGetLastError());
+  });
+}
+
+int jamun_baoab_pre(float* y, float* v, const float* psi, const float* noise, int32_t n, const jamun_mcmc_params* p,
+                    void* stream) {
+  return guarded([&] {
+    if (!y || !v || !psi || !noise || !p) throw Err(JAMUN_ERR_INVALID, "null argument");
+    if (n == 0) return;
+    launch_baoab_pre(y, v, psi, noise, 0, 0, n, make_consts(p), (hipStream_t)stream);
+    HIPCHECK(hipGetLastError());
+  });
+}
+int jamun_baoab_post(float* v, float* psi, const float* score, int32_t n, const jamun_mcmc_params* p, void* stream) {
+  return guarded([&] {
+    if (!v || !psi || !score || !p) throw Err(JAMUN_ERR_INVALID, "null argument");
+    if (n == 0) return;
+    launch_baoab_post(v, psi, score, nullptr, nullptr, n, make_consts(p), 1, nullptr, nullptr, nullptr, (hipStream_t)stream);
+    HIPCHECK(hipGetLastError());
+  });
+}
+
+int jamun_sampler_stats(jamun_sampler* s, jamun_stats* out, void* stream) {
+  return guarded([&] {
+    if (!s || !out) throw Err(JAMUN_ERR_INVALID, "null argument");
+    hipStream_t st = (hipStream_t)stream;
+    HIPCHECK(hipMemsetAsync(s->counter, 0, sizeof(unsigned long long), st));
+    launch_count_edges(s->deg, s->n_atoms, s->counter, st);
+    unsigned long long e = 0;
+    HIPCHECK(hipMemcpyAsync(&e, s->counter, sizeof(e), hipMemcpyDeviceToHost, st));
+    HIPCHECK(hipStreamSynchronize(st));
+    out->n_edges = (int64_t)e;
+    out->flop_ref_assoc = (int64_t)e * s->flop_ref_per_edge;
+    out->flop_executed = s->flop_exec;
+    out->conv_k0 = s->layers.back().p0.K;
+    out->conv_k1 = s->layers.back().p1.K;
+    {
+      const int64_t m0 = s->hp.mul0, m1 = s->hp.mul1, H1 = s->hp.edge_attr_dim + 1;
+      out->conv0_flop_alg = 2 * (int64_t)s->n_atoms * H1 * (m0 + m1) * (m0 + m1);
+      out->conv1_flop_alg = 2 * 3 * (int64_t)s->n_atoms * H1 * (m0 + 2 * m1) * m1;
+    }
+    out->edge_stride = s->S;
+    out->n_slices = s->n_slices;
+  });
+}
+
+int jamun_profile_enable(jamun_sampler* s, int32_t on) {
+  return guarded([&] {
+    if (!s) throw Err(JAMUN_ERR_INVALID, "null argument");
+    s->prof = on != 0;
+    s->ev_used.clear();
+    s->ev_next = 0;
+  });
+}
+
+int jamun_profile_read(jamun_sampler* s, double* ms_total, int64_t* launches, void* stream) {
+  return guarded([&] {
+    if (!s || !ms_total || !launches) throw Err(JAMUN_ERR_INVALID, "null argument");
+    HIPCHECK(hipStreamSynchronize((hipStream_t)stream));
+    for (int c = 0; c < JAMUN_PROF_NCLASS; ++c) { ms_total[c] = 0; launches[c] = 0; }
+    for (auto& u : s->ev_used) {
+      float ms = 0;
+      HIPCHECK(hipEventElapsedTime(&ms, s->ev_pool[u.second.first], s->ev_pool[u.second.second]));
+      ms_total[u.first] += ms;
+      launches[u.first] += 1;
+    }
+    s->ev_used.clear();
+    s->ev_next = 0;
+  });
+}
+
+int jamun_debug_read(jamun_sampler* s, int32_t what, int32_t layer, float* out, void* stream) {
+  return guarded([&] {
+    if (!s || !out) throw Err(JAMUN_ERR_INVALID, "null argument");
+    hipStream_t st = (hipStream_t)stream;
+    if (what == 0) {
+      if (layer < 0 || layer >= (int)s->x.size()) throw Err(JAMUN_ERR_INVALID, "layer out of range");
+      launch_copy(s->x[layer], out, s->n_atoms * s->XS, st);
+    } else if (what == 1) {
+      launch_deg_to_float(s->deg, out, s->n_atoms, st);
+    } else if (what == 2) {
+      launch_copy(s->g, out, s->n_atoms * 3, st);
+    } else {
+      throw Err(JAMUN_ERR_INVALID, "unknown debug buffer");
+    }
+    HIPCHECK(hipGetLastError());
+  });
+}
+
+}  // extern "C"

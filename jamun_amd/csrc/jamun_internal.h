@@ -1,0 +1,99 @@
+// Internal structures shared by jamun_kernels.hip (device code) and jamun_api.cpp (host runtime).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define JAMUN_MAX_NEIGHBORS 32  // torch_geometric.nn.radius_graph default (src/jamun/model/denoiser.py:149)
+#define JAMUN_HS 68             // row stride of the per-edge radial-MLP activations: 64 hidden + bias row + pad
+#define JAMUN_KPAD 66           // contraction rows per u: 64 hidden units + bias row, padded to the k-group size
+
+// k-group sizes (hidden units per lane) of the two conv GEMMs
+#define JAMUN_NK0 2  // scalar-output rows (RC = 1)
+#define JAMUN_NK1 1  // vector-output rows (RC = 3)
+
+// zeta types of a u-block (what the edge feeds into the contraction)
+#define JAMUN_T_X0 0   // x0_j[u]                      -> scalar rows
+#define JAMUN_T_DOT 1  // x1_j[u'] . vhat              -> scalar rows
+#define JAMUN_T_X0V 2  // x0_j[u] * vhat[m]            -> vector rows
+#define JAMUN_T_X1C 3  // lanes<32: x1_j[u'][m] ; lanes>=32: (x1_j[u'] x vhat)[m]  -> vector rows
+#define JAMUN_XOFF_CROSS 0x10000
+
+struct ConvArgs {
+  // graph
+  const int* deg;
+  const int* esrc;
+  const float4* egeo;
+  const float* h;  // [n_atoms*S][JAMUN_HS]
+  const float* x;  // [n_atoms][XS]
+  int n_atoms, n_pad, S, XS;
+  // problem
+  const float* wpack;
+  const int4* chunks;     // {ublk, k0, wofs/64, 0}
+  const int* slice_ptr;   // [n_slices+1]
+  const int4* ublk;       // {type, nu, 0, 0}
+  const int* lane_xoff;   // [n_ublk][64]
+  float* partial;         // [n_slices][n_pad][RC*NT*32]
+  int n_slices;
+};
+
+struct NodeArgs {
+  const float* partial0;  // [n_slices][n_pad][nt0*32]
+  const float* partial1;  // [n_slices][n_pad][3][nt1*32]
+  const int* deg;
+  const float* x_in;  // [n_atoms][XSin]  (x_old for hidden layers, scaled embedding for the initial projector)
+  float* x_out;       // [n_atoms][mul0+3*mul1]
+  const float* w_self0;  // [mul0][mul0]
+  const float* w_self1;  // [mul1][mul1]
+  const float* w_skip0;  // [in0][mul0]
+  const float* w_skip1;  // [in1][mul1]
+  const float* mix;      // [mul0+mul1] or nullptr (initial projector)
+  float cL, cS;
+  int n_atoms, n_pad, n_slices, nt0, nt1;
+  int mul0, mul1, in0, in1, XSin;
+};
+
+struct HeadArgs {
+  const float* x;       // [n_atoms][mul0+3*mul1]
+  const float* w_gate;  // [mul0][mul1]   (gate pre-activations: columns mul0.. of the 0e block of Linear(hidden->gate_in))
+  const float* w_vec;   // [mul1][mul1]
+  const float* w_out;   // [mul1]         (includes 1/sqrt(mul1) and output_gain)
+  float* g;             // [n_atoms][3]
+  float cS;
+  int n_atoms, mul0, mul1;
+};
+
+struct LangevinConsts {
+  float u_half_delta;  // (float)(u * (delta/2))
+  float half_delta;    // (float)(delta/2)
+  float exp_mg;        // (float)exp(-friction)
+  float zeta_sqrt_u;   // (float)(sqrt(1-exp(-2 friction)) * sqrt(u))
+  float beta;          // inverse_temperature
+  float clip;
+  int has_clip;
+};
+
+// launchers implemented in jamun_kernels.hip
+void launch_mean_center(const float* pos, const int* ptr, int n_graphs, float* out, hipStream_t st);
+void launch_radius_graph(const float* pos, const int* ptr, int n_graphs, float r2, int stride, int* nbr, int* deg,
+                         hipStream_t st);
+void launch_geom(const float* y, const int* ptr, int n_graphs, float c_in, float r2, int S, const int* bip,
+                 const int* bis, int mean_center, float* yc, int* deg, int* esrc, float4* egeo, hipStream_t st);
+void launch_edge_h(const int* deg, const int* esrc, const float4* egeo, int n_atoms, int S, const float* w1r,
+                   const float* cmask, const float* mu, float step, float* h, hipStream_t st);
+int launch_conv(const ConvArgs& a, int rc, int nt, int nk, hipStream_t st);
+void launch_node_update(const NodeArgs& a, hipStream_t st);
+void launch_head(const HeadArgs& a, hipStream_t st);
+void launch_finalize(const float* y, const float* yc, const float* g, const int* ptr, int n_graphs, float c_skip,
+                     float c_out, float sigma2, int mean_center, float* tmp, float* xhat, float* score,
+                     hipStream_t st);
+void launch_baoab_pre(float* y, float* v, const float* psi, const float* noise, uint64_t seed, uint32_t iter, int n,
+                      const LangevinConsts& k, hipStream_t st);
+void launch_baoab_post(float* v, float* psi, const float* score, const float* y, const float* xhat, int n,
+                       const LangevinConsts& k, int update_v, float* yf, float* sf, float* xf, hipStream_t st);
+void launch_aboba_a(float* y, const float* v, int n, float half_delta, hipStream_t st);
+void launch_aboba_b(float* y, float* v, const float* score, const float* noise, uint64_t seed, uint32_t iter, int n,
+                    const LangevinConsts& k, float* yf, float* sf, hipStream_t st);
+void launch_copy(const float* src, float* dst, int n, hipStream_t st);
+void launch_deg_to_float(const int* deg, float* out, int n, hipStream_t st);
+void launch_count_edges(const int* deg, int n, unsigned long long* out, hipStream_t st);
+void launch_scatter_mean(const float* src, const int* seg_ptr, int n_out, int width, float* out, hipStream_t st);

@@ -1,0 +1,707 @@
+// jamun_kernels.hip — gfx950 (MI355X / CDNA4) kernels of the JAMUN walk-jump sampling path.
+//
+// Layout conventions (all fp32 unless noted):
+//   node features x      [n_atoms][XS]  XS = mul0 + 3*mul1, e3nn layout: mul0 scalars, then mul1 vectors [u][m]
+//   edge table           fixed stride S per destination atom: slot e = i*S + t, t < deg[i];
+//                        radial neighbours first (ascending source index), then bonded in-edges (list order)
+//                        == the reference's edge order restricted to one destination
+//                        (src/jamun/model/denoiser.py:149-152)
+//   esrc[e]              source atom | (bonded << 31)
+//   egeo[e]              (vhat.x, vhat.y, vhat.z, d)  in c_in-scaled units (src/jamun/model/arch/e3conv.py:114-116)
+//   h[e][HS]             radial-MLP hidden activations SiLU(W1 a_e + b1) [64], then 1 (bias row), then zeros
+//
+// The conv contraction is the destination-grouped association:
+//   A[(i,c)][(k,u)] = sum_{e -> i} h_e[k] * zeta_e[c][u]         (formed on the fly, never leaves the CU)
+//   m[(i,c)][w]     = sum_{(k,u)} A[(i,c)][(k,u)] * Wp[(k,u)][w]   (v_mfma_f32_32x32x2_f32, exact fp32)
+// which is exact-arithmetic-identical to the reference's per-edge  tp(x[src], sh, radial_nn(edge_attr))
+// followed by scatter-mean (src/jamun/e3tools/nn/_conv.py:93-119) but needs deg(i) times fewer FLOPs.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "jamun_internal.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define FMUL(a, b) __fmul_rn((a), (b))
+#define FADD(a, b) __fadd_rn((a), (b))
+#define FSUB(a, b) __fsub_rn((a), (b))
+
+// ------------------------------------------------------------------------------------------------
+// mean_center (src/jamun/utils/mean_center.py:7-12) — one workgroup per graph, sequential sum in atom
+// order (same order as index_add_ on the CPU reference).
+// ------------------------------------------------------------------------------------------------
+__global__ void k_mean_center(const float* __restrict__ pos, const int* __restrict__ ptr, float* __restrict__ out) {
+  __shared__ float cen[3];
+  const int g = blockIdx.x;
+  const int lo = ptr[g], hi = ptr[g + 1];
+  if (threadIdx.x < 3) {
+    float s = 0.f;
+    for (int a = lo; a < hi; ++a) s = FADD(s, pos[a * 3 + threadIdx.x]);
+    float cnt = (float)(hi - lo);
+    cen[threadIdx.x] = s / (cnt < 1.f ? 1.f : cnt);
+  }
+  __syncthreads();
+  for (int a = lo * 3 + threadIdx.x; a < hi * 3; a += blockDim.x) out[a] = FSUB(pos[a], cen[a % 3]);
+}
+
+// ------------------------------------------------------------------------------------------------
+// radius graph, stand-alone form (torch_cluster CUDA semantics; call site src/jamun/model/denoiser.py:149)
+// ------------------------------------------------------------------------------------------------
+__global__ void k_radius_graph(const float* __restrict__ pos, const int* __restrict__ ptr, float r2, int stride,
+                               int* __restrict__ nbr, int* __restrict__ deg) {
+  const int g = blockIdx.x;
+  const int lo = ptr[g], hi = ptr[g + 1];
+  for (int i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+    const float px = pos[i * 3], py = pos[i * 3 + 1], pz = pos[i * 3 + 2];
+    int count = 0, nr = 0;
+    for (int j = lo; j < hi; ++j) {
+      float dx = FSUB(pos[j * 3], px), dy = FSUB(pos[j * 3 + 1], py), dz = FSUB(pos[j * 3 + 2], pz);
+      float d2 = FADD(FADD(FMUL(dx, dx), FMUL(dy, dy)), FMUL(dz, dz));
+      if (d2 < r2) {
+        if (j != i) nbr[(size_t)i * stride + nr++] = j;
+        if (++count >= JAMUN_MAX_NEIGHBORS + 1) break;
+      }
+    }
+    deg[i] = nr;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// geometry kernel: centre y, build the per-destination edge table (radial + bonded), edge unit vectors
+// and scaled lengths.  One workgroup per walker.  (src/jamun/model/denoiser.py:138-166,188-192;
+// src/jamun/model/arch/e3conv.py:114-116)
+// ------------------------------------------------------------------------------------------------
+__global__ void k_geom(const float* __restrict__ y, const int* __restrict__ ptr, float c_in, float r2, int S,
+                       const int* __restrict__ bond_in_ptr, const int* __restrict__ bond_in_src, int mean_center,
+                       float* __restrict__ yc, int* __restrict__ deg, int* __restrict__ esrc,
+                       float4* __restrict__ egeo) {
+  __shared__ float cen[3];
+  const int g = blockIdx.x;
+  const int lo = ptr[g], hi = ptr[g + 1];
+  if (threadIdx.x < 3) {
+    float s = 0.f;
+    if (mean_center) {
+      for (int a = lo; a < hi; ++a) s = FADD(s, y[a * 3 + threadIdx.x]);
+      float cnt = (float)(hi - lo);
+      s = s / (cnt < 1.f ? 1.f : cnt);
+    }
+    cen[threadIdx.x] = s;
+  }
+  __syncthreads();
+  for (int a = lo * 3 + threadIdx.x; a < hi * 3; a += blockDim.x) yc[a] = FSUB(y[a], cen[a % 3]);
+  __syncthreads();  // yc of this graph is only read by this workgroup (global memory, same CU)
+  for (int i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+    const float px = yc[i * 3], py = yc[i * 3 + 1], pz = yc[i * 3 + 2];
+    const float sx = FMUL(px, c_in), sy = FMUL(py, c_in), sz = FMUL(pz, c_in);
+    int count = 0, nr = 0;
+    const size_t base = (size_t)i * S;
+    for (int j = lo; j < hi; ++j) {
+      const float qx = yc[j * 3], qy = yc[j * 3 + 1], qz = yc[j * 3 + 2];
+      float dx = FSUB(qx, px), dy = FSUB(qy, py), dz = FSUB(qz, pz);
+      float d2 = FADD(FADD(FMUL(dx, dx), FMUL(dy, dy)), FMUL(dz, dz));
+      if (d2 < r2) {
+        if (j != i) {
+          // edge_vec = pos_scaled[src] - pos_scaled[dst]
+          float ex = FSUB(FMUL(qx, c_in), sx), ey = FSUB(FMUL(qy, c_in), sy), ez = FSUB(FMUL(qz, c_in), sz);
+          float d = sqrtf(FADD(FADD(FMUL(ex, ex), FMUL(ey, ey)), FMUL(ez, ez)));
+          float dn = d < 1e-12f ? 1e-12f : d;
+          esrc[base + nr] = j;
+          egeo[base + nr] = make_float4(ex / dn, ey / dn, ez / dn, d);
+          ++nr;
+        }
+        if (++count >= JAMUN_MAX_NEIGHBORS + 1) break;
+      }
+    }
+    for (int b = bond_in_ptr[i]; b < bond_in_ptr[i + 1]; ++b) {
+      const int j = bond_in_src[b];
+      const float qx = yc[j * 3], qy = yc[j * 3 + 1], qz = yc[j * 3 + 2];
+      float ex = FSUB(FMUL(qx, c_in), sx), ey = FSUB(FMUL(qy, c_in), sy), ez = FSUB(FMUL(qz, c_in), sz);
+      float d = sqrtf(FADD(FADD(FMUL(ex, ex), FMUL(ey, ey)), FMUL(ez, ez)));
+      float dn = d < 1e-12f ? 1e-12f : d;
+      esrc[base + nr] = (int)((unsigned)j | 0x80000000u);
+      egeo[base + nr] = make_float4(ex / dn, ey / dn, ez / dn, d);
+      ++nr;
+    }
+    deg[i] = nr;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// radial-MLP hidden layer per edge: h = SiLU(W1 [E_bond[mask] | radial(d)] + b1)
+// (src/jamun/model/arch/e3conv.py:118-127, src/jamun/e3tools/nn/_mlp.py:10-34).
+// One wave per destination atom, lane = hidden unit k.  cmask[mask][k] = b1[k] + W1[k,:32].E_bond[mask].
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_edge_h(const int* __restrict__ deg, const int* __restrict__ esrc,
+                                                const float4* __restrict__ egeo, int n_atoms, int S,
+                                                const float* __restrict__ w1r,    // [64][32] radial part of W1
+                                                const float* __restrict__ cmask,  // [2][64]
+                                                const float* __restrict__ mu,     // [32] basis centres
+                                                float step, float* __restrict__ h) {
+  const int lane = threadIdx.x & 63;
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= n_atoms) return;
+  float w[32];
+#pragma unroll
+  for (int r = 0; r < 32; ++r) w[r] = w1r[lane * 32 + r];
+  const float c0 = cmask[lane], c1 = cmask[64 + lane];
+  const float mu_l = mu[lane & 31];
+  const int d_i = deg[i];
+  for (int t = 0; t < d_i; ++t) {
+    const size_t e = (size_t)i * S + t;
+    const float d = egeo[e].w;
+    const bool bonded = (esrc[e] < 0);
+    float diff = FSUB(d, mu_l) / step;
+    float rad = expf(-FMUL(diff, diff)) / 1.12f;
+    float pre = bonded ? c1 : c0;
+#pragma unroll
+    for (int r = 0; r < 32; ++r) {
+      float rr = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, rad), r));
+      pre = fmaf(w[r], rr, pre);
+    }
+    float hv = pre / (1.f + expf(-pre));
+    h[e * JAMUN_HS + lane] = hv;
+    if (lane < JAMUN_HS - 64) h[e * JAMUN_HS + 64 + lane] = (lane == 0) ? 1.f : 0.f;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// conv contraction (see header comment).  One wave per workgroup: tile = 32 destination atoms,
+// K-slice = blockIdx.x % n_slices (so that all workgroups of one slice share an XCD's L2 under the
+// round-robin dispatch; a speed choice only).
+// ------------------------------------------------------------------------------------------------
+#define LDS_ROW 33
+
+template <int RC, int NK, int TYPE>
+__device__ __forceinline__ void form_chunk(float* __restrict__ A_lds, const ConvArgs& a, int n0, int k0, int nu,
+                                           int xoff, int lane) {
+  const bool active = lane < nu;
+  const bool is_cross = (xoff & JAMUN_XOFF_CROSS) != 0;
+  const int xo = xoff & 0xffff;
+  for (int il = 0; il < 32; ++il) {
+    const int i = n0 + il;
+    float g[RC][NK];
+#pragma unroll
+    for (int c = 0; c < RC; ++c)
+#pragma unroll
+      for (int kl = 0; kl < NK; ++kl) g[c][kl] = 0.f;
+    if (i < a.n_atoms) {
+      const int d_i = a.deg[i];
+      for (int t = 0; t < d_i; ++t) {
+        const size_t e = (size_t)i * a.S + t;
+        const int j = a.esrc[e] & 0x7fffffff;
+        const float4 geo = a.egeo[e];
+        float hk[NK];
+#pragma unroll
+        for (int kl = 0; kl < NK; ++kl) hk[kl] = a.h[e * JAMUN_HS + k0 + kl];
+        const float* __restrict__ xp = a.x + (size_t)j * a.XS + xo;
+        float z[RC];
+        if (TYPE == JAMUN_T_X0) {
+          z[0] = active ? xp[0] : 0.f;
+        } else if (TYPE == JAMUN_T_DOT) {
+          float x0 = active ? xp[0] : 0.f, x1 = active ? xp[1] : 0.f, x2 = active ? xp[2] : 0.f;
+          z[0] = x0 * geo.x + x1 * geo.y + x2 * geo.z;
+        } else if (TYPE == JAMUN_T_X0V) {
+          float x0 = active ? xp[0] : 0.f;
+          z[0] = x0 * geo.x;
+          if (RC > 1) { z[1 % RC] = x0 * geo.y; z[2 % RC] = x0 * geo.z; }
+        } else {  // JAMUN_T_X1C
+          float x0 = active ? xp[0] : 0.f, x1 = active ? xp[1] : 0.f, x2 = active ? xp[2] : 0.f;
+          float cx = x1 * geo.z - x2 * geo.y, cy = x2 * geo.x - x0 * geo.z, cz = x0 * geo.y - x1 * geo.x;
+          z[0] = is_cross ? cx : x0;
+          if (RC > 1) { z[1 % RC] = is_cross ? cy : x1; z[2 % RC] = is_cross ? cz : x2; }
+        }
+#pragma unroll
+        for (int c = 0; c < RC; ++c)
+#pragma unroll
+          for (int kl = 0; kl < NK; ++kl) g[c][kl] = fmaf(hk[kl], z[c], g[c][kl]);
+      }
+    }
+    if (active) {
+#pragma unroll
+      for (int c = 0; c < RC; ++c)
+#pragma unroll
+        for (int kl = 0; kl < NK; ++kl) A_lds[(c * NK * 64 + kl * nu + lane) * LDS_ROW + il] = g[c][kl];
+    }
+  }
+}
+
+template <int RC, int NT, int NK>
+__global__ __launch_bounds__(64) void k_conv(ConvArgs a) {
+  __shared__ float A_lds[RC * NK * 64 * LDS_ROW];
+  const int lane = threadIdx.x;
+  const int slice = blockIdx.x % a.n_slices;
+  const int tile = blockIdx.x / a.n_slices;
+  const int n0 = tile * 32;
+  const int r = lane & 31, hh = lane >> 5;
+
+  f32x16 acc[RC][NT];
+#pragma unroll
+  for (int c = 0; c < RC; ++c)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc[c][nt][q] = 0.f;
+
+  const int c_begin = a.slice_ptr[slice], c_end = a.slice_ptr[slice + 1];
+  for (int ci = c_begin; ci < c_end; ++ci) {
+    const int4 cd = a.chunks[ci];  // {ublk, k0, wofs (in 64-float units), unused}
+    const int4 ub = a.ublk[cd.x];  // {type, nu, 0, 0}
+    const int type = ub.x, nu = ub.y;
+    const int xoff = a.lane_xoff[cd.x * 64 + lane];
+    const int k0 = cd.y;
+    if (type == JAMUN_T_X0) form_chunk<RC, NK, JAMUN_T_X0>(A_lds, a, n0, k0, nu, xoff, lane);
+    else if (type == JAMUN_T_DOT) form_chunk<RC, NK, JAMUN_T_DOT>(A_lds, a, n0, k0, nu, xoff, lane);
+    else if (type == JAMUN_T_X0V) form_chunk<RC, NK, JAMUN_T_X0V>(A_lds, a, n0, k0, nu, xoff, lane);
+    else form_chunk<RC, NK, JAMUN_T_X1C>(A_lds, a, n0, k0, nu, xoff, lane);
+    __syncthreads();
+    const int nsteps = (NK * nu) >> 1;
+    const float* __restrict__ wp = a.wpack + (size_t)cd.z * 64;
+    for (int q = 0; q < nsteps; ++q) {
+      float av[RC];
+#pragma unroll
+      for (int c = 0; c < RC; ++c) av[c] = A_lds[(c * NK * 64 + 2 * q + hh) * LDS_ROW + r];
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const float b = wp[((size_t)q * NT + nt) * 64 + lane];
+#pragma unroll
+        for (int c = 0; c < RC; ++c) acc[c][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[c], b, acc[c][nt], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+  }
+  // partial slab: [slice][node][RC][NT*32]
+  const size_t row_w = (size_t)RC * NT * 32;
+#pragma unroll
+  for (int c = 0; c < RC; ++c)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int row = (q & 3) + 8 * (q >> 2) + 4 * hh;
+        a.partial[((size_t)slice * a.n_pad + n0 + row) * row_w + (size_t)c * NT * 32 + nt * 32 + r] = acc[c][nt][q];
+      }
+}
+
+// ------------------------------------------------------------------------------------------------
+// node update: sum the K-slice partials (fixed order), mean over in-edges, gate, self-interaction
+// Linear, skip Linear, noise-conditional skip mix.
+// (src/jamun/e3tools/nn/_conv.py:117, _gate.py:53-64, _interaction.py:26-30, model/noise_conditioning.py:69-73)
+// ------------------------------------------------------------------------------------------------
+#define NB_NODES 8
+__global__ __launch_bounds__(256) void k_node_update(NodeArgs a) {
+  extern __shared__ float sm[];
+  const int G0 = a.mul0 + a.mul1;
+  float* s_a = sm;                               // [NB][mul0]
+  float* s_gate = s_a + NB_NODES * a.mul0;       // [NB][mul1]
+  float* s_vec = s_gate + NB_NODES * a.mul1;     // [NB][mul1*3]
+  float* s_xin = s_vec + NB_NODES * a.mul1 * 3;  // [NB][XSin]
+  const int n0 = blockIdx.x * NB_NODES;
+  const int tid = threadIdx.x;
+  const int w0 = a.nt0 * 32;  // padded row width of partial0
+  for (int idx = tid; idx < NB_NODES * G0; idx += blockDim.x) {
+    const int nb = idx / G0, w = idx % G0, i = n0 + nb;
+    float m = 0.f;
+    if (i < a.n_atoms) {
+      for (int s = 0; s < a.n_slices; ++s) m += a.partial0[((size_t)s * a.n_pad + i) * w0 + w];
+      const int d = a.deg[i];
+      m = m / (float)(d < 1 ? 1 : d);
+    }
+    if (w < a.mul0) s_a[nb * a.mul0 + w] = a.cL * (m > 0.f ? m : 0.01f * m);
+    else s_gate[nb * a.mul1 + (w - a.mul0)] = a.cS / (1.f + expf(-m));
+  }
+  for (int idx = tid; idx < NB_NODES * a.XSin; idx += blockDim.x) {
+    const int nb = idx / a.XSin, u = idx % a.XSin, i = n0 + nb;
+    s_xin[idx] = (i < a.n_atoms) ? a.x_in[(size_t)i * a.XSin + u] : 0.f;
+  }
+  __syncthreads();
+  const int w1 = a.nt1 * 32;
+  for (int idx = tid; idx < NB_NODES * a.mul1 * 3; idx += blockDim.x) {
+    const int nb = idx / (a.mul1 * 3), rem = idx % (a.mul1 * 3), wv = rem / 3, mm = rem % 3, i = n0 + nb;
+    float m = 0.f;
+    if (i < a.n_atoms) {
+      for (int s = 0; s < a.n_slices; ++s) m += a.partial1[(((size_t)s * a.n_pad + i) * 3 + mm) * w1 + wv];
+      const int d = a.deg[i];
+      m = m / (float)(d < 1 ? 1 : d);
+    }
+    s_vec[idx] = m * s_gate[nb * a.mul1 + wv];
+  }
+  __syncthreads();
+  const int XSo = a.mul0 + 3 * a.mul1;
+  for (int o = tid; o < XSo; o += blockDim.x) {
+    float acc[NB_NODES];
+#pragma unroll
+    for (int nb = 0; nb < NB_NODES; ++nb) acc[nb] = 0.f;
+    int ch;
+    if (o < a.mul0) {
+      ch = o;
+      for (int w = 0; w < a.mul0; ++w) {
+        const float ww = a.w_self0[w * a.mul0 + o];
+#pragma unroll
+        for (int nb = 0; nb < NB_NODES; ++nb) acc[nb] = fmaf(ww, s_a[nb * a.mul0 + w], acc[nb]);
+      }
+      for (int u = 0; u < a.in0; ++u) {
+        const float ww = a.w_skip0[u * a.mul0 + o];
+#pragma unroll
+        for (int nb = 0; nb < NB_NODES; ++nb) acc[nb] = fmaf(ww, s_xin[nb * a.XSin + u], acc[nb]);
+      }
+    } else {
+      const int ov = (o - a.mul0) / 3, mm = (o - a.mul0) % 3;
+      ch = a.mul0 + ov;
+      for (int w = 0; w < a.mul1; ++w) {
+        const float ww = a.w_self1[w * a.mul1 + ov];
+#pragma unroll
+        for (int nb = 0; nb < NB_NODES; ++nb) acc[nb] = fmaf(ww, s_vec[(nb * a.mul1 + w) * 3 + mm], acc[nb]);
+      }
+      for (int u = 0; u < a.in1; ++u) {
+        const float ww = a.w_skip1[u * a.mul1 + ov];
+#pragma unroll
+        for (int nb = 0; nb < NB_NODES; ++nb) acc[nb] = fmaf(ww, s_xin[nb * a.XSin + a.in0 + u * 3 + mm], acc[nb]);
+      }
+    }
+    const float mw = a.mix ? a.mix[ch] : 0.f;
+#pragma unroll
+    for (int nb = 0; nb < NB_NODES; ++nb) {
+      const int i = n0 + nb;
+      if (i < a.n_atoms) {
+        float v = acc[nb];
+        if (a.mix) v = mw * s_xin[nb * a.XSin + o] + (1.f - mw) * v;  // hidden layers: XSin == XSo, x_in is x_old
+        a.x_out[(size_t)i * XSo + o] = v;
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// output head: Linear(hidden -> gate_in) . Gate . Linear(hidden -> 1x1e) * output_gain
+// (src/jamun/e3tools/nn/_mlp.py:76-81,109; src/jamun/model/arch/e3conv.py:134-135).  Only the gated
+// vectors reach the 1x1e output, so the mul0 activated scalars are never formed.
+// 32 lanes per atom (lane = vector channel w'), 8 atoms per workgroup.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_head(HeadArgs a) {
+  const int wv = threadIdx.x & 31;
+  const int i = blockIdx.x * 8 + (threadIdx.x >> 5);
+  float gx = 0.f, gy = 0.f, gz = 0.f;
+  if (i < a.n_atoms) {
+    const float* __restrict__ xi = a.x + (size_t)i * (a.mul0 + 3 * a.mul1);
+    for (int w0 = wv; w0 < a.mul1; w0 += 32) {
+      float gp = 0.f;
+      for (int u = 0; u < a.mul0; ++u) gp = fmaf(a.w_gate[u * a.mul1 + w0], xi[u], gp);
+      float hx = 0.f, hy = 0.f, hz = 0.f;
+      for (int u = 0; u < a.mul1; ++u) {
+        const float ww = a.w_vec[u * a.mul1 + w0];
+        hx = fmaf(ww, xi[a.mul0 + u * 3 + 0], hx);
+        hy = fmaf(ww, xi[a.mul0 + u * 3 + 1], hy);
+        hz = fmaf(ww, xi[a.mul0 + u * 3 + 2], hz);
+      }
+      const float gate = a.cS / (1.f + expf(-gp));
+      const float wo = a.w_out[w0];
+      gx = fmaf(wo, hx * gate, gx);
+      gy = fmaf(wo, hy * gate, gy);
+      gz = fmaf(wo, hz * gate, gz);
+    }
+  }
+#pragma unroll
+  for (int off = 16; off >= 1; off >>= 1) {
+    gx += __shfl_xor(gx, off, 32);
+    gy += __shfl_xor(gy, off, 32);
+    gz += __shfl_xor(gz, off, 32);
+  }
+  if (wv == 0 && i < a.n_atoms) {
+    a.g[i * 3 + 0] = gx;
+    a.g[i * 3 + 1] = gy;
+    a.g[i * 3 + 2] = gz;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// finalize: xhat = mean_center(c_skip * yc + c_out * g) ; score = (xhat - y) / sigma^2
+// (src/jamun/model/denoiser.py:200,213-215,111-114).  One workgroup per walker.
+// ------------------------------------------------------------------------------------------------
+__global__ void k_finalize(const float* __restrict__ y, const float* __restrict__ yc, const float* __restrict__ g,
+                           const int* __restrict__ ptr, float c_skip, float c_out, float sigma2, int mean_center,
+                           float* __restrict__ tmp, float* __restrict__ xhat, float* __restrict__ score) {
+  __shared__ float cen[3];
+  const int gi = blockIdx.x;
+  const int lo = ptr[gi], hi = ptr[gi + 1];
+  for (int a = lo * 3 + threadIdx.x; a < hi * 3; a += blockDim.x) tmp[a] = FADD(FMUL(c_skip, yc[a]), FMUL(c_out, g[a]));
+  __syncthreads();
+  if (threadIdx.x < 3) {
+    float s = 0.f;
+    if (mean_center) {
+      for (int a = lo; a < hi; ++a) s = FADD(s, tmp[a * 3 + threadIdx.x]);
+      float cnt = (float)(hi - lo);
+      s = s / (cnt < 1.f ? 1.f : cnt);
+    }
+    cen[threadIdx.x] = s;
+  }
+  __syncthreads();
+  for (int a = lo * 3 + threadIdx.x; a < hi * 3; a += blockDim.x) {
+    const float xh = FSUB(tmp[a], cen[a % 3]);
+    if (xhat) xhat[a] = xh;
+    if (score) score[a] = FSUB(xh, y[a]) / sigma2;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Langevin updates (src/jamun/sampling/mcmc/functional/_splitting.py:26-41,80-101,148-170).
+// Arithmetic order and rounding points follow the reference line by line (python-float constants are
+// rounded to fp32 once, every tensor op rounds separately: no FMA contraction).
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t mulhilo(uint32_t a, uint32_t b, uint32_t* hi) {
+  uint64_t p = (uint64_t)a * b;
+  *hi = (uint32_t)(p >> 32);
+  return (uint32_t)p;
+}
+__device__ __forceinline__ void philox4x32_10(uint32_t c[4], uint32_t k0, uint32_t k1) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    uint32_t hi0, hi1;
+    uint32_t lo0 = mulhilo(0xD2511F53u, c[0], &hi0);
+    uint32_t lo1 = mulhilo(0xCD9E8D57u, c[2], &hi1);
+    uint32_t n0 = hi1 ^ c[1] ^ k0, n1 = lo1, n2 = hi0 ^ c[3] ^ k1, n3 = lo0;
+    c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+}
+__device__ __forceinline__ void philox_normal3(uint64_t seed, uint32_t iter, uint32_t atom, float out[3]) {
+  uint32_t c[4] = {atom, iter, 0x4a414d55u, 0u};
+  philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+  const float inv = 2.3283064365386963e-10f;  // 2^-32
+  float u0 = ((float)c[0] + 0.5f) * inv, u1 = ((float)c[1] + 0.5f) * inv;
+  float u2 = ((float)c[2] + 0.5f) * inv, u3 = ((float)c[3] + 0.5f) * inv;
+  u0 = fminf(fmaxf(u0, 1e-10f), 1.f);
+  u2 = fminf(fmaxf(u2, 1e-10f), 1.f);
+  float r0 = sqrtf(-2.f * logf(u0)), r1 = sqrtf(-2.f * logf(u2));
+  out[0] = r0 * cosf(6.283185307179586f * u1);
+  out[1] = r0 * sinf(6.283185307179586f * u1);
+  out[2] = r1 * cosf(6.283185307179586f * u3);
+}
+
+// psi = clip(score) * beta  (create_score_fn, _splitting.py:26-41).  A zero-norm row gives NaN, as the reference.
+__device__ __forceinline__ void process_score(const float s[3], const LangevinConsts& k, float psi[3]) {
+  float p0 = s[0], p1 = s[1], p2 = s[2];
+  if (k.has_clip) {
+    float norm = sqrtf(FADD(FADD(FMUL(p0, p0), FMUL(p1, p1)), FMUL(p2, p2)));
+    float clip = fminf(norm, k.clip);
+    p0 = FMUL(p0 / norm, clip);
+    p1 = FMUL(p1 / norm, clip);
+    p2 = FMUL(p2 / norm, clip);
+  }
+  psi[0] = FMUL(p0, k.beta);
+  psi[1] = FMUL(p1, k.beta);
+  psi[2] = FMUL(p2, k.beta);
+}
+
+// BAOAB first half (B, A, O, A):  v += u(d/2) psi ; y += (d/2) v ; vhat = a v + z R ; y += (d/2) vhat.  v <- vhat.
+__global__ void k_baoab_pre(float* __restrict__ y, float* __restrict__ v, const float* __restrict__ psi,
+                            const float* __restrict__ noise, uint64_t seed, uint32_t iter, int n, LangevinConsts k) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float R[3];
+  if (noise) { R[0] = noise[i * 3]; R[1] = noise[i * 3 + 1]; R[2] = noise[i * 3 + 2]; }
+  else philox_normal3(seed, iter, (uint32_t)i, R);
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    float vv = FADD(v[i * 3 + c], FMUL(k.u_half_delta, psi[i * 3 + c]));
+    float yy = FADD(y[i * 3 + c], FMUL(k.half_delta, vv));
+    float vh = FADD(FMUL(k.exp_mg, vv), FMUL(k.zeta_sqrt_u, R[c]));
+    yy = FADD(yy, FMUL(k.half_delta, vh));
+    v[i * 3 + c] = vh;
+    y[i * 3 + c] = yy;
+  }
+}
+
+// BAOAB second half-kick + trajectory save:  psi = process(score) ; v = vhat + (d/2) psi  (no u, _splitting.py:166)
+__global__ void k_baoab_post(float* __restrict__ v, float* __restrict__ psi_out, const float* __restrict__ score,
+                             const float* __restrict__ y, const float* __restrict__ xhat, int n, LangevinConsts k,
+                             int update_v, float* __restrict__ y_frame, float* __restrict__ score_frame,
+                             float* __restrict__ xhat_frame) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float s[3] = {score[i * 3], score[i * 3 + 1], score[i * 3 + 2]};
+  float p[3];
+  process_score(s, k, p);
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    psi_out[i * 3 + c] = p[c];
+    if (update_v) v[i * 3 + c] = FADD(v[i * 3 + c], FMUL(k.half_delta, p[c]));
+    if (y_frame) y_frame[i * 3 + c] = y[i * 3 + c];
+    if (score_frame) score_frame[i * 3 + c] = s[c];
+    if (xhat_frame) xhat_frame[i * 3 + c] = xhat[i * 3 + c];
+  }
+}
+
+// ABOBA first A:  y += (d/2) v
+__global__ void k_aboba_a(float* __restrict__ y, const float* __restrict__ v, int n3, float half_delta) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n3) y[i] = FADD(y[i], FMUL(half_delta, v[i]));
+}
+
+// ABOBA  B O B A:  psi = process(score) ; v += u(d/2) psi ; vhat = a v + z R ; v = vhat + (d/2) psi ; y += (d/2) v
+__global__ void k_aboba_b(float* __restrict__ y, float* __restrict__ v, const float* __restrict__ score,
+                          const float* __restrict__ noise, uint64_t seed, uint32_t iter, int n, LangevinConsts k,
+                          float* __restrict__ y_frame, float* __restrict__ score_frame) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float s[3] = {score[i * 3], score[i * 3 + 1], score[i * 3 + 2]};
+  float p[3];
+  process_score(s, k, p);
+  float R[3];
+  if (noise) { R[0] = noise[i * 3]; R[1] = noise[i * 3 + 1]; R[2] = noise[i * 3 + 2]; }
+  else philox_normal3(seed, iter, (uint32_t)i, R);
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    float vv = FADD(v[i * 3 + c], FMUL(k.u_half_delta, p[c]));
+    float vh = FADD(FMUL(k.exp_mg, vv), FMUL(k.zeta_sqrt_u, R[c]));
+    vv = FADD(vh, FMUL(k.half_delta, p[c]));
+    float yy = FADD(y[i * 3 + c], FMUL(k.half_delta, vv));
+    v[i * 3 + c] = vv;
+    y[i * 3 + c] = yy;
+    if (y_frame) y_frame[i * 3 + c] = yy;
+    if (score_frame) score_frame[i * 3 + c] = s[c];
+  }
+}
+
+__global__ void k_copy(const float* __restrict__ src, float* __restrict__ dst, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dst[i] = src[i];
+}
+
+__global__ void k_deg_to_float(const int* __restrict__ deg, float* __restrict__ out, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = (float)deg[i];
+}
+
+__global__ void k_count_edges(const int* __restrict__ deg, int n, unsigned long long* out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  unsigned long long v = (i < n) ? (unsigned long long)deg[i] : 0ull;
+  for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
+  if ((threadIdx.x & 63) == 0 && v) atomicAdd(out, v);
+}
+
+// ------------------------------------------------------------------------------------------------
+// scatter-mean over destination-sorted rows (torch_scatter "mean"; call site _conv.py:117).
+// One wave per destination; lanes stride the feature width with 16-byte loads when width % 4 == 0;
+// rows are added in row order (bitwise reproducible, no atomics).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_scatter_mean(const float* __restrict__ src, const int* __restrict__ seg_ptr,
+                                                      int n_out, int width, float* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const int d = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (d >= n_out) return;
+  const int lo = seg_ptr[d], hi = seg_ptr[d + 1];
+  const float inv_cnt_den = (float)((hi - lo) < 1 ? 1 : (hi - lo));
+  if ((width & 3) == 0) {
+    const int w4 = width >> 2;
+    for (int c = lane; c < w4; c += 64) {
+      float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+      const float4* p = reinterpret_cast<const float4*>(src) + (size_t)lo * w4 + c;
+      int e = lo;
+      for (; e + 4 <= hi; e += 4) {  // four independent 16-B loads in flight, added in row order
+        float4 a0 = p[0], a1 = p[w4], a2 = p[2 * (size_t)w4], a3 = p[3 * (size_t)w4];
+        p += 4 * (size_t)w4;
+        acc.x = FADD(FADD(FADD(FADD(acc.x, a0.x), a1.x), a2.x), a3.x);
+        acc.y = FADD(FADD(FADD(FADD(acc.y, a0.y), a1.y), a2.y), a3.y);
+        acc.z = FADD(FADD(FADD(FADD(acc.z, a0.z), a1.z), a2.z), a3.z);
+        acc.w = FADD(FADD(FADD(FADD(acc.w, a0.w), a1.w), a2.w), a3.w);
+      }
+      for (; e < hi; ++e) {
+        float4 a0 = p[0];
+        p += w4;
+        acc.x = FADD(acc.x, a0.x); acc.y = FADD(acc.y, a0.y); acc.z = FADD(acc.z, a0.z); acc.w = FADD(acc.w, a0.w);
+      }
+      acc.x /= inv_cnt_den; acc.y /= inv_cnt_den; acc.z /= inv_cnt_den; acc.w /= inv_cnt_den;
+      reinterpret_cast<float4*>(out)[(size_t)d * w4 + c] = acc;
+    }
+  } else {
+    for (int c = lane; c < width; c += 64) {
+      float acc = 0.f;
+      for (int e = lo; e < hi; ++e) acc = FADD(acc, src[(size_t)e * width + c]);
+      out[(size_t)d * width + c] = acc / inv_cnt_den;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// launchers (called from jamun_api.cpp)
+// ------------------------------------------------------------------------------------------------
+void launch_mean_center(const float* pos, const int* ptr, int n_graphs, float* out, hipStream_t st) {
+  hipLaunchKernelGGL(k_mean_center, dim3(n_graphs), dim3(128), 0, st, pos, ptr, out);
+}
+void launch_radius_graph(const float* pos, const int* ptr, int n_graphs, float r2, int stride, int* nbr, int* deg,
+                         hipStream_t st) {
+  hipLaunchKernelGGL(k_radius_graph, dim3(n_graphs), dim3(128), 0, st, pos, ptr, r2, stride, nbr, deg);
+}
+void launch_geom(const float* y, const int* ptr, int n_graphs, float c_in, float r2, int S, const int* bip,
+                 const int* bis, int mean_center, float* yc, int* deg, int* esrc, float4* egeo, hipStream_t st) {
+  hipLaunchKernelGGL(k_geom, dim3(n_graphs), dim3(128), 0, st, y, ptr, c_in, r2, S, bip, bis, mean_center, yc, deg,
+                     esrc, egeo);
+}
+void launch_edge_h(const int* deg, const int* esrc, const float4* egeo, int n_atoms, int S, const float* w1r,
+                   const float* cmask, const float* mu, float step, float* h, hipStream_t st) {
+  hipLaunchKernelGGL(k_edge_h, dim3((n_atoms + 3) / 4), dim3(256), 0, st, deg, esrc, egeo, n_atoms, S, w1r, cmask, mu,
+                     step, h);
+}
+
+template <int RC, int NK>
+static void launch_conv_nt(const ConvArgs& a, int nt, int grid, hipStream_t st) {
+  switch (nt) {
+    case 1: hipLaunchKernelGGL((k_conv<RC, 1, NK>), dim3(grid), dim3(64), 0, st, a); break;
+    case 2: hipLaunchKernelGGL((k_conv<RC, 2, NK>), dim3(grid), dim3(64), 0, st, a); break;
+    case 3: hipLaunchKernelGGL((k_conv<RC, 3, NK>), dim3(grid), dim3(64), 0, st, a); break;
+    case 4: hipLaunchKernelGGL((k_conv<RC, 4, NK>), dim3(grid), dim3(64), 0, st, a); break;
+    case 5: hipLaunchKernelGGL((k_conv<RC, 5, NK>), dim3(grid), dim3(64), 0, st, a); break;
+    default: break;
+  }
+}
+int launch_conv(const ConvArgs& a, int rc, int nt, int nk, hipStream_t st) {
+  const int grid = (a.n_pad / 32) * a.n_slices;
+  if (nt < 1 || nt > 5) return -1;
+  if (rc == 1 && nk == JAMUN_NK0) launch_conv_nt<1, JAMUN_NK0>(a, nt, grid, st);
+  else if (rc == 3 && nk == JAMUN_NK1) launch_conv_nt<3, JAMUN_NK1>(a, nt, grid, st);
+  else return -1;
+  return 0;
+}
+void launch_node_update(const NodeArgs& a, hipStream_t st) {
+  const int grid = (a.n_atoms + NB_NODES - 1) / NB_NODES;
+  const size_t sm = sizeof(float) * NB_NODES * (a.mul0 + a.mul1 + 3 * a.mul1 + a.XSin);
+  hipLaunchKernelGGL(k_node_update, dim3(grid), dim3(256), sm, st, a);
+}
+void launch_head(const HeadArgs& a, hipStream_t st) {
+  hipLaunchKernelGGL(k_head, dim3((a.n_atoms + 7) / 8), dim3(256), 0, st, a);
+}
+void launch_finalize(const float* y, const float* yc, const float* g, const int* ptr, int n_graphs, float c_skip,
+                     float c_out, float sigma2, int mean_center, float* tmp, float* xhat, float* score,
+                     hipStream_t st) {
+  hipLaunchKernelGGL(k_finalize, dim3(n_graphs), dim3(128), 0, st, y, yc, g, ptr, c_skip, c_out, sigma2, mean_center,
+                     tmp, xhat, score);
+}
+void launch_baoab_pre(float* y, float* v, const float* psi, const float* noise, uint64_t seed, uint32_t iter, int n,
+                      const LangevinConsts& k, hipStream_t st) {
+  hipLaunchKernelGGL(k_baoab_pre, dim3((n + 255) / 256), dim3(256), 0, st, y, v, psi, noise, seed, iter, n, k);
+}
+void launch_baoab_post(float* v, float* psi, const float* score, const float* y, const float* xhat, int n,
+                       const LangevinConsts& k, int update_v, float* yf, float* sf, float* xf, hipStream_t st) {
+  hipLaunchKernelGGL(k_baoab_post, dim3((n + 255) / 256), dim3(256), 0, st, v, psi, score, y, xhat, n, k, update_v, yf,
+                     sf, xf);
+}
+void launch_aboba_a(float* y, const float* v, int n, float half_delta, hipStream_t st) {
+  hipLaunchKernelGGL(k_aboba_a, dim3((n * 3 + 255) / 256), dim3(256), 0, st, y, v, n * 3, half_delta);
+}
+void launch_aboba_b(float* y, float* v, const float* score, const float* noise, uint64_t seed, uint32_t iter, int n,
+                    const LangevinConsts& k, float* yf, float* sf, hipStream_t st) {
+  hipLaunchKernelGGL(k_aboba_b, dim3((n + 255) / 256), dim3(256), 0, st, y, v, score, noise, seed, iter, n, k, yf, sf);
+}
+void launch_copy(const float* src, float* dst, int n, hipStream_t st) {
+  hipLaunchKernelGGL(k_copy, dim3((n + 255) / 256), dim3(256), 0, st, src, dst, n);
+}
+void launch_deg_to_float(const int* deg, float* out, int n, hipStream_t st) {
+  hipLaunchKernelGGL(k_deg_to_float, dim3((n + 255) / 256), dim3(256), 0, st, deg, out, n);
+}
+void launch_count_edges(const int* deg, int n, unsigned long long* out, hipStream_t st) {
+  hipLaunchKernelGGL(k_count_edges, dim3((n + 255) / 256), dim3(256), 0, st, deg, n, out);
+}
+void launch_scatter_mean(const float* src, const int* seg_ptr, int n_out, int width, float* out, hipStream_t st) {
+  hipLaunchKernelGGL(k_scatter_mean, dim3((n_out + 3) / 4), dim3(256), 0, st, src, seg_ptr, n_out, width, out);
+}

@@ -7,10 +7,13 @@ checkpoint contract: embedding rows are indexed by them) and the collation rules
 
 from __future__ import annotations
 
-from dataclasses import dataclass, field
+import itertools
+from dataclasses import dataclass, field, replace
 from typing import List, Optional, Sequence
 
 import torch
+
+_topology_ids = itertools.count(1)
 
 ATOM_TYPES = ["C", "O", "N", "F", "S"]
 ATOM_CODES = ["C", "O", "N", "S", "CA", "CB"]
@@ -58,6 +61,15 @@ class WalkerBatch:
     ptr: torch.Tensor
     dataset_label: List[str] = field(default_factory=list)
     extras: Optional[List[dict]] = None  # per-walker passthrough (atom names etc.)
+    topology_id: int = field(default_factory=lambda: next(_topology_ids))  # identifies the static part (everything but pos)
+
+    def with_pos(self, pos: torch.Tensor) -> "WalkerBatch":
+        """Same walkers, new coordinates (``ModelSamplingWrapper.positions_to_graph``, sampling_wrapper.py:36-47)."""
+        assert pos.shape == self.pos.shape, "The number of positions and nodes should be the same"
+        return replace(self, pos=pos)
+
+    def clone(self) -> "WalkerBatch":
+        return replace(self, pos=self.pos.clone())
 
     @property
     def num_graphs(self) -> int:
@@ -112,7 +124,7 @@ class WalkerBatch:
         kw = {}
         for k, v in self.__dict__.items():
             kw[k] = v.to(device) if torch.is_tensor(v) else v
-        return WalkerBatch(**kw)
+        return WalkerBatch(**kw)  # topology_id is preserved: same static graph on another device
 
     def as_topology(self) -> dict:
         """Plain-dict view (what ``oracle.graph.collate`` returns) for tests."""
