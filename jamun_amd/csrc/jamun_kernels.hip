@@ -103,7 +103,7 @@ __global__ void k_geom(const float* __restrict__ y, const int* __restrict__ ptr,
         if (j != i) {
           // edge_vec = pos_scaled[src] - pos_scaled[dst]
           float ex = FSUB(FMUL(qx, c_in), sx), ey = FSUB(FMUL(qy, c_in), sy), ez = FSUB(FMUL(qz, c_in), sz);
-          float d = sqrtf(FADD(FADD(FMUL(ex, ex), FMUL(ey, ey)), FMUL(ez, ez)));
+          float d = sqrtf(fmaf(ez, ez, fmaf(ey, ey, FMUL(ex, ex))));  // edge_vec.norm(dim=1), CPU fma order
           float dn = d < 1e-12f ? 1e-12f : d;
           esrc[base + nr] = j;
           egeo[base + nr] = make_float4(ex / dn, ey / dn, ez / dn, d);
@@ -116,7 +116,7 @@ __global__ void k_geom(const float* __restrict__ y, const int* __restrict__ ptr,
       const int j = bond_in_src[b];
       const float qx = yc[j * 3], qy = yc[j * 3 + 1], qz = yc[j * 3 + 2];
       float ex = FSUB(FMUL(qx, c_in), sx), ey = FSUB(FMUL(qy, c_in), sy), ez = FSUB(FMUL(qz, c_in), sz);
-      float d = sqrtf(FADD(FADD(FMUL(ex, ex), FMUL(ey, ey)), FMUL(ez, ez)));
+      float d = sqrtf(fmaf(ez, ez, fmaf(ey, ey, FMUL(ex, ex))));
       float dn = d < 1e-12f ? 1e-12f : d;
       esrc[base + nr] = (int)((unsigned)j | 0x80000000u);
       egeo[base + nr] = make_float4(ex / dn, ey / dn, ez / dn, d);
@@ -482,7 +482,8 @@ __device__ __forceinline__ void philox_normal3(uint64_t seed, uint32_t iter, uin
 __device__ __forceinline__ void process_score(const float s[3], const LangevinConsts& k, float psi[3]) {
   float p0 = s[0], p1 = s[1], p2 = s[2];
   if (k.has_clip) {
-    float norm = sqrtf(FADD(FADD(FMUL(p0, p0), FMUL(p1, p1)), FMUL(p2, p2)));
+    // torch.linalg.vector_norm on CPU accumulates with fused multiply-adds: fma(z,z,fma(y,y,x*x))
+    float norm = sqrtf(fmaf(p2, p2, fmaf(p1, p1, FMUL(p0, p0))));
     float clip = fminf(norm, k.clip);
     p0 = FMUL(p0 / norm, clip);
     p1 = FMUL(p1 / norm, clip);

@@ -48,14 +48,17 @@ def random_chain(n_atoms: int, seed: int = 0, bond: float = 0.15, min_dist: floa
     for i in range(1, n_atoms):
         p = i - 2 if (i % 4 == 3 and i >= 2) else i - 1
         parents.append(p)
-        for _attempt in range(10000):
+        others = [j for j in range(i) if j != p]
+        thr = min_dist
+        for attempt in range(1, 100001):
             d = rng.normal(size=3)
             d /= np.linalg.norm(d)
             cand = pos[p] + bond * d
-            others = [j for j in range(i) if j != p]
-            if not others or np.min(np.linalg.norm(pos[others] - cand, axis=1)) >= min_dist:
+            if not others or np.min(np.linalg.norm(pos[others] - cand, axis=1)) >= thr:
                 pos[i] = cand
                 break
+            if attempt % 500 == 0:  # crowded site: relax the exclusion radius a little and keep going
+                thr *= 0.95
         else:  # pragma: no cover
             raise RuntimeError("could not place atom")
     bonds = np.array([[parents[i], i] for i in range(1, n_atoms)], dtype=np.int64).T.reshape(2, -1)

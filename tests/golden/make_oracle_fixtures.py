@@ -1,0 +1,109 @@
+"""Cache CPU-oracle outputs for the GPU parity tests (the oracle needs minutes of CPU time; GPU-minutes are scarce).
+
+    python tests/golden/make_oracle_fixtures.py
+
+Inputs are generated from fixed seeds with ``jamun_amd.synth``; outputs come from ``oracle/``.
+``tests/test_oracle.py::test_cached_oracle_fixtures_are_fresh`` re-runs a prefix of each case on the CPU and checks
+the cache bit for bit, so a stale cache cannot go unnoticed.
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+
+from jamun_amd import synth  # noqa: E402
+from oracle import denoiser as od  # noqa: E402
+from oracle import graph as og  # noqa: E402
+from oracle import walk as ow  # noqa: E402
+
+SIGMA = 0.04
+MCMC = dict(delta=0.04, friction=1.0, M=1.0, inverse_temperature=1.0, score_fn_clip=100.0, save_trajectory=True)
+# "strong": O(1) activations, stresses kernel numerics in one forward.  "stable": small output gain, contractive
+# dynamics, so that fp32 rounding differences are not amplified exponentially along a trajectory.
+GAINS = {"strong": 0.5, "stable": 0.05}
+
+
+def molecules(kind):
+    if kind == "ag4":
+        return [synth.ag_dipeptide()] * 4
+    if kind == "chain17x6":
+        return [synth.random_chain(17, seed=0)] * 6
+    if kind == "ragged":
+        return [synth.random_chain(n, seed=s) for s, n in enumerate([5, 17, 33, 9, 57, 2, 1, 29])]
+    if kind == "dense70":
+        return [synth.random_chain(70, seed=3, bond=0.12, min_dist=0.13)] * 2
+    raise KeyError(kind)
+
+
+def setup(kind, preset, dtype=torch.float32):
+    mols = molecules(kind)
+    topo = og.collate([{k: v for k, v in m.items() if torch.is_tensor(v)} for m in mols])
+    sd = synth.synthetic_state_dict(output_gain=GAINS[preset])
+    p = {k: v.to(dtype) for k, v in sd.items()}
+    return mols, topo, p, od.default_hparams()
+
+
+def forward_case(kind, with_layers):
+    mols, topo, p, hp = setup(kind, "strong")
+    torch.manual_seed(2)
+    y = topo["pos"] + SIGMA * torch.randn_like(topo["pos"])
+    x, inter = od.xhat(y, topo, SIGMA, p, hp, return_intermediates=True)
+    s = od.score(y, topo, SIGMA, p, hp)
+    out = dict(y=y, xhat=x, score=s, g=inter["g"], deg=torch.bincount(inter["edge_index"][1], minlength=y.shape[0]),
+               n_edges=torch.tensor(inter["edge_index"].shape[1]))
+    if with_layers:
+        for l in range(hp["n_layers"] + 1):
+            out[f"x{l}"] = inter[f"x{l}"]
+    return out
+
+
+def walk_case(kind, integrator, steps, preset, max_steps=None):
+    mols, topo, p, hp = setup(kind, preset)
+    g = torch.Generator().manual_seed(42)
+    noise = torch.randn(steps + 1, topo["pos"].shape[0], 3, generator=g)
+    run_steps = steps if max_steps is None else min(steps, max_steps)
+    rec = ow.RecordedNoise(noise)
+    y0 = topo["pos"] + rec(topo["pos"]) * SIGMA
+    out = ow.walk_jump(lambda y: od.score(y, topo, SIGMA, p, hp), lambda y: od.xhat(y, topo, SIGMA, p, hp),
+                       getattr(ow, integrator), y0, "gaussian", rec, steps=run_steps, **MCMC)
+    res = dict(noise=noise, y0=y0)
+    res.update({k: v for k, v in out.items() if torch.is_tensor(v)})
+    return res
+
+
+def sampler_case(continue_chain, steps=8, num_batches=2, max_batches=None):
+    mols, topo, p, hp = setup("ag4", "stable")
+    nb = num_batches if max_batches is None else min(num_batches, max_batches)
+    outs = ow.sampler_loop(topo["pos"], lambda y: od.score(y, topo, SIGMA, p, hp), lambda y: od.xhat(y, topo, SIGMA, p, hp), ow.baoab,
+                           SIGMA, nb, continue_chain, ow.TorchNoise(42), steps=steps, **MCMC)
+    return {f"xhat_traj_{b}": o["xhat_traj"] for b, o in enumerate(outs)} | {f"y_{b}": o["y"] for b, o in enumerate(outs)}
+
+
+CASES = {
+    "oracle_forward_ag4": lambda **kw: forward_case("ag4", True),
+    "oracle_forward_chain17x6": lambda **kw: forward_case("chain17x6", True),
+    "oracle_forward_ragged": lambda **kw: forward_case("ragged", False),
+    "oracle_forward_dense70": lambda **kw: forward_case("dense70", False),
+    "oracle_walk_baoab_ag4_50": lambda max_steps=None, **kw: walk_case("ag4", "baoab", 50, "stable", max_steps),
+    "oracle_walk_baoab_ag4_20_strong": lambda max_steps=None, **kw: walk_case("ag4", "baoab", 20, "strong", max_steps),
+    "oracle_walk_baoab_ragged_12": lambda max_steps=None, **kw: walk_case("ragged", "baoab", 12, "stable", max_steps),
+    "oracle_walk_aboba_ag4_20": lambda max_steps=None, **kw: walk_case("ag4", "aboba", 20, "stable", max_steps),
+    "oracle_sampler_cc1": lambda max_batches=None, **kw: sampler_case(True, max_batches=max_batches),
+    "oracle_sampler_cc0": lambda max_batches=None, **kw: sampler_case(False, max_batches=max_batches),
+}
+
+
+def main():
+    for name, fn in CASES.items():
+        out = fn()
+        np.savez_compressed(os.path.join(HERE, name + ".npz"), **{k: v.numpy() for k, v in out.items()})
+        print(name, {k: tuple(v.shape) for k, v in out.items()}, flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -118,41 +118,59 @@ def test_scatter_mean(dev, width):
 # ---- denoiser forward -----------------------------------------------------------------------------------------------
 
 
+def _golden(golden_dir, name):
+    return {k: torch.tensor(v) for k, v in np.load(os.path.join(golden_dir, name + ".npz")).items()}
+
+
+def _ckpt(preset):
+    from jamun_amd import synth
+
+    return synth.synthetic_checkpoint(output_gain={"strong": 0.5, "stable": 0.05}[preset])
+
+
 @pytest.mark.parametrize("kind", ["ag4", "chain17x6", "ragged", "dense70"])
-def test_forward_matches_oracle(dev, ckpt, kind):
+def test_forward_matches_oracle(dev, golden_dir, kind):
+    """One denoiser forward vs the cached CPU-oracle outputs (tests/golden/make_oracle_fixtures.py): edge structure
+    exactly, node features after every block, network output, xhat (<= 1e-5 nm RMSD) and score."""
+    from jamun_amd.data import WalkerBatch
+    from jamun_amd.model import Denoiser
+
+    ref = _golden(golden_dir, f"oracle_forward_{kind}")
+    sigma = 0.04
+    model = Denoiser.from_checkpoint_dict(_ckpt("strong")).to(dev)
+    batch = WalkerBatch.from_molecules(_mols(kind)).to(dev)
+    smp = model.sampler_for(batch, sigma)
+    y = ref["y"].to(dev)
+    x = smp.xhat(y)
+    assert torch.equal(smp.debug_read(1).cpu().flatten().long(), ref["deg"])
+    assert smp.stats()["n_edges"] == int(ref["n_edges"])
+    l = 0
+    while f"x{l}" in ref:
+        xl, r = smp.debug_read(0, l).cpu(), ref[f"x{l}"]
+        err = (xl - r).abs().max().item() / max(r.abs().max().item(), 1e-6)
+        assert err < 2e-5, (l, err)
+        l += 1
+    g = smp.debug_read(2).cpu()
+    assert (g - ref["g"]).abs().max().item() < 2e-5 * max(ref["g"].abs().max().item(), 1.0)
+    assert rmsd(x, ref["xhat"]) <= RMSD_TOL_NM, rmsd(x, ref["xhat"])
+    s = smp.score(y)
+    assert rmsd(s, ref["score"]) <= RMSD_TOL_NM / sigma**2  # score = (xhat - y)/sigma^2 amplifies by 625
+
+
+def test_forward_matches_live_oracle(dev, ckpt):
+    """Same comparison with the oracle run live on this box (small case), so the cache is not the only witness."""
     from jamun_amd.data import WalkerBatch
     from jamun_amd.model import Denoiser
     from oracle import denoiser as od
 
-    mols = _mols(kind)
+    mols = _mols("ag4")
     topo, p, hp = _oracle_setup(mols, ckpt)
-    sigma = 0.04
-    torch.manual_seed(2)
-    y = topo["pos"] + sigma * torch.randn_like(topo["pos"])
-    x_ref, inter = od.xhat(y, topo, sigma, p, hp, return_intermediates=True)
-    s_ref = od.score(y, topo, sigma, p, hp)
-
+    torch.manual_seed(11)
+    y = topo["pos"] + 0.04 * torch.randn_like(topo["pos"])
+    x_ref = od.xhat(y, topo, 0.04, p, hp)
     model = Denoiser.from_checkpoint_dict(ckpt).to(dev)
-    batch = WalkerBatch.from_molecules(mols).to(dev)
-    smp = model.sampler_for(batch, sigma)
-    x = smp.xhat(y.to(dev))
-    # structure: in-degree (radial + bonded) exactly equal
-    deg = smp.debug_read(1).cpu().flatten().long()
-    deg_ref = torch.bincount(inter["edge_index"][1], minlength=y.shape[0])
-    assert torch.equal(deg, deg_ref)
-    assert smp.stats()["n_edges"] == inter["edge_index"].shape[1]
-    # layer-by-layer features
-    for l in range(hp["n_layers"] + 1):
-        xl = smp.debug_read(0, l).cpu()
-        ref = inter[f"x{l}"]
-        err = (xl - ref).abs().max().item() / max(ref.abs().max().item(), 1e-6)
-        assert err < 2e-5, (l, err)
-    g = smp.debug_read(2).cpu()
-    assert (g - inter["g"]).abs().max().item() < 2e-5 * max(inter["g"].abs().max().item(), 1.0)
-    assert rmsd(x, x_ref) <= RMSD_TOL_NM, rmsd(x, x_ref)
-    s = smp.score(y.to(dev))
-    # score = (xhat - y)/sigma^2 amplifies by 1/sigma^2 = 625
-    assert rmsd(s, s_ref) <= RMSD_TOL_NM / sigma**2
+    x = model.xhat(WalkerBatch.from_molecules(mols).to(dev).with_pos(y.to(dev)), 0.04).pos
+    assert rmsd(x, x_ref) <= RMSD_TOL_NM
 
 
 def test_forward_zero_gain_closed_form(dev):
@@ -238,46 +256,26 @@ def test_baoab_update_kernels_match_reference_golden(dev, golden_dir, name):
     assert torch.equal(score_traj.cpu(), torch.tensor(d["score_traj"]))
 
 
-def _walk_oracle(mols, ckpt, integrator, sigma, kw, noise):
-    from oracle import denoiser as od
-    from oracle import walk as ow
-
-    topo, p, hp = _oracle_setup(mols, ckpt)
-    score_fn = lambda y: od.score(y, topo, sigma, p, hp)
-    xhat_fn = lambda y: od.xhat(y, topo, sigma, p, hp)
-    rec = ow.RecordedNoise(noise)
-    y0 = topo["pos"] + rec(topo["pos"]) * sigma
-    out = ow.walk_jump(score_fn, xhat_fn, getattr(ow, integrator), y0, "gaussian", rec, **kw)
-    return y0, out
-
-
-@pytest.mark.parametrize("integrator,kind,steps", [("baoab", "ag4", 50), ("baoab", "ragged", 12), ("aboba", "ag4", 20)])
-def test_fused_walk_matches_oracle(dev, ckpt, integrator, kind, steps):
-    """cfg1 of BASELINE.json: AG dipeptide, 4 walkers x 50 walk-jump steps, identical noise stream."""
+@pytest.mark.parametrize("case,integrator,kind,preset", [
+    ("oracle_walk_baoab_ag4_50", "baoab", "ag4", "stable"),  # cfg1 of BASELINE.json: AG dipeptide, 4 walkers x 50 steps
+    ("oracle_walk_baoab_ragged_12", "baoab", "ragged", "stable"),
+    ("oracle_walk_aboba_ag4_20", "aboba", "ag4", "stable"),
+])
+def test_fused_walk_matches_oracle(dev, golden_dir, case, integrator, kind, preset):
+    """Fused native walk vs the oracle's walk_jump on the identical noise stream: every saved frame's denoised
+    coordinates within 1e-5 nm RMSD (contractive checkpoint)."""
+    from jamun_amd import native
     from jamun_amd.data import WalkerBatch
     from jamun_amd.model import Denoiser
-    from jamun_amd.sampling import ABOBA, BAOAB, ModelSamplingWrapper, SingleMeasurementSampler
 
-    mols = _mols(kind)
+    ref = _golden(golden_dir, case)
     sigma = 0.04
-    kw = dict(steps=steps, delta=0.04, friction=1.0, M=1.0, inverse_temperature=1.0, score_fn_clip=100.0, save_trajectory=True)
-    batch = WalkerBatch.from_molecules(mols)
-    g = torch.Generator().manual_seed(42)
-    noise = torch.randn(steps + 1, batch.num_nodes, 3, generator=g)  # y0 draw, v0 draw, steps-1 step draws
-    y0, ref = _walk_oracle(mols, ckpt, integrator, sigma, kw, noise)
-
-    model = Denoiser.from_checkpoint_dict(ckpt).to(dev)
-    wrapped = ModelSamplingWrapper(model, batch.to(dev), sigma)
-    cls = BAOAB if integrator == "baoab" else ABOBA
-    mcmc = cls(**kw, cpu_offload=True, v_init="zero")
-    smp = SingleMeasurementSampler(mcmc=mcmc, sigma=sigma)
-    # replay the recorded stream: v0 and the per-step noise are passed explicitly
-    from jamun_amd import native
-
-    params = native.make_mcmc_params(steps, kw["delta"], kw["friction"], kw["M"], kw["inverse_temperature"], kw["score_fn_clip"])
-    ns = wrapped.native_sampler(sigma)
-    y = y0.to(dev).clone()
-    v = noise[1].to(dev).clone()
+    noise = ref["noise"]  # y0 draw, v0 draw, steps-1 step draws
+    steps = noise.shape[0] - 1
+    model = Denoiser.from_checkpoint_dict(_ckpt(preset)).to(dev)
+    ns = model.sampler_for(WalkerBatch.from_molecules(_mols(kind)).to(dev), sigma)
+    params = native.make_mcmc_params(steps, 0.04, 1.0, 1.0, 1.0, 100.0)
+    y, v = ref["y0"].to(dev).clone(), noise[1].to(dev).clone()
     y_traj, score_traj, xhat_traj, xhat = ns.walk(integrator, y, v, params, noise[2 : 2 + steps - 1].to(dev).contiguous(), 0, True)
     T = ref["y_traj"].shape[0]
     assert y_traj.shape[0] == T and xhat_traj.shape[0] == T and score_traj.shape[0] == ref["score_traj"].shape[0]
@@ -285,21 +283,40 @@ def test_fused_walk_matches_oracle(dev, ckpt, integrator, kind, steps):
     assert worst <= RMSD_TOL_NM, worst
     assert rmsd(xhat, ref["xhat"]) <= RMSD_TOL_NM
     assert rmsd(y, ref["y"]) <= RMSD_TOL_NM
-    assert rmsd(y_traj[-1], ref["y_traj"][-1]) <= RMSD_TOL_NM
+    assert max(rmsd(y_traj[t], ref["y_traj"][t]) for t in range(T)) <= RMSD_TOL_NM
     assert rmsd(v, ref["v"]) <= 1e-3
     assert rmsd(score_traj[-1], ref["score_traj"][-1]) <= RMSD_TOL_NM / sigma**2
 
 
-def test_sampler_protocol_and_rng_modes(dev, ckpt):
+def test_fused_walk_chaotic_checkpoint_tracks_oracle_early(dev, golden_dir):
+    """With the strongly non-linear random checkpoint the dynamics amplifies ANY fp32 rounding difference by ~4x
+    every 5 steps (the fp32 oracle itself leaves the fp64 oracle's trajectory at that rate),
+    so the 1e-5 nm bar is asserted on the first frames only and the growth is bounded afterwards."""
+    from jamun_amd import native
+    from jamun_amd.data import WalkerBatch
+    from jamun_amd.model import Denoiser
+
+    ref = _golden(golden_dir, "oracle_walk_baoab_ag4_20_strong")
+    noise = ref["noise"]
+    steps = noise.shape[0] - 1
+    model = Denoiser.from_checkpoint_dict(_ckpt("strong")).to(dev)
+    ns = model.sampler_for(WalkerBatch.from_molecules(_mols("ag4")).to(dev), 0.04)
+    params = native.make_mcmc_params(steps, 0.04, 1.0, 1.0, 1.0, 100.0)
+    y, v = ref["y0"].to(dev).clone(), noise[1].to(dev).clone()
+    _, _, xhat_traj, _ = ns.walk("baoab", y, v, params, noise[2 : 2 + steps - 1].to(dev).contiguous(), 0, True)
+    errs = [rmsd(xhat_traj[t], ref["xhat_traj"][t]) for t in range(steps)]
+    assert max(errs[:8]) <= RMSD_TOL_NM, errs[:8]
+    assert max(errs) <= 1e-3, errs
+
+
+def test_sampler_protocol_and_rng_modes(dev, golden_dir):
     """Sampler.sample hook order / output dict contract (sampling/_sampler.py:53-98, sampling_wrapper.py:49-83),
     reproducibility under torch.manual_seed for both RNG modes, and the torch_cpu mode against the oracle host loop."""
     from jamun_amd.data import WalkerBatch
     from jamun_amd.model import Denoiser
     from jamun_amd.sampling import BAOAB, Sampler, SingleMeasurementSampler
-    from oracle import denoiser as od
-    from oracle import walk as ow
-
     mols = _mols("ag4")
+    ckpt = _ckpt("stable")
     sigma, steps = 0.04, 8
     kw = dict(steps=steps, delta=0.04, friction=1.0, M=1.0, inverse_temperature=1.0, score_fn_clip=100.0, save_trajectory=True)
 
@@ -341,15 +358,14 @@ def test_sampler_protocol_and_rng_modes(dev, ckpt):
         assert torch.equal(a.samples[0][1]["y_traj"][:, -1].cpu(), a.samples[1][1]["y_traj"][:, 0].cpu())
 
     # torch_cpu mode == the reference host loop with torch.manual_seed(42): y0 draw, v0 draw, one draw per step
-    topo, p, hp = _oracle_setup(mols, ckpt)
+    ptr = WalkerBatch.from_molecules(mols).ptr
     for cc in (True, False):
-        outs = ow.sampler_loop(topo["pos"], lambda y: od.score(y, topo, sigma, p, hp), lambda y: od.xhat(y, topo, sigma, p, hp), ow.baoab,
-                               sigma, 2, cc, ow.TorchNoise(42), **kw)
+        ref = _golden(golden_dir, f"oracle_sampler_cc{int(cc)}")
         rec = run("torch_cpu", 42, continue_chain=cc)
         for bi in range(2):
-            ref = ow.unbatch(outs[bi]["xhat_traj"], topo["ptr"])
+            per_walker = ref[f"xhat_traj_{bi}"].permute(1, 0, 2)
             for w in range(4):
-                assert rmsd(rec.samples[bi][w]["xhat_traj"], ref[w]) <= RMSD_TOL_NM
+                assert rmsd(rec.samples[bi][w]["xhat_traj"], per_walker[ptr[w] : ptr[w + 1]]) <= RMSD_TOL_NM
 
 
 def test_missing_tensor_and_bad_config_fail_loudly(dev, ckpt):

@@ -192,3 +192,24 @@ def test_scatter_mean_empty_rows_are_zero():
     src = torch.ones(3, 2)
     out = og.scatter_mean(src, torch.tensor([0, 0, 2]), 4)
     assert torch.equal(out, torch.tensor([[1.0, 1], [0, 0], [1, 1], [0, 0]]))
+
+
+def test_cached_oracle_fixtures_are_fresh(golden_dir):
+    """The GPU tests read cached oracle outputs; re-run a prefix of each kind here and compare bit for bit."""
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("make_oracle_fixtures", os.path.join(golden_dir, "make_oracle_fixtures.py"))
+    mk = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mk)
+    for name, kw, keys in [
+        ("oracle_forward_ag4", {}, ["xhat", "score", "x3", "deg"]),
+        ("oracle_walk_baoab_ag4_50", {"max_steps": 3}, ["xhat_traj", "y_traj"]),
+        ("oracle_walk_aboba_ag4_20", {"max_steps": 3}, ["xhat_traj", "y_traj"]),
+        ("oracle_sampler_cc0", {"max_batches": 1}, ["xhat_traj_0"]),
+    ]:
+        fresh = mk.CASES[name](**kw)
+        cached = np.load(os.path.join(golden_dir, name + ".npz"))
+        for k in keys:
+            c = torch.tensor(cached[k])
+            f = fresh[k]
+            assert torch.equal(f, c[: f.shape[0]] if f.shape != c.shape else c), (name, k)
