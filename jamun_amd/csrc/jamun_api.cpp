@@ -87,12 +87,12 @@ struct UBlock {
   std::vector<UEntry> e;  // nu entries (even)
 };
 struct ConvProblemDev {
-  float* wpack = nullptr;
+  float4* wpack = nullptr;
   int4* chunks = nullptr;
   int* slice_ptr = nullptr;
   int4* ublk = nullptr;
   int* lane_xoff = nullptr;
-  int rc = 0, nt = 0, nk = 0;
+  int planes = 0, nt = 0, xw = 0;
   int64_t K = 0;  // padded contraction depth
 };
 struct LayerDev {
@@ -129,74 +129,99 @@ std::vector<double> noise_mlp(const jamun_model& m, const std::string& prefix, i
 
 struct InBlock { int mul, l, xoff, ch0; };
 
-ConvProblemDev pack_problem(const std::vector<UBlock>& blocks, int rc, int G, int nk, int n_slices,
+// K-slices are ranges of the hidden index k (hidden units + bias row); each is processed in k-subgroups of
+// ksub or ksub-1 hidden units (the two sizes the conv kernel is instantiated for).
+std::vector<std::pair<int, int>> k_subgroups(int n_k, int n_slices, int ksub, std::vector<int>& slice_first_sub) {
+  std::vector<std::pair<int, int>> subs;  // (k0, ks)
+  slice_first_sub.assign(n_slices + 1, 0);
+  const int base = n_k / n_slices, rem = n_k % n_slices;
+  int k = 0;
+  for (int s = 0; s < n_slices; ++s) {
+    const int size = base + (s >= n_slices - rem ? 1 : 0);
+    slice_first_sub[s] = (int)subs.size();
+    if (size == 0) continue;
+    const int n_sub = (size + ksub - 1) / ksub;
+    const int lo = size / n_sub, n_hi = size % n_sub;  // n_hi subgroups of lo+1, the rest of lo
+    if (lo + (n_hi ? 1 : 0) > ksub || lo < ksub - 1 || (lo < 1))
+      throw Err(JAMUN_ERR_INVALID, "cannot split a K-slice of " + std::to_string(size) + " hidden units into groups of " +
+                                       std::to_string(ksub - 1) + "/" + std::to_string(ksub));
+    for (int i = 0; i < n_sub; ++i) {
+      const int ks = lo + (i < n_hi ? 1 : 0);
+      subs.push_back({k, ks});
+      k += ks;
+    }
+  }
+  slice_first_sub[n_slices] = (int)subs.size();
+  return subs;
+}
+
+ConvProblemDev pack_problem(const std::vector<UBlock>& blocks, int planes, int G, int n_slices, int ksub,
                             const std::vector<float>& W3, const std::vector<float>& b3, int hidden) {
   ConvProblemDev P;
-  P.rc = rc;
-  P.nk = nk;
+  P.planes = planes;
   P.nt = (G + 31) / 32;
   const int NT = P.nt;
-  const int kp = ((hidden + 1 + nk - 1) / nk) * nk;  // hidden units + bias row, padded to the k-group size
+  std::vector<int> first_sub;
+  const auto subs = k_subgroups(hidden + 1, n_slices, ksub, first_sub);
   std::vector<int4> chunks;
-  std::vector<int> steps;
-  int64_t wofs = 0;  // in units of 64 floats
-  for (int k0 = 0; k0 < kp; k0 += nk)
-    for (size_t b = 0; b < blocks.size(); ++b) {
-      const int nu = (int)blocks[b].e.size();
-      const int ns = nk * nu / 2;
-      chunks.push_back(make_int4((int)b, k0, (int)wofs, 0));
-      steps.push_back(ns);
-      wofs += (int64_t)ns * NT;
-    }
-  if (wofs * 64 > (int64_t)1 << 31) throw Err(JAMUN_ERR_INVALID, "packed conv weights exceed 2^31 floats");
-  std::vector<float> wp((size_t)wofs * 64, 0.f);
+  std::vector<int> sp(n_slices + 1, 0);
+  int64_t gofs = 0;  // in weight groups (4 K-steps x NT tiles x 64 lanes x float)
+  for (int s = 0; s < n_slices; ++s) {
+    sp[s] = (int)chunks.size();
+    for (int si = first_sub[s]; si < first_sub[s + 1]; ++si)  // k-subgroup major: the staged h~ records are reused by the u-blocks
+      for (size_t b = 0; b < blocks.size(); ++b) {
+        const int nu = (int)blocks[b].e.size(), k0 = subs[si].first, ks = subs[si].second;
+        const int ng = (ks * nu / 2 + 3) / 4;
+        chunks.push_back(make_int4((int)b, k0 | (ks << 16), (int)gofs, ng));
+        gofs += ng;
+      }
+  }
+  sp[n_slices] = (int)chunks.size();
+  if (gofs * NT * 64 > (int64_t)0x7fffffff) throw Err(JAMUN_ERR_INVALID, "packed conv weights too large");
+  std::vector<float4> wp((size_t)gofs * NT * 64, make_float4(0.f, 0.f, 0.f, 0.f));
   int64_t Ktot = 0;
-  for (size_t ci = 0; ci < chunks.size(); ++ci) {
-    const UBlock& B = blocks[chunks[ci].x];
-    const int nu = (int)B.e.size(), k0 = chunks[ci].y;
-    float* dst = wp.data() + (size_t)chunks[ci].z * 64;
-    Ktot += (int64_t)nk * nu;
-    for (int q = 0; q < steps[ci]; ++q)
+  for (const int4& cd : chunks) {
+    const UBlock& B = blocks[cd.x];
+    const int nu = (int)B.e.size(), k0 = cd.y & 0xffff, ks = cd.y >> 16;
+    Ktot += (int64_t)cd.w * 8;
+    for (int g = 0; g < cd.w; ++g)
       for (int nt = 0; nt < NT; ++nt)
         for (int lane = 0; lane < 64; ++lane) {
-          const int hh = lane >> 5, c = lane & 31;
-          const int kidx = 2 * q + hh, kl = kidx / nu, ul = kidx % nu;
-          const int k = k0 + kl, col = nt * 32 + c;
-          const UEntry& ue = B.e[ul];
-          float v = 0.f;
-          if (k <= hidden && col < G && ue.scale != 0.0) {
-            const int64_t p = ue.wbase + col;
-            const double w = (k < hidden) ? (double)W3[(size_t)p * hidden + k] : (double)b3[p];
-            v = (float)(w * ue.scale);
+          const int hh = lane >> 5, c = lane & 31, col = nt * 32 + c;
+          float v[4] = {0.f, 0.f, 0.f, 0.f};
+          for (int st = 0; st < 4; ++st) {
+            const int kidx = 2 * (4 * g + st) + hh;
+            if (kidx >= ks * nu) continue;
+            const int kk = kidx / nu, ul = kidx % nu, k = k0 + kk;
+            const UEntry& ue = B.e[ul];
+            if (k <= hidden && col < G && ue.scale != 0.0) {
+              const int64_t p = ue.wbase + col;
+              const double w = (k < hidden) ? (double)W3[(size_t)p * hidden + k] : (double)b3[p];
+              v[st] = (float)(w * ue.scale);
+            }
           }
-          dst[((size_t)q * NT + nt) * 64 + lane] = v;
+          wp[((size_t)(cd.z + g) * NT + nt) * 64 + lane] = make_float4(v[0], v[1], v[2], v[3]);
         }
   }
   P.K = Ktot;
-  // contiguous slices balanced by K-steps
-  int64_t total = 0;
-  for (int s : steps) total += s;
-  std::vector<int> sp(n_slices + 1, 0);
-  {
-    int64_t cum = 0;
-    int s = 0;
-    for (size_t ci = 0; ci < chunks.size(); ++ci) {
-      while (s <= n_slices && cum * n_slices >= total * (int64_t)s) sp[s++] = (int)ci;
-      cum += steps[ci];
-    }
-    while (s <= n_slices) sp[s++] = (int)chunks.size();
-    sp[n_slices] = (int)chunks.size();
-  }
   std::vector<int4> ub;
   std::vector<int> lx;
+  int xw = 1;
   for (const UBlock& B : blocks) {
-    ub.push_back(make_int4(B.type, (int)B.e.size(), 0, 0));
+    int lo = 1 << 30, hi = 0;
+    const int per = (B.type == JAMUN_T_X0 || B.type == JAMUN_T_X0V) ? 1 : 3;
+    for (const UEntry& e : B.e)
+      if (e.scale != 0.0) { lo = std::min(lo, e.xoff); hi = std::max(hi, e.xoff + per); }
+    if (hi == 0) { lo = 0; hi = per; }
+    ub.push_back(make_int4(B.type, (int)B.e.size(), lo, hi - lo));
+    xw = std::max(xw, hi - lo);
     for (int lane = 0; lane < 64; ++lane) {
       int v = 0;
-      if (lane < (int)B.e.size()) v = B.e[lane].xoff | (B.e[lane].cross ? JAMUN_XOFF_CROSS : 0);
+      if (lane < (int)B.e.size() && B.e[lane].scale != 0.0) v = (B.e[lane].xoff - lo) | (B.e[lane].cross ? JAMUN_XOFF_CROSS : 0);
       lx.push_back(v);
     }
   }
+  P.xw = xw;
   P.wpack = dev_upload(wp);
   P.chunks = dev_upload(chunks);
   P.slice_ptr = dev_upload(sp);
@@ -219,6 +244,7 @@ struct jamun_sampler {
   float c_in = 0, c_skip = 0, c_out = 0, r_cut = 0, r2 = 0, rb_step = 0;
   // static device data
   int *ptr = nullptr, *bond_in_ptr = nullptr, *bond_in_src = nullptr;
+  int n_tiles = 0;
   float *x_emb = nullptr, *mu = nullptr;
   std::vector<LayerDev> layers;
   float *w_gate = nullptr, *w_vec = nullptr, *w_out = nullptr;
@@ -323,8 +349,8 @@ LayerDev build_layer(const jamun_model& m, const std::string& prefix, const std:
     pad_even(b);
     blocks1.push_back(b);
   }
-  L.p0 = pack_problem(blocks0, 1, G0, JAMUN_NK0, n_slices, W3, b3, H);
-  L.p1 = pack_problem(blocks1, 3, G1, JAMUN_NK1, n_slices, W3, b3, H);
+  L.p0 = pack_problem(blocks0, 1, G0, n_slices, JAMUN_KSUB0, W3, b3, H);
+  L.p1 = pack_problem(blocks1, 3, G1, n_slices, JAMUN_KSUB1, W3, b3, H);
 
   // ---- radial MLP first layer: split into the constant bonded part and the radial part
   const auto& W1 = m.get(prefix + ".gated_conv.f.f.radial_nn.0.weight", (int64_t)H * H);
@@ -412,14 +438,17 @@ void forward(jamun_sampler* s, const float* y, float* xhat, float* score, hipStr
     }
     ConvArgs a{};
     a.deg = s->deg; a.esrc = s->esrc; a.egeo = s->egeo; a.h = s->h; a.x = x_in;
-    a.n_atoms = s->n_atoms; a.n_pad = s->n_pad; a.S = s->S; a.XS = XSin; a.n_slices = s->n_slices;
+    a.n_atoms = s->n_atoms; a.n_pad = s->n_pad; a.n_tiles = s->n_tiles; a.S = s->S; a.XS = XSin;
+    a.n_slices = s->n_slices;
     for (int pi = 0; pi < 2; ++pi) {
       ConvProblemDev& P = pi == 0 ? L.p0 : L.p1;
       if (P.nt == 0) continue;
       a.wpack = P.wpack; a.chunks = P.chunks; a.slice_ptr = P.slice_ptr; a.ublk = P.ublk; a.lane_xoff = P.lane_xoff;
       a.partial = pi == 0 ? s->partial0 : s->partial1;
       ProfScope ps(s, l == 0 ? (pi == 0 ? JAMUN_PROF_CONV0_INIT : JAMUN_PROF_CONV1_INIT) : (pi == 0 ? JAMUN_PROF_CONV0 : JAMUN_PROF_CONV1), st);
-      if (launch_conv(a, P.rc, P.nt, P.nk, st) != 0) throw Err(JAMUN_ERR_INVALID, "unsupported conv tile configuration");
+      const int rcode = launch_conv(a, P.planes, P.nt, st);
+      if (rcode == -2) throw Err(JAMUN_ERR_INVALID, "walker batch needs more than 160 KiB of LDS per conv workgroup (edge stride too large)");
+      if (rcode != 0) throw Err(JAMUN_ERR_INVALID, "unsupported conv tile configuration");
     }
     NodeArgs n{};
     n.partial0 = s->partial0; n.partial1 = s->partial1; n.deg = s->deg; n.x_in = x_in; n.x_out = s->x[l];
@@ -481,8 +510,8 @@ int jamun_model_create(const jamun_hparams* hp, const jamun_tensor* tensors, int
     if (!hp || !out || (!tensors && n_tensors > 0)) throw Err(JAMUN_ERR_INVALID, "null argument");
     if (hp->edge_attr_dim != 64) throw Err(JAMUN_ERR_INVALID, "only edge_attr_dim = 64 is supported");
     if (hp->mul0 < 1 || hp->mul1 < 0 || hp->n_layers < 0) throw Err(JAMUN_ERR_INVALID, "bad irreps_hidden / n_layers");
-    if ((hp->mul0 + hp->mul1 + 31) / 32 > 5 || (hp->mul1 + 31) / 32 > 5)
-      throw Err(JAMUN_ERR_INVALID, "irreps_hidden too wide for the compiled conv tiles (mul0 + mul1 <= 160)");
+    if ((hp->mul0 + hp->mul1 + 31) / 32 > 5 || (hp->mul1 + 31) / 32 > 2)
+      throw Err(JAMUN_ERR_INVALID, "irreps_hidden too wide for the compiled conv tiles (mul0 + mul1 <= 160, mul1 <= 64)");
     if (hp->mul1 == 0) throw Err(JAMUN_ERR_INVALID, "irreps_hidden needs at least one 1e channel (output is 1x1e)");
     if (hp->emb_dim[0] != hp->emb_dim[1])
       throw Err(JAMUN_ERR_INVALID, "atom_type and atom_code embedding dims must match (reference atom_embedding.py:54-56)");
@@ -552,6 +581,8 @@ int jamun_sampler_create(const jamun_model* m, float sigma, const jamun_topology
     }
     s->S = std::min(std::max(nmax - 1, 0), JAMUN_MAX_NEIGHBORS + 1) + max_in;
     if (s->S < 1) s->S = 1;
+    s->n_tiles = s->n_pad / 32;
+    if (conv_set_max_lds() != 0) throw Err(JAMUN_ERR_HIP, "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed");
     std::vector<int> ptr_h(topo->ptr, topo->ptr + W + 1);
     s->ptr = dev_upload(ptr_h);
     s->bond_in_ptr = dev_upload(bip);

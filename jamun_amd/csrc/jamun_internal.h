@@ -5,11 +5,12 @@
 
 #define JAMUN_MAX_NEIGHBORS 32  // torch_geometric.nn.radius_graph default (src/jamun/model/denoiser.py:149)
 #define JAMUN_HS 68             // row stride of the per-edge radial-MLP activations: 64 hidden + bias row + pad
-#define JAMUN_KPAD 66           // contraction rows per u: 64 hidden units + bias row, padded to the k-group size
 
-// k-group sizes (hidden units per lane) of the two conv GEMMs
-#define JAMUN_NK0 2  // scalar-output rows (RC = 1)
-#define JAMUN_NK1 1  // vector-output rows (RC = 3)
+// conv kernel geometry (jamun_conv.hip)
+#define JAMUN_KSUB0 5  // hidden units per k-subgroup, scalar-output rows (subgroups of 4 or 5)
+#define JAMUN_KSUB1 2  // hidden units per k-subgroup, vector-output rows (3 planes per workgroup; subgroups of 1 or 2)
+#define JAMUN_MAX_DYN_LDS (160 * 1024)
+#define JAMUN_MAX_BATCH 128  // edge batches (of 4) per wave: 8 atoms x ceil(S / 4); limits the edge stride S to 64
 
 // zeta types of a u-block (what the edge feeds into the contraction)
 #define JAMUN_T_X0 0   // x0_j[u]                      -> scalar rows
@@ -25,14 +26,14 @@ struct ConvArgs {
   const float4* egeo;
   const float* h;  // [n_atoms*S][JAMUN_HS]
   const float* x;  // [n_atoms][XS]
-  int n_atoms, n_pad, S, XS;
+  int n_atoms, n_pad, n_tiles, S, XS;
   // problem
-  const float* wpack;
-  const int4* chunks;     // {ublk, k0, wofs/64, 0}
-  const int* slice_ptr;   // [n_slices+1]
-  const int4* ublk;       // {type, nu, 0, 0}
-  const int* lane_xoff;   // [n_ublk][64]
-  float* partial;         // [n_slices][n_pad][RC*NT*32]
+  const float4* wpack;   // 16-byte weight fragments: 4 consecutive K-steps of one lane
+  const int4* chunks;    // {ublk, k0 | ks << 16, first weight group, number of weight groups (of 4 K-steps)}
+  const int* slice_ptr;  // [n_slices+1] chunk ranges
+  const int4* ublk;      // {type, nu, xcol0, width}
+  const int* lane_xoff;  // [n_ublk][64] column relative to xcol0 | JAMUN_XOFF_CROSS
+  float* partial;        // [n_slices][n_pad][RC][NT*32]
   int n_slices;
 };
 
@@ -80,7 +81,8 @@ void launch_geom(const float* y, const int* ptr, int n_graphs, float c_in, float
                  const int* bis, int mean_center, float* yc, int* deg, int* esrc, float4* egeo, hipStream_t st);
 void launch_edge_h(const int* deg, const int* esrc, const float4* egeo, int n_atoms, int S, const float* w1r,
                    const float* cmask, const float* mu, float step, float* h, hipStream_t st);
-int launch_conv(const ConvArgs& a, int rc, int nt, int nk, hipStream_t st);
+int launch_conv(const ConvArgs& a, int rc, int nt, hipStream_t st);
+int conv_set_max_lds();
 void launch_node_update(const NodeArgs& a, hipStream_t st);
 void launch_head(const HeadArgs& a, hipStream_t st);
 void launch_finalize(const float* y, const float* yc, const float* g, const int* ptr, int n_graphs, float c_skip,

@@ -10,11 +10,7 @@
 //   egeo[e]              (vhat.x, vhat.y, vhat.z, d)  in c_in-scaled units (src/jamun/model/arch/e3conv.py:114-116)
 //   h[e][HS]             radial-MLP hidden activations SiLU(W1 a_e + b1) [64], then 1 (bias row), then zeros
 //
-// The conv contraction is the destination-grouped association:
-//   A[(i,c)][(k,u)] = sum_{e -> i} h_e[k] * zeta_e[c][u]         (formed on the fly, never leaves the CU)
-//   m[(i,c)][w]     = sum_{(k,u)} A[(i,c)][(k,u)] * Wp[(k,u)][w]   (v_mfma_f32_32x32x2_f32, exact fp32)
-// which is exact-arithmetic-identical to the reference's per-edge  tp(x[src], sh, radial_nn(edge_attr))
-// followed by scatter-mean (src/jamun/e3tools/nn/_conv.py:93-119) but needs deg(i) times fewer FLOPs.
+// The conv contraction itself lives in jamun_conv.hip.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -162,124 +158,6 @@ __global__ __launch_bounds__(256) void k_edge_h(const int* __restrict__ deg, con
     h[e * JAMUN_HS + lane] = hv;
     if (lane < JAMUN_HS - 64) h[e * JAMUN_HS + 64 + lane] = (lane == 0) ? 1.f : 0.f;
   }
-}
-
-// ------------------------------------------------------------------------------------------------
-// conv contraction (see header comment).  One wave per workgroup: tile = 32 destination atoms,
-// K-slice = blockIdx.x % n_slices (so that all workgroups of one slice share an XCD's L2 under the
-// round-robin dispatch; a speed choice only).
-// ------------------------------------------------------------------------------------------------
-#define LDS_ROW 33
-
-template <int RC, int NK, int TYPE>
-__device__ __forceinline__ void form_chunk(float* __restrict__ A_lds, const ConvArgs& a, int n0, int k0, int nu,
-                                           int xoff, int lane) {
-  const bool active = lane < nu;
-  const bool is_cross = (xoff & JAMUN_XOFF_CROSS) != 0;
-  const int xo = xoff & 0xffff;
-  for (int il = 0; il < 32; ++il) {
-    const int i = n0 + il;
-    float g[RC][NK];
-#pragma unroll
-    for (int c = 0; c < RC; ++c)
-#pragma unroll
-      for (int kl = 0; kl < NK; ++kl) g[c][kl] = 0.f;
-    if (i < a.n_atoms) {
-      const int d_i = a.deg[i];
-      for (int t = 0; t < d_i; ++t) {
-        const size_t e = (size_t)i * a.S + t;
-        const int j = a.esrc[e] & 0x7fffffff;
-        const float4 geo = a.egeo[e];
-        float hk[NK];
-#pragma unroll
-        for (int kl = 0; kl < NK; ++kl) hk[kl] = a.h[e * JAMUN_HS + k0 + kl];
-        const float* __restrict__ xp = a.x + (size_t)j * a.XS + xo;
-        float z[RC];
-        if (TYPE == JAMUN_T_X0) {
-          z[0] = active ? xp[0] : 0.f;
-        } else if (TYPE == JAMUN_T_DOT) {
-          float x0 = active ? xp[0] : 0.f, x1 = active ? xp[1] : 0.f, x2 = active ? xp[2] : 0.f;
-          z[0] = x0 * geo.x + x1 * geo.y + x2 * geo.z;
-        } else if (TYPE == JAMUN_T_X0V) {
-          float x0 = active ? xp[0] : 0.f;
-          z[0] = x0 * geo.x;
-          if (RC > 1) { z[1 % RC] = x0 * geo.y; z[2 % RC] = x0 * geo.z; }
-        } else {  // JAMUN_T_X1C
-          float x0 = active ? xp[0] : 0.f, x1 = active ? xp[1] : 0.f, x2 = active ? xp[2] : 0.f;
-          float cx = x1 * geo.z - x2 * geo.y, cy = x2 * geo.x - x0 * geo.z, cz = x0 * geo.y - x1 * geo.x;
-          z[0] = is_cross ? cx : x0;
-          if (RC > 1) { z[1 % RC] = is_cross ? cy : x1; z[2 % RC] = is_cross ? cz : x2; }
-        }
-#pragma unroll
-        for (int c = 0; c < RC; ++c)
-#pragma unroll
-          for (int kl = 0; kl < NK; ++kl) g[c][kl] = fmaf(hk[kl], z[c], g[c][kl]);
-      }
-    }
-    if (active) {
-#pragma unroll
-      for (int c = 0; c < RC; ++c)
-#pragma unroll
-        for (int kl = 0; kl < NK; ++kl) A_lds[(c * NK * 64 + kl * nu + lane) * LDS_ROW + il] = g[c][kl];
-    }
-  }
-}
-
-template <int RC, int NT, int NK>
-__global__ __launch_bounds__(64) void k_conv(ConvArgs a) {
-  __shared__ float A_lds[RC * NK * 64 * LDS_ROW];
-  const int lane = threadIdx.x;
-  const int slice = blockIdx.x % a.n_slices;
-  const int tile = blockIdx.x / a.n_slices;
-  const int n0 = tile * 32;
-  const int r = lane & 31, hh = lane >> 5;
-
-  f32x16 acc[RC][NT];
-#pragma unroll
-  for (int c = 0; c < RC; ++c)
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-      for (int q = 0; q < 16; ++q) acc[c][nt][q] = 0.f;
-
-  const int c_begin = a.slice_ptr[slice], c_end = a.slice_ptr[slice + 1];
-  for (int ci = c_begin; ci < c_end; ++ci) {
-    const int4 cd = a.chunks[ci];  // {ublk, k0, wofs (in 64-float units), unused}
-    const int4 ub = a.ublk[cd.x];  // {type, nu, 0, 0}
-    const int type = ub.x, nu = ub.y;
-    const int xoff = a.lane_xoff[cd.x * 64 + lane];
-    const int k0 = cd.y;
-    if (type == JAMUN_T_X0) form_chunk<RC, NK, JAMUN_T_X0>(A_lds, a, n0, k0, nu, xoff, lane);
-    else if (type == JAMUN_T_DOT) form_chunk<RC, NK, JAMUN_T_DOT>(A_lds, a, n0, k0, nu, xoff, lane);
-    else if (type == JAMUN_T_X0V) form_chunk<RC, NK, JAMUN_T_X0V>(A_lds, a, n0, k0, nu, xoff, lane);
-    else form_chunk<RC, NK, JAMUN_T_X1C>(A_lds, a, n0, k0, nu, xoff, lane);
-    __syncthreads();
-    const int nsteps = (NK * nu) >> 1;
-    const float* __restrict__ wp = a.wpack + (size_t)cd.z * 64;
-    for (int q = 0; q < nsteps; ++q) {
-      float av[RC];
-#pragma unroll
-      for (int c = 0; c < RC; ++c) av[c] = A_lds[(c * NK * 64 + 2 * q + hh) * LDS_ROW + r];
-#pragma unroll
-      for (int nt = 0; nt < NT; ++nt) {
-        const float b = wp[((size_t)q * NT + nt) * 64 + lane];
-#pragma unroll
-        for (int c = 0; c < RC; ++c) acc[c][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[c], b, acc[c][nt], 0, 0, 0);
-      }
-    }
-    __syncthreads();
-  }
-  // partial slab: [slice][node][RC][NT*32]
-  const size_t row_w = (size_t)RC * NT * 32;
-#pragma unroll
-  for (int c = 0; c < RC; ++c)
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-      for (int q = 0; q < 16; ++q) {
-        const int row = (q & 3) + 8 * (q >> 2) + 4 * hh;
-        a.partial[((size_t)slice * a.n_pad + n0 + row) * row_w + (size_t)c * NT * 32 + nt * 32 + r] = acc[c][nt][q];
-      }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -645,25 +523,6 @@ void launch_edge_h(const int* deg, const int* esrc, const float4* egeo, int n_at
                      step, h);
 }
 
-template <int RC, int NK>
-static void launch_conv_nt(const ConvArgs& a, int nt, int grid, hipStream_t st) {
-  switch (nt) {
-    case 1: hipLaunchKernelGGL((k_conv<RC, 1, NK>), dim3(grid), dim3(64), 0, st, a); break;
-    case 2: hipLaunchKernelGGL((k_conv<RC, 2, NK>), dim3(grid), dim3(64), 0, st, a); break;
-    case 3: hipLaunchKernelGGL((k_conv<RC, 3, NK>), dim3(grid), dim3(64), 0, st, a); break;
-    case 4: hipLaunchKernelGGL((k_conv<RC, 4, NK>), dim3(grid), dim3(64), 0, st, a); break;
-    case 5: hipLaunchKernelGGL((k_conv<RC, 5, NK>), dim3(grid), dim3(64), 0, st, a); break;
-    default: break;
-  }
-}
-int launch_conv(const ConvArgs& a, int rc, int nt, int nk, hipStream_t st) {
-  const int grid = (a.n_pad / 32) * a.n_slices;
-  if (nt < 1 || nt > 5) return -1;
-  if (rc == 1 && nk == JAMUN_NK0) launch_conv_nt<1, JAMUN_NK0>(a, nt, grid, st);
-  else if (rc == 3 && nk == JAMUN_NK1) launch_conv_nt<3, JAMUN_NK1>(a, nt, grid, st);
-  else return -1;
-  return 0;
-}
 void launch_node_update(const NodeArgs& a, hipStream_t st) {
   const int grid = (a.n_atoms + NB_NODES - 1) / NB_NODES;
   const size_t sm = sizeof(float) * NB_NODES * (a.mul0 + a.mul1 + 3 * a.mul1 + a.XSin);
