@@ -438,7 +438,7 @@ void forward(jamun_sampler* s, const float* y, float* xhat, float* score, hipStr
     }
     ConvArgs a{};
     a.deg = s->deg; a.esrc = s->esrc; a.egeo = s->egeo; a.h = s->h; a.x = x_in;
-    a.n_atoms = s->n_atoms; a.n_pad = s->n_pad; a.n_tiles = s->n_tiles; a.S = s->S; a.XS = XSin;
+    a.n_atoms = s->n_atoms; a.n_pad = s->n_pad; a.n_tiles = s->n_tiles; a.S = s->S; a.S4 = (s->S + 3) & ~3; a.XS = XSin;
     a.n_slices = s->n_slices;
     for (int pi = 0; pi < 2; ++pi) {
       ConvProblemDev& P = pi == 0 ? L.p0 : L.p1;

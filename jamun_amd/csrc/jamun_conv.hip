@@ -46,32 +46,29 @@ struct EdgeBatch {
   float4 gj[4];
   float hk[4][KS];
   float xv[4][NX];
-  int il, cnt, last;
+  int il, last;
 };
 
 template <int RC, int KSUB, int KS, int TYPE>
 __device__ __forceinline__ void load_batch(EdgeBatch<RC, KS, TYPE>& B, int entry, const float4* __restrict__ g_lds,
                                            const float* __restrict__ h_lds, const ConvArgs& a, int xc) {
   using L = ConvLds<RC, KSUB>;
-  // entry: il | t0 << 8 | cnt << 16 | last << 24   (wave-uniform)
+  // entry: il | t0 << 8 | last << 24   (wave-uniform).  Edge slots are padded to a multiple of 4 per atom: padding
+  // slots carry h~ = 0 and a valid source row, so no per-edge predicate is needed.
   B.il = entry & 0xff;
-  B.cnt = (entry >> 16) & 0xff;
   B.last = entry >> 24;
-  const int t0 = (entry >> 8) & 0xff;
-  if (B.cnt == 0) return;  // wave-uniform: an atom without in-edges (or a padding row) has no staged records
-  const int tmax = t0 + B.cnt - 1;
+  const int slot0 = B.il * a.S4 + ((entry >> 8) & 0xff);
 #pragma unroll
   for (int u = 0; u < 4; ++u) {
-    const int t = (t0 + u < tmax) ? t0 + u : tmax;  // clamp: slots past the batch re-read its last edge (never used)
-    const int slot = B.il * a.S + t;
-    B.gj[u] = g_lds[slot];
+    B.gj[u] = g_lds[slot0 + u];
 #pragma unroll
-    for (int kk = 0; kk < KS; ++kk) B.hk[u][kk] = h_lds[(size_t)slot * L::HST + kk];
+    for (int kk = 0; kk < KS; ++kk) B.hk[u][kk] = h_lds[(size_t)(slot0 + u) * L::HST + kk];
   }
+  const char* __restrict__ xb = reinterpret_cast<const char*>(a.x) + xc * 4;
 #pragma unroll
   for (int u = 0; u < 4; ++u) {
-    const int j = __builtin_amdgcn_readfirstlane(__float_as_int(B.gj[u].x));
-    const float* __restrict__ xp = a.x + (size_t)j * a.XS + xc;
+    const int off = __builtin_amdgcn_readfirstlane(__float_as_int(B.gj[u].x));  // byte offset of the source row
+    const float* __restrict__ xp = reinterpret_cast<const float*>(xb + off);
 #pragma unroll
     for (int q = 0; q < EdgeBatch<RC, KS, TYPE>::NX; ++q) B.xv[u][q] = xp[q];
   }
@@ -83,7 +80,7 @@ __device__ __forceinline__ void compute_batch(const EdgeBatch<RC, KS, TYPE>& B, 
   using L = ConvLds<RC, KSUB>;
 #pragma unroll
   for (int u = 0; u < 4; ++u) {
-    if (u < B.cnt) {  // wave-uniform
+    {
       const float4 gj = B.gj[u];
       float z[RC];
       if (TYPE == JAMUN_T_X0) {
@@ -158,12 +155,14 @@ __device__ __forceinline__ void form_dispatch(int type, float* A_lds, const floa
 template <int RC, int KSUB>
 __device__ __forceinline__ void stage_h(float* __restrict__ h_lds, const ConvArgs& a, int n0, int k0, int ks, int tid) {
   using L = ConvLds<RC, KSUB>;
-  const int per_node = a.S * ks;
+  const int per_node = a.S4 * ks;
   for (int idx = tid; idx < 32 * per_node; idx += 256) {
     const int il = idx / per_node, rem = idx - il * per_node;
     const int t = rem / ks, kk = rem - t * ks;
     const int i = n0 + il;
-    if (i < a.n_atoms && t < a.deg[i]) h_lds[((size_t)il * a.S + t) * L::HST + kk] = a.h[((size_t)i * a.S + t) * JAMUN_HS + k0 + kk];
+    float v = 0.f;  // padding slots (t >= deg) contribute nothing
+    if (i < a.n_atoms && t < a.deg[i]) v = a.h[((size_t)i * a.S + t) * JAMUN_HS + k0 + kk];
+    h_lds[((size_t)il * a.S4 + t) * L::HST + kk] = v;
   }
 }
 
@@ -174,8 +173,8 @@ __global__ __launch_bounds__(256, 2) void k_conv(ConvArgs a) {
   float* __restrict__ lds = reinterpret_cast<float*>(lds4);
   float* __restrict__ A_lds = lds;                                           // [RC][KSUB*64+8][33]
   float4* __restrict__ g_lds = reinterpret_cast<float4*>(lds + ((RC * L::A_PLANE + 3) & ~3));  // [32][S]
-  float* __restrict__ h_lds = reinterpret_cast<float*>(g_lds + 32 * a.S);     // [32][S][HST]
-  int* __restrict__ b_lds = reinterpret_cast<int*>(h_lds + 32 * a.S * L::HST); // [4 waves][JAMUN_MAX_BATCH] batch list
+  float* __restrict__ h_lds = reinterpret_cast<float*>(g_lds + 32 * a.S4);    // [32][S4][HST]
+  int* __restrict__ b_lds = reinterpret_cast<int*>(h_lds + 32 * a.S4 * L::HST); // [4 waves][JAMUN_MAX_BATCH] batch list
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform by construction; tell the compiler
   const int r = lane & 31, hh = lane >> 5;
@@ -193,14 +192,16 @@ __global__ __launch_bounds__(256, 2) void k_conv(ConvArgs a) {
 
   const int c_begin = a.slice_ptr[slice], c_end = a.slice_ptr[slice + 1];
   // edge table of the tile: (source, vhat) per slot
-  for (int idx = tid; idx < 32 * a.S; idx += 256) {
-    const int il = idx / a.S, t = idx - il * a.S;
+  for (int idx = tid; idx < 32 * a.S4; idx += 256) {
+    const int il = idx / a.S4, t = idx - il * a.S4;
     const int i = n0 + il;
+    float4 rec = make_float4(__int_as_float(0), 0.f, 0.f, 0.f);  // padding: row 0 (valid memory), zero geometry
     if (i < a.n_atoms && t < a.deg[i]) {
       const size_t e = (size_t)i * a.S + t;
       const float4 geo = a.egeo[e];
-      g_lds[idx] = make_float4(__int_as_float(a.esrc[e] & 0x7fffffff), geo.x, geo.y, geo.z);
+      rec = make_float4(__int_as_float((a.esrc[e] & 0x7fffffff) * a.XS * 4), geo.x, geo.y, geo.z);
     }
+    g_lds[idx] = rec;
   }
   if (c_begin < c_end) {
     const int4 cd = a.chunks[c_begin];
@@ -234,12 +235,8 @@ __global__ __launch_bounds__(256, 2) void k_conv(ConvArgs a) {
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
         const int pk = pks[k], nk = nks[k], dk = dks[k];
-        if (b >= pk && b < pk + nk) {
-          const int t0 = (b - pk) * 4;
-          int cnt = dk - t0;
-          cnt = cnt > 4 ? 4 : (cnt < 0 ? 0 : cnt);
-          ent = (wave * 8 + k) | (t0 << 8) | (cnt << 16) | ((b == pk + nk - 1 ? 1 : 0) << 24);
-        }
+        if (b >= pk && b < pk + nk) ent = (wave * 8 + k) | (((b - pk) * 4) << 8) | ((b == pk + nk - 1 ? 1 : 0) << 24);
+        (void)dk;
       }
       blist[b] = ent;
     }
@@ -269,10 +266,19 @@ __global__ __launch_bounds__(256, 2) void k_conv(ConvArgs a) {
     const int G = cd.w;
     const int g_begin = (G * wave) >> 2, g_end = (G * (wave + 1)) >> 2;
     const float4* __restrict__ wp = a.wpack + ((size_t)cd.z * NT) * 64 + lane;
+    float4 bn[NT];
+    if (g_begin < g_end) {
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) bn[nt] = wp[((size_t)g_begin * NT + nt) * 64];
+    }
     for (int g = g_begin; g < g_end; ++g) {
       float4 b[NT];
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt) b[nt] = wp[((size_t)g * NT + nt) * 64];
+      for (int nt = 0; nt < NT; ++nt) b[nt] = bn[nt];
+      if (g + 1 < g_end) {  // prefetch the next group's weight fragments behind this group's MFMAs
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) bn[nt] = wp[((size_t)(g + 1) * NT + nt) * 64];
+      }
       const int q0 = g * 4;
 #pragma unroll
       for (int c = 0; c < RC; ++c) {
@@ -340,7 +346,8 @@ __global__ __launch_bounds__(256, 2) void k_conv(ConvArgs a) {
 template <int RC, int KSUB>
 static size_t conv_lds_bytes(int S) {
   using L = ConvLds<RC, KSUB>;
-  return sizeof(float) * (size_t)(((RC * L::A_PLANE + 3) & ~3) + 32 * S * 4 + 32 * S * L::HST + 4 * JAMUN_MAX_BATCH);
+  const int S4 = (S + 3) & ~3;
+  return sizeof(float) * (size_t)(((RC * L::A_PLANE + 3) & ~3) + 32 * S4 * 4 + 32 * S4 * L::HST + 4 * JAMUN_MAX_BATCH);
 }
 
 int launch_conv(const ConvArgs& a, int rc, int nt, hipStream_t st) {

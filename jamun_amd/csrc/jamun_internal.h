@@ -26,7 +26,7 @@ struct ConvArgs {
   const float4* egeo;
   const float* h;  // [n_atoms*S][JAMUN_HS]
   const float* x;  // [n_atoms][XS]
-  int n_atoms, n_pad, n_tiles, S, XS;
+  int n_atoms, n_pad, n_tiles, S, S4, XS;  // S4 = S rounded up to a multiple of 4 (edge batches)
   // problem
   const float4* wpack;   // 16-byte weight fragments: 4 consecutive K-steps of one lane
   const int4* chunks;    // {ublk, k0 | ks << 16, first weight group, number of weight groups (of 4 K-steps)}
