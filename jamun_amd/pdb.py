@@ -1,0 +1,176 @@
+"""PDB -> walker graph without mdtraj.
+
+Restates what the sampling path needs of ``/root/reference/src/jamun/data/_mdtraj.py:56-89,169-256`` and
+``data/_utils.py:217-237``: select "protein and not type H", encode atom type / atom name / residue name
+(``utils/residue_metadata.py:62-83``), residue sequence index, and the bonded edges (each bond once, lower atom index
+first, as mdtraj's ``Topology.add_bond`` orders them): standard-residue templates + peptide bonds + CONECT records
+between selected atoms.  Coordinates are converted from Angstrom to nanometres (mdtraj convention).
+"""
+
+from __future__ import annotations
+
+import os
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+
+from .data import encode_atom_code, encode_atom_type, encode_residue
+
+_BACKBONE = [("N", "CA"), ("CA", "C"), ("C", "O"), ("C", "OXT"), ("CA", "CB")]
+_SIDECHAIN: Dict[str, List[Tuple[str, str]]] = {
+    "ALA": [], "GLY": [],
+    "ARG": [("CB", "CG"), ("CG", "CD"), ("CD", "NE"), ("NE", "CZ"), ("CZ", "NH1"), ("CZ", "NH2")],
+    "ASN": [("CB", "CG"), ("CG", "OD1"), ("CG", "ND2")],
+    "ASP": [("CB", "CG"), ("CG", "OD1"), ("CG", "OD2")],
+    "CYS": [("CB", "SG")],
+    "GLN": [("CB", "CG"), ("CG", "CD"), ("CD", "OE1"), ("CD", "NE2")],
+    "GLU": [("CB", "CG"), ("CG", "CD"), ("CD", "OE1"), ("CD", "OE2")],
+    "HIS": [("CB", "CG"), ("CG", "ND1"), ("CG", "CD2"), ("ND1", "CE1"), ("CD2", "NE2"), ("CE1", "NE2")],
+    "ILE": [("CB", "CG1"), ("CB", "CG2"), ("CG1", "CD1")],
+    "LEU": [("CB", "CG"), ("CG", "CD1"), ("CG", "CD2")],
+    "LYS": [("CB", "CG"), ("CG", "CD"), ("CD", "CE"), ("CE", "NZ")],
+    "MET": [("CB", "CG"), ("CG", "SD"), ("SD", "CE")],
+    "PHE": [("CB", "CG"), ("CG", "CD1"), ("CG", "CD2"), ("CD1", "CE1"), ("CD2", "CE2"), ("CE1", "CZ"), ("CE2", "CZ")],
+    "PRO": [("CB", "CG"), ("CG", "CD"), ("CD", "N")],
+    "SER": [("CB", "OG")],
+    "THR": [("CB", "OG1"), ("CB", "CG2")],
+    "TRP": [("CB", "CG"), ("CG", "CD1"), ("CG", "CD2"), ("CD1", "NE1"), ("NE1", "CE2"), ("CD2", "CE2"), ("CD2", "CE3"),
+            ("CE2", "CZ2"), ("CE3", "CZ3"), ("CZ2", "CH2"), ("CZ3", "CH2")],
+    "TYR": [("CB", "CG"), ("CG", "CD1"), ("CG", "CD2"), ("CD1", "CE1"), ("CD2", "CE2"), ("CE1", "CZ"), ("CE2", "CZ"), ("CZ", "OH")],
+    "VAL": [("CB", "CG1"), ("CB", "CG2")],
+}  # fmt: skip
+_ALIASES = {"HID": "HIS", "HIE": "HIS", "HIP": "HIS", "HSD": "HIS", "HSE": "HIS", "CYX": "CYS", "CYM": "CYS", "ASH": "ASP", "GLH": "GLU", "LYN": "LYS"}
+_CAPS = {"ACE": [("CH3", "C"), ("C", "O")], "NME": [("N", "CH3"), ("N", "C")], "NMA": [("N", "CH3")], "NH2": []}
+PROTEIN_RESIDUES = set(_SIDECHAIN) | set(_ALIASES) | set(_CAPS)
+
+
+def _element(line: str, name: str) -> str:
+    el = line[76:78].strip() if len(line) >= 78 else ""
+    if el:
+        return el.capitalize()
+    n = name.lstrip("0123456789")
+    return n[:1].upper() if n else "X"
+
+
+def read_pdb(path: str) -> dict:
+    """First model of a PDB file -> molecule dict (heavy protein atoms only)."""
+    atoms = []  # (serial, name, resname, chain, resseq+icode, x, y, z, element)
+    conect: List[Tuple[int, int]] = []
+    with open(path) as f:
+        for line in f:
+            rec = line[:6]
+            if rec in ("ATOM  ", "HETATM"):
+                name = line[12:16].strip()
+                resname = line[17:20].strip()
+                if resname not in PROTEIN_RESIDUES:
+                    continue
+                el = _element(line, name)
+                if el == "H" or el == "D":
+                    continue
+                atoms.append((int(line[6:11]), name, resname, line[21], line[22:27], float(line[30:38]), float(line[38:46]), float(line[46:54]), el))
+            elif rec == "CONECT":
+                f0 = line[6:].split()
+                if len(f0) >= 2:
+                    a0 = int(f0[0])
+                    conect += [(a0, int(b)) for b in f0[1:]]
+            elif rec == "ENDMDL":
+                break
+    if not atoms:
+        raise ValueError(f"{path}: no protein heavy atoms found")
+    # residues in file order
+    res_keys: List[Tuple[str, str]] = []
+    res_of_atom = []
+    for a in atoms:
+        key = (a[3], a[4])
+        if not res_keys or res_keys[-1] != key:
+            res_keys.append(key)
+        res_of_atom.append(len(res_keys) - 1)
+    n = len(atoms)
+    by_res: Dict[int, Dict[str, int]] = {}
+    for i, a in enumerate(atoms):
+        by_res.setdefault(res_of_atom[i], {})[a[1]] = i
+    bonds: List[Tuple[int, int]] = []
+    seen = set()
+
+    def add(i: Optional[int], j: Optional[int]):
+        if i is None or j is None or i == j:
+            return
+        b = (min(i, j), max(i, j))  # mdtraj Topology.add_bond: lower index first
+        if b not in seen:
+            seen.add(b)
+            bonds.append(b)
+
+    for r in range(len(res_keys)):
+        names = by_res[r]
+        resname = atoms[next(iter(names.values()))][2]
+        if r > 0 and res_keys[r][0] == res_keys[r - 1][0]:
+            add(by_res[r - 1].get("C"), names.get("N"))  # peptide bond
+        base = _ALIASES.get(resname, resname)
+        templ = _CAPS[base] if base in _CAPS else _BACKBONE + _SIDECHAIN[base]
+        for a, b in templ:
+            add(names.get(a), names.get(b))
+    serial_to_idx = {a[0]: i for i, a in enumerate(atoms)}
+    for s0, s1 in conect:
+        add(serial_to_idx.get(s0), serial_to_idx.get(s1))
+    pos = torch.tensor([[a[5], a[6], a[7]] for a in atoms], dtype=torch.float32) / 10.0
+    return dict(
+        pos=pos,
+        atom_type_index=torch.tensor([encode_atom_type(a[8]) for a in atoms], dtype=torch.int32),
+        atom_code_index=torch.tensor([encode_atom_code(a[1]) for a in atoms], dtype=torch.int32),
+        residue_code_index=torch.tensor([encode_residue(a[2]) for a in atoms], dtype=torch.int32),
+        residue_sequence_index=torch.tensor(res_of_atom, dtype=torch.int32),
+        bonds=torch.tensor(bonds, dtype=torch.long).reshape(-1, 2).T.contiguous(),
+        atom_names=[a[1] for a in atoms],
+        residues=[a[2] for a in atoms],
+        elements=[a[8] for a in atoms],
+        residue_ids=[int(a[4][:4]) for a in atoms],
+    )
+
+
+def write_pdb(path: str, mol: dict, frames: torch.Tensor) -> None:
+    """Multi-model PDB in Angstrom; columns as ``/root/reference/src/jamun/utils/mdtraj.py:26-60``.  ``frames`` is ``[T, n, 3]`` nm."""
+    frames = frames.detach().cpu().float() * 10.0
+    with open(path, "w") as f:
+        for t in range(frames.shape[0]):
+            f.write(f"MODEL     {t + 1:4d}\n")
+            for i in range(frames.shape[1]):
+                name = mol["atom_names"][i]
+                name_f = f" {name:<3s}" if len(name) < 4 else name[:4]
+                x, y, z = frames[t, i].tolist()
+                f.write(f"ATOM  {i + 1:5d} {name_f} {mol['residues'][i]:>3s} A{mol['residue_ids'][i]:4d}    {x:8.3f}{y:8.3f}{z:8.3f}  1.00  0.00          {mol['elements'][i]:>2s}\n")
+            f.write("ENDMDL\n")
+        f.write("END\n")
+
+
+class PDBDataset:
+    """Single-structure dataset: what ``MDtrajDataset(root, trajfiles=[pdb], pdbfile=pdb, label)`` provides the sampler."""
+
+    def __init__(self, root: str, pdbfile: str, label: str):
+        self.root, self.pdbfile, self._label = root, pdbfile, label
+        self.molecule = read_pdb(os.path.join(root, pdbfile))
+        self.molecule["dataset_label"] = label
+
+    def label(self) -> str:
+        return self._label
+
+    def __len__(self) -> int:
+        return 1
+
+    def __getitem__(self, idx: int) -> dict:
+        if idx not in (0, -1):
+            raise IndexError(idx)
+        return self.molecule
+
+
+def create_dataset_from_pdbs(pdbfiles: Sequence[str], label_prefix: Optional[str] = None) -> List[PDBDataset]:
+    """``jamun.data.create_dataset_from_pdbs`` (``data/_utils.py:217-237``): one dataset per file, label = file stem."""
+    if isinstance(pdbfiles, str):
+        pdbfiles = [pdbfiles]
+    out = []
+    for p in pdbfiles:
+        p = os.path.abspath(p)
+        label = os.path.basename(p).split(".")[0]
+        if label_prefix is not None:
+            label = f"{label_prefix}{label}"
+        out.append(PDBDataset(os.path.dirname(p), os.path.basename(p), label))
+    return out

@@ -1,0 +1,203 @@
+"""CPU tests of the host-side logic: config composition, PDB reader, checkpoint lookup, sharding and the N>1 gather
+(world_size-2 gloo processes)."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_pdb_round_trip_matches_hand_built_ag_dipeptide(tmp_path):
+    from jamun_amd import pdb, synth
+
+    mol = synth.ag_dipeptide()
+    mol = dict(mol, elements=["N", "C", "C", "C", "O", "N", "C", "C", "O", "O"], residue_ids=[1] * 5 + [2] * 5)
+    path = str(tmp_path / "uncapped_AG.pdb")
+    pdb.write_pdb(path, mol, mol["pos"][None])
+    # add hydrogens and a water that must be dropped ("protein and not type H", data/_mdtraj.py:60)
+    lines = open(path).read().splitlines()
+    extra = ["ATOM     11  H1  ALA A   1       0.500   0.900   0.100  1.00  0.00           H",
+             "HETATM   12  O   HOH B   3       9.000   9.000   9.000  1.00  0.00           O"]
+    lines = lines[:-2] + extra + lines[-2:]
+    open(path, "w").write("\n".join(lines) + "\n")
+    got = pdb.read_pdb(path)
+    for k in ("atom_type_index", "atom_code_index", "residue_code_index", "residue_sequence_index"):
+        assert torch.equal(got[k], mol[k]), k
+    assert torch.allclose(got["pos"], mol["pos"], atol=1e-4)
+    want = {tuple(b) for b in mol["bonds"].T.tolist()}
+    have = {tuple(b) for b in got["bonds"].T.tolist()}
+    assert want == have and got["bonds"].shape[1] == 9
+    assert all(a < b for a, b in got["bonds"].T.tolist())  # lower index first, each bond once
+    ds = pdb.create_dataset_from_pdbs([path])
+    assert ds[0].label() == "uncapped_AG" and len(ds[0]) == 1
+
+
+def test_config_composition_builtin_and_reference_style_overlay(tmp_path):
+    from jamun_amd import cmdline
+    from jamun_amd import config as C
+
+    cfg = cmdline.compose(["--config-dir=" + os.path.join(ROOT, "configs"), "experiment=sample_custom", "++init_pdbs=[a.pdb]", "++checkpoint_dir=ck",
+                           "num_sampling_steps_per_batch=50", "repeat_init_samples=4", "++trainer.accelerator=gpu"], cwd=str(tmp_path))
+    r = C.resolve(cfg)
+    assert r["batch_sampler"]["mcmc"]["steps"] == 50 and r["batch_sampler"]["sigma"] == 0.04
+    assert r["batch_sampler"]["mcmc"]["_target_"] == "jamun.sampling.mcmc.BAOAB"
+    assert r["init_pdbs"] == [str(tmp_path / "a.pdb")] and r["checkpoint_dir"] == str(tmp_path / "ck")
+    assert r["repeat_init_samples"] == 4 and r["sampler"]["devices"] == 1 and r["trainer"]["accelerator"] == "gpu"
+    assert r["paths"]["run_path"].startswith("./outputs/sample/dev/runs/")
+    # an overlay in the reference's style: unknown keys, ??? values, group override by command line
+    d = tmp_path / "cfgs" / "experiment"
+    d.mkdir(parents=True)
+    (d / "mine.yaml").write_text("# @package _global_\nsigma: 0.1\ndelta: ${sigma}\nfriction: 1.0\nM: 1.0\ninverse_temperature: 1.0\nscore_fn_clip: null\n"
+                                 "num_sampling_steps_per_batch: 7\nnum_init_samples_per_dataset: 1\ninit_pdbs: ???\ncheckpoint_dir: x\n"
+                                 "wandb_train_run_path: some/run\ninit_datasets:\n  _target_: jamun.data.create_dataset_from_pdbs\n  pdbfiles: ${init_pdbs}\n")
+    cfg = cmdline.compose(["--config-dir", str(tmp_path / "cfgs"), "experiment=mine", "batch_sampler/mcmc=aboba", "wandb_train_run_path=null"], cwd=str(tmp_path))
+    with pytest.raises(ValueError, match="Missing mandatory value"):
+        C.resolve(cfg)
+    cfg["init_pdbs"] = ["/x/y.pdb"]
+    r = C.resolve(cfg)
+    assert r["batch_sampler"]["mcmc"]["_target_"] == "jamun.sampling.mcmc.ABOBA" and r["batch_sampler"]["mcmc"]["delta"] == 0.1
+    assert r["batch_sampler"]["mcmc"]["score_fn_clip"] is None and r["wandb_train_run_path"] is None
+    with pytest.raises(KeyError):
+        cmdline.compose(["no_such_key=1"], cwd=str(tmp_path))
+
+
+def test_instantiate_maps_reference_targets():
+    from jamun_amd import config as C
+    from jamun_amd.sampling import BAOAB, SingleMeasurementSampler
+
+    bs = C.instantiate({"_target_": "jamun.sampling.walkjump.SingleMeasurementSampler", "sigma": 0.04,
+                        "mcmc": {"_target_": "jamun.sampling.mcmc.BAOAB", "steps": 5, "delta": 0.04, "v_init": "zero"}})
+    assert isinstance(bs, SingleMeasurementSampler) and isinstance(bs.mcmc, BAOAB) and bs.mcmc.steps == 5
+    with pytest.raises(RuntimeError, match="not in"):
+        BAOAB(v_init="nope")
+    p = C.instantiate({"_target_": "jamun.sampling.mcmc.BAOAB", "_partial_": True, "steps": 3})
+    assert p().steps == 3
+
+
+def test_find_checkpoint_rules(tmp_path):
+    from jamun_amd.checkpoint import find_checkpoint
+
+    for f in ["epoch=3-step=10.ckpt", "epoch=12-step=99.ckpt", "last.ckpt"]:
+        (tmp_path / f).write_bytes(b"")
+    d = str(tmp_path)
+    assert find_checkpoint(checkpoint_dir=d, checkpoint_type="last").endswith("last.ckpt")
+    assert find_checkpoint(checkpoint_dir=d, checkpoint_type="best_so_far").endswith("epoch=12-step=99.ckpt")
+    assert find_checkpoint(checkpoint_dir=d, checkpoint_type="epoch=3-step=10.ckpt").endswith("epoch=3-step=10.ckpt")
+    with pytest.raises(ValueError):
+        find_checkpoint(wandb_train_run_path="a/b/c", checkpoint_dir=d, checkpoint_type="last")
+    with pytest.raises(ValueError):
+        find_checkpoint()
+    with pytest.raises(ValueError):
+        find_checkpoint(checkpoint_dir=d, checkpoint_type="bogus")
+
+
+def test_checkpoint_file_round_trip_with_compile_prefix(tmp_path):
+    """Lightning-shaped .ckpt with the torch.compile'd 'g._orig_mod.' prefix and a functools.partial arch."""
+    import functools
+
+    from jamun_amd import synth
+    from jamun_amd.checkpoint import load_checkpoint_file
+    from jamun_amd.model import _kw, strip_prefix
+
+    ck = synth.synthetic_checkpoint(prefix="g._orig_mod.")
+    ck["hyper_parameters"]["arch"] = functools.partial(dict, **ck["hyper_parameters"]["arch"])
+    ck["state_dict"]["g._orig_mod.layers.0.gated_conv.f.gate.gate.mul.output_mask"] = torch.ones(3)  # e3nn bookkeeping buffer
+    path = str(tmp_path / "last.ckpt")
+    torch.save(ck, path)
+    back = load_checkpoint_file(path)
+    sd = strip_prefix(back["state_dict"])
+    assert "layers.0.gated_conv.f.f.radial_nn.3.weight" in sd and sd["output_gain"].ndim == 0
+    assert _kw(back["hyper_parameters"]["arch"])["n_layers"] == 5
+
+
+def test_walker_batch_collation_and_slicing():
+    from jamun_amd import synth
+    from jamun_amd.data import WalkerBatch
+
+    mols = [synth.random_chain(n, seed=s) for s, n in enumerate([5, 9, 3, 7])]
+    b = WalkerBatch.from_molecules(mols, labels=list("abcd"))
+    assert b.ptr.tolist() == [0, 5, 14, 17, 24] and b.num_graphs == 4
+    assert torch.equal(b.batch, torch.repeat_interleave(torch.arange(4), torch.tensor([5, 9, 3, 7])))
+    # bonds offset by the cumulative atom count (data_with_residue_info.py:27-28)
+    assert b.bonds[:, 4:12].min() >= 5 and b.bonds[:, 4:12].max() < 14
+    s = b.slice_graphs(1, 3)
+    assert s.ptr.tolist() == [0, 9, 12] and s.dataset_label == ["b", "c"]
+    assert torch.equal(s.pos, b.pos[5:17]) and s.bonds.min() >= 0 and s.bonds.max() < 12
+    assert s.bonds.shape[1] == 8 + 2
+    with pytest.raises(AssertionError):
+        b.with_pos(torch.zeros(3, 3))
+
+
+def test_shard_ranges_cover_everything():
+    from jamun_amd import dist
+
+    for n, w in [(2048, 8), (7, 8), (10, 3), (1, 1), (0, 4)]:
+        parts = [dist.shard_range(n, r, w) for r in range(w)]
+        assert parts[0][0] == 0 and parts[-1][1] == n
+        assert all(parts[i][1] == parts[i + 1][0] for i in range(w - 1))
+    costs = [17 * 16] * 10 + [57 * 32] * 3 + [9 * 8] * 20
+    parts = [dist.shard_range_balanced(costs, r, 4) for r in range(4)]
+    assert parts[0][0] == 0 and parts[-1][1] == len(costs) and all(parts[i][1] == parts[i + 1][0] for i in range(3))
+    loads = [sum(costs[a:b]) for a, b in parts]
+    assert max(loads) <= sum(costs) / 4 + max(costs)  # a contiguous split cannot do better than one item of slack
+
+
+_WORKER = r'''
+import os, sys, json
+sys.path.insert(0, sys.argv[1])
+import numpy as np, torch
+from jamun_amd import dist, synth
+from jamun_amd.callbacks import SaveTrajectoryCallback
+from jamun_amd.data import WalkerBatch
+rank, world = dist.init_process_group("gloo")
+assert world == 2
+# ragged gather: rank r contributes r+2 rows
+blk = torch.full((rank + 2, 3, 2), float(rank))
+got = dist.gather_ragged(blk, dst=0)
+if rank == 0:
+    assert [g.shape[0] for g in got] == [2, 3] and float(got[1].mean()) == 1.0
+else:
+    assert got is None
+# walker sharding + trajectory gather through the callback: 5 walkers of one molecule -> ranks get 3 and 2
+mol = synth.random_chain(6, seed=0)
+class DS:
+    molecule = dict(mol)
+    def label(self): return "m"
+batch = WalkerBatch.from_molecules([mol] * 5, labels=["m"] * 5)
+lo, hi = dist.shard_range(batch.num_graphs, rank, world)
+local = batch.slice_graphs(lo, hi)
+class FakeSampler:
+    device = torch.device("cpu"); is_global_zero = rank == 0; world_size = world; global_step = 0
+cb = SaveTrajectoryCallback([DS()], output_dir=os.path.join(sys.argv[2], "sampler"), write_pdb=False)
+samples = [{"dataset_label": "m", "xhat_traj": torch.full((6, 4, 3), float(lo + w))} for w in range(local.num_graphs)]
+cb.on_after_sample_batch(samples, FakeSampler())
+cb.on_after_sample_batch(samples, FakeSampler())
+dist.barrier()
+if rank == 0:
+    d = os.path.join(sys.argv[2], "sampler", "m", "predicted_samples", "npy")
+    j = np.load(os.path.join(d, "joined.npy"))
+    assert j.shape == (6, 10 * 4, 3), j.shape
+    firsts = [float(np.load(os.path.join(d, f"{i}.npy"))[0, 0, 0]) for i in range(10)]
+    assert firsts == [0, 1, 2, 3, 4, 0, 1, 2, 3, 4], firsts
+torch.manual_seed(42 + rank)
+print(json.dumps({"rank": rank, "draw": float(torch.randn(1))}))
+torch.distributed.destroy_process_group()
+'''
+
+
+def test_two_process_gloo_gather_and_sharding(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", WORLD_SIZE="2")
+    procs = [subprocess.Popen([sys.executable, str(script), ROOT, str(tmp_path)], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)),
+                              stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=180) for p in procs]
+    for p, (o, e) in zip(procs, outs):
+        assert p.returncode == 0, e[-2000:]
+    draws = [json.loads(o.strip().splitlines()[-1])["draw"] for o, _ in outs]
+    assert draws[0] != draws[1]  # seed + rank: ranks generate different chains
