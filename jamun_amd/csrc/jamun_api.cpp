@@ -6,6 +6,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <cstdlib>
 #include <map>
 #include <memory>
 #include <stdexcept>
@@ -95,13 +96,24 @@ struct ConvProblemDev {
   int planes = 0, nt = 0, xw = 0;
   int64_t K = 0;  // padded contraction depth
 };
+struct FusedDev {
+  float4* wpack = nullptr;
+  int4* units = nullptr;
+  int* wave_units = nullptr;
+  int* slice_k = nullptr;
+  int k_stride = 0, max_units = 0, n_units = 0, nt0 = 0;
+  int64_t mfma_per_k = 0;  // MFMA instructions per hidden unit k and tile (forming + main), for FLOP bookkeeping
+};
 struct LayerDev {
   ConvProblemDev p0, p1;
+  FusedDev fu;
   float *w1r = nullptr, *cmask = nullptr;
   float *w_self0 = nullptr, *w_self1 = nullptr, *w_skip0 = nullptr, *w_skip1 = nullptr, *mix = nullptr;
   int in0 = 0, in1 = 0, XSin = 0;
   int64_t tp_numel = 0;
 };
+
+void free_fused(FusedDev& f) { hipFree(f.wpack); hipFree(f.units); hipFree(f.wave_units); hipFree(f.slice_k); }
 
 void free_problem(ConvProblemDev& p) {
   hipFree(p.wpack); hipFree(p.chunks); hipFree(p.slice_ptr); hipFree(p.ublk); hipFree(p.lane_xoff);
@@ -245,6 +257,8 @@ struct jamun_sampler {
   // static device data
   int *ptr = nullptr, *bond_in_ptr = nullptr, *bond_in_src = nullptr;
   int n_tiles = 0;
+  int2* tile_span = nullptr;
+  int span_max = 0, fused_J = 0;  // fused_J > 0: the fused MFMA-forming conv kernel is used (small molecules)
   float *x_emb = nullptr, *mu = nullptr;
   std::vector<LayerDev> layers;
   float *w_gate = nullptr, *w_vec = nullptr, *w_out = nullptr;
@@ -263,9 +277,9 @@ struct jamun_sampler {
   size_t ev_next = 0;
 
   ~jamun_sampler() {
-    hipFree(ptr); hipFree(bond_in_ptr); hipFree(bond_in_src); hipFree(x_emb); hipFree(mu);
+    hipFree(ptr); hipFree(bond_in_ptr); hipFree(bond_in_src); hipFree(x_emb); hipFree(mu); hipFree(tile_span);
     for (auto& L : layers) {
-      free_problem(L.p0); free_problem(L.p1);
+      free_problem(L.p0); free_problem(L.p1); free_fused(L.fu);
       hipFree(L.w1r); hipFree(L.cmask); hipFree(L.w_self0); hipFree(L.w_self1); hipFree(L.w_skip0);
       hipFree(L.w_skip1); hipFree(L.mix);
     }
@@ -281,7 +295,7 @@ struct jamun_sampler {
 namespace {
 
 LayerDev build_layer(const jamun_model& m, const std::string& prefix, const std::vector<InBlock>& in_blocks,
-                     const std::vector<double>& s_in, int n_slices) {
+                     const std::vector<double>& s_in, int n_slices, int fused_J) {
   const jamun_hparams& hp = m.hp;
   const int mul0 = hp.mul0, mul1 = hp.mul1, G0 = mul0 + mul1, G1 = mul1, H = hp.edge_attr_dim;
   LayerDev L;
@@ -351,6 +365,111 @@ LayerDev build_layer(const jamun_model& m, const std::string& prefix, const std:
   }
   L.p0 = pack_problem(blocks0, 1, G0, n_slices, JAMUN_KSUB0, W3, b3, H);
   L.p1 = pack_problem(blocks1, 3, G1, n_slices, JAMUN_KSUB1, W3, b3, H);
+
+  // ---- fused kernel (jamun_conv_fused.hip): units, wave assignment, weights in accumulator-register K order
+  if (fused_J > 0 && G1 <= 32 && G1 > 0) {
+    struct FUnit { int n_terms, out, nt; int term[3]; std::vector<const UEntry*> ue; int u_count; };
+    auto term = [](int xcol0, int stride, int ctype, bool neg) { return xcol0 | (stride << 12) | (ctype << 16) | ((neg ? 1 : 0) << 20); };
+    std::vector<FUnit> fus;
+    const int NT0 = (G0 + 31) / 32;
+    // scalar-row units
+    for (size_t i = 0; i < x0e.size(); i += 32) {
+      FUnit u{1, 0, NT0, {term(x0e[i].xoff, 1, 0, false), 0, 0}, {}, 0};
+      for (size_t j = i; j < std::min(x0e.size(), i + 32); ++j) u.ue.push_back(&x0e[j]);
+      fus.push_back(u);
+    }
+    for (size_t i = 0; i < dote.size(); i += 32) {
+      FUnit u{3, 0, NT0, {term(dote[i].xoff + 0, 3, 1, false), term(dote[i].xoff + 1, 3, 2, false), term(dote[i].xoff + 2, 3, 3, false)}, {}, 0};
+      for (size_t j = i; j < std::min(dote.size(), i + 32); ++j) u.ue.push_back(&dote[j]);
+      fus.push_back(u);
+    }
+    // vector-row units, one per output plane m
+    for (int mm = 0; mm < 3; ++mm) {
+      for (size_t i = 0; i < x0ve.size(); i += 32) {
+        FUnit u{1, 1 + mm, 1, {term(x0ve[i].xoff, 1, 1 + mm, false), 0, 0}, {}, 0};
+        for (size_t j = i; j < std::min(x0ve.size(), i + 32); ++j) u.ue.push_back(&x0ve[j]);
+        fus.push_back(u);
+      }
+      for (size_t i = 0; i < x1e.size(); i += 32) {
+        FUnit u{1, 1 + mm, 1, {term(x1e[i].xoff + mm, 3, 0, false), 0, 0}, {}, 0};
+        for (size_t j = i; j < std::min(x1e.size(), i + 32); ++j) u.ue.push_back(&x1e[j]);
+        fus.push_back(u);
+      }
+      for (size_t i = 0; i < crosse.size(); i += 32) {
+        // (x1 x vhat)[m] = x1[m+1] vhat[m+2] - x1[m+2] vhat[m+1]
+        const int m1 = (mm + 1) % 3, m2 = (mm + 2) % 3;
+        FUnit u{2, 1 + mm, 1, {term(crosse[i].xoff + m1, 3, 1 + m2, false), term(crosse[i].xoff + m2, 3, 1 + m1, true), 0}, {}, 0};
+        for (size_t j = i; j < std::min(crosse.size(), i + 32); ++j) u.ue.push_back(&crosse[j]);
+        fus.push_back(u);
+      }
+    }
+    FusedDev& F = L.fu;
+    F.n_units = (int)fus.size();
+    F.nt0 = NT0;
+    std::vector<int4> ud(2 * fus.size());
+    int blocks = 0;  // (qg, nt) blocks of 64 float4 per k
+    std::vector<int> wofs(fus.size());
+    for (size_t i = 0; i < fus.size(); ++i) {
+      wofs[i] = blocks;
+      ud[2 * i] = make_int4(fus[i].n_terms, fus[i].out, blocks, 0);
+      ud[2 * i + 1] = make_int4(fus[i].term[0], fus[i].term[1], fus[i].term[2], 0);
+      blocks += 4 * fus[i].nt;
+    }
+    F.k_stride = blocks * 64;
+    const int n_k = H + 1;
+    std::vector<float4> wp((size_t)n_k * F.k_stride, make_float4(0.f, 0.f, 0.f, 0.f));
+    for (int k = 0; k < n_k; ++k)
+      for (size_t i = 0; i < fus.size(); ++i) {
+        const FUnit& u = fus[i];
+        const int Gout = u.out == 0 ? G0 : G1;
+        for (int qg = 0; qg < 4; ++qg)
+          for (int nt = 0; nt < u.nt; ++nt)
+            for (int lane = 0; lane < 64; ++lane) {
+              const int hh = lane >> 5, c = lane & 31, col = nt * 32 + c;
+              float v[4] = {0.f, 0.f, 0.f, 0.f};
+              for (int st = 0; st < 4; ++st) {
+                const int q = 4 * qg + st;
+                const int ul = (q & 3) + 8 * (q >> 2) + 4 * hh;  // accumulator row of register q in lane half hh
+                if (ul >= (int)u.ue.size() || col >= Gout) continue;
+                const UEntry& e = *u.ue[ul];
+                const int64_t p = e.wbase + col;
+                const double w = (k < H) ? (double)W3[(size_t)p * H + k] : (double)b3[p];
+                v[st] = (float)(w * e.scale);
+              }
+              wp[(size_t)k * F.k_stride + ((size_t)(wofs[i] + qg * u.nt + nt)) * 64 + lane] = make_float4(v[0], v[1], v[2], v[3]);
+            }
+      }
+    // static wave assignment: longest-processing-time greedy on the MFMA count of a unit
+    std::vector<int> order(fus.size()), cost(fus.size());
+    int64_t total_cost = 0;
+    for (size_t i = 0; i < fus.size(); ++i) {
+      order[i] = (int)i;
+      cost[i] = fus[i].n_terms * (fused_J / 2) + 16 * fus[i].nt;
+      total_cost += cost[i];
+    }
+    F.mfma_per_k = total_cost;
+    std::stable_sort(order.begin(), order.end(), [&](int a1, int b1) { return cost[a1] > cost[b1]; });
+    std::vector<std::vector<int>> per_wave(8);
+    std::vector<int64_t> load(8, 0);
+    for (int i : order) {
+      int w = 0;
+      for (int c = 1; c < 8; ++c)
+        if (load[c] < load[w]) w = c;
+      per_wave[w].push_back(i);
+      load[w] += cost[i];
+    }
+    F.max_units = 1;
+    for (auto& v : per_wave) F.max_units = std::max(F.max_units, (int)v.size() + 1);
+    std::vector<int> wu((size_t)8 * F.max_units, -1);
+    for (int w = 0; w < 8; ++w)
+      for (size_t i = 0; i < per_wave[w].size(); ++i) wu[(size_t)w * F.max_units + i] = per_wave[w][i];
+    std::vector<int> sk(n_slices + 1);
+    for (int sl = 0; sl <= n_slices; ++sl) sk[sl] = (int)(((int64_t)n_k * sl) / n_slices);
+    F.wpack = dev_upload(wp);
+    F.units = dev_upload(ud);
+    F.wave_units = dev_upload(wu);
+    F.slice_k = dev_upload(sk);
+  }
 
   // ---- radial MLP first layer: split into the constant bonded part and the radial part
   const auto& W1 = m.get(prefix + ".gated_conv.f.f.radial_nn.0.weight", (int64_t)H * H);
@@ -436,6 +555,18 @@ void forward(jamun_sampler* s, const float* y, float* xhat, float* score, hipStr
       ProfScope ps(s, JAMUN_PROF_EDGE_H, st);
       launch_edge_h(s->deg, s->esrc, s->egeo, s->n_atoms, s->S, L.w1r, L.cmask, s->mu, s->rb_step, s->h, st);
     }
+    if (L.fu.wpack) {
+      FusedArgs f{};
+      f.deg = s->deg; f.esrc = s->esrc; f.egeo = s->egeo; f.h = s->h; f.x = x_in;
+      f.n_atoms = s->n_atoms; f.n_pad = s->n_pad; f.n_tiles = s->n_tiles; f.S = s->S; f.S4 = (s->S + 3) & ~3;
+      f.XS = XSin; f.XR = XSin; f.J = s->fused_J; f.tile_span = s->tile_span;
+      f.wpack = L.fu.wpack; f.units = L.fu.units; f.wave_units = L.fu.wave_units; f.slice_k = L.fu.slice_k;
+      f.partial0 = s->partial0; f.partial1 = s->partial1;
+      f.k_stride = L.fu.k_stride; f.max_units = L.fu.max_units; f.n_slices = s->n_slices;
+      ProfScope ps(s, l == 0 ? JAMUN_PROF_CONV0_INIT : JAMUN_PROF_CONV0, st);
+      const int rcode = launch_conv_fused(f, L.fu.nt0, st);
+      if (rcode != 0) throw Err(JAMUN_ERR_INVALID, "fused conv launch failed (configuration not supported)");
+    } else {
     ConvArgs a{};
     a.deg = s->deg; a.esrc = s->esrc; a.egeo = s->egeo; a.h = s->h; a.x = x_in;
     a.n_atoms = s->n_atoms; a.n_pad = s->n_pad; a.n_tiles = s->n_tiles; a.S = s->S; a.S4 = (s->S + 3) & ~3; a.XS = XSin;
@@ -449,6 +580,7 @@ void forward(jamun_sampler* s, const float* y, float* xhat, float* score, hipStr
       const int rcode = launch_conv(a, P.planes, P.nt, st);
       if (rcode == -2) throw Err(JAMUN_ERR_INVALID, "walker batch needs more than 160 KiB of LDS per conv workgroup (edge stride too large)");
       if (rcode != 0) throw Err(JAMUN_ERR_INVALID, "unsupported conv tile configuration");
+    }
     }
     NodeArgs n{};
     n.partial0 = s->partial0; n.partial1 = s->partial1; n.deg = s->deg; n.x_in = x_in; n.x_out = s->x[l];
@@ -582,7 +714,32 @@ int jamun_sampler_create(const jamun_model* m, float sigma, const jamun_topology
     s->S = std::min(std::max(nmax - 1, 0), JAMUN_MAX_NEIGHBORS + 1) + max_in;
     if (s->S < 1) s->S = 1;
     s->n_tiles = s->n_pad / 32;
-    if (conv_set_max_lds() != 0) throw Err(JAMUN_ERR_HIP, "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed");
+    if (conv_set_max_lds() != 0 || conv_fused_set_max_lds() != 0)
+      throw Err(JAMUN_ERR_HIP, "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed");
+    {
+      std::vector<int2> spans(s->n_tiles);
+      for (int t = 0; t < s->n_tiles; ++t) {
+        const int a0 = t * 32, a1 = std::min(t * 32 + 31, N - 1);
+        spans[t] = make_int2(topo->ptr[graph_of[a0]], topo->ptr[graph_of[a1] + 1]);
+        s->span_max = std::max(s->span_max, spans[t].y - spans[t].x);
+      }
+      s->tile_span = dev_upload(spans);
+      // fused kernel: every tile must see <= 64 source atoms, <= 64 edge slots per atom, one bonded edge per ordered pair
+      bool dup = false;
+      {
+        std::vector<std::pair<int64_t, int64_t>> bb;
+        for (int b = 0; b < topo->n_bonds; ++b) bb.push_back({topo->bond_src[b], topo->bond_dst[b]});
+        std::sort(bb.begin(), bb.end());
+        dup = std::adjacent_find(bb.begin(), bb.end()) != bb.end();
+      }
+      const int J = (s->span_max + 1) & ~1;
+      const int S4 = (s->S + 3) & ~3;
+      const int nt0 = (hp.mul0 + hp.mul1 + 31) / 32;
+      const bool no_fused = getenv("JAMUN_NO_FUSED") != nullptr;  // debugging / A-B aid
+      if (!no_fused && !dup && J <= 64 && S4 <= 64 && hp.mul1 <= 32 && s->XS < 4096 &&
+          fused_lds_bytes(J, std::max(s->XS, s->n_emb), S4, nt0) <= JAMUN_MAX_DYN_LDS)
+        s->fused_J = J;
+    }
     std::vector<int> ptr_h(topo->ptr, topo->ptr + W + 1);
     s->ptr = dev_upload(ptr_h);
     s->bond_in_ptr = dev_upload(bip);
@@ -628,13 +785,13 @@ int jamun_sampler_create(const jamun_model* m, float sigma, const jamun_topology
       const int muls[4] = {hp.emb_dim[0], hp.emb_dim[0], hp.emb_dim[2], hp.emb_dim[3]};
       for (int b = 0; b < 4; ++b) { ib.push_back({muls[b], 0, xo, xo}); xo += muls[b]; }
       std::vector<double> ones(s->n_emb, 1.0);
-      s->layers.push_back(build_layer(*m, "initial_projector", ib, ones, s->n_slices));
+      s->layers.push_back(build_layer(*m, "initial_projector", ib, ones, s->n_slices, s->fused_J));
     }
     for (int l = 0; l < hp.n_layers; ++l) {
       std::vector<InBlock> ib = {{hp.mul0, 0, 0, 0}, {hp.mul1, 1, hp.mul0, hp.mul0}};
       const std::string li = std::to_string(l);
       std::vector<double> sc = noise_mlp(*m, "noise_scalings." + li + ".scale_predictor", hp.mul0 + hp.mul1, c_noise);
-      LayerDev L = build_layer(*m, "layers." + li, ib, sc, s->n_slices);
+      LayerDev L = build_layer(*m, "layers." + li, ib, sc, s->n_slices, s->fused_J);
       std::vector<double> wm = noise_mlp(*m, "skip_connections." + li + ".weights.scale_predictor", hp.mul0 + hp.mul1, c_noise);
       std::vector<float> mix(wm.size());
       for (size_t i = 0; i < wm.size(); ++i) mix[i] = (float)(1.0 / (1.0 + std::exp(-wm[i])));
@@ -679,7 +836,8 @@ int jamun_sampler_create(const jamun_model* m, float sigma, const jamun_topology
     s->flop_exec = 0;
     for (auto& L : s->layers) {
       s->flop_ref_per_edge += 2LL * 64 * 64 + 130LL * L.tp_numel;  // SURVEY.md §8 d
-      s->flop_exec += 2LL * s->n_pad * (1LL * L.p0.K * L.p0.nt * 32 + 3LL * L.p1.K * L.p1.nt * 32);
+      if (L.fu.wpack) s->flop_exec += (int64_t)s->n_tiles * (hp.edge_attr_dim + 1) * L.fu.mfma_per_k * 4096;  // 32x32x2 MFMA = 4096 FLOP
+      else s->flop_exec += 2LL * s->n_pad * (1LL * L.p0.K * L.p0.nt * 32 + 3LL * L.p1.K * L.p1.nt * 32);
     }
     HIPCHECK(hipDeviceSynchronize());
     *out = s.release();

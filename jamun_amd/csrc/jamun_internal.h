@@ -37,6 +37,24 @@ struct ConvArgs {
   int n_slices;
 };
 
+// fused conv (jamun_conv_fused.hip): A operand formed on the matrix cores from dense coefficient tiles
+struct FusedArgs {
+  const int* deg;
+  const int* esrc;
+  const float4* egeo;
+  const float* h;  // [n_atoms*S][JAMUN_HS]
+  const float* x;  // [n_atoms][XS]
+  int n_atoms, n_pad, n_tiles, S, S4, XS, XR, J;
+  const int2* tile_span;  // [n_tiles] {lo, hi}: atoms whose features the tile's in-edges can read (whole molecules)
+  const float4* wpack;    // [k][k_stride] 16-byte weight fragments, per unit [qg 0..3][nt][64 lanes]
+  const int4* units;      // [n_units][2]: {n_terms, out (0 scalar rows, 1..3 vector plane), wofs / 64, 0}, {term0, term1, term2, 0}
+  const int* wave_units;  // [8][max_units] unit ids per wave, -1 terminated
+  const int* slice_k;     // [n_slices+1] hidden-unit range of each K-slice
+  float* partial0;        // [n_slices][n_pad][NT0*32]
+  float* partial1;        // [n_slices][n_pad][3][32]
+  int k_stride, max_units, n_slices;
+};
+
 struct NodeArgs {
   const float* partial0;  // [n_slices][n_pad][nt0*32]
   const float* partial1;  // [n_slices][n_pad][3][nt1*32]
@@ -83,6 +101,9 @@ void launch_edge_h(const int* deg, const int* esrc, const float4* egeo, int n_at
                    const float* cmask, const float* mu, float step, float* h, hipStream_t st);
 int launch_conv(const ConvArgs& a, int rc, int nt, hipStream_t st);
 int conv_set_max_lds();
+int launch_conv_fused(const FusedArgs& a, int nt0, hipStream_t st);
+int conv_fused_set_max_lds();
+size_t fused_lds_bytes(int J, int XR, int S4, int nt0);
 void launch_node_update(const NodeArgs& a, hipStream_t st);
 void launch_head(const HeadArgs& a, hipStream_t st);
 void launch_finalize(const float* y, const float* yc, const float* g, const int* ptr, int n_graphs, float c_skip,
