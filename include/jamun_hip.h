@@ -185,6 +185,10 @@ int jamun_sampler_stats(jamun_sampler* s, jamun_stats* out, void* stream);
 int jamun_profile_enable(jamun_sampler* s, int32_t on);
 int jamun_profile_read(jamun_sampler* s, double* ms_total, int64_t* launches, void* stream);
 
+/* Diagnostic builds only (-DJAMUN_STAMP): summed s_memtime cycles per phase of the fused conv kernel
+ * {coefficient-tile write, barrier wait, forming MFMAs, main MFMAs}; synchronises the device and clears the counters. */
+int jamun_debug_stamps(unsigned long long* out8);
+
 /* Copy internal buffers out for layer-level parity tests (device->device on `stream`):
  *   what = 0: node features after block `layer` (0 = initial projector) [n_atoms, mul0+3*mul1]
  *   what = 1: in-degree (radial + bonded) as float [n_atoms]

@@ -97,11 +97,10 @@ struct ConvProblemDev {
   int64_t K = 0;  // padded contraction depth
 };
 struct FusedDev {
-  float4* wpack = nullptr;
-  int4* units = nullptr;
-  int* wave_units = nullptr;
-  int* slice_k = nullptr;
-  int k_stride = 0, max_units = 0, n_units = 0, nt0 = 0;
+  float4* wpack = nullptr;  // null: the layer cannot use the fused kernel
+  int4 *a_units = nullptr, *b_units = nullptr, *owner = nullptr;
+  int k_stride = 0, max_a = 0, n_dtiles = 0, nt0 = 0;
+  size_t lds_bytes = 0;
   int64_t mfma_per_k = 0;  // MFMA instructions per hidden unit k and tile (forming + main), for FLOP bookkeeping
 };
 struct LayerDev {
@@ -113,7 +112,10 @@ struct LayerDev {
   int64_t tp_numel = 0;
 };
 
-void free_fused(FusedDev& f) { hipFree(f.wpack); hipFree(f.units); hipFree(f.wave_units); hipFree(f.slice_k); }
+void free_fused(FusedDev& f) {
+  hipFree(f.wpack); hipFree(f.a_units); hipFree(f.b_units); hipFree(f.owner);
+  f = FusedDev{};
+}
 
 void free_problem(ConvProblemDev& p) {
   hipFree(p.wpack); hipFree(p.chunks); hipFree(p.slice_ptr); hipFree(p.ublk); hipFree(p.lane_xoff);
@@ -258,7 +260,11 @@ struct jamun_sampler {
   int *ptr = nullptr, *bond_in_ptr = nullptr, *bond_in_src = nullptr;
   int n_tiles = 0;
   int2* tile_span = nullptr;
-  int span_max = 0, fused_J = 0;  // fused_J > 0: the fused MFMA-forming conv kernel is used (small molecules)
+  int span_max = 0;
+  // fused MFMA-forming conv kernel (small molecules): fused_JR > 0 when in use
+  int fused_JR = 0, fused_grid = 0, fused_max_segs = 0, n_slabs = 0;
+  int4* fused_segs = nullptr;
+  int* tile_nslab = nullptr;
   float *x_emb = nullptr, *mu = nullptr;
   std::vector<LayerDev> layers;
   float *w_gate = nullptr, *w_vec = nullptr, *w_out = nullptr;
@@ -278,6 +284,7 @@ struct jamun_sampler {
 
   ~jamun_sampler() {
     hipFree(ptr); hipFree(bond_in_ptr); hipFree(bond_in_src); hipFree(x_emb); hipFree(mu); hipFree(tile_span);
+    hipFree(fused_segs); hipFree(tile_nslab);
     for (auto& L : layers) {
       free_problem(L.p0); free_problem(L.p1); free_fused(L.fu);
       hipFree(L.w1r); hipFree(L.cmask); hipFree(L.w_self0); hipFree(L.w_self1); hipFree(L.w_skip0);
@@ -295,7 +302,7 @@ struct jamun_sampler {
 namespace {
 
 LayerDev build_layer(const jamun_model& m, const std::string& prefix, const std::vector<InBlock>& in_blocks,
-                     const std::vector<double>& s_in, int n_slices, int fused_J) {
+                     const std::vector<double>& s_in, int n_slices, int fused_JR, int fused_span) {
   const jamun_hparams& hp = m.hp;
   const int mul0 = hp.mul0, mul1 = hp.mul1, G0 = mul0 + mul1, G1 = mul1, H = hp.edge_attr_dim;
   LayerDev L;
@@ -366,64 +373,56 @@ LayerDev build_layer(const jamun_model& m, const std::string& prefix, const std:
   L.p0 = pack_problem(blocks0, 1, G0, n_slices, JAMUN_KSUB0, W3, b3, H);
   L.p1 = pack_problem(blocks1, 3, G1, n_slices, JAMUN_KSUB1, W3, b3, H);
 
-  // ---- fused kernel (jamun_conv_fused.hip): units, wave assignment, weights in accumulator-register K order
-  if (fused_J > 0 && G1 <= 32 && G1 > 0) {
-    struct FUnit { int n_terms, out, nt; int term[3]; std::vector<const UEntry*> ue; int u_count; };
+  // ---- fused kernel (jamun_conv_fused.hip): forming units (stage A), owner entries (stage B), weights in
+  // accumulator-register K order
+  bool x0_contig = true;
+  for (size_t i = 1; i < x0ve.size(); ++i) x0_contig = x0_contig && x0ve[i].xoff == x0ve[0].xoff + (int)i;
+  const int NT0 = (G0 + 31) / 32;
+  if (fused_JR > 0 && G1 <= 32 && G1 > 0 && x0_contig && NT0 + 3 <= JAMUN_FUSED_WAVES) {
+    // kind 0: D' tile formed from coefficient tiles (n_terms products), consumed by `nt` owner tiles of output `out`
+    // (0 scalar rows, 1..3 vector plane); kind 1: T tile of source-row tile jt, applied by all three plane owners
+    struct AUnit { int kind, n_terms, out, nt; int term[3]; int jt; std::vector<const UEntry*> ue; int wofs, cost; };
     auto term = [](int xcol0, int stride, int ctype, bool neg) { return xcol0 | (stride << 12) | (ctype << 16) | ((neg ? 1 : 0) << 20); };
-    std::vector<FUnit> fus;
-    const int NT0 = (G0 + 31) / 32;
-    // scalar-row units
-    for (size_t i = 0; i < x0e.size(); i += 32) {
-      FUnit u{1, 0, NT0, {term(x0e[i].xoff, 1, 0, false), 0, 0}, {}, 0};
-      for (size_t j = i; j < std::min(x0e.size(), i + 32); ++j) u.ue.push_back(&x0e[j]);
-      fus.push_back(u);
-    }
-    for (size_t i = 0; i < dote.size(); i += 32) {
-      FUnit u{3, 0, NT0, {term(dote[i].xoff + 0, 3, 1, false), term(dote[i].xoff + 1, 3, 2, false), term(dote[i].xoff + 2, 3, 3, false)}, {}, 0};
-      for (size_t j = i; j < std::min(dote.size(), i + 32); ++j) u.ue.push_back(&dote[j]);
-      fus.push_back(u);
-    }
-    // vector-row units, one per output plane m
+    std::vector<AUnit> au;
+    auto add = [&](int n_terms, int out, int nt, int t0, int t1, int t2, const std::vector<UEntry>& src, size_t i) {
+      AUnit u{0, n_terms, out, nt, {t0, t1, t2}, 0, {}, 0, 0};
+      for (size_t j = i; j < std::min(src.size(), i + 32); ++j) u.ue.push_back(&src[j]);
+      au.push_back(u);
+    };
+    for (size_t i = 0; i < x0e.size(); i += 32) add(1, 0, NT0, term(x0e[i].xoff, 1, 0, false), 0, 0, x0e, i);
+    for (size_t i = 0; i < dote.size(); i += 32)
+      add(3, 0, NT0, term(dote[i].xoff + 0, 3, 1, false), term(dote[i].xoff + 1, 3, 2, false), term(dote[i].xoff + 2, 3, 3, false), dote, i);
+    const int n_tsg = ((int)x0ve.size() + 7) / 8;  // groups of 4 K-steps (8 input channels) of the T contraction
+    const int n_jt = x0ve.empty() ? 0 : (fused_JR + 31) / 32;
+    for (int jt = 0; jt < n_jt; ++jt) au.push_back(AUnit{1, 0, 4, 0, {0, 0, 0}, jt, {}, 0, 0});
     for (int mm = 0; mm < 3; ++mm) {
-      for (size_t i = 0; i < x0ve.size(); i += 32) {
-        FUnit u{1, 1 + mm, 1, {term(x0ve[i].xoff, 1, 1 + mm, false), 0, 0}, {}, 0};
-        for (size_t j = i; j < std::min(x0ve.size(), i + 32); ++j) u.ue.push_back(&x0ve[j]);
-        fus.push_back(u);
-      }
-      for (size_t i = 0; i < x1e.size(); i += 32) {
-        FUnit u{1, 1 + mm, 1, {term(x1e[i].xoff + mm, 3, 0, false), 0, 0}, {}, 0};
-        for (size_t j = i; j < std::min(x1e.size(), i + 32); ++j) u.ue.push_back(&x1e[j]);
-        fus.push_back(u);
-      }
+      for (size_t i = 0; i < x1e.size(); i += 32) add(1, 1 + mm, 1, term(x1e[i].xoff + mm, 3, 0, false), 0, 0, x1e, i);
       for (size_t i = 0; i < crosse.size(); i += 32) {
         // (x1 x vhat)[m] = x1[m+1] vhat[m+2] - x1[m+2] vhat[m+1]
         const int m1 = (mm + 1) % 3, m2 = (mm + 2) % 3;
-        FUnit u{2, 1 + mm, 1, {term(crosse[i].xoff + m1, 3, 1 + m2, false), term(crosse[i].xoff + m2, 3, 1 + m1, true), 0}, {}, 0};
-        for (size_t j = i; j < std::min(crosse.size(), i + 32); ++j) u.ue.push_back(&crosse[j]);
-        fus.push_back(u);
+        add(2, 1 + mm, 1, term(crosse[i].xoff + m1, 3, 1 + m2, false), term(crosse[i].xoff + m2, 3, 1 + m1, true), 0, crosse, i);
       }
     }
     FusedDev& F = L.fu;
-    F.n_units = (int)fus.size();
     F.nt0 = NT0;
-    std::vector<int4> ud(2 * fus.size());
-    int blocks = 0;  // (qg, nt) blocks of 64 float4 per k
-    std::vector<int> wofs(fus.size());
-    for (size_t i = 0; i < fus.size(); ++i) {
-      wofs[i] = blocks;
-      ud[2 * i] = make_int4(fus[i].n_terms, fus[i].out, blocks, 0);
-      ud[2 * i + 1] = make_int4(fus[i].term[0], fus[i].term[1], fus[i].term[2], 0);
-      blocks += 4 * fus[i].nt;
-    }
+    F.n_dtiles = (int)au.size();
+    // weight blocks (64 lanes x float4) per k: main units [nt][qg 0..3], then the shared T weights [n_tsg]
+    int blocks = 0;
+    for (auto& u : au)
+      if (u.kind == 0) { u.wofs = blocks; blocks += 4 * u.nt; }
+    const int t_wofs = blocks;
+    if (n_jt) blocks += n_tsg;
+    for (auto& u : au)
+      if (u.kind == 1) u.wofs = t_wofs;
     F.k_stride = blocks * 64;
     const int n_k = H + 1;
     std::vector<float4> wp((size_t)n_k * F.k_stride, make_float4(0.f, 0.f, 0.f, 0.f));
-    for (int k = 0; k < n_k; ++k)
-      for (size_t i = 0; i < fus.size(); ++i) {
-        const FUnit& u = fus[i];
+    for (int k = 0; k < n_k; ++k) {
+      for (const AUnit& u : au) {
+        if (u.kind != 0) continue;
         const int Gout = u.out == 0 ? G0 : G1;
-        for (int qg = 0; qg < 4; ++qg)
-          for (int nt = 0; nt < u.nt; ++nt)
+        for (int nt = 0; nt < u.nt; ++nt)
+          for (int qg = 0; qg < 4; ++qg)
             for (int lane = 0; lane < 64; ++lane) {
               const int hh = lane >> 5, c = lane & 31, col = nt * 32 + c;
               float v[4] = {0.f, 0.f, 0.f, 0.f};
@@ -436,39 +435,86 @@ LayerDev build_layer(const jamun_model& m, const std::string& prefix, const std:
                 const double w = (k < H) ? (double)W3[(size_t)p * H + k] : (double)b3[p];
                 v[st] = (float)(w * e.scale);
               }
-              wp[(size_t)k * F.k_stride + ((size_t)(wofs[i] + qg * u.nt + nt)) * 64 + lane] = make_float4(v[0], v[1], v[2], v[3]);
+              wp[(size_t)k * F.k_stride + ((size_t)(u.wofs + nt * 4 + qg)) * 64 + lane] = make_float4(v[0], v[1], v[2], v[3]);
             }
       }
-    // static wave assignment: longest-processing-time greedy on the MFMA count of a unit
-    std::vector<int> order(fus.size()), cost(fus.size());
-    int64_t total_cost = 0;
-    for (size_t i = 0; i < fus.size(); ++i) {
+      for (int sg = 0; sg < (n_jt ? n_tsg : 0); ++sg)  // T weights: lane (w = lane & 31, hh): W[(k, u = 2 (4 sg + st) + hh)][w]
+        for (int lane = 0; lane < 64; ++lane) {
+          const int hh = lane >> 5, c = lane & 31;
+          float v[4] = {0.f, 0.f, 0.f, 0.f};
+          for (int st = 0; st < 4; ++st) {
+            const int ul = 2 * (4 * sg + st) + hh;
+            if (ul >= (int)x0ve.size() || c >= G1) continue;
+            const UEntry& e = x0ve[ul];
+            const int64_t p = e.wbase + c;
+            const double w = (k < H) ? (double)W3[(size_t)p * H + k] : (double)b3[p];
+            v[st] = (float)(w * e.scale);
+          }
+          wp[(size_t)k * F.k_stride + ((size_t)(t_wofs + sg)) * 64 + lane] = make_float4(v[0], v[1], v[2], v[3]);
+        }
+    }
+    // stage A: longest-processing-time greedy on the MFMA count, onto the wave whose SIMD (waves w and w+4 share one)
+    // is least loaded
+    const int J4 = (fused_span + 3) & ~3;
+    const int steps = 4 * (J4 / 8) + ((J4 & 4) ? 2 : 0);
+    int64_t total = 0;
+    std::vector<int> order(au.size());
+    for (size_t i = 0; i < au.size(); ++i) {
       order[i] = (int)i;
-      cost[i] = fus[i].n_terms * (fused_J / 2) + 16 * fus[i].nt;
-      total_cost += cost[i];
+      au[i].cost = au[i].kind == 1 ? 4 * n_tsg : au[i].n_terms * steps;
+      total += au[i].cost + (au[i].kind == 1 ? 3 * 16 : 16 * au[i].nt);
     }
-    F.mfma_per_k = total_cost;
-    std::stable_sort(order.begin(), order.end(), [&](int a1, int b1) { return cost[a1] > cost[b1]; });
-    std::vector<std::vector<int>> per_wave(8);
-    std::vector<int64_t> load(8, 0);
+    F.mfma_per_k = total;
+    std::stable_sort(order.begin(), order.end(), [&](int a1, int b1) { return au[a1].cost > au[b1].cost; });
+    const int FWv = JAMUN_FUSED_WAVES;
+    std::vector<std::vector<int>> per_wave(FWv);
+    std::vector<int64_t> load(FWv, 0);
     for (int i : order) {
-      int w = 0;
-      for (int c = 1; c < 8; ++c)
-        if (load[c] < load[w]) w = c;
-      per_wave[w].push_back(i);
-      load[w] += cost[i];
+      int best = 0;
+      auto key = [&](int w) { return std::make_pair(load[w] + load[(w + FWv / 2) % FWv], load[w]); };
+      for (int c = 1; c < FWv; ++c)
+        if (key(c) < key(best)) best = c;
+      per_wave[best].push_back(i);
+      load[best] += au[i].cost;
     }
-    F.max_units = 1;
-    for (auto& v : per_wave) F.max_units = std::max(F.max_units, (int)v.size() + 1);
-    std::vector<int> wu((size_t)8 * F.max_units, -1);
-    for (int w = 0; w < 8; ++w)
-      for (size_t i = 0; i < per_wave[w].size(); ++i) wu[(size_t)w * F.max_units + i] = per_wave[w][i];
-    std::vector<int> sk(n_slices + 1);
-    for (int sl = 0; sl <= n_slices; ++sl) sk[sl] = (int)(((int64_t)n_k * sl) / n_slices);
-    F.wpack = dev_upload(wp);
-    F.units = dev_upload(ud);
-    F.wave_units = dev_upload(wu);
-    F.slice_k = dev_upload(sk);
+    F.max_a = 1;
+    for (auto& v : per_wave) F.max_a = std::max(F.max_a, (int)v.size() + 1);
+    std::vector<int4> ua((size_t)FWv * F.max_a * 2, make_int4(-1, 0, 0, 0));
+    for (int w = 0; w < FWv; ++w)
+      for (size_t i = 0; i < per_wave[w].size(); ++i) {
+        const int id = per_wave[w][i];
+        const AUnit& u = au[id];
+        int4* d = &ua[((size_t)w * F.max_a + i) * 2];
+        if (u.kind == 1) { d[0] = make_int4(1, id, u.wofs, 0); d[1] = make_int4(u.jt, n_tsg, x0ve[0].xoff, 0); }
+        else { d[0] = make_int4(0, id, u.n_terms, 0); d[1] = make_int4(u.term[0], u.term[1], u.term[2], 0); }
+      }
+    // stage B: wave w < NT0 owns scalar-row tile w; waves NT0 + m own vector plane m
+    std::vector<int4> ubv((size_t)FWv * JAMUN_FUSED_MAX_B, make_int4(-1, 0, 0, 0)), own(FWv, make_int4(-1, 0, 0, 0));
+    bool fits = true;
+    for (int w = 0; w < FWv; ++w) {
+      std::vector<int4> ent;
+      if (w < NT0) {
+        own[w] = make_int4(0, w, 0, 0);
+        for (size_t i = 0; i < au.size(); ++i)
+          if (au[i].kind == 0 && au[i].out == 0) ent.push_back(make_int4(0, (int)i, au[i].wofs + 4 * w, 0));
+      } else if (w < NT0 + 3) {
+        const int mm = w - NT0;
+        own[w] = make_int4(1, mm, 0, 0);
+        for (size_t i = 0; i < au.size(); ++i)
+          if (au[i].kind == 0 && au[i].out == 1 + mm) ent.push_back(make_int4(0, (int)i, au[i].wofs, 0));
+        for (size_t i = 0; i < au.size(); ++i)
+          if (au[i].kind == 1) ent.push_back(make_int4(1, (int)i, mm, au[i].jt));
+      }
+      if ((int)ent.size() > JAMUN_FUSED_MAX_B) { fits = false; break; }
+      for (size_t i = 0; i < ent.size(); ++i) ubv[(size_t)w * JAMUN_FUSED_MAX_B + i] = ent[i];
+    }
+    F.lds_bytes = fused_lds_bytes(L.XSin, fused_JR, F.n_dtiles, F.max_a);
+    if (fits && 32 * fused_JR <= F.n_dtiles * 1024) {
+      F.wpack = dev_upload(wp);
+      F.a_units = dev_upload(ua);
+      F.b_units = dev_upload(ubv);
+      F.owner = dev_upload(own);
+    }
   }
 
   // ---- radial MLP first layer: split into the constant bonded part and the radial part
@@ -558,13 +604,12 @@ void forward(jamun_sampler* s, const float* y, float* xhat, float* score, hipStr
     if (L.fu.wpack) {
       FusedArgs f{};
       f.deg = s->deg; f.esrc = s->esrc; f.egeo = s->egeo; f.h = s->h; f.x = x_in;
-      f.n_atoms = s->n_atoms; f.n_pad = s->n_pad; f.n_tiles = s->n_tiles; f.S = s->S; f.S4 = (s->S + 3) & ~3;
-      f.XS = XSin; f.XR = XSin; f.J = s->fused_J; f.tile_span = s->tile_span;
-      f.wpack = L.fu.wpack; f.units = L.fu.units; f.wave_units = L.fu.wave_units; f.slice_k = L.fu.slice_k;
-      f.partial0 = s->partial0; f.partial1 = s->partial1;
-      f.k_stride = L.fu.k_stride; f.max_units = L.fu.max_units; f.n_slices = s->n_slices;
+      f.n_atoms = s->n_atoms; f.n_pad = s->n_pad; f.S = s->S; f.XS = XSin; f.JR = s->fused_JR; f.tile_span = s->tile_span;
+      f.wpack = L.fu.wpack; f.a_units = L.fu.a_units; f.b_units = L.fu.b_units; f.owner = L.fu.owner; f.segs = s->fused_segs;
+      f.k_stride = L.fu.k_stride; f.max_a = L.fu.max_a; f.n_dtiles = L.fu.n_dtiles; f.max_segs = s->fused_max_segs;
+      f.nt0 = L.fu.nt0; f.partial0 = s->partial0; f.partial1 = s->partial1;
       ProfScope ps(s, l == 0 ? JAMUN_PROF_CONV0_INIT : JAMUN_PROF_CONV0, st);
-      const int rcode = launch_conv_fused(f, L.fu.nt0, st);
+      const int rcode = launch_conv_fused(f, s->fused_grid, st);
       if (rcode != 0) throw Err(JAMUN_ERR_INVALID, "fused conv launch failed (configuration not supported)");
     } else {
     ConvArgs a{};
@@ -588,6 +633,7 @@ void forward(jamun_sampler* s, const float* y, float* xhat, float* score, hipStr
     n.cL = s->hp.act_scalar_const; n.cS = s->hp.act_gate_const;
     n.n_atoms = s->n_atoms; n.n_pad = s->n_pad; n.n_slices = s->n_slices; n.nt0 = L.p0.nt; n.nt1 = L.p1.nt;
     n.mul0 = s->hp.mul0; n.mul1 = s->hp.mul1; n.in0 = L.in0; n.in1 = L.in1; n.XSin = XSin;
+    n.tile_nslab = L.fu.wpack ? s->tile_nslab : nullptr;
     {
       ProfScope ps(s, JAMUN_PROF_NODE, st);
       launch_node_update(n, st);
@@ -732,13 +778,12 @@ int jamun_sampler_create(const jamun_model* m, float sigma, const jamun_topology
         std::sort(bb.begin(), bb.end());
         dup = std::adjacent_find(bb.begin(), bb.end()) != bb.end();
       }
-      const int J = (s->span_max + 1) & ~1;
-      const int S4 = (s->S + 3) & ~3;
-      const int nt0 = (hp.mul0 + hp.mul1 + 31) / 32;
+      // row stride of the transposed tiles: a multiple of 4 (b128 reads) with JR/4 odd (8 lanes x 16 B cover all banks)
+      int JR = (s->span_max + 3) & ~3;
+      if ((JR / 4) % 2 == 0) JR += 4;
       const bool no_fused = getenv("JAMUN_NO_FUSED") != nullptr;  // debugging / A-B aid
-      if (!no_fused && !dup && J <= 64 && S4 <= 64 && hp.mul1 <= 32 && s->XS < 4096 &&
-          fused_lds_bytes(J, std::max(s->XS, s->n_emb), S4, nt0) <= JAMUN_MAX_DYN_LDS)
-        s->fused_J = J;
+      if (!no_fused && !dup && JR <= 64 && s->S < 255 && hp.mul1 <= 32 && (int64_t)N * s->S * JAMUN_HS < (int64_t)0x7fffffff)
+        s->fused_JR = JR;
     }
     std::vector<int> ptr_h(topo->ptr, topo->ptr + W + 1);
     s->ptr = dev_upload(ptr_h);
@@ -785,13 +830,13 @@ int jamun_sampler_create(const jamun_model* m, float sigma, const jamun_topology
       const int muls[4] = {hp.emb_dim[0], hp.emb_dim[0], hp.emb_dim[2], hp.emb_dim[3]};
       for (int b = 0; b < 4; ++b) { ib.push_back({muls[b], 0, xo, xo}); xo += muls[b]; }
       std::vector<double> ones(s->n_emb, 1.0);
-      s->layers.push_back(build_layer(*m, "initial_projector", ib, ones, s->n_slices, s->fused_J));
+      s->layers.push_back(build_layer(*m, "initial_projector", ib, ones, s->n_slices, s->fused_JR, s->span_max));
     }
     for (int l = 0; l < hp.n_layers; ++l) {
       std::vector<InBlock> ib = {{hp.mul0, 0, 0, 0}, {hp.mul1, 1, hp.mul0, hp.mul0}};
       const std::string li = std::to_string(l);
       std::vector<double> sc = noise_mlp(*m, "noise_scalings." + li + ".scale_predictor", hp.mul0 + hp.mul1, c_noise);
-      LayerDev L = build_layer(*m, "layers." + li, ib, sc, s->n_slices, s->fused_J);
+      LayerDev L = build_layer(*m, "layers." + li, ib, sc, s->n_slices, s->fused_JR, s->span_max);
       std::vector<double> wm = noise_mlp(*m, "skip_connections." + li + ".weights.scale_predictor", hp.mul0 + hp.mul1, c_noise);
       std::vector<float> mix(wm.size());
       for (size_t i = 0; i < wm.size(); ++i) mix[i] = (float)(1.0 / (1.0 + std::exp(-wm[i])));
@@ -813,6 +858,63 @@ int jamun_sampler_create(const jamun_model* m, float sigma, const jamun_topology
       s->w_vec = dev_upload(wv);
       s->w_out = dev_upload(wo);
     }
+    // ---- fused conv: all layers or none; persistent-workgroup segment lists
+    {
+      bool all = s->fused_JR > 0;
+      for (auto& L : s->layers) all = all && L.fu.wpack && L.fu.lds_bytes <= JAMUN_MAX_DYN_LDS;
+      if (!all) {
+        for (auto& L : s->layers) free_fused(L.fu);
+        s->fused_JR = 0;
+      }
+    }
+    if (s->fused_JR > 0) {
+      // Work items are (tile, hidden unit k).  k is sliced over the XCDs (workgroup g runs on XCD g % 8, so an XCD's L2
+      // holds only its slice of the weights); the n_k % 8 left-over k are dealt round-robin over (tile, XCD).  Each
+      // XCD's item list (tile-major) is cut evenly over its workgroups: a workgroup gets a few runs of k ("segments"),
+      // each written to its own partial slab of the tile.
+      hipDeviceProp_t prop;
+      int dev = 0;
+      HIPCHECK(hipGetDevice(&dev));
+      HIPCHECK(hipGetDeviceProperties(&prop, dev));
+      const int cus = std::max(prop.multiProcessorCount, 1);
+      const int n_k = hp.edge_attr_dim + 1;
+      const int ng = (cus % 8 == 0 && n_k >= 8) ? 8 : 1, ncx = cus / ng;
+      const int base = n_k / ng, rem = n_k % ng;
+      s->fused_grid = cus;
+      std::vector<std::vector<int4>> wg_segs(cus);
+      std::vector<int> nslab(s->n_tiles, 0);
+      for (int x = 0; x < ng; ++x) {
+        auto extra_of = [&](int t) { const int e = ((x - t) % ng + ng) % ng; return e < rem ? ng * base + e : -1; };
+        int64_t Lx = 0;
+        for (int t = 0; t < s->n_tiles; ++t) Lx += base + (extra_of(t) >= 0 ? 1 : 0);
+        int64_t off = 0;
+        int c = 0;
+        for (int t = 0; t < s->n_tiles; ++t) {
+          const int ex = extra_of(t), cnt = base + (ex >= 0 ? 1 : 0);
+          int i0 = 0;
+          while (i0 < cnt) {
+            while (c + 1 < ncx && (Lx * (c + 1)) / ncx <= off + i0) ++c;
+            const int64_t hi = (c + 1 < ncx) ? (Lx * (c + 1)) / ncx : Lx;
+            const int i1 = (int)std::min<int64_t>(cnt, hi - off);
+            const int kb = x * base + std::min(i0, base), ke = x * base + std::min(i1, base);
+            auto& v = wg_segs[(size_t)c * ng + x];
+            v.push_back(make_int4(t, nslab[t]++, kb, ke));
+            v.push_back(make_int4(i1 > base ? ex : -1, 0, 0, 0));
+            i0 = i1;
+          }
+          off += cnt;
+        }
+      }
+      size_t ms = 1;
+      for (auto& v : wg_segs) ms = std::max(ms, v.size() / 2 + 1);
+      s->fused_max_segs = (int)ms;
+      std::vector<int4> segs((size_t)cus * ms * 2, make_int4(-1, 0, 0, 0));
+      for (int g = 0; g < cus; ++g) std::copy(wg_segs[g].begin(), wg_segs[g].end(), segs.begin() + (size_t)g * ms * 2);
+      s->fused_segs = dev_upload(segs);
+      s->n_slabs = 1;
+      for (int v : nslab) s->n_slabs = std::max(s->n_slabs, v);
+      s->tile_nslab = dev_upload(nslab);
+    }
     // ---- work buffers
     const size_t NS = (size_t)N * s->S;
     s->yc = dev_alloc<float>((size_t)N * 3);
@@ -822,8 +924,9 @@ int jamun_sampler_create(const jamun_model* m, float sigma, const jamun_topology
     s->h = dev_alloc<float>(NS * JAMUN_HS);
     int nt0 = 0, nt1 = 0;
     for (auto& L : s->layers) { nt0 = std::max(nt0, L.p0.nt); nt1 = std::max(nt1, L.p1.nt); }
-    s->partial0 = dev_alloc<float>((size_t)s->n_slices * s->n_pad * nt0 * 32);
-    s->partial1 = dev_alloc<float>((size_t)s->n_slices * s->n_pad * 3 * nt1 * 32);
+    const size_t n_part = (size_t)std::max(s->n_slices, s->n_slabs);
+    s->partial0 = dev_alloc<float>(n_part * s->n_pad * nt0 * 32);
+    s->partial1 = dev_alloc<float>(n_part * s->n_pad * 3 * nt1 * 32);
     s->g = dev_alloc<float>((size_t)N * 3);
     s->tmp = dev_alloc<float>((size_t)N * 3);
     s->xhat_buf = dev_alloc<float>((size_t)N * 3);
@@ -1004,7 +1107,7 @@ int jamun_sampler_stats(jamun_sampler* s, jamun_stats* out, void* stream) {
       out->conv1_flop_alg = 2 * 3 * (int64_t)s->n_atoms * H1 * (m0 + 2 * m1) * m1;
     }
     out->edge_stride = s->S;
-    out->n_slices = s->n_slices;
+    out->n_slices = s->fused_JR > 0 ? s->n_slabs : s->n_slices;
   });
 }
 
@@ -1030,6 +1133,16 @@ int jamun_profile_read(jamun_sampler* s, double* ms_total, int64_t* launches, vo
     }
     s->ev_used.clear();
     s->ev_next = 0;
+  });
+}
+
+int jamun_debug_stamps(unsigned long long* out8) {
+  return guarded([&] {
+    if (!out8) throw Err(JAMUN_ERR_INVALID, "null argument");
+    HIPCHECK(hipDeviceSynchronize());
+    const int r = conv_fused_read_stamps(out8);
+    if (r == -2) throw Err(JAMUN_ERR_INVALID, "library was not built with -DJAMUN_STAMP");
+    if (r != 0) throw Err(JAMUN_ERR_HIP, "reading stamp counters failed");
   });
 }
 

@@ -1,22 +1,29 @@
-// jamun_conv_fused.hip — fused conv contraction for small molecules: the A operand is formed ON THE MATRIX CORES.
+// jamun_conv_fused.hip — fused conv contraction for small molecules: the A operand is formed ON THE MATRIX CORES and
+// every wave OWNS one output tile.
 //
 // Same mathematics as jamun_conv.hip (destination-grouped association of src/jamun/e3tools/nn/_conv.py:93-119):
 //     m[(i,c)][w] = sum_k sum_u ( sum_{e->i} h~_e[k] zeta_e[c][u] ) W~[(k,u)][w]
 // but the inner edge sum is written as a dense product over the source atoms j the tile can see (whole molecules,
-// J <= 64 rows):
+// JR <= 64 rows):
 //     D'_k[u][i] = sum_j X[j][u] * C_k[j][i]          C_k[j][i] = sum over the (<= 2) edges j->i of h~_e[k] * f_e
 // with f = 1 or a component of the edge unit vector.  D' is a 32x32 MFMA accumulator whose COLUMN is the destination
 // atom, i.e. exactly the lane layout of the A operand of the main product  out[i][w] += sum_u D'[u][i] W[(k,u)][w]:
-// register q of the accumulator is K-step q of the main MFMA (rows u = (q&3) + 8(q>>2) + 4(lane>>5)), so the formed
-// tile never leaves the register file — no LDS transpose, no VALU forming loop, no per-edge broadcast traffic (the
-// LDS-broadcast-bound part of jamun_conv.hip, profiles/r1b).  The weights are packed in that K order.
+// register q of the accumulator is K-step q of the main MFMA (rows u = (q&3) + 8(q>>2) + 4(lane>>5)).  The weights are
+// packed in that K order.
 //
-// One workgroup = 8 waves = one tile of 32 destination atoms x one K-slice of hidden units k, for BOTH output kinds
-// (scalar rows and the three vector planes).  Per k: all threads build the four coefficient tiles C^h, C^{h vx},
-// C^{h vy}, C^{h vz} in LDS (a gather through a (source, destination) -> edge-slot map, no read-modify-write), one
-// barrier (tiles are double buffered), then every wave runs its statically assigned units.  A unit = (u-tile of 32
-// input channels, up to 3 "terms" of (feature column set, coefficient tile, sign)) -> forming MFMAs over J/2 K-steps
-// per term -> 16 main K-steps into the scalar-row accumulators (NT0 tiles) or one vector-plane accumulator.
+// One persistent workgroup per CU = 8 waves.  Work items are (tile of 32 destination atoms, hidden unit k); a workgroup
+// walks a host-built list of segments (tile, run of k) — k is sliced over the 8 XCDs so every XCD's L2 holds only its own
+// weights, and the (tile, k) list of an XCD is cut evenly over its CUs (no tail round).  Per k two stages, one barrier
+// each:
+//   A  forming: the ~13 forming units of the k (4 scalar-input u-tiles, the dot-product u-tile, x1 / cross per plane, and
+//      the T tiles  T[j][w] = sum_u x0_j[u] W[(k,u)][w]  for the vector rows from scalar inputs) are spread over all
+//      waves; each result tile (16 registers x 64 lanes) is parked in LDS in register order (conflict-free b128).
+//   B  main: wave w < NT0 owns scalar-row tile w, waves NT0..NT0+2 own the vector planes.  An owner reads the formed
+//      tiles back as MFMA A operands (same lane, same register: no transpose) and runs the main K-steps against its
+//      weights; plane owners also apply  out_m[i][w] += sum_j C^{h v_m}[j][i] T[j][w]  with T as the B operand.
+// No accumulator is shared between waves: no cross-wave reduction, 16 accumulator registers per wave.
+// Feature rows and coefficient tiles are stored TRANSPOSED ([column][source row], row stride JR = 4 * odd) so the four
+// K-steps a lane needs are one ds_read_b128.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -24,213 +31,391 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-#define FUSED_WAVES 8
+#define FW JAMUN_FUSED_WAVES
+#define FT (64 * FW)
+#define FPAIRS (64 * 32 / FT)  // (source row, destination) pairs per thread, JR <= 64
+#define MAXB JAMUN_FUSED_MAX_B
 
-template <int NT>
-__device__ __forceinline__ void unit_main(f32x16 (&acc)[NT], const f32x16& af, const float4* __restrict__ wp, int lane) {
-  // wp: [qg 0..3][nt][64 lanes] float4 = weights of main K-steps 4qg..4qg+3
-  float4 bn[NT];
-#pragma unroll
-  for (int nt = 0; nt < NT; ++nt) bn[nt] = wp[nt * 64 + lane];
-#pragma unroll
-  for (int qg = 0; qg < 4; ++qg) {
-    float4 b[NT];
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) b[nt] = bn[nt];
-    if (qg < 3) {
-#pragma unroll
-      for (int nt = 0; nt < NT; ++nt) bn[nt] = wp[((qg + 1) * NT + nt) * 64 + lane];
-    }
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[4 * qg + 0], b[nt].x, acc[nt], 0, 0, 0);
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[4 * qg + 1], b[nt].y, acc[nt], 0, 0, 0);
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[4 * qg + 2], b[nt].z, acc[nt], 0, 0, 0);
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[4 * qg + 3], b[nt].w, acc[nt], 0, 0, 0);
-  }
-}
+#ifdef JAMUN_STAMP
+__device__ unsigned long long g_fstamp[8];
+#define FSTAMP(t) do { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory"); } while (0)
+#else
+#define FSTAMP(t) do { } while (0)
+#endif
 
-template <int NT0>
-__global__ __launch_bounds__(512, 1) void k_conv_fused(FusedArgs a) {
+#define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
+#define RFL(v) __builtin_amdgcn_readfirstlane(v)
+
+__global__ __launch_bounds__(FT, 1) void k_conv_fused(FusedArgs a) {
   extern __shared__ float4 lds4[];
   float* __restrict__ lds = reinterpret_cast<float*>(lds4);
-  const int J = a.J;                                  // rows of the x / coefficient tiles (even, >= every tile span)
-  float* __restrict__ x_lds = lds;                    // [J][XR]
-  float* __restrict__ c_lds = x_lds + J * a.XR;       // [2][4][J][32]
-  int* __restrict__ pm_lds = reinterpret_cast<int*>(c_lds + 2 * 4 * J * 32);  // [J][32] (slot_a+1) | (slot_b+1) << 8
-  float4* __restrict__ g_lds = reinterpret_cast<float4*>(pm_lds + J * 32);     // [32][S4] vhat per edge slot
-  int* __restrict__ deg_lds = reinterpret_cast<int*>(g_lds + 32 * a.S4);        // [32]
+  const int JR = a.JR;
+  const int CT = 32 * JR;                                                   // floats per coefficient tile
+  float* __restrict__ xT = lds;                                             // [XS][JR]
+  float* __restrict__ cT = xT + a.XS * JR;                                  // [2][4][32][JR]
+  float4* __restrict__ d4 = reinterpret_cast<float4*>(cT + 2 * 4 * CT);     // [n_dtiles][4][64] formed tiles, register order
+  int* __restrict__ pm = reinterpret_cast<int*>(d4);                        // [32][JR] slot map (prologue only; aliases d4)
+  int* __restrict__ ua = reinterpret_cast<int*>(d4 + a.n_dtiles * 256);     // [FW][max_a][8] stage A units
+  int* __restrict__ ub = ua + FW * a.max_a * 8;                             // [FW][MAXB][4] stage B entries
+  int* __restrict__ deg_lds = ub + FW * MAXB * 4;                           // [32]
   const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wave = RFL(tid >> 6);
   const int r = lane & 31, hh = lane >> 5;
-  const int slice = blockIdx.x % a.n_slices;
-  const int tile = blockIdx.x / a.n_slices;
-  const int n0 = tile * 32;
-  const int2 span = a.tile_span[tile];
-  const int rows = span.y - span.x;
-  const int Jt = (rows + 1) & ~1;  // K extent of the forming products for this tile
 
-  // ---- once per workgroup: feature rows, edge geometry, (source, destination) -> slot map
-  for (int idx = tid; idx < Jt * a.XS; idx += 512) {
-    const int jl = idx / a.XS, c = idx - jl * a.XS;
-    x_lds[jl * a.XR + c] = (jl < rows) ? a.x[(size_t)(span.x + jl) * a.XS + c] : 0.f;
-  }
-  for (int idx = tid; idx < J * 32; idx += 512) pm_lds[idx] = 0;
-  if (tid < 32) deg_lds[tid] = (n0 + tid < a.n_atoms) ? a.deg[n0 + tid] : 0;
-  __syncthreads();
-  for (int idx = tid; idx < 32 * a.S4; idx += 512) {
-    const int il = idx / a.S4, t = idx - il * a.S4;
-    if (t < deg_lds[il]) {
-      const size_t e = (size_t)(n0 + il) * a.S + t;
-      const int sj = a.esrc[e];
-      const float4 geo = a.egeo[e];
-      g_lds[idx] = make_float4(0.f, geo.x, geo.y, geo.z);
-      const int jl = (sj & 0x7fffffff) - span.x;
-      // radial and bonded edges of one (source, destination) pair go to different byte fields: no write conflict
-      // within a field because a destination's radial neighbours (and its bonded sources) are distinct atoms
-      atomicOr(&pm_lds[jl * 32 + il], (sj < 0) ? ((t + 1) << 8) : (t + 1));
-    }
-  }
+  // ---- once per workgroup: the unit tables
+  for (int idx = tid; idx < FW * a.max_a * 8; idx += FT) ua[idx] = reinterpret_cast<const int*>(a.a_units)[idx];
+  for (int idx = tid; idx < FW * MAXB * 4; idx += FT) ub[idx] = reinterpret_cast<const int*>(a.b_units)[idx];
+  const int4* __restrict__ my_a = reinterpret_cast<const int4*>(ua + wave * a.max_a * 8);
+  const int4* __restrict__ my_b = reinterpret_cast<const int4*>(ub + wave * MAXB * 4);
+  const int4 own = a.owner[wave];  // {kind: -1 none / 0 scalar-row tile / 1 vector plane, index}
+  const int own_kind = RFL(own.x), own_idx = RFL(own.y);
 
-  f32x16 acc0[NT0];
-  f32x16 acc1[3];
-#pragma unroll
-  for (int nt = 0; nt < NT0; ++nt)
-#pragma unroll
-    for (int q = 0; q < 16; ++q) acc0[nt][q] = 0.f;
-#pragma unroll
-  for (int m = 0; m < 3; ++m)
-#pragma unroll
-    for (int q = 0; q < 16; ++q) acc1[m][q] = 0.f;
-  __syncthreads();
+  unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0, s_pro = 0, s_wait = 0, s_a = 0, s_b = 0, s_build = 0, s_epi = 0;
+  (void)t0; (void)t1; (void)t2; (void)t3; (void)t4; (void)s_pro; (void)s_wait; (void)s_a; (void)s_b; (void)s_build; (void)s_epi;
 
-  const int k_begin = a.slice_k[slice], k_end = a.slice_k[slice + 1];
-  const int* __restrict__ my_units = a.wave_units + wave * a.max_units;
-  for (int k = k_begin; k < k_end; ++k) {
-    float* __restrict__ cb = c_lds + ((k - k_begin) & 1) * 4 * J * 32;
-    // ---- coefficient tiles of hidden unit k: gather through the slot map
-    for (int p = tid; p < Jt * 32; p += 512) {
-      const int il = p & 31;
-      const int pmv = pm_lds[p];
-      const int ta = pmv & 0xff, tb = (pmv >> 8) & 0xff;
-      float c0 = 0.f, cx = 0.f, cy = 0.f, cz = 0.f;
-      if (ta) {
-        const float hv = a.h[((size_t)(n0 + il) * a.S + (ta - 1)) * JAMUN_HS + k];
-        const float4 g = g_lds[il * a.S4 + ta - 1];
-        c0 = hv; cx = hv * g.y; cy = hv * g.z; cz = hv * g.w;
-      }
-      if (tb) {
-        const float hv = a.h[((size_t)(n0 + il) * a.S + (tb - 1)) * JAMUN_HS + k];
-        const float4 g = g_lds[il * a.S4 + tb - 1];
-        c0 += hv; cx = fmaf(hv, g.y, cx); cy = fmaf(hv, g.z, cy); cz = fmaf(hv, g.w, cz);
-      }
-      cb[p] = c0;
-      cb[J * 32 + p] = cx;
-      cb[2 * J * 32 + p] = cy;
-      cb[3 * J * 32 + p] = cz;
-    }
-    __syncthreads();  // tiles are double buffered: one barrier per k orders build(k) before use(k) and use(k-1) before build(k+1)
+  for (int sgi = 0; sgi < a.max_segs; ++sgi) {
+    const int4 sg0 = a.segs[((size_t)blockIdx.x * a.max_segs + sgi) * 2];
+    const int4 sg1 = a.segs[((size_t)blockIdx.x * a.max_segs + sgi) * 2 + 1];
+    const int tile = RFL(sg0.x);
+    if (tile < 0) break;
+    const int slab = RFL(sg0.y), k_begin = RFL(sg0.z), k_run = RFL(sg0.w) - k_begin, k_extra = RFL(sg1.x);
+    const int nk = k_run + (k_extra >= 0 ? 1 : 0);
+    FSTAMP(t0);
+    const int n0 = tile * 32;
+    const int2 span = a.tile_span[tile];
+    const int rows = span.y - span.x;
+    const int Jt4 = (rows + 3) & ~3;  // K extent of the forming products for this tile
+    const int n8 = Jt4 >> 3, tail4 = Jt4 & 4;
+    __syncthreads();  // the previous segment is done with the tiles (pm aliases the formed tiles)
 
-    const float4* __restrict__ wk = a.wpack + (size_t)k * a.k_stride;
-    for (int ui = 0; ui < a.max_units; ++ui) {
-      const int uid = my_units[ui];
-      if (uid < 0) break;
-      const int4 ud = a.units[2 * uid];       // {n_terms, out, wofs (float4 units / 64), 0}
-      const int4 ut = a.units[2 * uid + 1];   // up to 3 terms, each packed: xcol0 | stride << 12 | ctype << 16 | neg << 20
-      f32x16 af;
+    // ---- per segment: transposed feature rows, (source, destination) -> edge-slot map, per-pair edge geometry
+    {
+      const int ncg = (a.XS + 3) >> 2;  // 16-byte column groups; lane = source row
+      const float* __restrict__ xrow = a.x + (size_t)(span.x + (lane < rows ? lane : 0)) * a.XS;
+      const bool vec_ok = (a.XS & 3) == 0;
+      for (int cg0 = wave; cg0 < ncg; cg0 += 4 * FW) {
+        float4 v[4];
 #pragma unroll
-      for (int q = 0; q < 16; ++q) af[q] = 0.f;
+        for (int i = 0; i < 4; ++i) {
+          const int cg = cg0 + i * FW;
+          v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (cg < ncg && lane < rows) {
+            if (vec_ok) v[i] = reinterpret_cast<const float4*>(xrow)[cg];
+            else {
+              const int c = 4 * cg;
+              v[i].x = xrow[c];
+              if (c + 1 < a.XS) v[i].y = xrow[c + 1];
+              if (c + 2 < a.XS) v[i].z = xrow[c + 2];
+              if (c + 3 < a.XS) v[i].w = xrow[c + 3];
+            }
+          }
+        }
 #pragma unroll
-      for (int t = 0; t < 3; ++t) {
-        if (t >= ud.x) break;  // wave-uniform
-        const int td = t == 0 ? ut.x : (t == 1 ? ut.y : ut.z);
-        const int xcol0 = td & 0xfff, stride = (td >> 12) & 0xf, ctype = (td >> 16) & 0xf;
-        const float sgn = (td >> 20) & 1 ? -1.f : 1.f;
-        const float* __restrict__ xp = x_lds + hh * a.XR + xcol0 + r * stride;
-        const float* __restrict__ cp = cb + ctype * J * 32 + hh * 32 + r;
-        for (int s = 0; s < (Jt >> 1); ++s) {
-          const float av = xp[2 * s * a.XR];
-          const float bv = cp[2 * s * 32] * sgn;
-          af = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, af, 0, 0, 0);
+        for (int i = 0; i < 4; ++i) {
+          const int cg = cg0 + i * FW;
+          if (cg < ncg && lane < JR) {
+            const int c = 4 * cg;
+            xT[c * JR + lane] = v[i].x;
+            if (c + 1 < a.XS) xT[(c + 1) * JR + lane] = v[i].y;
+            if (c + 2 < a.XS) xT[(c + 2) * JR + lane] = v[i].z;
+            if (c + 3 < a.XS) xT[(c + 3) * JR + lane] = v[i].w;
+          }
         }
       }
-      const float4* __restrict__ wp = wk + (size_t)ud.z * 64;
-      if (ud.y == 0) unit_main<NT0>(acc0, af, wp, lane);
-      else if (ud.y == 1) unit_main<1>(reinterpret_cast<f32x16(&)[1]>(acc1[0]), af, wp, lane);
-      else if (ud.y == 2) unit_main<1>(reinterpret_cast<f32x16(&)[1]>(acc1[1]), af, wp, lane);
-      else unit_main<1>(reinterpret_cast<f32x16(&)[1]>(acc1[2]), af, wp, lane);
     }
-  }
-  __syncthreads();
+    for (int idx = tid; idx < CT; idx += FT) pm[idx] = 0;
+    if (tid < 32) deg_lds[tid] = (n0 + tid < a.n_atoms) ? a.deg[n0 + tid] : 0;
+    __syncthreads();
+    for (int idx = tid; idx < 32 * a.S; idx += FT) {
+      const int il = idx / a.S, t = idx - il * a.S;
+      if (t < deg_lds[il]) {
+        const int sj = a.esrc[(size_t)(n0 + il) * a.S + t];
+        const int jl = (sj & 0x7fffffff) - span.x;
+        // radial and bonded edges of one (source, destination) pair go to different byte fields: no write conflict
+        // within a field because a destination's radial neighbours (and its bonded sources) are distinct atoms
+        atomicOr(&pm[il * JR + jl], (sj < 0) ? ((t + 1) << 8) : (t + 1));
+      }
+    }
+    __syncthreads();
+    // Each thread owns up to FPAIRS (destination il, source row j) pairs, p = il * JR + j: slots, unit vectors and h~
+    // addresses live in registers for the whole segment.
+    int p_oa[FPAIRS], p_ob[FPAIRS];  // h~ element offsets of the radial / bonded edge of the pair, -1 if none
+    float p_ga[FPAIRS][3], p_gb[FPAIRS][3];
+    float p_ha[FPAIRS], p_hb[FPAIRS];
+#pragma unroll
+    for (int i = 0; i < FPAIRS; ++i) {
+      const int p = tid + FT * i;
+      const int pt = (p < CT) ? pm[p] : 0;
+      const int il = p / JR;
+      const int ta = pt & 0xff, tb = (pt >> 8) & 0xff;
+      const int ea = (n0 + il) * a.S + ta - 1, eb = (n0 + il) * a.S + tb - 1;
+      p_oa[i] = ta ? ea * JAMUN_HS : -1;
+      p_ob[i] = tb ? eb * JAMUN_HS : -1;
+      float4 ga = make_float4(0.f, 0.f, 0.f, 0.f), gb = ga;
+      if (ta) ga = a.egeo[ea];
+      if (tb) gb = a.egeo[eb];
+      p_ga[i][0] = ga.x; p_ga[i][1] = ga.y; p_ga[i][2] = ga.z;
+      p_gb[i][0] = gb.x; p_gb[i][1] = gb.y; p_gb[i][2] = gb.z;
+    }
+    auto load_h = [&](int k) {
+#pragma unroll
+      for (int i = 0; i < FPAIRS; ++i) {
+        p_ha[i] = p_oa[i] >= 0 ? a.h[p_oa[i] + k] : 0.f;
+        p_hb[i] = p_ob[i] >= 0 ? a.h[p_ob[i] + k] : 0.f;
+      }
+    };
+    auto write_c = [&](float* __restrict__ cbuf) {
+#pragma unroll
+      for (int i = 0; i < FPAIRS; ++i) {
+        const int p = tid + FT * i;
+        if (p < CT) {  // every (destination, row < JR) entry is written: absent pairs and rows >= the span get zeros
+          cbuf[p] = p_ha[i] + p_hb[i];
+          cbuf[CT + p] = fmaf(p_hb[i], p_gb[i][0], p_ha[i] * p_ga[i][0]);
+          cbuf[2 * CT + p] = fmaf(p_hb[i], p_gb[i][1], p_ha[i] * p_ga[i][1]);
+          cbuf[3 * CT + p] = fmaf(p_hb[i], p_gb[i][2], p_ha[i] * p_ga[i][2]);
+        }
+      }
+    };
+    auto k_of = [&](int kk) { return kk < k_run ? k_begin + kk : k_extra; };
 
-  // ---- fixed-order cross-wave reduction through LDS (wave 0 += wave 1, 2, ... 7), then wave 0 stores the slab rows
-  float* __restrict__ red = lds;  // (NT0 + 3) * 16 * 64 floats
-  for (int w = 1; w < FUSED_WAVES; ++w) {
-    if (wave == w) {
+    f32x16 acc;
 #pragma unroll
-      for (int nt = 0; nt < NT0; ++nt)
+    for (int q = 0; q < 16; ++q) acc[q] = 0.f;
+    load_h(k_of(0));
+    write_c(cT);
+    FSTAMP(t1);
+#ifdef JAMUN_STAMP
+    s_pro += t1 - t0;
+#endif
+
+    for (int kk = 0; kk < nk; ++kk) {
+      const int k = k_of(kk);
+      float* __restrict__ cb = cT + (kk & 1) * 4 * CT;
+      const float4* __restrict__ wk = a.wpack + (size_t)k * a.k_stride + lane;
+      FSTAMP(t0);
+      if (kk + 1 < nk) load_h(k_of(kk + 1));  // in flight behind both stages, written to the other buffer after stage B
+      // weights of the first two stage-B entries and of this wave's T tile: in flight behind stage A
+      float4 wb[2][4];
 #pragma unroll
-        for (int q = 0; q < 16; ++q) red[(nt * 16 + q) * 64 + lane] = acc0[nt][q];
+      for (int e = 0; e < 2; ++e) {
+        const int4 bd = my_b[e];
+        const int kind = RFL(bd.x), wofs = RFL(bd.z);
 #pragma unroll
-      for (int m = 0; m < 3; ++m)
+        for (int q = 0; q < 4; ++q) wb[e][q] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (kind == 0) {
 #pragma unroll
-        for (int q = 0; q < 16; ++q) red[((NT0 + m) * 16 + q) * 64 + lane] = acc1[m][q];
+          for (int q = 0; q < 4; ++q) wb[e][q] = wk[(wofs + q) * 64];
+        }
+      }
+      float4 tring[4];
+      int t_pre = -1;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) tring[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int ui = 0; ui < a.max_a; ++ui) {
+        const int4 ud = my_a[2 * ui];
+        const int kind = RFL(ud.x);
+        if (kind < 0) break;
+        if (kind == 1) {
+          const int wofs = RFL(ud.z), nsg = RFL(my_a[2 * ui + 1].y);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) tring[i] = wk[(wofs + (i < nsg ? i : nsg - 1)) * 64];
+          t_pre = ui;
+          break;
+        }
+      }
+      __syncthreads();  // C(k) is built; stage B of the previous k is done with the formed tiles
+      FSTAMP(t1);
+
+      // ================= stage A: forming =================
+      for (int ui = 0; ui < a.max_a; ++ui) {
+        const int4 ud = my_a[2 * ui];
+        const int4 ut = my_a[2 * ui + 1];
+        const int kind = RFL(ud.x), dtile = RFL(ud.y);
+        if (kind < 0) break;
+        f32x16 af;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) af[q] = 0.f;
+        if (kind == 1) {
+          // T tile: T[j][w] = sum_u x0_j[u] W[(k,u)][w] for one 32-row tile of source atoms.  A operand straight from
+          // the transposed feature rows (lane = row: consecutive banks), B operand = weights.
+          const int wofs = RFL(ud.z), jt = RFL(ut.x), nsg = RFL(ut.y), xcol0 = RFL(ut.z);
+          if (32 * jt >= Jt4) continue;  // wave-uniform: the tile sees no source atom in this row tile
+          int row = 32 * jt + r;
+          row = row < JR ? row : JR - 1;  // rows past the tile hold finite stand-ins; their coefficients are zero
+          const float* __restrict__ xr = xT + (xcol0 + hh) * JR + row;
+          float4 ring[4];
+          if (t_pre == ui) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) ring[i] = tring[i];
+          } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) ring[i] = wk[(wofs + (i < nsg ? i : nsg - 1)) * 64];
+          }
+          for (int sg = 0; sg < nsg; sg += 4) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              if (sg + i < nsg) {  // wave-uniform
+                const float4 w = ring[i];
+                if (sg + i + 4 < nsg) ring[i] = wk[(wofs + sg + i + 4) * 64];
+                const float* __restrict__ xs = xr + 8 * (sg + i) * JR;
+                af = MFMA(xs[0], w.x, af);
+                af = MFMA(xs[2 * JR], w.y, af);
+                af = MFMA(xs[4 * JR], w.z, af);
+                af = MFMA(xs[6 * JR], w.w, af);
+              }
+            }
+          }
+        } else {
+          const int n_terms = RFL(ud.z);
+#pragma unroll
+          for (int t = 0; t < 3; ++t) {
+            if (t >= n_terms) break;  // wave-uniform
+            const int td = RFL(t == 0 ? ut.x : (t == 1 ? ut.y : ut.z));
+            const int xcol0 = td & 0xfff, stride = (td >> 12) & 0xf, ctype = (td >> 16) & 0xf;
+            const float sgn = (td >> 20) & 1 ? -1.f : 1.f;
+            const float* __restrict__ xq = xT + (xcol0 + r * stride) * JR;
+            const float* __restrict__ cq = cb + ctype * CT + r * JR;
+            const float4* __restrict__ xp = reinterpret_cast<const float4*>(xq + 4 * hh);  // rows 8g + 4hh + (0..3)
+            const float4* __restrict__ cp = reinterpret_cast<const float4*>(cq + 4 * hh);
+            if (n8 > 0) {
+              float4 av = xp[0], bv = cp[0];
+              for (int g = 0; g < n8; ++g) {
+                float4 an = av, bn = bv;
+                if (g + 1 < n8) { an = xp[2 * (g + 1)]; bn = cp[2 * (g + 1)]; }
+                af = MFMA(av.x, bv.x * sgn, af);
+                af = MFMA(av.y, bv.y * sgn, af);
+                af = MFMA(av.z, bv.z * sgn, af);
+                af = MFMA(av.w, bv.w * sgn, af);
+                av = an; bv = bn;
+              }
+            }
+            if (tail4) {  // four more source rows: two K-steps, rows 8 n8 + 2s + hh
+              const float a0 = xq[8 * n8 + hh], b0 = cq[8 * n8 + hh];
+              const float a1 = xq[8 * n8 + 2 + hh], b1 = cq[8 * n8 + 2 + hh];
+              af = MFMA(a0, b0 * sgn, af);
+              af = MFMA(a1, b1 * sgn, af);
+            }
+          }
+        }
+#pragma unroll
+        for (int qg = 0; qg < 4; ++qg)
+          d4[(dtile * 4 + qg) * 64 + lane] = make_float4(af[4 * qg], af[4 * qg + 1], af[4 * qg + 2], af[4 * qg + 3]);
+      }
+      FSTAMP(t2);
+      __syncthreads();  // formed tiles are visible
+      FSTAMP(t3);
+
+      // ================= stage B: main K-steps into the tile this wave owns =================
+#pragma unroll
+      for (int e = 0; e < MAXB; ++e) {
+        const int4 bd = my_b[e];
+        const int kind = RFL(bd.x), dtile = RFL(bd.y);
+        if (kind < 0) break;
+        if (kind == 0) {
+          float4 w[4];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) w[q] = wb[e & 1][q];
+          if (e + 2 < MAXB) {
+            const int4 bn = my_b[e + 2];
+            if (RFL(bn.x) == 0) {
+              const int wofs = RFL(bn.z);
+#pragma unroll
+              for (int q = 0; q < 4; ++q) wb[e & 1][q] = wk[(wofs + q) * 64];
+            }
+          }
+#pragma unroll
+          for (int qg = 0; qg < 4; ++qg) {
+            const float4 av = d4[(dtile * 4 + qg) * 64 + lane];
+            acc = MFMA(av.x, w[qg].x, acc);
+            acc = MFMA(av.y, w[qg].y, acc);
+            acc = MFMA(av.z, w[qg].z, acc);
+            acc = MFMA(av.w, w[qg].w, acc);
+          }
+        } else {
+          // out_m[i][w] += sum_j C^{h v_m}[j][i] T[j][w]: A operand = coefficient tile rows in T's register order
+          const int m = RFL(bd.z), jt = RFL(bd.w);
+          if (32 * jt >= Jt4) continue;
+          const float* __restrict__ cm = cb + (1 + m) * CT + r * JR + 32 * jt + 4 * hh;
+#pragma unroll
+          for (int qg = 0; qg < 4; ++qg) {
+            const float4 tv = d4[(dtile * 4 + qg) * 64 + lane];
+            float4 cv = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (32 * jt + 4 * hh + 8 * qg < JR) cv = *reinterpret_cast<const float4*>(cm + 8 * qg);
+            acc = MFMA(cv.x, tv.x, acc);
+            acc = MFMA(cv.y, tv.y, acc);
+            acc = MFMA(cv.z, tv.z, acc);
+            acc = MFMA(cv.w, tv.w, acc);
+          }
+        }
+      }
+      FSTAMP(t4);
+      if (kk + 1 < nk) write_c(cT + ((kk + 1) & 1) * 4 * CT);
+#ifdef JAMUN_STAMP
+      {
+        unsigned long long t5;
+        FSTAMP(t5);
+        s_wait += (t1 - t0) + (t3 - t2); s_a += t2 - t1; s_b += t4 - t3; s_build += t5 - t4;
+      }
+#endif
     }
-    __syncthreads();
-    if (wave == 0) {
+
+    // ---- the owner stores its tile of the segment's partial slab
+    FSTAMP(t0);
+    if (own_kind == 0) {
 #pragma unroll
-      for (int nt = 0; nt < NT0; ++nt)
+      for (int q = 0; q < 16; ++q) {
+        const int row = (q & 3) + 8 * (q >> 2) + 4 * hh;
+        a.partial0[((size_t)slab * a.n_pad + n0 + row) * (a.nt0 * 32) + own_idx * 32 + r] = acc[q];
+      }
+    } else if (own_kind == 1) {
 #pragma unroll
-        for (int q = 0; q < 16; ++q) acc0[nt][q] += red[(nt * 16 + q) * 64 + lane];
-#pragma unroll
-      for (int m = 0; m < 3; ++m)
-#pragma unroll
-        for (int q = 0; q < 16; ++q) acc1[m][q] += red[((NT0 + m) * 16 + q) * 64 + lane];
+      for (int q = 0; q < 16; ++q) {
+        const int row = (q & 3) + 8 * (q >> 2) + 4 * hh;
+        a.partial1[(((size_t)slab * a.n_pad + n0 + row) * 3 + own_idx) * 32 + r] = acc[q];
+      }
     }
-    __syncthreads();
+#ifdef JAMUN_STAMP
+    FSTAMP(t1);
+    s_epi += t1 - t0;
+#endif
   }
-  if (wave == 0) {
-#pragma unroll
-    for (int q = 0; q < 16; ++q) {
-      const int row = (q & 3) + 8 * (q >> 2) + 4 * hh;
-      const size_t base = (size_t)slice * a.n_pad + n0 + row;
-#pragma unroll
-      for (int nt = 0; nt < NT0; ++nt) a.partial0[base * (NT0 * 32) + nt * 32 + r] = acc0[nt][q];
-#pragma unroll
-      for (int m = 0; m < 3; ++m) a.partial1[(base * 3 + m) * 32 + r] = acc1[m][q];
-    }
+#ifdef JAMUN_STAMP
+  if (lane == 0) {
+    atomicAdd(&g_fstamp[0], s_build); atomicAdd(&g_fstamp[1], s_wait); atomicAdd(&g_fstamp[2], s_a); atomicAdd(&g_fstamp[3], s_b);
+    atomicAdd(&g_fstamp[4], s_pro); atomicAdd(&g_fstamp[6], s_epi);
   }
+#endif
 }
 
-size_t fused_lds_bytes(int J, int XR, int S4, int nt0) {
-  size_t fl = (size_t)J * XR + 2 * 4 * (size_t)J * 32 + (size_t)J * 32 + 32 * (size_t)S4 * 4 + 32;
-  const size_t red = (size_t)(nt0 + 3) * 16 * 64;
-  if (fl < red) fl = red;
+size_t fused_lds_bytes(int XS, int JR, int n_dtiles, int max_a) {
+  const size_t fl = (size_t)XS * JR + 2 * 4 * 32 * (size_t)JR + (size_t)n_dtiles * 1024 + (size_t)FW * max_a * 8 +
+                    (size_t)FW * MAXB * 4 + 32;
   return sizeof(float) * ((fl + 3) & ~(size_t)3);
 }
 
-int launch_conv_fused(const FusedArgs& a, int nt0, hipStream_t st) {
-  const int grid = a.n_tiles * a.n_slices;
-  const size_t smem = fused_lds_bytes(a.J, a.XR, a.S4, nt0);
+int launch_conv_fused(const FusedArgs& a, int grid, hipStream_t st) {
+  const size_t smem = fused_lds_bytes(a.XS, a.JR, a.n_dtiles, a.max_a);
   if (smem > JAMUN_MAX_DYN_LDS) return -2;
-  switch (nt0) {
-    case 1: hipLaunchKernelGGL((k_conv_fused<1>), dim3(grid), dim3(512), smem, st, a); return 0;
-    case 2: hipLaunchKernelGGL((k_conv_fused<2>), dim3(grid), dim3(512), smem, st, a); return 0;
-    case 3: hipLaunchKernelGGL((k_conv_fused<3>), dim3(grid), dim3(512), smem, st, a); return 0;
-    case 4: hipLaunchKernelGGL((k_conv_fused<4>), dim3(grid), dim3(512), smem, st, a); return 0;
-    case 5: hipLaunchKernelGGL((k_conv_fused<5>), dim3(grid), dim3(512), smem, st, a); return 0;
-    default: return -1;
-  }
+  if (32 * a.JR > a.n_dtiles * 1024) return -1;  // the slot map aliases the formed tiles
+  hipLaunchKernelGGL(k_conv_fused, dim3(grid), dim3(FT), smem, st, a);
+  return 0;
+}
+
+int conv_fused_read_stamps(unsigned long long* out8) {
+#ifdef JAMUN_STAMP
+  if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_fstamp), sizeof(unsigned long long) * 8) != hipSuccess) return -1;
+  unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (hipMemcpyToSymbol(HIP_SYMBOL(g_fstamp), z, sizeof(z)) != hipSuccess) return -1;
+  return 0;
+#else
+  (void)out8;
+  return -2;
+#endif
 }
 
 int conv_fused_set_max_lds() {
-  hipError_t e = hipSuccess;
-#define SETATTR(NT)                                                                                                \
-  if (e == hipSuccess)                                                                                             \
-    e = hipFuncSetAttribute((const void*)k_conv_fused<NT>, hipFuncAttributeMaxDynamicSharedMemorySize, JAMUN_MAX_DYN_LDS);
-  SETATTR(1) SETATTR(2) SETATTR(3) SETATTR(4) SETATTR(5)
-#undef SETATTR
-  return e == hipSuccess ? 0 : -1;
+  return hipFuncSetAttribute((const void*)k_conv_fused, hipFuncAttributeMaxDynamicSharedMemorySize, JAMUN_MAX_DYN_LDS) ==
+                 hipSuccess
+             ? 0
+             : -1;
 }

@@ -10,6 +10,8 @@
 #define JAMUN_KSUB0 5  // hidden units per k-subgroup, scalar-output rows (subgroups of 4 or 5)
 #define JAMUN_KSUB1 2  // hidden units per k-subgroup, vector-output rows (3 planes per workgroup; subgroups of 1 or 2)
 #define JAMUN_MAX_DYN_LDS (160 * 1024)
+#define JAMUN_FUSED_WAVES 8   // waves per workgroup of the fused conv kernel; every wave owns at most one output tile
+#define JAMUN_FUSED_MAX_B 6   // stage-B entries (formed tiles consumed) per owner wave
 #define JAMUN_MAX_BATCH 128  // edge batches (of 4) per wave: 8 atoms x ceil(S / 4); limits the edge stride S to 64
 
 // zeta types of a u-block (what the edge feeds into the contraction)
@@ -37,22 +39,28 @@ struct ConvArgs {
   int n_slices;
 };
 
-// fused conv (jamun_conv_fused.hip): A operand formed on the matrix cores from dense coefficient tiles
+// fused conv (jamun_conv_fused.hip): A operand formed on the matrix cores from dense coefficient tiles; persistent
+// workgroups walk host-built segment lists
 struct FusedArgs {
   const int* deg;
   const int* esrc;
   const float4* egeo;
   const float* h;  // [n_atoms*S][JAMUN_HS]
   const float* x;  // [n_atoms][XS]
-  int n_atoms, n_pad, n_tiles, S, S4, XS, XR, J;
+  int n_atoms, n_pad, S, XS, JR;  // JR: row stride of the transposed feature / coefficient tiles (4 * odd, >= every tile span)
   const int2* tile_span;  // [n_tiles] {lo, hi}: atoms whose features the tile's in-edges can read (whole molecules)
-  const float4* wpack;    // [k][k_stride] 16-byte weight fragments, per unit [qg 0..3][nt][64 lanes]
-  const int4* units;      // [n_units][2]: {n_terms, out (0 scalar rows, 1..3 vector plane), wofs / 64, 0}, {term0, term1, term2, 0}
-  const int* wave_units;  // [8][max_units] unit ids per wave, -1 terminated
-  const int* slice_k;     // [n_slices+1] hidden-unit range of each K-slice
-  float* partial0;        // [n_slices][n_pad][NT0*32]
-  float* partial1;        // [n_slices][n_pad][3][32]
-  int k_stride, max_units, n_slices;
+  const float4* wpack;    // [k][k_stride] 16-byte weight fragments (blocks of 64 lanes)
+  // stage A units [waves][max_a][2]: {kind (0 forming from coefficient tiles, 1 T tile, -1 end), formed-tile id,
+  //   n_terms | weight block, 0}, {term0, term1, term2, 0} | {row tile, weight groups, first x0 column, 0}
+  const int4* a_units;
+  // stage B entries [waves][JAMUN_FUSED_MAX_B]: {kind (0 main K-steps, 1 apply T, -1 end), formed-tile id,
+  //   weight block | plane, row tile}
+  const int4* b_units;
+  const int4* owner;  // [waves] {kind (-1 none, 0 scalar-row tile, 1 vector plane), index, 0, 0}
+  const int4* segs;   // [grid][max_segs][2]: {tile (-1 end), slab, k_begin, k_end}, {k_extra (-1 none), 0, 0, 0}
+  int k_stride, max_a, n_dtiles, max_segs, nt0;
+  float* partial0;  // [slab][n_pad][nt0*32]
+  float* partial1;  // [slab][n_pad][3][32]
 };
 
 struct NodeArgs {
@@ -69,6 +77,7 @@ struct NodeArgs {
   float cL, cS;
   int n_atoms, n_pad, n_slices, nt0, nt1;
   int mul0, mul1, in0, in1, XSin;
+  const int* tile_nslab;  // [n_pad/32] partial slabs per 32-atom tile (fused conv), or nullptr: n_slices everywhere
 };
 
 struct HeadArgs {
@@ -101,9 +110,10 @@ void launch_edge_h(const int* deg, const int* esrc, const float4* egeo, int n_at
                    const float* cmask, const float* mu, float step, float* h, hipStream_t st);
 int launch_conv(const ConvArgs& a, int rc, int nt, hipStream_t st);
 int conv_set_max_lds();
-int launch_conv_fused(const FusedArgs& a, int nt0, hipStream_t st);
+int launch_conv_fused(const FusedArgs& a, int grid, hipStream_t st);
 int conv_fused_set_max_lds();
-size_t fused_lds_bytes(int J, int XR, int S4, int nt0);
+int conv_fused_read_stamps(unsigned long long* out8);
+size_t fused_lds_bytes(int XS, int JR, int n_dtiles, int max_a);
 void launch_node_update(const NodeArgs& a, hipStream_t st);
 void launch_head(const HeadArgs& a, hipStream_t st);
 void launch_finalize(const float* y, const float* yc, const float* g, const int* ptr, int n_graphs, float c_skip,

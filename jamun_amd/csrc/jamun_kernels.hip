@@ -180,7 +180,8 @@ __global__ __launch_bounds__(256) void k_node_update(NodeArgs a) {
     const int nb = idx / G0, w = idx % G0, i = n0 + nb;
     float m = 0.f;
     if (i < a.n_atoms) {
-      for (int s = 0; s < a.n_slices; ++s) m += a.partial0[((size_t)s * a.n_pad + i) * w0 + w];
+      const int ns = a.tile_nslab ? a.tile_nslab[i >> 5] : a.n_slices;
+      for (int s = 0; s < ns; ++s) m += a.partial0[((size_t)s * a.n_pad + i) * w0 + w];
       const int d = a.deg[i];
       m = m / (float)(d < 1 ? 1 : d);
     }
@@ -197,7 +198,8 @@ __global__ __launch_bounds__(256) void k_node_update(NodeArgs a) {
     const int nb = idx / (a.mul1 * 3), rem = idx % (a.mul1 * 3), wv = rem / 3, mm = rem % 3, i = n0 + nb;
     float m = 0.f;
     if (i < a.n_atoms) {
-      for (int s = 0; s < a.n_slices; ++s) m += a.partial1[(((size_t)s * a.n_pad + i) * 3 + mm) * w1 + wv];
+      const int ns = a.tile_nslab ? a.tile_nslab[i >> 5] : a.n_slices;
+      for (int s = 0; s < ns; ++s) m += a.partial1[(((size_t)s * a.n_pad + i) * 3 + mm) * w1 + wv];
       const int d = a.deg[i];
       m = m / (float)(d < 1 ? 1 : d);
     }
