@@ -26,6 +26,7 @@
 // K-steps a lane needs are one ds_read_b128.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdio.h>
 
 #include "jamun_internal.h"
 
@@ -38,11 +39,15 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 #ifdef JAMUN_STAMP
 __device__ unsigned long long g_fstamp[8];
+__device__ unsigned long long g_wstamp[32];
 #define FSTAMP(t) do { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory"); } while (0)
 #else
 #define FSTAMP(t) do { } while (0)
 #endif
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains the vector-memory counter, which would
+// expose the latency of every global prefetch (h~ of the next k, weights) issued before it.
+#define LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 #define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
 #define RFL(v) __builtin_amdgcn_readfirstlane(v)
 
@@ -223,7 +228,7 @@ __global__ __launch_bounds__(FT, 1) void k_conv_fused(FusedArgs a) {
           break;
         }
       }
-      __syncthreads();  // C(k) is built; stage B of the previous k is done with the formed tiles
+      LDS_BARRIER();  // C(k) is built; stage B of the previous k is done with the formed tiles
       FSTAMP(t1);
 
       // ================= stage A: forming =================
@@ -302,7 +307,7 @@ __global__ __launch_bounds__(FT, 1) void k_conv_fused(FusedArgs a) {
           d4[(dtile * 4 + qg) * 64 + lane] = make_float4(af[4 * qg], af[4 * qg + 1], af[4 * qg + 2], af[4 * qg + 3]);
       }
       FSTAMP(t2);
-      __syncthreads();  // formed tiles are visible
+      LDS_BARRIER();  // formed tiles are visible
       FSTAMP(t3);
 
       // ================= stage B: main K-steps into the tile this wave owns =================
@@ -383,6 +388,7 @@ __global__ __launch_bounds__(FT, 1) void k_conv_fused(FusedArgs a) {
   if (lane == 0) {
     atomicAdd(&g_fstamp[0], s_build); atomicAdd(&g_fstamp[1], s_wait); atomicAdd(&g_fstamp[2], s_a); atomicAdd(&g_fstamp[3], s_b);
     atomicAdd(&g_fstamp[4], s_pro); atomicAdd(&g_fstamp[6], s_epi);
+    atomicAdd(&g_wstamp[wave], s_a); atomicAdd(&g_wstamp[8 + wave], s_b); atomicAdd(&g_wstamp[16 + wave], s_wait); atomicAdd(&g_wstamp[24 + wave], s_build);
   }
 #endif
 }
@@ -404,6 +410,13 @@ int launch_conv_fused(const FusedArgs& a, int grid, hipStream_t st) {
 int conv_fused_read_stamps(unsigned long long* out8) {
 #ifdef JAMUN_STAMP
   if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_fstamp), sizeof(unsigned long long) * 8) != hipSuccess) return -1;
+  {
+    unsigned long long w[32], z32[32] = {0};
+    if (hipMemcpyFromSymbol(w, HIP_SYMBOL(g_wstamp), sizeof(w)) == hipSuccess) {
+      for (int i = 0; i < 32; ++i) fprintf(stderr, "%s%llu%s", i % 8 == 0 ? (i == 0 ? "wstamp A: " : i == 8 ? "wstamp B: " : i == 16 ? "wstamp wait: " : "wstamp build: ") : "", w[i] / 1000, i % 8 == 7 ? "\n" : " ");
+      (void)hipMemcpyToSymbol(HIP_SYMBOL(g_wstamp), z32, sizeof(z32));
+    }
+  }
   unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   if (hipMemcpyToSymbol(HIP_SYMBOL(g_fstamp), z, sizeof(z)) != hipSuccess) return -1;
   return 0;
