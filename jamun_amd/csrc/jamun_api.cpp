@@ -99,7 +99,7 @@ struct ConvProblemDev {
 struct FusedDev {
   float4* wpack = nullptr;  // null: the layer cannot use the fused kernel
   int4 *a_units = nullptr, *b_units = nullptr, *owner = nullptr;
-  int k_stride = 0, max_a = 0, n_dtiles = 0, nt0 = 0;
+  int k_stride = 0, max_a = 0, n_p = 0, n_t = 0, nt0 = 0;
   size_t lds_bytes = 0;
   int64_t mfma_per_k = 0;  // MFMA instructions per hidden unit k and tile (forming + main), for FLOP bookkeeping
 };
@@ -405,7 +405,14 @@ LayerDev build_layer(const jamun_model& m, const std::string& prefix, const std:
     }
     FusedDev& F = L.fu;
     F.nt0 = NT0;
-    F.n_dtiles = (int)au.size();
+    // parked tiles: scalar-row tiles (index p) and T tiles (index = row tile)
+    int n_p = 0;
+    std::vector<int> tix(au.size(), 0);
+    for (size_t i = 0; i < au.size(); ++i) {
+      if (au[i].kind == 0 && au[i].out == 0) tix[i] = n_p++;
+      if (au[i].kind == 1) tix[i] = au[i].jt;
+    }
+    F.n_p = n_p; F.n_t = std::max(n_jt, 1);
     // weight blocks (64 lanes x float4) per k: main units [nt][qg 0..3], then the shared T weights [n_tsg]
     int blocks = 0;
     for (auto& u : au)
@@ -453,22 +460,50 @@ LayerDev build_layer(const jamun_model& m, const std::string& prefix, const std:
           wp[(size_t)k * F.k_stride + ((size_t)(t_wofs + sg)) * 64 + lane] = make_float4(v[0], v[1], v[2], v[3]);
         }
     }
-    // stage A: longest-processing-time greedy on the MFMA count, onto the wave whose SIMD (waves w and w+4 share one)
-    // is least loaded
     const int J4 = (fused_span + 3) & ~3;
     const int steps = 4 * (J4 / 8) + ((J4 & 4) ? 2 : 0);
+    const int FWv = JAMUN_FUSED_WAVES;
+    // owner entries: wave w < NT0 owns scalar-row tile w; waves NT0 + m own vector plane m (its x1 / cross tiles are formed
+    // in the owner's registers)
+    std::vector<int4> ubv((size_t)FWv * JAMUN_FUSED_MAX_B * 2, make_int4(-1, 0, 0, 0)), own(FWv, make_int4(-1, 0, 0, 0));
+    std::vector<int64_t> load(FWv, 0);
+    bool fits = true;
     int64_t total = 0;
-    std::vector<int> order(au.size());
+    for (int w = 0; w < FWv; ++w) {
+      std::vector<std::pair<int4, int4>> ent;
+      const int4 z = make_int4(0, 0, 0, 0);
+      if (w < NT0) {
+        own[w] = make_int4(0, w, 0, 0);
+        for (size_t i = 0; i < au.size(); ++i)
+          if (au[i].kind == 0 && au[i].out == 0) { ent.push_back({make_int4(0, tix[i], au[i].wofs + 4 * w, 0), z}); load[w] += 16; }
+      } else if (w < NT0 + 3) {
+        const int mm = w - NT0;
+        own[w] = make_int4(1, mm, 0, 0);
+        for (size_t i = 0; i < au.size(); ++i)
+          if (au[i].kind == 0 && au[i].out == 1 + mm) {
+            ent.push_back({make_int4(2, au[i].n_terms, au[i].wofs, 0), make_int4(au[i].term[0], au[i].term[1], au[i].term[2], 0)});
+            load[w] += au[i].n_terms * steps + 16;
+          }
+        for (size_t i = 0; i < au.size(); ++i)
+          if (au[i].kind == 1) { ent.push_back({make_int4(1, tix[i], mm, au[i].jt), z}); load[w] += 16; }
+      }
+      total += load[w];
+      if ((int)ent.size() > JAMUN_FUSED_MAX_B) { fits = false; break; }
+      for (size_t i = 0; i < ent.size(); ++i) {
+        ubv[((size_t)w * JAMUN_FUSED_MAX_B + i) * 2] = ent[i].first;
+        ubv[((size_t)w * JAMUN_FUSED_MAX_B + i) * 2 + 1] = ent[i].second;
+      }
+    }
+    // parked-tile forming units: longest-processing-time greedy on the MFMA count, onto the wave whose SIMD (waves w and
+    // w + 4 share one) carries the least work per interval, owner entries included
+    std::vector<int> order;
     for (size_t i = 0; i < au.size(); ++i) {
-      order[i] = (int)i;
       au[i].cost = au[i].kind == 1 ? 4 * n_tsg : au[i].n_terms * steps;
-      total += au[i].cost + (au[i].kind == 1 ? 3 * 16 : 16 * au[i].nt);
+      if (au[i].kind == 1 || au[i].out == 0) { order.push_back((int)i); total += au[i].cost; }
     }
     F.mfma_per_k = total;
     std::stable_sort(order.begin(), order.end(), [&](int a1, int b1) { return au[a1].cost > au[b1].cost; });
-    const int FWv = JAMUN_FUSED_WAVES;
     std::vector<std::vector<int>> per_wave(FWv);
-    std::vector<int64_t> load(FWv, 0);
     for (int i : order) {
       int best = 0;
       auto key = [&](int w) { return std::make_pair(load[w] + load[(w + FWv / 2) % FWv], load[w]); };
@@ -485,35 +520,21 @@ LayerDev build_layer(const jamun_model& m, const std::string& prefix, const std:
         const int id = per_wave[w][i];
         const AUnit& u = au[id];
         int4* d = &ua[((size_t)w * F.max_a + i) * 2];
-        if (u.kind == 1) { d[0] = make_int4(1, id, u.wofs, 0); d[1] = make_int4(u.jt, n_tsg, x0ve[0].xoff, 0); }
-        else { d[0] = make_int4(0, id, u.n_terms, 0); d[1] = make_int4(u.term[0], u.term[1], u.term[2], 0); }
+        if (u.kind == 1) { d[0] = make_int4(1, tix[id], u.wofs, 0); d[1] = make_int4(u.jt, n_tsg, x0ve[0].xoff, 0); }
+        else { d[0] = make_int4(0, tix[id], u.n_terms, 0); d[1] = make_int4(u.term[0], u.term[1], u.term[2], 0); }
       }
-    // stage B: wave w < NT0 owns scalar-row tile w; waves NT0 + m own vector plane m
-    std::vector<int4> ubv((size_t)FWv * JAMUN_FUSED_MAX_B, make_int4(-1, 0, 0, 0)), own(FWv, make_int4(-1, 0, 0, 0));
-    bool fits = true;
-    for (int w = 0; w < FWv; ++w) {
-      std::vector<int4> ent;
-      if (w < NT0) {
-        own[w] = make_int4(0, w, 0, 0);
-        for (size_t i = 0; i < au.size(); ++i)
-          if (au[i].kind == 0 && au[i].out == 0) ent.push_back(make_int4(0, (int)i, au[i].wofs + 4 * w, 0));
-      } else if (w < NT0 + 3) {
-        const int mm = w - NT0;
-        own[w] = make_int4(1, mm, 0, 0);
-        for (size_t i = 0; i < au.size(); ++i)
-          if (au[i].kind == 0 && au[i].out == 1 + mm) ent.push_back(make_int4(0, (int)i, au[i].wofs, 0));
-        for (size_t i = 0; i < au.size(); ++i)
-          if (au[i].kind == 1) ent.push_back(make_int4(1, (int)i, mm, au[i].jt));
-      }
-      if ((int)ent.size() > JAMUN_FUSED_MAX_B) { fits = false; break; }
-      for (size_t i = 0; i < ent.size(); ++i) ubv[(size_t)w * JAMUN_FUSED_MAX_B + i] = ent[i];
-    }
-    F.lds_bytes = fused_lds_bytes(L.XSin, fused_JR, F.n_dtiles, F.max_a);
-    if (fits && 32 * fused_JR <= F.n_dtiles * 1024) {
+    F.lds_bytes = fused_lds_bytes(L.XSin, fused_JR, F.n_p, F.n_t, F.max_a);
+    if (fits && 32 * fused_JR <= 2 * F.n_p * 1024) {
       F.wpack = dev_upload(wp);
       F.a_units = dev_upload(ua);
       F.b_units = dev_upload(ubv);
       F.owner = dev_upload(own);
+    }
+    if (getenv("JAMUN_DEBUG_UNITS")) {
+      fprintf(stderr, "[jamun] %s: n_p %d n_t %d steps %d mfma/k %lld; per-wave MFMAs per interval:", prefix.c_str(), F.n_p, F.n_t,
+              steps, (long long)total);
+      for (int w = 0; w < FWv; ++w) fprintf(stderr, " %lld", (long long)load[w]);
+      fprintf(stderr, "\n");
     }
   }
 
@@ -606,7 +627,7 @@ void forward(jamun_sampler* s, const float* y, float* xhat, float* score, hipStr
       f.deg = s->deg; f.esrc = s->esrc; f.egeo = s->egeo; f.h = s->h; f.x = x_in;
       f.n_atoms = s->n_atoms; f.n_pad = s->n_pad; f.S = s->S; f.XS = XSin; f.JR = s->fused_JR; f.tile_span = s->tile_span;
       f.wpack = L.fu.wpack; f.a_units = L.fu.a_units; f.b_units = L.fu.b_units; f.owner = L.fu.owner; f.segs = s->fused_segs;
-      f.k_stride = L.fu.k_stride; f.max_a = L.fu.max_a; f.n_dtiles = L.fu.n_dtiles; f.max_segs = s->fused_max_segs;
+      f.k_stride = L.fu.k_stride; f.max_a = L.fu.max_a; f.n_p = L.fu.n_p; f.n_t = L.fu.n_t; f.max_segs = s->fused_max_segs;
       f.nt0 = L.fu.nt0; f.partial0 = s->partial0; f.partial1 = s->partial1;
       ProfScope ps(s, l == 0 ? JAMUN_PROF_CONV0_INIT : JAMUN_PROF_CONV0, st);
       const int rcode = launch_conv_fused(f, s->fused_grid, st);
@@ -878,7 +899,16 @@ int jamun_sampler_create(const jamun_model* m, float sigma, const jamun_topology
       HIPCHECK(hipGetDeviceProperties(&prop, dev));
       const int cus = std::max(prop.multiProcessorCount, 1);
       const int n_k = hp.edge_attr_dim + 1;
-      const int ng = (cus % 8 == 0 && n_k >= 8) ? 8 : 1, ncx = cus / ng;
+      // Two k-slices measured best on MI355X (profiles/r1d): longer runs of k per segment amortise the pipeline ramp and the
+      // per-tile staging, and beat the better L2 residency of the weights with 8 slices (one per XCD).
+      int ng = (cus % 8 == 0 && n_k >= 8) ? 2 : 1;
+      if (const char* e = getenv("JAMUN_FUSED_KGROUPS")) {  // tuning aid: 1, 2, 4 or 8 k-slices (XCDs x, x + ng, ... share one)
+        const int v = atoi(e);
+        if ((v == 1 || v == 2 || v == 4 || v == 8) && cus % 8 == 0 && n_k >= v) ng = v;
+      }
+      const int ncx = cus / ng;
+      std::vector<std::vector<int>> wg_of(ng);  // workgroups of k-slice x, in launch order
+      for (int g = 0; g < cus; ++g) wg_of[ng == 1 ? 0 : (g % 8) % ng].push_back(g);
       const int base = n_k / ng, rem = n_k % ng;
       s->fused_grid = cus;
       std::vector<std::vector<int4>> wg_segs(cus);
@@ -897,7 +927,7 @@ int jamun_sampler_create(const jamun_model* m, float sigma, const jamun_topology
             const int64_t hi = (c + 1 < ncx) ? (Lx * (c + 1)) / ncx : Lx;
             const int i1 = (int)std::min<int64_t>(cnt, hi - off);
             const int kb = x * base + std::min(i0, base), ke = x * base + std::min(i1, base);
-            auto& v = wg_segs[(size_t)c * ng + x];
+            auto& v = wg_segs[wg_of[x][c]];
             v.push_back(make_int4(t, nslab[t]++, kb, ke));
             v.push_back(make_int4(i1 > base ? ex : -1, 0, 0, 0));
             i0 = i1;

@@ -12,16 +12,20 @@
 // packed in that K order.
 //
 // One persistent workgroup per CU = 8 waves.  Work items are (tile of 32 destination atoms, hidden unit k); a workgroup
-// walks a host-built list of segments (tile, run of k) — k is sliced over the 8 XCDs so every XCD's L2 holds only its own
-// weights, and the (tile, k) list of an XCD is cut evenly over its CUs (no tail round).  Per k two stages, one barrier
-// each:
-//   A  forming: the ~13 forming units of the k (4 scalar-input u-tiles, the dot-product u-tile, x1 / cross per plane, and
-//      the T tiles  T[j][w] = sum_u x0_j[u] W[(k,u)][w]  for the vector rows from scalar inputs) are spread over all
-//      waves; each result tile (16 registers x 64 lanes) is parked in LDS in register order (conflict-free b128).
-//   B  main: wave w < NT0 owns scalar-row tile w, waves NT0..NT0+2 own the vector planes.  An owner reads the formed
-//      tiles back as MFMA A operands (same lane, same register: no transpose) and runs the main K-steps against its
-//      weights; plane owners also apply  out_m[i][w] += sum_j C^{h v_m}[j][i] T[j][w]  with T as the B operand.
-// No accumulator is shared between waves: no cross-wave reduction, 16 accumulator registers per wave.
+// walks a host-built list of segments (tile, run of k) — k is sliced over the XCDs so every XCD's L2 holds only its own
+// weights, and the (tile, k) list of an XCD is cut evenly over its CUs (no tail round).
+//
+// Every wave OWNS one output tile: wave w < NT0 the scalar-row tile w, waves NT0..NT0+2 the vector planes.  No accumulator
+// is shared between waves: no cross-wave reduction, 16 accumulator registers per wave.  The k of a segment are software
+// pipelined with ONE barrier per k; in the interval of k
+//   * the scalar-row tiles D' of k+1 (4 scalar-input u-tiles, the dot-product u-tile) and the T tiles of k+2
+//     (T[j][w] = sum_u x0_j[u] W[(k,u)][w], vector rows from scalar inputs) are formed by statically assigned waves and
+//     parked in LDS in register order (conflict-free b128, same lane / same register when read back as an operand),
+//   * a scalar-row owner runs the main K-steps of k against the tiles formed one interval earlier,
+//   * a plane owner forms its x1 / cross tiles of k+1 in registers, runs their main K-steps at once, and applies
+//     out_m[i][w] += sum_j C^{h v_m}[j][i] T[j][w]  with the T tile of k+1 as the B operand,
+//   * all threads build the coefficient tiles of k+2 (double buffered; h~ values prefetched one interval ahead).
+// The forming units are dealt so that every SIMD (waves w and w+4) carries the same number of MFMAs per interval.
 // Feature rows and coefficient tiles are stored TRANSPOSED ([column][source row], row stride JR = 4 * odd) so the four
 // K-steps a lane needs are one ds_read_b128.
 #include <hip/hip_runtime.h>
@@ -58,20 +62,21 @@ __global__ __launch_bounds__(FT, 1) void k_conv_fused(FusedArgs a) {
   const int CT = 32 * JR;                                                   // floats per coefficient tile
   float* __restrict__ xT = lds;                                             // [XS][JR]
   float* __restrict__ cT = xT + a.XS * JR;                                  // [2][4][32][JR]
-  float4* __restrict__ d4 = reinterpret_cast<float4*>(cT + 2 * 4 * CT);     // [n_dtiles][4][64] formed tiles, register order
-  int* __restrict__ pm = reinterpret_cast<int*>(d4);                        // [32][JR] slot map (prologue only; aliases d4)
-  int* __restrict__ ua = reinterpret_cast<int*>(d4 + a.n_dtiles * 256);     // [FW][max_a][8] stage A units
-  int* __restrict__ ub = ua + FW * a.max_a * 8;                             // [FW][MAXB][4] stage B entries
-  int* __restrict__ deg_lds = ub + FW * MAXB * 4;                           // [32]
+  float4* __restrict__ dP = reinterpret_cast<float4*>(cT + 2 * 4 * CT);     // [2][n_p][4][64] formed scalar-row tiles
+  float4* __restrict__ dT = dP + 2 * a.n_p * 256;                           // [2][n_t][4][64] T tiles
+  int* __restrict__ pm = reinterpret_cast<int*>(dP);                        // [32][JR] slot map (prologue only; aliases dP)
+  int* __restrict__ ua = reinterpret_cast<int*>(dT + 2 * a.n_t * 256);      // [FW][max_a][8] forming units
+  int* __restrict__ ub = ua + FW * a.max_a * 8;                             // [FW][MAXB][8] owner entries
+  int* __restrict__ deg_lds = ub + FW * MAXB * 8;                           // [32]
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = RFL(tid >> 6);
   const int r = lane & 31, hh = lane >> 5;
 
   // ---- once per workgroup: the unit tables
   for (int idx = tid; idx < FW * a.max_a * 8; idx += FT) ua[idx] = reinterpret_cast<const int*>(a.a_units)[idx];
-  for (int idx = tid; idx < FW * MAXB * 4; idx += FT) ub[idx] = reinterpret_cast<const int*>(a.b_units)[idx];
+  for (int idx = tid; idx < FW * MAXB * 8; idx += FT) ub[idx] = reinterpret_cast<const int*>(a.b_units)[idx];
   const int4* __restrict__ my_a = reinterpret_cast<const int4*>(ua + wave * a.max_a * 8);
-  const int4* __restrict__ my_b = reinterpret_cast<const int4*>(ub + wave * MAXB * 4);
+  const int4* __restrict__ my_b = reinterpret_cast<const int4*>(ub + wave * MAXB * 8);
   const int4 own = a.owner[wave];  // {kind: -1 none / 0 scalar-row tile / 1 vector plane, index}
   const int own_kind = RFL(own.x), own_idx = RFL(own.y);
 
@@ -85,15 +90,83 @@ __global__ __launch_bounds__(FT, 1) void k_conv_fused(FusedArgs a) {
     if (tile < 0) break;
     const int slab = RFL(sg0.y), k_begin = RFL(sg0.z), k_run = RFL(sg0.w) - k_begin, k_extra = RFL(sg1.x);
     const int nk = k_run + (k_extra >= 0 ? 1 : 0);
+    auto k_of = [&](int kk) { return kk < k_run ? k_begin + kk : k_extra; };
     FSTAMP(t0);
     const int n0 = tile * 32;
     const int2 span = a.tile_span[tile];
     const int rows = span.y - span.x;
     const int Jt4 = (rows + 3) & ~3;  // K extent of the forming products for this tile
     const int n8 = Jt4 >> 3, tail4 = Jt4 & 4;
-    __syncthreads();  // the previous segment is done with the tiles (pm aliases the formed tiles)
 
-    // ---- per segment: transposed feature rows, (source, destination) -> edge-slot map, per-pair edge geometry
+    // D'[u][i] += sum_j X[j][u] C[j][i] over the terms of a forming unit (transposed tiles: four K-steps per b128 read)
+    auto form = [&](f32x16& af, int n_terms, const int4& ut, const float* __restrict__ cb) {
+#pragma unroll
+      for (int t = 0; t < 3; ++t) {
+        if (t >= n_terms) break;  // wave-uniform
+        const int td = RFL(t == 0 ? ut.x : (t == 1 ? ut.y : ut.z));
+        const int xcol0 = td & 0xfff, stride = (td >> 12) & 0xf, ctype = (td >> 16) & 0xf;
+        const float sgn = (td >> 20) & 1 ? -1.f : 1.f;
+        const float* __restrict__ xq = xT + (xcol0 + r * stride) * JR;
+        const float* __restrict__ cq = cb + ctype * CT + r * JR;
+        const float4* __restrict__ xp = reinterpret_cast<const float4*>(xq + 4 * hh);  // rows 8g + 4hh + (0..3)
+        const float4* __restrict__ cp = reinterpret_cast<const float4*>(cq + 4 * hh);
+        if (n8 > 0) {
+          float4 av = xp[0], bv = cp[0];
+          for (int g = 0; g < n8; ++g) {
+            float4 an = av, bn = bv;
+            if (g + 1 < n8) { an = xp[2 * (g + 1)]; bn = cp[2 * (g + 1)]; }
+            af = MFMA(av.x, bv.x * sgn, af);
+            af = MFMA(av.y, bv.y * sgn, af);
+            af = MFMA(av.z, bv.z * sgn, af);
+            af = MFMA(av.w, bv.w * sgn, af);
+            av = an; bv = bn;
+          }
+        }
+        if (tail4) {  // four more source rows: two K-steps, rows 8 n8 + 2s + hh
+          const float a0 = xq[8 * n8 + hh], b0 = cq[8 * n8 + hh];
+          const float a1 = xq[8 * n8 + 2 + hh], b1 = cq[8 * n8 + 2 + hh];
+          af = MFMA(a0, b0 * sgn, af);
+          af = MFMA(a1, b1 * sgn, af);
+        }
+      }
+    };
+    // T tile: T[j][w] = sum_u x0_j[u] W[(k,u)][w] for one 32-row tile of source atoms.  A operand straight from the
+    // transposed feature rows (lane = row: consecutive banks), B operand = weights (4-block register ring).
+    auto t_form = [&](const int4& ud, const int4& ut, const float4* __restrict__ wk, float4 (&ring)[4], int dbuf) {
+      const int tix = RFL(ud.y), wofs = RFL(ud.z), jt = RFL(ut.x), nsg = RFL(ut.y), xcol0 = RFL(ut.z);
+      if (32 * jt >= Jt4) return;  // wave-uniform: the tile sees no source atom in this row tile
+      int row = 32 * jt + r;
+      row = row < JR ? row : JR - 1;  // rows past the tile hold finite stand-ins; their coefficients are zero
+      const float* __restrict__ xr = xT + (xcol0 + hh) * JR + row;
+      f32x16 af;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) af[q] = 0.f;
+      for (int sg = 0; sg < nsg; sg += 4) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          if (sg + i < nsg) {  // wave-uniform
+            const float4 w = ring[i];
+            if (sg + i + 4 < nsg) ring[i] = wk[(wofs + sg + i + 4) * 64];
+            const float* __restrict__ xs = xr + 8 * (sg + i) * JR;
+            af = MFMA(xs[0], w.x, af);
+            af = MFMA(xs[2 * JR], w.y, af);
+            af = MFMA(xs[4 * JR], w.z, af);
+            af = MFMA(xs[6 * JR], w.w, af);
+          }
+        }
+      }
+#pragma unroll
+      for (int qg = 0; qg < 4; ++qg)
+        dT[((dbuf * a.n_t + tix) * 4 + qg) * 64 + lane] = make_float4(af[4 * qg], af[4 * qg + 1], af[4 * qg + 2], af[4 * qg + 3]);
+    };
+    auto t_ring = [&](const int4& ud, const int4& ut, const float4* __restrict__ wk, float4 (&ring)[4]) {
+      const int wofs = RFL(ud.z), nsg = RFL(ut.y);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) ring[i] = wk[(wofs + (i < nsg ? i : nsg - 1)) * 64];
+    };
+
+    // ---- per segment: transposed feature rows, (source, destination) -> edge-slot map, per-pair edge geometry.
+    // (The previous segment ended with a barrier: nobody reads the tiles any more.)
     {
       const int ncg = (a.XS + 3) >> 2;  // 16-byte column groups; lane = source row
       const float* __restrict__ xrow = a.x + (size_t)(span.x + (lane < rows ? lane : 0)) * a.XS;
@@ -141,6 +214,17 @@ __global__ __launch_bounds__(FT, 1) void k_conv_fused(FusedArgs a) {
         atomicOr(&pm[il * JR + jl], (sj < 0) ? ((t + 1) << 8) : (t + 1));
       }
     }
+    // the T tiles of the first k need only the feature rows: formed here, behind the latency of the map build
+    for (int ui = 0; ui < a.max_a; ++ui) {
+      const int4 ud = my_a[2 * ui], ut = my_a[2 * ui + 1];
+      const int kind = RFL(ud.x);
+      if (kind < 0) break;
+      if (kind != 1) continue;
+      const float4* __restrict__ wk = a.wpack + (size_t)k_of(0) * a.k_stride + lane;
+      float4 ring[4];
+      t_ring(ud, ut, wk, ring);
+      t_form(ud, ut, wk, ring, 0);
+    }
     __syncthreads();
     // Each thread owns up to FPAIRS (destination il, source row j) pairs, p = il * JR + j: slots, unit vectors and h~
     // addresses live in registers for the whole segment.
@@ -181,169 +265,124 @@ __global__ __launch_bounds__(FT, 1) void k_conv_fused(FusedArgs a) {
         }
       }
     };
-    auto k_of = [&](int kk) { return kk < k_run ? k_begin + kk : k_extra; };
 
     f32x16 acc;
 #pragma unroll
     for (int q = 0; q < 16; ++q) acc[q] = 0.f;
     load_h(k_of(0));
-    write_c(cT);
+    write_c(cT);  // (the slot map, aliased on dP, is dead after the barrier below)
     FSTAMP(t1);
 #ifdef JAMUN_STAMP
     s_pro += t1 - t0;
 #endif
+    LDS_BARRIER();
 
-    for (int kk = 0; kk < nk; ++kk) {
-      const int k = k_of(kk);
-      float* __restrict__ cb = cT + (kk & 1) * 4 * CT;
-      const float4* __restrict__ wk = a.wpack + (size_t)k * a.k_stride + lane;
+    // ---- software pipeline over the k of the segment, ONE barrier per interval.  Interval `it` runs
+    //   T tiles of k(it+2)                     (feature rows x weights; no coefficient tile)        -> dT[(it+2)&1]
+    //   forming of k(it+1) from C(k(it+1))     (scalar-row tiles -> dP[(it+1)&1]; plane owners form their x1 / cross
+    //                                           tiles in registers and run the main K-steps at once; apply T(k(it+1)))
+    //   main K-steps of k(it) from dP[it&1]    (scalar-row owners)
+    //   build of C(k(it+2)) into the buffer C(k(it)) occupied (last read in interval it-1)
+    for (int it = -1; it < nk; ++it) {
+      const bool v_main = it >= 0, v_next = it + 1 < nk, v_t = it + 2 < nk;
+      const int k1 = v_next ? k_of(it + 1) : 0, k2 = v_t ? k_of(it + 2) : 0;
+      const float* __restrict__ cb = cT + ((it + 1) & 1) * 4 * CT;  // C(k(it+1))
       FSTAMP(t0);
-      if (kk + 1 < nk) load_h(k_of(kk + 1));  // in flight behind both stages, written to the other buffer after stage B
-      // weights of the first two stage-B entries and of this wave's T tile: in flight behind stage A
+      if (v_t) load_h(k2);  // in flight behind the interval, written to the free buffer at its end
+      const bool v_own = own_kind == 0 ? v_main : v_next;
+      const float4* __restrict__ wkb = a.wpack + (size_t)(own_kind == 0 ? (v_main ? k_of(it) : 0) : k1) * a.k_stride + lane;
+      const float4* __restrict__ wkt = a.wpack + (size_t)k2 * a.k_stride + lane;
+      // weights of the first two owner entries: in flight behind the forming units
       float4 wb[2][4];
 #pragma unroll
       for (int e = 0; e < 2; ++e) {
-        const int4 bd = my_b[e];
+        const int4 bd = my_b[2 * e];
         const int kind = RFL(bd.x), wofs = RFL(bd.z);
 #pragma unroll
         for (int q = 0; q < 4; ++q) wb[e][q] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (kind == 0) {
+        if (v_own && (kind == 0 || kind == 2)) {
 #pragma unroll
-          for (int q = 0; q < 4; ++q) wb[e][q] = wk[(wofs + q) * 64];
+          for (int q = 0; q < 4; ++q) wb[e][q] = wkb[(wofs + q) * 64];
         }
       }
-      float4 tring[4];
-      int t_pre = -1;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) tring[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-      for (int ui = 0; ui < a.max_a; ++ui) {
-        const int4 ud = my_a[2 * ui];
-        const int kind = RFL(ud.x);
-        if (kind < 0) break;
-        if (kind == 1) {
-          const int wofs = RFL(ud.z), nsg = RFL(my_a[2 * ui + 1].y);
-#pragma unroll
-          for (int i = 0; i < 4; ++i) tring[i] = wk[(wofs + (i < nsg ? i : nsg - 1)) * 64];
-          t_pre = ui;
-          break;
-        }
-      }
-      LDS_BARRIER();  // C(k) is built; stage B of the previous k is done with the formed tiles
-      FSTAMP(t1);
 
-      // ================= stage A: forming =================
+      // ================= forming units of this wave =================
       for (int ui = 0; ui < a.max_a; ++ui) {
         const int4 ud = my_a[2 * ui];
         const int4 ut = my_a[2 * ui + 1];
-        const int kind = RFL(ud.x), dtile = RFL(ud.y);
+        const int kind = RFL(ud.x);
         if (kind < 0) break;
-        f32x16 af;
-#pragma unroll
-        for (int q = 0; q < 16; ++q) af[q] = 0.f;
         if (kind == 1) {
-          // T tile: T[j][w] = sum_u x0_j[u] W[(k,u)][w] for one 32-row tile of source atoms.  A operand straight from
-          // the transposed feature rows (lane = row: consecutive banks), B operand = weights.
-          const int wofs = RFL(ud.z), jt = RFL(ut.x), nsg = RFL(ut.y), xcol0 = RFL(ut.z);
-          if (32 * jt >= Jt4) continue;  // wave-uniform: the tile sees no source atom in this row tile
-          int row = 32 * jt + r;
-          row = row < JR ? row : JR - 1;  // rows past the tile hold finite stand-ins; their coefficients are zero
-          const float* __restrict__ xr = xT + (xcol0 + hh) * JR + row;
+          if (!v_t) continue;
           float4 ring[4];
-          if (t_pre == ui) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) ring[i] = tring[i];
-          } else {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) ring[i] = wk[(wofs + (i < nsg ? i : nsg - 1)) * 64];
-          }
-          for (int sg = 0; sg < nsg; sg += 4) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-              if (sg + i < nsg) {  // wave-uniform
-                const float4 w = ring[i];
-                if (sg + i + 4 < nsg) ring[i] = wk[(wofs + sg + i + 4) * 64];
-                const float* __restrict__ xs = xr + 8 * (sg + i) * JR;
-                af = MFMA(xs[0], w.x, af);
-                af = MFMA(xs[2 * JR], w.y, af);
-                af = MFMA(xs[4 * JR], w.z, af);
-                af = MFMA(xs[6 * JR], w.w, af);
-              }
-            }
-          }
+          t_ring(ud, ut, wkt, ring);
+          t_form(ud, ut, wkt, ring, (it + 2) & 1);
         } else {
-          const int n_terms = RFL(ud.z);
+          if (!v_next) continue;
+          const int tix = RFL(ud.y);
+          f32x16 af;
 #pragma unroll
-          for (int t = 0; t < 3; ++t) {
-            if (t >= n_terms) break;  // wave-uniform
-            const int td = RFL(t == 0 ? ut.x : (t == 1 ? ut.y : ut.z));
-            const int xcol0 = td & 0xfff, stride = (td >> 12) & 0xf, ctype = (td >> 16) & 0xf;
-            const float sgn = (td >> 20) & 1 ? -1.f : 1.f;
-            const float* __restrict__ xq = xT + (xcol0 + r * stride) * JR;
-            const float* __restrict__ cq = cb + ctype * CT + r * JR;
-            const float4* __restrict__ xp = reinterpret_cast<const float4*>(xq + 4 * hh);  // rows 8g + 4hh + (0..3)
-            const float4* __restrict__ cp = reinterpret_cast<const float4*>(cq + 4 * hh);
-            if (n8 > 0) {
-              float4 av = xp[0], bv = cp[0];
-              for (int g = 0; g < n8; ++g) {
-                float4 an = av, bn = bv;
-                if (g + 1 < n8) { an = xp[2 * (g + 1)]; bn = cp[2 * (g + 1)]; }
-                af = MFMA(av.x, bv.x * sgn, af);
-                af = MFMA(av.y, bv.y * sgn, af);
-                af = MFMA(av.z, bv.z * sgn, af);
-                af = MFMA(av.w, bv.w * sgn, af);
-                av = an; bv = bn;
-              }
-            }
-            if (tail4) {  // four more source rows: two K-steps, rows 8 n8 + 2s + hh
-              const float a0 = xq[8 * n8 + hh], b0 = cq[8 * n8 + hh];
-              const float a1 = xq[8 * n8 + 2 + hh], b1 = cq[8 * n8 + 2 + hh];
-              af = MFMA(a0, b0 * sgn, af);
-              af = MFMA(a1, b1 * sgn, af);
-            }
-          }
+          for (int q = 0; q < 16; ++q) af[q] = 0.f;
+          form(af, RFL(ud.z), ut, cb);
+#pragma unroll
+          for (int qg = 0; qg < 4; ++qg)
+            dP[((((it + 1) & 1) * a.n_p + tix) * 4 + qg) * 64 + lane] =
+                make_float4(af[4 * qg], af[4 * qg + 1], af[4 * qg + 2], af[4 * qg + 3]);
         }
-#pragma unroll
-        for (int qg = 0; qg < 4; ++qg)
-          d4[(dtile * 4 + qg) * 64 + lane] = make_float4(af[4 * qg], af[4 * qg + 1], af[4 * qg + 2], af[4 * qg + 3]);
       }
-      FSTAMP(t2);
-      LDS_BARRIER();  // formed tiles are visible
-      FSTAMP(t3);
+      FSTAMP(t1);
 
-      // ================= stage B: main K-steps into the tile this wave owns =================
+      // ================= owner entries: K-steps into the tile this wave owns =================
 #pragma unroll
       for (int e = 0; e < MAXB; ++e) {
-        const int4 bd = my_b[e];
-        const int kind = RFL(bd.x), dtile = RFL(bd.y);
+        const int4 bd = my_b[2 * e];
+        const int kind = RFL(bd.x), tix = RFL(bd.y);
         if (kind < 0) break;
-        if (kind == 0) {
+        if (kind == 0 || kind == 2) {
+          if (!v_own) continue;
           float4 w[4];
 #pragma unroll
           for (int q = 0; q < 4; ++q) w[q] = wb[e & 1][q];
           if (e + 2 < MAXB) {
-            const int4 bn = my_b[e + 2];
-            if (RFL(bn.x) == 0) {
+            const int4 bn = my_b[2 * (e + 2)];
+            const int kn = RFL(bn.x);
+            if (kn == 0 || kn == 2) {
               const int wofs = RFL(bn.z);
 #pragma unroll
-              for (int q = 0; q < 4; ++q) wb[e & 1][q] = wk[(wofs + q) * 64];
+              for (int q = 0; q < 4; ++q) wb[e & 1][q] = wkb[(wofs + q) * 64];
             }
           }
+          if (kind == 0) {  // scalar-row tile formed in the previous interval
 #pragma unroll
-          for (int qg = 0; qg < 4; ++qg) {
-            const float4 av = d4[(dtile * 4 + qg) * 64 + lane];
-            acc = MFMA(av.x, w[qg].x, acc);
-            acc = MFMA(av.y, w[qg].y, acc);
-            acc = MFMA(av.z, w[qg].z, acc);
-            acc = MFMA(av.w, w[qg].w, acc);
+            for (int qg = 0; qg < 4; ++qg) {
+              const float4 av = dP[(((it & 1) * a.n_p + tix) * 4 + qg) * 64 + lane];
+              acc = MFMA(av.x, w[qg].x, acc);
+              acc = MFMA(av.y, w[qg].y, acc);
+              acc = MFMA(av.z, w[qg].z, acc);
+              acc = MFMA(av.w, w[qg].w, acc);
+            }
+          } else {  // plane owner: form the tile in registers, feed the accumulator registers straight into the main MFMAs
+            f32x16 af;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) af[q] = 0.f;
+            form(af, tix, my_b[2 * e + 1], cb);
+#pragma unroll
+            for (int qg = 0; qg < 4; ++qg) {
+              acc = MFMA(af[4 * qg + 0], w[qg].x, acc);
+              acc = MFMA(af[4 * qg + 1], w[qg].y, acc);
+              acc = MFMA(af[4 * qg + 2], w[qg].z, acc);
+              acc = MFMA(af[4 * qg + 3], w[qg].w, acc);
+            }
           }
         } else {
           // out_m[i][w] += sum_j C^{h v_m}[j][i] T[j][w]: A operand = coefficient tile rows in T's register order
+          if (!v_next) continue;
           const int m = RFL(bd.z), jt = RFL(bd.w);
           if (32 * jt >= Jt4) continue;
           const float* __restrict__ cm = cb + (1 + m) * CT + r * JR + 32 * jt + 4 * hh;
 #pragma unroll
           for (int qg = 0; qg < 4; ++qg) {
-            const float4 tv = d4[(dtile * 4 + qg) * 64 + lane];
+            const float4 tv = dT[((((it + 1) & 1) * a.n_t + tix) * 4 + qg) * 64 + lane];
             float4 cv = make_float4(0.f, 0.f, 0.f, 0.f);
             if (32 * jt + 4 * hh + 8 * qg < JR) cv = *reinterpret_cast<const float4*>(cm + 8 * qg);
             acc = MFMA(cv.x, tv.x, acc);
@@ -353,14 +392,13 @@ __global__ __launch_bounds__(FT, 1) void k_conv_fused(FusedArgs a) {
           }
         }
       }
-      FSTAMP(t4);
-      if (kk + 1 < nk) write_c(cT + ((kk + 1) & 1) * 4 * CT);
+      FSTAMP(t2);
+      if (v_t) write_c(cT + (it & 1) * 4 * CT);
+      FSTAMP(t3);
+      LDS_BARRIER();
 #ifdef JAMUN_STAMP
-      {
-        unsigned long long t5;
-        FSTAMP(t5);
-        s_wait += (t1 - t0) + (t3 - t2); s_a += t2 - t1; s_b += t4 - t3; s_build += t5 - t4;
-      }
+      FSTAMP(t4);
+      s_a += t1 - t0; s_b += t2 - t1; s_build += t3 - t2; s_wait += t4 - t3;
 #endif
     }
 
@@ -393,16 +431,16 @@ __global__ __launch_bounds__(FT, 1) void k_conv_fused(FusedArgs a) {
 #endif
 }
 
-size_t fused_lds_bytes(int XS, int JR, int n_dtiles, int max_a) {
-  const size_t fl = (size_t)XS * JR + 2 * 4 * 32 * (size_t)JR + (size_t)n_dtiles * 1024 + (size_t)FW * max_a * 8 +
-                    (size_t)FW * MAXB * 4 + 32;
+size_t fused_lds_bytes(int XS, int JR, int n_p, int n_t, int max_a) {
+  const size_t fl = (size_t)XS * JR + 2 * 4 * 32 * (size_t)JR + 2 * (size_t)(n_p + n_t) * 1024 + (size_t)FW * max_a * 8 +
+                    (size_t)FW * MAXB * 8 + 32;
   return sizeof(float) * ((fl + 3) & ~(size_t)3);
 }
 
 int launch_conv_fused(const FusedArgs& a, int grid, hipStream_t st) {
-  const size_t smem = fused_lds_bytes(a.XS, a.JR, a.n_dtiles, a.max_a);
+  const size_t smem = fused_lds_bytes(a.XS, a.JR, a.n_p, a.n_t, a.max_a);
   if (smem > JAMUN_MAX_DYN_LDS) return -2;
-  if (32 * a.JR > a.n_dtiles * 1024) return -1;  // the slot map aliases the formed tiles
+  if (32 * a.JR > 2 * a.n_p * 1024) return -1;  // the slot map aliases the formed scalar-row tiles
   hipLaunchKernelGGL(k_conv_fused, dim3(grid), dim3(FT), smem, st, a);
   return 0;
 }

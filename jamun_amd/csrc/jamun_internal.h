@@ -50,15 +50,15 @@ struct FusedArgs {
   int n_atoms, n_pad, S, XS, JR;  // JR: row stride of the transposed feature / coefficient tiles (4 * odd, >= every tile span)
   const int2* tile_span;  // [n_tiles] {lo, hi}: atoms whose features the tile's in-edges can read (whole molecules)
   const float4* wpack;    // [k][k_stride] 16-byte weight fragments (blocks of 64 lanes)
-  // stage A units [waves][max_a][2]: {kind (0 forming from coefficient tiles, 1 T tile, -1 end), formed-tile id,
+  // forming units [waves][max_a][2]: {kind (0 scalar-row tile from coefficient tiles, 1 T tile, -1 end), tile index,
   //   n_terms | weight block, 0}, {term0, term1, term2, 0} | {row tile, weight groups, first x0 column, 0}
   const int4* a_units;
-  // stage B entries [waves][JAMUN_FUSED_MAX_B]: {kind (0 main K-steps, 1 apply T, -1 end), formed-tile id,
-  //   weight block | plane, row tile}
+  // owner entries [waves][JAMUN_FUSED_MAX_B][2]: {kind (0 main K-steps of a parked tile, 1 apply T, 2 form in registers
+  //   + main K-steps, -1 end), tile index | n_terms, weight block | plane, row tile}, {term0, term1, term2, 0}
   const int4* b_units;
   const int4* owner;  // [waves] {kind (-1 none, 0 scalar-row tile, 1 vector plane), index, 0, 0}
   const int4* segs;   // [grid][max_segs][2]: {tile (-1 end), slab, k_begin, k_end}, {k_extra (-1 none), 0, 0, 0}
-  int k_stride, max_a, n_dtiles, max_segs, nt0;
+  int k_stride, max_a, n_p, n_t, max_segs, nt0;  // n_p / n_t: parked scalar-row / T tiles per k
   float* partial0;  // [slab][n_pad][nt0*32]
   float* partial1;  // [slab][n_pad][3][32]
 };
@@ -113,7 +113,7 @@ int conv_set_max_lds();
 int launch_conv_fused(const FusedArgs& a, int grid, hipStream_t st);
 int conv_fused_set_max_lds();
 int conv_fused_read_stamps(unsigned long long* out8);
-size_t fused_lds_bytes(int XS, int JR, int n_dtiles, int max_a);
+size_t fused_lds_bytes(int XS, int JR, int n_p, int n_t, int max_a);
 void launch_node_update(const NodeArgs& a, hipStream_t st);
 void launch_head(const HeadArgs& a, hipStream_t st);
 void launch_finalize(const float* y, const float* yc, const float* g, const int* ptr, int n_graphs, float c_skip,
