@@ -107,7 +107,9 @@ struct LayerDev {
   ConvProblemDev p0, p1;
   FusedDev fu;
   float *w1r = nullptr, *cmask = nullptr;
-  float *w_self0 = nullptr, *w_self1 = nullptr, *w_skip0 = nullptr, *w_skip1 = nullptr, *mix = nullptr;
+  float4 *wcat0 = nullptr, *wcat1 = nullptr;  // node update: [W_self ; W_skip] as MFMA fragments
+  int K0p = 0, K1p = 0;
+  float* mix = nullptr;
   int in0 = 0, in1 = 0, XSin = 0;
   int64_t tp_numel = 0;
 };
@@ -287,8 +289,7 @@ struct jamun_sampler {
     hipFree(fused_segs); hipFree(tile_nslab);
     for (auto& L : layers) {
       free_problem(L.p0); free_problem(L.p1); free_fused(L.fu);
-      hipFree(L.w1r); hipFree(L.cmask); hipFree(L.w_self0); hipFree(L.w_self1); hipFree(L.w_skip0);
-      hipFree(L.w_skip1); hipFree(L.mix);
+      hipFree(L.w1r); hipFree(L.cmask); hipFree(L.wcat0); hipFree(L.wcat1); hipFree(L.mix);
     }
     hipFree(w_gate); hipFree(w_vec); hipFree(w_out);
     hipFree(yc); hipFree(h); hipFree(partial0); hipFree(partial1); hipFree(g); hipFree(tmp);
@@ -581,10 +582,28 @@ LayerDev build_layer(const jamun_model& m, const std::string& prefix, const std:
   std::vector<float> wf0((size_t)mul0 * mul0), wf1((size_t)std::max(mul1 * mul1, 1));
   for (int i = 0; i < mul0 * mul0; ++i) wf0[i] = (float)((double)Wself[i] / std::sqrt((double)mul0));
   for (int i = 0; i < mul1 * mul1; ++i) wf1[i] = (float)((double)Wself[(size_t)mul0 * mul0 + i] / std::sqrt((double)mul1));
-  L.w_skip0 = dev_upload(ws0);
-  L.w_skip1 = dev_upload(ws1);
-  L.w_self0 = dev_upload(wf0);
-  L.w_self1 = dev_upload(wf1);
+  // concatenate along K ([self ; skip]) and pack as MFMA B fragments for k_node_update
+  auto pack_cat = [](const std::vector<float>& wself, int ks, const std::vector<float>& wskip, int kk, int ncol, int& Kp) {
+    Kp = (ks + kk + 7) & ~7;
+    const int nt = (ncol + 31) / 32, nsg = Kp / 8;
+    std::vector<float4> out((size_t)nt * nsg * 64, make_float4(0.f, 0.f, 0.f, 0.f));
+    for (int t = 0; t < nt; ++t)
+      for (int sg = 0; sg < nsg; ++sg)
+        for (int lane = 0; lane < 64; ++lane) {
+          const int hh = lane >> 5, c = t * 32 + (lane & 31);
+          float v[4] = {0.f, 0.f, 0.f, 0.f};
+          for (int st = 0; st < 4; ++st) {
+            const int row = 2 * (4 * sg + st) + hh;
+            if (c >= ncol) continue;
+            if (row < ks) v[st] = wself[(size_t)row * ncol + c];
+            else if (row < ks + kk) v[st] = wskip[(size_t)(row - ks) * ncol + c];
+          }
+          out[((size_t)t * nsg + sg) * 64 + lane] = make_float4(v[0], v[1], v[2], v[3]);
+        }
+    return out;
+  };
+  L.wcat0 = dev_upload(pack_cat(wf0, mul0, ws0, in0, mul0, L.K0p));
+  L.wcat1 = dev_upload(pack_cat(wf1, mul1, ws1, in1, std::max(mul1, 1), L.K1p));
   return L;
 }
 
@@ -650,7 +669,7 @@ void forward(jamun_sampler* s, const float* y, float* xhat, float* score, hipStr
     }
     NodeArgs n{};
     n.partial0 = s->partial0; n.partial1 = s->partial1; n.deg = s->deg; n.x_in = x_in; n.x_out = s->x[l];
-    n.w_self0 = L.w_self0; n.w_self1 = L.w_self1; n.w_skip0 = L.w_skip0; n.w_skip1 = L.w_skip1; n.mix = L.mix;
+    n.wcat0 = L.wcat0; n.wcat1 = L.wcat1; n.K0p = L.K0p; n.K1p = L.K1p; n.mix = L.mix;
     n.cL = s->hp.act_scalar_const; n.cS = s->hp.act_gate_const;
     n.n_atoms = s->n_atoms; n.n_pad = s->n_pad; n.n_slices = s->n_slices; n.nt0 = L.p0.nt; n.nt1 = L.p1.nt;
     n.mul0 = s->hp.mul0; n.mul1 = s->hp.mul1; n.in0 = L.in0; n.in1 = L.in1; n.XSin = XSin;
@@ -781,7 +800,7 @@ int jamun_sampler_create(const jamun_model* m, float sigma, const jamun_topology
     s->S = std::min(std::max(nmax - 1, 0), JAMUN_MAX_NEIGHBORS + 1) + max_in;
     if (s->S < 1) s->S = 1;
     s->n_tiles = s->n_pad / 32;
-    if (conv_set_max_lds() != 0 || conv_fused_set_max_lds() != 0)
+    if (conv_set_max_lds() != 0 || conv_fused_set_max_lds() != 0 || node_update_set_max_lds() != 0)
       throw Err(JAMUN_ERR_HIP, "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed");
     {
       std::vector<int2> spans(s->n_tiles);

@@ -69,10 +69,11 @@ struct NodeArgs {
   const int* deg;
   const float* x_in;  // [n_atoms][XSin]  (x_old for hidden layers, scaled embedding for the initial projector)
   float* x_out;       // [n_atoms][mul0+3*mul1]
-  const float* w_self0;  // [mul0][mul0]
-  const float* w_self1;  // [mul1][mul1]
-  const float* w_skip0;  // [in0][mul0]
-  const float* w_skip1;  // [in1][mul1]
+  // [W_self ; W_skip] concatenated along K, padded to K0p / K1p rows, as MFMA B fragments: wcat0 [nt][K0p/8][64 lanes]
+  // float4 (lane (c, hh): rows 2 (4 sg + st) + hh, column 32 nt + c), wcat1 [K1p/8][64]
+  const float4* wcat0;
+  const float4* wcat1;
+  int K0p, K1p;
   const float* mix;      // [mul0+mul1] or nullptr (initial projector)
   float cL, cS;
   int n_atoms, n_pad, n_slices, nt0, nt1;
@@ -115,6 +116,8 @@ int conv_fused_set_max_lds();
 int conv_fused_read_stamps(unsigned long long* out8);
 size_t fused_lds_bytes(int XS, int JR, int n_p, int n_t, int max_a);
 void launch_node_update(const NodeArgs& a, hipStream_t st);
+size_t node_update_lds_bytes(const NodeArgs& a);
+int node_update_set_max_lds();
 void launch_head(const HeadArgs& a, hipStream_t st);
 void launch_finalize(const float* y, const float* yc, const float* g, const int* ptr, int n_graphs, float c_skip,
                      float c_out, float sigma2, int mean_center, float* tmp, float* xhat, float* score,

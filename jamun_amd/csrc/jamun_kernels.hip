@@ -165,86 +165,155 @@ __global__ __launch_bounds__(256) void k_edge_h(const int* __restrict__ deg, con
 // Linear, skip Linear, noise-conditional skip mix.
 // (src/jamun/e3tools/nn/_conv.py:117, _gate.py:53-64, _interaction.py:26-30, model/noise_conditioning.py:69-73)
 // ------------------------------------------------------------------------------------------------
-#define NB_NODES 8
-__global__ __launch_bounds__(256) void k_node_update(NodeArgs a) {
+// One workgroup = 32 atoms, 8 waves.  Phase 1 (all threads) builds the two Linear inputs TRANSPOSED in LDS
+// ([K][33]: lane = atom, conflict-free): scalars [act(m0) | x_in scalars], per vector plane [gate * m1 | x_in vectors].
+// Phase 2 runs both o3.Linear layers (self-interaction + skip, concatenated along K) on the matrix cores:
+// one job per wave: scalar output tile nt (32 columns) or one vector plane.  Weights are host-packed
+// 16-byte fragments in MFMA operand order (4 consecutive K-steps of one lane).
+typedef float nu_f32x16 __attribute__((ext_vector_type(16)));
+#define NU_LD 33
+#define NU_T 512  // threads per workgroup
+#define NU_U 4    // independent elements per thread and pass (phase 1)
+#define NU_V 8    // vector-row elements per thread: 32 atoms x 3 planes x 32 channels / NU_T, rounded up (nt1 == 1)
+__global__ __launch_bounds__(NU_T) void k_node_update(NodeArgs a) {
   extern __shared__ float sm[];
   const int G0 = a.mul0 + a.mul1;
-  float* s_a = sm;                               // [NB][mul0]
-  float* s_gate = s_a + NB_NODES * a.mul0;       // [NB][mul1]
-  float* s_vec = s_gate + NB_NODES * a.mul1;     // [NB][mul1*3]
-  float* s_xin = s_vec + NB_NODES * a.mul1 * 3;  // [NB][XSin]
-  const int n0 = blockIdx.x * NB_NODES;
-  const int tid = threadIdx.x;
+  const int K0 = a.K0p, K1 = a.K1p;                 // padded contraction depths (multiples of 8)
+  float* __restrict__ A0 = sm;                      // [K0][33]
+  float* __restrict__ A1 = A0 + K0 * NU_LD;         // [3][K1][33]
+  float* __restrict__ s_gate = A1 + 3 * K1 * NU_LD; // [32][mul1]
+  const int n0 = blockIdx.x * 32;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 31, hh = lane >> 5;
   const int w0 = a.nt0 * 32;  // padded row width of partial0
-  for (int idx = tid; idx < NB_NODES * G0; idx += blockDim.x) {
-    const int nb = idx / G0, w = idx % G0, i = n0 + nb;
-    float m = 0.f;
-    if (i < a.n_atoms) {
-      const int ns = a.tile_nslab ? a.tile_nslab[i >> 5] : a.n_slices;
-      for (int s = 0; s < ns; ++s) m += a.partial0[((size_t)s * a.n_pad + i) * w0 + w];
-      const int d = a.deg[i];
-      m = m / (float)(d < 1 ? 1 : d);
-    }
-    if (w < a.mul0) s_a[nb * a.mul0 + w] = a.cL * (m > 0.f ? m : 0.01f * m);
-    else s_gate[nb * a.mul1 + (w - a.mul0)] = a.cS / (1.f + expf(-m));
-  }
-  for (int idx = tid; idx < NB_NODES * a.XSin; idx += blockDim.x) {
-    const int nb = idx / a.XSin, u = idx % a.XSin, i = n0 + nb;
-    s_xin[idx] = (i < a.n_atoms) ? a.x_in[(size_t)i * a.XSin + u] : 0.f;
-  }
-  __syncthreads();
   const int w1 = a.nt1 * 32;
-  for (int idx = tid; idx < NB_NODES * a.mul1 * 3; idx += blockDim.x) {
-    const int nb = idx / (a.mul1 * 3), rem = idx % (a.mul1 * 3), wv = rem / 3, mm = rem % 3, i = n0 + nb;
-    float m = 0.f;
-    if (i < a.n_atoms) {
-      const int ns = a.tile_nslab ? a.tile_nslab[i >> 5] : a.n_slices;
-      for (int s = 0; s < ns; ++s) m += a.partial1[(((size_t)s * a.n_pad + i) * 3 + mm) * w1 + wv];
-      const int d = a.deg[i];
-      m = m / (float)(d < 1 ? 1 : d);
+  const int ns = a.tile_nslab ? a.tile_nslab[blockIdx.x] : a.n_slices;
+  // ---- phase 1a: scalar rows: sum of the partial slabs (fixed order), mean over in-edges, activation / gate.
+  // NU_U independent elements per thread and pass, so their slab loads are in flight together.
+  for (int base = tid; base < 32 * w0; base += NU_T * NU_U) {
+    float m[NU_U];
+    int il[NU_U], w[NU_U];
+    bool ok[NU_U];
+#pragma unroll
+    for (int u = 0; u < NU_U; ++u) {
+      const int idx = base + NU_T * u;
+      il[u] = idx / w0;
+      w[u] = idx - il[u] * w0;
+      ok[u] = idx < 32 * w0 && w[u] < G0 && n0 + il[u] < a.n_atoms;
+      m[u] = 0.f;
     }
-    s_vec[idx] = m * s_gate[nb * a.mul1 + wv];
+    for (int s = 0; s < ns; ++s) {
+#pragma unroll
+      for (int u = 0; u < NU_U; ++u)
+        if (ok[u]) m[u] += a.partial0[((size_t)s * a.n_pad + n0 + il[u]) * w0 + w[u]];
+    }
+#pragma unroll
+    for (int u = 0; u < NU_U; ++u) {
+      const int idx = base + NU_T * u;
+      if (idx >= 32 * w0 || w[u] >= G0) continue;
+      float v = 0.f;
+      if (ok[u]) {
+        const int d = a.deg[n0 + il[u]];
+        v = m[u] / (float)(d < 1 ? 1 : d);
+      }
+      if (w[u] < a.mul0) A0[w[u] * NU_LD + il[u]] = a.cL * (v > 0.f ? v : 0.01f * v);
+      else s_gate[il[u] * a.mul1 + (w[u] - a.mul0)] = a.cS / (1.f + expf(-v));
+    }
+  }
+  // x_in: scalars extend the scalar K range, vectors extend each plane's K range; pad rows are zero
+  for (int base = tid; base < 32 * a.XSin; base += NU_T * NU_U) {
+    float v[NU_U];
+#pragma unroll
+    for (int u = 0; u < NU_U; ++u) {
+      const int idx = base + NU_T * u;
+      const int il = idx / a.XSin, c = idx - il * a.XSin;
+      v[u] = (idx < 32 * a.XSin && n0 + il < a.n_atoms) ? a.x_in[(size_t)(n0 + il) * a.XSin + c] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < NU_U; ++u) {
+      const int idx = base + NU_T * u;
+      if (idx >= 32 * a.XSin) continue;
+      const int il = idx / a.XSin, c = idx - il * a.XSin;
+      if (c < a.in0) A0[(a.mul0 + c) * NU_LD + il] = v[u];
+      else {
+        const int uu = (c - a.in0) / 3, mm = (c - a.in0) - 3 * uu;
+        A1[(mm * K1 + a.mul1 + uu) * NU_LD + il] = v[u];
+      }
+    }
+  }
+  for (int idx = tid; idx < (K0 - a.mul0 - a.in0) * 32; idx += NU_T) A0[(a.mul0 + a.in0 + (idx >> 5)) * NU_LD + (idx & 31)] = 0.f;
+  for (int idx = tid; idx < 3 * (K1 - a.mul1 - a.in1) * 32; idx += NU_T) {
+    const int mm = idx / ((K1 - a.mul1 - a.in1) * 32), rem = idx - mm * (K1 - a.mul1 - a.in1) * 32;
+    A1[(mm * K1 + a.mul1 + a.in1 + (rem >> 5)) * NU_LD + (rem & 31)] = 0.f;
+  }
+  // ---- phase 1b: vector rows (slab sums and mean here, the gate after the barrier)
+  {
+    const int nv = 32 * 3 * w1;
+    float mv[NU_V];
+#pragma unroll
+    for (int u = 0; u < NU_V; ++u) mv[u] = 0.f;
+    for (int s = 0; s < ns; ++s) {
+#pragma unroll
+      for (int u = 0; u < NU_V; ++u) {
+        const int idx = tid + NU_T * u;
+        const int il = idx / (3 * w1), rem = idx - il * 3 * w1;
+        if (idx < nv && n0 + il < a.n_atoms) mv[u] += a.partial1[((size_t)s * a.n_pad + n0 + il) * 3 * w1 + rem];
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < NU_V; ++u) {
+      const int idx = tid + NU_T * u;
+      const int il = idx / (3 * w1), rem = idx - il * 3 * w1, mm = rem / w1, wv = rem - mm * w1;
+      if (idx < nv && wv < a.mul1) {
+        float m = 0.f;
+        if (n0 + il < a.n_atoms) {
+          const int d = a.deg[n0 + il];
+          m = mv[u] / (float)(d < 1 ? 1 : d);
+        }
+        A1[(mm * K1 + wv) * NU_LD + il] = m * s_gate[il * a.mul1 + wv];
+      }
+    }
   }
   __syncthreads();
+  // ---- phase 2: out = [act | x_in] . [W_self ; W_skip] on the matrix cores, then the noise-conditional skip mix
   const int XSo = a.mul0 + 3 * a.mul1;
-  for (int o = tid; o < XSo; o += blockDim.x) {
-    float acc[NB_NODES];
+  const int nts = (a.mul0 + 31) >> 5, nsg0 = K0 >> 3, nsg1 = K1 >> 3;
+  for (int job = wave; job < nts + 3; job += NU_T / 64) {
+    const bool scalar = job < nts;
+    const int nsg = scalar ? nsg0 : nsg1;
+    const float4* __restrict__ wp = (scalar ? a.wcat0 + (size_t)job * nsg0 * 64 : a.wcat1) + lane;
+    const float* __restrict__ ap = (scalar ? A0 : A1 + (job - nts) * K1 * NU_LD) + hh * NU_LD + r;
+    nu_f32x16 acc;
 #pragma unroll
-    for (int nb = 0; nb < NB_NODES; ++nb) acc[nb] = 0.f;
-    int ch;
-    if (o < a.mul0) {
-      ch = o;
-      for (int w = 0; w < a.mul0; ++w) {
-        const float ww = a.w_self0[w * a.mul0 + o];
+    for (int q = 0; q < 16; ++q) acc[q] = 0.f;
+    float4 ring[4];
 #pragma unroll
-        for (int nb = 0; nb < NB_NODES; ++nb) acc[nb] = fmaf(ww, s_a[nb * a.mul0 + w], acc[nb]);
-      }
-      for (int u = 0; u < a.in0; ++u) {
-        const float ww = a.w_skip0[u * a.mul0 + o];
+    for (int i = 0; i < 4; ++i) ring[i] = wp[(i < nsg ? i : nsg - 1) * 64];
+    for (int sg = 0; sg < nsg; sg += 4) {
 #pragma unroll
-        for (int nb = 0; nb < NB_NODES; ++nb) acc[nb] = fmaf(ww, s_xin[nb * a.XSin + u], acc[nb]);
-      }
-    } else {
-      const int ov = (o - a.mul0) / 3, mm = (o - a.mul0) % 3;
-      ch = a.mul0 + ov;
-      for (int w = 0; w < a.mul1; ++w) {
-        const float ww = a.w_self1[w * a.mul1 + ov];
-#pragma unroll
-        for (int nb = 0; nb < NB_NODES; ++nb) acc[nb] = fmaf(ww, s_vec[(nb * a.mul1 + w) * 3 + mm], acc[nb]);
-      }
-      for (int u = 0; u < a.in1; ++u) {
-        const float ww = a.w_skip1[u * a.mul1 + ov];
-#pragma unroll
-        for (int nb = 0; nb < NB_NODES; ++nb) acc[nb] = fmaf(ww, s_xin[nb * a.XSin + a.in0 + u * 3 + mm], acc[nb]);
+      for (int i = 0; i < 4; ++i) {
+        if (sg + i < nsg) {  // wave-uniform
+          const float4 w = ring[i];
+          if (sg + i + 4 < nsg) ring[i] = wp[(sg + i + 4) * 64];
+          const float* __restrict__ as = ap + 8 * (sg + i) * NU_LD;
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(as[0], w.x, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(as[2 * NU_LD], w.y, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(as[4 * NU_LD], w.z, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(as[6 * NU_LD], w.w, acc, 0, 0, 0);
+        }
       }
     }
-    const float mw = a.mix ? a.mix[ch] : 0.f;
+    const int col = scalar ? job * 32 + r : r;                 // output channel within the irrep block
+    const bool col_ok = scalar ? col < a.mul0 : col < a.mul1;
+    const int o = scalar ? col : a.mul0 + 3 * col + (job - nts);  // column of x_out
+    const float mw = (a.mix && col_ok) ? a.mix[scalar ? col : a.mul0 + col] : 0.f;
 #pragma unroll
-    for (int nb = 0; nb < NB_NODES; ++nb) {
-      const int i = n0 + nb;
-      if (i < a.n_atoms) {
-        float v = acc[nb];
-        if (a.mix) v = mw * s_xin[nb * a.XSin + o] + (1.f - mw) * v;  // hidden layers: XSin == XSo, x_in is x_old
+    for (int q = 0; q < 16; ++q) {
+      const int i = n0 + (q & 3) + 8 * (q >> 2) + 4 * hh;
+      if (col_ok && i < a.n_atoms) {
+        float v = acc[q];
+        if (a.mix) v = mw * a.x_in[(size_t)i * a.XSin + o] + (1.f - mw) * v;  // hidden layers: XSin == XSo, x_in is x_old
         a.x_out[(size_t)i * XSo + o] = v;
       }
     }
@@ -525,10 +594,15 @@ void launch_edge_h(const int* deg, const int* esrc, const float4* egeo, int n_at
                      step, h);
 }
 
+size_t node_update_lds_bytes(const NodeArgs& a) {
+  return sizeof(float) * ((size_t)a.K0p * NU_LD + 3 * (size_t)a.K1p * NU_LD + 32 * (size_t)a.mul1);
+}
 void launch_node_update(const NodeArgs& a, hipStream_t st) {
-  const int grid = (a.n_atoms + NB_NODES - 1) / NB_NODES;
-  const size_t sm = sizeof(float) * NB_NODES * (a.mul0 + a.mul1 + 3 * a.mul1 + a.XSin);
-  hipLaunchKernelGGL(k_node_update, dim3(grid), dim3(256), sm, st, a);
+  hipLaunchKernelGGL(k_node_update, dim3(a.n_pad / 32), dim3(NU_T), node_update_lds_bytes(a), st, a);
+}
+int node_update_set_max_lds() {
+  return hipFuncSetAttribute((const void*)k_node_update, hipFuncAttributeMaxDynamicSharedMemorySize, JAMUN_MAX_DYN_LDS) ==
+                 hipSuccess ? 0 : -1;
 }
 void launch_head(const HeadArgs& a, hipStream_t st) {
   hipLaunchKernelGGL(k_head, dim3((a.n_atoms + 7) / 8), dim3(256), 0, st, a);
