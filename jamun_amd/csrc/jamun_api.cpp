@@ -106,7 +106,7 @@ struct FusedDev {
 struct LayerDev {
   ConvProblemDev p0, p1;
   FusedDev fu;
-  float *w1r = nullptr, *cmask = nullptr;
+  std::vector<float> w1r_h, cmask_h;  // radial MLP first layer (uploaded for all layers together: jamun_sampler::w1r_all)
   float4 *wcat0 = nullptr, *wcat1 = nullptr;  // node update: [W_self ; W_skip] as MFMA fragments
   int K0p = 0, K1p = 0;
   float* mix = nullptr;
@@ -271,6 +271,9 @@ struct jamun_sampler {
   std::vector<LayerDev> layers;
   float *w_gate = nullptr, *w_vec = nullptr, *w_out = nullptr;
   // work buffers
+  float *w1r_all = nullptr, *cmask_all = nullptr;  // [layers][64][32], [layers][2][64]
+  size_t h_stride = 0;
+  bool h_batched = false;
   float *yc = nullptr, *h = nullptr, *partial0 = nullptr, *partial1 = nullptr, *g = nullptr, *tmp = nullptr;
   float *xhat_buf = nullptr, *score_buf = nullptr, *psi = nullptr;
   int *deg = nullptr, *esrc = nullptr;
@@ -286,10 +289,10 @@ struct jamun_sampler {
 
   ~jamun_sampler() {
     hipFree(ptr); hipFree(bond_in_ptr); hipFree(bond_in_src); hipFree(x_emb); hipFree(mu); hipFree(tile_span);
-    hipFree(fused_segs); hipFree(tile_nslab);
+    hipFree(fused_segs); hipFree(tile_nslab); hipFree(w1r_all); hipFree(cmask_all);
     for (auto& L : layers) {
       free_problem(L.p0); free_problem(L.p1); free_fused(L.fu);
-      hipFree(L.w1r); hipFree(L.cmask); hipFree(L.wcat0); hipFree(L.wcat1); hipFree(L.mix);
+      hipFree(L.wcat0); hipFree(L.wcat1); hipFree(L.mix);
     }
     hipFree(w_gate); hipFree(w_vec); hipFree(w_out);
     hipFree(yc); hipFree(h); hipFree(partial0); hipFree(partial1); hipFree(g); hipFree(tmp);
@@ -546,15 +549,15 @@ LayerDev build_layer(const jamun_model& m, const std::string& prefix, const std:
   const auto& Eb = m.get("embed_bondedness.weight", 2 * nb);
   std::vector<float> w1r((size_t)H * nr), cmask(2 * (size_t)H);
   for (int k = 0; k < H; ++k) {
-    for (int r = 0; r < nr; ++r) w1r[(size_t)k * nr + r] = W1[(size_t)k * H + nb + r];
+    for (int r = 0; r < nr; ++r) w1r[(size_t)r * H + k] = W1[(size_t)k * H + nb + r];  // [basis][hidden]: lane = hidden unit
     for (int mk = 0; mk < 2; ++mk) {
       double s = b1[k];
       for (int c = 0; c < nb; ++c) s += (double)W1[(size_t)k * H + c] * Eb[(size_t)mk * nb + c];
       cmask[(size_t)mk * H + k] = (float)s;
     }
   }
-  L.w1r = dev_upload(w1r);
-  L.cmask = dev_upload(cmask);
+  L.w1r_h = w1r;
+  L.cmask_h = cmask;
 
   // ---- o3.Linear skip (in -> hidden) and self-interaction (hidden -> hidden)  (_interaction.py:23-30)
   int64_t n_skip = 0;
@@ -637,13 +640,17 @@ void forward(jamun_sampler* s, const float* y, float* xhat, float* score, hipStr
   int XSin = s->n_emb;
   for (size_t l = 0; l < s->layers.size(); ++l) {
     LayerDev& L = s->layers[l];
-    {
+    const float* h_l = s->h + (s->h_batched ? l * s->h_stride : 0);
+    if (!s->h_batched || l == 0) {
+      // the radial MLPs depend only on the edge geometry: one launch covers every layer when the buffer fits
+      const size_t NL = s->h_batched ? s->layers.size() : 1;
       ProfScope ps(s, JAMUN_PROF_EDGE_H, st);
-      launch_edge_h(s->deg, s->esrc, s->egeo, s->n_atoms, s->S, L.w1r, L.cmask, s->mu, s->rb_step, s->h, st);
+      launch_edge_h(s->deg, s->esrc, s->egeo, s->n_atoms, s->S, s->w1r_all + l * 64 * 32, s->cmask_all + l * 128, (int)NL,
+                    s->mu, s->rb_step, s->h, s->h_stride, st);
     }
     if (L.fu.wpack) {
       FusedArgs f{};
-      f.deg = s->deg; f.esrc = s->esrc; f.egeo = s->egeo; f.h = s->h; f.x = x_in;
+      f.deg = s->deg; f.esrc = s->esrc; f.egeo = s->egeo; f.h = h_l; f.x = x_in;
       f.n_atoms = s->n_atoms; f.n_pad = s->n_pad; f.S = s->S; f.XS = XSin; f.JR = s->fused_JR; f.tile_span = s->tile_span;
       f.wpack = L.fu.wpack; f.a_units = L.fu.a_units; f.b_units = L.fu.b_units; f.owner = L.fu.owner; f.segs = s->fused_segs;
       f.k_stride = L.fu.k_stride; f.max_a = L.fu.max_a; f.n_p = L.fu.n_p; f.n_t = L.fu.n_t; f.max_segs = s->fused_max_segs;
@@ -653,7 +660,7 @@ void forward(jamun_sampler* s, const float* y, float* xhat, float* score, hipStr
       if (rcode != 0) throw Err(JAMUN_ERR_INVALID, "fused conv launch failed (configuration not supported)");
     } else {
     ConvArgs a{};
-    a.deg = s->deg; a.esrc = s->esrc; a.egeo = s->egeo; a.h = s->h; a.x = x_in;
+    a.deg = s->deg; a.esrc = s->esrc; a.egeo = s->egeo; a.h = h_l; a.x = x_in;
     a.n_atoms = s->n_atoms; a.n_pad = s->n_pad; a.n_tiles = s->n_tiles; a.S = s->S; a.S4 = (s->S + 3) & ~3; a.XS = XSin;
     a.n_slices = s->n_slices;
     for (int pi = 0; pi < 2; ++pi) {
@@ -970,7 +977,18 @@ int jamun_sampler_create(const jamun_model* m, float sigma, const jamun_topology
     s->deg = dev_alloc<int>(N);
     s->esrc = dev_alloc<int>(NS);
     s->egeo = dev_alloc<float4>(NS);
-    s->h = dev_alloc<float>(NS * JAMUN_HS);
+    {
+      std::vector<float> w1r_all, cmask_all;
+      for (auto& L : s->layers) {
+        w1r_all.insert(w1r_all.end(), L.w1r_h.begin(), L.w1r_h.end());
+        cmask_all.insert(cmask_all.end(), L.cmask_h.begin(), L.cmask_h.end());
+      }
+      s->w1r_all = dev_upload(w1r_all);
+      s->cmask_all = dev_upload(cmask_all);
+      s->h_stride = NS * JAMUN_HS;
+      s->h_batched = s->h_stride * s->layers.size() * sizeof(float) <= ((size_t)4 << 30);  // all layers' h~ at once, up to 4 GiB
+      s->h = dev_alloc<float>(s->h_stride * (s->h_batched ? s->layers.size() : 1));
+    }
     int nt0 = 0, nt1 = 0;
     for (auto& L : s->layers) { nt0 = std::max(nt0, L.p0.nt); nt1 = std::max(nt1, L.p1.nt); }
     const size_t n_part = (size_t)std::max(s->n_slices, s->n_slabs);

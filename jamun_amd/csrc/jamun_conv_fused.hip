@@ -40,6 +40,9 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define FT (64 * FW)
 #define FPAIRS (64 * 32 / FT)  // (source row, destination) pairs per thread, JR <= 64
 #define MAXB JAMUN_FUSED_MAX_B
+#ifndef TR
+#define TR 8  // depth of the T-tile weight ring (blocks of 4 K-steps): 32 MFMAs of prefetch distance
+#endif
 
 #ifdef JAMUN_STAMP
 __device__ unsigned long long g_fstamp[8];
@@ -132,7 +135,7 @@ __global__ __launch_bounds__(FT, 1) void k_conv_fused(FusedArgs a) {
     };
     // T tile: T[j][w] = sum_u x0_j[u] W[(k,u)][w] for one 32-row tile of source atoms.  A operand straight from the
     // transposed feature rows (lane = row: consecutive banks), B operand = weights (4-block register ring).
-    auto t_form = [&](const int4& ud, const int4& ut, const float4* __restrict__ wk, float4 (&ring)[4], int dbuf) {
+    auto t_form = [&](const int4& ud, const int4& ut, const float4* __restrict__ wk, float4 (&ring)[TR], int dbuf) {
       const int tix = RFL(ud.y), wofs = RFL(ud.z), jt = RFL(ut.x), nsg = RFL(ut.y), xcol0 = RFL(ut.z);
       if (32 * jt >= Jt4) return;  // wave-uniform: the tile sees no source atom in this row tile
       int row = 32 * jt + r;
@@ -141,12 +144,12 @@ __global__ __launch_bounds__(FT, 1) void k_conv_fused(FusedArgs a) {
       f32x16 af;
 #pragma unroll
       for (int q = 0; q < 16; ++q) af[q] = 0.f;
-      for (int sg = 0; sg < nsg; sg += 4) {
+      for (int sg = 0; sg < nsg; sg += TR) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < TR; ++i) {
           if (sg + i < nsg) {  // wave-uniform
             const float4 w = ring[i];
-            if (sg + i + 4 < nsg) ring[i] = wk[(wofs + sg + i + 4) * 64];
+            if (sg + i + TR < nsg) ring[i] = wk[(wofs + sg + i + TR) * 64];
             const float* __restrict__ xs = xr + 8 * (sg + i) * JR;
             af = MFMA(xs[0], w.x, af);
             af = MFMA(xs[2 * JR], w.y, af);
@@ -159,10 +162,10 @@ __global__ __launch_bounds__(FT, 1) void k_conv_fused(FusedArgs a) {
       for (int qg = 0; qg < 4; ++qg)
         dT[((dbuf * a.n_t + tix) * 4 + qg) * 64 + lane] = make_float4(af[4 * qg], af[4 * qg + 1], af[4 * qg + 2], af[4 * qg + 3]);
     };
-    auto t_ring = [&](const int4& ud, const int4& ut, const float4* __restrict__ wk, float4 (&ring)[4]) {
+    auto t_ring = [&](const int4& ud, const int4& ut, const float4* __restrict__ wk, float4 (&ring)[TR]) {
       const int wofs = RFL(ud.z), nsg = RFL(ut.y);
 #pragma unroll
-      for (int i = 0; i < 4; ++i) ring[i] = wk[(wofs + (i < nsg ? i : nsg - 1)) * 64];
+      for (int i = 0; i < TR; ++i) ring[i] = wk[(wofs + (i < nsg ? i : nsg - 1)) * 64];
     };
 
     // ---- per segment: transposed feature rows, (source, destination) -> edge-slot map, per-pair edge geometry.
@@ -221,7 +224,7 @@ __global__ __launch_bounds__(FT, 1) void k_conv_fused(FusedArgs a) {
       if (kind < 0) break;
       if (kind != 1) continue;
       const float4* __restrict__ wk = a.wpack + (size_t)k_of(0) * a.k_stride + lane;
-      float4 ring[4];
+      float4 ring[TR];
       t_ring(ud, ut, wk, ring);
       t_form(ud, ut, wk, ring, 0);
     }
@@ -314,7 +317,7 @@ __global__ __launch_bounds__(FT, 1) void k_conv_fused(FusedArgs a) {
         if (kind < 0) break;
         if (kind == 1) {
           if (!v_t) continue;
-          float4 ring[4];
+          float4 ring[TR];
           t_ring(ud, ut, wkt, ring);
           t_form(ud, ut, wkt, ring, (it + 2) & 1);
         } else {

@@ -107,8 +107,9 @@ void launch_radius_graph(const float* pos, const int* ptr, int n_graphs, float r
                          hipStream_t st);
 void launch_geom(const float* y, const int* ptr, int n_graphs, float c_in, float r2, int S, const int* bip,
                  const int* bis, int mean_center, float* yc, int* deg, int* esrc, float4* egeo, hipStream_t st);
-void launch_edge_h(const int* deg, const int* esrc, const float4* egeo, int n_atoms, int S, const float* w1r,
-                   const float* cmask, const float* mu, float step, float* h, hipStream_t st);
+void launch_edge_h(const int* deg, const int* esrc, const float4* egeo, int n_atoms, int S, const float* w1r_all,
+                   const float* cmask_all, int n_layers, const float* mu, float step, float* h_all, size_t h_layer_stride,
+                   hipStream_t st);
 int launch_conv(const ConvArgs& a, int rc, int nt, hipStream_t st);
 int conv_set_max_lds();
 int launch_conv_fused(const FusedArgs& a, int grid, hipStream_t st);

@@ -127,36 +127,51 @@ __global__ void k_geom(const float* __restrict__ y, const int* __restrict__ ptr,
 // (src/jamun/model/arch/e3conv.py:118-127, src/jamun/e3tools/nn/_mlp.py:10-34).
 // One wave per destination atom, lane = hidden unit k.  cmask[mask][k] = b1[k] + W1[k,:32].E_bond[mask].
 // ------------------------------------------------------------------------------------------------
+// blockIdx.y = layer: all layers of a forward share the edge geometry, so their radial MLPs run in one launch.
 __global__ __launch_bounds__(256) void k_edge_h(const int* __restrict__ deg, const int* __restrict__ esrc,
                                                 const float4* __restrict__ egeo, int n_atoms, int S,
-                                                const float* __restrict__ w1r,    // [64][32] radial part of W1
-                                                const float* __restrict__ cmask,  // [2][64]
-                                                const float* __restrict__ mu,     // [32] basis centres
-                                                float step, float* __restrict__ h) {
+                                                const float* __restrict__ w1r_all,    // [layers][32][64] radial part of W1, transposed
+                                                const float* __restrict__ cmask_all,  // [layers][2][64]
+                                                const float* __restrict__ mu,         // [32] basis centres
+                                                float step, float* __restrict__ h_all, size_t h_layer_stride) {
   const int lane = threadIdx.x & 63;
   const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (i >= n_atoms) return;
+  const float* __restrict__ w1r = w1r_all + (size_t)blockIdx.y * 64 * 32;
+  const float* __restrict__ cmask = cmask_all + (size_t)blockIdx.y * 128;
+  float* __restrict__ h = h_all + (size_t)blockIdx.y * h_layer_stride;
   float w[32];
 #pragma unroll
-  for (int r = 0; r < 32; ++r) w[r] = w1r[lane * 32 + r];
+  for (int r = 0; r < 32; ++r) w[r] = w1r[r * 64 + lane];  // host-transposed: coalesced
   const float c0 = cmask[lane], c1 = cmask[64 + lane];
   const float mu_l = mu[lane & 31];
   const int d_i = deg[i];
-  for (int t = 0; t < d_i; ++t) {
-    const size_t e = (size_t)i * S + t;
-    const float d = egeo[e].w;
-    const bool bonded = (esrc[e] < 0);
-    float diff = FSUB(d, mu_l) / step;
-    float rad = expf(-FMUL(diff, diff)) / 1.12f;
-    float pre = bonded ? c1 : c0;
-#pragma unroll
-    for (int r = 0; r < 32; ++r) {
-      float rr = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, rad), r));
-      pre = fmaf(w[r], rr, pre);
+  for (int t0 = 0; t0 < d_i; t0 += 64) {
+    // lane t loads edge t0 + t (one coalesced load for the whole atom); the loop below reads them back with readlane
+    float d_l = 0.f;
+    int b_l = 0;
+    if (t0 + lane < d_i) {
+      const size_t e = (size_t)i * S + t0 + lane;
+      d_l = egeo[e].w;
+      b_l = esrc[e] < 0 ? 1 : 0;
     }
-    float hv = pre / (1.f + expf(-pre));
-    h[e * JAMUN_HS + lane] = hv;
-    if (lane < JAMUN_HS - 64) h[e * JAMUN_HS + 64 + lane] = (lane == 0) ? 1.f : 0.f;
+    const int cnt = d_i - t0 < 64 ? d_i - t0 : 64;
+    for (int t = 0; t < cnt; ++t) {
+      const size_t e = (size_t)i * S + t0 + t;
+      const float d = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, d_l), t));
+      const bool bonded = __builtin_amdgcn_readlane(b_l, t) != 0;
+      float diff = FSUB(d, mu_l) / step;
+      float rad = expf(-FMUL(diff, diff)) / 1.12f;
+      float pre = bonded ? c1 : c0;
+#pragma unroll
+      for (int r = 0; r < 32; ++r) {
+        float rr = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, rad), r));
+        pre = fmaf(w[r], rr, pre);
+      }
+      float hv = pre / (1.f + expf(-pre));
+      h[e * JAMUN_HS + lane] = hv;
+      if (lane < JAMUN_HS - 64) h[e * JAMUN_HS + 64 + lane] = (lane == 0) ? 1.f : 0.f;
+    }
   }
 }
 
@@ -327,17 +342,31 @@ __global__ __launch_bounds__(NU_T) void k_node_update(NodeArgs a) {
 // 32 lanes per atom (lane = vector channel w'), 8 atoms per workgroup.
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_head(HeadArgs a) {
+  extern __shared__ float hs[];
+  const int XS = a.mul0 + 3 * a.mul1;
+  float* __restrict__ s_wg = hs;                         // [mul0][mul1]
+  float* __restrict__ s_wv = s_wg + a.mul0 * a.mul1;     // [mul1][mul1]
+  float* __restrict__ s_x = s_wv + a.mul1 * a.mul1;      // [8][XS]
   const int wv = threadIdx.x & 31;
   const int i = blockIdx.x * 8 + (threadIdx.x >> 5);
+  // weights and the 8 feature rows go through LDS once: the contraction loops below then run at LDS latency instead of
+  // one dependent global load per iteration
+  for (int idx = threadIdx.x; idx < a.mul0 * a.mul1; idx += 256) s_wg[idx] = a.w_gate[idx];
+  for (int idx = threadIdx.x; idx < a.mul1 * a.mul1; idx += 256) s_wv[idx] = a.w_vec[idx];
+  for (int idx = threadIdx.x; idx < 8 * XS; idx += 256) {
+    const size_t gidx = (size_t)blockIdx.x * 8 * XS + idx;
+    s_x[idx] = gidx < (size_t)a.n_atoms * XS ? a.x[gidx] : 0.f;
+  }
+  __syncthreads();
   float gx = 0.f, gy = 0.f, gz = 0.f;
   if (i < a.n_atoms) {
-    const float* __restrict__ xi = a.x + (size_t)i * (a.mul0 + 3 * a.mul1);
+    const float* __restrict__ xi = s_x + (threadIdx.x >> 5) * XS;
     for (int w0 = wv; w0 < a.mul1; w0 += 32) {
       float gp = 0.f;
-      for (int u = 0; u < a.mul0; ++u) gp = fmaf(a.w_gate[u * a.mul1 + w0], xi[u], gp);
+      for (int u = 0; u < a.mul0; ++u) gp = fmaf(s_wg[u * a.mul1 + w0], xi[u], gp);
       float hx = 0.f, hy = 0.f, hz = 0.f;
       for (int u = 0; u < a.mul1; ++u) {
-        const float ww = a.w_vec[u * a.mul1 + w0];
+        const float ww = s_wv[u * a.mul1 + w0];
         hx = fmaf(ww, xi[a.mul0 + u * 3 + 0], hx);
         hy = fmaf(ww, xi[a.mul0 + u * 3 + 1], hy);
         hz = fmaf(ww, xi[a.mul0 + u * 3 + 2], hz);
@@ -588,10 +617,11 @@ void launch_geom(const float* y, const int* ptr, int n_graphs, float c_in, float
   hipLaunchKernelGGL(k_geom, dim3(n_graphs), dim3(128), 0, st, y, ptr, c_in, r2, S, bip, bis, mean_center, yc, deg,
                      esrc, egeo);
 }
-void launch_edge_h(const int* deg, const int* esrc, const float4* egeo, int n_atoms, int S, const float* w1r,
-                   const float* cmask, const float* mu, float step, float* h, hipStream_t st) {
-  hipLaunchKernelGGL(k_edge_h, dim3((n_atoms + 3) / 4), dim3(256), 0, st, deg, esrc, egeo, n_atoms, S, w1r, cmask, mu,
-                     step, h);
+void launch_edge_h(const int* deg, const int* esrc, const float4* egeo, int n_atoms, int S, const float* w1r_all,
+                   const float* cmask_all, int n_layers, const float* mu, float step, float* h_all, size_t h_layer_stride,
+                   hipStream_t st) {
+  hipLaunchKernelGGL(k_edge_h, dim3((n_atoms + 3) / 4, n_layers), dim3(256), 0, st, deg, esrc, egeo, n_atoms, S, w1r_all,
+                     cmask_all, mu, step, h_all, h_layer_stride);
 }
 
 size_t node_update_lds_bytes(const NodeArgs& a) {
@@ -605,7 +635,8 @@ int node_update_set_max_lds() {
                  hipSuccess ? 0 : -1;
 }
 void launch_head(const HeadArgs& a, hipStream_t st) {
-  hipLaunchKernelGGL(k_head, dim3((a.n_atoms + 7) / 8), dim3(256), 0, st, a);
+  const size_t sm = sizeof(float) * ((size_t)a.mul0 * a.mul1 + (size_t)a.mul1 * a.mul1 + 8 * (size_t)(a.mul0 + 3 * a.mul1));
+  hipLaunchKernelGGL(k_head, dim3((a.n_atoms + 7) / 8), dim3(256), sm, st, a);
 }
 void launch_finalize(const float* y, const float* yc, const float* g, const int* ptr, int n_graphs, float c_skip,
                      float c_out, float sigma2, int mean_center, float* tmp, float* xhat, float* score,
