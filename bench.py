@@ -161,9 +161,12 @@ def main():
             ms0, c0 = prof["conv0"]
             ms1, c1 = prof["conv1"]
             avg0 = ms0 / max(c0, 1)
-            ach = stats["conv0_flop_alg"] / (avg0 * 1e-3) / 1e12 if avg0 > 0 else 0.0
+            fused = c1 == 0  # fused kernel: scalar-row and vector-row contractions of a hidden layer in ONE launch
+            flop = stats["conv0_flop_alg"] + (stats["conv1_flop_alg"] if fused else 0)
+            ach = flop / (avg0 * 1e-3) / 1e12 if avg0 > 0 else 0.0
             out["roofline"] = {
-                "kernel": "k_conv<RC=1,NT=5,NK=2> (scalar-output conv contraction, hidden layers)",
+                "kernel": ("k_conv_fused (destination-grouped conv contraction of one hidden layer, scalar + vector rows)" if fused
+                           else "k_conv<RC=1,NT=5,NK=5> (scalar-output conv contraction, hidden layers)"),
                 "bound": "mfma",
                 "achieved": ach,
                 "peak": F32_MFMA_PEAK_TFLOPS,
@@ -172,7 +175,8 @@ def main():
                 "traffic": None,
                 "avg_launch_ms": avg0,
                 "launches": c0,
-                "flop_per_launch": stats["conv0_flop_alg"],
+                "flop_per_launch": flop,
+                "mfma_flop_executed_per_forward": stats["flop_executed"],  # all conv launches of one forward, padding included
             }
             tot = sum(ms for ms, _ in prof.values())
             out["kernel_time_share"] = {k: round(ms / tot, 4) for k, (ms, _) in prof.items()} if tot > 0 else {}

@@ -396,7 +396,8 @@ LayerDev build_layer(const jamun_model& m, const std::string& prefix, const std:
     for (size_t i = 0; i < x0e.size(); i += 32) add(1, 0, NT0, term(x0e[i].xoff, 1, 0, false), 0, 0, x0e, i);
     for (size_t i = 0; i < dote.size(); i += 32)
       add(3, 0, NT0, term(dote[i].xoff + 0, 3, 1, false), term(dote[i].xoff + 1, 3, 2, false), term(dote[i].xoff + 2, 3, 3, false), dote, i);
-    const int n_tsg = ((int)x0ve.size() + 7) / 8;  // groups of 4 K-steps (8 input channels) of the T contraction
+    // groups of 4 K-steps (8 input channels) of the T contraction, padded to the depth of the kernel's weight ring (8)
+    const int n_tsg = ((((int)x0ve.size() + 7) / 8) + 7) & ~7;
     const int n_jt = x0ve.empty() ? 0 : (fused_JR + 31) / 32;
     for (int jt = 0; jt < n_jt; ++jt) au.push_back(AUnit{1, 0, 4, 0, {0, 0, 0}, jt, {}, 0, 0});
     for (int mm = 0; mm < 3; ++mm) {
@@ -469,7 +470,7 @@ LayerDev build_layer(const jamun_model& m, const std::string& prefix, const std:
     const int FWv = JAMUN_FUSED_WAVES;
     // owner entries: wave w < NT0 owns scalar-row tile w; waves NT0 + m own vector plane m (its x1 / cross tiles are formed
     // in the owner's registers)
-    std::vector<int4> ubv((size_t)FWv * JAMUN_FUSED_MAX_B * 2, make_int4(-1, 0, 0, 0)), own(FWv, make_int4(-1, 0, 0, 0));
+    std::vector<int4> ubv((size_t)FWv * JAMUN_FUSED_MAX_B * 2, make_int4(-1, 0, 0, 0)), own(FWv, make_int4(-1, 0, -1, 0));
     std::vector<int64_t> load(FWv, 0);
     bool fits = true;
     int64_t total = 0;
@@ -477,12 +478,12 @@ LayerDev build_layer(const jamun_model& m, const std::string& prefix, const std:
       std::vector<std::pair<int4, int4>> ent;
       const int4 z = make_int4(0, 0, 0, 0);
       if (w < NT0) {
-        own[w] = make_int4(0, w, 0, 0);
+        own[w] = make_int4(0, w, -1, 0);
         for (size_t i = 0; i < au.size(); ++i)
           if (au[i].kind == 0 && au[i].out == 0) { ent.push_back({make_int4(0, tix[i], au[i].wofs + 4 * w, 0), z}); load[w] += 16; }
       } else if (w < NT0 + 3) {
         const int mm = w - NT0;
-        own[w] = make_int4(1, mm, 0, 0);
+        own[w] = make_int4(1, mm, -1, 0);
         for (size_t i = 0; i < au.size(); ++i)
           if (au[i].kind == 0 && au[i].out == 1 + mm) {
             ent.push_back({make_int4(2, au[i].n_terms, au[i].wofs, 0), make_int4(au[i].term[0], au[i].term[1], au[i].term[2], 0)});
@@ -523,6 +524,7 @@ LayerDev build_layer(const jamun_model& m, const std::string& prefix, const std:
       for (size_t i = 0; i < per_wave[w].size(); ++i) {
         const int id = per_wave[w][i];
         const AUnit& u = au[id];
+        if (u.kind == 1 && own[w].z < 0) own[w].z = (int)i;  // the wave's first T unit: its weight ring is prefetched
         int4* d = &ua[((size_t)w * F.max_a + i) * 2];
         if (u.kind == 1) { d[0] = make_int4(1, tix[id], u.wofs, 0); d[1] = make_int4(u.jt, n_tsg, x0ve[0].xoff, 0); }
         else { d[0] = make_int4(0, tix[id], u.n_terms, 0); d[1] = make_int4(u.term[0], u.term[1], u.term[2], 0); }

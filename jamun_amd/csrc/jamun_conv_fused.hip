@@ -78,10 +78,12 @@ __global__ __launch_bounds__(FT, 1) void k_conv_fused(FusedArgs a) {
   // ---- once per workgroup: the unit tables
   for (int idx = tid; idx < FW * a.max_a * 8; idx += FT) ua[idx] = reinterpret_cast<const int*>(a.a_units)[idx];
   for (int idx = tid; idx < FW * MAXB * 8; idx += FT) ub[idx] = reinterpret_cast<const int*>(a.b_units)[idx];
+  // tiles start finite: stand-in reads (padding K-groups, ramp intervals) must never see NaN bit patterns
+  for (int idx = tid; idx < 2 * 4 * CT + 2 * (a.n_p + a.n_t) * 1024; idx += FT) cT[idx] = 0.f;
   const int4* __restrict__ my_a = reinterpret_cast<const int4*>(ua + wave * a.max_a * 8);
   const int4* __restrict__ my_b = reinterpret_cast<const int4*>(ub + wave * MAXB * 8);
   const int4 own = a.owner[wave];  // {kind: -1 none / 0 scalar-row tile / 1 vector plane, index}
-  const int own_kind = RFL(own.x), own_idx = RFL(own.y);
+  const int own_kind = RFL(own.x), own_idx = RFL(own.y), own_t = RFL(own.z);  // own_t: index of this wave's first T unit, -1 if none
 
   unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0, s_pro = 0, s_wait = 0, s_a = 0, s_b = 0, s_build = 0, s_epi = 0;
   (void)t0; (void)t1; (void)t2; (void)t3; (void)t4; (void)s_pro; (void)s_wait; (void)s_a; (void)s_b; (void)s_build; (void)s_epi;
@@ -103,38 +105,66 @@ __global__ __launch_bounds__(FT, 1) void k_conv_fused(FusedArgs a) {
 
     // D'[u][i] += sum_j X[j][u] C[j][i] over the terms of a forming unit (transposed tiles: four K-steps per b128 read)
     auto form = [&](f32x16& af, int n_terms, const int4& ut, const float* __restrict__ cb) {
+      // operand pointers of all terms first; the K-groups of all terms then run as ONE flat loop whose body always
+      // fetches the next group (next term's first group at a term boundary, a harmless re-read at the very end): no
+      // branches around the LDS reads, so the waits can be counted exactly
+      const float* xq[3];
+      const float* cq[3];
+      float sgn[3];
 #pragma unroll
       for (int t = 0; t < 3; ++t) {
-        if (t >= n_terms) break;  // wave-uniform
         const int td = RFL(t == 0 ? ut.x : (t == 1 ? ut.y : ut.z));
         const int xcol0 = td & 0xfff, stride = (td >> 12) & 0xf, ctype = (td >> 16) & 0xf;
-        const float sgn = (td >> 20) & 1 ? -1.f : 1.f;
-        const float* __restrict__ xq = xT + (xcol0 + r * stride) * JR;
-        const float* __restrict__ cq = cb + ctype * CT + r * JR;
-        const float4* __restrict__ xp = reinterpret_cast<const float4*>(xq + 4 * hh);  // rows 8g + 4hh + (0..3)
-        const float4* __restrict__ cp = reinterpret_cast<const float4*>(cq + 4 * hh);
-        if (n8 > 0) {
-          float4 av = xp[0], bv = cp[0];
-          for (int g = 0; g < n8; ++g) {
-            float4 an = av, bn = bv;
-            if (g + 1 < n8) { an = xp[2 * (g + 1)]; bn = cp[2 * (g + 1)]; }
-            af = MFMA(av.x, bv.x * sgn, af);
-            af = MFMA(av.y, bv.y * sgn, af);
-            af = MFMA(av.z, bv.z * sgn, af);
-            af = MFMA(av.w, bv.w * sgn, af);
-            av = an; bv = bn;
-          }
+        sgn[t] = (td >> 20) & 1 ? -1.f : 1.f;
+        xq[t] = xT + (xcol0 + r * stride) * JR;
+        cq[t] = cb + ctype * CT + r * JR;
+      }
+      if (tail4) {  // four more source rows per term: two K-steps, rows 8 n8 + 2s + hh (all fetched before the first MFMA)
+        float ta[3][2], tb[3][2];
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+          const int tt = t < n_terms ? t : 0;
+          const float* __restrict__ xs = tt == 0 ? xq[0] : (tt == 1 ? xq[1] : xq[2]);
+          const float* __restrict__ cs = tt == 0 ? cq[0] : (tt == 1 ? cq[1] : cq[2]);
+          ta[t][0] = xs[8 * n8 + hh]; tb[t][0] = cs[8 * n8 + hh];
+          ta[t][1] = xs[8 * n8 + 2 + hh]; tb[t][1] = cs[8 * n8 + 2 + hh];
         }
-        if (tail4) {  // four more source rows: two K-steps, rows 8 n8 + 2s + hh
-          const float a0 = xq[8 * n8 + hh], b0 = cq[8 * n8 + hh];
-          const float a1 = xq[8 * n8 + 2 + hh], b1 = cq[8 * n8 + 2 + hh];
-          af = MFMA(a0, b0 * sgn, af);
-          af = MFMA(a1, b1 * sgn, af);
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+          if (t >= n_terms) break;  // wave-uniform
+          af = MFMA(ta[t][0], tb[t][0] * sgn[t], af);
+          af = MFMA(ta[t][1], tb[t][1] * sgn[t], af);
+        }
+      }
+      if (n8 > 0) {
+        const float4* __restrict__ xp = reinterpret_cast<const float4*>(xq[0] + 4 * hh);  // rows 8g + 4hh + (0..3)
+        const float4* __restrict__ cp = reinterpret_cast<const float4*>(cq[0] + 4 * hh);
+        float4 av = xp[0], bv = cp[0];
+        float sg = sgn[0];
+        int t = 0, g = 0;
+        const int total = n_terms * n8;
+        for (int i = 0; i < total; ++i) {
+          int gn = g + 1, tn = t;
+          if (gn == n8) { gn = 0; tn = t + 1; }
+          const int tl = tn < n_terms ? tn : t;  // past the end: re-read the last group's term
+          const float* __restrict__ xs = tl == 0 ? xq[0] : (tl == 1 ? xq[1] : xq[2]);
+          const float* __restrict__ cs = tl == 0 ? cq[0] : (tl == 1 ? cq[1] : cq[2]);
+          const float4 an = reinterpret_cast<const float4*>(xs + 4 * hh)[2 * gn];
+          const float4 bn = reinterpret_cast<const float4*>(cs + 4 * hh)[2 * gn];
+          af = MFMA(av.x, bv.x * sg, af);
+          af = MFMA(av.y, bv.y * sg, af);
+          af = MFMA(av.z, bv.z * sg, af);
+          af = MFMA(av.w, bv.w * sg, af);
+          av = an; bv = bn;
+          sg = tl == 0 ? sgn[0] : (tl == 1 ? sgn[1] : sgn[2]);
+          t = tn; g = gn;
         }
       }
     };
-    // T tile: T[j][w] = sum_u x0_j[u] W[(k,u)][w] for one 32-row tile of source atoms.  A operand straight from the
-    // transposed feature rows (lane = row: consecutive banks), B operand = weights (4-block register ring).
+
+    // The weight-group count is padded to a multiple of TR on the host (zero weights; the feature columns read for the
+    // padding are finite stand-ins), so the loop body is straight-line: unconditional ring loads let the compiler count
+    // vmcnt exactly instead of draining the whole queue.
     auto t_form = [&](const int4& ud, const int4& ut, const float4* __restrict__ wk, float4 (&ring)[TR], int dbuf) {
       const int tix = RFL(ud.y), wofs = RFL(ud.z), jt = RFL(ut.x), nsg = RFL(ut.y), xcol0 = RFL(ut.z);
       if (32 * jt >= Jt4) return;  // wave-uniform: the tile sees no source atom in this row tile
@@ -144,28 +174,35 @@ __global__ __launch_bounds__(FT, 1) void k_conv_fused(FusedArgs a) {
       f32x16 af;
 #pragma unroll
       for (int q = 0; q < 16; ++q) af[q] = 0.f;
+      float xa[4], xn[4];
+#pragma unroll
+      for (int st = 0; st < 4; ++st) xa[st] = xr[2 * st * JR];
       for (int sg = 0; sg < nsg; sg += TR) {
 #pragma unroll
         for (int i = 0; i < TR; ++i) {
-          if (sg + i < nsg) {  // wave-uniform
-            const float4 w = ring[i];
-            if (sg + i + TR < nsg) ring[i] = wk[(wofs + sg + i + TR) * 64];
-            const float* __restrict__ xs = xr + 8 * (sg + i) * JR;
-            af = MFMA(xs[0], w.x, af);
-            af = MFMA(xs[2 * JR], w.y, af);
-            af = MFMA(xs[4 * JR], w.z, af);
-            af = MFMA(xs[6 * JR], w.w, af);
-          }
+          const float4 w = ring[i];
+          const int nxt = sg + i + TR < nsg ? sg + i + TR : nsg - 1;
+          ring[i] = wk[(wofs + nxt) * 64];
+          const int nb = sg + i + 1 < nsg ? sg + i + 1 : nsg - 1;
+          const float* __restrict__ xs = xr + 8 * nb * JR;
+#pragma unroll
+          for (int st = 0; st < 4; ++st) xn[st] = xs[2 * st * JR];
+          af = MFMA(xa[0], w.x, af);
+          af = MFMA(xa[1], w.y, af);
+          af = MFMA(xa[2], w.z, af);
+          af = MFMA(xa[3], w.w, af);
+#pragma unroll
+          for (int st = 0; st < 4; ++st) xa[st] = xn[st];
         }
       }
 #pragma unroll
       for (int qg = 0; qg < 4; ++qg)
         dT[((dbuf * a.n_t + tix) * 4 + qg) * 64 + lane] = make_float4(af[4 * qg], af[4 * qg + 1], af[4 * qg + 2], af[4 * qg + 3]);
     };
-    auto t_ring = [&](const int4& ud, const int4& ut, const float4* __restrict__ wk, float4 (&ring)[TR]) {
-      const int wofs = RFL(ud.z), nsg = RFL(ut.y);
+    auto t_ring = [&](const int4& ud, const float4* __restrict__ wk, float4 (&ring)[TR]) {
+      const int wofs = RFL(ud.z);
 #pragma unroll
-      for (int i = 0; i < TR; ++i) ring[i] = wk[(wofs + (i < nsg ? i : nsg - 1)) * 64];
+      for (int i = 0; i < TR; ++i) ring[i] = wk[(wofs + i) * 64];
     };
 
     // ---- per segment: transposed feature rows, (source, destination) -> edge-slot map, per-pair edge geometry.
@@ -225,13 +262,14 @@ __global__ __launch_bounds__(FT, 1) void k_conv_fused(FusedArgs a) {
       if (kind != 1) continue;
       const float4* __restrict__ wk = a.wpack + (size_t)k_of(0) * a.k_stride + lane;
       float4 ring[TR];
-      t_ring(ud, ut, wk, ring);
+      t_ring(ud, wk, ring);
       t_form(ud, ut, wk, ring, 0);
     }
     __syncthreads();
     // Each thread owns up to FPAIRS (destination il, source row j) pairs, p = il * JR + j: slots, unit vectors and h~
     // addresses live in registers for the whole segment.
-    int p_oa[FPAIRS], p_ob[FPAIRS];  // h~ element offsets of the radial / bonded edge of the pair, -1 if none
+    int p_oa[FPAIRS], p_ob[FPAIRS];  // h~ element offsets of the radial / bonded edge of the pair (0 if none)
+    int p_has = 0;                   // bit 2i: pair i has a radial edge, bit 2i+1: a bonded edge
     float p_ga[FPAIRS][3], p_gb[FPAIRS][3];
     float p_ha[FPAIRS], p_hb[FPAIRS];
 #pragma unroll
@@ -240,20 +278,20 @@ __global__ __launch_bounds__(FT, 1) void k_conv_fused(FusedArgs a) {
       const int pt = (p < CT) ? pm[p] : 0;
       const int il = p / JR;
       const int ta = pt & 0xff, tb = (pt >> 8) & 0xff;
-      const int ea = (n0 + il) * a.S + ta - 1, eb = (n0 + il) * a.S + tb - 1;
-      p_oa[i] = ta ? ea * JAMUN_HS : -1;
-      p_ob[i] = tb ? eb * JAMUN_HS : -1;
-      float4 ga = make_float4(0.f, 0.f, 0.f, 0.f), gb = ga;
-      if (ta) ga = a.egeo[ea];
-      if (tb) gb = a.egeo[eb];
-      p_ga[i][0] = ga.x; p_ga[i][1] = ga.y; p_ga[i][2] = ga.z;
-      p_gb[i][0] = gb.x; p_gb[i][1] = gb.y; p_gb[i][2] = gb.z;
+      // loads are unconditional (slot 0 of atom n0 stands in for absent edges): no branches around them
+      const int ea = ta ? (n0 + il) * a.S + ta - 1 : n0 * a.S, eb = tb ? (n0 + il) * a.S + tb - 1 : n0 * a.S;
+      p_oa[i] = ea * JAMUN_HS;
+      p_ob[i] = eb * JAMUN_HS;
+      p_has |= (ta ? 1 : 0) << (2 * i) | (tb ? 1 : 0) << (2 * i + 1);
+      const float4 ga = a.egeo[ea], gb = a.egeo[eb];
+      p_ga[i][0] = ta ? ga.x : 0.f; p_ga[i][1] = ta ? ga.y : 0.f; p_ga[i][2] = ta ? ga.z : 0.f;
+      p_gb[i][0] = tb ? gb.x : 0.f; p_gb[i][1] = tb ? gb.y : 0.f; p_gb[i][2] = tb ? gb.z : 0.f;
     }
-    auto load_h = [&](int k) {
+    auto load_h = [&](int k) {  // raw loads; write_c masks out the stand-ins of absent edges
 #pragma unroll
       for (int i = 0; i < FPAIRS; ++i) {
-        p_ha[i] = p_oa[i] >= 0 ? a.h[p_oa[i] + k] : 0.f;
-        p_hb[i] = p_ob[i] >= 0 ? a.h[p_ob[i] + k] : 0.f;
+        p_ha[i] = a.h[p_oa[i] + k];
+        p_hb[i] = a.h[p_ob[i] + k];
       }
     };
     auto write_c = [&](float* __restrict__ cbuf) {
@@ -261,10 +299,11 @@ __global__ __launch_bounds__(FT, 1) void k_conv_fused(FusedArgs a) {
       for (int i = 0; i < FPAIRS; ++i) {
         const int p = tid + FT * i;
         if (p < CT) {  // every (destination, row < JR) entry is written: absent pairs and rows >= the span get zeros
-          cbuf[p] = p_ha[i] + p_hb[i];
-          cbuf[CT + p] = fmaf(p_hb[i], p_gb[i][0], p_ha[i] * p_ga[i][0]);
-          cbuf[2 * CT + p] = fmaf(p_hb[i], p_gb[i][1], p_ha[i] * p_ga[i][1]);
-          cbuf[3 * CT + p] = fmaf(p_hb[i], p_gb[i][2], p_ha[i] * p_ga[i][2]);
+          const float ha = (p_has >> (2 * i)) & 1 ? p_ha[i] : 0.f, hb = (p_has >> (2 * i + 1)) & 1 ? p_hb[i] : 0.f;
+          cbuf[p] = ha + hb;
+          cbuf[CT + p] = fmaf(hb, p_gb[i][0], ha * p_ga[i][0]);
+          cbuf[2 * CT + p] = fmaf(hb, p_gb[i][1], ha * p_ga[i][1]);
+          cbuf[3 * CT + p] = fmaf(hb, p_gb[i][2], ha * p_ga[i][2]);
         }
       }
     };
@@ -288,26 +327,26 @@ __global__ __launch_bounds__(FT, 1) void k_conv_fused(FusedArgs a) {
     //   build of C(k(it+2)) into the buffer C(k(it)) occupied (last read in interval it-1)
     for (int it = -1; it < nk; ++it) {
       const bool v_main = it >= 0, v_next = it + 1 < nk, v_t = it + 2 < nk;
-      const int k1 = v_next ? k_of(it + 1) : 0, k2 = v_t ? k_of(it + 2) : 0;
+      // k of the three pipeline stages, clamped into the segment: loads are issued unconditionally (ramp intervals fetch a
+      // valid stand-in they never use), only the arithmetic is skipped
+      const int k0 = k_of(it < 0 ? 0 : it), k1 = k_of(it + 1 < nk ? it + 1 : nk - 1), k2 = k_of(it + 2 < nk ? it + 2 : nk - 1);
       const float* __restrict__ cb = cT + ((it + 1) & 1) * 4 * CT;  // C(k(it+1))
       FSTAMP(t0);
-      if (v_t) load_h(k2);  // in flight behind the interval, written to the free buffer at its end
       const bool v_own = own_kind == 0 ? v_main : v_next;
-      const float4* __restrict__ wkb = a.wpack + (size_t)(own_kind == 0 ? (v_main ? k_of(it) : 0) : k1) * a.k_stride + lane;
+      const float4* __restrict__ wkb = a.wpack + (size_t)(own_kind == 0 ? k0 : k1) * a.k_stride + lane;
       const float4* __restrict__ wkt = a.wpack + (size_t)k2 * a.k_stride + lane;
-      // weights of the first two owner entries: in flight behind the forming units
+      // weights of the first two owner entries: in flight behind the forming units.  (Entry fields z of non-weight and
+      // terminator entries are small valid block offsets, so every fetch is in range.)
       float4 wb[2][4];
 #pragma unroll
       for (int e = 0; e < 2; ++e) {
-        const int4 bd = my_b[2 * e];
-        const int kind = RFL(bd.x), wofs = RFL(bd.z);
+        const int wofs = RFL(my_b[2 * e].z);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) wb[e][q] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (v_own && (kind == 0 || kind == 2)) {
-#pragma unroll
-          for (int q = 0; q < 4; ++q) wb[e][q] = wkb[(wofs + q) * 64];
-        }
+        for (int q = 0; q < 4; ++q) wb[e][q] = wkb[(wofs + q) * 64];
       }
+      // weight ring of this wave's T tile (if it has one)
+      float4 tring[TR];
+      if (own_t >= 0) t_ring(my_a[2 * own_t], wkt, tring);
 
       // ================= forming units of this wave =================
       for (int ui = 0; ui < a.max_a; ++ui) {
@@ -317,9 +356,8 @@ __global__ __launch_bounds__(FT, 1) void k_conv_fused(FusedArgs a) {
         if (kind < 0) break;
         if (kind == 1) {
           if (!v_t) continue;
-          float4 ring[TR];
-          t_ring(ud, ut, wkt, ring);
-          t_form(ud, ut, wkt, ring, (it + 2) & 1);
+          if (ui != own_t) t_ring(ud, wkt, tring);  // (a second T tile on the same wave: not prefetched)
+          t_form(ud, ut, wkt, tring, (it + 2) & 1);
         } else {
           if (!v_next) continue;
           const int tix = RFL(ud.y);
@@ -334,6 +372,9 @@ __global__ __launch_bounds__(FT, 1) void k_conv_fused(FusedArgs a) {
         }
       }
       FSTAMP(t1);
+      // h~ of k(it+2): in flight behind the owner entries, written to the free buffer at the end of the interval.  (Issued
+      // here rather than at the top so the waves do not all hit the texture addresser right after the barrier.)
+      load_h(k2);
 
       // ================= owner entries: K-steps into the tile this wave owns =================
 #pragma unroll
@@ -346,23 +387,22 @@ __global__ __launch_bounds__(FT, 1) void k_conv_fused(FusedArgs a) {
           float4 w[4];
 #pragma unroll
           for (int q = 0; q < 4; ++q) w[q] = wb[e & 1][q];
-          if (e + 2 < MAXB) {
-            const int4 bn = my_b[2 * (e + 2)];
-            const int kn = RFL(bn.x);
-            if (kn == 0 || kn == 2) {
-              const int wofs = RFL(bn.z);
+          if (e + 2 < MAXB) {  // weights of entry e + 2 (any kind: see above), always fetched
+            const int wofs = RFL(my_b[2 * (e + 2)].z);
 #pragma unroll
-              for (int q = 0; q < 4; ++q) wb[e & 1][q] = wkb[(wofs + q) * 64];
-            }
+            for (int q = 0; q < 4; ++q) wb[e & 1][q] = wkb[(wofs + q) * 64];
           }
           if (kind == 0) {  // scalar-row tile formed in the previous interval
+            float4 av[4];
+#pragma unroll
+            for (int qg = 0; qg < 4; ++qg) av[qg] = dP[(((it & 1) * a.n_p + tix) * 4 + qg) * 64 + lane];
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int qg = 0; qg < 4; ++qg) {
-              const float4 av = dP[(((it & 1) * a.n_p + tix) * 4 + qg) * 64 + lane];
-              acc = MFMA(av.x, w[qg].x, acc);
-              acc = MFMA(av.y, w[qg].y, acc);
-              acc = MFMA(av.z, w[qg].z, acc);
-              acc = MFMA(av.w, w[qg].w, acc);
+              acc = MFMA(av[qg].x, w[qg].x, acc);
+              acc = MFMA(av[qg].y, w[qg].y, acc);
+              acc = MFMA(av[qg].z, w[qg].z, acc);
+              acc = MFMA(av[qg].w, w[qg].w, acc);
             }
           } else {  // plane owner: form the tile in registers, feed the accumulator registers straight into the main MFMAs
             f32x16 af;
@@ -383,15 +423,21 @@ __global__ __launch_bounds__(FT, 1) void k_conv_fused(FusedArgs a) {
           const int m = RFL(bd.z), jt = RFL(bd.w);
           if (32 * jt >= Jt4) continue;
           const float* __restrict__ cm = cb + (1 + m) * CT + r * JR + 32 * jt + 4 * hh;
+          // all eight operand fragments are requested before the first MFMA (the waits then retire them one by one)
+          float4 tv[4], cv[4];
 #pragma unroll
           for (int qg = 0; qg < 4; ++qg) {
-            const float4 tv = dT[((((it + 1) & 1) * a.n_t + tix) * 4 + qg) * 64 + lane];
-            float4 cv = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (32 * jt + 4 * hh + 8 * qg < JR) cv = *reinterpret_cast<const float4*>(cm + 8 * qg);
-            acc = MFMA(cv.x, tv.x, acc);
-            acc = MFMA(cv.y, tv.y, acc);
-            acc = MFMA(cv.z, tv.z, acc);
-            acc = MFMA(cv.w, tv.w, acc);
+            tv[qg] = dT[((((it + 1) & 1) * a.n_t + tix) * 4 + qg) * 64 + lane];
+            cv[qg] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (32 * jt + 4 * hh + 8 * qg < JR) cv[qg] = *reinterpret_cast<const float4*>(cm + 8 * qg);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int qg = 0; qg < 4; ++qg) {
+            acc = MFMA(cv[qg].x, tv[qg].x, acc);
+            acc = MFMA(cv[qg].y, tv[qg].y, acc);
+            acc = MFMA(cv[qg].z, tv[qg].z, acc);
+            acc = MFMA(cv[qg].w, tv[qg].w, acc);
           }
         }
       }
