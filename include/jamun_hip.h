@@ -165,7 +165,9 @@ typedef struct jamun_stats {
   int64_t conv0_flop_alg;   /* useful FLOPs of ONE hidden-layer scalar-row conv launch: 2*n_atoms*65*(mul0+mul1)*(mul0+mul1) */
   int64_t conv1_flop_alg;   /* useful FLOPs of ONE hidden-layer vector-row conv launch: 2*3*n_atoms*65*(mul0+2*mul1)*mul1   */
   int32_t edge_stride;
-  int32_t n_slices;
+  int32_t n_slices;       /* partial slabs per tile summed by the node update (max over tiles)          */
+  int32_t conv_path;      /* 1: fused matrix-core-forming conv kernel (small molecules), 0: general k_conv */
+  int32_t reserved;
 } jamun_stats;
 /* Synchronises `stream`. */
 int jamun_sampler_stats(jamun_sampler* s, jamun_stats* out, void* stream);
@@ -175,9 +177,9 @@ int jamun_sampler_stats(jamun_sampler* s, jamun_stats* out, void* stream);
  * elapsed milliseconds and launch count per class (arrays of JAMUN_PROF_NCLASS) and clears the collection. */
 #define JAMUN_PROF_GEOM 0        /* centring + radius graph + edge geometry                         */
 #define JAMUN_PROF_EDGE_H 1      /* radial-MLP hidden layer per edge                                */
-#define JAMUN_PROF_CONV0_INIT 2  /* conv contraction, scalar-output rows, initial projector          */
+#define JAMUN_PROF_CONV0_INIT 2  /* conv contraction, initial projector (fused path: all rows)        */
 #define JAMUN_PROF_CONV1_INIT 3  /* conv contraction, vector-output rows, initial projector          */
-#define JAMUN_PROF_CONV0 4       /* conv contraction, scalar-output rows, hidden layers (dominant)   */
+#define JAMUN_PROF_CONV0 4       /* conv contraction, hidden layers (dominant; fused path: all rows)  */
 #define JAMUN_PROF_CONV1 5       /* conv contraction, vector-output rows, hidden layers              */
 #define JAMUN_PROF_NODE 6        /* partial-slab reduce + gate + self/skip Linear + noise skip mix   */
 #define JAMUN_PROF_HEAD 7        /* output head + xhat/score finalize                                */

@@ -76,6 +76,8 @@ class jamun_stats(C.Structure):
         ("conv1_flop_alg", C.c_int64),
         ("edge_stride", C.c_int32),
         ("n_slices", C.c_int32),
+        ("conv_path", C.c_int32),
+        ("reserved", C.c_int32),
     ]
 
 

@@ -264,9 +264,11 @@ struct jamun_sampler {
   int2* tile_span = nullptr;
   int span_max = 0;
   // fused MFMA-forming conv kernel (small molecules): fused_JR > 0 when in use
-  int fused_JR = 0, fused_grid = 0, fused_max_segs = 0, n_slabs = 0;
+  int fused_JR = 0, fused_grid = 0, fused_max_segs = 0, n_slabs = 0, n_ftiles = 0;
   int4* fused_segs = nullptr;
-  int* tile_nslab = nullptr;
+  int2* tile_atoms = nullptr;         // [n_ftiles] {first atom, atoms (<= 32)} of each fused-kernel tile
+  std::vector<int2> ftile_atoms_h;
+  int* atom_nslab = nullptr;          // [n_atoms] partial slabs of the tile the atom belongs to
   float *x_emb = nullptr, *mu = nullptr;
   std::vector<LayerDev> layers;
   float *w_gate = nullptr, *w_vec = nullptr, *w_out = nullptr;
@@ -289,7 +291,7 @@ struct jamun_sampler {
 
   ~jamun_sampler() {
     hipFree(ptr); hipFree(bond_in_ptr); hipFree(bond_in_src); hipFree(x_emb); hipFree(mu); hipFree(tile_span);
-    hipFree(fused_segs); hipFree(tile_nslab); hipFree(w1r_all); hipFree(cmask_all);
+    hipFree(fused_segs); hipFree(atom_nslab); hipFree(tile_atoms); hipFree(w1r_all); hipFree(cmask_all);
     for (auto& L : layers) {
       free_problem(L.p0); free_problem(L.p1); free_fused(L.fu);
       hipFree(L.wcat0); hipFree(L.wcat1); hipFree(L.mix);
@@ -653,7 +655,7 @@ void forward(jamun_sampler* s, const float* y, float* xhat, float* score, hipStr
     if (L.fu.wpack) {
       FusedArgs f{};
       f.deg = s->deg; f.esrc = s->esrc; f.egeo = s->egeo; f.h = h_l; f.x = x_in;
-      f.n_atoms = s->n_atoms; f.n_pad = s->n_pad; f.S = s->S; f.XS = XSin; f.JR = s->fused_JR; f.tile_span = s->tile_span;
+      f.n_atoms = s->n_atoms; f.n_pad = s->n_pad; f.S = s->S; f.XS = XSin; f.JR = s->fused_JR; f.tile_span = s->tile_span; f.tile_atoms = s->tile_atoms;
       f.wpack = L.fu.wpack; f.a_units = L.fu.a_units; f.b_units = L.fu.b_units; f.owner = L.fu.owner; f.segs = s->fused_segs;
       f.k_stride = L.fu.k_stride; f.max_a = L.fu.max_a; f.n_p = L.fu.n_p; f.n_t = L.fu.n_t; f.max_segs = s->fused_max_segs;
       f.nt0 = L.fu.nt0; f.partial0 = s->partial0; f.partial1 = s->partial1;
@@ -682,7 +684,8 @@ void forward(jamun_sampler* s, const float* y, float* xhat, float* score, hipStr
     n.cL = s->hp.act_scalar_const; n.cS = s->hp.act_gate_const;
     n.n_atoms = s->n_atoms; n.n_pad = s->n_pad; n.n_slices = s->n_slices; n.nt0 = L.p0.nt; n.nt1 = L.p1.nt;
     n.mul0 = s->hp.mul0; n.mul1 = s->hp.mul1; n.in0 = L.in0; n.in1 = L.in1; n.XSin = XSin;
-    n.tile_nslab = L.fu.wpack ? s->tile_nslab : nullptr;
+    n.atom_nslab = L.fu.wpack ? s->atom_nslab : nullptr;
+    n.max_slabs = L.fu.wpack ? s->n_slabs : s->n_slices;
     {
       ProfScope ps(s, JAMUN_PROF_NODE, st);
       launch_node_update(n, st);
@@ -812,14 +815,9 @@ int jamun_sampler_create(const jamun_model* m, float sigma, const jamun_topology
     if (conv_set_max_lds() != 0 || conv_fused_set_max_lds() != 0 || node_update_set_max_lds() != 0)
       throw Err(JAMUN_ERR_HIP, "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed");
     {
-      std::vector<int2> spans(s->n_tiles);
-      for (int t = 0; t < s->n_tiles; ++t) {
-        const int a0 = t * 32, a1 = std::min(t * 32 + 31, N - 1);
-        spans[t] = make_int2(topo->ptr[graph_of[a0]], topo->ptr[graph_of[a1] + 1]);
-        s->span_max = std::max(s->span_max, spans[t].y - spans[t].x);
-      }
-      s->tile_span = dev_upload(spans);
-      // fused kernel: every tile must see <= 64 source atoms, <= 64 edge slots per atom, one bonded edge per ordered pair
+      // ---- fused conv kernel: eligibility and tiling.  A tile = up to 32 consecutive destination atoms whose source
+      // span (whole molecules) fits the LDS budget; tiles are cut greedily at molecule granularity, so molecules larger
+      // than 17 atoms get partly filled tiles instead of spans that do not fit.  Needs one bonded edge per ordered pair.
       bool dup = false;
       {
         std::vector<std::pair<int64_t, int64_t>> bb;
@@ -827,12 +825,49 @@ int jamun_sampler_create(const jamun_model* m, float sigma, const jamun_topology
         std::sort(bb.begin(), bb.end());
         dup = std::adjacent_find(bb.begin(), bb.end()) != bb.end();
       }
-      // row stride of the transposed tiles: a multiple of 4 (b128 reads) with JR/4 odd (8 lanes x 16 B cover all banks)
-      int JR = (s->span_max + 3) & ~3;
-      if ((JR / 4) % 2 == 0) JR += 4;
       const bool no_fused = getenv("JAMUN_NO_FUSED") != nullptr;  // debugging / A-B aid
-      if (!no_fused && !dup && JR <= 64 && s->S < 255 && hp.mul1 <= 32 && (int64_t)N * s->S * JAMUN_HS < (int64_t)0x7fffffff)
+      const int nt0 = (hp.mul0 + hp.mul1 + 31) / 32;
+      bool ok = !no_fused && !dup && s->S < 255 && hp.mul1 <= 32 && hp.mul1 > 0 && nt0 + 3 <= JAMUN_FUSED_WAVES &&
+                (int64_t)N * s->S * JAMUN_HS < (int64_t)0x7fffffff;
+      // largest row stride JR = 4 * odd (b128 reads; 8 lanes x 16 B cover all banks) whose LDS footprint fits both layer kinds
+      int jr_cap = 0;
+      for (int jr = 60; jr >= 4 && ok; jr -= 8) {
+        const int n_t = (jr + 31) / 32;
+        const size_t hid = fused_lds_bytes(s->XS, jr, (hp.mul0 + 31) / 32 + (hp.mul1 + 31) / 32, n_t, 8);
+        const size_t ini = fused_lds_bytes(s->n_emb, jr, (s->n_emb + 31) / 32, n_t, 8);
+        if (std::max(hid, ini) <= JAMUN_MAX_DYN_LDS) { jr_cap = jr; break; }
+      }
+      std::vector<int2> t_atoms, t_span;
+      if (ok && jr_cap > 0) {
+        int a0 = 0;
+        while (a0 < N && ok) {
+          const int lo = topo->ptr[graph_of[a0]];
+          int cnt = 0, hi = lo;
+          while (a0 + cnt < N && cnt < 32) {
+            const int g2 = graph_of[a0 + cnt], nhi = topo->ptr[g2 + 1];
+            if (nhi - lo > jr_cap) {
+              if (cnt == 0) ok = false;  // a single molecule exceeds the budget: general kernel
+              break;
+            }
+            cnt += std::min(nhi - (a0 + cnt), 32 - cnt);
+            hi = nhi;
+          }
+          if (!ok) break;
+          t_atoms.push_back(make_int2(a0, cnt));
+          t_span.push_back(make_int2(lo, hi));
+          s->span_max = std::max(s->span_max, hi - lo);
+          a0 += cnt;
+        }
+      } else ok = false;
+      if (ok) {
+        int JR = (s->span_max + 3) & ~3;
+        if ((JR / 4) % 2 == 0) JR += 4;
         s->fused_JR = JR;
+        s->n_ftiles = (int)t_atoms.size();
+        s->ftile_atoms_h = t_atoms;
+        s->tile_atoms = dev_upload(t_atoms);
+        s->tile_span = dev_upload(t_span);
+      }
     }
     std::vector<int> ptr_h(topo->ptr, topo->ptr + W + 1);
     s->ptr = dev_upload(ptr_h);
@@ -940,14 +975,15 @@ int jamun_sampler_create(const jamun_model* m, float sigma, const jamun_topology
       const int base = n_k / ng, rem = n_k % ng;
       s->fused_grid = cus;
       std::vector<std::vector<int4>> wg_segs(cus);
-      std::vector<int> nslab(s->n_tiles, 0);
+      const int n_tiles = s->n_ftiles;
+      std::vector<int> nslab(n_tiles, 0);
       for (int x = 0; x < ng; ++x) {
         auto extra_of = [&](int t) { const int e = ((x - t) % ng + ng) % ng; return e < rem ? ng * base + e : -1; };
         int64_t Lx = 0;
-        for (int t = 0; t < s->n_tiles; ++t) Lx += base + (extra_of(t) >= 0 ? 1 : 0);
+        for (int t = 0; t < n_tiles; ++t) Lx += base + (extra_of(t) >= 0 ? 1 : 0);
         int64_t off = 0;
         int c = 0;
-        for (int t = 0; t < s->n_tiles; ++t) {
+        for (int t = 0; t < n_tiles; ++t) {
           const int ex = extra_of(t), cnt = base + (ex >= 0 ? 1 : 0);
           int i0 = 0;
           while (i0 < cnt) {
@@ -971,7 +1007,10 @@ int jamun_sampler_create(const jamun_model* m, float sigma, const jamun_topology
       s->fused_segs = dev_upload(segs);
       s->n_slabs = 1;
       for (int v : nslab) s->n_slabs = std::max(s->n_slabs, v);
-      s->tile_nslab = dev_upload(nslab);
+      std::vector<int> an(N, 1);
+      for (int t = 0; t < n_tiles; ++t)
+        for (int i = 0; i < s->ftile_atoms_h[t].y; ++i) an[s->ftile_atoms_h[t].x + i] = nslab[t];
+      s->atom_nslab = dev_upload(an);
     }
     // ---- work buffers
     const size_t NS = (size_t)N * s->S;
@@ -1008,7 +1047,7 @@ int jamun_sampler_create(const jamun_model* m, float sigma, const jamun_topology
     s->flop_exec = 0;
     for (auto& L : s->layers) {
       s->flop_ref_per_edge += 2LL * 64 * 64 + 130LL * L.tp_numel;  // SURVEY.md §8 d
-      if (L.fu.wpack) s->flop_exec += (int64_t)s->n_tiles * (hp.edge_attr_dim + 1) * L.fu.mfma_per_k * 4096;  // 32x32x2 MFMA = 4096 FLOP
+      if (L.fu.wpack) s->flop_exec += (int64_t)s->n_ftiles * (hp.edge_attr_dim + 1) * L.fu.mfma_per_k * 4096;  // 32x32x2 MFMA = 4096 FLOP
       else s->flop_exec += 2LL * s->n_pad * (1LL * L.p0.K * L.p0.nt * 32 + 3LL * L.p1.K * L.p1.nt * 32);
     }
     HIPCHECK(hipDeviceSynchronize());
@@ -1177,6 +1216,8 @@ int jamun_sampler_stats(jamun_sampler* s, jamun_stats* out, void* stream) {
     }
     out->edge_stride = s->S;
     out->n_slices = s->fused_JR > 0 ? s->n_slabs : s->n_slices;
+    out->conv_path = s->fused_JR > 0 ? 1 : 0;
+    out->reserved = 0;
   });
 }
 

@@ -97,7 +97,8 @@ __global__ __launch_bounds__(FT, 1) void k_conv_fused(FusedArgs a) {
     const int nk = k_run + (k_extra >= 0 ? 1 : 0);
     auto k_of = [&](int kk) { return kk < k_run ? k_begin + kk : k_extra; };
     FSTAMP(t0);
-    const int n0 = tile * 32;
+    const int2 t_at = a.tile_atoms[tile];
+    const int n0 = t_at.x, n_dst = t_at.y;  // first destination atom and number of destination atoms (<= 32) of the tile
     const int2 span = a.tile_span[tile];
     const int rows = span.y - span.x;
     const int Jt4 = (rows + 3) & ~3;  // K extent of the forming products for this tile
@@ -242,7 +243,7 @@ __global__ __launch_bounds__(FT, 1) void k_conv_fused(FusedArgs a) {
       }
     }
     for (int idx = tid; idx < CT; idx += FT) pm[idx] = 0;
-    if (tid < 32) deg_lds[tid] = (n0 + tid < a.n_atoms) ? a.deg[n0 + tid] : 0;
+    if (tid < 32) deg_lds[tid] = (tid < n_dst) ? a.deg[n0 + tid] : 0;
     __syncthreads();
     for (int idx = tid; idx < 32 * a.S; idx += FT) {
       const int il = idx / a.S, t = idx - il * a.S;
@@ -457,13 +458,13 @@ __global__ __launch_bounds__(FT, 1) void k_conv_fused(FusedArgs a) {
 #pragma unroll
       for (int q = 0; q < 16; ++q) {
         const int row = (q & 3) + 8 * (q >> 2) + 4 * hh;
-        a.partial0[((size_t)slab * a.n_pad + n0 + row) * (a.nt0 * 32) + own_idx * 32 + r] = acc[q];
+        if (row < n_dst) a.partial0[((size_t)slab * a.n_pad + n0 + row) * (a.nt0 * 32) + own_idx * 32 + r] = acc[q];
       }
     } else if (own_kind == 1) {
 #pragma unroll
       for (int q = 0; q < 16; ++q) {
         const int row = (q & 3) + 8 * (q >> 2) + 4 * hh;
-        a.partial1[(((size_t)slab * a.n_pad + n0 + row) * 3 + own_idx) * 32 + r] = acc[q];
+        if (row < n_dst) a.partial1[(((size_t)slab * a.n_pad + n0 + row) * 3 + own_idx) * 32 + r] = acc[q];
       }
     }
 #ifdef JAMUN_STAMP

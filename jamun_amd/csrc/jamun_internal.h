@@ -49,6 +49,7 @@ struct FusedArgs {
   const float* x;  // [n_atoms][XS]
   int n_atoms, n_pad, S, XS, JR;  // JR: row stride of the transposed feature / coefficient tiles (4 * odd, >= every tile span)
   const int2* tile_span;  // [n_tiles] {lo, hi}: atoms whose features the tile's in-edges can read (whole molecules)
+  const int2* tile_atoms; // [n_tiles] {first destination atom, number of destination atoms (<= 32)}
   const float4* wpack;    // [k][k_stride] 16-byte weight fragments (blocks of 64 lanes)
   // forming units [waves][max_a][2]: {kind (0 scalar-row tile from coefficient tiles, 1 T tile, -1 end), tile index,
   //   n_terms | weight block, 0}, {term0, term1, term2, 0} | {row tile, weight groups, first x0 column, 0}
@@ -78,7 +79,8 @@ struct NodeArgs {
   float cL, cS;
   int n_atoms, n_pad, n_slices, nt0, nt1;
   int mul0, mul1, in0, in1, XSin;
-  const int* tile_nslab;  // [n_pad/32] partial slabs per 32-atom tile (fused conv), or nullptr: n_slices everywhere
+  const int* atom_nslab;  // [n_atoms] partial slabs to sum for the atom (fused conv), or nullptr: n_slices everywhere
+  int max_slabs;          // upper bound of the above
 };
 
 struct HeadArgs {

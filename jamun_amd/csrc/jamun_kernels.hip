@@ -202,12 +202,12 @@ __global__ __launch_bounds__(NU_T) void k_node_update(NodeArgs a) {
   const int r = lane & 31, hh = lane >> 5;
   const int w0 = a.nt0 * 32;  // padded row width of partial0
   const int w1 = a.nt1 * 32;
-  const int ns = a.tile_nslab ? a.tile_nslab[blockIdx.x] : a.n_slices;
+  const int ns_max = a.atom_nslab ? a.max_slabs : a.n_slices;
   // ---- phase 1a: scalar rows: sum of the partial slabs (fixed order), mean over in-edges, activation / gate.
   // NU_U independent elements per thread and pass, so their slab loads are in flight together.
   for (int base = tid; base < 32 * w0; base += NU_T * NU_U) {
     float m[NU_U];
-    int il[NU_U], w[NU_U];
+    int il[NU_U], w[NU_U], ns[NU_U];
     bool ok[NU_U];
 #pragma unroll
     for (int u = 0; u < NU_U; ++u) {
@@ -215,12 +215,13 @@ __global__ __launch_bounds__(NU_T) void k_node_update(NodeArgs a) {
       il[u] = idx / w0;
       w[u] = idx - il[u] * w0;
       ok[u] = idx < 32 * w0 && w[u] < G0 && n0 + il[u] < a.n_atoms;
+      ns[u] = !ok[u] ? 0 : (a.atom_nslab ? a.atom_nslab[n0 + il[u]] : a.n_slices);
       m[u] = 0.f;
     }
-    for (int s = 0; s < ns; ++s) {
+    for (int s = 0; s < ns_max; ++s) {
 #pragma unroll
       for (int u = 0; u < NU_U; ++u)
-        if (ok[u]) m[u] += a.partial0[((size_t)s * a.n_pad + n0 + il[u]) * w0 + w[u]];
+        if (s < ns[u]) m[u] += a.partial0[((size_t)s * a.n_pad + n0 + il[u]) * w0 + w[u]];
     }
 #pragma unroll
     for (int u = 0; u < NU_U; ++u) {
@@ -265,14 +266,19 @@ __global__ __launch_bounds__(NU_T) void k_node_update(NodeArgs a) {
   {
     const int nv = 32 * 3 * w1;
     float mv[NU_V];
+    int nsv[NU_V];
 #pragma unroll
-    for (int u = 0; u < NU_V; ++u) mv[u] = 0.f;
-    for (int s = 0; s < ns; ++s) {
+    for (int u = 0; u < NU_V; ++u) {
+      const int idx = tid + NU_T * u, il = idx / (3 * w1);
+      mv[u] = 0.f;
+      nsv[u] = (idx < nv && n0 + il < a.n_atoms) ? (a.atom_nslab ? a.atom_nslab[n0 + il] : a.n_slices) : 0;
+    }
+    for (int s = 0; s < ns_max; ++s) {
 #pragma unroll
       for (int u = 0; u < NU_V; ++u) {
         const int idx = tid + NU_T * u;
         const int il = idx / (3 * w1), rem = idx - il * 3 * w1;
-        if (idx < nv && n0 + il < a.n_atoms) mv[u] += a.partial1[((size_t)s * a.n_pad + n0 + il) * 3 * w1 + rem];
+        if (s < nsv[u]) mv[u] += a.partial1[((size_t)s * a.n_pad + n0 + il) * 3 * w1 + rem];
       }
     }
     __syncthreads();

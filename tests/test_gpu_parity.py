@@ -157,6 +157,47 @@ def test_forward_matches_oracle(dev, golden_dir, kind):
     assert rmsd(s, ref["score"]) <= RMSD_TOL_NM / sigma**2  # score = (xhat - y)/sigma^2 amplifies by 625
 
 
+@pytest.mark.parametrize("kind", ["ag4", "chain17x6", "ragged_small"])
+def test_fused_and_fallback_conv_agree(dev, golden_dir, kind, monkeypatch):
+    """The two conv kernels (fused matrix-core forming for small molecules, general k_conv) are independent
+    implementations of the same contraction: both must meet the oracle (where a cached oracle output exists), and each
+    other, on the same input.  `ragged` (molecules up to 57 atoms) and `dense70` must select the general kernel by
+    themselves."""
+    from jamun_amd import synth
+    from jamun_amd.data import WalkerBatch
+    from jamun_amd.model import Denoiser
+    from jamun_amd.native import NativeSampler
+
+    model = Denoiser.from_checkpoint_dict(_ckpt("strong")).to(dev)
+    if kind == "ragged_small":  # ragged atom counts incl. 1- and 2-atom walkers, tile spans <= 60 atoms
+        mols = [synth.random_chain(n, seed=100 + i) for i, n in enumerate([5, 9, 20, 1, 13, 2, 17, 20, 3, 11, 19, 7])]
+        ref = None
+        torch.manual_seed(5)
+        batch = WalkerBatch.from_molecules(mols).to(dev)
+        y = batch.pos + 0.04 * torch.randn(batch.pos.shape).to(dev)
+    else:
+        ref = _golden(golden_dir, f"oracle_forward_{kind}")
+        batch = WalkerBatch.from_molecules(_mols(kind)).to(dev)
+        y = ref["y"].to(dev)
+    monkeypatch.delenv("JAMUN_NO_FUSED", raising=False)
+    fused = NativeSampler(model._native, 0.04, batch, dev)
+    assert fused.stats()["conv_path"] == 1
+    monkeypatch.setenv("JAMUN_NO_FUSED", "1")
+    general = NativeSampler(model._native, 0.04, batch, dev)
+    assert general.stats()["conv_path"] == 0
+    xf, xg = fused.xhat(y), general.xhat(y)
+    if ref is not None:
+        assert rmsd(xf, ref["xhat"]) <= RMSD_TOL_NM and rmsd(xg, ref["xhat"]) <= RMSD_TOL_NM
+    assert rmsd(xf, xg) <= RMSD_TOL_NM
+    for l in range(6):
+        a, b = fused.debug_read(0, l).cpu(), general.debug_read(0, l).cpu()
+        assert (a - b).abs().max().item() <= 2e-5 * max(b.abs().max().item(), 1e-6), l
+    monkeypatch.delenv("JAMUN_NO_FUSED")
+    for big in ("ragged", "dense70"):
+        smp = NativeSampler(model._native, 0.04, WalkerBatch.from_molecules(_mols(big)).to(dev), dev)
+        assert smp.stats()["conv_path"] == 0, big
+
+
 def test_forward_matches_live_oracle(dev, ckpt):
     """Same comparison with the oracle run live on this box (small case), so the cache is not the only witness."""
     from jamun_amd.data import WalkerBatch
