@@ -70,6 +70,21 @@ def cpu_baseline(budget_walkers=8, frames=3):
     }
 
 
+def _pmc_traffic(kernel: str):
+    import glob
+
+    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "*_pmc_traffic.json")))
+    for f in reversed(files):
+        try:
+            d = json.load(open(f))
+        except Exception:
+            continue
+        for k, v in d.items():
+            if isinstance(v, dict) and k.startswith(kernel) and "FETCH_SIZE_KB_per_dispatch" in v:
+                return (2.0 * v["FETCH_SIZE_KB_per_dispatch"] + v.get("WRITE_SIZE_KB_per_dispatch", 0.0)) * 1024.0, os.path.basename(f)
+    return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -173,11 +188,18 @@ def main():
                 "unit": "TFLOP/s",
                 "frac": ach / F32_MFMA_PEAK_TFLOPS,
                 "traffic": None,
+                "traffic_unit": "bytes per launch = 2 x FETCH_SIZE + WRITE_SIZE (gfx950 read correction of MI355X_MICROARCH.md)",
                 "avg_launch_ms": avg0,
                 "launches": c0,
                 "flop_per_launch": flop,
                 "mfma_flop_executed_per_forward": stats["flop_executed"],  # all conv launches of one forward, padding included
             }
+            # HBM-side bytes per launch from the committed PMC passes of this same command (profiles/collect.sh); rocprofv3
+            # cannot run inside the timed process, so the newest committed summary is quoted, with its file name
+            tr = _pmc_traffic("k_conv_fused" if fused else "k_conv")
+            if tr is not None:
+                out["roofline"]["traffic"] = tr[0]
+                out["roofline"]["traffic_source"] = tr[1]
             tot = sum(ms for ms, _ in prof.values())
             out["kernel_time_share"] = {k: round(ms / tot, 4) for k, (ms, _) in prof.items()} if tot > 0 else {}
             out["kernel_avg_ms"] = {k: (ms / c if c else 0.0) for k, (ms, c) in prof.items()}
