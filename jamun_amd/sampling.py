@@ -146,6 +146,11 @@ class ABOBA:
     def _kwargs(self, kwargs):
         return {f.name: getattr(self, f.name) for f in dataclasses.fields(self)} | kwargs
 
+    def replace(self, **changes):
+        """New integrator with some fields changed — what the parameter-schedule callbacks below call on the
+        integrator (``walkjump/_callbacks.py:20,44,63``)."""
+        return dataclasses.replace(self, **changes)
+
     def __call__(self, y: torch.Tensor, score_fn: Callable, **kwargs):
         y, v, y_traj, score_traj, self.last_extras = _run_walk("aboba", y, score_fn, **self._kwargs(kwargs))
         return y, v, y_traj, score_traj
@@ -156,6 +161,60 @@ class BAOAB(ABOBA):
     def __call__(self, y: torch.Tensor, score_fn: Callable, **kwargs):
         y, v, y_traj, score_traj, self.last_extras = _run_walk("baoab", y, score_fn, **self._kwargs(kwargs))
         return y, v, y_traj, score_traj
+
+
+# ---- parameter schedules for measurement-indexed sampling (``walkjump/_callbacks.py:10-77``).  Protocol:
+# ``mcmc = cb.on_before_sample(mcmc, t)`` ... ``mcmc = cb.on_after_sample(mcmc, t)`` with t the 1-based measurement index.
+class MeasurementDependentParametersCallback:
+    """Overrides integrator fields for the measurements listed in ``parameters_by_measurement`` and restores them after."""
+
+    def __init__(self, parameters_by_measurement: Optional[dict] = None, verbose: bool = False):
+        self.parameters_by_measurement = parameters_by_measurement or {}
+        self.verbose = verbose
+        self.previous_params = None
+
+    def on_before_sample(self, mcmc, t: int):
+        override = self.parameters_by_measurement.get(t)
+        if override:
+            self.previous_params = {f.name: getattr(mcmc, f.name) for f in dataclasses.fields(mcmc)}
+            mcmc = mcmc.replace(**(self.previous_params | override))
+        return mcmc
+
+    def on_after_sample(self, mcmc, t: int):
+        if self.previous_params is not None:
+            mcmc, self.previous_params = mcmc.replace(**self.previous_params), None
+        return mcmc
+
+
+class DeltaSqrtDecayCallback:
+    """``delta / sqrt(t)`` for measurement t, original step size restored afterwards."""
+
+    def __init__(self, verbose: bool = False):
+        self.verbose = verbose
+        self.delta_orig = None
+
+    def on_before_sample(self, mcmc, t: int):
+        self.delta_orig = mcmc.delta
+        return mcmc.replace(delta=self.delta_orig / math.sqrt(t))
+
+    def on_after_sample(self, mcmc, t: int):
+        return mcmc.replace(delta=self.delta_orig)
+
+
+class InterpolateParametersCallback:
+    """Moves each listed field from ``params[name][0]`` to ``params[name][1]`` with weight ``1 - sqrt(1/t)``; the
+    result keeps the type of the start value (ints stay ints).  Not restored after the sample (as the reference)."""
+
+    def __init__(self, params: Dict[str, tuple], verbose: bool = False):
+        self.params = params
+        self.verbose = verbose
+
+    def on_before_sample(self, mcmc, t: int):
+        f = 1 - math.sqrt(1.0 / t)
+        return mcmc.replace(**{k: type(v[0])((1 - f) * v[0] + f * v[1]) for k, v in self.params.items()})
+
+    def on_after_sample(self, mcmc, t: int):
+        return mcmc
 
 
 class SingleMeasurementSampler:

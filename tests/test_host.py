@@ -201,3 +201,28 @@ def test_two_process_gloo_gather_and_sharding(tmp_path):
         assert p.returncode == 0, e[-2000:]
     draws = [json.loads(o.strip().splitlines()[-1])["draw"] for o, _ in outs]
     assert draws[0] != draws[1]  # seed + rank: ranks generate different chains
+
+
+def test_parameter_schedule_callbacks():
+    """walkjump/_callbacks.py:10-77 — override / decay / interpolate integrator fields per measurement index."""
+    import math
+
+    from jamun_amd.sampling import (BAOAB, DeltaSqrtDecayCallback, InterpolateParametersCallback,
+                                    MeasurementDependentParametersCallback)
+
+    base = BAOAB(delta=0.04, friction=1.0, steps=50)
+    cb = MeasurementDependentParametersCallback({2: {"delta": 0.01, "steps": 7}})
+    assert cb.on_before_sample(base, 1) is base and cb.on_after_sample(base, 1) is base
+    m2 = cb.on_before_sample(base, 2)
+    assert (m2.delta, m2.steps, m2.friction) == (0.01, 7, 1.0) and isinstance(m2, BAOAB)
+    back = cb.on_after_sample(m2, 2)
+    assert (back.delta, back.steps) == (0.04, 50) and cb.previous_params is None
+    dc = DeltaSqrtDecayCallback()
+    m4 = dc.on_before_sample(base, 4)
+    assert m4.delta == 0.04 / math.sqrt(4) and dc.on_after_sample(m4, 4).delta == 0.04
+    ip = InterpolateParametersCallback({"delta": (0.04, 0.01), "steps": (10, 50)})
+    m1 = ip.on_before_sample(base, 1)
+    assert m1.delta == 0.04 and m1.steps == 10
+    m4 = ip.on_before_sample(base, 4)  # f = 0.5
+    assert abs(m4.delta - 0.025) < 1e-12 and m4.steps == 30 and isinstance(m4.steps, int)
+    assert ip.on_after_sample(m4, 4) is m4
