@@ -63,7 +63,15 @@ class Denoiser:
     def from_checkpoint_dict(cls, ckpt: dict) -> "Denoiser":
         hp = ckpt["hyper_parameters"]
         arch = _kw(hp["arch"])
-        # the output-head / hidden-layer factories are fixed for the default architecture (e3conv.yaml:15-33)
+        # the output-head / hidden-layer factories are fixed for the default architecture (e3conv.yaml:15-33); the
+        # separable-convolution variant (e3conv_separable.yaml:14-19) has a different tensor product and is not built
+        try:
+            conv = _kw(arch.get("hidden_layer_factory", {})).get("conv")
+            conv_name = repr(getattr(conv, "func", None) or (conv.get("_target_") if hasattr(conv, "get") else conv))
+        except TypeError:
+            conv_name = ""
+        if "Separable" in conv_name or "Experimental" in conv_name:
+            raise NotImplementedError(f"hidden_layer_factory.conv = {conv_name}: only jamun.e3tools.nn.Conv is implemented")
         arch = {k: v for k, v in arch.items() if k not in ("hidden_layer_factory", "output_head_factory", "_target_", "_partial_")}
         return cls(
             strip_prefix(ckpt["state_dict"]),

@@ -226,3 +226,20 @@ def test_parameter_schedule_callbacks():
     m4 = ip.on_before_sample(base, 4)  # f = 0.5
     assert abs(m4.delta - 0.025) < 1e-12 and m4.steps == 30 and isinstance(m4.steps, int)
     assert ip.on_after_sample(m4, 4) is m4
+
+
+def test_separable_conv_checkpoint_is_rejected():
+    """e3conv_separable.yaml swaps the tensor product; that variant is not built and must fail loudly at load."""
+    import functools
+
+    from jamun_amd import synth
+    from jamun_amd.model import Denoiser
+
+    class SeparableConv:  # stands in for jamun.e3tools.nn.SeparableConv inside the pickled partial
+        pass
+
+    ck = synth.synthetic_checkpoint()
+    ck["hyper_parameters"]["arch"] = dict(ck["hyper_parameters"]["arch"])
+    ck["hyper_parameters"]["arch"]["hidden_layer_factory"] = functools.partial(dict, conv=functools.partial(SeparableConv))
+    with pytest.raises(NotImplementedError, match="Separable"):
+        Denoiser.from_checkpoint_dict(ck)
