@@ -274,7 +274,7 @@ struct jamun_sampler {
   float *w_gate = nullptr, *w_vec = nullptr, *w_out = nullptr;
   // work buffers
   float *w1r_all = nullptr, *cmask_all = nullptr;  // [layers][64][32], [layers][2][64]
-  size_t h_stride = 0;
+  size_t h_stride = 0, h_kstride = 0;  // per layer: [65 hidden rows][h_kstride edge slots]
   bool h_batched = false;
   float *yc = nullptr, *h = nullptr, *partial0 = nullptr, *partial1 = nullptr, *g = nullptr, *tmp = nullptr;
   float *xhat_buf = nullptr, *score_buf = nullptr, *psi = nullptr;
@@ -650,11 +650,11 @@ void forward(jamun_sampler* s, const float* y, float* xhat, float* score, hipStr
       const size_t NL = s->h_batched ? s->layers.size() : 1;
       ProfScope ps(s, JAMUN_PROF_EDGE_H, st);
       launch_edge_h(s->deg, s->esrc, s->egeo, s->n_atoms, s->S, s->w1r_all + l * 64 * 32, s->cmask_all + l * 128, (int)NL,
-                    s->mu, s->rb_step, s->h, s->h_stride, st);
+                    s->mu, s->rb_step, s->h, s->h_stride, s->h_kstride, st);
     }
     if (L.fu.wpack) {
       FusedArgs f{};
-      f.deg = s->deg; f.esrc = s->esrc; f.egeo = s->egeo; f.h = h_l; f.x = x_in;
+      f.deg = s->deg; f.esrc = s->esrc; f.egeo = s->egeo; f.h = h_l; f.h_kstride = s->h_kstride; f.x = x_in;
       f.n_atoms = s->n_atoms; f.n_pad = s->n_pad; f.S = s->S; f.XS = XSin; f.JR = s->fused_JR; f.tile_span = s->tile_span; f.tile_atoms = s->tile_atoms;
       f.wpack = L.fu.wpack; f.a_units = L.fu.a_units; f.b_units = L.fu.b_units; f.owner = L.fu.owner; f.segs = s->fused_segs;
       f.k_stride = L.fu.k_stride; f.max_a = L.fu.max_a; f.n_p = L.fu.n_p; f.n_t = L.fu.n_t; f.max_segs = s->fused_max_segs;
@@ -664,7 +664,7 @@ void forward(jamun_sampler* s, const float* y, float* xhat, float* score, hipStr
       if (rcode != 0) throw Err(JAMUN_ERR_INVALID, "fused conv launch failed (configuration not supported)");
     } else {
     ConvArgs a{};
-    a.deg = s->deg; a.esrc = s->esrc; a.egeo = s->egeo; a.h = h_l; a.x = x_in;
+    a.deg = s->deg; a.esrc = s->esrc; a.egeo = s->egeo; a.h = h_l; a.h_kstride = s->h_kstride; a.x = x_in;
     a.n_atoms = s->n_atoms; a.n_pad = s->n_pad; a.n_tiles = s->n_tiles; a.S = s->S; a.S4 = (s->S + 3) & ~3; a.XS = XSin;
     a.n_slices = s->n_slices;
     for (int pi = 0; pi < 2; ++pi) {
@@ -828,7 +828,7 @@ int jamun_sampler_create(const jamun_model* m, float sigma, const jamun_topology
       const bool no_fused = getenv("JAMUN_NO_FUSED") != nullptr;  // debugging / A-B aid
       const int nt0 = (hp.mul0 + hp.mul1 + 31) / 32;
       bool ok = !no_fused && !dup && s->S < 255 && hp.mul1 <= 32 && hp.mul1 > 0 && nt0 + 3 <= JAMUN_FUSED_WAVES &&
-                (int64_t)N * s->S * JAMUN_HS < (int64_t)0x7fffffff;
+                (int64_t)N * s->S < (int64_t)0x7fffffff;
       // largest row stride JR = 4 * odd (b128 reads; 8 lanes x 16 B cover all banks) whose LDS footprint fits both layer kinds
       int jr_cap = 0;
       for (int jr = 60; jr >= 4 && ok; jr -= 8) {
@@ -1026,7 +1026,8 @@ int jamun_sampler_create(const jamun_model* m, float sigma, const jamun_topology
       }
       s->w1r_all = dev_upload(w1r_all);
       s->cmask_all = dev_upload(cmask_all);
-      s->h_stride = NS * JAMUN_HS;
+      s->h_kstride = (NS + 63) & ~(size_t)63;
+      s->h_stride = s->h_kstride * JAMUN_HROWS;
       s->h_batched = s->h_stride * s->layers.size() * sizeof(float) <= ((size_t)4 << 30);  // all layers' h~ at once, up to 4 GiB
       s->h = dev_alloc<float>(s->h_stride * (s->h_batched ? s->layers.size() : 1));
     }

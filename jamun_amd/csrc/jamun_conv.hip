@@ -161,7 +161,7 @@ __device__ __forceinline__ void stage_h(float* __restrict__ h_lds, const ConvArg
     const int t = rem / ks, kk = rem - t * ks;
     const int i = n0 + il;
     float v = 0.f;  // padding slots (t >= deg) contribute nothing
-    if (i < a.n_atoms && t < a.deg[i]) v = a.h[((size_t)i * a.S + t) * JAMUN_HS + k0 + kk];
+    if (i < a.n_atoms && t < a.deg[i]) v = a.h[(size_t)(k0 + kk) * a.h_kstride + (size_t)i * a.S + t];
     h_lds[((size_t)il * a.S4 + t) * L::HST + kk] = v;
   }
 }

@@ -269,7 +269,7 @@ __global__ __launch_bounds__(FT, 1) void k_conv_fused(FusedArgs a) {
     __syncthreads();
     // Each thread owns up to FPAIRS (destination il, source row j) pairs, p = il * JR + j: slots, unit vectors and h~
     // addresses live in registers for the whole segment.
-    int p_oa[FPAIRS], p_ob[FPAIRS];  // h~ element offsets of the radial / bonded edge of the pair (0 if none)
+    int p_oa[FPAIRS], p_ob[FPAIRS];  // edge slot of the radial / bonded edge of the pair (a stand-in if none)
     int p_has = 0;                   // bit 2i: pair i has a radial edge, bit 2i+1: a bonded edge
     float p_ga[FPAIRS][3], p_gb[FPAIRS][3];
     float p_ha[FPAIRS], p_hb[FPAIRS];
@@ -281,18 +281,19 @@ __global__ __launch_bounds__(FT, 1) void k_conv_fused(FusedArgs a) {
       const int ta = pt & 0xff, tb = (pt >> 8) & 0xff;
       // loads are unconditional (slot 0 of atom n0 stands in for absent edges): no branches around them
       const int ea = ta ? (n0 + il) * a.S + ta - 1 : n0 * a.S, eb = tb ? (n0 + il) * a.S + tb - 1 : n0 * a.S;
-      p_oa[i] = ea * JAMUN_HS;
-      p_ob[i] = eb * JAMUN_HS;
+      p_oa[i] = ea;
+      p_ob[i] = eb;
       p_has |= (ta ? 1 : 0) << (2 * i) | (tb ? 1 : 0) << (2 * i + 1);
       const float4 ga = a.egeo[ea], gb = a.egeo[eb];
       p_ga[i][0] = ta ? ga.x : 0.f; p_ga[i][1] = ta ? ga.y : 0.f; p_ga[i][2] = ta ? ga.z : 0.f;
       p_gb[i][0] = tb ? gb.x : 0.f; p_gb[i][1] = tb ? gb.y : 0.f; p_gb[i][2] = tb ? gb.z : 0.f;
     }
-    auto load_h = [&](int k) {  // raw loads; write_c masks out the stand-ins of absent edges
+    auto load_h = [&](int k) {  // raw loads (row k of the [k][slot] table: neighbouring slots share cache lines); write_c masks out the stand-ins of absent edges
+      const float* __restrict__ hk = a.h + (size_t)k * a.h_kstride;
 #pragma unroll
       for (int i = 0; i < FPAIRS; ++i) {
-        p_ha[i] = a.h[p_oa[i] + k];
-        p_hb[i] = a.h[p_ob[i] + k];
+        p_ha[i] = hk[p_oa[i]];
+        p_hb[i] = hk[p_ob[i]];
       }
     };
     auto write_c = [&](float* __restrict__ cbuf) {

@@ -4,7 +4,7 @@
 #include <stdint.h>
 
 #define JAMUN_MAX_NEIGHBORS 32  // torch_geometric.nn.radius_graph default (src/jamun/model/denoiser.py:149)
-#define JAMUN_HS 68             // row stride of the per-edge radial-MLP activations: 64 hidden + bias row + pad
+#define JAMUN_HROWS 65          // rows of the per-layer radial-MLP activation table: 64 hidden units + the bias row
 
 // conv kernel geometry (jamun_conv.hip)
 #define JAMUN_KSUB0 5  // hidden units per k-subgroup, scalar-output rows (subgroups of 4 or 5)
@@ -26,7 +26,8 @@ struct ConvArgs {
   const int* deg;
   const int* esrc;
   const float4* egeo;
-  const float* h;  // [n_atoms*S][JAMUN_HS]
+  const float* h;  // [hidden unit k (65 rows)][h_kstride >= n_atoms*S]: radial-MLP activations per edge slot
+  size_t h_kstride;
   const float* x;  // [n_atoms][XS]
   int n_atoms, n_pad, n_tiles, S, S4, XS;  // S4 = S rounded up to a multiple of 4 (edge batches)
   // problem
@@ -45,7 +46,8 @@ struct FusedArgs {
   const int* deg;
   const int* esrc;
   const float4* egeo;
-  const float* h;  // [n_atoms*S][JAMUN_HS]
+  const float* h;  // [hidden unit k (65 rows)][h_kstride >= n_atoms*S]: radial-MLP activations per edge slot
+  size_t h_kstride;
   const float* x;  // [n_atoms][XS]
   int n_atoms, n_pad, S, XS, JR;  // JR: row stride of the transposed feature / coefficient tiles (4 * odd, >= every tile span)
   const int2* tile_span;  // [n_tiles] {lo, hi}: atoms whose features the tile's in-edges can read (whole molecules)
@@ -111,7 +113,7 @@ void launch_geom(const float* y, const int* ptr, int n_graphs, float c_in, float
                  const int* bis, int mean_center, float* yc, int* deg, int* esrc, float4* egeo, hipStream_t st);
 void launch_edge_h(const int* deg, const int* esrc, const float4* egeo, int n_atoms, int S, const float* w1r_all,
                    const float* cmask_all, int n_layers, const float* mu, float step, float* h_all, size_t h_layer_stride,
-                   hipStream_t st);
+                   size_t h_kstride, hipStream_t st);
 int launch_conv(const ConvArgs& a, int rc, int nt, hipStream_t st);
 int conv_set_max_lds();
 int launch_conv_fused(const FusedArgs& a, int grid, hipStream_t st);

@@ -127,51 +127,71 @@ __global__ void k_geom(const float* __restrict__ y, const int* __restrict__ ptr,
 // (src/jamun/model/arch/e3conv.py:118-127, src/jamun/e3tools/nn/_mlp.py:10-34).
 // One wave per destination atom, lane = hidden unit k.  cmask[mask][k] = b1[k] + W1[k,:32].E_bond[mask].
 // ------------------------------------------------------------------------------------------------
-// blockIdx.y = layer: all layers of a forward share the edge geometry, so their radial MLPs run in one launch.
+// On the matrix cores, transposed: D^T[k][e] = sum_r W1[k][r] rad_e[r] for a tile of 32 edge slots, so that the result
+// lands as rows of hidden units over consecutive slots — the `[k][slot]` layout the conv kernels read with coalesced
+// loads.  One wave = 32 consecutive slots of the fixed-stride edge table, ALL layers (the radial basis of a slot is
+// computed once, in the lane that owns it, directly in B-operand layout: lane (slot, hh) holds basis 2s+hh).
+typedef float eh_f32x16 __attribute__((ext_vector_type(16)));
 __global__ __launch_bounds__(256) void k_edge_h(const int* __restrict__ deg, const int* __restrict__ esrc,
                                                 const float4* __restrict__ egeo, int n_atoms, int S,
                                                 const float* __restrict__ w1r_all,    // [layers][32][64] radial part of W1, transposed
                                                 const float* __restrict__ cmask_all,  // [layers][2][64]
+                                                int n_layers,
                                                 const float* __restrict__ mu,         // [32] basis centres
-                                                float step, float* __restrict__ h_all, size_t h_layer_stride) {
-  const int lane = threadIdx.x & 63;
-  const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (i >= n_atoms) return;
-  const float* __restrict__ w1r = w1r_all + (size_t)blockIdx.y * 64 * 32;
-  const float* __restrict__ cmask = cmask_all + (size_t)blockIdx.y * 128;
-  float* __restrict__ h = h_all + (size_t)blockIdx.y * h_layer_stride;
-  float w[32];
+                                                float step, float* __restrict__ h_all, size_t h_layer_stride,
+                                                size_t h_kstride) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int e_l = lane & 31, hh = lane >> 5;
+  const long n_slots = (long)n_atoms * S;
+  const long slot = ((long)blockIdx.x * 4 + wave) * 32 + e_l;
+  const int i = slot < n_slots ? (int)(slot / S) : 0;
+  const int t = (int)(slot - (long)i * S);
+  const bool valid = slot < n_slots && t < deg[i];
+  if (__ballot(valid) == 0) return;  // wave-uniform: no edge in these 32 slots
+  float d = 0.f;
+  int bonded = 0;
+  if (valid) {
+    d = egeo[slot].w;
+    bonded = esrc[slot] < 0 ? 1 : 0;
+  }
+  float rad[16];
 #pragma unroll
-  for (int r = 0; r < 32; ++r) w[r] = w1r[r * 64 + lane];  // host-transposed: coalesced
-  const float c0 = cmask[lane], c1 = cmask[64 + lane];
-  const float mu_l = mu[lane & 31];
-  const int d_i = deg[i];
-  for (int t0 = 0; t0 < d_i; t0 += 64) {
-    // lane t loads edge t0 + t (one coalesced load for the whole atom); the loop below reads them back with readlane
-    float d_l = 0.f;
-    int b_l = 0;
-    if (t0 + lane < d_i) {
-      const size_t e = (size_t)i * S + t0 + lane;
-      d_l = egeo[e].w;
-      b_l = esrc[e] < 0 ? 1 : 0;
-    }
-    const int cnt = d_i - t0 < 64 ? d_i - t0 : 64;
-    for (int t = 0; t < cnt; ++t) {
-      const size_t e = (size_t)i * S + t0 + t;
-      const float d = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, d_l), t));
-      const bool bonded = __builtin_amdgcn_readlane(b_l, t) != 0;
-      float diff = FSUB(d, mu_l) / step;
-      float rad = expf(-FMUL(diff, diff)) / 1.12f;
-      float pre = bonded ? c1 : c0;
+  for (int s = 0; s < 16; ++s) {
+    const float diff = FSUB(d, mu[2 * s + hh]) / step;
+    rad[s] = expf(-FMUL(diff, diff)) / 1.12f;
+  }
+  // (layer, k-tile) pairs run as one flat loop; the A fragments of the next pair are fetched before the MFMAs of the current
+  // blockIdx.y picks a group of layers (more waves in flight; the radial basis is recomputed per group, 16 expf)
+  const int l_per = (n_layers + gridDim.y - 1) / gridDim.y, l_begin = blockIdx.y * l_per;
+  const int l_end = l_begin + l_per < n_layers ? l_begin + l_per : n_layers;
+  const float* __restrict__ wbase = w1r_all + hh * 64 + e_l;  // A operand: W1[k = 32 mt + (lane & 31)][r = 2s + hh]
+  float av[16], an[16];
 #pragma unroll
-      for (int r = 0; r < 32; ++r) {
-        float rr = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, rad), r));
-        pre = fmaf(w[r], rr, pre);
-      }
-      float hv = pre / (1.f + expf(-pre));
-      h[e * JAMUN_HS + lane] = hv;
-      if (lane < JAMUN_HS - 64) h[e * JAMUN_HS + 64 + lane] = (lane == 0) ? 1.f : 0.f;
+  for (int s = 0; s < 16; ++s) av[s] = wbase[(size_t)l_begin * 64 * 32 + 2 * s * 64];
+  const int n_jobs = 2 * l_end;
+  for (int j = 2 * l_begin; j < n_jobs; ++j) {
+    const int l = j >> 1, mt = j & 1;
+    const int jn = j + 1 < n_jobs ? j + 1 : j;
+    const float* __restrict__ wn = wbase + (size_t)(jn >> 1) * 64 * 32 + 32 * (jn & 1);
+#pragma unroll
+    for (int s = 0; s < 16; ++s) an[s] = wn[2 * s * 64];
+    const float* __restrict__ c = cmask_all + (size_t)l * 128 + bonded * 64 + 4 * hh;  // c_mask[mask of this lane's slot][k]
+    float* __restrict__ h = h_all + (size_t)l * h_layer_stride + slot;
+    eh_f32x16 acc;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc[q] = c[32 * mt + (q & 3) + 8 * (q >> 2)];  // accumulator row of register q: hidden unit
+#pragma unroll
+    for (int s = 0; s < 16; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], rad[s], acc, 0, 0, 0);
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int k = 32 * mt + (q & 3) + 8 * (q >> 2) + 4 * hh;
+      const float pre = acc[q];
+      const float hv = pre / (1.f + expf(-pre));
+      if (valid) h[(size_t)k * h_kstride] = hv;
     }
+    if (mt == 1 && valid && hh == 0) h[(size_t)64 * h_kstride] = 1.f;  // bias row of the second radial-MLP layer
+#pragma unroll
+    for (int s = 0; s < 16; ++s) av[s] = an[s];
   }
 }
 
@@ -625,9 +645,11 @@ void launch_geom(const float* y, const int* ptr, int n_graphs, float c_in, float
 }
 void launch_edge_h(const int* deg, const int* esrc, const float4* egeo, int n_atoms, int S, const float* w1r_all,
                    const float* cmask_all, int n_layers, const float* mu, float step, float* h_all, size_t h_layer_stride,
-                   hipStream_t st) {
-  hipLaunchKernelGGL(k_edge_h, dim3((n_atoms + 3) / 4, n_layers), dim3(256), 0, st, deg, esrc, egeo, n_atoms, S, w1r_all,
-                     cmask_all, mu, step, h_all, h_layer_stride);
+                   size_t h_kstride, hipStream_t st) {
+  const long tiles = ((long)n_atoms * S + 31) / 32;
+  const int groups = n_layers >= 6 ? 3 : (n_layers >= 2 ? 2 : 1);
+  hipLaunchKernelGGL(k_edge_h, dim3((unsigned)((tiles + 3) / 4), groups), dim3(256), 0, st, deg, esrc, egeo, n_atoms, S, w1r_all,
+                     cmask_all, n_layers, mu, step, h_all, h_layer_stride, h_kstride);
 }
 
 size_t node_update_lds_bytes(const NodeArgs& a) {
