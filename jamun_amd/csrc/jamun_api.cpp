@@ -773,6 +773,8 @@ int jamun_sampler_create(const jamun_model* m, float sigma, const jamun_topology
     s->n_pad = ((topo->n_atoms + 31) / 32) * 32;
     s->XS = hp.mul0 + 3 * hp.mul1;
     s->n_emb = hp.emb_dim[0] + hp.emb_dim[1] + hp.emb_dim[2] + hp.emb_dim[3];
+    if (s->n_emb > 224 || hp.mul0 + 3 * hp.mul1 > 224 || hp.mul0 + hp.mul1 > 160 || hp.mul1 > 32)
+      throw Err(JAMUN_ERR_INVALID, "irreps too wide for the node-update tiling (embedding <= 224, hidden <= 160 channels, <= 32 vectors)");
     const int N = topo->n_atoms, W = topo->n_graphs;
     // ---- normalisation factors in fp32, op for op as Denoiser.normalization_factors (denoiser.py:116-136,177-178)
     {

@@ -208,8 +208,9 @@ __global__ __launch_bounds__(256) void k_edge_h(const int* __restrict__ deg, con
 typedef float nu_f32x16 __attribute__((ext_vector_type(16)));
 #define NU_LD 33
 #define NU_T 512  // threads per workgroup
-#define NU_U 4    // independent elements per thread and pass (phase 1)
-#define NU_V 8    // vector-row elements per thread: 32 atoms x 3 planes x 32 channels / NU_T, rounded up (nt1 == 1)
+#define NU_U 5    // 32-column tiles of the scalar rows per thread (nt0 <= 5)
+#define NU_X 7    // 32-column tiles of the input features per thread (XSin <= 224)
+#define NU_V 6    // (atom, plane) rows per thread: 32 atoms x 3 planes / 16 rows per pass (nt1 == 1)
 __global__ __launch_bounds__(NU_T) void k_node_update(NodeArgs a) {
   extern __shared__ float sm[];
   const int G0 = a.mul0 + a.mul1;
@@ -223,98 +224,93 @@ __global__ __launch_bounds__(NU_T) void k_node_update(NodeArgs a) {
   const int w0 = a.nt0 * 32;  // padded row width of partial0
   const int w1 = a.nt1 * 32;
   const int ns_max = a.atom_nslab ? a.max_slabs : a.n_slices;
-  // ---- phase 1a: scalar rows: sum of the partial slabs (fixed order), mean over in-edges, activation / gate.
-  // NU_U independent elements per thread and pass, so their slab loads are in flight together.
-  for (int base = tid; base < 32 * w0; base += NU_T * NU_U) {
-    float m[NU_U];
-    int il[NU_U], w[NU_U], ns[NU_U];
-    bool ok[NU_U];
+  __shared__ int s_ns[32];
+  __shared__ float s_deg[32];
+  if (tid < 32) {
+    const int i = n0 + tid;
+    s_ns[tid] = i < a.n_atoms ? (a.atom_nslab ? a.atom_nslab[i] : a.n_slices) : 0;
+    const int d = i < a.n_atoms ? a.deg[i] : 1;
+    s_deg[tid] = (float)(d < 1 ? 1 : d);
+  }
+  __syncthreads();
+  // Thread -> element maps without integer division: a wave row of 32 lanes covers 32 consecutive columns (one 128-byte
+  // segment) of one atom; 16 rows per pass.  All global loads of phase 1 are issued before the first use.
+  const int col = tid & 31, row = tid >> 5;  // row < 16
+  // ---- vector-row slab sums: 96 (atom, plane) rows x 32 channels (nt1 == 1)
+  float mv[NU_V];
 #pragma unroll
-    for (int u = 0; u < NU_U; ++u) {
-      const int idx = base + NU_T * u;
-      il[u] = idx / w0;
-      w[u] = idx - il[u] * w0;
-      ok[u] = idx < 32 * w0 && w[u] < G0 && n0 + il[u] < a.n_atoms;
-      ns[u] = !ok[u] ? 0 : (a.atom_nslab ? a.atom_nslab[n0 + il[u]] : a.n_slices);
-      m[u] = 0.f;
-    }
-    for (int s = 0; s < ns_max; ++s) {
+  for (int u = 0; u < NU_V; ++u) mv[u] = 0.f;
+  for (int s = 0; s < ns_max; ++s) {
 #pragma unroll
-      for (int u = 0; u < NU_U; ++u)
-        if (s < ns[u]) m[u] += a.partial0[((size_t)s * a.n_pad + n0 + il[u]) * w0 + w[u]];
-    }
-#pragma unroll
-    for (int u = 0; u < NU_U; ++u) {
-      const int idx = base + NU_T * u;
-      if (idx >= 32 * w0 || w[u] >= G0) continue;
-      float v = 0.f;
-      if (ok[u]) {
-        const int d = a.deg[n0 + il[u]];
-        v = m[u] / (float)(d < 1 ? 1 : d);
-      }
-      if (w[u] < a.mul0) A0[w[u] * NU_LD + il[u]] = a.cL * (v > 0.f ? v : 0.01f * v);
-      else s_gate[il[u] * a.mul1 + (w[u] - a.mul0)] = a.cS / (1.f + expf(-v));
+    for (int u = 0; u < NU_V; ++u) {
+      const int rr = row + 16 * u, il = rr / 3;  // rr = il * 3 + plane
+      if (s < s_ns[il]) mv[u] += a.partial1[((size_t)s * a.n_pad + n0) * 3 * w1 + rr * w1 + col];
     }
   }
-  // x_in: scalars extend the scalar K range, vectors extend each plane's K range; pad rows are zero
-  for (int base = tid; base < 32 * a.XSin; base += NU_T * NU_U) {
-    float v[NU_U];
+  // ---- scalar-row slab sums: 32 atoms x w0 columns
+  float m0[2][NU_U];
 #pragma unroll
-    for (int u = 0; u < NU_U; ++u) {
-      const int idx = base + NU_T * u;
-      const int il = idx / a.XSin, c = idx - il * a.XSin;
-      v[u] = (idx < 32 * a.XSin && n0 + il < a.n_atoms) ? a.x_in[(size_t)(n0 + il) * a.XSin + c] : 0.f;
+  for (int v = 0; v < 2; ++v)
+#pragma unroll
+    for (int u = 0; u < NU_U; ++u) m0[v][u] = 0.f;
+  for (int s = 0; s < ns_max; ++s) {
+#pragma unroll
+    for (int v = 0; v < 2; ++v) {
+      const int il = row + 16 * v;
+#pragma unroll
+      for (int u = 0; u < NU_U; ++u) {
+        const int w = col + 32 * u;
+        if (u < a.nt0 && s < s_ns[il]) m0[v][u] += a.partial0[((size_t)s * a.n_pad + n0 + il) * w0 + w];
+      }
     }
+  }
+  // ---- input features
+  float xv[2][NU_X];
+#pragma unroll
+  for (int v = 0; v < 2; ++v) {
+    const int il = row + 16 * v;
+#pragma unroll
+    for (int u = 0; u < NU_X; ++u) {
+      const int c = col + 32 * u;
+      xv[v][u] = (c < a.XSin && n0 + il < a.n_atoms) ? a.x_in[(size_t)(n0 + il) * a.XSin + c] : 0.f;
+    }
+  }
+  // ---- phase 1a: mean over in-edges, activation / gate
+#pragma unroll
+  for (int v = 0; v < 2; ++v) {
+    const int il = row + 16 * v;
 #pragma unroll
     for (int u = 0; u < NU_U; ++u) {
-      const int idx = base + NU_T * u;
-      if (idx >= 32 * a.XSin) continue;
-      const int il = idx / a.XSin, c = idx - il * a.XSin;
-      if (c < a.in0) A0[(a.mul0 + c) * NU_LD + il] = v[u];
+      const int w = col + 32 * u;
+      if (u >= a.nt0 || w >= G0) continue;
+      const float val = m0[v][u] / s_deg[il];
+      if (w < a.mul0) A0[w * NU_LD + il] = a.cL * (val > 0.f ? val : 0.01f * val);
+      else s_gate[il * a.mul1 + (w - a.mul0)] = a.cS / (1.f + expf(-val));
+    }
+    // x_in: scalars extend the scalar K range, vectors extend each plane's K range; pad rows are zero
+#pragma unroll
+    for (int u = 0; u < NU_X; ++u) {
+      const int c = col + 32 * u;
+      if (c >= a.XSin) continue;
+      if (c < a.in0) A0[(a.mul0 + c) * NU_LD + il] = xv[v][u];
       else {
         const int uu = (c - a.in0) / 3, mm = (c - a.in0) - 3 * uu;
-        A1[(mm * K1 + a.mul1 + uu) * NU_LD + il] = v[u];
+        A1[(mm * K1 + a.mul1 + uu) * NU_LD + il] = xv[v][u];
       }
     }
   }
   for (int idx = tid; idx < (K0 - a.mul0 - a.in0) * 32; idx += NU_T) A0[(a.mul0 + a.in0 + (idx >> 5)) * NU_LD + (idx & 31)] = 0.f;
   for (int idx = tid; idx < 3 * (K1 - a.mul1 - a.in1) * 32; idx += NU_T) {
-    const int mm = idx / ((K1 - a.mul1 - a.in1) * 32), rem = idx - mm * (K1 - a.mul1 - a.in1) * 32;
+    const int per = (K1 - a.mul1 - a.in1) * 32;
+    const int mm = idx >= 2 * per ? 2 : (idx >= per ? 1 : 0), rem = idx - mm * per;
     A1[(mm * K1 + a.mul1 + a.in1 + (rem >> 5)) * NU_LD + (rem & 31)] = 0.f;
   }
-  // ---- phase 1b: vector rows (slab sums and mean here, the gate after the barrier)
-  {
-    const int nv = 32 * 3 * w1;
-    float mv[NU_V];
-    int nsv[NU_V];
+  __syncthreads();
+  // ---- phase 1b: gated vectors
 #pragma unroll
-    for (int u = 0; u < NU_V; ++u) {
-      const int idx = tid + NU_T * u, il = idx / (3 * w1);
-      mv[u] = 0.f;
-      nsv[u] = (idx < nv && n0 + il < a.n_atoms) ? (a.atom_nslab ? a.atom_nslab[n0 + il] : a.n_slices) : 0;
-    }
-    for (int s = 0; s < ns_max; ++s) {
-#pragma unroll
-      for (int u = 0; u < NU_V; ++u) {
-        const int idx = tid + NU_T * u;
-        const int il = idx / (3 * w1), rem = idx - il * 3 * w1;
-        if (s < nsv[u]) mv[u] += a.partial1[((size_t)s * a.n_pad + n0 + il) * 3 * w1 + rem];
-      }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int u = 0; u < NU_V; ++u) {
-      const int idx = tid + NU_T * u;
-      const int il = idx / (3 * w1), rem = idx - il * 3 * w1, mm = rem / w1, wv = rem - mm * w1;
-      if (idx < nv && wv < a.mul1) {
-        float m = 0.f;
-        if (n0 + il < a.n_atoms) {
-          const int d = a.deg[n0 + il];
-          m = mv[u] / (float)(d < 1 ? 1 : d);
-        }
-        A1[(mm * K1 + wv) * NU_LD + il] = m * s_gate[il * a.mul1 + wv];
-      }
-    }
+  for (int u = 0; u < NU_V; ++u) {
+    const int rr = row + 16 * u, il = rr / 3, mm = rr - 3 * il;
+    if (col < a.mul1) A1[(mm * K1 + col) * NU_LD + il] = (mv[u] / s_deg[il]) * s_gate[il * a.mul1 + col];
   }
   __syncthreads();
   // ---- phase 2: out = [act | x_in] . [W_self ; W_skip] on the matrix cores, then the noise-conditional skip mix
@@ -659,7 +655,7 @@ void launch_node_update(const NodeArgs& a, hipStream_t st) {
   hipLaunchKernelGGL(k_node_update, dim3(a.n_pad / 32), dim3(NU_T), node_update_lds_bytes(a), st, a);
 }
 int node_update_set_max_lds() {
-  return hipFuncSetAttribute((const void*)k_node_update, hipFuncAttributeMaxDynamicSharedMemorySize, JAMUN_MAX_DYN_LDS) ==
+  return hipFuncSetAttribute((const void*)k_node_update, hipFuncAttributeMaxDynamicSharedMemorySize, JAMUN_MAX_DYN_LDS - 1024) ==
                  hipSuccess ? 0 : -1;
 }
 void launch_head(const HeadArgs& a, hipStream_t st) {
