@@ -513,7 +513,11 @@ LayerDev build_layer(const jamun_model& m, const std::string& prefix, const std:
     std::vector<std::vector<int>> per_wave(FWv);
     for (int i : order) {
       int best = 0;
-      auto key = [&](int w) { return std::make_pair(load[w] + load[(w + FWv / 2) % FWv], load[w]); };
+      auto key = [&](int w) {  // (MFMAs on the wave's SIMD: waves w, w+4, ... share one; then the wave's own)
+        int64_t simd = 0;
+        for (int c = w % 4; c < FWv; c += 4) simd += load[c];
+        return std::make_pair(simd, load[w]);
+      };
       for (int c = 1; c < FWv; ++c)
         if (key(c) < key(best)) best = c;
       per_wave[best].push_back(i);

@@ -38,7 +38,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 #define FW JAMUN_FUSED_WAVES
 #define FT (64 * FW)
-#define FPAIRS (64 * 32 / FT)  // (source row, destination) pairs per thread, JR <= 64
+#define FPAIRS ((64 * 32 + FT - 1) / FT)  // (source row, destination) pairs per thread, JR <= 64
 #define MAXB JAMUN_FUSED_MAX_B
 #ifndef TR
 #define TR 8  // depth of the T-tile weight ring (blocks of 4 K-steps): 32 MFMAs of prefetch distance
@@ -271,7 +271,7 @@ __global__ __launch_bounds__(FT, 1) void k_conv_fused(FusedArgs a) {
     // addresses live in registers for the whole segment.
     int p_oa[FPAIRS], p_ob[FPAIRS];  // edge slot of the radial / bonded edge of the pair (a stand-in if none)
     int p_has = 0;                   // bit 2i: pair i has a radial edge, bit 2i+1: a bonded edge
-    float p_ga[FPAIRS][3], p_gb[FPAIRS][3];
+    float p_g[FPAIRS][3];            // unit vector of the pair (its radial and bonded edge point the same way)
     float p_ha[FPAIRS], p_hb[FPAIRS];
 #pragma unroll
     for (int i = 0; i < FPAIRS; ++i) {
@@ -284,9 +284,9 @@ __global__ __launch_bounds__(FT, 1) void k_conv_fused(FusedArgs a) {
       p_oa[i] = ea;
       p_ob[i] = eb;
       p_has |= (ta ? 1 : 0) << (2 * i) | (tb ? 1 : 0) << (2 * i + 1);
-      const float4 ga = a.egeo[ea], gb = a.egeo[eb];
-      p_ga[i][0] = ta ? ga.x : 0.f; p_ga[i][1] = ta ? ga.y : 0.f; p_ga[i][2] = ta ? ga.z : 0.f;
-      p_gb[i][0] = tb ? gb.x : 0.f; p_gb[i][1] = tb ? gb.y : 0.f; p_gb[i][2] = tb ? gb.z : 0.f;
+      const float4 ge = a.egeo[ta ? ea : eb];
+      const bool any = ta || tb;
+      p_g[i][0] = any ? ge.x : 0.f; p_g[i][1] = any ? ge.y : 0.f; p_g[i][2] = any ? ge.z : 0.f;
     }
     auto load_h = [&](int k) {  // raw loads (row k of the [k][slot] table: neighbouring slots share cache lines); write_c masks out the stand-ins of absent edges
       const float* __restrict__ hk = a.h + (size_t)k * a.h_kstride;
@@ -303,9 +303,9 @@ __global__ __launch_bounds__(FT, 1) void k_conv_fused(FusedArgs a) {
         if (p < CT) {  // every (destination, row < JR) entry is written: absent pairs and rows >= the span get zeros
           const float ha = (p_has >> (2 * i)) & 1 ? p_ha[i] : 0.f, hb = (p_has >> (2 * i + 1)) & 1 ? p_hb[i] : 0.f;
           cbuf[p] = ha + hb;
-          cbuf[CT + p] = fmaf(hb, p_gb[i][0], ha * p_ga[i][0]);
-          cbuf[2 * CT + p] = fmaf(hb, p_gb[i][1], ha * p_ga[i][1]);
-          cbuf[3 * CT + p] = fmaf(hb, p_gb[i][2], ha * p_ga[i][2]);
+          cbuf[CT + p] = fmaf(hb, p_g[i][0], ha * p_g[i][0]);
+          cbuf[2 * CT + p] = fmaf(hb, p_g[i][1], ha * p_g[i][1]);
+          cbuf[3 * CT + p] = fmaf(hb, p_g[i][2], ha * p_g[i][2]);
         }
       }
     };
