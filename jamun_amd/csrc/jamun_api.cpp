@@ -387,11 +387,14 @@ LayerDev build_layer(const jamun_model& m, const std::string& prefix, const std:
   if (fused_JR > 0 && G1 <= 32 && G1 > 0 && x0_contig && NT0 + 3 <= JAMUN_FUSED_WAVES) {
     // kind 0: D' tile formed from coefficient tiles (n_terms products), consumed by `nt` owner tiles of output `out`
     // (0 scalar rows, 1..3 vector plane); kind 1: T tile of source-row tile jt, applied by all three plane owners
-    struct AUnit { int kind, n_terms, out, nt; int term[3]; int jt; std::vector<const UEntry*> ue; int wofs, cost; };
+    // n_enc = positive terms | negative terms << 4 (terms are listed positives first)
+    struct AUnit { int kind, n_terms, out, nt; int term[3]; int jt; std::vector<const UEntry*> ue; int wofs, cost, n_enc; };
     auto term = [](int xcol0, int stride, int ctype, bool neg) { return xcol0 | (stride << 12) | (ctype << 16) | ((neg ? 1 : 0) << 20); };
     std::vector<AUnit> au;
     auto add = [&](int n_terms, int out, int nt, int t0, int t1, int t2, const std::vector<UEntry>& src, size_t i) {
-      AUnit u{0, n_terms, out, nt, {t0, t1, t2}, 0, {}, 0, 0};
+      int n_neg = 0;
+      for (int t : {t0, t1, t2}) n_neg += (t >> 20) & 1;
+      AUnit u{0, n_terms, out, nt, {t0, t1, t2}, 0, {}, 0, 0, (n_terms - n_neg) | (n_neg << 4)};
       for (size_t j = i; j < std::min(src.size(), i + 32); ++j) u.ue.push_back(&src[j]);
       au.push_back(u);
     };
@@ -401,7 +404,7 @@ LayerDev build_layer(const jamun_model& m, const std::string& prefix, const std:
     // groups of 4 K-steps (8 input channels) of the T contraction, padded to the depth of the kernel's weight ring (8)
     const int n_tsg = ((((int)x0ve.size() + 7) / 8) + 7) & ~7;
     const int n_jt = x0ve.empty() ? 0 : (fused_JR + 31) / 32;
-    for (int jt = 0; jt < n_jt; ++jt) au.push_back(AUnit{1, 0, 4, 0, {0, 0, 0}, jt, {}, 0, 0});
+    for (int jt = 0; jt < n_jt; ++jt) au.push_back(AUnit{1, 0, 4, 0, {0, 0, 0}, jt, {}, 0, 0, 0});
     for (int mm = 0; mm < 3; ++mm) {
       for (size_t i = 0; i < x1e.size(); i += 32) add(1, 1 + mm, 1, term(x1e[i].xoff + mm, 3, 0, false), 0, 0, x1e, i);
       for (size_t i = 0; i < crosse.size(); i += 32) {
@@ -479,6 +482,7 @@ LayerDev build_layer(const jamun_model& m, const std::string& prefix, const std:
     for (int w = 0; w < FWv; ++w) {
       std::vector<std::pair<int4, int4>> ent;
       const int4 z = make_int4(0, 0, 0, 0);
+      int n_self = 0;
       if (w < NT0) {
         own[w] = make_int4(0, w, -1, 0);
         for (size_t i = 0; i < au.size(); ++i)
@@ -488,14 +492,16 @@ LayerDev build_layer(const jamun_model& m, const std::string& prefix, const std:
         own[w] = make_int4(1, mm, -1, 0);
         for (size_t i = 0; i < au.size(); ++i)
           if (au[i].kind == 0 && au[i].out == 1 + mm) {
-            ent.push_back({make_int4(2, au[i].n_terms, au[i].wofs, 0), make_int4(au[i].term[0], au[i].term[1], au[i].term[2], 0)});
+            ent.push_back({make_int4(2, au[i].n_enc, au[i].wofs, 0), make_int4(au[i].term[0], au[i].term[1], au[i].term[2], 0)});
+            ++n_self;
             load[w] += au[i].n_terms * steps + 16;
           }
         for (size_t i = 0; i < au.size(); ++i)
           if (au[i].kind == 1) { ent.push_back({make_int4(1, tix[i], mm, au[i].jt), z}); load[w] += 16; }
       }
       total += load[w];
-      if ((int)ent.size() > JAMUN_FUSED_MAX_B) { fits = false; break; }
+      if ((int)ent.size() > JAMUN_FUSED_MAX_B || n_self > 2) { fits = false; break; }
+      own[w].w = (int)ent.size() | (n_self << 8);
       for (size_t i = 0; i < ent.size(); ++i) {
         ubv[((size_t)w * JAMUN_FUSED_MAX_B + i) * 2] = ent[i].first;
         ubv[((size_t)w * JAMUN_FUSED_MAX_B + i) * 2 + 1] = ent[i].second;
@@ -533,7 +539,7 @@ LayerDev build_layer(const jamun_model& m, const std::string& prefix, const std:
         if (u.kind == 1 && own[w].z < 0) own[w].z = (int)i;  // the wave's first T unit: its weight ring is prefetched
         int4* d = &ua[((size_t)w * F.max_a + i) * 2];
         if (u.kind == 1) { d[0] = make_int4(1, tix[id], u.wofs, 0); d[1] = make_int4(u.jt, n_tsg, x0ve[0].xoff, 0); }
-        else { d[0] = make_int4(0, tix[id], u.n_terms, 0); d[1] = make_int4(u.term[0], u.term[1], u.term[2], 0); }
+        else { d[0] = make_int4(0, tix[id], u.n_enc, 0); d[1] = make_int4(u.term[0], u.term[1], u.term[2], 0); }
       }
     F.lds_bytes = fused_lds_bytes(L.XSin, fused_JR, F.n_p, F.n_t, F.max_a);
     if (fits && 32 * fused_JR <= 2 * F.n_p * 1024) {

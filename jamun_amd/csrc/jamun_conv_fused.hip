@@ -84,6 +84,7 @@ __global__ __launch_bounds__(FT, 1) void k_conv_fused(FusedArgs a) {
   const int4* __restrict__ my_b = reinterpret_cast<const int4*>(ub + wave * MAXB * 8);
   const int4 own = a.owner[wave];  // {kind: -1 none / 0 scalar-row tile / 1 vector plane, index}
   const int own_kind = RFL(own.x), own_idx = RFL(own.y), own_t = RFL(own.z);  // own_t: index of this wave's first T unit, -1 if none
+  const int n_ent = RFL(own.w) & 0xff, n_self = RFL(own.w) >> 8;  // owner entries; of which formed in registers (plane owners, <= 2)
 
   unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0, s_pro = 0, s_wait = 0, s_a = 0, s_b = 0, s_build = 0, s_epi = 0;
   (void)t0; (void)t1; (void)t2; (void)t3; (void)t4; (void)s_pro; (void)s_wait; (void)s_a; (void)s_b; (void)s_build; (void)s_epi;
@@ -105,18 +106,19 @@ __global__ __launch_bounds__(FT, 1) void k_conv_fused(FusedArgs a) {
     const int n8 = Jt4 >> 3, tail4 = Jt4 & 4;
 
     // D'[u][i] += sum_j X[j][u] C[j][i] over the terms of a forming unit (transposed tiles: four K-steps per b128 read)
+    // (No sign handling here: the K-steps feed the operands straight from LDS.  A unit's negative terms — the second
+    // term of a cross product — are formed into a second accumulator by a second call and subtracted by the caller; one
+    // v_mul per MFMA in this loop costs ~10 % of the forming rate, profiles/r1e micro-benchmark.)
     auto form = [&](f32x16& af, int n_terms, const int4& ut, const float* __restrict__ cb) {
       // operand pointers of all terms first; the K-groups of all terms then run as ONE flat loop whose body always
       // fetches the next group (next term's first group at a term boundary, a harmless re-read at the very end): no
       // branches around the LDS reads, so the waits can be counted exactly
       const float* xq[3];
       const float* cq[3];
-      float sgn[3];
 #pragma unroll
       for (int t = 0; t < 3; ++t) {
         const int td = RFL(t == 0 ? ut.x : (t == 1 ? ut.y : ut.z));
         const int xcol0 = td & 0xfff, stride = (td >> 12) & 0xf, ctype = (td >> 16) & 0xf;
-        sgn[t] = (td >> 20) & 1 ? -1.f : 1.f;
         xq[t] = xT + (xcol0 + r * stride) * JR;
         cq[t] = cb + ctype * CT + r * JR;
       }
@@ -133,15 +135,14 @@ __global__ __launch_bounds__(FT, 1) void k_conv_fused(FusedArgs a) {
 #pragma unroll
         for (int t = 0; t < 3; ++t) {
           if (t >= n_terms) break;  // wave-uniform
-          af = MFMA(ta[t][0], tb[t][0] * sgn[t], af);
-          af = MFMA(ta[t][1], tb[t][1] * sgn[t], af);
+          af = MFMA(ta[t][0], tb[t][0], af);
+          af = MFMA(ta[t][1], tb[t][1], af);
         }
       }
       if (n8 > 0) {
         const float4* __restrict__ xp = reinterpret_cast<const float4*>(xq[0] + 4 * hh);  // rows 8g + 4hh + (0..3)
         const float4* __restrict__ cp = reinterpret_cast<const float4*>(cq[0] + 4 * hh);
         float4 av = xp[0], bv = cp[0];
-        float sg = sgn[0];
         int t = 0, g = 0;
         const int total = n_terms * n8;
         for (int i = 0; i < total; ++i) {
@@ -152,14 +153,27 @@ __global__ __launch_bounds__(FT, 1) void k_conv_fused(FusedArgs a) {
           const float* __restrict__ cs = tl == 0 ? cq[0] : (tl == 1 ? cq[1] : cq[2]);
           const float4 an = reinterpret_cast<const float4*>(xs + 4 * hh)[2 * gn];
           const float4 bn = reinterpret_cast<const float4*>(cs + 4 * hh)[2 * gn];
-          af = MFMA(av.x, bv.x * sg, af);
-          af = MFMA(av.y, bv.y * sg, af);
-          af = MFMA(av.z, bv.z * sg, af);
-          af = MFMA(av.w, bv.w * sg, af);
+          af = MFMA(av.x, bv.x, af);
+          af = MFMA(av.y, bv.y, af);
+          af = MFMA(av.z, bv.z, af);
+          af = MFMA(av.w, bv.w, af);
           av = an; bv = bn;
-          sg = tl == 0 ? sgn[0] : (tl == 1 ? sgn[1] : sgn[2]);
           t = tn; g = gn;
         }
+      }
+    };
+    // a unit = positive terms, then negative terms (n_terms = positive | negative << 4)
+    auto form_unit = [&](f32x16& af, int n_terms, const int4& ut, const float* __restrict__ cb) {
+      const int n_pos = n_terms & 0xf, n_neg = n_terms >> 4;
+      form(af, n_pos, ut, cb);
+      if (n_neg > 0) {  // wave-uniform
+        f32x16 afn;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) afn[q] = 0.f;
+        const int4 un = n_pos == 1 ? make_int4(ut.y, ut.z, 0, 0) : (n_pos == 2 ? make_int4(ut.z, 0, 0, 0) : make_int4(ut.x, ut.y, ut.z, 0));
+        form(afn, n_neg, un, cb);
+#pragma unroll
+        for (int q = 0; q < 16; ++q) af[q] -= afn[q];
       }
     };
 
@@ -334,18 +348,20 @@ __global__ __launch_bounds__(FT, 1) void k_conv_fused(FusedArgs a) {
       const int k0 = k_of(it < 0 ? 0 : it), k1 = k_of(it + 1 < nk ? it + 1 : nk - 1), k2 = k_of(it + 2 < nk ? it + 2 : nk - 1);
       const float* __restrict__ cb = cT + ((it + 1) & 1) * 4 * CT;  // C(k(it+1))
       FSTAMP(t0);
-      const bool v_own = own_kind == 0 ? v_main : v_next;
       const float4* __restrict__ wkb = a.wpack + (size_t)(own_kind == 0 ? k0 : k1) * a.k_stride + lane;
       const float4* __restrict__ wkt = a.wpack + (size_t)k2 * a.k_stride + lane;
       // weights of the first two owner entries: in flight behind the forming units.  (Entry fields z of non-weight and
-      // terminator entries are small valid block offsets, so every fetch is in range.)
-      float4 wb[2][4];
+      // terminator entries are small valid block offsets, so every fetch is in range.)  Three buffers rotate: entry e reads
+      // B[e % 3] in place while B[(e + 2) % 3] — consumed by entry e-1 — is refilled with the weights of entry e+2: no
+      // register copies, so the compiler never has to wait for a load it has just issued.
+      float4 B0[4], B1[4], B2[4];
+      auto wload = [&](float4 (&B)[4], int e) {
+        const int wofs = RFL(my_b[2 * (e < MAXB ? e : MAXB - 1)].z);
 #pragma unroll
-      for (int e = 0; e < 2; ++e) {
-        const int wofs = RFL(my_b[2 * e].z);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) wb[e][q] = wkb[(wofs + q) * 64];
-      }
+        for (int q = 0; q < 4; ++q) B[q] = wkb[(wofs + q) * 64];
+      };
+      wload(B0, 0);
+      wload(B1, 1);
       // weight ring of this wave's T tile (if it has one)
       float4 tring[TR];
       if (own_t >= 0) t_ring(my_a[2 * own_t], wkt, tring);
@@ -366,7 +382,7 @@ __global__ __launch_bounds__(FT, 1) void k_conv_fused(FusedArgs a) {
           f32x16 af;
 #pragma unroll
           for (int q = 0; q < 16; ++q) af[q] = 0.f;
-          form(af, RFL(ud.z), ut, cb);
+          form_unit(af, RFL(ud.z), ut, cb);
 #pragma unroll
           for (int qg = 0; qg < 4; ++qg)
             dP[((((it + 1) & 1) * a.n_p + tix) * 4 + qg) * 64 + lane] =
@@ -379,61 +395,60 @@ __global__ __launch_bounds__(FT, 1) void k_conv_fused(FusedArgs a) {
       load_h(k2);
 
       // ================= owner entries: K-steps into the tile this wave owns =================
+      if (own_kind == 0) {
+        // ---- scalar-row owner: main K-steps of k(it) against the tiles parked in the previous interval
+        auto main_entry = [&](const float4 (&w)[4], int e) {
+          const int tix = RFL(my_b[2 * e].y);
+          float4 av[4];
 #pragma unroll
-      for (int e = 0; e < MAXB; ++e) {
-        const int4 bd = my_b[2 * e];
-        const int kind = RFL(bd.x), tix = RFL(bd.y);
-        if (kind < 0) break;
-        if (kind == 0 || kind == 2) {
-          if (!v_own) continue;
-          float4 w[4];
+          for (int qg = 0; qg < 4; ++qg) av[qg] = dP[(((it & 1) * a.n_p + tix) * 4 + qg) * 64 + lane];
 #pragma unroll
-          for (int q = 0; q < 4; ++q) w[q] = wb[e & 1][q];
-          if (e + 2 < MAXB) {  // weights of entry e + 2 (any kind: see above), always fetched
-            const int wofs = RFL(my_b[2 * (e + 2)].z);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) wb[e & 1][q] = wkb[(wofs + q) * 64];
+          for (int qg = 0; qg < 4; ++qg) {
+            acc = MFMA(av[qg].x, w[qg].x, acc);
+            acc = MFMA(av[qg].y, w[qg].y, acc);
+            acc = MFMA(av[qg].z, w[qg].z, acc);
+            acc = MFMA(av[qg].w, w[qg].w, acc);
           }
-          if (kind == 0) {  // scalar-row tile formed in the previous interval
-            float4 av[4];
+        };
+        if (v_main) {
+          wload(B2, 2); if (0 < n_ent) main_entry(B0, 0);
+          wload(B0, 3); if (1 < n_ent) main_entry(B1, 1);
+          wload(B1, 4); if (2 < n_ent) main_entry(B2, 2);
+          wload(B2, 5); if (3 < n_ent) main_entry(B0, 3);
+          if (4 < n_ent) main_entry(B1, 4);
+          if (5 < n_ent) main_entry(B2, 5);
+        }
+      } else if (own_kind == 1 && v_next) {
+        // ---- plane owner: form its x1 / cross tiles of k(it+1) in registers, feed the accumulator registers straight into
+        // the main MFMAs, then apply the T tiles of k(it+1)
+        auto self_entry = [&](const float4 (&w)[4], int e) {
+          f32x16 af;
 #pragma unroll
-            for (int qg = 0; qg < 4; ++qg) av[qg] = dP[(((it & 1) * a.n_p + tix) * 4 + qg) * 64 + lane];
-            __builtin_amdgcn_sched_barrier(0);
+          for (int q = 0; q < 16; ++q) af[q] = 0.f;
+          form_unit(af, RFL(my_b[2 * e].y), my_b[2 * e + 1], cb);
 #pragma unroll
-            for (int qg = 0; qg < 4; ++qg) {
-              acc = MFMA(av[qg].x, w[qg].x, acc);
-              acc = MFMA(av[qg].y, w[qg].y, acc);
-              acc = MFMA(av[qg].z, w[qg].z, acc);
-              acc = MFMA(av[qg].w, w[qg].w, acc);
-            }
-          } else {  // plane owner: form the tile in registers, feed the accumulator registers straight into the main MFMAs
-            f32x16 af;
-#pragma unroll
-            for (int q = 0; q < 16; ++q) af[q] = 0.f;
-            form(af, tix, my_b[2 * e + 1], cb);
-#pragma unroll
-            for (int qg = 0; qg < 4; ++qg) {
-              acc = MFMA(af[4 * qg + 0], w[qg].x, acc);
-              acc = MFMA(af[4 * qg + 1], w[qg].y, acc);
-              acc = MFMA(af[4 * qg + 2], w[qg].z, acc);
-              acc = MFMA(af[4 * qg + 3], w[qg].w, acc);
-            }
+          for (int qg = 0; qg < 4; ++qg) {
+            acc = MFMA(af[4 * qg + 0], w[qg].x, acc);
+            acc = MFMA(af[4 * qg + 1], w[qg].y, acc);
+            acc = MFMA(af[4 * qg + 2], w[qg].z, acc);
+            acc = MFMA(af[4 * qg + 3], w[qg].w, acc);
           }
-        } else {
+        };
+        if (0 < n_self) self_entry(B0, 0);
+        if (1 < n_self) self_entry(B1, 1);
+        for (int e = n_self; e < n_ent; ++e) {
           // out_m[i][w] += sum_j C^{h v_m}[j][i] T[j][w]: A operand = coefficient tile rows in T's register order
-          if (!v_next) continue;
-          const int m = RFL(bd.z), jt = RFL(bd.w);
+          const int4 bd = my_b[2 * e];
+          const int tix = RFL(bd.y), m = RFL(bd.z), jt = RFL(bd.w);
           if (32 * jt >= Jt4) continue;
           const float* __restrict__ cm = cb + (1 + m) * CT + r * JR + 32 * jt + 4 * hh;
-          // all eight operand fragments are requested before the first MFMA (the waits then retire them one by one)
-          float4 tv[4], cv[4];
+          float4 tv[4], cv[4];  // all eight operand fragments are requested before the first MFMA
 #pragma unroll
           for (int qg = 0; qg < 4; ++qg) {
             tv[qg] = dT[((((it + 1) & 1) * a.n_t + tix) * 4 + qg) * 64 + lane];
             cv[qg] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (32 * jt + 4 * hh + 8 * qg < JR) cv[qg] = *reinterpret_cast<const float4*>(cm + 8 * qg);
           }
-          __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
           for (int qg = 0; qg < 4; ++qg) {
             acc = MFMA(cv[qg].x, tv[qg].x, acc);
