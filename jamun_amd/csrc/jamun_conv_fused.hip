@@ -195,9 +195,12 @@ __global__ __launch_bounds__(FT, 1) void k_conv_fused(FusedArgs a) {
       for (int sg = 0; sg < nsg; sg += TR) {
 #pragma unroll
         for (int i = 0; i < TR; ++i) {
-          const float4 w = ring[i];
-          const int nxt = sg + i + TR < nsg ? sg + i + TR : nsg - 1;
-          ring[i] = wk[(wofs + nxt) * 64];
+          // block sg+i reads ring[i] IN PLACE; the slot the previous block consumed is refilled with the block TR-1 ahead
+          // (a copy of ring[i] followed by a refill of the same slot makes the compiler wait for the load it just issued)
+          const float4 (&w) = ring[i];
+          int nxt = sg + i == 0 ? TR - 1 : sg + i - 1 + TR;
+          nxt = nxt < nsg ? nxt : nsg - 1;
+          ring[(i + TR - 1) % TR] = wk[(wofs + nxt) * 64];
           const int nb = sg + i + 1 < nsg ? sg + i + 1 : nsg - 1;
           const float* __restrict__ xs = xr + 8 * nb * JR;
 #pragma unroll
