@@ -284,7 +284,7 @@ struct jamun_sampler {
   unsigned long long* counter = nullptr;
   int64_t flop_ref_per_edge = 0, flop_exec = 0;
   // optional per-kernel-class timing with HIP events on the launch stream (jamun_profile_*)
-  bool prof = false;
+  unsigned prof_mask = 0;  // bit c: record HIP events around launches of profile class c
   std::vector<hipEvent_t> ev_pool;
   std::vector<std::pair<int, std::pair<int, int>>> ev_used;  // (class, (begin, end))
   size_t ev_next = 0;
@@ -627,7 +627,7 @@ LayerDev build_layer(const jamun_model& m, const std::string& prefix, const std:
 struct ProfScope {
   jamun_sampler* s; int cls; hipStream_t st; int b = -1;
   ProfScope(jamun_sampler* s_, int cls_, hipStream_t st_) : s(s_), cls(cls_), st(st_) {
-    if (!s->prof) return;
+    if (!(s->prof_mask >> cls & 1u)) return;
     while (s->ev_pool.size() < s->ev_next + 2) {
       hipEvent_t e;
       HIPCHECK(hipEventCreate(&e));
@@ -1237,7 +1237,7 @@ int jamun_sampler_stats(jamun_sampler* s, jamun_stats* out, void* stream) {
 int jamun_profile_enable(jamun_sampler* s, int32_t on) {
   return guarded([&] {
     if (!s) throw Err(JAMUN_ERR_INVALID, "null argument");
-    s->prof = on != 0;
+    s->prof_mask = on == 1 ? 0xffffffffu : (unsigned)on >> 1;  // 1: every class; otherwise bit (c + 1) selects class c
     s->ev_used.clear();
     s->ev_next = 0;
   });

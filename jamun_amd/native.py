@@ -203,8 +203,14 @@ class NativeSampler:
             _lib.check(self._lib.jamun_sampler_stats(self._h, C.byref(st), _stream()))
         return {k: getattr(st, k) for k, _ in st._fields_}
 
-    def profile_enable(self, on: bool = True) -> None:
-        _lib.check(self._lib.jamun_profile_enable(self._h, int(on)))
+    def profile_enable(self, on: bool = True, classes=None) -> None:
+        """Record HIP events around the forward's launches: all classes, or only the named ones (``_lib.PROF_CLASSES``)."""
+        code = int(bool(on))
+        if on and classes is not None:
+            code = 0
+            for c in classes:
+                code |= 1 << (_lib.PROF_CLASSES.index(c) + 1)
+        _lib.check(self._lib.jamun_profile_enable(self._h, code))
 
     def profile_read(self) -> dict:
         """{class: (total_ms, launches)} from HIP events recorded on the launch stream; synchronises the stream."""
