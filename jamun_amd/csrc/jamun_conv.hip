@@ -266,19 +266,15 @@ __global__ __launch_bounds__(256, 2) void k_conv(ConvArgs a) {
     const int G = cd.w;
     const int g_begin = (G * wave) >> 2, g_end = (G * (wave + 1)) >> 2;
     const float4* __restrict__ wp = a.wpack + ((size_t)cd.z * NT) * 64 + lane;
-    float4 bn[NT];
-    if (g_begin < g_end) {
+    // two weight buffers used in place, alternately: the buffer the next group needs is fetched before this group's MFMAs
+    // (a copy `b = bn; bn = load` makes the compiler wait for the load it has just issued)
+    float4 b0[NT], b1[NT];
+    auto wfetch = [&](float4 (&b)[NT], int g) {
+      const int gc = g < g_end ? g : g_end - 1;
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt) bn[nt] = wp[((size_t)g_begin * NT + nt) * 64];
-    }
-    for (int g = g_begin; g < g_end; ++g) {
-      float4 b[NT];
-#pragma unroll
-      for (int nt = 0; nt < NT; ++nt) b[nt] = bn[nt];
-      if (g + 1 < g_end) {  // prefetch the next group's weight fragments behind this group's MFMAs
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) bn[nt] = wp[((size_t)(g + 1) * NT + nt) * 64];
-      }
+      for (int nt = 0; nt < NT; ++nt) b[nt] = wp[((size_t)gc * NT + nt) * 64];
+    };
+    auto kgroup = [&](const float4 (&b)[NT], int g) {
       const int q0 = g * 4;
 #pragma unroll
       for (int c = 0; c < RC; ++c) {
@@ -293,6 +289,17 @@ __global__ __launch_bounds__(256, 2) void k_conv(ConvArgs a) {
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) acc[c][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a3, b[nt].w, acc[c][nt], 0, 0, 0);
       }
+    };
+    if (g_begin < g_end) {
+      wfetch(b0, g_begin);
+      int g = g_begin;
+      for (; g + 1 < g_end; g += 2) {
+        wfetch(b1, g + 1);
+        kgroup(b0, g);
+        wfetch(b0, g + 2);
+        kgroup(b1, g + 1);
+      }
+      if (g < g_end) kgroup(b0, g);
     }
     __syncthreads();
   }
