@@ -107,6 +107,8 @@ struct LayerDev {
   ConvProblemDev p0, p1;
   FusedDev fu;
   std::vector<float> w1r_h, cmask_h;  // radial MLP first layer (uploaded for all layers together: jamun_sampler::w1r_all)
+  float* tt = nullptr;  // initial projector only: [k][distinct embedding row][32 (nt0 + 1)] input-times-weight table
+  int tt_row = 0, tt_U = 0;
   float4 *wcat0 = nullptr, *wcat1 = nullptr;  // node update: [W_self ; W_skip] as MFMA fragments
   int K0p = 0, K1p = 0;
   float* mix = nullptr;
@@ -267,6 +269,7 @@ struct jamun_sampler {
   int fused_JR = 0, fused_grid = 0, fused_max_segs = 0, n_slabs = 0, n_ftiles = 0;
   int4* fused_segs = nullptr;
   int2* tile_atoms = nullptr;         // [n_ftiles] {first atom, atoms (<= 32)} of each fused-kernel tile
+  int* atom_uid = nullptr;            // [n_atoms] index of the atom's distinct (scaled) embedding row
   std::vector<int2> ftile_atoms_h;
   int* atom_nslab = nullptr;          // [n_atoms] partial slabs of the tile the atom belongs to
   float *x_emb = nullptr, *mu = nullptr;
@@ -291,10 +294,10 @@ struct jamun_sampler {
 
   ~jamun_sampler() {
     hipFree(ptr); hipFree(bond_in_ptr); hipFree(bond_in_src); hipFree(x_emb); hipFree(mu); hipFree(tile_span);
-    hipFree(fused_segs); hipFree(atom_nslab); hipFree(tile_atoms); hipFree(w1r_all); hipFree(cmask_all);
+    hipFree(fused_segs); hipFree(atom_nslab); hipFree(tile_atoms); hipFree(atom_uid); hipFree(w1r_all); hipFree(cmask_all);
     for (auto& L : layers) {
       free_problem(L.p0); free_problem(L.p1); free_fused(L.fu);
-      hipFree(L.wcat0); hipFree(L.wcat1); hipFree(L.mix);
+      hipFree(L.wcat0); hipFree(L.wcat1); hipFree(L.mix); hipFree(L.tt);
     }
     hipFree(w_gate); hipFree(w_vec); hipFree(w_out);
     hipFree(yc); hipFree(h); hipFree(partial0); hipFree(partial1); hipFree(g); hipFree(tmp);
@@ -308,7 +311,8 @@ struct jamun_sampler {
 namespace {
 
 LayerDev build_layer(const jamun_model& m, const std::string& prefix, const std::vector<InBlock>& in_blocks,
-                     const std::vector<double>& s_in, int n_slices, int fused_JR, int fused_span) {
+                     const std::vector<double>& s_in, int n_slices, int fused_JR, int fused_span,
+                     const std::vector<float>* uniq_rows = nullptr, int row_len = 0) {
   const jamun_hparams& hp = m.hp;
   const int mul0 = hp.mul0, mul1 = hp.mul1, G0 = mul0 + mul1, G1 = mul1, H = hp.edge_attr_dim;
   LayerDev L;
@@ -556,6 +560,41 @@ LayerDev build_layer(const jamun_model& m, const std::string& prefix, const std:
     }
   }
 
+  // ---- initial projector: input-times-weight table for jamun_conv_init.hip (inputs are constant per distinct embedding row)
+  if (uniq_rows && L.fu.wpack && G0 <= 32 * NT0 && G1 <= 32) {
+    bool scalar_only = true;
+    for (auto& ib : in_blocks) scalar_only = scalar_only && ib.l == 0;
+    const int U = (int)(uniq_rows->size() / (size_t)row_len);
+    const int tt_row = 32 * (NT0 + 1);
+    if (scalar_only && U > 0 && (size_t)U * tt_row * (H + 1) * sizeof(float) <= ((size_t)256 << 20)) {
+      std::vector<float> tt((size_t)(H + 1) * U * tt_row, 0.f);
+      for (int k = 0; k <= H; ++k)
+        for (int uid = 0; uid < U; ++uid) {
+          const float* xr = uniq_rows->data() + (size_t)uid * row_len;
+          float* out = tt.data() + ((size_t)k * U + uid) * tt_row;
+          for (int w = 0; w < G0; ++w) {
+            double acc = 0;
+            for (const UEntry& e : x0e) {
+              const int64_t p = e.wbase + w;
+              acc += (double)xr[e.xoff] * ((k < H) ? (double)W3[(size_t)p * H + k] : (double)b3[p]) * e.scale;
+            }
+            out[w] = (float)acc;
+          }
+          for (int w = 0; w < G1; ++w) {
+            double acc = 0;
+            for (const UEntry& e : x0ve) {
+              const int64_t p = e.wbase + w;
+              acc += (double)xr[e.xoff] * ((k < H) ? (double)W3[(size_t)p * H + k] : (double)b3[p]) * e.scale;
+            }
+            out[32 * NT0 + w] = (float)acc;
+          }
+        }
+      L.tt = dev_upload(tt);
+      L.tt_row = tt_row;
+      L.tt_U = U;
+    }
+  }
+
   // ---- radial MLP first layer: split into the constant bonded part and the radial part
   const auto& W1 = m.get(prefix + ".gated_conv.f.f.radial_nn.0.weight", (int64_t)H * H);
   const auto& b1 = m.get(prefix + ".gated_conv.f.f.radial_nn.0.bias", H);
@@ -662,7 +701,17 @@ void forward(jamun_sampler* s, const float* y, float* xhat, float* score, hipStr
       launch_edge_h(s->deg, s->esrc, s->egeo, s->n_atoms, s->S, s->w1r_all + l * 64 * 32, s->cmask_all + l * 128, (int)NL,
                     s->mu, s->rb_step, s->h, s->h_stride, s->h_kstride, st);
     }
-    if (L.fu.wpack) {
+    if (l == 0 && L.tt) {
+      InitArgs f{};
+      f.deg = s->deg; f.esrc = s->esrc; f.egeo = s->egeo; f.h = h_l; f.h_kstride = s->h_kstride;
+      f.n_pad = s->n_pad; f.S = s->S; f.JR = s->fused_JR; f.nt0 = L.fu.nt0;
+      f.tile_span = s->tile_span; f.tile_atoms = s->tile_atoms; f.segs = s->fused_segs; f.max_segs = s->fused_max_segs;
+      f.atom_uid = s->atom_uid; f.tt = L.tt; f.tt_row = L.tt_row; f.tt_kstride = (size_t)L.tt_U * L.tt_row;
+      f.partial0 = s->partial0; f.partial1 = s->partial1;
+      ProfScope ps(s, JAMUN_PROF_CONV0_INIT, st);
+      const int rcode = launch_conv_init(f, s->fused_grid, st);
+      if (rcode != 0) throw Err(JAMUN_ERR_INVALID, "initial-projector conv launch failed (configuration not supported)");
+    } else if (L.fu.wpack) {
       FusedArgs f{};
       f.deg = s->deg; f.esrc = s->esrc; f.egeo = s->egeo; f.h = h_l; f.h_kstride = s->h_kstride; f.x = x_in;
       f.n_atoms = s->n_atoms; f.n_pad = s->n_pad; f.S = s->S; f.XS = XSin; f.JR = s->fused_JR; f.tile_span = s->tile_span; f.tile_atoms = s->tile_atoms;
@@ -824,7 +873,7 @@ int jamun_sampler_create(const jamun_model* m, float sigma, const jamun_topology
     s->S = std::min(std::max(nmax - 1, 0), JAMUN_MAX_NEIGHBORS + 1) + max_in;
     if (s->S < 1) s->S = 1;
     s->n_tiles = s->n_pad / 32;
-    if (conv_set_max_lds() != 0 || conv_fused_set_max_lds() != 0 || node_update_set_max_lds() != 0)
+    if (conv_set_max_lds() != 0 || conv_fused_set_max_lds() != 0 || node_update_set_max_lds() != 0 || conv_init_set_max_lds() != 0)
       throw Err(JAMUN_ERR_HIP, "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed");
     {
       // ---- fused conv kernel: eligibility and tiling.  A tile = up to 32 consecutive destination atoms whose source
@@ -897,13 +946,15 @@ int jamun_sampler_create(const jamun_model* m, float sigma, const jamun_topology
       s->mu = dev_upload(mu);
     }
     // ---- scaled atom embeddings (constant per topology and sigma): atom_embedding.py:58-76, noise_conditioning.py:50-54
+    std::vector<float> xe_host;
     {
       const char* names[4] = {"atom_embedder.atom_type_embedding.weight", "atom_embedder.atom_code_embedding.weight",
                               "atom_embedder.residue_code_embedding.weight", "atom_embedder.residue_index_embedding.weight"};
       const int32_t* idx[4] = {topo->atom_type_index, topo->atom_code_index, topo->residue_code_index,
                                topo->residue_sequence_index};
       std::vector<double> s0 = noise_mlp(*m, "initial_noise_scaling.scale_predictor", s->n_emb, c_noise);
-      std::vector<float> xe((size_t)N * s->n_emb);
+      std::vector<float>& xe = xe_host;
+      xe.assign((size_t)N * s->n_emb, 0.f);
       int col = 0;
       for (int tb = 0; tb < 4; ++tb) {
         const auto& T = m->get(names[tb], (int64_t)hp.emb_rows[tb] * hp.emb_dim[tb]);
@@ -926,7 +977,26 @@ int jamun_sampler_create(const jamun_model* m, float sigma, const jamun_topology
       const int muls[4] = {hp.emb_dim[0], hp.emb_dim[0], hp.emb_dim[2], hp.emb_dim[3]};
       for (int b = 0; b < 4; ++b) { ib.push_back({muls[b], 0, xo, xo}); xo += muls[b]; }
       std::vector<double> ones(s->n_emb, 1.0);
-      s->layers.push_back(build_layer(*m, "initial_projector", ib, ones, s->n_slices, s->fused_JR, s->span_max));
+      // distinct rows of the scaled embedding (atoms with equal embedding indices share one): the initial projector's
+      // input-times-weight products are tabulated per distinct row
+      std::vector<float> uniq;
+      std::vector<int> uid(N);
+      {
+        std::map<std::vector<float>, int> seen;
+        for (int i = 0; i < N; ++i) {
+          std::vector<float> row(xe_host.begin() + (size_t)i * s->n_emb, xe_host.begin() + (size_t)(i + 1) * s->n_emb);
+          auto it = seen.find(row);
+          if (it == seen.end()) {
+            it = seen.emplace(row, (int)seen.size()).first;
+            uniq.insert(uniq.end(), row.begin(), row.end());
+          }
+          uid[i] = it->second;
+        }
+      }
+      const bool no_init = getenv("JAMUN_NO_INIT_TABLE") != nullptr;  // debugging / A-B aid
+      s->layers.push_back(build_layer(*m, "initial_projector", ib, ones, s->n_slices, s->fused_JR, s->span_max,
+                                      (s->fused_JR > 0 && !no_init) ? &uniq : nullptr, s->n_emb));
+      if (s->layers.back().tt) s->atom_uid = dev_upload(uid);
     }
     for (int l = 0; l < hp.n_layers; ++l) {
       std::vector<InBlock> ib = {{hp.mul0, 0, 0, 0}, {hp.mul1, 1, hp.mul0, hp.mul0}};
@@ -959,7 +1029,7 @@ int jamun_sampler_create(const jamun_model* m, float sigma, const jamun_topology
       bool all = s->fused_JR > 0;
       for (auto& L : s->layers) all = all && L.fu.wpack && L.fu.lds_bytes <= JAMUN_MAX_DYN_LDS;
       if (!all) {
-        for (auto& L : s->layers) free_fused(L.fu);
+        for (auto& L : s->layers) { free_fused(L.fu); hipFree(L.tt); L.tt = nullptr; }
         s->fused_JR = 0;
       }
     }

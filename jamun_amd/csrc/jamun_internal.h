@@ -66,6 +66,26 @@ struct FusedArgs {
   float* partial1;  // [slab][n_pad][3][32]
 };
 
+// initial-projector conv (jamun_conv_init.hip): apply-only contraction against the precomputed input-times-weight table
+struct InitArgs {
+  const int* deg;
+  const int* esrc;
+  const float4* egeo;
+  const float* h;  // [hidden unit k (65 rows)][h_kstride]
+  size_t h_kstride;
+  int n_pad, S, JR, nt0;
+  const int2* tile_span;
+  const int2* tile_atoms;
+  const int4* segs;  // same segment lists as the fused kernel
+  int max_segs;
+  const int* atom_uid;  // [n_atoms] index of the atom's distinct embedding row
+  const float* tt;      // [k][U][tt_row]: columns 32 t + c of output tile t (t < nt0 scalar rows, t = nt0 vector rows)
+  size_t tt_kstride;    // U * tt_row
+  int tt_row;           // 32 * (nt0 + 1)
+  float* partial0;      // [slab][n_pad][nt0*32]
+  float* partial1;      // [slab][n_pad][3][32]
+};
+
 struct NodeArgs {
   const float* partial0;  // [n_slices][n_pad][nt0*32]
   const float* partial1;  // [n_slices][n_pad][3][nt1*32]
@@ -119,6 +139,9 @@ int conv_set_max_lds();
 int launch_conv_fused(const FusedArgs& a, int grid, hipStream_t st);
 int conv_fused_set_max_lds();
 int conv_fused_read_stamps(unsigned long long* out8);
+int launch_conv_init(const InitArgs& a, int grid, hipStream_t st);
+int conv_init_set_max_lds();
+size_t conv_init_lds_bytes(int JR);
 size_t fused_lds_bytes(int XS, int JR, int n_p, int n_t, int max_a);
 void launch_node_update(const NodeArgs& a, hipStream_t st);
 size_t node_update_lds_bytes(const NodeArgs& a);

@@ -193,6 +193,14 @@ def test_fused_and_fallback_conv_agree(dev, golden_dir, kind, monkeypatch):
         a, b = fused.debug_read(0, l).cpu(), general.debug_read(0, l).cpu()
         assert (a - b).abs().max().item() <= 2e-5 * max(b.abs().max().item(), 1e-6), l
     monkeypatch.delenv("JAMUN_NO_FUSED")
+    # the initial projector has a third implementation (input-times-weight table, jamun_conv_init.hip): switch it off and
+    # the fused kernel takes that layer as well — same result
+    monkeypatch.setenv("JAMUN_NO_INIT_TABLE", "1")
+    no_table = NativeSampler(model._native, 0.04, batch, dev)
+    monkeypatch.delenv("JAMUN_NO_INIT_TABLE")
+    a0, b0 = fused.debug_read(0, 0).cpu(), (no_table.xhat(y), no_table.debug_read(0, 0).cpu())[1]
+    assert (a0 - b0).abs().max().item() <= 2e-5 * max(b0.abs().max().item(), 1e-6)
+    assert rmsd(no_table.xhat(y), xf) <= RMSD_TOL_NM
     for big in ("ragged", "dense70"):
         smp = NativeSampler(model._native, 0.04, WalkerBatch.from_molecules(_mols(big)).to(dev), dev)
         assert smp.stats()["conv_path"] == 0, big
