@@ -1065,6 +1065,10 @@ int jamun_sampler_create(const jamun_model* m, float sigma, const jamun_topology
         for (int t = 0; t < n_tiles; ++t) Lx += base + (extra_of(t) >= 0 ? 1 : 0);
         int64_t off = 0;
         int c = 0;
+        // small batches: do not cut the list finer than 8 items per workgroup (a tile's partial slabs are summed by the node
+        // update; one slab per hidden unit would make that kernel the bottleneck)
+        const int ncx_all = ncx;
+        const int ncx = (int)std::max<int64_t>(1, std::min<int64_t>(ncx_all, Lx / 8));
         for (int t = 0; t < n_tiles; ++t) {
           const int ex = extra_of(t), cnt = base + (ex >= 0 ? 1 : 0);
           int i0 = 0;
