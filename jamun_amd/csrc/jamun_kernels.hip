@@ -210,6 +210,7 @@ typedef float nu_f32x16 __attribute__((ext_vector_type(16)));
 #define NU_T 512  // threads per workgroup
 #define NU_U 5    // 32-column tiles of the scalar rows per thread (nt0 <= 5)
 #define NU_X 7    // 32-column tiles of the input features per thread (XSin <= 224)
+#define NU_S 3    // partial slabs fetched at once (more are summed in a loop)
 #define NU_V 6    // (atom, plane) rows per thread: 32 atoms x 3 planes / 16 rows per pass (nt1 == 1)
 __global__ __launch_bounds__(NU_T) void k_node_update(NodeArgs a) {
   extern __shared__ float sm[];
@@ -237,23 +238,54 @@ __global__ __launch_bounds__(NU_T) void k_node_update(NodeArgs a) {
   // segment) of one atom; 16 rows per pass.  All global loads of phase 1 are issued before the first use.
   const int col = tid & 31, row = tid >> 5;  // row < 16
   // ---- vector-row slab sums: 96 (atom, plane) rows x 32 channels (nt1 == 1)
+  // The first NU_S slabs are fetched unconditionally (slab index clamped, result masked) so that all their loads are in
+  // flight together; a loop over s would wait for slab s before asking for slab s+1.  Summation order stays s = 0, 1, ...
   float mv[NU_V];
+  {
+    float lv[NU_S][NU_V];
 #pragma unroll
-  for (int u = 0; u < NU_V; ++u) mv[u] = 0.f;
-  for (int s = 0; s < ns_max; ++s) {
+    for (int s = 0; s < NU_S; ++s)
+#pragma unroll
+      for (int u = 0; u < NU_V; ++u) {
+        const int rr = row + 16 * u, il = rr / 3;  // rr = il * 3 + plane
+        const int sc = s < s_ns[il] ? s : 0;
+        lv[s][u] = a.partial1[((size_t)sc * a.n_pad + n0) * 3 * w1 + rr * w1 + col];
+      }
 #pragma unroll
     for (int u = 0; u < NU_V; ++u) {
-      const int rr = row + 16 * u, il = rr / 3;  // rr = il * 3 + plane
+      const int rr = row + 16 * u, il = rr / 3;
+      mv[u] = 0.f;
+#pragma unroll
+      for (int s = 0; s < NU_S; ++s) mv[u] += s < s_ns[il] ? lv[s][u] : 0.f;
+    }
+  }
+  for (int s = NU_S; s < ns_max; ++s) {
+#pragma unroll
+    for (int u = 0; u < NU_V; ++u) {
+      const int rr = row + 16 * u, il = rr / 3;
       if (s < s_ns[il]) mv[u] += a.partial1[((size_t)s * a.n_pad + n0) * 3 * w1 + rr * w1 + col];
     }
   }
   // ---- scalar-row slab sums: 32 atoms x w0 columns
   float m0[2][NU_U];
 #pragma unroll
-  for (int v = 0; v < 2; ++v)
+  for (int v = 0; v < 2; ++v) {
+    const int il = row + 16 * v;
+    float ls[NU_S][NU_U];
 #pragma unroll
-    for (int u = 0; u < NU_U; ++u) m0[v][u] = 0.f;
-  for (int s = 0; s < ns_max; ++s) {
+    for (int s = 0; s < NU_S; ++s) {
+      const int sc = s < s_ns[il] ? s : 0;
+#pragma unroll
+      for (int u = 0; u < NU_U; ++u) ls[s][u] = u < a.nt0 ? a.partial0[((size_t)sc * a.n_pad + n0 + il) * w0 + col + 32 * u] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < NU_U; ++u) {
+      m0[v][u] = 0.f;
+#pragma unroll
+      for (int s = 0; s < NU_S; ++s) m0[v][u] += s < s_ns[il] ? ls[s][u] : 0.f;
+    }
+  }
+  for (int s = NU_S; s < ns_max; ++s) {
 #pragma unroll
     for (int v = 0; v < 2; ++v) {
       const int il = row + 16 * v;
