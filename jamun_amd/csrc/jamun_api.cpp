@@ -271,6 +271,8 @@ struct jamun_sampler {
   int2* tile_atoms = nullptr;         // [n_ftiles] {first atom, atoms (<= 32)} of each fused-kernel tile
   int* atom_uid = nullptr;            // [n_atoms] index of the atom's distinct (scaled) embedding row
   std::vector<int2> ftile_atoms_h;
+  std::vector<int> ftile_chunk_h;     // destination chunk of each tile
+  int n_fchunks = 0;
   int* atom_nslab = nullptr;          // [n_atoms] partial slabs of the tile the atom belongs to
   float *x_emb = nullptr, *mu = nullptr;
   std::vector<LayerDev> layers;
@@ -899,23 +901,42 @@ int jamun_sampler_create(const jamun_model* m, float sigma, const jamun_topology
         if (std::max(hid, ini) <= JAMUN_MAX_DYN_LDS) { jr_cap = jr; break; }
       }
       std::vector<int2> t_atoms, t_span;
+      std::vector<int> t_chunk;  // destination chunk of each tile (tiles of one chunk share its partial-slab numbering)
+      int n_chunks = 0;
       if (ok && jr_cap > 0) {
         int a0 = 0;
-        while (a0 < N && ok) {
-          const int lo = topo->ptr[graph_of[a0]];
+        while (a0 < N) {
+          const int g0 = graph_of[a0], lo = topo->ptr[g0], mol_hi = topo->ptr[g0 + 1];
+          if (mol_hi - lo > jr_cap) {
+            // A molecule larger than the LDS budget: its sources are cut into row blocks of <= jr_cap atoms and every
+            // destination chunk (<= 32 atoms of the molecule) gets one tile PER source block.  The contraction is linear
+            // in the coefficient tile, so the blocks' results are just more partial slabs for the node update to sum
+            // (edges whose source lies outside a tile's block are skipped by that tile).
+            const int n_mol = mol_hi - lo, nb = (n_mol + jr_cap - 1) / jr_cap;
+            for (int d0 = lo; d0 < mol_hi; d0 += 32) {
+              const int cnt = std::min(32, mol_hi - d0);
+              for (int b = 0; b < nb; ++b) {
+                const int blo = lo + (int)((int64_t)n_mol * b / nb), bhi = lo + (int)((int64_t)n_mol * (b + 1) / nb);
+                t_atoms.push_back(make_int2(d0, cnt));
+                t_span.push_back(make_int2(blo, bhi));
+                t_chunk.push_back(n_chunks);
+                s->span_max = std::max(s->span_max, bhi - blo);
+              }
+              ++n_chunks;
+            }
+            a0 = mol_hi;
+            continue;
+          }
           int cnt = 0, hi = lo;
           while (a0 + cnt < N && cnt < 32) {
             const int g2 = graph_of[a0 + cnt], nhi = topo->ptr[g2 + 1];
-            if (nhi - lo > jr_cap) {
-              if (cnt == 0) ok = false;  // a single molecule exceeds the budget: general kernel
-              break;
-            }
+            if (nhi - lo > jr_cap) break;  // (also stops in front of a molecule that needs row blocks)
             cnt += std::min(nhi - (a0 + cnt), 32 - cnt);
             hi = nhi;
           }
-          if (!ok) break;
           t_atoms.push_back(make_int2(a0, cnt));
           t_span.push_back(make_int2(lo, hi));
+          t_chunk.push_back(n_chunks++);
           s->span_max = std::max(s->span_max, hi - lo);
           a0 += cnt;
         }
@@ -926,6 +947,8 @@ int jamun_sampler_create(const jamun_model* m, float sigma, const jamun_topology
         s->fused_JR = JR;
         s->n_ftiles = (int)t_atoms.size();
         s->ftile_atoms_h = t_atoms;
+        s->ftile_chunk_h = t_chunk;
+        s->n_fchunks = n_chunks;
         s->tile_atoms = dev_upload(t_atoms);
         s->tile_span = dev_upload(t_span);
       }
@@ -1058,7 +1081,7 @@ int jamun_sampler_create(const jamun_model* m, float sigma, const jamun_topology
       s->fused_grid = cus;
       std::vector<std::vector<int4>> wg_segs(cus);
       const int n_tiles = s->n_ftiles;
-      std::vector<int> nslab(n_tiles, 0);
+      std::vector<int> nslab(s->n_fchunks, 0);  // per destination chunk: its tiles (source row blocks, k runs) number their slabs jointly
       for (int x = 0; x < ng; ++x) {
         auto extra_of = [&](int t) { const int e = ((x - t) % ng + ng) % ng; return e < rem ? ng * base + e : -1; };
         int64_t Lx = 0;
@@ -1078,7 +1101,7 @@ int jamun_sampler_create(const jamun_model* m, float sigma, const jamun_topology
             const int i1 = (int)std::min<int64_t>(cnt, hi - off);
             const int kb = x * base + std::min(i0, base), ke = x * base + std::min(i1, base);
             auto& v = wg_segs[wg_of[x][c]];
-            v.push_back(make_int4(t, nslab[t]++, kb, ke));
+            v.push_back(make_int4(t, nslab[s->ftile_chunk_h[t]]++, kb, ke));
             v.push_back(make_int4(i1 > base ? ex : -1, 0, 0, 0));
             i0 = i1;
           }
@@ -1095,7 +1118,7 @@ int jamun_sampler_create(const jamun_model* m, float sigma, const jamun_topology
       for (int v : nslab) s->n_slabs = std::max(s->n_slabs, v);
       std::vector<int> an(N, 1);
       for (int t = 0; t < n_tiles; ++t)
-        for (int i = 0; i < s->ftile_atoms_h[t].y; ++i) an[s->ftile_atoms_h[t].x + i] = nslab[t];
+        for (int i = 0; i < s->ftile_atoms_h[t].y; ++i) an[s->ftile_atoms_h[t].x + i] = nslab[s->ftile_chunk_h[t]];
       s->atom_nslab = dev_upload(an);
     }
     // ---- work buffers

@@ -268,8 +268,9 @@ __global__ __launch_bounds__(FT, 1) void k_conv_fused(FusedArgs a) {
         const int sj = a.esrc[(size_t)(n0 + il) * a.S + t];
         const int jl = (sj & 0x7fffffff) - span.x;
         // radial and bonded edges of one (source, destination) pair go to different byte fields: no write conflict
-        // within a field because a destination's radial neighbours (and its bonded sources) are distinct atoms
-        atomicOr(&pm[il * JR + jl], (sj < 0) ? ((t + 1) << 8) : (t + 1));
+        // within a field because a destination's radial neighbours (and its bonded sources) are distinct atoms.
+        // (Sources outside the span belong to another tile of the same destinations: large molecules are cut into row blocks.)
+        if (jl >= 0 && jl < rows) atomicOr(&pm[il * JR + jl], (sj < 0) ? ((t + 1) << 8) : (t + 1));
       }
     }
     // the T tiles of the first k need only the feature rows: formed here, behind the latency of the map build
@@ -304,6 +305,23 @@ __global__ __launch_bounds__(FT, 1) void k_conv_fused(FusedArgs a) {
       const float4 ge = a.egeo[ta ? ea : eb];
       const bool any = ta || tb;
       p_g[i][0] = any ? ge.x : 0.f; p_g[i][1] = any ? ge.y : 0.f; p_g[i][2] = any ? ge.z : 0.f;
+    }
+    // A tile of a large molecule (destination chunk x source row block) may have no edge at all: its slab is zero
+    if (!__syncthreads_or(p_has)) {
+      if (own_kind == 0) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+          const int row = (q & 3) + 8 * (q >> 2) + 4 * hh;
+          if (row < n_dst) a.partial0[((size_t)slab * a.n_pad + n0 + row) * (a.nt0 * 32) + own_idx * 32 + r] = 0.f;
+        }
+      } else if (own_kind == 1) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+          const int row = (q & 3) + 8 * (q >> 2) + 4 * hh;
+          if (row < n_dst) a.partial1[(((size_t)slab * a.n_pad + n0 + row) * 3 + own_idx) * 32 + r] = 0.f;
+        }
+      }
+      continue;
     }
     auto load_h = [&](int k) {  // raw loads (row k of the [k][slot] table: neighbouring slots share cache lines); write_c masks out the stand-ins of absent edges
       const float* __restrict__ hk = a.h + (size_t)k * a.h_kstride;

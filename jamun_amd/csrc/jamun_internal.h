@@ -9,7 +9,7 @@
 // conv kernel geometry (jamun_conv.hip)
 #define JAMUN_KSUB0 5  // hidden units per k-subgroup, scalar-output rows (subgroups of 4 or 5)
 #define JAMUN_KSUB1 2  // hidden units per k-subgroup, vector-output rows (3 planes per workgroup; subgroups of 1 or 2)
-#define JAMUN_MAX_DYN_LDS (160 * 1024)
+#define JAMUN_MAX_DYN_LDS (159 * 1024)  // dynamic LDS per workgroup: 160 KiB minus room for the kernels' few static words
 #define JAMUN_FUSED_WAVES 8   // waves per workgroup of the fused conv kernel; every wave owns at most one output tile
 #define JAMUN_FUSED_MAX_B 6   // stage-B entries (formed tiles consumed) per owner wave
 #define JAMUN_MAX_BATCH 128  // edge batches (of 4) per wave: 8 atoms x ceil(S / 4); limits the edge stride S to 64

@@ -687,7 +687,7 @@ void launch_node_update(const NodeArgs& a, hipStream_t st) {
   hipLaunchKernelGGL(k_node_update, dim3(a.n_pad / 32), dim3(NU_T), node_update_lds_bytes(a), st, a);
 }
 int node_update_set_max_lds() {
-  return hipFuncSetAttribute((const void*)k_node_update, hipFuncAttributeMaxDynamicSharedMemorySize, JAMUN_MAX_DYN_LDS - 1024) ==
+  return hipFuncSetAttribute((const void*)k_node_update, hipFuncAttributeMaxDynamicSharedMemorySize, JAMUN_MAX_DYN_LDS) ==
                  hipSuccess ? 0 : -1;
 }
 void launch_head(const HeadArgs& a, hipStream_t st) {

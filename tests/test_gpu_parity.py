@@ -157,12 +157,12 @@ def test_forward_matches_oracle(dev, golden_dir, kind):
     assert rmsd(s, ref["score"]) <= RMSD_TOL_NM / sigma**2  # score = (xhat - y)/sigma^2 amplifies by 625
 
 
-@pytest.mark.parametrize("kind", ["ag4", "chain17x6", "ragged_small"])
+@pytest.mark.parametrize("kind", ["ag4", "chain17x6", "ragged_small", "ragged", "dense70"])
 def test_fused_and_fallback_conv_agree(dev, golden_dir, kind, monkeypatch):
-    """The two conv kernels (fused matrix-core forming for small molecules, general k_conv) are independent
-    implementations of the same contraction: both must meet the oracle (where a cached oracle output exists), and each
-    other, on the same input.  `ragged` (molecules up to 57 atoms) and `dense70` must select the general kernel by
-    themselves."""
+    """The two conv kernels (fused matrix-core forming, general k_conv) are independent implementations of the same
+    contraction: both must meet the oracle (where a cached oracle output exists), and each other, on the same input.
+    `ragged` (molecules up to 57 atoms) and `dense70` exceed the fused kernel's LDS budget per tile and exercise its
+    source-row-block tiling (several tiles per destination chunk, summed as extra partial slabs)."""
     from jamun_amd import synth
     from jamun_amd.data import WalkerBatch
     from jamun_amd.model import Denoiser
@@ -201,9 +201,6 @@ def test_fused_and_fallback_conv_agree(dev, golden_dir, kind, monkeypatch):
     a0, b0 = fused.debug_read(0, 0).cpu(), (no_table.xhat(y), no_table.debug_read(0, 0).cpu())[1]
     assert (a0 - b0).abs().max().item() <= 2e-5 * max(b0.abs().max().item(), 1e-6)
     assert rmsd(no_table.xhat(y), xf) <= RMSD_TOL_NM
-    for big in ("ragged", "dense70"):
-        smp = NativeSampler(model._native, 0.04, WalkerBatch.from_molecules(_mols(big)).to(dev), dev)
-        assert smp.stats()["conv_path"] == 0, big
 
 
 def test_forward_matches_live_oracle(dev, ckpt):
