@@ -272,7 +272,9 @@ struct jamun_sampler {
   int* atom_uid = nullptr;            // [n_atoms] index of the atom's distinct (scaled) embedding row
   std::vector<int2> ftile_atoms_h;
   std::vector<int> ftile_chunk_h;     // destination chunk of each tile
+  std::vector<int2> ftile_span_h;
   int n_fchunks = 0;
+  bool row_blocks = false;            // some molecule exceeds the per-tile source budget
   int* atom_nslab = nullptr;          // [n_atoms] partial slabs of the tile the atom belongs to
   float *x_emb = nullptr, *mu = nullptr;
   std::vector<LayerDev> layers;
@@ -706,7 +708,7 @@ void forward(jamun_sampler* s, const float* y, float* xhat, float* score, hipStr
     if (l == 0 && L.tt) {
       InitArgs f{};
       f.deg = s->deg; f.esrc = s->esrc; f.egeo = s->egeo; f.h = h_l; f.h_kstride = s->h_kstride;
-      f.n_pad = s->n_pad; f.S = s->S; f.JR = s->fused_JR; f.nt0 = L.fu.nt0;
+      f.n_pad = s->n_pad; f.S = s->S; f.JR = s->fused_JR; f.nt0 = L.fu.nt0; f.row_blocks = s->row_blocks ? 1 : 0;
       f.tile_span = s->tile_span; f.tile_atoms = s->tile_atoms; f.segs = s->fused_segs; f.max_segs = s->fused_max_segs;
       f.atom_uid = s->atom_uid; f.tt = L.tt; f.tt_row = L.tt_row; f.tt_kstride = (size_t)L.tt_U * L.tt_row;
       f.partial0 = s->partial0; f.partial1 = s->partial1;
@@ -719,7 +721,7 @@ void forward(jamun_sampler* s, const float* y, float* xhat, float* score, hipStr
       f.n_atoms = s->n_atoms; f.n_pad = s->n_pad; f.S = s->S; f.XS = XSin; f.JR = s->fused_JR; f.tile_span = s->tile_span; f.tile_atoms = s->tile_atoms;
       f.wpack = L.fu.wpack; f.a_units = L.fu.a_units; f.b_units = L.fu.b_units; f.owner = L.fu.owner; f.segs = s->fused_segs;
       f.k_stride = L.fu.k_stride; f.max_a = L.fu.max_a; f.n_p = L.fu.n_p; f.n_t = L.fu.n_t; f.max_segs = s->fused_max_segs;
-      f.nt0 = L.fu.nt0; f.partial0 = s->partial0; f.partial1 = s->partial1;
+      f.nt0 = L.fu.nt0; f.partial0 = s->partial0; f.partial1 = s->partial1; f.row_blocks = s->row_blocks ? 1 : 0;
       ProfScope ps(s, l == 0 ? JAMUN_PROF_CONV0_INIT : JAMUN_PROF_CONV0, st);
       const int rcode = launch_conv_fused(f, s->fused_grid, st);
       if (rcode != 0) throw Err(JAMUN_ERR_INVALID, "fused conv launch failed (configuration not supported)");
@@ -913,6 +915,7 @@ int jamun_sampler_create(const jamun_model* m, float sigma, const jamun_topology
             // in the coefficient tile, so the blocks' results are just more partial slabs for the node update to sum
             // (edges whose source lies outside a tile's block are skipped by that tile).
             const int n_mol = mol_hi - lo, nb = (n_mol + jr_cap - 1) / jr_cap;
+            s->row_blocks = true;
             for (int d0 = lo; d0 < mol_hi; d0 += 32) {
               const int cnt = std::min(32, mol_hi - d0);
               for (int b = 0; b < nb; ++b) {
@@ -948,6 +951,7 @@ int jamun_sampler_create(const jamun_model* m, float sigma, const jamun_topology
         s->n_ftiles = (int)t_atoms.size();
         s->ftile_atoms_h = t_atoms;
         s->ftile_chunk_h = t_chunk;
+        s->ftile_span_h = t_span;
         s->n_fchunks = n_chunks;
         s->tile_atoms = dev_upload(t_atoms);
         s->tile_span = dev_upload(t_span);
@@ -1084,28 +1088,45 @@ int jamun_sampler_create(const jamun_model* m, float sigma, const jamun_topology
       std::vector<int> nslab(s->n_fchunks, 0);  // per destination chunk: its tiles (source row blocks, k runs) number their slabs jointly
       for (int x = 0; x < ng; ++x) {
         auto extra_of = [&](int t) { const int e = ((x - t) % ng + ng) % ng; return e < rem ? ng * base + e : -1; };
-        int64_t Lx = 0;
-        for (int t = 0; t < n_tiles; ++t) Lx += base + (extra_of(t) >= 0 ? 1 : 0);
-        int64_t off = 0;
-        int c = 0;
+        // items are weighted by the MFMA count of one hidden-layer (tile, k): forming scales with the tile's source rows
+        auto weight = [&](int t) -> int64_t {
+          const int J4 = (s->ftile_span_h[t].y - s->ftile_span_h[t].x + 3) & ~3;
+          const int steps = 4 * (J4 / 8) + ((J4 & 4) ? 2 : 0), n_jt = (J4 + 31) / 32;
+          return 16 * steps + n_jt * (64 + 48) + 496 + 256;  // + the fixed per-interval cost (barrier, build), in MFMA units
+        };
+        // (near-uniform batches are cut by item count: measured 1 % better on cfg2 than the modelled weights, whose error
+        // then exceeds the spread they describe)
+        int64_t w_min = weight(0), w_max = w_min;
+        for (int t = 1; t < n_tiles; ++t) { w_min = std::min(w_min, weight(t)); w_max = std::max(w_max, weight(t)); }
+        const bool uniform = 4 * (w_max - w_min) < w_max;
+        auto weight_of = [&](int t) -> int64_t { return uniform ? 1 : weight(t); };
+        int64_t Lx = 0, Wx = 0;
+        for (int t = 0; t < n_tiles; ++t) {
+          const int cnt = base + (extra_of(t) >= 0 ? 1 : 0);
+          Lx += cnt;
+          Wx += cnt * weight_of(t);
+        }
         // small batches: do not cut the list finer than 8 items per workgroup (a tile's partial slabs are summed by the node
         // update; one slab per hidden unit would make that kernel the bottleneck)
         const int ncx_all = ncx;
         const int ncx = (int)std::max<int64_t>(1, std::min<int64_t>(ncx_all, Lx / 8));
+        int64_t off_w = 0;
         for (int t = 0; t < n_tiles; ++t) {
           const int ex = extra_of(t), cnt = base + (ex >= 0 ? 1 : 0);
+          const int64_t w = weight_of(t);
+          auto wg_of_item = [&](int i) { return (int)std::min<int64_t>(ncx - 1, ((off_w + i * w + w / 2) * ncx) / Wx); };
           int i0 = 0;
           while (i0 < cnt) {
-            while (c + 1 < ncx && (Lx * (c + 1)) / ncx <= off + i0) ++c;
-            const int64_t hi = (c + 1 < ncx) ? (Lx * (c + 1)) / ncx : Lx;
-            const int i1 = (int)std::min<int64_t>(cnt, hi - off);
+            const int c = wg_of_item(i0);
+            int i1 = i0 + 1;
+            while (i1 < cnt && wg_of_item(i1) == c) ++i1;
             const int kb = x * base + std::min(i0, base), ke = x * base + std::min(i1, base);
             auto& v = wg_segs[wg_of[x][c]];
             v.push_back(make_int4(t, nslab[s->ftile_chunk_h[t]]++, kb, ke));
             v.push_back(make_int4(i1 > base ? ex : -1, 0, 0, 0));
             i0 = i1;
           }
-          off += cnt;
+          off_w += cnt * w;
         }
       }
       size_t ms = 1;

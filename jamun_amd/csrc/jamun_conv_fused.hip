@@ -307,7 +307,7 @@ __global__ __launch_bounds__(FT, 1) void k_conv_fused(FusedArgs a) {
       p_g[i][0] = any ? ge.x : 0.f; p_g[i][1] = any ? ge.y : 0.f; p_g[i][2] = any ? ge.z : 0.f;
     }
     // A tile of a large molecule (destination chunk x source row block) may have no edge at all: its slab is zero
-    if (!__syncthreads_or(p_has)) {
+    if (a.row_blocks && !__syncthreads_or(p_has)) {  // (only batches with row-block tiles pay for the vote)
       if (own_kind == 0) {
 #pragma unroll
         for (int q = 0; q < 16; ++q) {

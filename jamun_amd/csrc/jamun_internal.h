@@ -62,6 +62,7 @@ struct FusedArgs {
   const int4* owner;  // [waves] {kind (-1 none, 0 scalar-row tile, 1 vector plane), index, 0, 0}
   const int4* segs;   // [grid][max_segs][2]: {tile (-1 end), slab, k_begin, k_end}, {k_extra (-1 none), 0, 0, 0}
   int k_stride, max_a, n_p, n_t, max_segs, nt0;  // n_p / n_t: parked scalar-row / T tiles per k
+  int row_blocks;  // 1: some molecule's sources are cut into row blocks (tiles may be edge-less: checked at run time)
   float* partial0;  // [slab][n_pad][nt0*32]
   float* partial1;  // [slab][n_pad][3][32]
 };
@@ -78,6 +79,7 @@ struct InitArgs {
   const int2* tile_atoms;
   const int4* segs;  // same segment lists as the fused kernel
   int max_segs;
+  int row_blocks;       // as FusedArgs
   const int* atom_uid;  // [n_atoms] index of the atom's distinct embedding row
   const float* tt;      // [k][U][tt_row]: columns 32 t + c of output tile t (t < nt0 scalar rows, t = nt0 vector rows)
   size_t tt_kstride;    // U * tt_row
