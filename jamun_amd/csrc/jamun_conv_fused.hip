@@ -1,10 +1,10 @@
-// jamun_conv_fused.hip — fused conv contraction for small molecules: the A operand is formed ON THE MATRIX CORES and
-// every wave OWNS one output tile.
+// jamun_conv_fused.hip — fused conv contraction (hidden layers): the A operand is formed ON THE MATRIX CORES and every
+// wave OWNS one output tile.
 //
 // Same mathematics as jamun_conv.hip (destination-grouped association of src/jamun/e3tools/nn/_conv.py:93-119):
 //     m[(i,c)][w] = sum_k sum_u ( sum_{e->i} h~_e[k] zeta_e[c][u] ) W~[(k,u)][w]
-// but the inner edge sum is written as a dense product over the source atoms j the tile can see (whole molecules,
-// JR <= 64 rows):
+// but the inner edge sum is written as a dense product over the source atoms j of the tile's span (whole small molecules,
+// or one row block of a large molecule — the product is linear in C, so blocks simply add partial slabs; JR <= 64 rows):
 //     D'_k[u][i] = sum_j X[j][u] * C_k[j][i]          C_k[j][i] = sum over the (<= 2) edges j->i of h~_e[k] * f_e
 // with f = 1 or a component of the edge unit vector.  D' is a 32x32 MFMA accumulator whose COLUMN is the destination
 // atom, i.e. exactly the lane layout of the A operand of the main product  out[i][w] += sum_u D'[u][i] W[(k,u)][w]:
@@ -12,8 +12,8 @@
 // packed in that K order.
 //
 // One persistent workgroup per CU = 8 waves.  Work items are (tile of 32 destination atoms, hidden unit k); a workgroup
-// walks a host-built list of segments (tile, run of k) — k is sliced over the XCDs so every XCD's L2 holds only its own
-// weights, and the (tile, k) list of an XCD is cut evenly over its CUs (no tail round).
+// walks a host-built list of segments (tile, run of k): the (tile, k) list (optionally sliced in k over XCD groups) is cut
+// evenly — by item count or by modelled cost — over the workgroups, so there is no tail round.
 //
 // Every wave OWNS one output tile: wave w < NT0 the scalar-row tile w, waves NT0..NT0+2 the vector planes.  No accumulator
 // is shared between waves: no cross-wave reduction, 16 accumulator registers per wave.  The k of a segment are software
