@@ -203,6 +203,40 @@ def test_fused_and_fallback_conv_agree(dev, golden_dir, kind, monkeypatch):
     assert rmsd(no_table.xhat(y), xf) <= RMSD_TOL_NM
 
 
+@pytest.mark.parametrize("seed", [0, 7])
+def test_fused_and_fallback_conv_agree_on_random_ragged_batches(dev, seed, monkeypatch):
+    """Fuzz the tiling of the fused conv path (multi-molecule tiles, partly filled tiles, source-row blocks of molecules
+    above the per-tile budget, 1-atom walkers, tiny batches) against the general kernel: random walker counts and sizes."""
+    import random
+
+    from jamun_amd import synth
+    from jamun_amd.data import WalkerBatch
+    from jamun_amd.model import Denoiser
+    from jamun_amd.native import NativeSampler
+
+    model = Denoiser.from_checkpoint_dict(_ckpt("strong")).to(dev)
+    rng = random.Random(seed)
+    for trial in range(6):
+        nw = rng.choice([1, 2, 3, 5, 8, 13, 40])
+        hi = rng.choice([3, 9, 20, 33, 52, 53, 60, 104, 130])
+        mols = [synth.random_chain(rng.randint(1, hi), seed=1000 * trial + i + 17 * seed) for i in range(nw)]
+        batch = WalkerBatch.from_molecules(mols).to(dev)
+        torch.manual_seed(trial)
+        y = batch.pos + 0.04 * torch.randn(batch.pos.shape).to(dev)
+        monkeypatch.delenv("JAMUN_NO_FUSED", raising=False)
+        fused = NativeSampler(model._native, 0.04, batch, dev)
+        monkeypatch.setenv("JAMUN_NO_FUSED", "1")
+        general = NativeSampler(model._native, 0.04, batch, dev)
+        monkeypatch.delenv("JAMUN_NO_FUSED")
+        assert fused.stats()["conv_path"] == 1 and general.stats()["conv_path"] == 0
+        xf, xg = fused.xhat(y), general.xhat(y)
+        assert torch.isfinite(xf).all()
+        assert rmsd(xf, xg) <= RMSD_TOL_NM, (trial, nw, hi)
+        for l in range(6):
+            a, b = fused.debug_read(0, l).cpu(), general.debug_read(0, l).cpu()
+            assert (a - b).abs().max().item() <= 2e-5 * max(b.abs().max().item(), 1e-6), (trial, l)
+
+
 def test_forward_matches_live_oracle(dev, ckpt):
     """Same comparison with the oracle run live on this box (small case), so the cache is not the only witness."""
     from jamun_amd.data import WalkerBatch
