@@ -84,6 +84,38 @@ class SaveTrajectoryCallback:
             write_pdb(os.path.join(self._dir(label, "pdb"), "joined.pdb"), mol, torch.tensor(joined).permute(1, 0, 2))
 
 
+class TrajectoryMetricCallback:
+    """Feeds per-walker samples to one metric object per dataset label (``callbacks/sampler/_utils.py:22-56``).
+
+    ``metric_fn(dataset=...)`` builds the meter of a dataset; a meter offers ``update(sample)``, ``compute() -> dict`` and
+    the hooks ``on_sample_start / on_after_sample_batch / on_sample_end`` (and optionally ``to(device)``), i.e. the
+    reference's ``TrajectoryMetric`` protocol, so metric classes written against it plug in unchanged.  Datasets are
+    de-duplicated by label and ordered by label."""
+
+    def __init__(self, datasets: Sequence, metric_fn):
+        unique = {}
+        for d in datasets:
+            unique.setdefault(d.label(), d)
+        self.meters = {label: metric_fn(dataset=unique[label]) for label in sorted(unique)}
+
+    def on_sample_start(self, sampler):
+        for meter in self.meters.values():
+            if hasattr(meter, "to"):
+                meter.to(sampler.fabric.device)
+            meter.on_sample_start()
+
+    def on_after_sample_batch(self, sample: Sequence, sampler):
+        for sample_graph in sample:
+            self.meters[sample_graph["dataset_label"]].update(sample_graph)
+        for meter in self.meters.values():
+            sampler.fabric.log_dict(meter.compute())
+            meter.on_after_sample_batch()
+
+    def on_sample_end(self, sampler):
+        for meter in self.meters.values():
+            meter.on_sample_end()
+
+
 class MeasureSamplingTimeCallback:
     """Wall time per batch and per sampled conformation (one saved (walker, frame) pair — the reference's unit,
     ``callbacks/sampler/_measure_sampling_time.py:57,71``).  Writes ``sampler/timing.json`` on rank 0."""

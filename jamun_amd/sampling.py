@@ -301,11 +301,11 @@ class ModelSamplingWrapper:
         outs = []
         for w in range(g.num_graphs):
             a, b = ptr[w], ptr[w + 1]
-            d = {
-                "pos": g.pos[a:b], "atom_type_index": g.atom_type_index[a:b], "atom_code_index": g.atom_code_index[a:b],
-                "residue_code_index": g.residue_code_index[a:b], "residue_sequence_index": g.residue_sequence_index[a:b],
-                "dataset_label": g.dataset_label[w] if g.dataset_label else None, "num_nodes": b - a,
-            }  # fmt: skip
+            d = SampleGraph(
+                pos=g.pos[a:b], atom_type_index=g.atom_type_index[a:b], atom_code_index=g.atom_code_index[a:b],
+                residue_code_index=g.residue_code_index[a:b], residue_sequence_index=g.residue_sequence_index[a:b],
+                dataset_label=g.dataset_label[w] if g.dataset_label else None, num_nodes=b - a,
+            )  # fmt: skip
             outs.append(d)
         for key, value in samples.items():
             if value is None or value.ndim not in [2, 3]:
@@ -320,6 +320,17 @@ class ModelSamplingWrapper:
                     raise ValueError(f"Number of nodes in unbatched value ({chunk.shape[0]}) for key {key} does not match number of nodes in output graph ({d['num_nodes']}).")
                 d[key] = chunk
         return outs
+
+
+class SampleGraph(dict):
+    """One walker's sample as handed to callbacks: a dict whose keys are also attributes (``sample.xhat_traj``,
+    ``sample.dataset_label``), like the per-walker PyG ``Data`` objects of the reference (``sampling_wrapper.py:49-83``)."""
+
+    def __getattr__(self, name):
+        try:
+            return self[name]
+        except KeyError:
+            raise AttributeError(name) from None
 
 
 class Sampler:
@@ -350,7 +361,19 @@ class Sampler:
         self.shard_walkers = shard_walkers
         self.rng = rng
         self.global_step = None
+        self.logged: List[tuple] = []  # (step, metrics) pairs passed to log_dict
         self.fabric = self  # `sampler.fabric.global_rank` is read by cmdline/sample.py:86-88
+
+    # ---- the slice of Fabric's logging surface that sampler callbacks use (``callbacks/sampler/_utils.py:49``)
+    def log_dict(self, metrics: Dict[str, Any], step: Optional[int] = None) -> None:
+        step = self.global_step if step is None else step
+        self.logged.append((step, dict(metrics)))
+        for lg in (self.loggers if isinstance(self.loggers, (list, tuple)) else ([self.loggers] if self.loggers else [])):
+            if hasattr(lg, "log_metrics"):
+                lg.log_metrics(dict(metrics), step=step)
+
+    def log(self, name: str, value: Any, step: Optional[int] = None) -> None:
+        self.log_dict({name: value}, step=step)
 
     def call(self, hook: str, **kwargs):
         for cb in self.callbacks:

@@ -243,3 +243,59 @@ def test_separable_conv_checkpoint_is_rejected():
     ck["hyper_parameters"]["arch"]["hidden_layer_factory"] = functools.partial(dict, conv=functools.partial(SeparableConv))
     with pytest.raises(NotImplementedError, match="Separable"):
         Denoiser.from_checkpoint_dict(ck)
+
+
+def test_trajectory_metric_callback_dispatches_by_label():
+    """callbacks/sampler/_utils.py:22-56 — one meter per dataset label, samples routed by `dataset_label`, compute()
+    results logged through the sampler, hooks forwarded; samples answer both key and attribute access."""
+    from jamun_amd.callbacks import TrajectoryMetricCallback
+    from jamun_amd.sampling import SampleGraph
+
+    class DS:
+        def __init__(self, label):
+            self._l = label
+
+        def label(self):
+            return self._l
+
+    class Meter:
+        def __init__(self, dataset):
+            self.dataset, self.seen, self.events = dataset, [], []
+
+        def to(self, device):
+            self.events.append(("to", device))
+
+        def on_sample_start(self):
+            self.events.append("start")
+
+        def update(self, sample):
+            self.seen.append(sample.xhat_traj)  # attribute access, as reference metrics do
+
+        def compute(self):
+            return {f"{self.dataset.label()}/n": len(self.seen)}
+
+        def on_after_sample_batch(self):
+            self.events.append("batch")
+
+        def on_sample_end(self):
+            self.events.append("end")
+
+    class FakeSampler:
+        def __init__(self):
+            self.fabric, self.device, self.logged = self, "dev0", []
+
+        def log_dict(self, m):
+            self.logged.append(m)
+
+    cb = TrajectoryMetricCallback([DS("b"), DS("a"), DS("b")], Meter)
+    assert list(cb.meters) == ["a", "b"]
+    smp = FakeSampler()
+    cb.on_sample_start(smp)
+    cb.on_after_sample_batch([SampleGraph(dataset_label="b", xhat_traj=1), SampleGraph(dataset_label="a", xhat_traj=2),
+                              SampleGraph(dataset_label="b", xhat_traj=3)], smp)
+    cb.on_sample_end(smp)
+    assert cb.meters["b"].seen == [1, 3] and cb.meters["a"].seen == [2]
+    assert smp.logged == [{"a/n": 1}, {"b/n": 2}]
+    assert cb.meters["a"].events == [("to", "dev0"), "start", "batch", "end"]
+    with pytest.raises(AttributeError):
+        SampleGraph(a=1).missing
