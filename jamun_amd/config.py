@@ -32,6 +32,10 @@ TARGET_ALIASES = {
     "jamun.data.create_dataset_from_pdbs": "jamun_amd.pdb.create_dataset_from_pdbs",
     "jamun.callbacks.sampler.SaveTrajectoryCallback": "jamun_amd.callbacks.SaveTrajectoryCallback",
     "jamun.callbacks.sampler.MeasureSamplingTimeCallback": "jamun_amd.callbacks.MeasureSamplingTimeCallback",
+    "jamun.callbacks.sampler.TrajectoryMetricCallback": "jamun_amd.callbacks.TrajectoryMetricCallback",
+    "jamun.sampling.walkjump.MeasurementDependentParametersCallback": "jamun_amd.sampling.MeasurementDependentParametersCallback",
+    "jamun.sampling.walkjump.InterpolateParametersCallback": "jamun_amd.sampling.InterpolateParametersCallback",
+    "jamun.utils.ModelSamplingWrapper": "jamun_amd.sampling.ModelSamplingWrapper",
 }
 
 
