@@ -237,6 +237,35 @@ def test_fused_and_fallback_conv_agree_on_random_ragged_batches(dev, seed, monke
             assert (a - b).abs().max().item() <= 2e-5 * max(b.abs().max().item(), 1e-6), (trial, l)
 
 
+def test_walkers_are_independent_at_baseline_batch_size(dev, golden_dir):
+    """BASELINE configs[1] shape (17-atom molecule x 256 walkers = 136 tiles, ~2.5 segments per workgroup, 2-3 partial
+    slabs per tile): the denoised coordinates of a walker must not depend on which walkers share its batch.  Walkers 0, 1,
+    100 and 255 of the big batch are compared with the same four walkers sampled alone — and, through the 6-walker cached
+    oracle case of the same molecule, with the CPU oracle."""
+    from jamun_amd import synth
+    from jamun_amd.data import WalkerBatch
+    from jamun_amd.model import Denoiser
+
+    model = Denoiser.from_checkpoint_dict(_ckpt("strong")).to(dev)
+    mol = synth.random_chain(17, seed=0)
+    big = WalkerBatch.from_molecules([mol] * 256).to(dev)
+    torch.manual_seed(3)
+    y = big.pos + 0.04 * torch.randn(big.pos.shape).to(dev)
+    x_big = model.xhat(big.with_pos(y), 0.04).pos.view(256, 17, 3)
+    pick = [0, 1, 100, 255]
+    small = WalkerBatch.from_molecules([mol] * len(pick)).to(dev)
+    y_small = y.view(256, 17, 3)[pick].reshape(-1, 3)
+    x_small = model.xhat(small.with_pos(y_small), 0.04).pos.view(len(pick), 17, 3)
+    assert rmsd(x_big[pick].reshape(-1, 3), x_small.reshape(-1, 3)) <= RMSD_TOL_NM / 10
+    # tie the big batch to the oracle: put the cached 6-walker oracle input into walkers 5..10 of the big batch
+    ref = _golden(golden_dir, "oracle_forward_chain17x6")
+    if _mols("chain17x6")[0]["pos"].shape[0] == 17:
+        big6 = WalkerBatch.from_molecules(_mols("chain17x6") + [mol] * 250).to(dev)
+        y6 = torch.cat([ref["y"].to(dev), y[6 * 17:]])
+        x6 = model.xhat(big6.with_pos(y6), 0.04).pos[: 6 * 17]
+        assert rmsd(x6, ref["xhat"]) <= RMSD_TOL_NM
+
+
 def test_forward_matches_live_oracle(dev, ckpt):
     """Same comparison with the oracle run live on this box (small case), so the cache is not the only witness."""
     from jamun_amd.data import WalkerBatch
