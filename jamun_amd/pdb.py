@@ -55,11 +55,14 @@ def _element(line: str, name: str) -> str:
 def read_pdb(path: str) -> dict:
     """First model of a PDB file -> molecule dict (heavy protein atoms only)."""
     atoms = []  # (serial, name, resname, chain, resseq+icode, x, y, z, element)
+    kept: List[int] = []  # index of each kept atom among ALL atom records of the model (trajectory arrays carry all atoms)
+    n_records = 0
     conect: List[Tuple[int, int]] = []
     with open(path) as f:
         for line in f:
             rec = line[:6]
             if rec in ("ATOM  ", "HETATM"):
+                n_records += 1
                 name = line[12:16].strip()
                 resname = line[17:20].strip()
                 if resname not in PROTEIN_RESIDUES:
@@ -68,6 +71,7 @@ def read_pdb(path: str) -> dict:
                 if el == "H" or el == "D":
                     continue
                 atoms.append((int(line[6:11]), name, resname, line[21], line[22:27], float(line[30:38]), float(line[38:46]), float(line[46:54]), el))
+                kept.append(n_records - 1)
             elif rec == "CONECT":
                 f0 = line[6:].split()
                 if len(f0) >= 2:
@@ -124,6 +128,8 @@ def read_pdb(path: str) -> dict:
         residues=[a[2] for a in atoms],
         elements=[a[8] for a in atoms],
         residue_ids=[int(a[4][:4]) for a in atoms],
+        all_atom_index=torch.tensor(kept, dtype=torch.long),
+        n_all_atoms=n_records,
     )
 
 
@@ -160,6 +166,53 @@ class PDBDataset:
         if idx not in (0, -1):
             raise IndexError(idx)
         return self.molecule
+
+
+class MDtrajDataset:
+    """Frames of one molecule (``data/_mdtraj.py:155-237`` without mdtraj): topology from ``pdbfile``, coordinates from
+    ``trajfiles`` — the PDB itself (one frame) or Timewarp-style ``*.npz`` / ``*.npy`` arrays whose ``positions`` are
+    ``[frames, all atoms, 3]`` in nanometres (``_mdtraj.py:194-200``).  Frames ``start_frame : start_frame + num_frames :
+    subsample``; atoms = the reference's selection "protein and not type H"; item = molecule dict with that frame."""
+
+    def __init__(self, root: str, trajfiles: Sequence[str], pdbfile: str, label: str, num_frames: Optional[int] = None,
+                 start_frame: Optional[int] = None, transform=None, subsample: Optional[int] = None, loss_weight: float = 1.0,
+                 verbose: bool = False):
+        import numpy as np
+
+        self.root, self._label, self.transform, self.loss_weight = root, label, transform, loss_weight
+        self.molecule = read_pdb(os.path.join(root, pdbfile))
+        self.molecule["dataset_label"] = label
+        keep = self.molecule["all_atom_index"]
+        files = [os.path.join(root, f) for f in trajfiles]
+        if files[0].endswith((".npz", ".npy")):
+            chunks = []
+            for f in files:
+                arr = np.load(f)
+                arr = arr["positions"] if hasattr(arr, "files") else arr
+                if arr.ndim != 3 or arr.shape[1] != self.molecule["n_all_atoms"] or arr.shape[2] != 3:
+                    raise ValueError(f"{f}: positions {arr.shape} do not match the {self.molecule['n_all_atoms']} atoms of {pdbfile}")
+                chunks.append(np.asarray(arr, dtype=np.float32))
+            xyz = torch.from_numpy(np.vstack(chunks))[:, keep]
+        elif all(f.endswith(".pdb") for f in files):
+            xyz = torch.stack([read_pdb(f)["pos"] for f in files])
+        else:
+            raise NotImplementedError(f"trajectory format of {files[0]} (supported: .pdb, .npz, .npy)")
+        start = 0 if start_frame is None else start_frame
+        n = xyz.shape[0] - start if num_frames in (-1, None) else num_frames
+        step = 1 if not subsample else subsample
+        self.xyz = xyz[start : start + n : step].contiguous()
+        self.molecule["pos"] = self.xyz[0]
+
+    def label(self) -> str:
+        return self._label
+
+    def __len__(self) -> int:
+        return self.xyz.shape[0]
+
+    def __getitem__(self, idx: int) -> dict:
+        mol = dict(self.molecule)
+        mol["pos"] = self.xyz[idx]
+        return self.transform(mol) if self.transform else mol
 
 
 def create_dataset_from_pdbs(pdbfiles: Sequence[str], label_prefix: Optional[str] = None) -> List[PDBDataset]:

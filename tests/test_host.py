@@ -299,3 +299,32 @@ def test_trajectory_metric_callback_dispatches_by_label():
     assert cb.meters["a"].events == [("to", "dev0"), "start", "batch", "end"]
     with pytest.raises(AttributeError):
         SampleGraph(a=1).missing
+
+
+def test_mdtraj_dataset_reads_npz_frames(tmp_path):
+    """data/_mdtraj.py:155-237 — topology from the PDB (heavy protein atoms), frames from Timewarp-style arrays that
+    carry ALL atoms (hydrogens included): slicing by start_frame / num_frames / subsample, atom selection, item layout."""
+    import numpy as np
+
+    from jamun_amd.pdb import MDtrajDataset, read_pdb
+
+    lines = []
+    recs = [("N", "ALA", "N"), ("H", "ALA", "H"), ("CA", "ALA", "C"), ("HA", "ALA", "H"), ("C", "ALA", "C"), ("O", "ALA", "O"),
+            ("CB", "ALA", "C"), ("O", "HOH", "O")]
+    for i, (name, res, el) in enumerate(recs):
+        lines.append(f"ATOM  {i + 1:5d} {name:<4s} {res:>3s} A   1    {i * 1.0:8.3f}{0.0:8.3f}{0.0:8.3f}  1.00  0.00          {el:>2s}")
+    (tmp_path / "m.pdb").write_text("\n".join(lines) + "\nEND\n")
+    mol = read_pdb(str(tmp_path / "m.pdb"))
+    assert mol["all_atom_index"].tolist() == [0, 2, 4, 5, 6] and mol["n_all_atoms"] == 8
+    frames = np.arange(6 * 8 * 3, dtype=np.float32).reshape(6, 8, 3) / 100.0
+    np.savez(tmp_path / "m-traj-arrays.npz", positions=frames)
+    ds = MDtrajDataset(str(tmp_path), ["m-traj-arrays.npz"], "m.pdb", "m", num_frames=4, start_frame=1, subsample=2)
+    assert len(ds) == 2 and ds.label() == "m"
+    g = ds[1]
+    assert g["dataset_label"] == "m" and g["pos"].shape == (5, 3)
+    assert torch.equal(g["pos"], torch.from_numpy(frames[3][[0, 2, 4, 5, 6]]))
+    assert torch.equal(ds[0]["pos"], torch.from_numpy(frames[1][[0, 2, 4, 5, 6]]))
+    assert g["atom_type_index"].shape == (5,) and g["bonds"].shape[0] == 2
+    with pytest.raises(ValueError):
+        np.savez(tmp_path / "bad.npz", positions=frames[:, :7])
+        MDtrajDataset(str(tmp_path), ["bad.npz"], "m.pdb", "m")
