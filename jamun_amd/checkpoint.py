@@ -96,3 +96,48 @@ def load_checkpoint_file(path: str) -> dict:
     if not isinstance(ckpt, dict) or "state_dict" not in ckpt or "hyper_parameters" not in ckpt:
         raise RuntimeError(f"{path} is not a Lightning checkpoint with state_dict + hyper_parameters")
     return ckpt
+
+
+def w3j_111_sign_from_state_dict(state_dict) -> float:
+    """Cross-check of the Clebsch-Gordan convention against a real checkpoint.
+
+    e3nn keeps the real Wigner-3j tensors it compiled a tensor product with as buffers named ``..._w3j_{l1}_{l2}_{l3}``.
+    This path assumes ``w3j(1,1,1) = +epsilon_ijk / sqrt(6)`` and ``w3j(0,1,1) = w3j(1,0,1) = w3j(1,1,0) = delta / sqrt(3)``
+    (``oracle/e3.py``); a checkpoint that carries the buffers either confirms that (+1.0), asks for the opposite sign of the
+    cross-product path (-1.0, passed to the kernels as ``jamun_hparams.w3j_111_sign``), or disagrees in a way this code does
+    not understand (``ValueError``).  Without such buffers the assumed convention is returned."""
+    import math
+
+    import torch
+
+    eps = torch.zeros(3, 3, 3, dtype=torch.float64)
+    for i, j, k in ((0, 1, 2), (1, 2, 0), (2, 0, 1)):
+        eps[i, j, k], eps[i, k, j] = 1.0, -1.0
+    eps /= math.sqrt(6.0)
+    delta = torch.eye(3, dtype=torch.float64) / math.sqrt(3.0)
+    sign = None
+    for name, value in state_dict.items():
+        if not torch.is_tensor(value):
+            continue
+        tail = name.rsplit(".", 1)[-1]
+        if not tail.startswith("_w3j_"):
+            continue
+        w = value.detach().to("cpu", torch.float64)
+        if tail == "_w3j_1_1_1" and w.numel() == 27:
+            w = w.reshape(3, 3, 3)
+            if torch.allclose(w, eps, atol=1e-5):
+                s = 1.0
+            elif torch.allclose(w, -eps, atol=1e-5):
+                s = -1.0
+            else:
+                raise ValueError(f"{name}: not +-epsilon/sqrt(6) in the assumed real basis")
+            if sign is not None and s != sign:
+                raise ValueError("inconsistent _w3j_1_1_1 buffers in the checkpoint")
+            sign = s
+        elif tail in ("_w3j_0_1_1", "_w3j_1_0_1", "_w3j_1_1_0") and w.numel() == 9:
+            if not torch.allclose(w.reshape(3, 3), delta, atol=1e-5):
+                raise ValueError(f"{name}: not delta/sqrt(3) in the assumed real basis")
+        elif tail == "_w3j_0_0_0" and w.numel() == 1:
+            if abs(float(w.reshape(())) - 1.0) > 1e-5:
+                raise ValueError(f"{name}: expected 1")
+    return 1.0 if sign is None else sign

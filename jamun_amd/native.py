@@ -90,7 +90,9 @@ class NativeModel:
         hp.average_squared_distance = float(average_squared_distance)
         hp.act_scalar_const = normalize2mom_const("leaky_relu")
         hp.act_gate_const = normalize2mom_const("sigmoid")
-        hp.w3j_111_sign = 1.0
+        from .checkpoint import w3j_111_sign_from_state_dict
+
+        hp.w3j_111_sign = w3j_111_sign_from_state_dict(state_dict)  # +1 unless the checkpoint's e3nn buffers say otherwise
         self.hparams_struct = hp
         keep = []  # keep host buffers alive during the call
         arr = (_lib.jamun_tensor * len(state_dict))()

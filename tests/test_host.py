@@ -328,3 +328,23 @@ def test_mdtraj_dataset_reads_npz_frames(tmp_path):
     with pytest.raises(ValueError):
         np.savez(tmp_path / "bad.npz", positions=frames[:, :7])
         MDtrajDataset(str(tmp_path), ["bad.npz"], "m.pdb", "m")
+
+
+def test_w3j_buffers_cross_check():
+    """A checkpoint that carries e3nn's compiled Wigner-3j buffers confirms or flips the sign of the cross-product path."""
+    import math
+
+    from jamun_amd.checkpoint import w3j_111_sign_from_state_dict as f
+
+    eps = torch.zeros(3, 3, 3)
+    for i, j, k in ((0, 1, 2), (1, 2, 0), (2, 0, 1)):
+        eps[i, j, k], eps[i, k, j] = 1.0, -1.0
+    eps /= math.sqrt(6.0)
+    pre = "layers.0.gated_conv.f.f.tp._compiled_main_left_right."
+    assert f({"a.weight": torch.ones(3)}) == 1.0
+    assert f({pre + "_w3j_1_1_1": eps.flatten(), pre + "_w3j_1_1_0": torch.eye(3) / math.sqrt(3.0), pre + "_w3j_0_0_0": torch.ones(1, 1, 1)}) == 1.0
+    assert f({pre + "_w3j_1_1_1": -eps}) == -1.0
+    with pytest.raises(ValueError):
+        f({pre + "_w3j_1_1_1": eps.permute(1, 0, 2) * 0.5})
+    with pytest.raises(ValueError):
+        f({pre + "_w3j_1_0_1": torch.eye(3)})
