@@ -1,25 +1,40 @@
 #!/usr/bin/env python3
 """Benchmark of the walk-jump hot path: sampled conformations / second, whole job.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config cfg2|cfg3|cfg4|cfg5]
 
 One "step" = one pass of the hot path over the walker batch: one denoiser forward + the BAOAB state update + one saved
 frame for every walker (save_every_n_steps = 1), i.e. one conformation per walker per step — the unit the reference calls
 a "sample" (/root/reference/src/jamun/callbacks/sampler/_measure_sampling_time.py:57,71).  A walk with ``steps = K``
 evaluates exactly K forwards and saves K frames (frame 0 is the initial state, functional/_splitting.py:136-155).
 
-Workload (BASELINE.json configs[1]): uncapped-2AA shape — 17 heavy atoms per walker, 256 walkers per GPU (weak scaling:
-2048 walkers on 8 GPUs), default e3conv architecture, sigma = delta = 0.04, friction 1, M 1, clip 100, synthetic
-molecule + seeded synthetic checkpoint (no datasets / published checkpoints are reachable offline).  Arithmetic is fp32
-end to end (exact-fp32 MFMA): the reference's sampling precision is "32-true" and its bf16 mode is undefined
-(SURVEY.md Appendix C.12), and the 1e-5 nm parity bar needs fp32.
+Workloads (per GPU; weak scaling: the walker count grows with the number of GPUs), default e3conv architecture,
+sigma = delta = 0.04, friction 1, M 1, clip 100, synthetic molecules + seeded synthetic checkpoint (no datasets / published
+checkpoints are reachable offline):
+    cfg2  BASELINE.json configs[1]  uncapped-2AA shape: 17 heavy atoms x 256 walkers              (the default, the metric's config)
+    cfg3  configs[2]                uncapped-4AA shape: 33 atoms x 256 walkers per GPU (2048 on 8)
+    cfg4  configs[3]                MDGen-4AA-like ragged batch: 256 walkers of 17..57 atoms
+    cfg5  configs[4]                chignolin size with hydrogens: 166 atoms x 64 walkers per GPU (512 on 8)
+Arithmetic is fp32 end to end (exact-fp32 MFMA): the reference's sampling precision is "32-true" and its bf16 mode is
+undefined, and the 1e-5 nm parity bar needs fp32.
 
-Multi-GPU: one process per GPU (torch.distributed.run), walkers sharded, no data-path collective; value = all ranks'
+Timing: W untimed warm-up steps, then the K-step walk is timed R times back to back — each repeat bracketed by a barrier +
+torch.cuda.synchronize() on both sides and taken as the MAX over ranks — until >= ~2 s of timed work have accumulated
+(a 20-step walk lasts 50 ms, below what an external GPU-busy sampler resolves); ``ms_per_step`` and ``value`` are the
+MEDIAN repeat.  ``--repeats R`` fixes R.
+
+Multi-GPU: one process per GPU.  Either launch with ``python -m torch.distributed.run --nproc-per-node N bench.py --gpus N``
+or just ``python bench.py --gpus N``: without WORLD_SIZE in the environment the parent spawns the N ranks itself (before any
+GPU call is made) and relays rank 0's JSON line.  Walkers are sharded, there is no data-path collective; value = all ranks'
 conformations / max-over-ranks time.
 """
 import argparse
 import json
+import math
 import os
+import socket
+import statistics
+import subprocess
 import sys
 import time
 
@@ -27,29 +42,57 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-import torch  # noqa: E402
-
-N_ATOMS = 17
-WALKERS_PER_GPU = 256
 SIGMA = 0.04
 MCMC = dict(delta=0.04, friction=1.0, M=1.0, inverse_temperature=1.0, score_fn_clip=100.0)
 F32_MFMA_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+HBM_PEAK_GBS = 8000.0         # same guide, "HBM3E peak BW" (spec; ~6.3 TB/s measured on a float4 copy)
+MIN_TIMED_S = 2.0
+
+CONFIGS = {
+    "cfg2": dict(baseline="configs[1]", desc="uncapped-2AA-like 17-atom molecule", atoms=17, walkers=256),
+    "cfg3": dict(baseline="configs[2]", desc="uncapped-4AA-like 33-atom molecule (2048 walkers over 8 GPUs)", atoms=33, walkers=256),
+    "cfg4": dict(baseline="configs[3]", desc="MDGen-4AA-like ragged batch, 17..57 atoms per walker", atoms=None, walkers=256),
+    "cfg5": dict(baseline="configs[4]", desc="chignolin-size 166-atom molecule with hydrogens (512 walkers over 8 GPUs)", atoms=166, walkers=64),
+}
 
 
-def cpu_baseline(budget_walkers=8, frames=3):
-    """The CPU oracle (op-for-op PyTorch restatement of the reference path, kind="port") timed on this box's host cores
-    on a bounded sample of the same workload: `budget_walkers` walkers of the 17-atom molecule x `frames` walk-jump
-    frames (each frame costs two forwards, as the reference)."""
+def workload_molecules(cfg: str, walkers: int, atoms=None, rank: int = 0):
+    """The walker batch of one rank.  Equal molecules are consecutive (as get_initial_graphs' repeat, cmdline/sample.py:36)."""
+    from jamun_amd import synth
+
+    c = CONFIGS[cfg]
+    n = atoms if atoms is not None else c["atoms"]
+    if n is not None:
+        return [synth.random_chain(n, seed=0)] * walkers
+    import random
+
+    rng = random.Random(1234 + rank)  # ragged: sizes ~ U{17..57}, 8 distinct sequences per rank, each repeated
+    kinds = [synth.random_chain(rng.randint(17, 57), seed=100 + i + 16 * rank) for i in range(8)]
+    per = -(-walkers // len(kinds))
+    return [m for m in kinds for _ in range(per)][:walkers]
+
+
+# ---- CPU baseline (rank 0, N = 1 only) ---------------------------------------------------------------------------------
+
+
+def _cpu_threads():
+    import torch
+
+    avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = min(avail, 16)  # these small-tensor ops get slower, not faster, with hundreds of threads (measured: 256 threads 40x slower than 8)
+    torch.set_num_threads(cores)
+    return cores
+
+
+def _cpu_walk(mols, steps):
+    import torch
+
     from jamun_amd import synth
     from oracle import denoiser as od
     from oracle import graph as og
     from oracle import walk as ow
 
-    avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    cores = min(avail, 16)  # these small-tensor ops get slower, not faster, with hundreds of threads (measured: 256 threads 40x slower than 8)
-    torch.set_num_threads(cores)
-    mol = synth.random_chain(N_ATOMS, seed=0)
-    topo = og.collate([{k: v for k, v in mol.items() if torch.is_tensor(v)}] * budget_walkers)
+    topo = og.collate([{k: v for k, v in m.items() if torch.is_tensor(v)} for m in mols])
     sd = synth.synthetic_state_dict()
     hp = od.default_hparams()
     noise = ow.TorchNoise(42)
@@ -58,22 +101,97 @@ def cpu_baseline(budget_walkers=8, frames=3):
     xhat_fn = lambda y: od.xhat(y, topo, SIGMA, sd, hp)
     score_fn(y0)  # warm-up (thread pools, allocator)
     t0 = time.perf_counter()
-    ow.walk_jump(score_fn, xhat_fn, ow.baoab, y0, "gaussian", noise, steps=frames, save_trajectory=True, **MCMC)
-    dt = time.perf_counter() - t0
-    # walk_jump evaluates xhat(y_final) once more on top of the 2 forwards per frame
-    return {
-        "value": budget_walkers * frames / dt,
+    ow.walk_jump(score_fn, xhat_fn, ow.baoab, y0, "gaussian", noise, steps=steps, save_trajectory=True, **MCMC)
+    return time.perf_counter() - t0
+
+
+def cpu_baseline(cfg: str, sample_walkers=8, frames=3, cfg1_exact=True):
+    """The CPU oracle (op-for-op PyTorch restatement of the reference path, kind="port") timed on this box's host cores:
+    a bounded sample of the benchmarked workload (`sample_walkers` walkers x `frames` walk-jump frames; each frame costs two
+    forwards, as the reference) and — BASELINE.md section 2 — BASELINE.json configs[0] EXACTLY: AG dipeptide, 4 walkers x 50
+    walk-jump steps."""
+    from jamun_amd import synth
+
+    cores = _cpu_threads()
+    mols = workload_molecules(cfg, sample_walkers)
+    dt = _cpu_walk(mols, frames)
+    out = {
+        "value": sample_walkers * frames / dt,
         "unit": "conformations/s",
         "cores": cores,
         "kind": "port",
-        "sample": f"{budget_walkers} walkers x {frames} walk-jump frames of the {N_ATOMS}-atom workload molecule, fp32, {dt:.1f} s",
+        "sample": f"{sample_walkers} walkers x {frames} walk-jump frames of the {cfg} workload ({sum(m['pos'].shape[0] for m in mols)} atoms), fp32, {dt:.1f} s",
     }
+    if cfg1_exact:
+        dt1 = _cpu_walk([synth.ag_dipeptide()] * 4, 50)
+        out["cfg1_exact"] = {"value": 4 * 50 / dt1, "unit": "conformations/s", "cores": cores, "kind": "port",
+                             "sample": f"BASELINE configs[0] exactly: AG dipeptide, 4 walkers x 50 walk-jump steps, fp32, {dt1:.1f} s"}
+    return out
+
+
+# ---- secondary rooflines: the HBM-bound kernels north_star names --------------------------------------------------------
+
+
+def _time_launches(fn, iters, warm=5):
+    import torch
+
+    for _ in range(warm):
+        fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()  # the stand-alone operators launch on torch's current stream, which these events see
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e-3 / iters
+
+
+def secondary_rooflines(dev):
+    """HIP-event timing, in this process, of the HBM-bound kernels of the path at the 256 x 17 and 2048 x 17 walker shapes:
+    `k_scatter_mean` (torch_scatter mean over [E,248] messages, _conv.py:117; algorithmic bytes = E*992 read + N*992 written +
+    CSR pointers) and the Langevin update kernels `k_baoab_pre` / `k_baoab_post` (60 B/atom/step + 36 B/atom/saved frame,
+    SURVEY.md section 8d).  Back-to-back launches; buffers above the 256 MiB Infinity Cache are cycled so reads come from HBM."""
+    import torch
+
+    from jamun_amd import native
+
+    out = []
+    for walkers in (256, 2048):
+        n, deg = walkers * 17, 17
+        E = n * deg
+        seg = torch.arange(0, E + 1, deg, dtype=torch.int32, device=dev)
+        nbytes = E * 248 * 4 + n * 248 * 4 + (n + 1) * 4
+        n_buf = max(1, min(8, int(math.ceil((300 << 20) / (E * 248 * 4)))))  # rotate sources so the set exceeds the Infinity Cache
+        srcs = [torch.randn(E, 248, device=dev) for _ in range(n_buf)]
+        it = [0]
+
+        def run():
+            native.scatter_mean(srcs[it[0] % n_buf], seg, n)
+            it[0] += 1
+
+        dt = _time_launches(run, 40 if walkers == 256 else 12)
+        out.append({"kernel": "k_scatter_mean", "shape": f"{walkers} walkers x 17 atoms, in-degree {deg}: [E={E},248] f32 -> [{n},248]",
+                    "bound": "hbm", "bytes": nbytes, "avg_launch_ms": dt * 1e3, "achieved": nbytes / dt / 1e9, "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s", "frac": nbytes / dt / 1e9 / HBM_PEAK_GBS})
+        del srcs
+        params = native.make_mcmc_params(2, **MCMC)
+        y, v, psi, R, sc = (torch.randn(n, 3, device=dev) for _ in range(5))
+        dt = _time_launches(lambda: native.baoab_pre(y, v, psi, R, params), 200)
+        b = n * 3 * 4 * 6  # read y, v, psi, noise (parity mode); write y, v
+        out.append({"kernel": "k_baoab_pre", "shape": f"{walkers} walkers x 17 atoms (host-supplied noise: +12 B/atom read)", "bound": "hbm",
+                    "bytes": b, "avg_launch_ms": dt * 1e3, "achieved": b / dt / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": b / dt / 1e9 / HBM_PEAK_GBS})
+        dt = _time_launches(lambda: native.baoab_post(v, psi, sc, params), 200)
+        b = n * 3 * 4 * 4  # read v, score; write v, psi
+        out.append({"kernel": "k_baoab_post", "shape": f"{walkers} walkers x 17 atoms (no frame save)", "bound": "hbm",
+                    "bytes": b, "avg_launch_ms": dt * 1e3, "achieved": b / dt / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": b / dt / 1e9 / HBM_PEAK_GBS})
+    return out
 
 
 def _pmc_traffic(kernel: str):
     import glob
 
-    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "*_pmc_traffic.json")))
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")))
     for f in reversed(files):
         try:
             d = json.load(open(f))
@@ -85,31 +203,84 @@ def _pmc_traffic(kernel: str):
     return None
 
 
+# ---- self-launch ---------------------------------------------------------------------------------------------------------
+
+
+def spawn_ranks(n: int) -> int:
+    """`python bench.py --gpus N` without a launcher: start N copies of this script, one per GPU, with the torchrun environment
+    (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT), relay rank 0's stdout, return the worst exit code.  Called
+    before this process has made any GPU call (children are ordinary subprocesses; nothing is exec'ed over a GPU process)."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out0, _ = procs[0].communicate()
+    rc = procs[0].returncode
+    for p in procs[1:]:
+        p.wait()
+        rc = rc or p.returncode
+    for line in out0.decode().splitlines():  # stdout carries the ONE JSON line; library chatter (gloo / RCCL banners) goes to stderr
+        (sys.stdout if line.lstrip().startswith("{") else sys.stderr).write(line + "\n")
+    sys.stdout.flush()
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--walkers", type=int, default=WALKERS_PER_GPU, help="walkers per GPU")
-    ap.add_argument("--atoms", type=int, default=N_ATOMS)
+    ap.add_argument("--config", choices=sorted(CONFIGS), default="cfg2", help="workload (default: cfg2 = BASELINE configs[1], the metric's config)")
+    ap.add_argument("--walkers", type=int, default=None, help="walkers per GPU (default: the config's)")
+    ap.add_argument("--atoms", type=int, default=None, help="atoms per walker (default: the config's)")
+    ap.add_argument("--repeats", type=int, default=0, help="timed repeats of the K-step walk (default: until >= 2 s)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-cfg1-cpu", action="store_true", help="skip the exact configs[0] CPU run (~1 min) inside cpu_baseline")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the scatter-mean / Langevin-kernel bandwidth measurements")
     ap.add_argument("--no-profile", action="store_true", help="do not record per-kernel HIP events in the timed region")
+    ap.add_argument("--dry-run", action="store_true", help="rank plumbing only (gloo, no kernels): used by the CPU test of the self-launch")
     args = ap.parse_args()
 
-    from jamun_amd import dist, native, synth
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(spawn_ranks(args.gpus))
+
+    import torch
+
+    from jamun_amd import dist
+
+    if args.dry_run:
+        rank, world = dist.init_process_group(backend="gloo")
+        t = torch.tensor([float(rank + 1)], dtype=torch.float64)
+        if world > 1:
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        if rank == 0:
+            print(json.dumps({"metric": "dry-run", "value": 0.0, "n_gpus": world, "ranks_seen": int(t.item()), "steps": args.steps, "warmup": args.warmup}), flush=True)
+        if world > 1:
+            torch.distributed.destroy_process_group()
+        return
+
+    from jamun_amd import native
     from jamun_amd.data import WalkerBatch
     from jamun_amd.model import Denoiser
+    from jamun_amd import synth
 
     rank, world = dist.init_process_group()
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch multi-GPU runs with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     assert torch.cuda.is_available(), "bench.py needs a GPU (jamun_amd has no CPU path)"
     dev = dist.local_device()
     torch.cuda.set_device(dev)
 
-    mol = synth.random_chain(args.atoms, seed=0)
-    batch = WalkerBatch.from_molecules([mol] * args.walkers).to(dev)
+    cfg = CONFIGS[args.config]
+    walkers = args.walkers if args.walkers is not None else cfg["walkers"]
+    mols = workload_molecules(args.config, walkers, args.atoms, rank)
+    batch = WalkerBatch.from_molecules(mols).to(dev)
     model = Denoiser.from_checkpoint_dict(synth.synthetic_checkpoint()).to(dev)
     smp = model.sampler_for(batch, SIGMA)
     n = batch.num_nodes
@@ -125,22 +296,39 @@ def main():
             smp.profile_enable(True, classes=["conv0", "conv1"])
         elif profile == "all":
             smp.profile_enable(True)
-        out = smp.walk("baoab", y, v, params, None, seed=1234 + rank, save_trajectory=True)
-        return out
+        return smp.walk("baoab", y, v, params, None, seed=1234 + rank, save_trajectory=True)
+
+    def timed(steps, profile):
+        torch.cuda.synchronize()
+        dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        out = walk(steps, profile)
+        torch.cuda.synchronize()
+        dist.barrier()
+        return time.perf_counter() - t0, out
 
     if args.warmup > 0:
         walk(args.warmup)
-    torch.cuda.synchronize()
-    dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
     # HIP events only around the dominant kernel inside the timed region (timing all 16 launches of a step costs ~4 %)
-    y_traj, score_traj, xhat_traj, xhat = walk(args.steps, profile=None if args.no_profile else "dominant")
-    torch.cuda.synchronize()
-    dist.barrier()
-    dt = time.perf_counter() - t0
+    prof_mode = None if args.no_profile else "dominant"
+    dts = []
+    dt, (y_traj, score_traj, xhat_traj, xhat) = timed(args.steps, prof_mode)
     assert xhat_traj.shape[0] == args.steps and torch.isfinite(xhat_traj).all()
-    prof = smp.profile_read() if not args.no_profile else None
+    dts.append(dt)
+    prof = smp.profile_read() if prof_mode else None  # events of the first repeat (the pool is re-armed per repeat)
+    reps = args.repeats if args.repeats > 0 else None
+    t_first = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        torch.distributed.all_reduce(t_first, op=torch.distributed.ReduceOp.MAX)
+    if reps is None:  # the same count on every rank: derived from the max-over-ranks time of the first repeat
+        reps = int(min(400, max(1, math.ceil(MIN_TIMED_S / max(float(t_first.item()), 1e-6)))))
+    for _ in range(reps - 1):
+        dt, _o = timed(args.steps, prof_mode)
+        dts.append(dt)
+        if prof_mode:
+            p2 = smp.profile_read()
+            prof = {k: (prof[k][0] + p2[k][0], prof[k][1] + p2[k][1]) for k in prof}
     smp.profile_enable(False)
     prof_all = None
     if prof is not None and rank == 0 and world == 1:
@@ -151,32 +339,42 @@ def main():
         smp.profile_enable(False)
     stats = smp.stats()
 
-    t = torch.tensor([dt], dtype=torch.float64, device=dev)
+    t = torch.tensor(dts, dtype=torch.float64, device=dev)
     if world > 1:
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-    dt_max = float(t.item())
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)  # per repeat: the slowest rank
+    per_rep = [float(x) for x in t.tolist()]
+    dt_med = statistics.median(per_rep)
+    tot_walkers = torch.tensor([batch.num_graphs], dtype=torch.int64, device=dev)
+    tot_atoms = torch.tensor([n], dtype=torch.int64, device=dev)
+    if world > 1:
+        torch.distributed.all_reduce(tot_walkers)
+        torch.distributed.all_reduce(tot_atoms)
 
     if rank == 0:
-        total_conf = args.walkers * world * args.steps
+        total_conf = int(tot_walkers.item()) * args.steps
+        sizes = sorted({int(m["pos"].shape[0]) for m in mols})
         out = {
-            "metric": "sampled conformations/sec (whole node), uncapped-2AA",
-            "value": total_conf / dt_max,
+            "metric": "sampled conformations/sec (whole node), uncapped-2AA" if args.config == "cfg2" else f"sampled conformations/sec (whole node), {args.config}",
+            "value": total_conf / dt_med,
             "unit": "conformations/s",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
-            "ms_per_step": 1e3 * dt_max / args.steps,
+            "ms_per_step": 1e3 * dt_med / args.steps,
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
+            "timed_repeats": len(per_rep),
+            "timed_total_s": sum(per_rep),
+            "ms_per_step_min_max": [1e3 * min(per_rep) / args.steps, 1e3 * max(per_rep) / args.steps],
             "config": {
-                "workload": f"BASELINE configs[1] shape: uncapped-2AA-like {args.atoms}-atom molecule, {args.walkers} walkers per GPU, "
-                            f"BAOAB walk-jump, sigma=delta=0.04, save_every_n_steps=1, default e3conv (1+5 ConvBlocks, 120x0e+32x1e); "
-                            f"fp32 (reference precision 32-true)",
-                "walkers_per_gpu": args.walkers,
-                "atoms_per_walker": args.atoms,
+                "workload": f"BASELINE {cfg['baseline']} shape ({args.config}): {cfg['desc']}, {walkers} walkers per GPU, BAOAB walk-jump, "
+                            f"sigma=delta=0.04, save_every_n_steps=1, default e3conv (1+5 ConvBlocks, 120x0e+32x1e); fp32 (reference precision 32-true)",
+                "walkers_per_gpu": walkers,
+                "atoms_per_walker": sizes[0] if len(sizes) == 1 else f"{sizes[0]}..{sizes[-1]} (ragged)",
+                "atoms_total": int(tot_atoms.item()),
                 "edges_per_forward": stats["n_edges"],
                 "mean_in_degree": stats["n_edges"] / n,
                 "parallelism": f"walkers sharded over {world} GPU(s), no data-path collective",
@@ -191,8 +389,8 @@ def main():
             flop = stats["conv0_flop_alg"] + (stats["conv1_flop_alg"] if fused else 0)
             ach = flop / (avg0 * 1e-3) / 1e12 if avg0 > 0 else 0.0
             out["roofline"] = {
-                "kernel": ("k_conv_fused (destination-grouped conv contraction of one hidden layer, scalar + vector rows)" if fused
-                           else "k_conv<RC=1,NT=5,NK=5> (scalar-output conv contraction, hidden layers)"),
+                "kernel": ("hidden-layer conv contraction, scalar + vector rows in one launch (destination-grouped; conv_path "
+                           f"{stats['conv_path']})" if fused else "k_conv<RC=1,NT=5,NK=5> (scalar-output conv contraction, hidden layers)"),
                 "bound": "mfma",
                 "achieved": ach,
                 "peak": F32_MFMA_PEAK_TFLOPS,
@@ -205,23 +403,28 @@ def main():
                 "flop_per_launch": flop,
                 "mfma_flop_executed_per_forward": stats["flop_executed"],  # all conv launches of one forward, padding included
             }
-            # HBM-side bytes per launch from the committed PMC passes of this same command (profiles/collect.sh); rocprofv3
+            # HBM-side bytes per launch from the committed PMC passes of the cfg2 command (profiles/collect.sh); rocprofv3
             # cannot run inside the timed process, so the newest committed summary is quoted, with its file name
-            tr = _pmc_traffic("k_conv_fused" if fused else "k_conv")
-            if tr is not None:
-                out["roofline"]["traffic"] = tr[0]
-                out["roofline"]["traffic_source"] = tr[1]
+            if args.config == "cfg2" and args.atoms is None and args.walkers is None:
+                tr = _pmc_traffic("k_conv")
+                if tr is not None:
+                    out["roofline"]["traffic"] = tr[0]
+                    out["roofline"]["traffic_source"] = tr[1]
             if prof_all is not None:  # separate untimed pass (see above)
                 tot = sum(ms for ms, _ in prof_all.values())
                 out["kernel_time_share"] = {k: round(ms / tot, 4) for k, (ms, _) in prof_all.items()} if tot > 0 else {}
                 out["kernel_avg_ms"] = {k: (ms / c if c else 0.0) for k, (ms, c) in prof_all.items()}
                 out["kernel_breakdown_source"] = f"separate untimed pass of {min(args.steps, 5)} steps with every launch bracketed by HIP events"
             # the reference-association FLOP rate, for comparison with SURVEY.md section 8(d) (not a roofline fraction)
-            out["config"]["ref_association_tflops_equiv"] = stats["flop_ref_assoc"] * args.steps / dt_max / 1e12
+            out["config"]["ref_association_tflops_equiv"] = stats["flop_ref_assoc"] * args.steps / dt_med / 1e12
+        if not args.no_secondary and world == 1:
+            del y_traj, score_traj, xhat_traj
+            out["secondary_rooflines"] = secondary_rooflines(dev)
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline()
+            out["cpu_baseline"] = cpu_baseline(args.config, cfg1_exact=not args.no_cfg1_cpu)
         print(json.dumps(out), flush=True)
     if world > 1:
+        torch.distributed.barrier()
         torch.distributed.destroy_process_group()
 
 

@@ -111,8 +111,11 @@ int jamun_score(jamun_sampler* s, const float* y_dev, float* score_dev, void* st
  *                 or NULL to draw them in-kernel from Philox4x32-10 keyed by (seed, iteration, atom)
  *   y_traj_dev, score_traj_dev, xhat_traj_dev  [T, n_atoms, 3] or NULL (save_trajectory=False);
  *                 T = jamun_num_frames(params, 0).  xhat_traj[t] = y_traj[t] + sigma^2 * score_traj[t]
- *                 (identical to the reference's extra forward per frame, in exact arithmetic)
- *   xhat_dev      [n_atoms,3] xhat(y_final) or NULL
+ *                 (identical to the reference's extra forward per frame, in exact arithmetic).
+ *                 With y_traj_dev == NULL (save_trajectory=False) a non-NULL score_traj_dev receives exactly ONE
+ *                 frame, the initial score — the reference appends later scores only together with y
+ *                 (_splitting.py:155,168-170) — so a [1, n_atoms, 3] buffer is enough and nothing past it is written.
+ *   xhat_dev     [n_atoms,3] xhat(y_final) or NULL
  * No host synchronisation; all steps are enqueued on `stream`. */
 int jamun_walk_baoab(jamun_sampler* s, float* y_dev, float* v_dev, const jamun_mcmc_params* p, const float* noise_dev,
                      uint64_t seed, float* y_traj_dev, float* score_traj_dev, float* xhat_traj_dev, float* xhat_dev,
@@ -155,6 +158,16 @@ int jamun_baoab_pre(float* y_dev, float* v_dev, const float* psi_dev, const floa
                     const jamun_mcmc_params* p, void* stream);
 int jamun_baoab_post(float* v_dev, float* psi_dev, const float* score_dev, int32_t n, const jamun_mcmc_params* p,
                      void* stream);
+
+/* One ABOBA iteration's state update around the score evaluation
+ * (src/jamun/sampling/mcmc/functional/_splitting.py:86-97):
+ *   a : y += (delta/2)*v                                              (:87, the score is then evaluated at this y)
+ *   b : psi = clip(score)*beta ; v += u*(delta/2)*psi ; vhat = exp(-gamma)*v + zeta*sqrt(u)*R ;
+ *       v = vhat + (delta/2)*psi (no u, :96) ; y += (delta/2)*v
+ * n = number of atoms; arrays are [n,3]. */
+int jamun_aboba_a(float* y_dev, const float* v_dev, int32_t n, const jamun_mcmc_params* p, void* stream);
+int jamun_aboba_b(float* y_dev, float* v_dev, const float* score_dev, const float* noise_dev, int32_t n,
+                  const jamun_mcmc_params* p, void* stream);
 
 /* Introspection for tests / benchmarks. */
 typedef struct jamun_stats {

@@ -100,6 +100,8 @@ SYMBOLS = {
     "jamun_scatter_mean": (C.c_int, [_P, _P, C.c_int32, C.c_int32, _P, _P]),
     "jamun_baoab_pre": (C.c_int, [_P, _P, _P, _P, C.c_int32, C.POINTER(jamun_mcmc_params), _P]),
     "jamun_baoab_post": (C.c_int, [_P, _P, _P, C.c_int32, C.POINTER(jamun_mcmc_params), _P]),
+    "jamun_aboba_a": (C.c_int, [_P, _P, C.c_int32, C.POINTER(jamun_mcmc_params), _P]),
+    "jamun_aboba_b": (C.c_int, [_P, _P, _P, _P, C.c_int32, C.POINTER(jamun_mcmc_params), _P]),
     "jamun_sampler_stats": (C.c_int, [_P, C.POINTER(jamun_stats), _P]),
     "jamun_profile_enable": (C.c_int, [_P, C.c_int32]),
     "jamun_profile_read": (C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(C.c_int64), _P]),
@@ -112,11 +114,29 @@ PROF_CLASSES = ["geom", "edge_h", "conv0_init", "conv1_init", "conv0", "conv1", 
 _lib: Optional[C.CDLL] = None
 
 
+def _check_fresh() -> None:
+    """Refuse to run a library that was built from other sources than the ones in the tree: ``csrc/build.py`` stamps the
+    binary with a digest of its sources and flags; after an edit the stamp no longer matches.  With ``hipcc`` at hand the
+    library is rebuilt (seconds); without it — or with ``JAMUN_NO_REBUILD=1`` — a stale binary is an error, never silently
+    used."""
+    from .csrc import build as b
+
+    stamp = LIB_PATH + ".sha256"
+    if not os.path.exists(LIB_PATH) or not os.path.exists(stamp):
+        return  # missing library: reported by load(); a library without a stamp was built by hand (explicit hipcc command)
+    if open(stamp).read().strip() == b._digest():
+        return
+    if os.environ.get("JAMUN_NO_REBUILD") or not os.path.exists(b.HIPCC):
+        raise RuntimeError(f"{LIB_PATH} is stale: its sources changed since it was built. Run `python jamun_amd/csrc/build.py`.")
+    b.build(verbose=False)
+
+
 def load() -> C.CDLL:
     """Load the HIP library or raise.  There is deliberately no fallback."""
     global _lib
     if _lib is not None:
         return _lib
+    _check_fresh()
     if not os.path.exists(LIB_PATH):
         raise RuntimeError(
             f"{LIB_PATH} not found: the HIP extension is not built. Run `python jamun_amd/csrc/build.py` "

@@ -1,11 +1,18 @@
-"""Sampler callbacks: trajectory writer and timing.
+"""Sampler callbacks: trajectory writer, metric dispatch and timing.
 
-``SaveTrajectoryCallback`` keeps the npy layout of the reference's ``SaveTrajectory`` metric
-(``/root/reference/src/jamun/metrics/_save_trajectory.py:17-30,78-97``, ``metrics/_utils.py:84-97``): under
-``sampler/<label>/predicted_samples/npy/`` one ``<chain>.npy`` of shape ``[n_atoms, frames, 3]`` per chain and
-``joined.npy`` ``[n_atoms, chains*frames, 3]``; samples are dispatched by ``dataset_label``
-(``callbacks/sampler/_utils.py:42-52``).  With several ranks the per-rank blocks are gathered to rank 0 once per batch
-(one collective, ``jamun_amd.dist.gather_ragged``) — what torchmetrics' ``dist_reduce_fx="cat"`` does in the reference.
+``SaveTrajectoryCallback`` writes the file set of the reference's ``SaveTrajectory`` metric
+(``/root/reference/src/jamun/metrics/_save_trajectory.py:17-30,53-56,78-97``, ``metrics/_utils.py:84-113``) under
+``sampler/<label>/``:
+
+    topology.pdb                                   first frame of the dataset            (on_sample_start)
+    predicted_samples/npy/<i>.npy   [n, T, 3] nm   one per chain                         (every batch)
+    predicted_samples/pdb/<i>.pdb, dcd/<i>.dcd     the same chain as PDB models / CHARMM DCD (Angstrom)
+    predicted_samples/{npy,pdb,dcd}/joined.*       all chains so far, frames concatenated: [n, chains*T, 3]
+
+``analysis/load_trajectory.py:88-107`` needs ``dcd/joined.dcd`` plus ``topology.pdb`` (or ``pdb/0.pdb``).  Samples are
+dispatched by ``dataset_label`` (``callbacks/sampler/_utils.py:42-52``) and validated against the dataset
+(``metrics/_utils.py:15-28``).  With several ranks the per-rank blocks are gathered to rank 0 once per batch and label
+(``jamun_amd.dist.gather_ragged``) — what torchmetrics' ``dist_reduce_fx="cat"`` does in the reference.
 """
 
 from __future__ import annotations
@@ -19,10 +26,27 @@ import numpy as np
 import torch
 
 from . import dist
+from .data import ATOM_TYPES
+
+
+def validate_sample(sample, dataset) -> None:
+    """``metrics/_utils.py:15-28``: the sample's label must be the dataset's and its atom types must be the topology's."""
+    label = sample["dataset_label"] if "dataset_label" in sample else None
+    if label != dataset.label():
+        raise ValueError(f"Sample dataset label {label} does not match expected label {dataset.label()}.")
+    mol = getattr(dataset, "molecule", None)
+    if mol is None or "atom_type_index" not in sample:
+        return
+    name = lambda i: ATOM_TYPES[i] if 0 <= i < len(ATOM_TYPES) else "?"
+    expected = [name(int(i)) for i in mol["atom_type_index"]]
+    actual = [name(int(i)) for i in sample["atom_type_index"]]
+    if expected != actual:
+        raise ValueError(f"Atom types in init_graph ({actual}) do not match expected atom types in structure ({expected}).")
 
 
 class SaveTrajectoryCallback:
-    def __init__(self, datasets: Sequence, sample_key: str = "xhat_traj", output_dir: str = "sampler", write_pdb: bool = True, **_):
+    def __init__(self, datasets: Sequence, sample_key: str = "xhat_traj", output_dir: str = "sampler", write_pdb: bool = True,
+                 write_dcd: bool = True, **_):
         labels = []
         self.datasets = {}
         for d in datasets:
@@ -33,6 +57,7 @@ class SaveTrajectoryCallback:
         self.sample_key = sample_key
         self.output_dir = output_dir
         self.write_pdb = write_pdb
+        self.write_dcd = write_dcd
         self.chains: Dict[str, List[np.ndarray]] = {l: [] for l in self.labels}  # per label: list of [n, T, 3]
         self.num_chains_seen = {l: 0 for l in self.labels}
 
@@ -41,47 +66,65 @@ class SaveTrajectoryCallback:
         os.makedirs(d, exist_ok=True)
         return d
 
+    def _mol(self, label: str) -> Optional[dict]:
+        mol = getattr(self.datasets[label], "molecule", None)
+        return mol if (mol is not None and "atom_names" in mol) else None
+
+    def filename_pred(self, label: str, trajectory_index, extension: str) -> str:
+        if extension not in ("npy", "pdb", "dcd"):
+            raise ValueError(f"Invalid extension: {extension}")
+        return os.path.join(self._dir(label, extension), f"{trajectory_index}.{extension}")
+
     def on_sample_start(self, sampler):
-        pass
+        if not sampler.is_global_zero:
+            return
+        from .pdb import save_pdb
+
+        for label in self.labels:
+            for ext in ("npy", "pdb", "dcd"):
+                self._dir(label, ext)
+            mol = self._mol(label)
+            if mol is not None and self.write_pdb:  # topology from the dataset's first frame (_save_trajectory.py:53-56)
+                save_pdb(os.path.join(self.output_dir, label, "topology.pdb"), mol, mol["pos"][None])
+
+    def _write_chain(self, label: str, index, arr: np.ndarray) -> None:
+        """arr [n, T, 3] nm -> <index>.npy / .pdb / .dcd"""
+        from .pdb import save_dcd, save_pdb
+
+        np.save(self.filename_pred(label, index, "npy"), arr)
+        frames = np.transpose(arr, (1, 0, 2))  # "atoms frames coords -> frames atoms coords" (utils/mdtraj.py:17-21)
+        mol = self._mol(label)
+        if self.write_pdb and mol is not None:
+            save_pdb(self.filename_pred(label, index, "pdb"), mol, frames)
+        if self.write_dcd:
+            save_dcd(self.filename_pred(label, index, "dcd"), frames)
 
     def on_after_sample_batch(self, sample: Sequence[dict], sampler):
+        for s in sample:
+            if s.get("dataset_label") not in self.datasets:
+                raise KeyError(f"sample dataset label {s.get('dataset_label')!r} has no dataset")
         for label in self.labels:
-            mine = [s[self.sample_key] for s in sample if s.get("dataset_label") == label]
-            unknown = [s.get("dataset_label") for s in sample if s.get("dataset_label") not in self.datasets]
-            if unknown:
-                raise KeyError(f"sample dataset label {unknown[0]!r} has no dataset")
-            if mine:
-                for m in mine:
-                    if m.ndim != 3:
-                        raise ValueError(f"Invalid sample shape: {tuple(m.shape)}, expected (num_atoms, num_frames, 3).")
-                block = torch.stack(mine)  # [chains_local, n, T, 3]
-            else:
-                n = self.datasets[label].molecule["pos"].shape[0]
-                block = torch.zeros(0, n, 1, 3, device=sampler.device)
-            gathered = dist.gather_ragged(block.contiguous(), dst=0)
+            mine = [s for s in sample if s.get("dataset_label") == label]
+            for s in mine:
+                validate_sample(s, self.datasets[label])
+                if s[self.sample_key].ndim != 3:
+                    raise ValueError(f"Invalid sample shape: {tuple(s[self.sample_key].shape)}, expected (num_atoms, num_frames, 3).")
+            # a rank without walkers of this label contributes nothing; gather_ragged agrees on the trailing shape first
+            block = torch.stack([s[self.sample_key] for s in mine]).contiguous() if mine else None  # [chains_local, n, T, 3]
+            gathered = dist.gather_ragged(block, dst=0, device=sampler.device)
             if gathered is None:
                 continue
             new = [c for g in gathered for c in g.detach().cpu().numpy()]
             start = len(self.chains[label])
             self.chains[label].extend(new)
             for i, arr in enumerate(new, start=start):
-                np.save(os.path.join(self._dir(label, "npy"), f"{i}.npy"), arr)
+                self._write_chain(label, i, arr)
             if self.chains[label]:
-                joined = np.concatenate(self.chains[label], axis=1)  # "b n t c -> n (b t) c"
-                np.save(os.path.join(self._dir(label, "npy"), "joined.npy"), joined)
+                self._write_chain(label, "joined", np.concatenate(self.chains[label], axis=1))  # "b n t c -> n (b t) c"
             self.num_chains_seen[label] = len(self.chains[label])
 
     def on_sample_end(self, sampler):
-        if not sampler.is_global_zero or not self.write_pdb:
-            return
-        from .pdb import write_pdb
-
-        for label in self.labels:
-            mol = getattr(self.datasets[label], "molecule", None)
-            if mol is None or "atom_names" not in mol or not self.chains[label]:
-                continue
-            joined = np.concatenate(self.chains[label], axis=1)
-            write_pdb(os.path.join(self._dir(label, "pdb"), "joined.pdb"), mol, torch.tensor(joined).permute(1, 0, 2))
+        pass  # the reference only uploads the joined files to wandb here (_save_trajectory.py:64-76): out of scope
 
 
 class TrajectoryMetricCallback:
@@ -96,6 +139,7 @@ class TrajectoryMetricCallback:
         unique = {}
         for d in datasets:
             unique.setdefault(d.label(), d)
+        self.datasets = unique
         self.meters = {label: metric_fn(dataset=unique[label]) for label in sorted(unique)}
 
     def on_sample_start(self, sampler):
@@ -106,6 +150,7 @@ class TrajectoryMetricCallback:
 
     def on_after_sample_batch(self, sample: Sequence, sampler):
         for sample_graph in sample:
+            validate_sample(sample_graph, self.datasets[sample_graph["dataset_label"]])  # TrajectoryMetric.update, metrics/_utils.py:64
             self.meters[sample_graph["dataset_label"]].update(sample_graph)
         for meter in self.meters.values():
             sampler.fabric.log_dict(meter.compute())

@@ -62,10 +62,50 @@ class _Inert:
     def __setstate__(self, state):
         self.__dict__["_state"] = state
 
+    # dict / list subclasses (e.g. Lightning's AttributeDict) are rebuilt item by item
+    def __setitem__(self, key, value):
+        self.__dict__.setdefault("_items", {})[key] = value
+
+    def append(self, value):
+        self.__dict__.setdefault("_list", []).append(value)
+
+    def extend(self, values):
+        self.__dict__.setdefault("_list", []).extend(values)
+
     def items(self):
-        st = self.__dict__.get("_state") or {}
-        content = st.get("_content", st) if isinstance(st, dict) else {}
-        return content.items() if isinstance(content, dict) else []
+        plain = to_plain(self)
+        return plain.items() if isinstance(plain, dict) else []
+
+
+def to_plain(obj):
+    """Plain Python data out of what the tolerant unpickler produced.  A Lightning checkpoint written under Hydra's default
+    ``_convert_="none"`` nests ``omegaconf.DictConfig`` / ``ListConfig`` objects in its hyper-parameters, whose pickled state
+    is ``{"_metadata", "_parent", "_content"}`` with ``_content`` a dict / list of NODE objects (``AnyNode``, ``IntegerNode``,
+    ...: state ``{"_metadata", "_parent", "_val"}``).  Containers become dicts / lists, value nodes their ``_val``;
+    ``functools.partial`` keeps its (possibly inert) callable and gets plain arguments; anything else is returned as is."""
+    import functools
+
+    if isinstance(obj, _Inert):
+        st = obj.__dict__.get("_state")
+        if isinstance(st, tuple) and len(st) == 2 and isinstance(st[0], dict):  # (dict state, slots state)
+            st = st[0]
+        if isinstance(st, dict):
+            if "_content" in st:
+                return to_plain(st["_content"])
+            if "_val" in st:
+                return to_plain(st["_val"])
+        if "_items" in obj.__dict__:
+            return to_plain(obj.__dict__["_items"])
+        if "_list" in obj.__dict__:
+            return to_plain(obj.__dict__["_list"])
+        return obj
+    if isinstance(obj, dict):
+        return {to_plain(k): to_plain(v) for k, v in obj.items()}
+    if isinstance(obj, (list, tuple)):
+        return type(obj)(to_plain(v) for v in obj)
+    if isinstance(obj, functools.partial):
+        return functools.partial(obj.func, *[to_plain(a) for a in obj.args], **{k: to_plain(v) for k, v in obj.keywords.items()})
+    return obj
 
 
 class _TolerantUnpickler(pickle.Unpickler):

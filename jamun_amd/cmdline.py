@@ -19,6 +19,7 @@ from typing import List, Optional, Sequence
 import torch
 
 from . import config as C
+from . import dist
 from .checkpoint import find_checkpoint
 from .data import WalkerBatch
 
@@ -29,7 +30,10 @@ def get_initial_graphs(datasets: Sequence, num_init_samples_per_dataset: int, re
     """``cmdline/sample.py:27-38``: per dataset ``randperm(len)[:k]`` frames, each repeated ``repeat`` times (consecutive)."""
     mols, labels = [], []
     for dataset in datasets:
-        random_indices = torch.randperm(len(dataset))[:num_init_samples_per_dataset]
+        random_indices = torch.randperm(len(dataset))[:num_init_samples_per_dataset].tolist()
+        # The reference draws this before any seed is set (sample.py:33 vs :86-88), so ranks may pick different frames.  Here
+        # rank 0's draw is used on every rank: with sharded walkers the shards must partition ONE initial batch.
+        random_indices = dist.broadcast_object(random_indices, src=0)
         for index in random_indices:
             g = dataset[int(index)]
             for _ in range(repeat):
@@ -99,8 +103,6 @@ def compose(argv: List[str], cwd: Optional[str] = None) -> dict:
 def main(argv: Optional[List[str]] = None):
     argv = list(sys.argv[1:] if argv is None else argv)
     logging.basicConfig(level=logging.INFO)
-    from . import dist
-
     dist.init_process_group()
     cwd = os.getcwd()
     cfg = compose(argv, cwd)

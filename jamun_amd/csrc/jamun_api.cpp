@@ -1238,7 +1238,9 @@ int jamun_walk_baoab(jamun_sampler* s, float* y, float* v, const jamun_mcmc_para
       const bool sv = saves(p, i);
       float* yf = (y_traj && sv) ? y_traj + fr * fy : nullptr;
       float* xf = (xhat_traj && sv) ? xhat_traj + fr * fy : nullptr;
-      float* sf = (score_traj && sv) ? score_traj + fr * fs : nullptr;
+      // scores after the initial one are kept only together with the trajectory (_splitting.py:168-170): without y_traj
+      // the caller's score_traj holds ONE frame
+      float* sf = (score_traj && y_traj && sv) ? score_traj + fr * fs : nullptr;
       launch_baoab_post(v, s->psi, s->score_buf, y, s->xhat_buf, n, k, /*update_v=*/1, yf, sf, xf, st);
       if (sv) { ++fy; ++fs; }
     }
@@ -1322,6 +1324,24 @@ int jamun_baoab_post(float* v, float* psi, const float* score, int32_t n, const 
     if (!v || !psi || !score || !p) throw Err(JAMUN_ERR_INVALID, "null argument");
     if (n == 0) return;
     launch_baoab_post(v, psi, score, nullptr, nullptr, n, make_consts(p), 1, nullptr, nullptr, nullptr, (hipStream_t)stream);
+    HIPCHECK(hipGetLastError());
+  });
+}
+
+int jamun_aboba_a(float* y, const float* v, int32_t n, const jamun_mcmc_params* p, void* stream) {
+  return guarded([&] {
+    if (!y || !v || !p) throw Err(JAMUN_ERR_INVALID, "null argument");
+    if (n == 0) return;
+    launch_aboba_a(y, v, n, make_consts(p).half_delta, (hipStream_t)stream);
+    HIPCHECK(hipGetLastError());
+  });
+}
+int jamun_aboba_b(float* y, float* v, const float* score, const float* noise, int32_t n, const jamun_mcmc_params* p,
+                  void* stream) {
+  return guarded([&] {
+    if (!y || !v || !score || !noise || !p) throw Err(JAMUN_ERR_INVALID, "null argument");
+    if (n == 0) return;
+    launch_aboba_b(y, v, score, noise, 0, 0, n, make_consts(p), nullptr, nullptr, (hipStream_t)stream);
     HIPCHECK(hipGetLastError());
   });
 }

@@ -2,7 +2,7 @@
 
 Walkers (graphs) are independent — no term of the path couples two graphs (``radius_graph`` is per batch segment,
 ``/root/reference/src/jamun/model/denoiser.py:140-149``) — so the data path needs NO collective.  The only exchange
-is the gather of per-rank trajectory blocks, which mirrors what torchmetrics' ``dist_reduce_fx="cat"`` does for the
+is the gather of per-rank trajectory blocks to rank 0, which mirrors what torchmetrics' ``dist_reduce_fx="cat"`` does for the
 reference's callbacks (``src/jamun/metrics/_utils.py:40``).  Backend "nccl" is RCCL on ROCm; "gloo" is used by the
 CPU tests.
 """
@@ -66,27 +66,70 @@ def shard_range_balanced(costs: List[int], rank: int, world: int) -> Tuple[int, 
     return bounds[rank], bounds[rank + 1]
 
 
-def gather_ragged(block: torch.Tensor, dst: int = 0, group=None) -> Optional[List[torch.Tensor]]:
-    """Gather per-rank blocks ``[n_rank, ...]`` with different leading sizes to ``dst`` (padded all-gather underneath).
+_MAX_NDIM = 8
 
-    Returns the list of un-padded blocks on ``dst`` and ``None`` elsewhere.  One collective per call — the only
-    communication of a sampling batch.
-    """
+
+def gather_ragged(block: Optional[torch.Tensor], dst: int = 0, group=None, device=None) -> Optional[List[torch.Tensor]]:
+    """Gather per-rank blocks ``[n_rank, ...]`` with different leading sizes to ``dst``.
+
+    A rank with nothing to contribute passes ``None`` (or a block with zero rows).  First every rank learns every rank's
+    shape (one small all-gather of int64 metadata), so all ranks agree on the trailing shape and on who sends; then each
+    non-empty rank sends exactly its rows to ``dst`` (batched point-to-point: no padding, nothing lands on the other ranks —
+    an all-gather would put every rank's block on every rank).  Returns the list of non-empty blocks in rank order on
+    ``dst`` and ``None`` elsewhere.  Mismatching trailing shapes raise on EVERY rank (before any payload moves), so no
+    rank is left waiting in a collective."""
     rank, world = rank_world()
     if world == 1:
-        return [block]
-    n = torch.tensor([block.shape[0]], dtype=torch.int64, device=block.device)
-    sizes = [torch.zeros_like(n) for _ in range(world)]
-    dist.all_gather(sizes, n, group=group)
-    sizes = [int(s.item()) for s in sizes]
-    nmax = max(sizes)
-    pad = torch.zeros((nmax,) + tuple(block.shape[1:]), dtype=block.dtype, device=block.device)
-    pad[: block.shape[0]] = block
-    out = [torch.empty_like(pad) for _ in range(world)]
-    dist.all_gather(out, pad, group=group)
+        return [block] if block is not None and block.shape[0] > 0 else []
+    if device is None:
+        device = block.device if block is not None else (local_device() if dist.get_backend(group) == "nccl" else torch.device("cpu"))
+    meta = torch.zeros(_MAX_NDIM + 2, dtype=torch.int64, device=device)
+    if block is not None and block.shape[0] > 0:
+        if block.ndim > _MAX_NDIM:
+            raise ValueError("gather_ragged: too many dimensions")
+        meta[0] = block.ndim
+        meta[1 : 1 + block.ndim] = torch.tensor(list(block.shape), dtype=torch.int64)
+        meta[-1] = {torch.float32: 0, torch.float64: 1, torch.int64: 2, torch.int32: 3}[block.dtype]
+    metas = [torch.zeros_like(meta) for _ in range(world)]
+    dist.all_gather(metas, meta, group=group)
+    shapes = []
+    for m in metas:
+        m = m.tolist()
+        shapes.append(tuple(m[1 : 1 + m[0]]) if m[0] > 0 else None)
+    trailing = {sh[1:] for sh in shapes if sh is not None}
+    dtypes = {int(m[-1]) for m, sh in zip(metas, shapes) if sh is not None}
+    if len(trailing) > 1 or len(dtypes) > 1:
+        raise ValueError(f"gather_ragged: ranks disagree on the block's trailing shape / dtype: {shapes}")
+    senders = [r for r, sh in enumerate(shapes) if sh is not None and r != dst]
+    ops, bufs = [], {}
+    if rank == dst:
+        dtype = [torch.float32, torch.float64, torch.int64, torch.int32][dtypes.pop()] if dtypes else torch.float32
+        for r in senders:
+            bufs[r] = torch.empty(shapes[r], dtype=dtype, device=device)
+            ops.append(dist.P2POp(dist.irecv, bufs[r], r, group))
+    elif rank in senders:
+        ops.append(dist.P2POp(dist.isend, block.contiguous(), dst, group))
+    if ops:
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
     if rank != dst:
         return None
-    return [o[:s] for o, s in zip(out, sizes)]
+    out = []
+    for r, sh in enumerate(shapes):
+        if sh is None:
+            continue
+        out.append(block if r == dst else bufs[r])
+    return out
+
+
+def broadcast_object(obj, src: int = 0):
+    """``obj`` of rank ``src`` on every rank (small Python objects: index lists)."""
+    rank, world = rank_world()
+    if world == 1 or not (dist.is_available() and dist.is_initialized()):
+        return obj
+    box = [obj if rank == src else None]
+    dist.broadcast_object_list(box, src=src, device=local_device() if dist.get_backend() == "nccl" else None)
+    return box[0]
 
 
 def barrier():

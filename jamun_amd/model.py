@@ -32,15 +32,20 @@ def strip_prefix(state_dict: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]
 
 
 def _kw(obj) -> dict:
-    """Keyword dict of a hyper-parameter entry: plain dict, functools.partial (Hydra ``_partial_``) or DictConfig-like."""
+    """Keyword dict of a hyper-parameter entry: plain dict, functools.partial (Hydra ``_partial_``) or DictConfig-like.
+    Values are plain Python data (ints, strs, lists, nested dicts / partials), also when the checkpoint carried omegaconf
+    containers that were unpickled without omegaconf (``checkpoint.to_plain``)."""
+    from .checkpoint import to_plain
+
+    obj = to_plain(obj)
     if isinstance(obj, functools.partial):
         return dict(obj.keywords)
     if isinstance(obj, dict):
         return dict(obj)
     if hasattr(obj, "keywords"):
-        return dict(obj.keywords)
+        return {k: to_plain(v) for k, v in dict(obj.keywords).items()}
     if hasattr(obj, "items"):
-        return dict(obj.items())
+        return {k: to_plain(v) for k, v in dict(obj.items()).items()}
     raise TypeError(f"cannot read hyper-parameters from {type(obj)}")
 
 
@@ -61,7 +66,9 @@ class Denoiser:
     # ---- construction ---------------------------------------------------------------------------------------
     @classmethod
     def from_checkpoint_dict(cls, ckpt: dict) -> "Denoiser":
-        hp = ckpt["hyper_parameters"]
+        from .checkpoint import to_plain
+
+        hp = to_plain(ckpt["hyper_parameters"])
         arch = _kw(hp["arch"])
         # the output-head / hidden-layer factories are fixed for the default architecture (e3conv.yaml:15-33); the
         # separable-convolution variant (e3conv_separable.yaml:14-19) has a different tensor product and is not built

@@ -306,3 +306,15 @@ def baoab_post(v, psi, score, params):
     lib = _lib.load()
     with torch.cuda.device(v.device):
         _lib.check(lib.jamun_baoab_post(_ptr(v), _ptr(psi), _ptr(score), v.shape[0], C.byref(params), _stream()))
+
+
+def aboba_a(y, v, params):
+    lib = _lib.load()
+    with torch.cuda.device(y.device):
+        _lib.check(lib.jamun_aboba_a(_ptr(y), _ptr(v), y.shape[0], C.byref(params), _stream()))
+
+
+def aboba_b(y, v, score, noise, params):
+    lib = _lib.load()
+    with torch.cuda.device(y.device):
+        _lib.check(lib.jamun_aboba_b(_ptr(y), _ptr(v), _ptr(score), _ptr(noise), y.shape[0], C.byref(params), _stream()))

@@ -52,6 +52,12 @@ def _element(line: str, name: str) -> str:
     return n[:1].upper() if n else "X"
 
 
+def _chain_indices(chain_ids: List[str]) -> List[int]:
+    """0-based index of each atom's chain, chains numbered in order of first appearance (mdtraj ``chain.index``)."""
+    order: Dict[str, int] = {}
+    return [order.setdefault(c, len(order)) for c in chain_ids]
+
+
 def read_pdb(path: str) -> dict:
     """First model of a PDB file -> molecule dict (heavy protein atoms only)."""
     atoms = []  # (serial, name, resname, chain, resseq+icode, x, y, z, element)
@@ -128,24 +134,77 @@ def read_pdb(path: str) -> dict:
         residues=[a[2] for a in atoms],
         elements=[a[8] for a in atoms],
         residue_ids=[int(a[4][:4]) for a in atoms],
+        chain_index=_chain_indices([a[3] for a in atoms]),
         all_atom_index=torch.tensor(kept, dtype=torch.long),
         n_all_atoms=n_records,
     )
 
 
-def write_pdb(path: str, mol: dict, frames: torch.Tensor) -> None:
-    """Multi-model PDB in Angstrom; columns as ``/root/reference/src/jamun/utils/mdtraj.py:26-60``.  ``frames`` is ``[T, n, 3]`` nm."""
-    frames = frames.detach().cpu().float() * 10.0
+def save_pdb(path: str, mol: dict, frames: torch.Tensor) -> None:
+    """Multi-model PDB in Angstrom, record for record what ``/root/reference/src/jamun/utils/mdtraj.py:26-60`` writes:
+    ``MODEL <frame index from 0>``, ATOM records (serial, name, residue name, chain index as one digit, residue index + 1,
+    coordinates x 10, element), a TER record, one CONECT record per atom listing its bonded partners, ``ENDMDL``; ``END``.
+    ``frames`` is ``[T, n, 3]`` in nanometres; ``mol`` is a molecule dict of ``read_pdb``."""
+    frames = frames.detach().cpu().float() if torch.is_tensor(frames) else torch.as_tensor(frames, dtype=torch.float32)
+    if frames.ndim == 2:
+        frames = frames[None]
+    n = frames.shape[1]
+    names, resn, els = mol["atom_names"], mol["residues"], mol["elements"]
+    res_idx = [int(i) for i in mol["residue_sequence_index"]]
+    chain = [int(c) for c in mol.get("chain_index", [0] * n)]
+    partners = [[i + 1] for i in range(n)]
+    seen = set()
+    for a, b in mol["bonds"].T.tolist():
+        if (a, b) not in seen:  # the reference de-duplicates (atom1, atom2) pairs
+            seen.add((a, b))
+            partners[a].append(b + 1)
+            partners[b].append(a + 1)
+    conect = "".join("CONECT" + "".join(f"{q:5d}" for q in ps) + "\n" for ps in partners)
     with open(path, "w") as f:
         for t in range(frames.shape[0]):
-            f.write(f"MODEL     {t + 1:4d}\n")
-            for i in range(frames.shape[1]):
-                name = mol["atom_names"][i]
-                name_f = f" {name:<3s}" if len(name) < 4 else name[:4]
-                x, y, z = frames[t, i].tolist()
-                f.write(f"ATOM  {i + 1:5d} {name_f} {mol['residues'][i]:>3s} A{mol['residue_ids'][i]:4d}    {x:8.3f}{y:8.3f}{z:8.3f}  1.00  0.00          {mol['elements'][i]:>2s}\n")
+            f.write(f"MODEL        {t}\n")
+            xyz = (frames[t] * 10).tolist()
+            for i in range(n):
+                x, y, z = xyz[i]
+                f.write(f"ATOM  {i + 1:5d} {names[i]:<4s} {resn[i]:3s} {chain[i]:1d}{res_idx[i] + 1:4d}    {x:8.3f}{y:8.3f}{z:8.3f}  1.00  0.00          {els[i]:>2s}\n")
+            f.write(f"TER   {n + 1:5d}      {resn[n - 1]:3s} {chain[n - 1]:1d}{res_idx[n - 1] + 1:4d}\n")
+            f.write(conect)
             f.write("ENDMDL\n")
         f.write("END\n")
+
+
+write_pdb = save_pdb  # older name
+
+
+def save_dcd(path: str, frames) -> None:
+    """CHARMM-format DCD (what mdtraj's ``Trajectory.save_dcd`` produces for a trajectory without a unit cell, called at
+    ``/root/reference/src/jamun/metrics/_save_trajectory.py:56,92,96``): little-endian Fortran records — an 84-byte ``CORD``
+    header (NSET frames, ISTART 0, NSAVC 1, DELTA 1.0 as float32, no unit cell, CHARMM version 24), a two-line title block,
+    the atom count, then per frame three float32 records X, Y, Z in Angstrom.  ``frames`` is ``[T, n, 3]`` in nanometres."""
+    import struct
+
+    import numpy as np
+
+    xyz = np.asarray(frames.detach().cpu() if torch.is_tensor(frames) else frames, dtype=np.float32)
+    if xyz.ndim != 3 or xyz.shape[2] != 3:
+        raise ValueError(f"expected [frames, atoms, 3], got {xyz.shape}")
+    nset, natom = xyz.shape[0], xyz.shape[1]
+    icntrl = [0] * 20
+    icntrl[0], icntrl[1], icntrl[2], icntrl[3] = nset, 0, 1, nset  # NSET, ISTART, NSAVC, NSTEP
+    icntrl[19] = 24
+    head = b"CORD" + struct.pack("<9i", *icntrl[:9]) + struct.pack("<f", 1.0) + struct.pack("<10i", *icntrl[10:])
+    assert len(head) == 84
+    titles = [b"Created by jamun_amd (DCD, CHARMM format)".ljust(80), b"REMARKS coordinates in Angstrom".ljust(80)]
+    with open(path, "wb") as f:
+        f.write(struct.pack("<i", 84) + head + struct.pack("<i", 84))
+        tb = struct.pack("<i", len(titles)) + b"".join(titles)
+        f.write(struct.pack("<i", len(tb)) + tb + struct.pack("<i", len(tb)))
+        f.write(struct.pack("<3i", 4, natom, 4))
+        rec = struct.pack("<i", 4 * natom)
+        ang = np.ascontiguousarray(np.transpose(xyz * np.float32(10.0), (0, 2, 1)))  # [T, 3, n]
+        for t in range(nset):
+            for c in range(3):
+                f.write(rec + ang[t, c].astype("<f4").tobytes() + rec)
 
 
 class PDBDataset:

@@ -99,14 +99,26 @@ def _run_walk(integrator: str, y: Tensor, score_fn: Callable, *, steps: int, v_i
 
 
 def _python_walk(integrator, y, v, score_fn, params, noise, seed, save_trajectory):
-    """Per-step loop for an arbitrary ``score_fn`` (BAOAB only): the state updates are still the HIP kernels."""
-    if integrator != "baoab":
-        raise NotImplementedError("ABOBA with a foreign score function is not supported; use the model's score")
+    """Per-step loop for an arbitrary ``score_fn``: the state updates are still the HIP kernels (``k_baoab_pre/post``,
+    ``k_aboba_a/b``) around a score evaluated by the caller — the form the integrator parity tests use."""
     if noise is None:
         g = torch.Generator(device=y.device).manual_seed(seed)
         noise = torch.randn((max(params.steps - 1, 0),) + tuple(y.shape), generator=g, device=y.device, dtype=torch.float32)
     saves = lambda i: (i % params.save_every_n_steps) == 0 and i >= params.burn_in_steps
-    y_traj = [y.clone()] if (save_trajectory and saves(0)) else ([] if save_trajectory else None)
+    y_traj = None
+    if save_trajectory:
+        y_traj = [y.clone()] if params.burn_in_steps <= 0 else []  # frame 0 is kept iff 0 >= burn_in (_splitting.py:70-72,138-140)
+    if integrator == "aboba":
+        score_traj = []
+        for i in range(1, params.steps):
+            native.aboba_a(y, v, params)
+            score = score_fn(y).to(torch.float32).contiguous()
+            native.aboba_b(y, v, score, noise[i - 1].contiguous(), params)
+            if y_traj is not None and saves(i):
+                y_traj.append(y.clone())
+                score_traj.append(score.clone())
+        # the reference stacks the score list unconditionally (:106-107): empty without a trajectory -> it raises
+        return (torch.stack(y_traj) if y_traj is not None else None), torch.stack(score_traj), {}
     psi = torch.empty_like(y)
     score = score_fn(y).to(torch.float32).contiguous()
     vv = torch.zeros_like(v)
@@ -387,8 +399,20 @@ class Sampler:
         model.to(self.device)
         model.eval()
         if self.shard_walkers and self.world_size > 1:
-            lo, hi = dist.shard_range(init_graphs.num_graphs, self.rank, self.world_size)
+            # contiguous blocks of walkers, balanced by modelled cost = atoms x capped in-degree: equal
+            # walkers give the even split, ragged batches (MDGen-4AA-like) are cut where the work is
+            ptr = init_graphs.ptr.tolist()
+            sizes = [ptr[w + 1] - ptr[w] for w in range(init_graphs.num_graphs)]
+            lo, hi = dist.shard_range_balanced([n * (min(n - 1, 32) + 2) for n in sizes], self.rank, self.world_size)
             init_graphs = init_graphs.slice_graphs(lo, hi)
+        if init_graphs.num_graphs == 0:
+            # more ranks than walkers: this rank has nothing to walk but still takes part in every callback's collectives
+            self.call("on_sample_start", sampler=self)
+            for batch_idx in range(num_batches):
+                self.global_step = batch_idx
+                self.call("on_after_sample_batch", sample=[], sampler=self)
+            self.call("on_sample_end", sampler=self)
+            return
         init_graphs = init_graphs.to(self.device)
         model_wrapped = ModelSamplingWrapper(model=model, init_graphs=init_graphs, sigma=batch_sampler.sigma, rng=self.rng)
         if hasattr(batch_sampler.mcmc, "rng"):

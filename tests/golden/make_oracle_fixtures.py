@@ -25,7 +25,10 @@ SIGMA = 0.04
 MCMC = dict(delta=0.04, friction=1.0, M=1.0, inverse_temperature=1.0, score_fn_clip=100.0, save_trajectory=True)
 # "strong": O(1) activations, stresses kernel numerics in one forward.  "stable": small output gain, contractive
 # dynamics, so that fp32 rounding differences are not amplified exponentially along a trajectory.
-GAINS = {"strong": 0.5, "stable": 0.05}
+# Measured (tests/test_oracle.py::test_fp32_oracle_leaves_fp64_trajectory, AG x 4, 50 steps): gains 0.05 and 0.1 are contractive
+# (fp32 vs fp64 oracle stay at 2e-8 .. 7e-8 nm for all 50 frames); 0.2 and 0.5 are chaotic (1.5e-5 / 5.8e-5 nm at step 21,
+# 5e-2 / 2e-1 nm at step 49).
+GAINS = {"strong": 0.5, "stable": 0.05, "mid": 0.1, "g02": 0.2}
 
 
 def molecules(kind):
@@ -37,6 +40,12 @@ def molecules(kind):
         return [synth.random_chain(n, seed=s) for s, n in enumerate([5, 17, 33, 9, 57, 2, 1, 29])]
     if kind == "dense70":
         return [synth.random_chain(70, seed=3, bond=0.12, min_dist=0.13)] * 2
+    # BASELINE configs[4] sizes: chignolin with hydrogens (~166 atoms) and H-stripped as the reference feeds it to the model
+    # (93 heavy atoms, src/jamun/data/_mdtraj.py:60,218).  44 % / 8 % of the atoms hit torch_cluster's 32-neighbour cap.
+    if kind == "chig93x2":
+        return [synth.random_chain(93, seed=5)] * 2
+    if kind == "chig166x2":
+        return [synth.random_chain(166, seed=5)] * 2
     raise KeyError(kind)
 
 
@@ -89,6 +98,11 @@ CASES = {
     "oracle_forward_chain17x6": lambda **kw: forward_case("chain17x6", True),
     "oracle_forward_ragged": lambda **kw: forward_case("ragged", False),
     "oracle_forward_dense70": lambda **kw: forward_case("dense70", False),
+    "oracle_forward_chig93x2": lambda **kw: forward_case("chig93x2", False),
+    "oracle_forward_chig166x2": lambda **kw: forward_case("chig166x2", False),
+    "oracle_walk_baoab_chig93_6": lambda max_steps=None, **kw: walk_case("chig93x2", "baoab", 6, "stable", max_steps),
+    "oracle_walk_baoab_ag4_50_mid": lambda max_steps=None, **kw: walk_case("ag4", "baoab", 50, "mid", max_steps),
+    "oracle_walk_baoab_ag4_50_g02": lambda max_steps=None, **kw: walk_case("ag4", "baoab", 50, "g02", max_steps),
     "oracle_walk_baoab_ag4_50": lambda max_steps=None, **kw: walk_case("ag4", "baoab", 50, "stable", max_steps),
     "oracle_walk_baoab_ag4_20_strong": lambda max_steps=None, **kw: walk_case("ag4", "baoab", 20, "strong", max_steps),
     "oracle_walk_baoab_ragged_12": lambda max_steps=None, **kw: walk_case("ragged", "baoab", 12, "stable", max_steps),
@@ -99,7 +113,10 @@ CASES = {
 
 
 def main():
+    only = set(sys.argv[1:])
     for name, fn in CASES.items():
+        if only and name not in only:
+            continue
         out = fn()
         np.savez_compressed(os.path.join(HERE, name + ".npz"), **{k: v.numpy() for k, v in out.items()})
         print(name, {k: tuple(v.shape) for k, v in out.items()}, flush=True)

@@ -348,3 +348,293 @@ def test_w3j_buffers_cross_check():
         f({pre + "_w3j_1_1_1": eps.permute(1, 0, 2) * 0.5})
     with pytest.raises(ValueError):
         f({pre + "_w3j_1_0_1": torch.eye(3)})
+
+
+def _read_dcd(path):
+    """Independent minimal reader of the CHARMM DCD layout (Fortran records, little endian): returns [frames, atoms, 3] A."""
+    import struct
+
+    b = open(path, "rb").read()
+    o = 0
+
+    def rec():
+        nonlocal o
+        n = struct.unpack_from("<i", b, o)[0]
+        body = b[o + 4 : o + 4 + n]
+        assert struct.unpack_from("<i", b, o + 4 + n)[0] == n, "record length markers disagree"
+        o += n + 8
+        return body
+
+    head = rec()
+    assert len(head) == 84 and head[:4] == b"CORD"
+    ic = struct.unpack("<20i", head[4:])
+    nset, has_cell, version = ic[0], ic[10], ic[19]
+    assert version == 24 and has_cell == 0 and ic[2] == 1
+    title = rec()
+    assert struct.unpack_from("<i", title)[0] * 80 + 4 == len(title)
+    natom = struct.unpack("<i", rec())[0]
+    frames = np.zeros((nset, natom, 3), dtype=np.float32)
+    for t in range(nset):
+        for c in range(3):
+            frames[t, :, c] = np.frombuffer(rec(), dtype="<f4")
+    assert o == len(b)
+    return frames
+
+
+def test_save_trajectory_writes_reference_file_set(tmp_path):
+    """metrics/_save_trajectory.py:17-30,53-56,78-97: topology.pdb, <i>.npy/.pdb/.dcd per chain, joined.npy/.pdb/.dcd — and
+    what analysis/load_trajectory.py:88-107 needs (dcd/joined.dcd + topology.pdb).  DCD parsed back by an independent reader."""
+    from jamun_amd import pdb, synth
+    from jamun_amd.callbacks import SaveTrajectoryCallback
+    from jamun_amd.sampling import SampleGraph
+
+    mol = dict(synth.ag_dipeptide(), elements=["N", "C", "C", "C", "O", "N", "C", "C", "O", "O"], residue_ids=[1] * 5 + [2] * 5)
+    src = str(tmp_path / "uncapped_AG.pdb")
+    pdb.save_pdb(src, mol, mol["pos"][None])
+    ds = pdb.create_dataset_from_pdbs([src])
+
+    class FakeSampler:
+        device = torch.device("cpu"); is_global_zero = True; world_size = 1; global_step = 0
+
+    out = str(tmp_path / "sampler")
+    cb = SaveTrajectoryCallback(ds, output_dir=out)
+    cb.on_sample_start(FakeSampler())
+    torch.manual_seed(0)
+    T = 5
+    base = ds[0].molecule
+    mk = lambda w: SampleGraph(dataset_label="uncapped_AG", atom_type_index=base["atom_type_index"],
+                               xhat_traj=base["pos"][:, None, :] + 0.01 * torch.randn(10, T, 3) + w)
+    batch0, batch1 = [mk(0), mk(1), mk(2)], [mk(3), mk(4), mk(5)]
+    cb.on_after_sample_batch(batch0, FakeSampler())
+    cb.on_after_sample_batch(batch1, FakeSampler())
+    cb.on_sample_end(FakeSampler())
+    root = os.path.join(out, "uncapped_AG")
+    have = sorted(os.path.relpath(os.path.join(dp, f), root) for dp, _, fs in os.walk(root) for f in fs)
+    want = ["topology.pdb"] + [f"predicted_samples/{e}/{i}.{e}" for e in ("dcd", "npy", "pdb") for i in list(range(6)) + ["joined"]]
+    assert have == sorted(want)
+    # DCD: Angstrom, frames x atoms; joined = chains' frames concatenated in chain order
+    d3 = _read_dcd(os.path.join(root, "predicted_samples/dcd/3.dcd"))
+    assert d3.shape == (T, 10, 3)
+    assert np.allclose(d3, 10.0 * batch1[0]["xhat_traj"].permute(1, 0, 2).numpy(), atol=1e-5)
+    dj = _read_dcd(os.path.join(root, "predicted_samples/dcd/joined.dcd"))
+    nj = np.load(os.path.join(root, "predicted_samples/npy/joined.npy"))
+    assert dj.shape == (6 * T, 10, 3) and nj.shape == (10, 6 * T, 3)
+    assert np.allclose(dj, 10.0 * np.transpose(nj, (1, 0, 2)), atol=1e-5)
+    assert np.array_equal(nj[:, 2 * T : 3 * T], batch0[2]["xhat_traj"].numpy())
+    # PDB: the reference's record layout (utils/mdtraj.py:26-60), readable back as the same molecule
+    txt = open(os.path.join(root, "predicted_samples/pdb/0.pdb")).read().splitlines()
+    assert txt[0] == "MODEL        0" and txt[-1] == "END" and sum(l.startswith("MODEL") for l in txt) == T
+    assert txt[1].startswith("ATOM      1 N    ALA 0   1    ") and txt[1].endswith(" N")
+    assert sum(l.startswith("CONECT") for l in txt) == 10 * T and txt[11].startswith("TER      11      GLY 0   2")
+    topo = pdb.read_pdb(os.path.join(root, "topology.pdb"))
+    assert torch.equal(topo["atom_type_index"], base["atom_type_index"]) and topo["bonds"].shape[1] == 9
+    assert torch.allclose(topo["pos"], base["pos"], atol=1e-4)
+    # validate_sample (metrics/_utils.py:15-28): wrong atom types / unknown label are refused
+    bad = mk(0)
+    bad["atom_type_index"] = torch.zeros(10, dtype=torch.int32)
+    with pytest.raises(ValueError, match="Atom types"):
+        cb.on_after_sample_batch([bad], FakeSampler())
+    with pytest.raises(KeyError):
+        cb.on_after_sample_batch([SampleGraph(dataset_label="other", xhat_traj=torch.zeros(10, T, 3))], FakeSampler())
+
+
+_WORKER2 = r'''
+import os, sys, json
+sys.path.insert(0, sys.argv[1])
+import numpy as np, torch
+from jamun_amd import dist, synth
+from jamun_amd.callbacks import SaveTrajectoryCallback
+from jamun_amd.data import WalkerBatch
+from jamun_amd.sampling import Sampler
+rank, world = dist.init_process_group("gloo")
+assert world == 2
+# ---- (1) gather with a rank that owns NO walker of a label: rank 1 contributes nothing for label "a"
+got = dist.gather_ragged(torch.full((2, 3, 4, 3), 5.0) if rank == 0 else None, dst=0, device=torch.device("cpu"))
+assert (got is None) if rank else ([tuple(g.shape) for g in got] == [(2, 3, 4, 3)])
+got = dist.gather_ragged(None, dst=0, device=torch.device("cpu"))  # nobody has anything
+assert (got is None) if rank else (got == [])
+try:  # trailing shapes that disagree raise on EVERY rank, before any payload moves
+    dist.gather_ragged(torch.zeros(1, 3 + rank), dst=0)
+    raise SystemExit("expected ValueError")
+except ValueError:
+    pass
+# ---- (2) Sampler.sample(shard_walkers=True) end to end with a stub model / batch sampler, two dataset labels, ragged sizes
+mol_a, mol_b = synth.random_chain(6, seed=0), synth.random_chain(9, seed=1)
+class DS:
+    def __init__(self, mol, label): self.molecule, self._l = dict(mol), label
+    def label(self): return self._l
+# walkers: a a a b b   -> the contiguous split balanced by cost (42 42 42 90 90) puts [a a a b] on rank 0 and [b] on rank 1:
+# rank 1 has no walker of label "a"
+batch = WalkerBatch.from_molecules([mol_a] * 3 + [mol_b] * 2, labels=["a"] * 3 + ["b"] * 2)
+class StubModel:
+    device = torch.device("cpu")
+    def to(self, d): return self
+    def eval(self): return self
+class StubBatchSampler:
+    sigma = 0.04
+    mcmc = type("M", (), {"rng": "philox"})()
+    def sample(self, model, y_init, v_init):
+        T = 3
+        r = torch.randn(1)  # rank-dependent stream (seed + rank)
+        walker_id = torch.repeat_interleave(torch.arange(model.init_graphs.num_graphs), model.init_graphs.ptr.diff())
+        xt = torch.zeros(T, y_init.shape[0], 3) + walker_id[None, :, None].float() + 100.0 * rank
+        return {"xhat": y_init, "y": y_init, "v": torch.zeros_like(y_init), "sample": y_init, "xhat_traj": xt, "y_traj": xt.clone(),
+                "score_traj": xt.clone(), "t_traj": torch.ones(T), "_draw": r}
+out_dir = os.path.join(sys.argv[2], "sampler")
+cb = SaveTrajectoryCallback([DS(mol_a, "a"), DS(mol_b, "b")], output_dir=out_dir, write_pdb=False)
+sampler = Sampler(callbacks=[cb], shard_walkers=True)
+torch.manual_seed(42 + sampler.fabric.global_rank)
+sampler.sample(model=StubModel(), batch_sampler=StubBatchSampler(), num_batches=2, init_graphs=batch, continue_chain=True)
+dist.barrier()
+if rank == 0:
+    a = os.path.join(out_dir, "a", "predicted_samples", "npy"); b = os.path.join(out_dir, "b", "predicted_samples", "npy")
+    ja, jb = np.load(os.path.join(a, "joined.npy")), np.load(os.path.join(b, "joined.npy"))
+    assert ja.shape == (6, 2 * 3 * 3, 3) and jb.shape == (9, 2 * 2 * 3, 3), (ja.shape, jb.shape)
+    # global walker order within a label, per batch: rank 0's walkers first (local ids 0..2 are "a", 3 is "b"), then rank 1's
+    # (its only walker, local id 0, marked + 100)
+    assert [float(np.load(os.path.join(a, f"{i}.npy"))[0, 0, 0]) for i in range(6)] == [0, 1, 2, 0, 1, 2]
+    assert [float(np.load(os.path.join(b, f"{i}.npy"))[0, 0, 0]) for i in range(4)] == [3, 100, 3, 100]
+    assert os.path.exists(os.path.join(out_dir, "b", "predicted_samples", "dcd", "joined.dcd"))
+# ---- (3) more ranks than walkers: the empty rank still takes part in the collectives
+one = WalkerBatch.from_molecules([mol_a], labels=["a"])
+cb2 = SaveTrajectoryCallback([DS(mol_a, "a")], output_dir=os.path.join(sys.argv[2], "sampler1"), write_pdb=False)
+s2 = Sampler(callbacks=[cb2], shard_walkers=True)
+s2.sample(model=StubModel(), batch_sampler=StubBatchSampler(), num_batches=1, init_graphs=one)
+dist.barrier()
+if rank == 0:
+    assert np.load(os.path.join(sys.argv[2], "sampler1", "a", "predicted_samples", "npy", "joined.npy")).shape == (6, 3, 3)
+print(json.dumps({"rank": rank, "ok": True}))
+torch.distributed.destroy_process_group()
+'''
+
+
+def test_two_process_gloo_sharded_sampler_two_labels(tmp_path):
+    """Sampler.sample(shard_walkers=True) on 2 gloo ranks through to the written files: a rank that owns no walker of a
+    label, balanced ragged sharding, global walker order, seed + rank, and a rank with an empty shard."""
+    script = tmp_path / "worker2.py"
+    script.write_text(_WORKER2)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29541", WORLD_SIZE="2")
+    procs = [subprocess.Popen([sys.executable, str(script), ROOT, str(tmp_path)], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)),
+                              stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=240) for p in procs]
+    for p, (o, e) in zip(procs, outs):
+        assert p.returncode == 0, e[-3000:]
+        assert json.loads(o.strip().splitlines()[-1])["ok"]
+
+
+def test_bench_self_launches_ranks(tmp_path):
+    """`python bench.py --gpus 2` without a launcher spawns the two ranks itself (before any GPU call) and relays ONE JSON
+    line from rank 0; --dry-run keeps the rank plumbing (gloo) and skips the kernels."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1", "--dry-run"],
+                       env=env, capture_output=True, text=True, timeout=240)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["ranks_seen"] == 2 and d["steps"] == 4
+    # under a launcher (WORLD_SIZE set) the script must NOT spawn again: a single rank with WORLD_SIZE=1 just runs
+    r1 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--dry-run"], env=dict(env, WORLD_SIZE="1", RANK="0"),
+                        capture_output=True, text=True, timeout=240)
+    assert r1.returncode == 0 and json.loads([l for l in r1.stdout.splitlines() if l.startswith("{")][-1])["n_gpus"] == 1
+
+
+def test_unpickler_reads_omegaconf_shaped_hparams(tmp_path):
+    """A real JAMUN checkpoint nests omegaconf containers and partials of classes from modules that are not installed here
+    (SURVEY.md section 5, "Checkpoint format").  Build that shape with stand-in modules, save, REMOVE the modules, load."""
+    import functools
+    import types
+
+    from jamun_amd import synth
+    from jamun_amd.checkpoint import load_checkpoint_file
+    from jamun_amd.model import Denoiser, _kw
+
+    def module(name, **classes):
+        m = types.ModuleType(name)
+        for cname, cls in classes.items():
+            cls.__module__, cls.__qualname__ = name, cname
+            setattr(m, cname, cls)
+        sys.modules[name] = m
+        return m
+
+    class Metadata:
+        def __init__(self, **kw): self.__dict__.update(kw)
+
+    class AnyNode:  # omegaconf value node: pickled state {_metadata, _parent, _val}
+        def __init__(self, val, parent=None): self._metadata, self._parent, self._val = Metadata(optional=True), parent, val
+
+    class DictConfig:  # container: {_metadata, _parent, _content: {key: node}} with back references to the parent
+        def __init__(self, content, parent=None):
+            self._metadata, self._parent, self._content = Metadata(key_type=str), parent, {}
+            for k, v in content.items():
+                self._content[k] = v if isinstance(v, (DictConfig, ListConfig)) else AnyNode(v, self)
+                self._content[k]._parent = self
+
+    class ListConfig:
+        def __init__(self, content, parent=None):
+            self._metadata, self._parent = Metadata(element_type=str), parent
+            self._content = [AnyNode(v, self) for v in content]
+
+    class AttributeDict(dict): pass
+    class E3Conv: pass
+    class ConvBlock: pass
+    class Conv: pass
+    class EquivariantMLP: pass
+    class ConstantSigma:
+        def __init__(self, sigma): self.sigma = sigma
+    class Adam: pass
+
+    names = ["omegaconf", "omegaconf.dictconfig", "omegaconf.listconfig", "omegaconf.nodes", "omegaconf.base", "jamun", "jamun.model", "jamun.model.arch",
+             "jamun.model.arch.e3conv", "jamun.e3tools", "jamun.e3tools.nn", "jamun.e3tools.nn._conv", "jamun.e3tools.nn._mlp", "jamun.distributions",
+             "jamun.distributions._distributions", "lightning_fake", "lightning_fake.fabric", "lightning_fake.fabric.utilities", "lightning_fake.fabric.utilities.data",
+             "torch_fake_optim"]
+    saved = {n: sys.modules.get(n) for n in names}
+    try:
+        for n in names:
+            module(n)
+        module("omegaconf.dictconfig", DictConfig=DictConfig)
+        module("omegaconf.listconfig", ListConfig=ListConfig)
+        module("omegaconf.nodes", AnyNode=AnyNode)
+        module("omegaconf.base", Metadata=Metadata)
+        module("jamun.model.arch.e3conv", E3Conv=E3Conv)
+        module("jamun.e3tools.nn._conv", ConvBlock=ConvBlock, Conv=Conv)
+        module("jamun.e3tools.nn._mlp", EquivariantMLP=EquivariantMLP)
+        module("jamun.distributions._distributions", ConstantSigma=ConstantSigma)
+        module("lightning_fake.fabric.utilities.data", AttributeDict=AttributeDict)
+        module("torch_fake_optim", Adam=Adam)
+        base = synth.synthetic_checkpoint(prefix="g._orig_mod.")
+        a = base["hyper_parameters"]["arch"]
+        arch = functools.partial(
+            E3Conv, irreps_out=a["irreps_out"], irreps_hidden=a["irreps_hidden"], irreps_sh=a["irreps_sh"], n_layers=a["n_layers"],
+            edge_attr_dim=a["edge_attr_dim"], atom_type_embedding_dim=8, atom_code_embedding_dim=8, residue_code_embedding_dim=32,
+            residue_index_embedding_dim=8, use_residue_information=True, use_residue_sequence_index=False,
+            hidden_layer_factory=functools.partial(ConvBlock, conv=functools.partial(Conv)),
+            output_head_factory=functools.partial(EquivariantMLP, irreps_hidden_list=ListConfig([a["irreps_hidden"]])),
+        )
+        hp = AttributeDict(base["hyper_parameters"])
+        hp.update(arch=arch, optim=functools.partial(Adam, lr=0.002), sigma_distribution=ConstantSigma(0.04),
+                  torch_compile_kwargs=DictConfig({"fullgraph": True, "dynamic": True, "mode": "default", "nested": DictConfig({"k": 3})}),
+                  use_torch_compile=True)
+        path = str(tmp_path / "last.ckpt")
+        torch.save({"state_dict": base["state_dict"], "hyper_parameters": hp, "pytorch-lightning_version": "2.4.0", "epoch": 7}, path)
+    finally:
+        for n, m in saved.items():
+            if m is None:
+                sys.modules.pop(n, None)
+            else:
+                sys.modules[n] = m
+    assert "omegaconf" not in sys.modules or not hasattr(sys.modules["omegaconf"], "dictconfig")
+    ck = load_checkpoint_file(path)
+    from jamun_amd.checkpoint import to_plain
+
+    hp2 = to_plain(ck["hyper_parameters"])
+    assert isinstance(hp2, dict) and hp2["max_radius"] == base["hyper_parameters"]["max_radius"]
+    kw = _kw(hp2["arch"])
+    assert kw["n_layers"] == 5 and isinstance(kw["n_layers"], int) and kw["irreps_hidden"] == "120x0e + 32x1e"
+    head = _kw(kw["output_head_factory"])
+    assert head["irreps_hidden_list"] == ["120x0e + 32x1e"] and all(type(x) is str for x in head["irreps_hidden_list"])
+    assert _kw(hp2["torch_compile_kwargs"]) == {"fullgraph": True, "dynamic": True, "mode": "default", "nested": {"k": 3}}
+    conv = _kw(kw["hidden_layer_factory"])["conv"]
+    assert isinstance(conv, functools.partial) and conv.func.__name__ == "Conv"
+    model = Denoiser.load_from_checkpoint(path)  # the whole way: hparams -> arch dict -> native model handle
+    assert model.arch["n_layers"] == 5 and model.max_radius == base["hyper_parameters"]["max_radius"]

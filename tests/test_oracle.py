@@ -204,6 +204,7 @@ def test_cached_oracle_fixtures_are_fresh(golden_dir):
     for name, kw, keys in [
         ("oracle_forward_ag4", {}, ["xhat", "score", "x3", "deg"]),
         ("oracle_walk_baoab_ag4_50", {"max_steps": 3}, ["xhat_traj", "y_traj"]),
+        ("oracle_walk_baoab_ag4_50_mid", {"max_steps": 3}, ["xhat_traj", "y_traj"]),
         ("oracle_walk_aboba_ag4_20", {"max_steps": 3}, ["xhat_traj", "y_traj"]),
         ("oracle_sampler_cc0", {"max_batches": 1}, ["xhat_traj_0"]),
     ]:
@@ -213,3 +214,39 @@ def test_cached_oracle_fixtures_are_fresh(golden_dir):
             c = torch.tensor(cached[k])
             f = fresh[k]
             assert torch.equal(f, c[: f.shape[0]] if f.shape != c.shape else c), (name, k)
+
+
+def test_fp32_oracle_leaves_fp64_trajectory():
+    """Evidence for the trajectory tolerances of tests/test_gpu_parity.py: the walk is a dynamical
+    system, and with the strongly non-linear random checkpoint (output gain 0.5) it amplifies fp32 rounding — the fp32
+    ORACLE itself leaves the fp64 oracle's trajectory exponentially (about x4 per 5 steps), crossing the 1e-5 nm bar within
+    ~20 steps (gain 0.2 behaves the same: 1.5e-5 nm at step 21), so no fp32 implementation can be held to 1e-5 nm at step 50
+    there.  With the contractive checkpoints (gains 0.05 and 0.1, used for the 50-step BASELINE configs[0] walks) the same
+    comparison stays at 2e-8 .. 7e-8 nm for all 50 frames, which is why the whole-trajectory parity tests use those and the
+    chaotic ones are held to the bar on their first frames only."""
+    mols = [synth.ag_dipeptide()] * 4
+    topo = og.collate([{k: v for k, v in m.items() if torch.is_tensor(v)} for m in mols])
+    hp = od.default_hparams()
+    sigma, steps = 0.04, 26
+    noise = torch.randn(steps + 1, topo["pos"].shape[0], 3, generator=torch.Generator().manual_seed(42))
+    kw = dict(steps=steps, delta=0.04, friction=1.0, M=1.0, inverse_temperature=1.0, score_fn_clip=100.0, save_trajectory=True)
+
+    def drift(gain):
+        sd = synth.synthetic_state_dict(output_gain=gain)
+        res = {}
+        for name, dt in (("f32", torch.float32), ("f64", torch.float64)):
+            p = {k: v.to(dt) for k, v in sd.items()}
+            rec = ow.RecordedNoise(noise)
+            pos = topo["pos"].to(dt)
+            y0 = pos + rec(pos) * sigma
+            _, _, y_traj, score_traj = ow.baoab(y0, lambda y: od.score(y, topo, sigma, p, hp), noise=rec, v_init="gaussian", **kw)
+            res[name] = y_traj + sigma**2 * score_traj  # xhat of every frame
+        return ((res["f32"].double() - res["f64"]) ** 2).sum(-1).mean(-1).sqrt()  # RMSD per frame, nm
+
+    strong = drift(0.5)
+    assert strong[:4].max() < 1e-6                                   # one forward: rounding level (1e-7)
+    assert strong[25] > 1e-5                                         # ... but past the parity bar within 25 steps
+    growth = (strong[25] / strong[5]).item() ** (1 / 4)               # per 5 steps, over steps 5 -> 25
+    assert 2.0 < growth < 8.0, growth
+    mid = drift(0.1)
+    assert mid.max() < 1e-6, mid.max()                                # contractive: stays at rounding level (measured 7e-8)
