@@ -1,13 +1,16 @@
 # Collects the rocprofv3 evidence bench.py and DESIGN.md cite.  Run on the GPU box from the repo root:
 #   bash profiles/collect.sh <tag>      -> gpurun_out/prof_<tag>/{kernel_stats_summary.csv, pmc_summary.txt, pmc_traffic.json}
 # then copy the summaries to profiles/<tag>_*.  Kernel trace and every PMC set run in separate passes (no --sys-trace).
-cd $GRAFT_REPO_ROOT
+set -euo pipefail
+cd "${GRAFT_REPO_ROOT:?run on the GPU box (gpurun exports GRAFT_REPO_ROOT)}"
 export TMPDIR=/tmp
-tag=$1
+tag=${1:?usage: collect.sh <tag>}
 out=gpurun_out/prof_$tag
-mkdir -p $out
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline > $out/bench_under_rocprof.log 2>&1
+mkdir -p "$out"
+BENCH="python3 bench.py --no-cpu-baseline --no-secondary --repeats 1"
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- $BENCH --steps 10 --warmup 2 > $out/bench_under_rocprof.log 2>&1
 f=$(find $out/trace -name "*kernel_stats.csv" | head -1)
+[ -n "$f" ] || { echo "no kernel_stats.csv produced; see $out/bench_under_rocprof.log" >&2; exit 1; }
 python3 - "$f" "$out/kernel_stats_summary.csv" <<'PY'
 import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
@@ -19,8 +22,9 @@ print(open(sys.argv[2]).read())
 PY
 for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_VMEM_RD" "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" "FETCH_SIZE" "WRITE_SIZE"; do
   d=$out/pmc_$(echo $set | cut -c1-12 | tr ' ' '_')
-  rocprofv3 --pmc $set --kernel-trace --output-format csv -d $d -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-profile > $d.log 2>&1
+  rocprofv3 --pmc $set --kernel-trace --output-format csv -d $d -- $BENCH --steps 3 --warmup 1 --no-profile > $d.log 2>&1
   f=$(find $d -name "*counter_collection.csv" | head -1)
+  [ -n "$f" ] || { echo "no counter_collection.csv for [$set]; see $d.log" >&2; exit 1; }
   python3 - "$f" >> $out/pmc_summary.txt <<'PY'
 import csv, sys, collections
 agg=collections.defaultdict(lambda: collections.defaultdict(float)); n=collections.Counter(); seen=set()
