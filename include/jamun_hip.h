@@ -179,7 +179,8 @@ typedef struct jamun_stats {
   int64_t conv1_flop_alg;   /* useful FLOPs of ONE hidden-layer vector-row conv launch: 2*3*n_atoms*65*(mul0+2*mul1)*mul1   */
   int32_t edge_stride;
   int32_t n_slices;       /* partial slabs per tile summed by the node update (max over tiles)          */
-  int32_t conv_path;      /* 1: fused matrix-core-forming conv kernel (small molecules), 0: general k_conv */
+  int32_t conv_path;      /* hidden layers: 2 destination-grouped VALU-forming kernel (jamun_conv_dg.hip), 1 fused
+                             matrix-core-forming kernel, 0 general k_conv */
   int32_t reserved;
 } jamun_stats;
 /* Synchronises `stream`. */

@@ -103,9 +103,13 @@ struct FusedDev {
   size_t lds_bytes = 0;
   int64_t mfma_per_k = 0;  // MFMA instructions per hidden unit k and tile (forming + main), for FLOP bookkeeping
 };
+struct DgDev {
+  float4 *wx = nullptr, *wd = nullptr, *wv = nullptr, *wt = nullptr;  // null: the layer cannot use jamun_conv_dg.hip
+};
 struct LayerDev {
   ConvProblemDev p0, p1;
   FusedDev fu;
+  DgDev dg;
   std::vector<float> w1r_h, cmask_h;  // radial MLP first layer (uploaded for all layers together: jamun_sampler::w1r_all)
   float* tt = nullptr;  // initial projector only: [k][distinct embedding row][32 (nt0 + 1)] input-times-weight table
   int tt_row = 0, tt_U = 0;
@@ -119,6 +123,11 @@ struct LayerDev {
 void free_fused(FusedDev& f) {
   hipFree(f.wpack); hipFree(f.a_units); hipFree(f.b_units); hipFree(f.owner);
   f = FusedDev{};
+}
+
+void free_dg(DgDev& d) {
+  hipFree(d.wx); hipFree(d.wd); hipFree(d.wv); hipFree(d.wt);
+  d = DgDev{};
 }
 
 void free_problem(ConvProblemDev& p) {
@@ -276,6 +285,12 @@ struct jamun_sampler {
   int n_fchunks = 0;
   bool row_blocks = false;            // some molecule exceeds the per-tile source budget
   int* atom_nslab = nullptr;          // [n_atoms] partial slabs of the tile the atom belongs to
+  // destination-grouped VALU-forming conv kernel (jamun_conv_dg.hip; hidden layers): own tile plan (larger source spans)
+  bool dg_on = false, dg_row_blocks = false;
+  int dg_RS = 0, dg_grid = 0, dg_max_segs = 0, dg_n_slabs = 0, dg_n_tiles = 0;
+  int2 *dg_tile_atoms = nullptr, *dg_tile_span = nullptr;
+  int4* dg_segs = nullptr;
+  int* dg_atom_nslab = nullptr;
   float *x_emb = nullptr, *mu = nullptr;
   std::vector<LayerDev> layers;
   float *w_gate = nullptr, *w_vec = nullptr, *w_out = nullptr;
@@ -299,8 +314,9 @@ struct jamun_sampler {
   ~jamun_sampler() {
     hipFree(ptr); hipFree(bond_in_ptr); hipFree(bond_in_src); hipFree(x_emb); hipFree(mu); hipFree(tile_span);
     hipFree(fused_segs); hipFree(atom_nslab); hipFree(tile_atoms); hipFree(atom_uid); hipFree(w1r_all); hipFree(cmask_all);
+    hipFree(dg_tile_atoms); hipFree(dg_tile_span); hipFree(dg_segs); hipFree(dg_atom_nslab);
     for (auto& L : layers) {
-      free_problem(L.p0); free_problem(L.p1); free_fused(L.fu);
+      free_problem(L.p0); free_problem(L.p1); free_fused(L.fu); free_dg(L.dg);
       hipFree(L.wcat0); hipFree(L.wcat1); hipFree(L.mix); hipFree(L.tt);
     }
     hipFree(w_gate); hipFree(w_vec); hipFree(w_out);
@@ -316,7 +332,7 @@ namespace {
 
 LayerDev build_layer(const jamun_model& m, const std::string& prefix, const std::vector<InBlock>& in_blocks,
                      const std::vector<double>& s_in, int n_slices, int fused_JR, int fused_span,
-                     const std::vector<float>* uniq_rows = nullptr, int row_len = 0) {
+                     const std::vector<float>* uniq_rows = nullptr, int row_len = 0, bool pack_dg = false) {
   const jamun_hparams& hp = m.hp;
   const int mul0 = hp.mul0, mul1 = hp.mul1, G0 = mul0 + mul1, G1 = mul1, H = hp.edge_attr_dim;
   LayerDev L;
@@ -564,6 +580,62 @@ LayerDev build_layer(const jamun_model& m, const std::string& prefix, const std:
     }
   }
 
+  // ---- destination-grouped VALU-forming kernel (jamun_conv_dg.hip): weights as 64-lane float4 blocks in MFMA operand order
+  if (pack_dg && mul0 == 120 && mul1 == 32 && x0e.size() == 120 && dote.size() == 32 && x1e.size() == 32 && crosse.size() == 32 &&
+      x0ve.size() == 120 && x0_contig && x0e[0].xoff == 0 && dote[0].xoff == 120) {
+    const int n_k = H + 1;
+    auto Wk = [&](int k, int64_t p) -> double { return (k < H) ? (double)W3[(size_t)p * H + k] : (double)b3[p]; };
+    std::vector<float4> wx((size_t)n_k * 5 * 16 * 64), wd((size_t)n_k * 5 * 4 * 64), wv((size_t)n_k * 2 * 4 * 64), wt((size_t)n_k * 8 * 2 * 64);
+    for (int k = 0; k < n_k; ++k) {
+      for (int t = 0; t < 5; ++t)
+        for (int g = 0; g < 16; ++g)
+          for (int lane = 0; lane < 64; ++lane) {
+            const int hh = lane >> 5, c = lane & 31, col = 32 * t + c;
+            float v[4] = {0.f, 0.f, 0.f, 0.f};
+            for (int st = 0; st < 4; ++st) {
+              const int u = 8 * g + 4 * hh + st;
+              if (u < 120 && col < G0) v[st] = (float)(Wk(k, x0e[u].wbase + col) * x0e[u].scale);
+            }
+            wx[(((size_t)k * 5 + t) * 16 + g) * 64 + lane] = make_float4(v[0], v[1], v[2], v[3]);
+            if (g < 4) {
+              float d[4] = {0.f, 0.f, 0.f, 0.f};
+              for (int st = 0; st < 4; ++st) {
+                const int u = 8 * g + 4 * hh + st;
+                if (col < G0) d[st] = (float)(Wk(k, dote[u].wbase + col) * dote[u].scale);
+              }
+              wd[(((size_t)k * 5 + t) * 4 + g) * 64 + lane] = make_float4(d[0], d[1], d[2], d[3]);
+            }
+          }
+      for (int lane = 0; lane < 64; ++lane) {
+        const int kq = lane >> 4, c = lane & 15;
+        for (int ch = 0; ch < 2; ++ch) {
+          const int col = 16 * ch + c;
+          for (int g = 0; g < 4; ++g) {  // vector planes: kappa = 16 g + 4 kq + st over [x1 (32) | cross (32)]
+            float v[4];
+            for (int st = 0; st < 4; ++st) {
+              const int kap = 16 * g + 4 * kq + st;
+              const UEntry& e = kap < 32 ? x1e[kap] : crosse[kap - 32];
+              v[st] = (float)(Wk(k, e.wbase + col) * e.scale);
+            }
+            wv[(((size_t)k * 2 + ch) * 4 + g) * 64 + lane] = make_float4(v[0], v[1], v[2], v[3]);
+          }
+          for (int g = 0; g < 8; ++g) {  // T product: u = 16 g + 4 kq + st over the 120 scalar inputs (padded to 128)
+            float v[4] = {0.f, 0.f, 0.f, 0.f};
+            for (int st = 0; st < 4; ++st) {
+              const int u = 16 * g + 4 * kq + st;
+              if (u < 120) v[st] = (float)(Wk(k, x0ve[u].wbase + col) * x0ve[u].scale);
+            }
+            wt[(((size_t)k * 8 + g) * 2 + ch) * 64 + lane] = make_float4(v[0], v[1], v[2], v[3]);
+          }
+        }
+      }
+    }
+    L.dg.wx = dev_upload(wx);
+    L.dg.wd = dev_upload(wd);
+    L.dg.wv = dev_upload(wv);
+    L.dg.wt = dev_upload(wt);
+  }
+
   // ---- initial projector: input-times-weight table for jamun_conv_init.hip (inputs are constant per distinct embedding row)
   if (uniq_rows && L.fu.wpack && G0 <= 32 * NT0 && G1 <= 32) {
     bool scalar_only = true;
@@ -715,6 +787,17 @@ void forward(jamun_sampler* s, const float* y, float* xhat, float* score, hipStr
       ProfScope ps(s, JAMUN_PROF_CONV0_INIT, st);
       const int rcode = launch_conv_init(f, s->fused_grid, st);
       if (rcode != 0) throw Err(JAMUN_ERR_INVALID, "initial-projector conv launch failed (configuration not supported)");
+    } else if (l > 0 && s->dg_on) {
+      DgArgs f{};
+      f.deg = s->deg; f.esrc = s->esrc; f.egeo = s->egeo; f.h = h_l; f.h_kstride = s->h_kstride; f.x = x_in;
+      f.n_pad = s->n_pad; f.S = s->S; f.XS = XSin; f.RS = s->dg_RS; f.PMAX = s->S;
+      f.tile_span = s->dg_tile_span; f.tile_atoms = s->dg_tile_atoms; f.segs = s->dg_segs; f.max_segs = s->dg_max_segs;
+      f.row_blocks = s->dg_row_blocks ? 1 : 0; f.nt0 = L.p0.nt;
+      f.wx = L.dg.wx; f.wd = L.dg.wd; f.wv = L.dg.wv; f.wt = L.dg.wt;
+      f.partial0 = s->partial0; f.partial1 = s->partial1;
+      ProfScope ps(s, JAMUN_PROF_CONV0, st);
+      const int rcode = launch_conv_dg(f, s->dg_grid, st);
+      if (rcode != 0) throw Err(JAMUN_ERR_INVALID, "destination-grouped conv launch failed (configuration not supported)");
     } else if (L.fu.wpack) {
       FusedArgs f{};
       f.deg = s->deg; f.esrc = s->esrc; f.egeo = s->egeo; f.h = h_l; f.h_kstride = s->h_kstride; f.x = x_in;
@@ -747,8 +830,9 @@ void forward(jamun_sampler* s, const float* y, float* xhat, float* score, hipStr
     n.cL = s->hp.act_scalar_const; n.cS = s->hp.act_gate_const;
     n.n_atoms = s->n_atoms; n.n_pad = s->n_pad; n.n_slices = s->n_slices; n.nt0 = L.p0.nt; n.nt1 = L.p1.nt;
     n.mul0 = s->hp.mul0; n.mul1 = s->hp.mul1; n.in0 = L.in0; n.in1 = L.in1; n.XSin = XSin;
-    n.atom_nslab = L.fu.wpack ? s->atom_nslab : nullptr;
-    n.max_slabs = L.fu.wpack ? s->n_slabs : s->n_slices;
+    const bool dg_layer = l > 0 && s->dg_on;
+    n.atom_nslab = dg_layer ? s->dg_atom_nslab : (L.fu.wpack ? s->atom_nslab : nullptr);
+    n.max_slabs = dg_layer ? s->dg_n_slabs : (L.fu.wpack ? s->n_slabs : s->n_slices);
     {
       ProfScope ps(s, JAMUN_PROF_NODE, st);
       launch_node_update(n, st);
@@ -790,6 +874,117 @@ void check_mcmc(const jamun_mcmc_params* p) {
 }
 
 bool saves(const jamun_mcmc_params* p, int i) { return (i % p->save_every_n_steps) == 0 && i >= p->burn_in_steps; }
+
+// Tiles of the destination-grouped conv kernels.  A tile = up to 32 consecutive destination atoms whose source span (whole
+// molecules) has at most `cap` rows; tiles are cut greedily at molecule granularity.  A molecule larger than `cap`: its sources
+// are cut into row blocks of <= cap atoms and every destination chunk (<= 32 atoms of the molecule) gets one tile PER source
+// block — the contraction is linear in the edge coefficients, so the blocks' results are just more partial slabs for the node
+// update to sum (edges whose source lies outside a tile's block are skipped by that tile).
+void plan_tiles(const int32_t* ptr, const std::vector<int>& graph_of, int N, int cap, std::vector<int2>& t_atoms,
+                std::vector<int2>& t_span, std::vector<int>& t_chunk, int& n_chunks, int& span_max, bool& row_blocks) {
+  int a0 = 0;
+  while (a0 < N) {
+    const int g0 = graph_of[a0], lo = ptr[g0], mol_hi = ptr[g0 + 1];
+    if (mol_hi - lo > cap) {
+      const int n_mol = mol_hi - lo, nb = (n_mol + cap - 1) / cap;
+      row_blocks = true;
+      for (int d0 = lo; d0 < mol_hi; d0 += 32) {
+        const int cnt = std::min(32, mol_hi - d0);
+        for (int b = 0; b < nb; ++b) {
+          const int blo = lo + (int)((int64_t)n_mol * b / nb), bhi = lo + (int)((int64_t)n_mol * (b + 1) / nb);
+          t_atoms.push_back(make_int2(d0, cnt));
+          t_span.push_back(make_int2(blo, bhi));
+          t_chunk.push_back(n_chunks);
+          span_max = std::max(span_max, bhi - blo);
+        }
+        ++n_chunks;
+      }
+      a0 = mol_hi;
+      continue;
+    }
+    int cnt = 0, hi = lo;
+    while (a0 + cnt < N && cnt < 32) {
+      const int g2 = graph_of[a0 + cnt], nhi = ptr[g2 + 1];
+      if (nhi - lo > cap) break;  // (also stops in front of a molecule that needs row blocks)
+      cnt += std::min(nhi - (a0 + cnt), 32 - cnt);
+      hi = nhi;
+    }
+    t_atoms.push_back(make_int2(a0, cnt));
+    t_span.push_back(make_int2(lo, hi));
+    t_chunk.push_back(n_chunks++);
+    span_max = std::max(span_max, hi - lo);
+    a0 += cnt;
+  }
+}
+
+// Work lists of the persistent conv kernels.  Work items are (tile, hidden unit k).  k is sliced over `ng` groups of XCDs
+// (workgroup g runs on XCD g % 8, so an XCD's L2 holds only its slice of the weights); the n_k % ng left-over k are dealt
+// round-robin over (tile, slice).  Each slice's item list (tile-major) is cut over its workgroups — evenly by item count for
+// near-uniform batches, by modelled cost otherwise: a workgroup gets a few runs of k ("segments"), each written to its own
+// partial slab of the tile's destination chunk.
+struct SegPlan {
+  std::vector<int4> segs;  // [cus][max_segs][2]
+  int max_segs = 1, n_slabs = 1;
+  std::vector<int> atom_nslab;
+};
+template <typename WeightFn>
+SegPlan plan_segments(int cus, int ng, int n_k, int N, const std::vector<int2>& t_atoms, const std::vector<int>& t_chunk, int n_chunks,
+                      WeightFn weight) {
+  SegPlan P;
+  const int ncx_all = cus / ng;
+  std::vector<std::vector<int>> wg_of(ng);  // workgroups of k-slice x, in launch order
+  for (int g = 0; g < cus; ++g) wg_of[ng == 1 ? 0 : (g % 8) % ng].push_back(g);
+  const int base = n_k / ng, rem = n_k % ng;
+  std::vector<std::vector<int4>> wg_segs(cus);
+  const int n_tiles = (int)t_atoms.size();
+  std::vector<int> nslab(n_chunks, 0);  // per destination chunk: its tiles (source row blocks, k runs) number their slabs jointly
+  for (int x = 0; x < ng; ++x) {
+    auto extra_of = [&](int t) { const int e = ((x - t) % ng + ng) % ng; return e < rem ? ng * base + e : -1; };
+    // (near-uniform batches are cut by item count: measured 1 % better on cfg2 than the modelled weights, whose error
+    // then exceeds the spread they describe)
+    int64_t w_min = weight(0), w_max = w_min;
+    for (int t = 1; t < n_tiles; ++t) { w_min = std::min<int64_t>(w_min, weight(t)); w_max = std::max<int64_t>(w_max, weight(t)); }
+    const bool uniform = 4 * (w_max - w_min) < w_max;
+    auto weight_of = [&](int t) -> int64_t { return uniform ? 1 : weight(t); };
+    int64_t Lx = 0, Wx = 0;
+    for (int t = 0; t < n_tiles; ++t) {
+      const int cnt = base + (extra_of(t) >= 0 ? 1 : 0);
+      Lx += cnt;
+      Wx += cnt * weight_of(t);
+    }
+    // small batches: do not cut the list finer than 8 items per workgroup (a tile's partial slabs are summed by the node
+    // update; one slab per hidden unit would make that kernel the bottleneck)
+    const int ncx = (int)std::max<int64_t>(1, std::min<int64_t>(ncx_all, Lx / 8));
+    int64_t off_w = 0;
+    for (int t = 0; t < n_tiles; ++t) {
+      const int ex = extra_of(t), cnt = base + (ex >= 0 ? 1 : 0);
+      const int64_t w = weight_of(t);
+      auto wg_of_item = [&](int i) { return (int)std::min<int64_t>(ncx - 1, ((off_w + i * w + w / 2) * ncx) / Wx); };
+      int i0 = 0;
+      while (i0 < cnt) {
+        const int c = wg_of_item(i0);
+        int i1 = i0 + 1;
+        while (i1 < cnt && wg_of_item(i1) == c) ++i1;
+        const int kb = x * base + std::min(i0, base), ke = x * base + std::min(i1, base);
+        auto& v = wg_segs[wg_of[x][c]];
+        v.push_back(make_int4(t, nslab[t_chunk[t]]++, kb, ke));
+        v.push_back(make_int4(i1 > base ? ex : -1, 0, 0, 0));
+        i0 = i1;
+      }
+      off_w += cnt * w;
+    }
+  }
+  size_t ms = 1;
+  for (auto& v : wg_segs) ms = std::max(ms, v.size() / 2 + 1);
+  P.max_segs = (int)ms;
+  P.segs.assign((size_t)cus * ms * 2, make_int4(-1, 0, 0, 0));
+  for (int g = 0; g < cus; ++g) std::copy(wg_segs[g].begin(), wg_segs[g].end(), P.segs.begin() + (size_t)g * ms * 2);
+  for (int v : nslab) P.n_slabs = std::max(P.n_slabs, v);
+  P.atom_nslab.assign(N, 1);
+  for (int t = 0; t < n_tiles; ++t)
+    for (int i = 0; i < t_atoms[t].y; ++i) P.atom_nslab[t_atoms[t].x + i] = nslab[t_chunk[t]];
+  return P;
+}
 
 }  // namespace
 
@@ -877,7 +1072,8 @@ int jamun_sampler_create(const jamun_model* m, float sigma, const jamun_topology
     s->S = std::min(std::max(nmax - 1, 0), JAMUN_MAX_NEIGHBORS + 1) + max_in;
     if (s->S < 1) s->S = 1;
     s->n_tiles = s->n_pad / 32;
-    if (conv_set_max_lds() != 0 || conv_fused_set_max_lds() != 0 || node_update_set_max_lds() != 0 || conv_init_set_max_lds() != 0)
+    if (conv_set_max_lds() != 0 || conv_fused_set_max_lds() != 0 || node_update_set_max_lds() != 0 || conv_init_set_max_lds() != 0 ||
+        conv_dg_set_max_lds() != 0)
       throw Err(JAMUN_ERR_HIP, "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed");
     {
       // ---- fused conv kernel: eligibility and tiling.  A tile = up to 32 consecutive destination atoms whose source
@@ -905,45 +1101,8 @@ int jamun_sampler_create(const jamun_model* m, float sigma, const jamun_topology
       std::vector<int2> t_atoms, t_span;
       std::vector<int> t_chunk;  // destination chunk of each tile (tiles of one chunk share its partial-slab numbering)
       int n_chunks = 0;
-      if (ok && jr_cap > 0) {
-        int a0 = 0;
-        while (a0 < N) {
-          const int g0 = graph_of[a0], lo = topo->ptr[g0], mol_hi = topo->ptr[g0 + 1];
-          if (mol_hi - lo > jr_cap) {
-            // A molecule larger than the LDS budget: its sources are cut into row blocks of <= jr_cap atoms and every
-            // destination chunk (<= 32 atoms of the molecule) gets one tile PER source block.  The contraction is linear
-            // in the coefficient tile, so the blocks' results are just more partial slabs for the node update to sum
-            // (edges whose source lies outside a tile's block are skipped by that tile).
-            const int n_mol = mol_hi - lo, nb = (n_mol + jr_cap - 1) / jr_cap;
-            s->row_blocks = true;
-            for (int d0 = lo; d0 < mol_hi; d0 += 32) {
-              const int cnt = std::min(32, mol_hi - d0);
-              for (int b = 0; b < nb; ++b) {
-                const int blo = lo + (int)((int64_t)n_mol * b / nb), bhi = lo + (int)((int64_t)n_mol * (b + 1) / nb);
-                t_atoms.push_back(make_int2(d0, cnt));
-                t_span.push_back(make_int2(blo, bhi));
-                t_chunk.push_back(n_chunks);
-                s->span_max = std::max(s->span_max, bhi - blo);
-              }
-              ++n_chunks;
-            }
-            a0 = mol_hi;
-            continue;
-          }
-          int cnt = 0, hi = lo;
-          while (a0 + cnt < N && cnt < 32) {
-            const int g2 = graph_of[a0 + cnt], nhi = topo->ptr[g2 + 1];
-            if (nhi - lo > jr_cap) break;  // (also stops in front of a molecule that needs row blocks)
-            cnt += std::min(nhi - (a0 + cnt), 32 - cnt);
-            hi = nhi;
-          }
-          t_atoms.push_back(make_int2(a0, cnt));
-          t_span.push_back(make_int2(lo, hi));
-          t_chunk.push_back(n_chunks++);
-          s->span_max = std::max(s->span_max, hi - lo);
-          a0 += cnt;
-        }
-      } else ok = false;
+      if (ok && jr_cap > 0) plan_tiles(topo->ptr, graph_of, N, jr_cap, t_atoms, t_span, t_chunk, n_chunks, s->span_max, s->row_blocks);
+      else ok = false;
       if (ok) {
         int JR = (s->span_max + 3) & ~3;
         if ((JR / 4) % 2 == 0) JR += 4;
@@ -1029,7 +1188,8 @@ int jamun_sampler_create(const jamun_model* m, float sigma, const jamun_topology
       std::vector<InBlock> ib = {{hp.mul0, 0, 0, 0}, {hp.mul1, 1, hp.mul0, hp.mul0}};
       const std::string li = std::to_string(l);
       std::vector<double> sc = noise_mlp(*m, "noise_scalings." + li + ".scale_predictor", hp.mul0 + hp.mul1, c_noise);
-      LayerDev L = build_layer(*m, "layers." + li, ib, sc, s->n_slices, s->fused_JR, s->span_max);
+      LayerDev L = build_layer(*m, "layers." + li, ib, sc, s->n_slices, s->fused_JR, s->span_max, nullptr, 0,
+                               /*pack_dg=*/getenv("JAMUN_NO_DG") == nullptr);
       std::vector<double> wm = noise_mlp(*m, "skip_connections." + li + ".weights.scale_predictor", hp.mul0 + hp.mul1, c_noise);
       std::vector<float> mix(wm.size());
       for (size_t i = 0; i < wm.size(); ++i) mix[i] = (float)(1.0 / (1.0 + std::exp(-wm[i])));
@@ -1060,87 +1220,69 @@ int jamun_sampler_create(const jamun_model* m, float sigma, const jamun_topology
         s->fused_JR = 0;
       }
     }
-    if (s->fused_JR > 0) {
-      // Work items are (tile, hidden unit k).  k is sliced over the XCDs (workgroup g runs on XCD g % 8, so an XCD's L2
-      // holds only its slice of the weights); the n_k % 8 left-over k are dealt round-robin over (tile, XCD).  Each
-      // XCD's item list (tile-major) is cut evenly over its workgroups: a workgroup gets a few runs of k ("segments"),
-      // each written to its own partial slab of the tile.
-      hipDeviceProp_t prop;
+    hipDeviceProp_t prop;
+    {
       int dev = 0;
       HIPCHECK(hipGetDevice(&dev));
       HIPCHECK(hipGetDeviceProperties(&prop, dev));
-      const int cus = std::max(prop.multiProcessorCount, 1);
-      const int n_k = hp.edge_attr_dim + 1;
-      // Two k-slices measured best on MI355X (profiles/r1d): longer runs of k per segment amortise the pipeline ramp and the
-      // per-tile staging, and beat the better L2 residency of the weights with 8 slices (one per XCD).
-      int ng = (cus % 8 == 0 && n_k >= 8) ? 2 : 1;
-      if (const char* e = getenv("JAMUN_FUSED_KGROUPS")) {  // tuning aid: 1, 2, 4 or 8 k-slices (XCDs x, x + ng, ... share one)
+    }
+    const int cus = std::max(prop.multiProcessorCount, 1);
+    const int n_k = hp.edge_attr_dim + 1;
+    auto k_groups = [&](const char* env, int dflt) {  // k-slices over XCD groups: 1, 2, 4 or 8 (XCDs x, x + ng, ... share one)
+      int ng = (cus % 8 == 0 && n_k >= 8) ? dflt : 1;
+      if (const char* e = getenv(env)) {
         const int v = atoi(e);
         if ((v == 1 || v == 2 || v == 4 || v == 8) && cus % 8 == 0 && n_k >= v) ng = v;
       }
-      const int ncx = cus / ng;
-      std::vector<std::vector<int>> wg_of(ng);  // workgroups of k-slice x, in launch order
-      for (int g = 0; g < cus; ++g) wg_of[ng == 1 ? 0 : (g % 8) % ng].push_back(g);
-      const int base = n_k / ng, rem = n_k % ng;
+      return ng;
+    };
+    if (s->fused_JR > 0) {
+      // Two k-slices measured best on MI355X for the fused kernel (profiles/r1d): longer runs of k per segment amortise the
+      // pipeline ramp and the per-tile staging, and beat the better L2 residency of the weights with 8 slices (one per XCD).
+      const int ng = k_groups("JAMUN_FUSED_KGROUPS", 2);
+      // items are weighted by the MFMA count of one hidden-layer (tile, k): forming scales with the tile's source rows
+      auto weight = [&](int t) -> int64_t {
+        const int J4 = (s->ftile_span_h[t].y - s->ftile_span_h[t].x + 3) & ~3;
+        const int steps = 4 * (J4 / 8) + ((J4 & 4) ? 2 : 0), n_jt = (J4 + 31) / 32;
+        return 16 * steps + n_jt * (64 + 48) + 496 + 256;  // + the fixed per-interval cost (barrier, build), in MFMA units
+      };
+      SegPlan P = plan_segments(cus, ng, n_k, N, s->ftile_atoms_h, s->ftile_chunk_h, s->n_fchunks, weight);
       s->fused_grid = cus;
-      std::vector<std::vector<int4>> wg_segs(cus);
-      const int n_tiles = s->n_ftiles;
-      std::vector<int> nslab(s->n_fchunks, 0);  // per destination chunk: its tiles (source row blocks, k runs) number their slabs jointly
-      for (int x = 0; x < ng; ++x) {
-        auto extra_of = [&](int t) { const int e = ((x - t) % ng + ng) % ng; return e < rem ? ng * base + e : -1; };
-        // items are weighted by the MFMA count of one hidden-layer (tile, k): forming scales with the tile's source rows
-        auto weight = [&](int t) -> int64_t {
-          const int J4 = (s->ftile_span_h[t].y - s->ftile_span_h[t].x + 3) & ~3;
-          const int steps = 4 * (J4 / 8) + ((J4 & 4) ? 2 : 0), n_jt = (J4 + 31) / 32;
-          return 16 * steps + n_jt * (64 + 48) + 496 + 256;  // + the fixed per-interval cost (barrier, build), in MFMA units
-        };
-        // (near-uniform batches are cut by item count: measured 1 % better on cfg2 than the modelled weights, whose error
-        // then exceeds the spread they describe)
-        int64_t w_min = weight(0), w_max = w_min;
-        for (int t = 1; t < n_tiles; ++t) { w_min = std::min(w_min, weight(t)); w_max = std::max(w_max, weight(t)); }
-        const bool uniform = 4 * (w_max - w_min) < w_max;
-        auto weight_of = [&](int t) -> int64_t { return uniform ? 1 : weight(t); };
-        int64_t Lx = 0, Wx = 0;
-        for (int t = 0; t < n_tiles; ++t) {
-          const int cnt = base + (extra_of(t) >= 0 ? 1 : 0);
-          Lx += cnt;
-          Wx += cnt * weight_of(t);
-        }
-        // small batches: do not cut the list finer than 8 items per workgroup (a tile's partial slabs are summed by the node
-        // update; one slab per hidden unit would make that kernel the bottleneck)
-        const int ncx_all = ncx;
-        const int ncx = (int)std::max<int64_t>(1, std::min<int64_t>(ncx_all, Lx / 8));
-        int64_t off_w = 0;
-        for (int t = 0; t < n_tiles; ++t) {
-          const int ex = extra_of(t), cnt = base + (ex >= 0 ? 1 : 0);
-          const int64_t w = weight_of(t);
-          auto wg_of_item = [&](int i) { return (int)std::min<int64_t>(ncx - 1, ((off_w + i * w + w / 2) * ncx) / Wx); };
-          int i0 = 0;
-          while (i0 < cnt) {
-            const int c = wg_of_item(i0);
-            int i1 = i0 + 1;
-            while (i1 < cnt && wg_of_item(i1) == c) ++i1;
-            const int kb = x * base + std::min(i0, base), ke = x * base + std::min(i1, base);
-            auto& v = wg_segs[wg_of[x][c]];
-            v.push_back(make_int4(t, nslab[s->ftile_chunk_h[t]]++, kb, ke));
-            v.push_back(make_int4(i1 > base ? ex : -1, 0, 0, 0));
-            i0 = i1;
-          }
-          off_w += cnt * w;
-        }
+      s->fused_max_segs = P.max_segs;
+      s->fused_segs = dev_upload(P.segs);
+      s->n_slabs = P.n_slabs;
+      s->atom_nslab = dev_upload(P.atom_nslab);
+    }
+    // ---- destination-grouped VALU-forming kernel for the hidden layers (jamun_conv_dg.hip): own tile plan, larger spans
+    {
+      bool ok = getenv("JAMUN_NO_DG") == nullptr && hp.n_layers > 0 && s->S <= 64 && (int64_t)N * s->S < (int64_t)0x7fffffff;
+      for (size_t l = 1; l < s->layers.size(); ++l) ok = ok && s->layers[l].dg.wx != nullptr;
+      int cap = 0;
+      for (int rs = 128; rs >= 16 && ok; rs -= 16)
+        if (conv_dg_lds_bytes(rs, s->S) <= JAMUN_MAX_DYN_LDS) { cap = rs; break; }
+      if (ok && cap > 0) {
+        std::vector<int2> t_atoms, t_span;
+        std::vector<int> t_chunk;
+        int n_chunks = 0, span_max = 0;
+        plan_tiles(topo->ptr, graph_of, N, cap, t_atoms, t_span, t_chunk, n_chunks, span_max, s->dg_row_blocks);
+        s->dg_RS = (span_max + 15) & ~15;
+        s->dg_n_tiles = (int)t_atoms.size();
+        // One k-slice per XCD keeps an XCD's share of the weights (1/8 of ~7.7 MB per layer) inside its 4 MB L2; the matrix
+        // waves stream ~170 KB of weight blocks per (tile, k).
+        const int ng = k_groups("JAMUN_DG_KGROUPS", 8);
+        auto weight = [&](int t) -> int64_t { return 604 + 8 * ((t_span[t].y - t_span[t].x + 15) / 16); };
+        SegPlan P = plan_segments(cus, ng, n_k, N, t_atoms, t_chunk, n_chunks, weight);
+        s->dg_grid = cus;
+        s->dg_max_segs = P.max_segs;
+        s->dg_segs = dev_upload(P.segs);
+        s->dg_n_slabs = P.n_slabs;
+        s->dg_atom_nslab = dev_upload(P.atom_nslab);
+        s->dg_tile_atoms = dev_upload(t_atoms);
+        s->dg_tile_span = dev_upload(t_span);
+        s->dg_on = true;
       }
-      size_t ms = 1;
-      for (auto& v : wg_segs) ms = std::max(ms, v.size() / 2 + 1);
-      s->fused_max_segs = (int)ms;
-      std::vector<int4> segs((size_t)cus * ms * 2, make_int4(-1, 0, 0, 0));
-      for (int g = 0; g < cus; ++g) std::copy(wg_segs[g].begin(), wg_segs[g].end(), segs.begin() + (size_t)g * ms * 2);
-      s->fused_segs = dev_upload(segs);
-      s->n_slabs = 1;
-      for (int v : nslab) s->n_slabs = std::max(s->n_slabs, v);
-      std::vector<int> an(N, 1);
-      for (int t = 0; t < n_tiles; ++t)
-        for (int i = 0; i < s->ftile_atoms_h[t].y; ++i) an[s->ftile_atoms_h[t].x + i] = nslab[s->ftile_chunk_h[t]];
-      s->atom_nslab = dev_upload(an);
+      if (!s->dg_on)
+        for (auto& L : s->layers) free_dg(L.dg);
     }
     // ---- work buffers
     const size_t NS = (size_t)N * s->S;
@@ -1163,7 +1305,7 @@ int jamun_sampler_create(const jamun_model* m, float sigma, const jamun_topology
     }
     int nt0 = 0, nt1 = 0;
     for (auto& L : s->layers) { nt0 = std::max(nt0, L.p0.nt); nt1 = std::max(nt1, L.p1.nt); }
-    const size_t n_part = (size_t)std::max(s->n_slices, s->n_slabs);
+    const size_t n_part = (size_t)std::max(std::max(s->n_slices, s->n_slabs), s->dg_n_slabs);
     s->partial0 = dev_alloc<float>(n_part * s->n_pad * nt0 * 32);
     s->partial1 = dev_alloc<float>(n_part * s->n_pad * 3 * nt1 * 32);
     s->g = dev_alloc<float>((size_t)N * 3);
@@ -1178,7 +1320,8 @@ int jamun_sampler_create(const jamun_model* m, float sigma, const jamun_topology
     s->flop_exec = 0;
     for (auto& L : s->layers) {
       s->flop_ref_per_edge += 2LL * 64 * 64 + 130LL * L.tp_numel;  // SURVEY.md §8 d
-      if (L.fu.wpack) s->flop_exec += (int64_t)s->n_ftiles * (hp.edge_attr_dim + 1) * L.fu.mfma_per_k * 4096;  // 32x32x2 MFMA = 4096 FLOP
+      if (s->dg_on && &L != &s->layers[0]) s->flop_exec += (int64_t)s->dg_n_tiles * (hp.edge_attr_dim + 1) * (604 + 0) * 4096;  // MFMA units per (tile, k)
+      else if (L.fu.wpack) s->flop_exec += (int64_t)s->n_ftiles * (hp.edge_attr_dim + 1) * L.fu.mfma_per_k * 4096;  // 32x32x2 MFMA = 4096 FLOP
       else s->flop_exec += 2LL * s->n_pad * (1LL * L.p0.K * L.p0.nt * 32 + 3LL * L.p1.K * L.p1.nt * 32);
     }
     HIPCHECK(hipDeviceSynchronize());
@@ -1366,8 +1509,8 @@ int jamun_sampler_stats(jamun_sampler* s, jamun_stats* out, void* stream) {
       out->conv1_flop_alg = 2 * 3 * (int64_t)s->n_atoms * H1 * (m0 + 2 * m1) * m1;
     }
     out->edge_stride = s->S;
-    out->n_slices = s->fused_JR > 0 ? s->n_slabs : s->n_slices;
-    out->conv_path = s->fused_JR > 0 ? 1 : 0;
+    out->n_slices = s->dg_on ? s->dg_n_slabs : (s->fused_JR > 0 ? s->n_slabs : s->n_slices);
+    out->conv_path = s->dg_on ? 2 : (s->fused_JR > 0 ? 1 : 0);
     out->reserved = 0;
   });
 }

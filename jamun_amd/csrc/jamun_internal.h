@@ -67,6 +67,30 @@ struct FusedArgs {
   float* partial1;  // [slab][n_pad][3][32]
 };
 
+// destination-grouped conv with VALU forming (jamun_conv_dg.hip): hidden layers with irreps 120x0e + 32x1e
+struct DgArgs {
+  const int* deg;
+  const int* esrc;
+  const float4* egeo;
+  const float* h;  // [hidden unit k (65 rows)][h_kstride]
+  size_t h_kstride;
+  const float* x;  // [n_atoms][XS = 216]
+  int n_pad, S, XS;
+  int RS;    // rows of the LDS source-row tile: multiple of 16, >= every tile span
+  int PMAX;  // per-destination capacity of the coefficient tables (= edge stride S)
+  const int2* tile_span;   // [n_tiles] {lo, hi} source atoms of the tile
+  const int2* tile_atoms;  // [n_tiles] {first destination atom, number of destination atoms (<= 32)}
+  const int4* segs;        // [grid][max_segs][2]: as FusedArgs
+  int max_segs, row_blocks, nt0;
+  // weights, 64-lane x float4 blocks (one block = the B operand of 4 consecutive MFMAs):
+  const float4* wx;  // [k][5 output tiles][16 groups (15 = zeros)]   scalar inputs -> scalar rows   (32x32x2: u = 8g + 4hh + st)
+  const float4* wd;  // [k][5][4]                                      dot(x1, v)    -> scalar rows
+  const float4* wv;  // [k][2 column halves][4]   x1 | cross -> vector rows                          (16x16x4: kappa = 16g + 4kq + st)
+  const float4* wt;  // [k][8 groups][2 column halves]   scalar inputs -> T                             (16x16x4: u = 16g + 4kq + st)
+  float* partial0;   // [slab][n_pad][nt0*32]
+  float* partial1;   // [slab][n_pad][3][32]
+};
+
 // initial-projector conv (jamun_conv_init.hip): apply-only contraction against the precomputed input-times-weight table
 struct InitArgs {
   const int* deg;
@@ -141,6 +165,9 @@ int conv_set_max_lds();
 int launch_conv_fused(const FusedArgs& a, int grid, hipStream_t st);
 int conv_fused_set_max_lds();
 int conv_fused_read_stamps(unsigned long long* out8);
+int launch_conv_dg(const DgArgs& a, int grid, hipStream_t st);
+int conv_dg_set_max_lds();
+size_t conv_dg_lds_bytes(int rs, int pmax);
 int launch_conv_init(const InitArgs& a, int grid, hipStream_t st);
 int conv_init_set_max_lds();
 size_t conv_init_lds_bytes(int JR);

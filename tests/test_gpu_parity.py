@@ -166,8 +166,9 @@ def test_forward_matches_oracle(dev, golden_dir, kind):
 
 @pytest.mark.parametrize("kind", ["ag4", "chain17x6", "ragged_small", "ragged", "dense70", "chig93x2", "chig166x2"])
 def test_fused_and_fallback_conv_agree(dev, golden_dir, kind, monkeypatch):
-    """The two conv kernels (fused matrix-core forming, general k_conv) are independent implementations of the same
-    contraction: both must meet the oracle (where a cached oracle output exists), and each other, on the same input.
+    """The three conv kernels (VALU-forming jamun_conv_dg, matrix-core-forming jamun_conv_fused, general k_conv) are
+    independent implementations of the same contraction: all must meet the oracle (where a cached oracle output exists),
+    and each other, on the same input.
     `ragged` (molecules up to 57 atoms) and `dense70` exceed the fused kernel's LDS budget per tile and exercise its
     source-row-block tiling (several tiles per destination chunk, summed as extra partial slabs)."""
     from jamun_amd import synth
@@ -187,18 +188,26 @@ def test_fused_and_fallback_conv_agree(dev, golden_dir, kind, monkeypatch):
         batch = WalkerBatch.from_molecules(_mols(kind)).to(dev)
         y = ref["y"].to(dev)
     monkeypatch.delenv("JAMUN_NO_FUSED", raising=False)
+    monkeypatch.delenv("JAMUN_NO_DG", raising=False)
+    dg = NativeSampler(model._native, 0.04, batch, dev)  # default: VALU-forming kernel for the hidden layers
+    assert dg.stats()["conv_path"] == 2
+    monkeypatch.setenv("JAMUN_NO_DG", "1")
     fused = NativeSampler(model._native, 0.04, batch, dev)
     assert fused.stats()["conv_path"] == 1
     monkeypatch.setenv("JAMUN_NO_FUSED", "1")
     general = NativeSampler(model._native, 0.04, batch, dev)
     assert general.stats()["conv_path"] == 0
-    xf, xg = fused.xhat(y), general.xhat(y)
+    xd, xf, xg = dg.xhat(y), fused.xhat(y), general.xhat(y)
     if ref is not None:
+        assert rmsd(xd, ref["xhat"]) <= RMSD_TOL_NM, rmsd(xd, ref["xhat"])
         assert rmsd(xf, ref["xhat"]) <= RMSD_TOL_NM and rmsd(xg, ref["xhat"]) <= RMSD_TOL_NM
-    assert rmsd(xf, xg) <= RMSD_TOL_NM
+    assert rmsd(xf, xg) <= RMSD_TOL_NM and rmsd(xd, xg) <= RMSD_TOL_NM
     for l in range(6):
-        a, b = fused.debug_read(0, l).cpu(), general.debug_read(0, l).cpu()
-        assert (a - b).abs().max().item() <= 2e-5 * max(b.abs().max().item(), 1e-6), l
+        b = general.debug_read(0, l).cpu()
+        for other in (fused, dg):
+            a = other.debug_read(0, l).cpu()
+            assert (a - b).abs().max().item() <= 2e-5 * max(b.abs().max().item(), 1e-6), l
+    monkeypatch.delenv("JAMUN_NO_DG")
     monkeypatch.delenv("JAMUN_NO_FUSED")
     # the initial projector has a third implementation (input-times-weight table, jamun_conv_init.hip): switch it off and
     # the fused kernel takes that layer as well — same result
@@ -231,17 +240,24 @@ def test_fused_and_fallback_conv_agree_on_random_ragged_batches(dev, seed, monke
         torch.manual_seed(trial)
         y = batch.pos + 0.04 * torch.randn(batch.pos.shape).to(dev)
         monkeypatch.delenv("JAMUN_NO_FUSED", raising=False)
+        monkeypatch.delenv("JAMUN_NO_DG", raising=False)
+        dg = NativeSampler(model._native, 0.04, batch, dev)
+        monkeypatch.setenv("JAMUN_NO_DG", "1")
         fused = NativeSampler(model._native, 0.04, batch, dev)
         monkeypatch.setenv("JAMUN_NO_FUSED", "1")
         general = NativeSampler(model._native, 0.04, batch, dev)
         monkeypatch.delenv("JAMUN_NO_FUSED")
-        assert fused.stats()["conv_path"] == 1 and general.stats()["conv_path"] == 0
-        xf, xg = fused.xhat(y), general.xhat(y)
-        assert torch.isfinite(xf).all()
+        monkeypatch.delenv("JAMUN_NO_DG")
+        assert dg.stats()["conv_path"] == 2 and fused.stats()["conv_path"] == 1 and general.stats()["conv_path"] == 0
+        xd, xf, xg = dg.xhat(y), fused.xhat(y), general.xhat(y)
+        assert torch.isfinite(xf).all() and torch.isfinite(xd).all()
         assert rmsd(xf, xg) <= RMSD_TOL_NM, (trial, nw, hi)
+        assert rmsd(xd, xg) <= RMSD_TOL_NM, (trial, nw, hi)
         for l in range(6):
-            a, b = fused.debug_read(0, l).cpu(), general.debug_read(0, l).cpu()
-            assert (a - b).abs().max().item() <= 2e-5 * max(b.abs().max().item(), 1e-6), (trial, l)
+            b = general.debug_read(0, l).cpu()
+            for other in (fused, dg):
+                a = other.debug_read(0, l).cpu()
+                assert (a - b).abs().max().item() <= 2e-5 * max(b.abs().max().item(), 1e-6), (trial, l)
 
 
 def test_walkers_are_independent_at_baseline_batch_size(dev, golden_dir):
