@@ -790,11 +790,13 @@ void forward(jamun_sampler* s, const float* y, float* xhat, float* score, hipStr
     } else if (l > 0 && s->dg_on) {
       DgArgs f{};
       f.deg = s->deg; f.esrc = s->esrc; f.egeo = s->egeo; f.h = h_l; f.h_kstride = s->h_kstride; f.x = x_in;
-      f.n_pad = s->n_pad; f.S = s->S; f.XS = XSin; f.RS = s->dg_RS; f.PMAX = s->S;
+      f.n_pad = s->n_pad; f.S = s->S; f.XS = XSin; f.RS = s->dg_RS; f.PMAX = (s->S + 3) & ~3;  // multiple of the forming batch
       f.tile_span = s->dg_tile_span; f.tile_atoms = s->dg_tile_atoms; f.segs = s->dg_segs; f.max_segs = s->dg_max_segs;
       f.row_blocks = s->dg_row_blocks ? 1 : 0; f.nt0 = L.p0.nt;
       f.wx = L.dg.wx; f.wd = L.dg.wd; f.wv = L.dg.wv; f.wt = L.dg.wt;
       f.partial0 = s->partial0; f.partial1 = s->partial1;
+      static const int dg_dbg = getenv("JAMUN_DG_DBG") ? atoi(getenv("JAMUN_DG_DBG")) : 0;
+      f.dbg = dg_dbg;
       ProfScope ps(s, JAMUN_PROF_CONV0, st);
       const int rcode = launch_conv_dg(f, s->dg_grid, st);
       if (rcode != 0) throw Err(JAMUN_ERR_INVALID, "destination-grouped conv launch failed (configuration not supported)");
@@ -1259,7 +1261,7 @@ int jamun_sampler_create(const jamun_model* m, float sigma, const jamun_topology
       for (size_t l = 1; l < s->layers.size(); ++l) ok = ok && s->layers[l].dg.wx != nullptr;
       int cap = 0;
       for (int rs = 128; rs >= 16 && ok; rs -= 16)
-        if (conv_dg_lds_bytes(rs, s->S) <= JAMUN_MAX_DYN_LDS) { cap = rs; break; }
+        if (conv_dg_lds_bytes(rs, (s->S + 3) & ~3) <= JAMUN_MAX_DYN_LDS) { cap = rs; break; }
       if (ok && cap > 0) {
         std::vector<int2> t_atoms, t_span;
         std::vector<int> t_chunk;
@@ -1267,9 +1269,10 @@ int jamun_sampler_create(const jamun_model* m, float sigma, const jamun_topology
         plan_tiles(topo->ptr, graph_of, N, cap, t_atoms, t_span, t_chunk, n_chunks, span_max, s->dg_row_blocks);
         s->dg_RS = (span_max + 15) & ~15;
         s->dg_n_tiles = (int)t_atoms.size();
-        // One k-slice per XCD keeps an XCD's share of the weights (1/8 of ~7.7 MB per layer) inside its 4 MB L2; the matrix
-        // waves stream ~170 KB of weight blocks per (tile, k).
-        const int ng = k_groups("JAMUN_DG_KGROUPS", 8);
+        // k-slices over XCD groups (JAMUN_DG_KGROUPS = 1, 2, 4, 8).  Measured on MI355X (cfg2, profiles/r2*): 1 slice 0.317 ms per
+        // launch, 2: 0.318, 4: 0.328, 8: 0.343 and the node update slows from 25 to 71 us (more partial slabs per tile): the
+        // ~7.7 MB of weight blocks per layer are served from L2 / Infinity Cache fast enough, longer runs of k per segment win.
+        const int ng = k_groups("JAMUN_DG_KGROUPS", 1);
         auto weight = [&](int t) -> int64_t { return 604 + 8 * ((t_span[t].y - t_span[t].x + 15) / 16); };
         SegPlan P = plan_segments(cus, ng, n_k, N, t_atoms, t_chunk, n_chunks, weight);
         s->dg_grid = cus;
@@ -1544,6 +1547,7 @@ int jamun_debug_stamps(unsigned long long* out8) {
   return guarded([&] {
     if (!out8) throw Err(JAMUN_ERR_INVALID, "null argument");
     HIPCHECK(hipDeviceSynchronize());
+    conv_dg_print_stamps();
     const int r = conv_fused_read_stamps(out8);
     if (r == -2) throw Err(JAMUN_ERR_INVALID, "library was not built with -DJAMUN_STAMP");
     if (r != 0) throw Err(JAMUN_ERR_HIP, "reading stamp counters failed");

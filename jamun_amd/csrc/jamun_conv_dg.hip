@@ -31,23 +31,37 @@
 // Work distribution, partial slabs, fixed summation order: as jamun_conv_fused.hip (host-built segment lists).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdio.h>
 
 #include "jamun_internal.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-#define DG_WAVES 12
+#define DG_WAVES 12   // 4 matrix waves + 8 forming waves (two forming waves per SIMD co-issue VALU and LDS instructions; with one
+                      // per SIMD the forming phases took 25 % longer)
+#define DG_NDP 2     // destination pairs per forming wave: 32 / (2 * forming waves)
 #define DG_THREADS (64 * DG_WAVES)
-#define DG_XST 284   // xs row: x0 [0,120) | x1 as [u][4] (x,y,z,0) [120,248) | T_k[j][w] [248,280) | pad: 4 * 71 floats
+#define DG_XST 252   // xs row: x0 [0,120) | [u][4] = (x1_j[u].x, T_k[j][u], x1_j[u].y, .z) [120,248) | pad: 4 * 63 floats
 #define DG_XS0 124   // X tile row stride (120 + 4):  4 * 31
 #define DG_YD 36     // Yd tile row stride (32 + 4):   4 * 9
 #define DG_YV 68     // Yv tile row stride (64 + 4):   4 * 17
+#define DG_U 4       // edges per batch of the forming loops
 
 #define LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 #define MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 #define RFL(v) __builtin_amdgcn_readfirstlane(v)
+
+#ifdef JAMUN_STAMP
+__device__ unsigned long long g_dgstamp[2][8];  // [role][prologue, P1 work, P1 wait, P2 work, P2 wait, epilogue]
+#define DSTAMP(t) do { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory"); } while (0)
+#define DACC(slot, t1, t0) do { st_acc[slot] += (t1) - (t0); } while (0)
+#else
+#define DSTAMP(t) do { } while (0)
+#define DACC(slot, t1, t0) do { } while (0)
+#endif
 
 __host__ __device__ inline size_t dg_lds_floats(int rs, int pmax) {
   // xs | X (+4: the dummy quarter group reads 4 floats past the last row) | Yd | Yv | tabA | tabJ | deg
@@ -64,19 +78,30 @@ __global__ __launch_bounds__(DG_THREADS) void k_conv_dg(DgArgs a) {
   float4* __restrict__ tabA = reinterpret_cast<float4*>(Yv + 3 * 32 * DG_YV);  // [32][PMAX] (c, c vx, c vy, c vz)
   int* __restrict__ tabJ = reinterpret_cast<int*>(tabA + 32 * a.PMAX);          // [32][PMAX] byte offset of the source row in xs
   int* __restrict__ deg_lds = tabJ + 32 * a.PMAX;                               // [32]
-  float* __restrict__ OL = Xt;   // [3][32][32]   segment end: vector rows accumulated by the forming waves (aliases X, Yd)
-  float* __restrict__ QL = Yv;   // [4][16][64]   segment end: the four K-quarter partials of scalar tile 4 (aliases Yv)
+  // segment end: the output tile is staged in LDS (dead A tiles / source rows) and stored by ALL threads as coalesced float4 rows
+  float* __restrict__ OM = Xt;               // [32][128]    scalar tiles 0..3
+  float* __restrict__ OQ = OM + 32 * 128;    // [4][32][32]  the four K-quarter partials of scalar tile 4
+  float* __restrict__ OP = OQ + 4 * 32 * 32; // [32][96]     vector planes from the matrix waves
+  float* __restrict__ OL = xs;               // [32][96]     vector rows accumulated by the forming waves (T term)
 
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = RFL(tid >> 6);
+  const int tid0 = threadIdx.x, lane0 = tid0 & 63;
+  const int wave = RFL(tid0 >> 6);
   const bool is_mat = wave < 4;
   const int PMAX = a.PMAX;
+  const bool dbg_noform = a.dbg & 1, dbg_nomfma = a.dbg & 2;
+  unsigned long long st_acc[6] = {0, 0, 0, 0, 0, 0}, ta = 0, tb = 0;
+  (void)st_acc; (void)ta; (void)tb;
 
   for (int sgi = 0; sgi < a.max_segs; ++sgi) {
     const int4 sg0 = a.segs[((size_t)blockIdx.x * a.max_segs + sgi) * 2];
     const int4 sg1 = a.segs[((size_t)blockIdx.x * a.max_segs + sgi) * 2 + 1];
     const int tile = RFL(sg0.x);
     if (tile < 0) break;
+    // Everything derived from the lane id is recomputed per segment: an opaque copy keeps the compiler from hoisting dozens of
+    // lane-only address expressions out of this loop and spilling them (each reload then costs a full memory round trip).
+    int lane = lane0;
+    asm volatile("" : "+v"(lane));
+    const int tid = wave * 64 + lane;
     const int slab = RFL(sg0.y), k_begin = RFL(sg0.z), k_run = RFL(sg0.w) - k_begin, k_extra = RFL(sg1.x);
     const int nk = k_run + (k_extra >= 0 ? 1 : 0);
     auto k_of = [&](int kk) { kk = kk < 0 ? 0 : (kk < nk ? kk : nk - 1); return kk < k_run ? k_begin + kk : k_extra; };
@@ -86,21 +111,22 @@ __global__ __launch_bounds__(DG_THREADS) void k_conv_dg(DgArgs a) {
     const int s_lo = RFL(span.x), rows = RFL(span.y) - s_lo;
     const int rows16 = (rows + 15) & ~15;   // rows of the T product (multiples of the 16-row MFMA tile), <= RS
     const int n_rt = rows16 >> 4;
+    DSTAMP(ta);
 
-    // ---- segment prologue: source rows -> LDS (x1 re-laid as [u][4]); zero the A tiles and the T columns
+    // ---- segment prologue: source rows -> LDS (x1 re-laid as [u][4] with the T slot second); zero the A tiles
     for (int idx = tid; idx < rows16 * (DG_XST / 4); idx += DG_THREADS) {
       const int j = idx / (DG_XST / 4), q = idx - j * (DG_XST / 4);
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
       if (j < rows) {
         const float* __restrict__ xr = a.x + (size_t)(s_lo + j) * a.XS;
         if (q < 30) v = *reinterpret_cast<const float4*>(xr + 4 * q);             // x0 (120 = 30 x 4)
-        else if (q < 62) { const float* p = xr + 120 + 3 * (q - 30); v = make_float4(p[0], p[1], p[2], 0.f); }  // x1[u] -> (x, y, z, 0)
+        else if (q < 62) { const float* p = xr + 120 + 3 * (q - 30); v = make_float4(p[0], 0.f, p[1], p[2]); }  // x1[u] -> (x, T = 0, y, z)
       }
       *reinterpret_cast<float4*>(xs + (size_t)j * DG_XST + 4 * q) = v;
     }
     for (int idx = tid; idx < 32 * DG_XS0 + 8 + 32 * DG_YD + 3 * 32 * DG_YV; idx += DG_THREADS) Xt[idx] = 0.f;
     if (tid < 32) deg_lds[tid] = (tid < n_dst) ? a.deg[n0 + tid] : 0;
-    __syncthreads();
+    LDS_BARRIER();  // (LDS-only: the previous segment's slab stores keep draining in the background)
 
     if (is_mat) {
       // =========================================== MATRIX waves ===========================================
@@ -133,21 +159,26 @@ __global__ __launch_bounds__(DG_THREADS) void k_conv_dg(DgArgs a) {
         for (int i = 0; i < 4; ++i) B[i] = WX(k, w, (4 * c + i) < 15 ? 4 * c + i : 15);
         B[4] = WX(k, 4, 4 * c + w);  // group 15 (wave 3, chunk 3) is a zero block
       };
+      // (A fragments are requested one group ahead of the MFMAs that consume them: a 32x32x2 MFMA leaves the pipe after 64
+      // cycles, an LDS read under load takes longer, so reading right before use leaves the matrix pipe idle at every group)
       auto run_x = [&](const float4 (&B)[5], int c) {
+        if (dbg_nomfma) return;
+        float4 av = *reinterpret_cast<const float4*>(Xa + 8 * (4 * c));
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           if (4 * c + i >= 15) break;
-          const float4 av = *reinterpret_cast<const float4*>(Xa + 8 * (4 * c + i));
+          const int gn = (i < 3 && 4 * c + i + 1 < 15) ? 4 * c + i + 1 : 4 * c + w;  // next main group, or this wave's quarter group
+          const float4 an = *reinterpret_cast<const float4*>(Xa + 8 * gn);
           accM = MFMA32(av.x, B[i].x, accM);
           accM = MFMA32(av.y, B[i].y, accM);
           accM = MFMA32(av.z, B[i].z, accM);
           accM = MFMA32(av.w, B[i].w, accM);
+          av = an;
         }
-        const float4 aq = *reinterpret_cast<const float4*>(Xa + 8 * (4 * c + w));
-        acc4 = MFMA32(aq.x, B[4].x, acc4);
-        acc4 = MFMA32(aq.y, B[4].y, acc4);
-        acc4 = MFMA32(aq.z, B[4].z, acc4);
-        acc4 = MFMA32(aq.w, B[4].w, acc4);
+        acc4 = MFMA32(av.x, B[4].x, acc4);
+        acc4 = MFMA32(av.y, B[4].y, acc4);
+        acc4 = MFMA32(av.z, B[4].z, acc4);
+        acc4 = MFMA32(av.w, B[4].w, acc4);
       };
       auto load_d = [&](float4 (&B)[5], int k) {
 #pragma unroll
@@ -155,30 +186,35 @@ __global__ __launch_bounds__(DG_THREADS) void k_conv_dg(DgArgs a) {
         B[4] = WD(k, 4, w);
       };
       auto run_d = [&](const float4 (&B)[5]) {
-        const float4 aq = *reinterpret_cast<const float4*>(Da + 8 * w);  // this wave's K quarter of scalar tile 4: group w
+        if (dbg_nomfma) return;
+        float4 av = *reinterpret_cast<const float4*>(Da);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          const float4 av = *reinterpret_cast<const float4*>(Da + 8 * i);
+          const float4 an = *reinterpret_cast<const float4*>(Da + 8 * (i < 3 ? i + 1 : w));  // (last: this wave's K quarter of scalar tile 4)
           accM = MFMA32(av.x, B[i].x, accM);
           accM = MFMA32(av.y, B[i].y, accM);
           accM = MFMA32(av.z, B[i].z, accM);
           accM = MFMA32(av.w, B[i].w, accM);
+          av = an;
         }
-        acc4 = MFMA32(aq.x, B[4].x, acc4);
-        acc4 = MFMA32(aq.y, B[4].y, acc4);
-        acc4 = MFMA32(aq.z, B[4].z, acc4);
-        acc4 = MFMA32(aq.w, B[4].w, acc4);
+        acc4 = MFMA32(av.x, B[4].x, acc4);
+        acc4 = MFMA32(av.y, B[4].y, acc4);
+        acc4 = MFMA32(av.z, B[4].z, acc4);
+        acc4 = MFMA32(av.w, B[4].w, acc4);
       };
       auto load_v = [&](float4 (&B)[5], int k) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) B[i] = WV(k, ch, i);
       };
       auto run_v = [&](const float4 (&B)[5]) {
+        if (dbg_nomfma) return;
+        float4 av[3], an[3];
+#pragma unroll
+        for (int m = 0; m < 3; ++m) av[m] = *reinterpret_cast<const float4*>(Va + m * 32 * DG_YV);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          float4 av[3];
 #pragma unroll
-          for (int m = 0; m < 3; ++m) av[m] = *reinterpret_cast<const float4*>(Va + m * 32 * DG_YV + 16 * i);
+          for (int m = 0; m < 3; ++m) an[m] = *reinterpret_cast<const float4*>(Va + m * 32 * DG_YV + 16 * (i < 3 ? i + 1 : 3));
 #pragma unroll
           for (int m = 0; m < 3; ++m) accP[m] = MFMA16(av[m].x, B[i].x, accP[m]);
 #pragma unroll
@@ -187,6 +223,8 @@ __global__ __launch_bounds__(DG_THREADS) void k_conv_dg(DgArgs a) {
           for (int m = 0; m < 3; ++m) accP[m] = MFMA16(av[m].z, B[i].z, accP[m]);
 #pragma unroll
           for (int m = 0; m < 3; ++m) accP[m] = MFMA16(av[m].w, B[i].w, accP[m]);
+#pragma unroll
+          for (int m = 0; m < 3; ++m) av[m] = an[m];
         }
       };
       // T product of hidden unit k: T[j][w'] = sum_u x0_j[u] W[(k,u)][w'], row tiles rt = w, w + 4 (16 rows each), both
@@ -197,13 +235,17 @@ __global__ __launch_bounds__(DG_THREADS) void k_conv_dg(DgArgs a) {
         for (int i = 0; i < 4; ++i) B[i] = WT(k, 2 * c + (i >> 1), i & 1);
       };
       auto run_t = [&](const float4 (&B)[5], int c) {
+        if (dbg_nomfma) return;
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
           if (w + 4 * p >= n_rt) break;  // wave-uniform
           const float* __restrict__ Ta = xs + (size_t)(16 * (w + 4 * p) + r16) * DG_XST + 4 * kq;
+          float4 avs[2];
+#pragma unroll
+          for (int gi = 0; gi < 2; ++gi) avs[gi] = *reinterpret_cast<const float4*>(Ta + 16 * (2 * c + gi));  // both groups up front
 #pragma unroll
           for (int gi = 0; gi < 2; ++gi) {
-            const float4 av = *reinterpret_cast<const float4*>(Ta + 16 * (2 * c + gi));
+            const float4 av = avs[gi];
             accT[p][0] = MFMA16(av.x, B[2 * gi].x, accT[p][0]);
             accT[p][1] = MFMA16(av.x, B[2 * gi + 1].x, accT[p][1]);
             accT[p][0] = MFMA16(av.y, B[2 * gi].y, accT[p][0]);
@@ -221,14 +263,14 @@ __global__ __launch_bounds__(DG_THREADS) void k_conv_dg(DgArgs a) {
 #pragma unroll
           for (int c = 0; c < 2; ++c) accT[p][c] = f32x4{0.f, 0.f, 0.f, 0.f};
       };
-      auto store_t = [&]() {  // D[row = 4 kq + q][col = r16] of each 16x16 sub-tile -> xs[row][248 + col]
+      auto store_t = [&]() {  // D[row = 4 kq + q][col = r16] of each 16x16 sub-tile -> slot 1 of xs[row][120 + 4 col ..]
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
           if (w + 4 * p >= n_rt) break;
 #pragma unroll
           for (int c = 0; c < 2; ++c)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) xs[(size_t)(16 * (w + 4 * p) + 4 * kq + q) * DG_XST + 248 + 16 * c + r16] = accT[p][c][q];
+            for (int q = 0; q < 4; ++q) xs[(size_t)(16 * (w + 4 * p) + 4 * kq + q) * DG_XST + 120 + 4 * (16 * c + r16) + 1] = accT[p][c][q];
         }
       };
       // (row tiles beyond w + 4 — spans above 128 rows — do not occur: the host caps the span at RS <= 128)
@@ -259,15 +301,19 @@ __global__ __launch_bounds__(DG_THREADS) void k_conv_dg(DgArgs a) {
         store_t();
       }
       LDS_BARRIER();
+      DSTAMP(tb); DACC(0, tb, ta);
       for (int it = 0; it < nk; ++it) {
         const int k = k_of(it), kn = k_of(it + 1);
+        DSTAMP(ta);
         const bool has_next = it + 1 < nk;
         // ---- P1: X(k) x W  (B0 = chunk 0, B1 = chunk 1 already in flight)
         run_x(B0, 0); load_x(B0, k, 2);
         run_x(B1, 1); load_x(B1, k, 3);
         run_x(B0, 2); load_d(B0, k);
         run_x(B1, 3); load_v(B1, k);
+        DSTAMP(tb); DACC(1, tb, ta);
         LDS_BARRIER();
+        DSTAMP(ta); DACC(2, ta, tb);
         // ---- P2: Y(k) x W, then T(k+1)
         run_d(B0); load_t(B0, kn, 0);
         run_v(B1); load_t(B1, kn, 1);
@@ -279,49 +325,37 @@ __global__ __launch_bounds__(DG_THREADS) void k_conv_dg(DgArgs a) {
           run_t(B1, 3); load_x(B1, kn, 1);
           store_t();
         }
+        DSTAMP(tb); DACC(3, tb, ta);
         LDS_BARRIER();
+        DSTAMP(ta); DACC(4, ta, tb);
       }
-      // ---- segment end: scalar tile w straight to the slab; tile 4 and the vector planes through LDS
+      DSTAMP(ta);
+      // ---- segment end: accumulators -> LDS staging tile (the A tiles are dead after the last barrier)
 #pragma unroll
       for (int q = 0; q < 16; ++q) {
         const int row = (q & 3) + 8 * (q >> 2) + 4 * hh;
-        if (row < n_dst) a.partial0[((size_t)slab * a.n_pad + n0 + row) * (a.nt0 * 32) + w * 32 + r] = accM[q];
-      }
-#pragma unroll
-      for (int q = 0; q < 16; ++q) QL[(w * 16 + q) * 64 + lane] = acc4[q];
-      __syncthreads();  // (forming waves have written OL)
-#pragma unroll
-      for (int qq = 0; qq < 4; ++qq) {  // wave w sums registers 4w..4w+3 of the four partials, in wave order
-        const int q = 4 * w + qq;
-        float s = QL[(0 * 16 + q) * 64 + lane];
-        s += QL[(1 * 16 + q) * 64 + lane];
-        s += QL[(2 * 16 + q) * 64 + lane];
-        s += QL[(3 * 16 + q) * 64 + lane];
-        const int row = (q & 3) + 8 * (q >> 2) + 4 * hh;
-        if (row < n_dst && 4 * 32 + r < a.nt0 * 32) a.partial0[((size_t)slab * a.n_pad + n0 + row) * (a.nt0 * 32) + 4 * 32 + r] = s;
+        OM[row * 128 + w * 32 + r] = accM[q];
+        OQ[(w * 32 + row) * 32 + r] = acc4[q];
       }
 #pragma unroll
       for (int m = 0; m < 3; ++m)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int row = 16 * rh + 4 * kq + q, col = 16 * ch + r16;
-          if (row < n_dst) a.partial1[(((size_t)slab * a.n_pad + n0 + row) * 3 + m) * 32 + col] = accP[m][q] + OL[(m * 32 + row) * 32 + col];
-        }
-      __syncthreads();  // the next segment rewrites the tiles
+        for (int q = 0; q < 4; ++q) OP[(16 * rh + 4 * kq + q) * 96 + m * 32 + 16 * ch + r16] = accP[m][q];
+      DSTAMP(tb); DACC(5, tb, ta);
     } else {
       // =========================================== FORMING waves ===========================================
-      const int fw = wave - 4;                    // 0..7: destinations 4 fw .. 4 fw + 3
+      const int fw = wave - 4;                    // forming wave index: destinations 2 DG_NDP fw .. 2 DG_NDP (fw + 1) - 1
       const int h = lane >> 5, u = lane & 31;
       // per destination pair dp: this lane's edge slots t = u (page 0) and u + 32 (page 1) of destination i = 4 fw + 2 dp + h
-      float evx[2][2], evy[2][2], evz[2][2];
-      int hidx[2][2];
-      int P[2];
+      float evx[DG_NDP][2], evy[DG_NDP][2], evz[DG_NDP][2];
+      int hidx[DG_NDP][2];
+      int P[DG_NDP];
       const bool two_pages = a.S > 32;
 #pragma unroll
-      for (int dp = 0; dp < 2; ++dp) {
-        const int i = 4 * fw + 2 * dp + h;
+      for (int dp = 0; dp < DG_NDP; ++dp) {
+        const int i = 2 * DG_NDP * fw + 2 * dp + h;
         const int dg = deg_lds[i];
-        P[dp] = RFL(max(deg_lds[4 * fw + 2 * dp], deg_lds[4 * fw + 2 * dp + 1]));
+        P[dp] = RFL(max(deg_lds[2 * DG_NDP * fw + 2 * dp], deg_lds[2 * DG_NDP * fw + 2 * dp + 1]));
 #pragma unroll
         for (int pg = 0; pg < 2; ++pg) {
           evx[dp][pg] = evy[dp][pg] = evz[dp][pg] = 0.f;
@@ -336,7 +370,7 @@ __global__ __launch_bounds__(DG_THREADS) void k_conv_dg(DgArgs a) {
               const float4 ge = a.egeo[slot];
               evx[dp][pg] = ge.x; evy[dp][pg] = ge.y; evz[dp][pg] = ge.z;
               hidx[dp][pg] = slot;
-              jofs = jl * DG_XST * 4;
+              jofs = jl * DG_XST * 4;  // byte offset of the source row inside xs
             }
           }
           if (t < PMAX) tabJ[i * PMAX + t] = jofs;
@@ -345,7 +379,7 @@ __global__ __launch_bounds__(DG_THREADS) void k_conv_dg(DgArgs a) {
       // A tile of a large molecule (destination chunk x source row block) may have no edge at all: checked below by all waves
       int any_edge = 0;
 #pragma unroll
-      for (int dp = 0; dp < 2; ++dp)
+      for (int dp = 0; dp < DG_NDP; ++dp)
 #pragma unroll
         for (int pg = 0; pg < 2; ++pg) any_edge |= hidx[dp][pg] >= 0;
       if (a.row_blocks && !__syncthreads_or(any_edge)) {  // (only batches with row-block tiles pay for the vote)
@@ -353,21 +387,21 @@ __global__ __launch_bounds__(DG_THREADS) void k_conv_dg(DgArgs a) {
         continue;
       }
 
-      float O[2][3];  // vector rows from scalar inputs, accumulated over the hidden units of the segment: lane = (h, w' = u)
+      float O[DG_NDP][3];  // vector rows from scalar inputs, accumulated over the hidden units of the segment: lane = (h, w' = u)
 #pragma unroll
-      for (int dp = 0; dp < 2; ++dp) O[dp][0] = O[dp][1] = O[dp][2] = 0.f;
-      float hv[2][2];  // h~ of this lane's edges for the NEXT hidden unit (prefetched)
+      for (int dp = 0; dp < DG_NDP; ++dp) O[dp][0] = O[dp][1] = O[dp][2] = 0.f;
+      float hv[DG_NDP][2];  // h~ of this lane's edges for the NEXT hidden unit (prefetched)
       auto load_h = [&](int k) {
         const float* __restrict__ hk = a.h + (size_t)k * a.h_kstride;
 #pragma unroll
-        for (int dp = 0; dp < 2; ++dp)
+        for (int dp = 0; dp < DG_NDP; ++dp)
 #pragma unroll
           for (int pg = 0; pg < 2; ++pg) hv[dp][pg] = hk[hidx[dp][pg] >= 0 ? hidx[dp][pg] : n0 * a.S];
       };
       auto write_tab = [&]() {  // coefficients of the prefetched hidden unit -> this wave's private table rows
 #pragma unroll
-        for (int dp = 0; dp < 2; ++dp) {
-          const int i = 4 * fw + 2 * dp + h;
+        for (int dp = 0; dp < DG_NDP; ++dp) {
+          const int i = 2 * DG_NDP * fw + 2 * dp + h;
 #pragma unroll
           for (int pg = 0; pg < 2; ++pg) {
             if (pg == 1 && !two_pages) continue;
@@ -378,52 +412,120 @@ __global__ __launch_bounds__(DG_THREADS) void k_conv_dg(DgArgs a) {
         }
       };
       const char* __restrict__ xsb = reinterpret_cast<const char*>(xs);
+      // The edge loops run in batches of DG_U edges, software pipelined by one batch: while the FMAs of batch b issue, the
+      // coefficients and source-row fragments of batch b+1 and the row offsets of batch b+2 are in flight.  Table entries past
+      // a destination's degree are zero (PMAX is a multiple of DG_U), so the loads are unconditional and the tail batch needs
+      // no predicate.  The VALU of a SIMD issues one wave64 instruction per 4 cycles and the two forming waves of a SIMD
+      // saturate it, so the arithmetic is written as PACKED FMAs (v_pk_fma_f32: two products per lane per instruction) on the
+      // register pairs the loads deliver: coefficients (c, c vx | c vy, c vz), row fragment (x, T | y, z) — 15 products per edge
+      // in 7 packed + 1 scalar FMA with no sign flips inside the loop (negative terms have their own accumulators), and one address add per edge and phase.
+      auto pk = [](f32x2 a2, f32x2 b2, f32x2 c2) -> f32x2 { return __builtin_elementwise_fma(a2, b2, c2); };
+      const int offx = u * 16, offy = 480 + u * 16;
       // X(k): scalar inputs, lanes u < 30 own channels 4u..4u+3 (lanes 30, 31 compute on x1 data and are not stored)
       auto form_x = [&]() {
 #pragma unroll
-        for (int dp = 0; dp < 2; ++dp) {
-          const int i = 4 * fw + 2 * dp + h;
-          float ax0 = 0.f, ax1 = 0.f, ax2 = 0.f, ax3 = 0.f;
+        for (int dp = 0; dp < DG_NDP; ++dp) {
+          const int i = 2 * DG_NDP * fw + 2 * dp + h;
+          f32x2 ax01 = {0.f, 0.f}, ax23 = {0.f, 0.f};
           const float4* __restrict__ ta = tabA + i * PMAX;
           const int* __restrict__ tj = tabJ + i * PMAX;
-          const int n = P[dp];
-#pragma unroll 2
-          for (int t = 0; t < n; ++t) {
-            const float c = ta[t].x;
-            const float4 xv = *reinterpret_cast<const float4*>(xsb + tj[t] + u * 16);
-            ax0 = fmaf(c, xv.x, ax0); ax1 = fmaf(c, xv.y, ax1); ax2 = fmaf(c, xv.z, ax2); ax3 = fmaf(c, xv.w, ax3);
+          const int nb = dbg_noform ? 0 : (P[dp] + DG_U - 1) / DG_U;
+          float cA[DG_U], cB[DG_U];
+          float4 xA[DG_U], xB[DG_U];
+          int jA[DG_U], jB[DG_U];
+          auto ld_j = [&](int (&J)[DG_U], int bb) {
+            bb = bb < nb ? bb : nb - 1;
+#pragma unroll
+            for (int q = 0; q < DG_U; ++q) J[q] = tj[DG_U * bb + q];
+          };
+          auto ld_cx = [&](float (&c)[DG_U], float4 (&x)[DG_U], const int (&J)[DG_U], int bb) {
+            bb = bb < nb ? bb : nb - 1;
+#pragma unroll
+            for (int q = 0; q < DG_U; ++q) {
+              c[q] = ta[DG_U * bb + q].x;
+              x[q] = *reinterpret_cast<const float4*>(xsb + (J[q] + offx));
+            }
+          };
+          auto fm = [&](const float (&c)[DG_U], const float4 (&x)[DG_U]) {
+#pragma unroll
+            for (int q = 0; q < DG_U; ++q) {
+              const f32x2 cc = {c[q], c[q]};
+              ax01 = pk(cc, f32x2{x[q].x, x[q].y}, ax01);
+              ax23 = pk(cc, f32x2{x[q].z, x[q].w}, ax23);
+            }
+          };
+          if (nb > 0) {
+            ld_j(jA, 0); ld_cx(cA, xA, jA, 0); ld_j(jB, 1);
+            for (int bb = 0; bb < nb; bb += 2) {
+              ld_cx(cB, xB, jB, bb + 1); ld_j(jA, bb + 2);
+              fm(cA, xA);
+              if (bb + 1 < nb) {
+                ld_cx(cA, xA, jA, bb + 2); ld_j(jB, bb + 3);
+                fm(cB, xB);
+              }
+            }
           }
-          if (u < 30) *reinterpret_cast<float4*>(Xt + i * DG_XS0 + 4 * u) = make_float4(ax0, ax1, ax2, ax3);
+          if (u < 30) *reinterpret_cast<float4*>(Xt + i * DG_XS0 + 4 * u) = make_float4(ax01.x, ax01.y, ax23.x, ax23.y);
         }
       };
       // Y(k): vector inputs (lane u = channel u) + the T term (lane u = output channel w')
       auto form_y = [&]() {
 #pragma unroll
-        for (int dp = 0; dp < 2; ++dp) {
-          const int i = 4 * fw + 2 * dp + h;
-          float a1x = 0.f, a1y = 0.f, a1z = 0.f, ad = 0.f, acx = 0.f, acy = 0.f, acz = 0.f;
-          float o0 = O[dp][0], o1 = O[dp][1], o2 = O[dp][2];
+        for (int dp = 0; dp < DG_NDP; ++dp) {
+          const int i = 2 * DG_NDP * fw + 2 * dp + h;
+          // accumulator pairs: (a1x, o0) (a1y, a1z) (o1, o2) (d0, d1), scalar d2, and the cross-product terms
+          // n3 = (cx y, cx z), n5 = (cy x, cz x), n7 = (cy z, cz y):  acx = n7.y - n7.x, acy = n3.y - n5.y, acz = n5.x - n3.x
+          f32x2 p_a1x_o0 = {0.f, O[dp][0]}, p_a1yz = {0.f, 0.f}, p_o12 = {O[dp][1], O[dp][2]}, n3 = {0.f, 0.f}, n5 = {0.f, 0.f},
+                n7 = {0.f, 0.f}, p_d = {0.f, 0.f};
+          float d2 = 0.f;
           const float4* __restrict__ ta = tabA + i * PMAX;
           const int* __restrict__ tj = tabJ + i * PMAX;
-          const int n = P[dp];
-#pragma unroll 2
-          for (int t = 0; t < n; ++t) {
-            const float4 cf = ta[t];  // c, c vx, c vy, c vz
-            const char* __restrict__ row = xsb + tj[t];
-            const float4 xv = *reinterpret_cast<const float4*>(row + 480 + u * 16);  // x1_j[u] = (x, y, z, 0)
-            const float tw = *reinterpret_cast<const float*>(row + 992 + u * 4);     // T_k[j][w' = u]
-            a1x = fmaf(cf.x, xv.x, a1x); a1y = fmaf(cf.x, xv.y, a1y); a1z = fmaf(cf.x, xv.z, a1z);
-            ad = fmaf(cf.y, xv.x, ad); ad = fmaf(cf.z, xv.y, ad); ad = fmaf(cf.w, xv.z, ad);
-            // (x1 x v)[m] = x1[m+1] v[m+2] - x1[m+2] v[m+1]
-            acx = fmaf(cf.w, xv.y, acx); acx = fmaf(-cf.z, xv.z, acx);
-            acy = fmaf(cf.y, xv.z, acy); acy = fmaf(-cf.w, xv.x, acy);
-            acz = fmaf(cf.z, xv.x, acz); acz = fmaf(-cf.y, xv.y, acz);
-            o0 = fmaf(cf.y, tw, o0); o1 = fmaf(cf.z, tw, o1); o2 = fmaf(cf.w, tw, o2);
+          const int nb = dbg_noform ? 0 : (P[dp] + DG_U - 1) / DG_U;
+          float4 cA[DG_U], cB[DG_U], xA[DG_U], xB[DG_U];
+          int jA[DG_U], jB[DG_U];
+          auto ld_j = [&](int (&J)[DG_U], int bb) {
+            bb = bb < nb ? bb : nb - 1;
+#pragma unroll
+            for (int q = 0; q < DG_U; ++q) J[q] = tj[DG_U * bb + q];
+          };
+          auto ld_cx = [&](float4 (&c)[DG_U], float4 (&x)[DG_U], const int (&J)[DG_U], int bb) {
+            bb = bb < nb ? bb : nb - 1;
+#pragma unroll
+            for (int q = 0; q < DG_U; ++q) {
+              c[q] = ta[DG_U * bb + q];                                            // c, c vx | c vy, c vz
+              x[q] = *reinterpret_cast<const float4*>(xsb + (J[q] + offy));         // T_k[j][u], x1_j[u].x | .y, .z
+            }
+          };
+          auto fm = [&](const float4 (&c)[DG_U], const float4 (&x)[DG_U]) {
+#pragma unroll
+            for (int q = 0; q < DG_U; ++q) {
+              const float4 cf = c[q], xv = x[q];  // cf = (c, cx | cy, cz), xv = (x, T | y, z)
+              p_a1x_o0 = pk(f32x2{cf.x, cf.y}, f32x2{xv.x, xv.y}, p_a1x_o0);    // (c x, cx T)
+              p_a1yz = pk(f32x2{cf.x, cf.x}, f32x2{xv.z, xv.w}, p_a1yz);        // (c y, c z)
+              p_o12 = pk(f32x2{cf.z, cf.w}, f32x2{xv.y, xv.y}, p_o12);          // (cy T, cz T)
+              n3 = pk(f32x2{cf.y, cf.y}, f32x2{xv.z, xv.w}, n3);                // (cx y, cx z)
+              n5 = pk(f32x2{cf.z, cf.w}, f32x2{xv.x, xv.x}, n5);                // (cy x, cz x)
+              n7 = pk(f32x2{cf.z, cf.w}, f32x2{xv.w, xv.z}, n7);                // (cy z, cz y)
+              p_d = pk(f32x2{cf.z, cf.w}, f32x2{xv.z, xv.w}, p_d);              // (cy y, cz z)
+              d2 = fmaf(cf.y, xv.x, d2);                                          // cx x
+            }
+          };
+          if (nb > 0) {
+            ld_j(jA, 0); ld_cx(cA, xA, jA, 0); ld_j(jB, 1);
+            for (int bb = 0; bb < nb; bb += 2) {
+              ld_cx(cB, xB, jB, bb + 1); ld_j(jA, bb + 2);
+              fm(cA, xA);
+              if (bb + 1 < nb) {
+                ld_cx(cA, xA, jA, bb + 2); ld_j(jB, bb + 3);
+                fm(cB, xB);
+              }
+            }
           }
-          O[dp][0] = o0; O[dp][1] = o1; O[dp][2] = o2;
-          Yd[i * DG_YD + u] = ad;
-          Yv[(0 * 32 + i) * DG_YV + u] = a1x; Yv[(1 * 32 + i) * DG_YV + u] = a1y; Yv[(2 * 32 + i) * DG_YV + u] = a1z;
-          Yv[(0 * 32 + i) * DG_YV + 32 + u] = acx; Yv[(1 * 32 + i) * DG_YV + 32 + u] = acy; Yv[(2 * 32 + i) * DG_YV + 32 + u] = acz;
+          O[dp][0] = p_a1x_o0.y; O[dp][1] = p_o12.x; O[dp][2] = p_o12.y;
+          Yd[i * DG_YD + u] = (p_d.x + p_d.y) + d2;
+          Yv[(0 * 32 + i) * DG_YV + u] = p_a1x_o0.x; Yv[(1 * 32 + i) * DG_YV + u] = p_a1yz.x; Yv[(2 * 32 + i) * DG_YV + u] = p_a1yz.y;
+          // (x1 x v)[m] = x1[m+1] v[m+2] - x1[m+2] v[m+1]
+          Yv[(0 * 32 + i) * DG_YV + 32 + u] = n7.y - n7.x; Yv[(1 * 32 + i) * DG_YV + 32 + u] = n3.y - n5.y; Yv[(2 * 32 + i) * DG_YV + 32 + u] = n5.x - n3.x;
         }
       };
 
@@ -433,29 +535,78 @@ __global__ __launch_bounds__(DG_THREADS) void k_conv_dg(DgArgs a) {
       load_h(k_of(1));
       form_x();
       LDS_BARRIER();
+      DSTAMP(tb); DACC(0, tb, ta);
       for (int it = 0; it < nk; ++it) {
         // ---- P1: Y(k) with the table of k (written in the previous P2) and T(k)
+        DSTAMP(ta);
         form_y();
+        DSTAMP(tb); DACC(1, tb, ta);
         LDS_BARRIER();
+        DSTAMP(ta); DACC(2, ta, tb);
         // ---- P2: table of k+1, X(k+1)
         if (it + 1 < nk) {
           write_tab();
           load_h(k_of(it + 2));
           form_x();
         }
+        DSTAMP(tb); DACC(3, tb, ta);
         LDS_BARRIER();
+        DSTAMP(ta); DACC(4, ta, tb);
       }
-      // ---- segment end: hand the accumulated vector rows to the plane owners (OL aliases X / Yd: dead after the last barrier)
+      DSTAMP(ta);
+      // ---- segment end: the accumulated vector rows (T term) join the staging tile (OL aliases the source rows: dead by now)
 #pragma unroll
-      for (int dp = 0; dp < 2; ++dp) {
-        const int i = 4 * fw + 2 * dp + h;
+      for (int dp = 0; dp < DG_NDP; ++dp) {
+        const int i = 2 * DG_NDP * fw + 2 * dp + h;
 #pragma unroll
-        for (int m = 0; m < 3; ++m) OL[(m * 32 + i) * 32 + u] = O[dp][m];
+        for (int m = 0; m < 3; ++m) OL[i * 96 + m * 32 + u] = O[dp][m];
       }
-      __syncthreads();
-      __syncthreads();
+      DSTAMP(tb); DACC(5, tb, ta);
     }
+    // ---- all threads: staged tile -> partial slab of this segment, coalesced 16-byte stores in fixed summation order
+    LDS_BARRIER();
+    {
+      float* __restrict__ p0 = a.partial0 + ((size_t)slab * a.n_pad + n0) * (size_t)(a.nt0 * 32);
+      float* __restrict__ p1 = a.partial1 + ((size_t)slab * a.n_pad + n0) * 96;
+      for (int idx = tid; idx < 32 * 40; idx += DG_THREADS) {
+        const int row = idx / 40, c4 = idx - row * 40;
+        float4 v;
+        if (c4 < 32) v = *reinterpret_cast<const float4*>(OM + row * 128 + 4 * c4);
+        else {
+          const float* __restrict__ q0 = OQ + row * 32 + 4 * (c4 - 32);
+          const float4 a0 = *reinterpret_cast<const float4*>(q0), a1 = *reinterpret_cast<const float4*>(q0 + 1024),
+                       a2 = *reinterpret_cast<const float4*>(q0 + 2048), a3 = *reinterpret_cast<const float4*>(q0 + 3072);
+          v = make_float4(((a0.x + a1.x) + a2.x) + a3.x, ((a0.y + a1.y) + a2.y) + a3.y, ((a0.z + a1.z) + a2.z) + a3.z,
+                          ((a0.w + a1.w) + a2.w) + a3.w);
+        }
+        if (row < n_dst) *reinterpret_cast<float4*>(p0 + row * 160 + 4 * c4) = v;
+      }
+      for (int idx = tid; idx < 32 * 24; idx += DG_THREADS) {
+        const int row = idx / 24, c4 = idx - row * 24;
+        const float4 pv = *reinterpret_cast<const float4*>(OP + row * 96 + 4 * c4), ov = *reinterpret_cast<const float4*>(OL + row * 96 + 4 * c4);
+        if (row < n_dst) *reinterpret_cast<float4*>(p1 + row * 96 + 4 * c4) = make_float4(pv.x + ov.x, pv.y + ov.y, pv.z + ov.z, pv.w + ov.w);
+      }
+    }
+    LDS_BARRIER();  // the next segment rewrites the tiles
   }
+#ifdef JAMUN_STAMP
+  if (lane0 == 0)
+    for (int i = 0; i < 6; ++i) atomicAdd(&g_dgstamp[is_mat ? 0 : 1][i], st_acc[i]);
+#endif
+}
+
+void conv_dg_print_stamps() {
+#ifdef JAMUN_STAMP
+  unsigned long long v[2][8], z[2][8] = {};
+  if (hipMemcpyFromSymbol(v, HIP_SYMBOL(g_dgstamp), sizeof(v)) != hipSuccess) return;
+  const char* names[6] = {"prologue", "P1 work", "P1 wait", "P2 work", "P2 wait", "epilogue"};
+  for (int r = 0; r < 2; ++r) {
+    fprintf(stderr, "dg stamps %s waves (cycles summed over waves):", r == 0 ? "matrix" : "forming");
+    for (int i = 0; i < 6; ++i) fprintf(stderr, " %s %llu", names[i], v[r][i]);
+    fprintf(stderr, "\n");
+  }
+  (void)hipMemcpyToSymbol(HIP_SYMBOL(g_dgstamp), z, sizeof(z));
+#endif
 }
 
 size_t conv_dg_lds_bytes(int rs, int pmax) { return sizeof(float) * ((dg_lds_floats(rs, pmax) + 3) & ~(size_t)3); }
