@@ -157,6 +157,20 @@ def secondary_rooflines(dev):
     from jamun_amd import native
 
     out = []
+    params = native.make_mcmc_params(2, **MCMC)
+    # the Langevin update at a size where it is bandwidth- and not launch-bound (the bench shape, 4352 atoms = 0.3 MB per launch,
+    # is pure launch latency; the path fuses nothing around it yet)
+    n_big = 1 << 22
+    y, v, psi, R, sc = (torch.randn(n_big, 3, device=dev) for _ in range(5))
+    dt = _time_launches(lambda: native.baoab_pre(y, v, psi, R, params), 20)
+    b = n_big * 3 * 4 * 6
+    out.append({"kernel": "k_baoab_pre", "shape": f"{n_big} atoms (bandwidth-bound size; host-supplied noise)", "bound": "hbm", "bytes": b,
+                "avg_launch_ms": dt * 1e3, "achieved": b / dt / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": b / dt / 1e9 / HBM_PEAK_GBS})
+    dt = _time_launches(lambda: native.baoab_post(v, psi, sc, params), 20)
+    b = n_big * 3 * 4 * 4
+    out.append({"kernel": "k_baoab_post", "shape": f"{n_big} atoms (bandwidth-bound size; no frame save)", "bound": "hbm", "bytes": b,
+                "avg_launch_ms": dt * 1e3, "achieved": b / dt / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": b / dt / 1e9 / HBM_PEAK_GBS})
+    del y, v, psi, R, sc
     for walkers in (256, 2048):
         n, deg = walkers * 17, 17
         E = n * deg
@@ -175,15 +189,14 @@ def secondary_rooflines(dev):
                     "bound": "hbm", "bytes": nbytes, "avg_launch_ms": dt * 1e3, "achieved": nbytes / dt / 1e9, "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": nbytes / dt / 1e9 / HBM_PEAK_GBS})
         del srcs
-        params = native.make_mcmc_params(2, **MCMC)
         y, v, psi, R, sc = (torch.randn(n, 3, device=dev) for _ in range(5))
         dt = _time_launches(lambda: native.baoab_pre(y, v, psi, R, params), 200)
         b = n * 3 * 4 * 6  # read y, v, psi, noise (parity mode); write y, v
-        out.append({"kernel": "k_baoab_pre", "shape": f"{walkers} walkers x 17 atoms (host-supplied noise: +12 B/atom read)", "bound": "hbm",
+        out.append({"kernel": "k_baoab_pre", "shape": f"{walkers} walkers x 17 atoms (launch-latency-bound at this size; host-supplied noise: +12 B/atom read)", "bound": "hbm",
                     "bytes": b, "avg_launch_ms": dt * 1e3, "achieved": b / dt / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": b / dt / 1e9 / HBM_PEAK_GBS})
         dt = _time_launches(lambda: native.baoab_post(v, psi, sc, params), 200)
         b = n * 3 * 4 * 4  # read v, score; write v, psi
-        out.append({"kernel": "k_baoab_post", "shape": f"{walkers} walkers x 17 atoms (no frame save)", "bound": "hbm",
+        out.append({"kernel": "k_baoab_post", "shape": f"{walkers} walkers x 17 atoms (launch-latency-bound at this size; no frame save)", "bound": "hbm",
                     "bytes": b, "avg_launch_ms": dt * 1e3, "achieved": b / dt / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": b / dt / 1e9 / HBM_PEAK_GBS})
     return out
 
@@ -406,7 +419,7 @@ def main():
             # HBM-side bytes per launch from the committed PMC passes of the cfg2 command (profiles/collect.sh); rocprofv3
             # cannot run inside the timed process, so the newest committed summary is quoted, with its file name
             if args.config == "cfg2" and args.atoms is None and args.walkers is None:
-                tr = _pmc_traffic("k_conv")
+                tr = _pmc_traffic({2: "k_conv_dg", 1: "k_conv_fused"}.get(stats["conv_path"], "k_conv<"))
                 if tr is not None:
                     out["roofline"]["traffic"] = tr[0]
                     out["roofline"]["traffic_source"] = tr[1]

@@ -349,13 +349,15 @@ __global__ __launch_bounds__(DG_THREADS) void k_conv_dg(DgArgs a) {
       // per destination pair dp: this lane's edge slots t = u (page 0) and u + 32 (page 1) of destination i = 4 fw + 2 dp + h
       float evx[DG_NDP][2], evy[DG_NDP][2], evz[DG_NDP][2];
       int hidx[DG_NDP][2];
+      int hidx2[DG_NDP];  // page 0 only: slot of the bonded edge merged into this lane's radial edge (same source), or -1
       int P[DG_NDP];
       const bool two_pages = a.S > 32;
 #pragma unroll
       for (int dp = 0; dp < DG_NDP; ++dp) {
         const int i = 2 * DG_NDP * fw + 2 * dp + h;
         const int dg = deg_lds[i];
-        P[dp] = RFL(max(deg_lds[2 * DG_NDP * fw + 2 * dp], deg_lds[2 * DG_NDP * fw + 2 * dp + 1]));
+        hidx2[dp] = -1;
+        int sj0 = 0;
 #pragma unroll
         for (int pg = 0; pg < 2; ++pg) {
           evx[dp][pg] = evy[dp][pg] = evz[dp][pg] = 0.f;
@@ -365,7 +367,9 @@ __global__ __launch_bounds__(DG_THREADS) void k_conv_dg(DgArgs a) {
           int jofs = 0;
           if (t < dg) {
             const int slot = (n0 + i) * a.S + t;
-            const int jl = (a.esrc[slot] & 0x7fffffff) - s_lo;
+            const int sj = a.esrc[slot];
+            if (pg == 0) sj0 = sj;
+            const int jl = (sj & 0x7fffffff) - s_lo;
             if (jl >= 0 && jl < rows) {  // (a source outside the span belongs to another row-block tile of these destinations)
               const float4 ge = a.egeo[slot];
               evx[dp][pg] = ge.x; evy[dp][pg] = ge.y; evz[dp][pg] = ge.z;
@@ -374,6 +378,32 @@ __global__ __launch_bounds__(DG_THREADS) void k_conv_dg(DgArgs a) {
             }
           }
           if (t < PMAX) tabJ[i * PMAX + t] = jofs;
+        }
+        if (!two_pages) {
+          // A bonded pair inside the cutoff appears twice in the edge table (radial edge + bonded edge, same source and unit
+          // vector; src/jamun/model/denoiser.py:152): the bonded edge is folded into its radial twin (coefficients add), which
+          // shortens the edge loops — for a 17-atom molecule from 17 slots (5 batches of DG_U) to 16 (4 batches).  The bonded
+          // in-edges are the LAST slots of a destination (k_geom), so their lanes are dg - nb .. dg - 1 of the half.
+          const bool is_b = u < dg && sj0 < 0;  // bit 31 = bonded
+          const unsigned long long bal = __ballot(is_b);
+          const int nb = __popc((unsigned)(bal >> (32 * h)));
+          const int nb_max = RFL(max(__popc((unsigned)bal), __popc((unsigned)(bal >> 32))));
+          const int jraw = sj0 & 0x7fffffff;
+          bool merged = false;
+          for (int b = 0; b < nb_max; ++b) {
+            const int lb = dg - nb + b;  // lane (slot) of this half's b-th bonded edge
+            const int jb = __shfl(jraw, lb & 31, 32);
+            const bool match = b < nb && u < dg && !is_b && jraw == jb && hidx[dp][0] >= 0 && hidx2[dp] < 0;  // (a second bond of the same pair stays its own edge)
+            if (match) hidx2[dp] = (n0 + i) * a.S + lb;
+            const unsigned long long mb = __ballot(match);
+            if (is_b && u == lb && (unsigned)(mb >> (32 * h)) != 0u) merged = true;
+          }
+          if (merged) hidx[dp][0] = -1;  // (its table entry becomes zero; its geometry is the twin's)
+          const unsigned long long act = __ballot(hidx[dp][0] >= 0);
+          const int p_lo = 32 - __clz((unsigned)act), p_hi = 32 - __clz((unsigned)(act >> 32));  // __clz(0) = 32
+          P[dp] = RFL(max(p_lo, p_hi));
+        } else {
+          P[dp] = RFL(max(deg_lds[2 * DG_NDP * fw + 2 * dp], deg_lds[2 * DG_NDP * fw + 2 * dp + 1]));
         }
       }
       // A tile of a large molecule (destination chunk x source row block) may have no edge at all: checked below by all waves
@@ -391,12 +421,15 @@ __global__ __launch_bounds__(DG_THREADS) void k_conv_dg(DgArgs a) {
 #pragma unroll
       for (int dp = 0; dp < DG_NDP; ++dp) O[dp][0] = O[dp][1] = O[dp][2] = 0.f;
       float hv[DG_NDP][2];  // h~ of this lane's edges for the NEXT hidden unit (prefetched)
+      float hv2[DG_NDP];
       auto load_h = [&](int k) {
         const float* __restrict__ hk = a.h + (size_t)k * a.h_kstride;
 #pragma unroll
-        for (int dp = 0; dp < DG_NDP; ++dp)
+        for (int dp = 0; dp < DG_NDP; ++dp) {
 #pragma unroll
           for (int pg = 0; pg < 2; ++pg) hv[dp][pg] = hk[hidx[dp][pg] >= 0 ? hidx[dp][pg] : n0 * a.S];
+          hv2[dp] = hk[hidx2[dp] >= 0 ? hidx2[dp] : n0 * a.S];
+        }
       };
       auto write_tab = [&]() {  // coefficients of the prefetched hidden unit -> this wave's private table rows
 #pragma unroll
@@ -406,7 +439,8 @@ __global__ __launch_bounds__(DG_THREADS) void k_conv_dg(DgArgs a) {
           for (int pg = 0; pg < 2; ++pg) {
             if (pg == 1 && !two_pages) continue;
             const int t = u + 32 * pg;
-            const float c = hidx[dp][pg] >= 0 ? hv[dp][pg] : 0.f;
+            float c = hidx[dp][pg] >= 0 ? hv[dp][pg] : 0.f;
+            if (pg == 0 && hidx2[dp] >= 0) c += hv2[dp];  // radial + bonded edge of the same pair
             if (t < PMAX) tabA[i * PMAX + t] = make_float4(c, c * evx[dp][pg], c * evy[dp][pg], c * evz[dp][pg]);
           }
         }
