@@ -160,7 +160,7 @@ def secondary_rooflines(dev):
     params = native.make_mcmc_params(2, **MCMC)
     # the Langevin update at a size where it is bandwidth- and not launch-bound (the bench shape, 4352 atoms = 0.3 MB per launch,
     # is pure launch latency; the path fuses nothing around it yet)
-    n_big = 1 << 22
+    n_big = 1 << 24  # 201 MB per [n,3] array: far beyond the 256 MiB Infinity Cache in total
     y, v, psi, R, sc = (torch.randn(n_big, 3, device=dev) for _ in range(5))
     dt = _time_launches(lambda: native.baoab_pre(y, v, psi, R, params), 20)
     b = n_big * 3 * 4 * 6

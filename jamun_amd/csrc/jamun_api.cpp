@@ -759,11 +759,14 @@ struct ProfScope {
   }
 };
 
-void forward(jamun_sampler* s, const float* y, float* xhat, float* score, hipStream_t st) {
+// One denoiser forward.  `pre` / `post`: the two halves of a BAOAB iteration fused into the first and the last kernel of the
+// forward (y is then advanced in place before the geometry is built).
+void forward(jamun_sampler* s, float* y, float* xhat, float* score, hipStream_t st, const LangevinPre& pre = LangevinPre(),
+             const LangevinPost& post = LangevinPost()) {
   {
     ProfScope ps(s, JAMUN_PROF_GEOM, st);
     launch_geom(y, s->ptr, s->n_graphs, s->c_in, s->r2, s->S, s->bond_in_ptr, s->bond_in_src, s->hp.mean_center, s->yc,
-                s->deg, s->esrc, s->egeo, st);
+                s->deg, s->esrc, s->egeo, pre, st);
   }
   const float* x_in = s->x_emb;
   int XSin = s->n_emb;
@@ -849,7 +852,7 @@ void forward(jamun_sampler* s, const float* y, float* xhat, float* score, hipStr
     ProfScope ps(s, JAMUN_PROF_HEAD, st);
     launch_head(hd, st);
     launch_finalize(y, s->yc, s->g, s->ptr, s->n_graphs, s->c_skip, s->c_out, s->sigma * s->sigma, s->hp.mean_center,
-                    s->tmp, xhat, score, st);
+                    s->tmp, xhat, score, post, st);
   }
   HIPCHECK(hipGetLastError());
 }
@@ -1336,13 +1339,13 @@ void jamun_sampler_destroy(jamun_sampler* s) { delete s; }
 int jamun_xhat(jamun_sampler* s, const float* y_dev, float* xhat_dev, void* stream) {
   return guarded([&] {
     if (!s || !y_dev || !xhat_dev) throw Err(JAMUN_ERR_INVALID, "null argument");
-    forward(s, y_dev, xhat_dev, nullptr, (hipStream_t)stream);
+    forward(s, const_cast<float*>(y_dev), xhat_dev, nullptr, (hipStream_t)stream);  // (y is written only with a fused pre-update)
   });
 }
 int jamun_score(jamun_sampler* s, const float* y_dev, float* score_dev, void* stream) {
   return guarded([&] {
     if (!s || !y_dev || !score_dev) throw Err(JAMUN_ERR_INVALID, "null argument");
-    forward(s, y_dev, nullptr, score_dev, (hipStream_t)stream);
+    forward(s, const_cast<float*>(y_dev), nullptr, score_dev, (hipStream_t)stream);
   });
 }
 
@@ -1367,27 +1370,31 @@ int jamun_walk_baoab(jamun_sampler* s, float* y, float* v, const jamun_mcmc_para
     const int n = s->n_atoms;
     const size_t fr = (size_t)n * 3;
     int fy = 0, fs = 0;
-    // i = 0: initial frame + initial score (_splitting.py:136-155)
-    forward(s, y, s->xhat_buf, s->score_buf, st);
+    // The two halves of an iteration run inside the first and the last kernel of the forward (k_geom, k_finalize): one step =
+    // the forward's launches and nothing else.  i = 0: initial frame + initial score (_splitting.py:136-155)
     {
       const bool sv = saves(p, 0);
-      float* yf = (y_traj && sv) ? y_traj + fr * fy : nullptr;
-      float* xf = (xhat_traj && sv) ? xhat_traj + fr * fy : nullptr;
-      float* sf = score_traj ? score_traj + fr * fs : nullptr;
-      launch_baoab_post(v, s->psi, s->score_buf, y, s->xhat_buf, n, k, /*update_v=*/0, yf, sf, xf, st);
+      LangevinPost post;
+      post.psi_out = s->psi; post.v = v; post.update_v = 0; post.k = k;
+      post.y_frame = (y_traj && sv) ? y_traj + fr * fy : nullptr;
+      post.xhat_frame = (xhat_traj && sv) ? xhat_traj + fr * fy : nullptr;
+      post.score_frame = score_traj ? score_traj + fr * fs : nullptr;
+      forward(s, y, s->xhat_buf, s->score_buf, st, LangevinPre(), post);
       if (sv) ++fy;
       ++fs;
     }
     for (int i = 1; i < p->steps; ++i) {
-      launch_baoab_pre(y, v, s->psi, noise ? noise + fr * (size_t)(i - 1) : nullptr, seed, (uint32_t)i, n, k, st);
-      forward(s, y, s->xhat_buf, s->score_buf, st);
+      LangevinPre pre;
+      pre.v = v; pre.psi = s->psi; pre.noise = noise ? noise + fr * (size_t)(i - 1) : nullptr; pre.seed = seed; pre.iter = (uint32_t)i; pre.k = k;
       const bool sv = saves(p, i);
-      float* yf = (y_traj && sv) ? y_traj + fr * fy : nullptr;
-      float* xf = (xhat_traj && sv) ? xhat_traj + fr * fy : nullptr;
+      LangevinPost post;
+      post.psi_out = s->psi; post.v = v; post.update_v = 1; post.k = k;
+      post.y_frame = (y_traj && sv) ? y_traj + fr * fy : nullptr;
+      post.xhat_frame = (xhat_traj && sv) ? xhat_traj + fr * fy : nullptr;
       // scores after the initial one are kept only together with the trajectory (_splitting.py:168-170): without y_traj
       // the caller's score_traj holds ONE frame
-      float* sf = (score_traj && y_traj && sv) ? score_traj + fr * fs : nullptr;
-      launch_baoab_post(v, s->psi, s->score_buf, y, s->xhat_buf, n, k, /*update_v=*/1, yf, sf, xf, st);
+      post.score_frame = (score_traj && y_traj && sv) ? score_traj + fr * fs : nullptr;
+      forward(s, y, s->xhat_buf, s->score_buf, st, pre, post);
       if (sv) { ++fy; ++fs; }
     }
     if (xhat_out) launch_copy(s->xhat_buf, xhat_out, n * 3, st);  // last forward was evaluated at the final y

@@ -152,12 +152,30 @@ struct LangevinConsts {
   int has_clip;
 };
 
+// BAOAB halves fused into the ends of the forward (k_geom / k_finalize); a null `v` / `psi_out` switches the half off
+struct LangevinPre {
+  float* v = nullptr;             // in: v, out: vhat
+  const float* psi = nullptr;
+  const float* noise = nullptr;   // this iteration's [n,3] draws, or null: Philox keyed by (seed, iter, atom)
+  uint64_t seed = 0;
+  uint32_t iter = 0;
+  LangevinConsts k{};
+};
+struct LangevinPost {
+  float* psi_out = nullptr;
+  float* v = nullptr;
+  int update_v = 0;
+  float *y_frame = nullptr, *score_frame = nullptr, *xhat_frame = nullptr;
+  LangevinConsts k{};
+};
+
 // launchers implemented in jamun_kernels.hip
 void launch_mean_center(const float* pos, const int* ptr, int n_graphs, float* out, hipStream_t st);
 void launch_radius_graph(const float* pos, const int* ptr, int n_graphs, float r2, int stride, int* nbr, int* deg,
                          hipStream_t st);
-void launch_geom(const float* y, const int* ptr, int n_graphs, float c_in, float r2, int S, const int* bip,
-                 const int* bis, int mean_center, float* yc, int* deg, int* esrc, float4* egeo, hipStream_t st);
+void launch_geom(float* y, const int* ptr, int n_graphs, float c_in, float r2, int S, const int* bip,
+                 const int* bis, int mean_center, float* yc, int* deg, int* esrc, float4* egeo, const LangevinPre& pre,
+                 hipStream_t st);
 void launch_edge_h(const int* deg, const int* esrc, const float4* egeo, int n_atoms, int S, const float* w1r_all,
                    const float* cmask_all, int n_layers, const float* mu, float step, float* h_all, size_t h_layer_stride,
                    size_t h_kstride, hipStream_t st);
@@ -180,7 +198,7 @@ int node_update_set_max_lds();
 void launch_head(const HeadArgs& a, hipStream_t st);
 void launch_finalize(const float* y, const float* yc, const float* g, const int* ptr, int n_graphs, float c_skip,
                      float c_out, float sigma2, int mean_center, float* tmp, float* xhat, float* score,
-                     hipStream_t st);
+                     const LangevinPost& post, hipStream_t st);
 void launch_baoab_pre(float* y, float* v, const float* psi, const float* noise, uint64_t seed, uint32_t iter, int n,
                       const LangevinConsts& k, hipStream_t st);
 void launch_baoab_post(float* v, float* psi, const float* score, const float* y, const float* xhat, int n,

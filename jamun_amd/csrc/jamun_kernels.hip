@@ -67,13 +67,35 @@ __global__ void k_radius_graph(const float* __restrict__ pos, const int* __restr
 // and scaled lengths.  One workgroup per walker.  (src/jamun/model/denoiser.py:138-166,188-192;
 // src/jamun/model/arch/e3conv.py:114-116)
 // ------------------------------------------------------------------------------------------------
-__global__ void k_geom(const float* __restrict__ y, const int* __restrict__ ptr, float c_in, float r2, int S,
+__device__ __forceinline__ void philox_normal3(uint64_t seed, uint32_t iter, uint32_t atom, float out[3]);
+
+// Optional BAOAB first half (B, A, O, A) fused in front of the geometry: the walker's workgroup first advances its own atoms
+//   v += u(d/2) psi ; y += (d/2) v ; vhat = a v + z R ; y += (d/2) vhat ; v <- vhat      (functional/_splitting.py:158-163)
+// with exactly the arithmetic of k_baoab_pre, then centres and builds the edge table from the new y.
+__global__ void k_geom(float* __restrict__ y, const int* __restrict__ ptr, float c_in, float r2, int S,
                        const int* __restrict__ bond_in_ptr, const int* __restrict__ bond_in_src, int mean_center,
                        float* __restrict__ yc, int* __restrict__ deg, int* __restrict__ esrc,
-                       float4* __restrict__ egeo) {
+                       float4* __restrict__ egeo, LangevinPre pre) {
   __shared__ float cen[3];
   const int g = blockIdx.x;
   const int lo = ptr[g], hi = ptr[g + 1];
+  if (pre.v) {
+    for (int i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+      float R[3];
+      if (pre.noise) { R[0] = pre.noise[i * 3]; R[1] = pre.noise[i * 3 + 1]; R[2] = pre.noise[i * 3 + 2]; }
+      else philox_normal3(pre.seed, pre.iter, (uint32_t)i, R);
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        float vv = FADD(pre.v[i * 3 + c], FMUL(pre.k.u_half_delta, pre.psi[i * 3 + c]));
+        float yy = FADD(y[i * 3 + c], FMUL(pre.k.half_delta, vv));
+        float vh = FADD(FMUL(pre.k.exp_mg, vv), FMUL(pre.k.zeta_sqrt_u, R[c]));
+        yy = FADD(yy, FMUL(pre.k.half_delta, vh));
+        pre.v[i * 3 + c] = vh;
+        y[i * 3 + c] = yy;
+      }
+    }
+    __syncthreads();  // (this walker's y is read below by this workgroup only)
+  }
   if (threadIdx.x < 3) {
     float s = 0.f;
     if (mean_center) {
@@ -449,9 +471,13 @@ __global__ __launch_bounds__(256) void k_head(HeadArgs a) {
 // finalize: xhat = mean_center(c_skip * yc + c_out * g) ; score = (xhat - y) / sigma^2
 // (src/jamun/model/denoiser.py:200,213-215,111-114).  One workgroup per walker.
 // ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void process_score(const float s[3], const LangevinConsts& k, float psi[3]);
+
+// Optional BAOAB second half fused behind it:  psi = clip(score) * beta ; v = vhat + (d/2) psi (no u, _splitting.py:166) ; the
+// saved frame (y, score, xhat) — exactly the arithmetic of k_baoab_post.
 __global__ void k_finalize(const float* __restrict__ y, const float* __restrict__ yc, const float* __restrict__ g,
                            const int* __restrict__ ptr, float c_skip, float c_out, float sigma2, int mean_center,
-                           float* __restrict__ tmp, float* __restrict__ xhat, float* __restrict__ score) {
+                           float* __restrict__ tmp, float* __restrict__ xhat, float* __restrict__ score, LangevinPost post) {
   __shared__ float cen[3];
   const int gi = blockIdx.x;
   const int lo = ptr[gi], hi = ptr[gi + 1];
@@ -467,10 +493,27 @@ __global__ void k_finalize(const float* __restrict__ y, const float* __restrict_
     cen[threadIdx.x] = s;
   }
   __syncthreads();
-  for (int a = lo * 3 + threadIdx.x; a < hi * 3; a += blockDim.x) {
-    const float xh = FSUB(tmp[a], cen[a % 3]);
-    if (xhat) xhat[a] = xh;
-    if (score) score[a] = FSUB(xh, y[a]) / sigma2;
+  for (int i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+    float xh[3], sc[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      xh[c] = FSUB(tmp[i * 3 + c], cen[c]);
+      sc[c] = FSUB(xh[c], y[i * 3 + c]) / sigma2;
+      if (xhat) xhat[i * 3 + c] = xh[c];
+      if (score) score[i * 3 + c] = sc[c];
+    }
+    if (post.psi_out) {
+      float p[3];
+      process_score(sc, post.k, p);
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        post.psi_out[i * 3 + c] = p[c];
+        if (post.update_v) post.v[i * 3 + c] = FADD(post.v[i * 3 + c], FMUL(post.k.half_delta, p[c]));
+        if (post.y_frame) post.y_frame[i * 3 + c] = y[i * 3 + c];
+        if (post.score_frame) post.score_frame[i * 3 + c] = sc[c];
+        if (post.xhat_frame) post.xhat_frame[i * 3 + c] = xh[c];
+      }
+    }
   }
 }
 
@@ -666,10 +709,11 @@ void launch_radius_graph(const float* pos, const int* ptr, int n_graphs, float r
                          hipStream_t st) {
   hipLaunchKernelGGL(k_radius_graph, dim3(n_graphs), dim3(128), 0, st, pos, ptr, r2, stride, nbr, deg);
 }
-void launch_geom(const float* y, const int* ptr, int n_graphs, float c_in, float r2, int S, const int* bip,
-                 const int* bis, int mean_center, float* yc, int* deg, int* esrc, float4* egeo, hipStream_t st) {
+void launch_geom(float* y, const int* ptr, int n_graphs, float c_in, float r2, int S, const int* bip,
+                 const int* bis, int mean_center, float* yc, int* deg, int* esrc, float4* egeo, const LangevinPre& pre,
+                 hipStream_t st) {
   hipLaunchKernelGGL(k_geom, dim3(n_graphs), dim3(128), 0, st, y, ptr, c_in, r2, S, bip, bis, mean_center, yc, deg,
-                     esrc, egeo);
+                     esrc, egeo, pre);
 }
 void launch_edge_h(const int* deg, const int* esrc, const float4* egeo, int n_atoms, int S, const float* w1r_all,
                    const float* cmask_all, int n_layers, const float* mu, float step, float* h_all, size_t h_layer_stride,
@@ -696,9 +740,9 @@ void launch_head(const HeadArgs& a, hipStream_t st) {
 }
 void launch_finalize(const float* y, const float* yc, const float* g, const int* ptr, int n_graphs, float c_skip,
                      float c_out, float sigma2, int mean_center, float* tmp, float* xhat, float* score,
-                     hipStream_t st) {
+                     const LangevinPost& post, hipStream_t st) {
   hipLaunchKernelGGL(k_finalize, dim3(n_graphs), dim3(128), 0, st, y, yc, g, ptr, c_skip, c_out, sigma2, mean_center,
-                     tmp, xhat, score);
+                     tmp, xhat, score, post);
 }
 void launch_baoab_pre(float* y, float* v, const float* psi, const float* noise, uint64_t seed, uint32_t iter, int n,
                       const LangevinConsts& k, hipStream_t st) {

@@ -455,6 +455,41 @@ def test_fused_baoab_without_trajectory_writes_one_score_frame(dev):
     assert yt is None and st.shape == (1, n, 3) and torch.isfinite(y1).all() and not torch.equal(y1, y0)
 
 
+def test_fused_integrator_halves_equal_standalone_update_kernels(dev):
+    """The BAOAB halves fused into the first / last kernel of the forward (k_geom, k_finalize) against the stand-alone
+    k_baoab_pre / k_baoab_post driven step by step around the same native score — the kernels that are pinned bit-exactly to
+    the reference's baoab() above.  Mass 2, a clip that binds, inverse temperature 0.8, burn-in and save_every > 1: every
+    output must be bit-identical."""
+    import jamun_amd.sampling as S
+    from jamun_amd import native
+    from jamun_amd.data import WalkerBatch
+    from jamun_amd.model import Denoiser
+
+    model = Denoiser.from_checkpoint_dict(_ckpt("stable")).to(dev)
+    batch = WalkerBatch.from_molecules(_mols("ragged")).to(dev)
+    smp = model.sampler_for(batch, 0.04)
+    steps = 9
+    params = native.make_mcmc_params(steps, 0.05, 0.7, 2.0, 0.8, 3.0, save_every_n_steps=2, burn_in_steps=3)
+    torch.manual_seed(4)
+    y0 = batch.pos + 0.04 * torch.randn(batch.pos.shape).to(dev)
+    v0 = torch.randn(batch.pos.shape).to(dev)
+    noise = torch.randn(steps - 1, batch.num_nodes, 3).to(dev)
+    ya, va = y0.clone(), v0.clone()
+    yt_a, st_a, xt_a, xh_a = smp.walk("baoab", ya, va, params, noise, 0, True)
+    yb, vb = y0.clone(), v0.clone()
+    yt_b, st_b, _ = S._python_walk("baoab", yb, vb, lambda t: smp.score(t), params, noise, 0, True)
+    assert torch.equal(ya, yb) and torch.equal(va, vb)
+    assert torch.equal(yt_a, yt_b) and torch.equal(st_a, st_b) and yt_a.shape[0] == 3 and st_a.shape[0] == 4
+    assert float((st_a[0].norm(dim=-1) > 3.0).float().mean()) > 0.5  # the clip actually binds
+    assert torch.equal(xh_a, smp.xhat(ya))  # the jump of the final state comes out of the same forward
+    # in-kernel Philox noise: fused walk == the same walk on a fresh sampler (determinism of the fused pre-update)
+    yc1, vc1 = y0.clone(), v0.clone()
+    r1 = smp.walk("baoab", yc1, vc1, params, None, 77, True)
+    yc2, vc2 = y0.clone(), v0.clone()
+    r2 = smp.walk("baoab", yc2, vc2, params, None, 77, True)
+    assert torch.equal(yc1, yc2) and torch.equal(r1[0], r2[0]) and not torch.equal(yc1, ya)
+
+
 @pytest.mark.parametrize("case,integrator,kind,preset", [
     ("oracle_walk_baoab_ag4_50", "baoab", "ag4", "stable"),  # cfg1 of BASELINE.json: AG dipeptide, 4 walkers x 50 steps
     ("oracle_walk_baoab_ag4_50_mid", "baoab", "ag4", "mid"),  # the same with twice the output gain (still contractive, see test_oracle)
