@@ -286,7 +286,7 @@ struct jamun_sampler {
   bool row_blocks = false;            // some molecule exceeds the per-tile source budget
   int* atom_nslab = nullptr;          // [n_atoms] partial slabs of the tile the atom belongs to
   // destination-grouped VALU-forming conv kernel (jamun_conv_dg.hip; hidden layers): own tile plan (larger source spans)
-  bool dg_on = false, dg_row_blocks = false;
+  bool dg_on = false, dg_row_blocks = false, dg_alt = false;
   int dg_RS = 0, dg_grid = 0, dg_max_segs = 0, dg_n_slabs = 0, dg_n_tiles = 0;
   int2 *dg_tile_atoms = nullptr, *dg_tile_span = nullptr;
   int4* dg_segs = nullptr;
@@ -795,7 +795,7 @@ void forward(jamun_sampler* s, float* y, float* xhat, float* score, hipStream_t 
       f.deg = s->deg; f.esrc = s->esrc; f.egeo = s->egeo; f.h = h_l; f.h_kstride = s->h_kstride; f.x = x_in;
       f.n_pad = s->n_pad; f.S = s->S; f.XS = XSin; f.RS = s->dg_RS; f.PMAX = (s->S + 3) & ~3;  // multiple of the forming batch
       f.tile_span = s->dg_tile_span; f.tile_atoms = s->dg_tile_atoms; f.segs = s->dg_segs; f.max_segs = s->dg_max_segs;
-      f.row_blocks = s->dg_row_blocks ? 1 : 0; f.nt0 = L.p0.nt;
+      f.row_blocks = s->dg_row_blocks ? 1 : 0; f.nt0 = L.p0.nt; f.alt = s->dg_alt ? 1 : 0;
       f.wx = L.dg.wx; f.wd = L.dg.wd; f.wv = L.dg.wv; f.wt = L.dg.wt;
       f.partial0 = s->partial0; f.partial1 = s->partial1;
       static const int dg_dbg = getenv("JAMUN_DG_DBG") ? atoi(getenv("JAMUN_DG_DBG")) : 0;
@@ -1262,9 +1262,20 @@ int jamun_sampler_create(const jamun_model* m, float sigma, const jamun_topology
     {
       bool ok = getenv("JAMUN_NO_DG") == nullptr && hp.n_layers > 0 && s->S <= 64 && (int64_t)N * s->S < (int64_t)0x7fffffff;
       for (size_t l = 1; l < s->layers.size(); ++l) ok = ok && s->layers[l].dg.wx != nullptr;
-      int cap = 0;
-      for (int rs = 128; rs >= 16 && ok; rs -= 16)
-        if (conv_dg_lds_bytes(rs, (s->S + 3) & ~3) <= JAMUN_MAX_DYN_LDS) { cap = rs; break; }
+      // Source rows resident in LDS for the whole segment when the largest molecule fits the resident budget (~80 rows);
+      // otherwise the alternating-residency mode of the kernel (rows re-staged per phase: spans up to ~170 rows), and only
+      // molecules above THAT are cut into source row blocks.
+      const int pmax = (s->S + 3) & ~3;
+      auto cap_of = [&](int alt) {
+        for (int rs = alt ? 192 : 128; rs >= 16; rs -= 16)
+          if (conv_dg_lds_bytes(rs, pmax, alt) <= JAMUN_MAX_DYN_LDS) return rs;
+        return 0;
+      };
+      int cap = ok ? cap_of(0) : 0;
+      if (ok && nmax > cap && getenv("JAMUN_DG_NO_ALT") == nullptr) {
+        const int cap_alt = cap_of(1);
+        if (cap_alt > cap) { cap = cap_alt; s->dg_alt = true; }
+      }
       if (ok && cap > 0) {
         std::vector<int2> t_atoms, t_span;
         std::vector<int> t_chunk;
@@ -1276,7 +1287,7 @@ int jamun_sampler_create(const jamun_model* m, float sigma, const jamun_topology
         // launch, 2: 0.318, 4: 0.328, 8: 0.343 and the node update slows from 25 to 71 us (more partial slabs per tile): the
         // ~7.7 MB of weight blocks per layer are served from L2 / Infinity Cache fast enough, longer runs of k per segment win.
         const int ng = k_groups("JAMUN_DG_KGROUPS", 1);
-        auto weight = [&](int t) -> int64_t { return 604 + 8 * ((t_span[t].y - t_span[t].x + 15) / 16); };
+        auto weight = [&](int t) -> int64_t { return 604 + (s->dg_alt ? 24 : 8) * ((t_span[t].y - t_span[t].x + 15) / 16); };
         SegPlan P = plan_segments(cus, ng, n_k, N, t_atoms, t_chunk, n_chunks, weight);
         s->dg_grid = cus;
         s->dg_max_segs = P.max_segs;

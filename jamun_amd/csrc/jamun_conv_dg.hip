@@ -43,7 +43,10 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
                       // per SIMD the forming phases took 25 % longer)
 #define DG_NDP 2     // destination pairs per forming wave: 32 / (2 * forming waves)
 #define DG_THREADS (64 * DG_WAVES)
-#define DG_XST 252   // xs row: x0 [0,120) | [u][4] = (x1_j[u].x, T_k[j][u], x1_j[u].y, .z) [120,248) | pad: 4 * 63 floats
+#define DG_XST_RES 252  // resident mode, xs row: x0 [0,120) | [u][4] = (x1_j[u].x, T_k[j][u], x1_j[u].y, .z) [120,248) | pad: 4 * 63 floats
+#define DG_XST_ALT 132  // alternating mode, xs row = EITHER x0 [0,120) + zeros (phase P2) OR the [u][4] block [0,128) (phase P1): 4 * 33 floats
+#define DG_NP_RES 2     // 16-row tiles of the T product per matrix wave: spans up to 128 rows
+#define DG_NP_ALT 3     //                                                  up to 192 rows
 #define DG_XS0 124   // X tile row stride (120 + 4):  4 * 31
 #define DG_YD 36     // Yd tile row stride (32 + 4):   4 * 9
 #define DG_YV 68     // Yv tile row stride (64 + 4):   4 * 17
@@ -63,12 +66,24 @@ __device__ unsigned long long g_dgstamp[2][8];  // [role][prologue, P1 work, P1 
 #define DACC(slot, t1, t0) do { } while (0)
 #endif
 
-__host__ __device__ inline size_t dg_lds_floats(int rs, int pmax) {
+__host__ __device__ inline size_t dg_lds_floats(int rs, int pmax, int alt) {
   // xs | X (+4: the dummy quarter group reads 4 floats past the last row) | Yd | Yv | tabA | tabJ | deg
-  return (size_t)rs * DG_XST + 32 * DG_XS0 + 8 + 32 * DG_YD + 3 * 32 * DG_YV + (size_t)32 * pmax * 4 + (size_t)32 * pmax + 32;
+  return (size_t)rs * (alt ? DG_XST_ALT : DG_XST_RES) + 32 * DG_XS0 + 8 + 32 * DG_YD + 3 * 32 * DG_YV + (size_t)32 * pmax * 4 +
+         (size_t)32 * pmax + 32;
 }
 
+// ALT = false: the source rows of a tile stay in LDS for the whole segment (spans up to ~80 rows).
+// ALT = true (molecules above that): LDS holds only what the CURRENT PHASE reads — the vector block (x, T, y, z)[32] of every
+// source row during P1 (Y forming), the 120 scalar channels during P2 (X forming, T product) — and all threads re-stage the
+// rows from global memory (L2) at both phase boundaries of every hidden unit: 2 x rows x ~0.5 KB per k and two more barriers,
+// instead of cutting the sources into row blocks whose (destination chunk, block) tiles each pay the full contraction.
+// T(k+1) stays in the matrix waves' accumulators across the re-staging and is written into the freshly staged vector block.
+template <bool ALT>
 __global__ __launch_bounds__(DG_THREADS) void k_conv_dg(DgArgs a) {
+  constexpr int DG_XST = ALT ? DG_XST_ALT : DG_XST_RES;
+  constexpr int NP = ALT ? DG_NP_ALT : DG_NP_RES;
+  constexpr int OFFY = ALT ? 0 : 480;    // byte offset of the vector block inside a row
+  constexpr int TCOL = ALT ? 0 : 120;    // float column of the vector block
   extern __shared__ float4 lds4[];
   float* __restrict__ lds = reinterpret_cast<float*>(lds4);
   float* __restrict__ xs = lds;                                  // [RS][DG_XST]
@@ -114,15 +129,36 @@ __global__ __launch_bounds__(DG_THREADS) void k_conv_dg(DgArgs a) {
     DSTAMP(ta);
 
     // ---- segment prologue: source rows -> LDS (x1 re-laid as [u][4] with the T slot second); zero the A tiles
-    for (int idx = tid; idx < rows16 * (DG_XST / 4); idx += DG_THREADS) {
-      const int j = idx / (DG_XST / 4), q = idx - j * (DG_XST / 4);
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (j < rows) {
-        const float* __restrict__ xr = a.x + (size_t)(s_lo + j) * a.XS;
-        if (q < 30) v = *reinterpret_cast<const float4*>(xr + 4 * q);             // x0 (120 = 30 x 4)
-        else if (q < 62) { const float* p = xr + 120 + 3 * (q - 30); v = make_float4(p[0], 0.f, p[1], p[2]); }  // x1[u] -> (x, T = 0, y, z)
+    auto stage_x0 = [&]() {  // ALT: scalar channels of every source row (+ zero padding; rows >= `rows` zero: the T product reads them)
+      for (int idx = tid; idx < rows16 * (DG_XST_ALT / 4); idx += DG_THREADS) {
+        const int j = idx / (DG_XST_ALT / 4), q = idx - j * (DG_XST_ALT / 4);
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (j < rows && q < 30) v = *reinterpret_cast<const float4*>(a.x + (size_t)(s_lo + j) * a.XS + 4 * q);
+        *reinterpret_cast<float4*>(xs + (size_t)j * DG_XST_ALT + 4 * q) = v;
       }
-      *reinterpret_cast<float4*>(xs + (size_t)j * DG_XST + 4 * q) = v;
+    };
+    auto stage_x1 = [&]() {  // ALT: vector block (x, *, y, z) of every source row; the T slot (*) is written by the matrix waves
+      for (int idx = tid; idx < rows * 32; idx += DG_THREADS) {
+        const int j = idx >> 5, uu = idx & 31;
+        const float* __restrict__ p1 = a.x + (size_t)(s_lo + j) * a.XS + 120 + 3 * uu;
+        float* __restrict__ d = xs + (size_t)j * DG_XST_ALT + 4 * uu;
+        d[0] = p1[0];
+        *reinterpret_cast<float2*>(d + 2) = make_float2(p1[1], p1[2]);
+      }
+    };
+    if constexpr (ALT) {
+      stage_x0();
+    } else {
+      for (int idx = tid; idx < rows16 * (DG_XST / 4); idx += DG_THREADS) {
+        const int j = idx / (DG_XST / 4), q = idx - j * (DG_XST / 4);
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (j < rows) {
+          const float* __restrict__ xr = a.x + (size_t)(s_lo + j) * a.XS;
+          if (q < 30) v = *reinterpret_cast<const float4*>(xr + 4 * q);             // x0 (120 = 30 x 4)
+          else if (q < 62) { const float* p = xr + 120 + 3 * (q - 30); v = make_float4(p[0], 0.f, p[1], p[2]); }  // x1[u] -> (x, T = 0, y, z)
+        }
+        *reinterpret_cast<float4*>(xs + (size_t)j * DG_XST + 4 * q) = v;
+      }
     }
     for (int idx = tid; idx < 32 * DG_XS0 + 8 + 32 * DG_YD + 3 * 32 * DG_YV; idx += DG_THREADS) Xt[idx] = 0.f;
     if (tid < 32) deg_lds[tid] = (tid < n_dst) ? a.deg[n0 + tid] : 0;
@@ -229,7 +265,7 @@ __global__ __launch_bounds__(DG_THREADS) void k_conv_dg(DgArgs a) {
       };
       // T product of hidden unit k: T[j][w'] = sum_u x0_j[u] W[(k,u)][w'], row tiles rt = w, w + 4 (16 rows each), both
       // 16-column halves per row tile (two independent accumulators keep the 16x16x4 MFMA at its issue rate)
-      f32x4 accT[2][2];
+      f32x4 accT[NP][2];
       auto load_t = [&](float4 (&B)[5], int k, int c) {  // chunk c: groups 2c, 2c+1, both column halves
 #pragma unroll
         for (int i = 0; i < 4; ++i) B[i] = WT(k, 2 * c + (i >> 1), i & 1);
@@ -237,7 +273,7 @@ __global__ __launch_bounds__(DG_THREADS) void k_conv_dg(DgArgs a) {
       auto run_t = [&](const float4 (&B)[5], int c) {
         if (dbg_nomfma) return;
 #pragma unroll
-        for (int p = 0; p < 2; ++p) {
+        for (int p = 0; p < NP; ++p) {
           if (w + 4 * p >= n_rt) break;  // wave-uniform
           const float* __restrict__ Ta = xs + (size_t)(16 * (w + 4 * p) + r16) * DG_XST + 4 * kq;
           float4 avs[2];
@@ -259,21 +295,21 @@ __global__ __launch_bounds__(DG_THREADS) void k_conv_dg(DgArgs a) {
       };
       auto zero_t = [&]() {
 #pragma unroll
-        for (int p = 0; p < 2; ++p)
+        for (int p = 0; p < NP; ++p)
 #pragma unroll
           for (int c = 0; c < 2; ++c) accT[p][c] = f32x4{0.f, 0.f, 0.f, 0.f};
       };
-      auto store_t = [&]() {  // D[row = 4 kq + q][col = r16] of each 16x16 sub-tile -> slot 1 of xs[row][120 + 4 col ..]
+      auto store_t = [&]() {  // D[row = 4 kq + q][col = r16] of each 16x16 sub-tile -> slot 1 of the vector block of xs[row]
 #pragma unroll
-        for (int p = 0; p < 2; ++p) {
+        for (int p = 0; p < NP; ++p) {
           if (w + 4 * p >= n_rt) break;
 #pragma unroll
           for (int c = 0; c < 2; ++c)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) xs[(size_t)(16 * (w + 4 * p) + 4 * kq + q) * DG_XST + 120 + 4 * (16 * c + r16) + 1] = accT[p][c][q];
+            for (int q = 0; q < 4; ++q) xs[(size_t)(16 * (w + 4 * p) + 4 * kq + q) * DG_XST + TCOL + 4 * (16 * c + r16) + 1] = accT[p][c][q];
         }
       };
-      // (row tiles beyond w + 4 — spans above 128 rows — do not occur: the host caps the span at RS <= 128)
+      // (row tiles beyond w + 4 (NP - 1) do not occur: the host caps the span at RS <= 64 NP)
 
       if (a.row_blocks && !__syncthreads_or(0)) {  // a (destination chunk x source row block) tile without any edge: zero slab
 #pragma unroll
@@ -298,9 +334,14 @@ __global__ __launch_bounds__(DG_THREADS) void k_conv_dg(DgArgs a) {
         run_t(B1, 1); load_t(B1, k0, 3);
         run_t(B0, 2); load_x(B0, k0, 0);
         run_t(B1, 3); load_x(B1, k0, 1);
-        store_t();
+        if constexpr (!ALT) store_t();
       }
       LDS_BARRIER();
+      if constexpr (ALT) {  // swap the scalar channels for the vector blocks; T(k0) goes into its slots
+        stage_x1();
+        store_t();
+        LDS_BARRIER();
+      }
       DSTAMP(tb); DACC(0, tb, ta);
       for (int it = 0; it < nk; ++it) {
         const int k = k_of(it), kn = k_of(it + 1);
@@ -313,6 +354,10 @@ __global__ __launch_bounds__(DG_THREADS) void k_conv_dg(DgArgs a) {
         run_x(B1, 3); load_v(B1, k);
         DSTAMP(tb); DACC(1, tb, ta);
         LDS_BARRIER();
+        if constexpr (ALT) {
+          if (has_next) { stage_x0(); }
+          LDS_BARRIER();
+        }
         DSTAMP(ta); DACC(2, ta, tb);
         // ---- P2: Y(k) x W, then T(k+1)
         run_d(B0); load_t(B0, kn, 0);
@@ -323,10 +368,14 @@ __global__ __launch_bounds__(DG_THREADS) void k_conv_dg(DgArgs a) {
           run_t(B1, 1); load_t(B1, kn, 3);
           run_t(B0, 2); load_x(B0, kn, 0);
           run_t(B1, 3); load_x(B1, kn, 1);
-          store_t();
+          if constexpr (!ALT) store_t();
         }
         DSTAMP(tb); DACC(3, tb, ta);
         LDS_BARRIER();
+        if constexpr (ALT) {
+          if (has_next) { stage_x1(); store_t(); }
+          LDS_BARRIER();
+        }
         DSTAMP(ta); DACC(4, ta, tb);
       }
       DSTAMP(ta);
@@ -454,7 +503,7 @@ __global__ __launch_bounds__(DG_THREADS) void k_conv_dg(DgArgs a) {
       // register pairs the loads deliver: coefficients (c, c vx | c vy, c vz), row fragment (x, T | y, z) — 15 products per edge
       // in 7 packed + 1 scalar FMA with no sign flips inside the loop (negative terms have their own accumulators), and one address add per edge and phase.
       auto pk = [](f32x2 a2, f32x2 b2, f32x2 c2) -> f32x2 { return __builtin_elementwise_fma(a2, b2, c2); };
-      const int offx = u * 16, offy = 480 + u * 16;
+      const int offx = u * 16, offy = OFFY + u * 16;
       // X(k): scalar inputs, lanes u < 30 own channels 4u..4u+3 (lanes 30, 31 compute on x1 data and are not stored)
       auto form_x = [&]() {
 #pragma unroll
@@ -569,22 +618,35 @@ __global__ __launch_bounds__(DG_THREADS) void k_conv_dg(DgArgs a) {
       load_h(k_of(1));
       form_x();
       LDS_BARRIER();
+      if constexpr (ALT) {
+        stage_x1();
+        LDS_BARRIER();
+      }
       DSTAMP(tb); DACC(0, tb, ta);
       for (int it = 0; it < nk; ++it) {
+        const bool has_next = it + 1 < nk;
         // ---- P1: Y(k) with the table of k (written in the previous P2) and T(k)
         DSTAMP(ta);
         form_y();
         DSTAMP(tb); DACC(1, tb, ta);
         LDS_BARRIER();
+        if constexpr (ALT) {
+          if (has_next) { stage_x0(); }
+          LDS_BARRIER();
+        }
         DSTAMP(ta); DACC(2, ta, tb);
         // ---- P2: table of k+1, X(k+1)
-        if (it + 1 < nk) {
+        if (has_next) {
           write_tab();
           load_h(k_of(it + 2));
           form_x();
         }
         DSTAMP(tb); DACC(3, tb, ta);
         LDS_BARRIER();
+        if constexpr (ALT) {
+          if (has_next) { stage_x1(); }
+          LDS_BARRIER();
+        }
         DSTAMP(ta); DACC(4, ta, tb);
       }
       DSTAMP(ta);
@@ -643,16 +705,20 @@ void conv_dg_print_stamps() {
 #endif
 }
 
-size_t conv_dg_lds_bytes(int rs, int pmax) { return sizeof(float) * ((dg_lds_floats(rs, pmax) + 3) & ~(size_t)3); }
+size_t conv_dg_lds_bytes(int rs, int pmax, int alt) { return sizeof(float) * ((dg_lds_floats(rs, pmax, alt) + 3) & ~(size_t)3); }
 
 int launch_conv_dg(const DgArgs& a, int grid, hipStream_t st) {
-  const size_t smem = conv_dg_lds_bytes(a.RS, a.PMAX);
+  const size_t smem = conv_dg_lds_bytes(a.RS, a.PMAX, a.alt);
   if (smem > JAMUN_MAX_DYN_LDS) return -2;
-  if (a.RS > 128 || (a.RS & 15) || a.XS != 216 || a.nt0 != 5) return -1;
-  hipLaunchKernelGGL(k_conv_dg, dim3(grid), dim3(DG_THREADS), smem, st, a);
+  if (a.RS > 64 * (a.alt ? DG_NP_ALT : DG_NP_RES) || (a.RS & 15) || a.XS != 216 || a.nt0 != 5) return -1;
+  if (a.alt) hipLaunchKernelGGL(k_conv_dg<true>, dim3(grid), dim3(DG_THREADS), smem, st, a);
+  else hipLaunchKernelGGL(k_conv_dg<false>, dim3(grid), dim3(DG_THREADS), smem, st, a);
   return 0;
 }
 
 int conv_dg_set_max_lds() {
-  return hipFuncSetAttribute((const void*)k_conv_dg, hipFuncAttributeMaxDynamicSharedMemorySize, JAMUN_MAX_DYN_LDS) == hipSuccess ? 0 : -1;
+  return (hipFuncSetAttribute((const void*)k_conv_dg<false>, hipFuncAttributeMaxDynamicSharedMemorySize, JAMUN_MAX_DYN_LDS) == hipSuccess &&
+          hipFuncSetAttribute((const void*)k_conv_dg<true>, hipFuncAttributeMaxDynamicSharedMemorySize, JAMUN_MAX_DYN_LDS) == hipSuccess)
+             ? 0
+             : -1;
 }
