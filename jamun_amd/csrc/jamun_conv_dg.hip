@@ -51,6 +51,8 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 #define DG_YD 36     // Yd tile row stride (32 + 4):   4 * 9
 #define DG_YV 68     // Yv tile row stride (64 + 4):   4 * 17
 #define DG_U 4       // edges per batch of the forming loops
+#define DG_SB 8      // elements per thread in flight in the staging loop of the segment prologue
+#define DG_SBA 4     // ... and in the per-phase re-staging of the alternating mode (accumulators are live there)
 
 #define LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 #define MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
@@ -129,35 +131,71 @@ __global__ __launch_bounds__(DG_THREADS) void k_conv_dg(DgArgs a) {
     DSTAMP(ta);
 
     // ---- segment prologue: source rows -> LDS (x1 re-laid as [u][4] with the T slot second); zero the A tiles
+    // (staging loops: DG_SB global loads are issued before the first LDS store — a load-store-load chain would serialise one
+    // L2 round trip per element and the re-staging of the alternating mode sits on the critical path of every hidden unit)
     auto stage_x0 = [&]() {  // ALT: scalar channels of every source row (+ zero padding; rows >= `rows` zero: the T product reads them)
-      for (int idx = tid; idx < rows16 * (DG_XST_ALT / 4); idx += DG_THREADS) {
-        const int j = idx / (DG_XST_ALT / 4), q = idx - j * (DG_XST_ALT / 4);
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (j < rows && q < 30) v = *reinterpret_cast<const float4*>(a.x + (size_t)(s_lo + j) * a.XS + 4 * q);
-        *reinterpret_cast<float4*>(xs + (size_t)j * DG_XST_ALT + 4 * q) = v;
+      const int total = rows16 * (DG_XST_ALT / 4);
+      for (int base = tid; base < total; base += DG_SBA * DG_THREADS) {
+        float4 v[DG_SBA];
+#pragma unroll
+        for (int q8 = 0; q8 < DG_SBA; ++q8) {
+          const int idx = base + q8 * DG_THREADS;
+          const int j = idx / (DG_XST_ALT / 4), q = idx - j * (DG_XST_ALT / 4);
+          v[q8] = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (idx < total && j < rows && q < 30) v[q8] = *reinterpret_cast<const float4*>(a.x + (size_t)(s_lo + j) * a.XS + 4 * q);
+        }
+#pragma unroll
+        for (int q8 = 0; q8 < DG_SBA; ++q8) {
+          const int idx = base + q8 * DG_THREADS;
+          const int j = idx / (DG_XST_ALT / 4), q = idx - j * (DG_XST_ALT / 4);
+          if (idx < total) *reinterpret_cast<float4*>(xs + (size_t)j * DG_XST_ALT + 4 * q) = v[q8];
+        }
       }
     };
     auto stage_x1 = [&]() {  // ALT: vector block (x, *, y, z) of every source row; the T slot (*) is written by the matrix waves
-      for (int idx = tid; idx < rows * 32; idx += DG_THREADS) {
-        const int j = idx >> 5, uu = idx & 31;
-        const float* __restrict__ p1 = a.x + (size_t)(s_lo + j) * a.XS + 120 + 3 * uu;
-        float* __restrict__ d = xs + (size_t)j * DG_XST_ALT + 4 * uu;
-        d[0] = p1[0];
-        *reinterpret_cast<float2*>(d + 2) = make_float2(p1[1], p1[2]);
+      const int total = rows * 32;
+      for (int base = tid; base < total; base += DG_SBA * DG_THREADS) {
+        float vx[DG_SBA], vy[DG_SBA], vz[DG_SBA];
+#pragma unroll
+        for (int q8 = 0; q8 < DG_SBA; ++q8) {
+          const int idx = min(base + q8 * DG_THREADS, total - 1);
+          const float* __restrict__ p1 = a.x + (size_t)(s_lo + (idx >> 5)) * a.XS + 120 + 3 * (idx & 31);
+          vx[q8] = p1[0]; vy[q8] = p1[1]; vz[q8] = p1[2];
+        }
+#pragma unroll
+        for (int q8 = 0; q8 < DG_SBA; ++q8) {
+          const int idx = base + q8 * DG_THREADS;
+          if (idx < total) {
+            float* __restrict__ d = xs + (size_t)(idx >> 5) * DG_XST_ALT + 4 * (idx & 31);
+            d[0] = vx[q8];
+            *reinterpret_cast<float2*>(d + 2) = make_float2(vy[q8], vz[q8]);
+          }
+        }
       }
     };
     if constexpr (ALT) {
       stage_x0();
     } else {
-      for (int idx = tid; idx < rows16 * (DG_XST / 4); idx += DG_THREADS) {
-        const int j = idx / (DG_XST / 4), q = idx - j * (DG_XST / 4);
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (j < rows) {
-          const float* __restrict__ xr = a.x + (size_t)(s_lo + j) * a.XS;
-          if (q < 30) v = *reinterpret_cast<const float4*>(xr + 4 * q);             // x0 (120 = 30 x 4)
-          else if (q < 62) { const float* p = xr + 120 + 3 * (q - 30); v = make_float4(p[0], 0.f, p[1], p[2]); }  // x1[u] -> (x, T = 0, y, z)
+      const int total = rows16 * (DG_XST / 4);
+      for (int base = tid; base < total; base += DG_SB * DG_THREADS) {
+        float4 v[DG_SB];
+#pragma unroll
+        for (int q8 = 0; q8 < DG_SB; ++q8) {
+          const int idx = base + q8 * DG_THREADS;
+          const int j = idx / (DG_XST / 4), q = idx - j * (DG_XST / 4);
+          v[q8] = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (idx < total && j < rows) {
+            const float* __restrict__ xr = a.x + (size_t)(s_lo + j) * a.XS;
+            if (q < 30) v[q8] = *reinterpret_cast<const float4*>(xr + 4 * q);             // x0 (120 = 30 x 4)
+            else if (q < 62) { const float* p = xr + 120 + 3 * (q - 30); v[q8] = make_float4(p[0], 0.f, p[1], p[2]); }  // x1[u] -> (x, T = 0, y, z)
+          }
         }
-        *reinterpret_cast<float4*>(xs + (size_t)j * DG_XST + 4 * q) = v;
+#pragma unroll
+        for (int q8 = 0; q8 < DG_SB; ++q8) {
+          const int idx = base + q8 * DG_THREADS;
+          const int j = idx / (DG_XST / 4), q = idx - j * (DG_XST / 4);
+          if (idx < total) *reinterpret_cast<float4*>(xs + (size_t)j * DG_XST + 4 * q) = v[q8];
+        }
       }
     }
     for (int idx = tid; idx < 32 * DG_XS0 + 8 + 32 * DG_YD + 3 * 32 * DG_YV; idx += DG_THREADS) Xt[idx] = 0.f;
