@@ -291,6 +291,7 @@ struct jamun_sampler {
   int2 *dg_tile_atoms = nullptr, *dg_tile_span = nullptr;
   int4* dg_segs = nullptr;
   int* dg_atom_nslab = nullptr;
+  float* dg_T = nullptr;  // [n_k][n_atoms][32] pre-pass product of a hidden layer (k_tprod), reused by every layer
   float *x_emb = nullptr, *mu = nullptr;
   std::vector<LayerDev> layers;
   float *w_gate = nullptr, *w_vec = nullptr, *w_out = nullptr;
@@ -314,7 +315,7 @@ struct jamun_sampler {
   ~jamun_sampler() {
     hipFree(ptr); hipFree(bond_in_ptr); hipFree(bond_in_src); hipFree(x_emb); hipFree(mu); hipFree(tile_span);
     hipFree(fused_segs); hipFree(atom_nslab); hipFree(tile_atoms); hipFree(atom_uid); hipFree(w1r_all); hipFree(cmask_all);
-    hipFree(dg_tile_atoms); hipFree(dg_tile_span); hipFree(dg_segs); hipFree(dg_atom_nslab);
+    hipFree(dg_tile_atoms); hipFree(dg_tile_span); hipFree(dg_segs); hipFree(dg_atom_nslab); hipFree(dg_T);
     for (auto& L : layers) {
       free_problem(L.p0); free_problem(L.p1); free_fused(L.fu); free_dg(L.dg);
       hipFree(L.wcat0); hipFree(L.wcat1); hipFree(L.mix); hipFree(L.tt);
@@ -585,7 +586,7 @@ LayerDev build_layer(const jamun_model& m, const std::string& prefix, const std:
       x0ve.size() == 120 && x0_contig && x0e[0].xoff == 0 && dote[0].xoff == 120) {
     const int n_k = H + 1;
     auto Wk = [&](int k, int64_t p) -> double { return (k < H) ? (double)W3[(size_t)p * H + k] : (double)b3[p]; };
-    std::vector<float4> wx((size_t)n_k * 5 * 16 * 64), wd((size_t)n_k * 5 * 4 * 64), wv((size_t)n_k * 2 * 4 * 64), wt((size_t)n_k * 8 * 2 * 64);
+    std::vector<float4> wx((size_t)n_k * 5 * 16 * 64), wd((size_t)n_k * 5 * 4 * 64), wv((size_t)n_k * 2 * 4 * 64), wt((size_t)n_k * 15 * 64);
     for (int k = 0; k < n_k; ++k) {
       for (int t = 0; t < 5; ++t)
         for (int g = 0; g < 16; ++g)
@@ -619,16 +620,18 @@ LayerDev build_layer(const jamun_model& m, const std::string& prefix, const std:
             }
             wv[(((size_t)k * 2 + ch) * 4 + g) * 64 + lane] = make_float4(v[0], v[1], v[2], v[3]);
           }
-          for (int g = 0; g < 8; ++g) {  // T product: u = 16 g + 4 kq + st over the 120 scalar inputs (padded to 128)
-            float v[4] = {0.f, 0.f, 0.f, 0.f};
-            for (int st = 0; st < 4; ++st) {
-              const int u = 16 * g + 4 * kq + st;
-              if (u < 120) v[st] = (float)(Wk(k, x0ve[u].wbase + col) * x0ve[u].scale);
-            }
-            wt[(((size_t)k * 8 + g) * 2 + ch) * 64 + lane] = make_float4(v[0], v[1], v[2], v[3]);
-          }
         }
       }
+      for (int g = 0; g < 15; ++g)  // T pre-pass (k_tprod, 32x32x2): lane (c = w', hh), u = 8 g + 4 hh + st over the 120 scalar inputs
+        for (int lane = 0; lane < 64; ++lane) {
+          const int hh = lane >> 5, c = lane & 31;
+          float v[4];
+          for (int st = 0; st < 4; ++st) {
+            const int u = 8 * g + 4 * hh + st;
+            v[st] = (float)(Wk(k, x0ve[u].wbase + c) * x0ve[u].scale);
+          }
+          wt[((size_t)k * 15 + g) * 64 + lane] = make_float4(v[0], v[1], v[2], v[3]);
+        }
     }
     L.dg.wx = dev_upload(wx);
     L.dg.wd = dev_upload(wd);
@@ -796,11 +799,12 @@ void forward(jamun_sampler* s, float* y, float* xhat, float* score, hipStream_t 
       f.n_pad = s->n_pad; f.S = s->S; f.XS = XSin; f.RS = s->dg_RS; f.PMAX = (s->S + 3) & ~3;  // multiple of the forming batch
       f.tile_span = s->dg_tile_span; f.tile_atoms = s->dg_tile_atoms; f.segs = s->dg_segs; f.max_segs = s->dg_max_segs;
       f.row_blocks = s->dg_row_blocks ? 1 : 0; f.nt0 = L.p0.nt; f.alt = s->dg_alt ? 1 : 0;
-      f.wx = L.dg.wx; f.wd = L.dg.wd; f.wv = L.dg.wv; f.wt = L.dg.wt;
+      f.wx = L.dg.wx; f.wd = L.dg.wd; f.wv = L.dg.wv; f.T = s->dg_T; f.n_atoms = s->n_atoms;
       f.partial0 = s->partial0; f.partial1 = s->partial1;
       static const int dg_dbg = getenv("JAMUN_DG_DBG") ? atoi(getenv("JAMUN_DG_DBG")) : 0;
       f.dbg = dg_dbg;
-      ProfScope ps(s, JAMUN_PROF_CONV0, st);
+      ProfScope ps(s, JAMUN_PROF_CONV0, st);  // (the T pre-pass is part of the hidden-layer conv: timed with it)
+      launch_tprod(x_in, XSin, s->n_atoms, s->hp.edge_attr_dim + 1, L.dg.wt, s->dg_T, st);
       const int rcode = launch_conv_dg(f, s->dg_grid, st);
       if (rcode != 0) throw Err(JAMUN_ERR_INVALID, "destination-grouped conv launch failed (configuration not supported)");
     } else if (L.fu.wpack) {
@@ -1267,7 +1271,7 @@ int jamun_sampler_create(const jamun_model* m, float sigma, const jamun_topology
       // molecules above THAT are cut into source row blocks.
       const int pmax = (s->S + 3) & ~3;
       auto cap_of = [&](int alt) {
-        for (int rs = alt ? 192 : 128; rs >= 16; rs -= 16)
+        for (int rs = alt ? 192 : 128; rs >= 16; rs -= 4)
           if (conv_dg_lds_bytes(rs, pmax, alt) <= JAMUN_MAX_DYN_LDS) return rs;
         return 0;
       };
@@ -1281,13 +1285,13 @@ int jamun_sampler_create(const jamun_model* m, float sigma, const jamun_topology
         std::vector<int> t_chunk;
         int n_chunks = 0, span_max = 0;
         plan_tiles(topo->ptr, graph_of, N, cap, t_atoms, t_span, t_chunk, n_chunks, span_max, s->dg_row_blocks);
-        s->dg_RS = (span_max + 15) & ~15;
+        s->dg_RS = std::max((span_max + 3) & ~3, 16);  // (>= 16 rows: the segment-end staging tile of the forming waves aliases the source rows)
         s->dg_n_tiles = (int)t_atoms.size();
         // k-slices over XCD groups (JAMUN_DG_KGROUPS = 1, 2, 4, 8).  Measured on MI355X (cfg2, profiles/r2*): 1 slice 0.317 ms per
         // launch, 2: 0.318, 4: 0.328, 8: 0.343 and the node update slows from 25 to 71 us (more partial slabs per tile): the
         // ~7.7 MB of weight blocks per layer are served from L2 / Infinity Cache fast enough, longer runs of k per segment win.
         const int ng = k_groups("JAMUN_DG_KGROUPS", 1);
-        auto weight = [&](int t) -> int64_t { return 604 + (s->dg_alt ? 24 : 8) * ((t_span[t].y - t_span[t].x + 15) / 16); };
+        auto weight = [&](int t) -> int64_t { return 476 + (s->dg_alt ? 24 : 2) * ((t_span[t].y - t_span[t].x + 15) / 16); };
         SegPlan P = plan_segments(cus, ng, n_k, N, t_atoms, t_chunk, n_chunks, weight);
         s->dg_grid = cus;
         s->dg_max_segs = P.max_segs;
@@ -1296,6 +1300,7 @@ int jamun_sampler_create(const jamun_model* m, float sigma, const jamun_topology
         s->dg_atom_nslab = dev_upload(P.atom_nslab);
         s->dg_tile_atoms = dev_upload(t_atoms);
         s->dg_tile_span = dev_upload(t_span);
+        s->dg_T = dev_alloc<float>((size_t)n_k * N * 32);
         s->dg_on = true;
       }
       if (!s->dg_on)
@@ -1337,7 +1342,8 @@ int jamun_sampler_create(const jamun_model* m, float sigma, const jamun_topology
     s->flop_exec = 0;
     for (auto& L : s->layers) {
       s->flop_ref_per_edge += 2LL * 64 * 64 + 130LL * L.tp_numel;  // SURVEY.md §8 d
-      if (s->dg_on && &L != &s->layers[0]) s->flop_exec += (int64_t)s->dg_n_tiles * (hp.edge_attr_dim + 1) * (604 + 0) * 4096;  // MFMA units per (tile, k)
+      if (s->dg_on && &L != &s->layers[0])  // MFMA units (4096 FLOP) per (tile, k) in k_conv_dg + per (32 atoms, k) in the T pre-pass
+        s->flop_exec += ((int64_t)s->dg_n_tiles * 476 + (int64_t)((s->n_atoms + 31) / 32) * 60) * (hp.edge_attr_dim + 1) * 4096;
       else if (L.fu.wpack) s->flop_exec += (int64_t)s->n_ftiles * (hp.edge_attr_dim + 1) * L.fu.mfma_per_k * 4096;  // 32x32x2 MFMA = 4096 FLOP
       else s->flop_exec += 2LL * s->n_pad * (1LL * L.p0.K * L.p0.nt * 32 + 3LL * L.p1.K * L.p1.nt * 32);
     }

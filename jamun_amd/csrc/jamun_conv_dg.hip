@@ -45,8 +45,8 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 #define DG_THREADS (64 * DG_WAVES)
 #define DG_XST_RES 252  // resident mode, xs row: x0 [0,120) | [u][4] = (x1_j[u].x, T_k[j][u], x1_j[u].y, .z) [120,248) | pad: 4 * 63 floats
 #define DG_XST_ALT 132  // alternating mode, xs row = EITHER x0 [0,120) + zeros (phase P2) OR the [u][4] block [0,128) (phase P1): 4 * 33 floats
-#define DG_NP_RES 2     // 16-row tiles of the T product per matrix wave: spans up to 128 rows
-#define DG_NP_ALT 3     //                                                  up to 192 rows
+#define DG_RS_MAX_RES 128
+#define DG_RS_MAX_ALT 192
 #define DG_XS0 124   // X tile row stride (120 + 4):  4 * 31
 #define DG_YD 36     // Yd tile row stride (32 + 4):   4 * 9
 #define DG_YV 68     // Yv tile row stride (64 + 4):   4 * 17
@@ -83,7 +83,6 @@ __host__ __device__ inline size_t dg_lds_floats(int rs, int pmax, int alt) {
 template <bool ALT>
 __global__ __launch_bounds__(DG_THREADS) void k_conv_dg(DgArgs a) {
   constexpr int DG_XST = ALT ? DG_XST_ALT : DG_XST_RES;
-  constexpr int NP = ALT ? DG_NP_ALT : DG_NP_RES;
   constexpr int OFFY = ALT ? 0 : 480;    // byte offset of the vector block inside a row
   constexpr int TCOL = ALT ? 0 : 120;    // float column of the vector block
   extern __shared__ float4 lds4[];
@@ -126,14 +125,13 @@ __global__ __launch_bounds__(DG_THREADS) void k_conv_dg(DgArgs a) {
     const int n0 = RFL(t_at.x), n_dst = RFL(t_at.y);
     const int2 span = a.tile_span[tile];
     const int s_lo = RFL(span.x), rows = RFL(span.y) - s_lo;
-    const int rows16 = (rows + 15) & ~15;   // rows of the T product (multiples of the 16-row MFMA tile), <= RS
-    const int n_rt = rows16 >> 4;
+    const int rows16 = rows;
     DSTAMP(ta);
 
     // ---- segment prologue: source rows -> LDS (x1 re-laid as [u][4] with the T slot second); zero the A tiles
     // (staging loops: DG_SB global loads are issued before the first LDS store — a load-store-load chain would serialise one
     // L2 round trip per element and the re-staging of the alternating mode sits on the critical path of every hidden unit)
-    auto stage_x0 = [&]() {  // ALT: scalar channels of every source row (+ zero padding; rows >= `rows` zero: the T product reads them)
+    auto stage_x0 = [&]() {  // ALT: scalar channels of every source row (+ zero padding)
       const int total = rows16 * (DG_XST_ALT / 4);
       for (int base = tid; base < total; base += DG_SBA * DG_THREADS) {
         float4 v[DG_SBA];
@@ -152,24 +150,21 @@ __global__ __launch_bounds__(DG_THREADS) void k_conv_dg(DgArgs a) {
         }
       }
     };
-    auto stage_x1 = [&]() {  // ALT: vector block (x, *, y, z) of every source row; the T slot (*) is written by the matrix waves
+    auto stage_x1 = [&](int k) {  // ALT: vector block (x, T_k, y, z) of every source row (T from the pre-pass buffer)
       const int total = rows * 32;
+      const float* __restrict__ tk = a.T + ((size_t)k * a.n_atoms + s_lo) * 32;
       for (int base = tid; base < total; base += DG_SBA * DG_THREADS) {
-        float vx[DG_SBA], vy[DG_SBA], vz[DG_SBA];
+        float4 v[DG_SBA];
 #pragma unroll
         for (int q8 = 0; q8 < DG_SBA; ++q8) {
           const int idx = min(base + q8 * DG_THREADS, total - 1);
           const float* __restrict__ p1 = a.x + (size_t)(s_lo + (idx >> 5)) * a.XS + 120 + 3 * (idx & 31);
-          vx[q8] = p1[0]; vy[q8] = p1[1]; vz[q8] = p1[2];
+          v[q8] = make_float4(p1[0], tk[idx], p1[1], p1[2]);
         }
 #pragma unroll
         for (int q8 = 0; q8 < DG_SBA; ++q8) {
           const int idx = base + q8 * DG_THREADS;
-          if (idx < total) {
-            float* __restrict__ d = xs + (size_t)(idx >> 5) * DG_XST_ALT + 4 * (idx & 31);
-            d[0] = vx[q8];
-            *reinterpret_cast<float2*>(d + 2) = make_float2(vy[q8], vz[q8]);
-          }
+          if (idx < total) *reinterpret_cast<float4*>(xs + (size_t)(idx >> 5) * DG_XST_ALT + 4 * (idx & 31)) = v[q8];
         }
       }
     };
@@ -220,12 +215,11 @@ __global__ __launch_bounds__(DG_THREADS) void k_conv_dg(DgArgs a) {
 
       // weight blocks (64 lanes x float4) of one hidden unit, in the order this wave consumes them:
       //   P1: WX[w][g], g = 0..14, with WX[4][4 s + w] after g = 3, 7, 11, 14          (19 blocks: chunks 5 5 5 4)
-      //   P2: WD[w][0..3], WD[4][w] | WV[ch][0..3] | WT[g][0..1], g = 0..7              (5 | 4 | 4 x 4)
+      //   P2: WD[w][0..3], WD[4][w] | WV[ch][0..3]                                       (5 | 4)
       // (uniform block base in scalar registers + the lane as a 32-bit offset: one address register per load, not two)
       auto WX = [&](int k, int t, int g) { return (a.wx + ((size_t)k * 5 * 16 + t * 16 + g) * 64)[lane]; };
       auto WD = [&](int k, int t, int g) { return (a.wd + ((size_t)k * 5 * 4 + t * 4 + g) * 64)[lane]; };
       auto WV = [&](int k, int c, int g) { return (a.wv + ((size_t)k * 2 * 4 + c * 4 + g) * 64)[lane]; };
-      auto WT = [&](int k, int g, int c) { return (a.wt + ((size_t)k * 8 * 2 + g * 2 + c) * 64)[lane]; };
 
       float4 B0[5], B1[5];
       auto load_x = [&](float4 (&B)[5], int k, int c) {  // chunk c of P1: groups 4c..4c+3 (+ the quarter group 4c + w)
@@ -301,53 +295,34 @@ __global__ __launch_bounds__(DG_THREADS) void k_conv_dg(DgArgs a) {
           for (int m = 0; m < 3; ++m) av[m] = an[m];
         }
       };
-      // T product of hidden unit k: T[j][w'] = sum_u x0_j[u] W[(k,u)][w'], row tiles rt = w, w + 4 (16 rows each), both
-      // 16-column halves per row tile (two independent accumulators keep the 16x16x4 MFMA at its issue rate)
-      f32x4 accT[NP][2];
-      auto load_t = [&](float4 (&B)[5], int k, int c) {  // chunk c: groups 2c, 2c+1, both column halves
+      // T_k[j][w'] = sum_u x0_j[u] W[(k,u)][w'] comes from the pre-pass k_tprod (once per source atom and layer, not once
+      // per tile span).  Resident mode: the matrix waves copy the rows of the span for hidden unit k+1 into the T slots of the
+      // source rows during P2(k) (loads issued at the start of the phase, stores at its end).  Alternating mode: T is staged
+      // together with the vector block by all threads (stage_x1).
+      constexpr int TLD = ALT ? 1 : 7;  // T elements per matrix-wave thread held in registers: 256 threads x 7 = 56 rows x 32
+      float tpre[TLD];
+      auto load_tslots = [&](int k) {
+        if constexpr (!ALT) {
+          const float* __restrict__ tk = a.T + ((size_t)k * a.n_atoms + s_lo) * 32;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) B[i] = WT(k, 2 * c + (i >> 1), i & 1);
-      };
-      auto run_t = [&](const float4 (&B)[5], int c) {
-        if (dbg_nomfma) return;
-#pragma unroll
-        for (int p = 0; p < NP; ++p) {
-          if (w + 4 * p >= n_rt) break;  // wave-uniform
-          const float* __restrict__ Ta = xs + (size_t)(16 * (w + 4 * p) + r16) * DG_XST + 4 * kq;
-          float4 avs[2];
-#pragma unroll
-          for (int gi = 0; gi < 2; ++gi) avs[gi] = *reinterpret_cast<const float4*>(Ta + 16 * (2 * c + gi));  // both groups up front
-#pragma unroll
-          for (int gi = 0; gi < 2; ++gi) {
-            const float4 av = avs[gi];
-            accT[p][0] = MFMA16(av.x, B[2 * gi].x, accT[p][0]);
-            accT[p][1] = MFMA16(av.x, B[2 * gi + 1].x, accT[p][1]);
-            accT[p][0] = MFMA16(av.y, B[2 * gi].y, accT[p][0]);
-            accT[p][1] = MFMA16(av.y, B[2 * gi + 1].y, accT[p][1]);
-            accT[p][0] = MFMA16(av.z, B[2 * gi].z, accT[p][0]);
-            accT[p][1] = MFMA16(av.z, B[2 * gi + 1].z, accT[p][1]);
-            accT[p][0] = MFMA16(av.w, B[2 * gi].w, accT[p][0]);
-            accT[p][1] = MFMA16(av.w, B[2 * gi + 1].w, accT[p][1]);
+          for (int q = 0; q < TLD; ++q) {
+            const int idx = min(w * 64 + lane + 256 * q, rows * 32 - 1);
+            tpre[q] = tk[idx];
           }
         }
       };
-      auto zero_t = [&]() {
+      auto store_tslots = [&](int k) {
+        if constexpr (!ALT) {
 #pragma unroll
-        for (int p = 0; p < NP; ++p)
-#pragma unroll
-          for (int c = 0; c < 2; ++c) accT[p][c] = f32x4{0.f, 0.f, 0.f, 0.f};
-      };
-      auto store_t = [&]() {  // D[row = 4 kq + q][col = r16] of each 16x16 sub-tile -> slot 1 of the vector block of xs[row]
-#pragma unroll
-        for (int p = 0; p < NP; ++p) {
-          if (w + 4 * p >= n_rt) break;
-#pragma unroll
-          for (int c = 0; c < 2; ++c)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) xs[(size_t)(16 * (w + 4 * p) + 4 * kq + q) * DG_XST + TCOL + 4 * (16 * c + r16) + 1] = accT[p][c][q];
+          for (int q = 0; q < TLD; ++q) {
+            const int idx = w * 64 + lane + 256 * q;
+            if (idx < rows * 32) xs[(size_t)(idx >> 5) * DG_XST + TCOL + 4 * (idx & 31) + 1] = tpre[q];
+          }
+          // spans above 56 rows: the rest in a plain loop (two 29..40-atom molecules per tile)
+          const float* __restrict__ tk = a.T + ((size_t)k * a.n_atoms + s_lo) * 32;
+          for (int idx = w * 64 + lane + 256 * TLD; idx < rows * 32; idx += 256) xs[(size_t)(idx >> 5) * DG_XST + TCOL + 4 * (idx & 31) + 1] = tk[idx];
         }
       };
-      // (row tiles beyond w + 4 (NP - 1) do not occur: the host caps the span at RS <= 64 NP)
 
       if (a.row_blocks && !__syncthreads_or(0)) {  // a (destination chunk x source row block) tile without any edge: zero slab
 #pragma unroll
@@ -362,22 +337,17 @@ __global__ __launch_bounds__(DG_THREADS) void k_conv_dg(DgArgs a) {
         __syncthreads();
         continue;
       }
-      // "P2(-1)": T of the first hidden unit (no Y yet)
+      // "P2(-1)": T slots of the first hidden unit (no Y yet); first weight chunks
       {
         const int k0 = k_of(0);
-        zero_t();
-        load_t(B0, k0, 0);
-        load_t(B1, k0, 1);
-        run_t(B0, 0); load_t(B0, k0, 2);
-        run_t(B1, 1); load_t(B1, k0, 3);
-        run_t(B0, 2); load_x(B0, k0, 0);
-        run_t(B1, 3); load_x(B1, k0, 1);
-        if constexpr (!ALT) store_t();
+        load_tslots(k0);
+        load_x(B0, k0, 0);
+        load_x(B1, k0, 1);
+        store_tslots(k0);
       }
       LDS_BARRIER();
-      if constexpr (ALT) {  // swap the scalar channels for the vector blocks; T(k0) goes into its slots
-        stage_x1();
-        store_t();
+      if constexpr (ALT) {  // swap the scalar channels for the vector blocks (+ T of the first hidden unit)
+        stage_x1(k_of(0));
         LDS_BARRIER();
       }
       DSTAMP(tb); DACC(0, tb, ta);
@@ -397,21 +367,15 @@ __global__ __launch_bounds__(DG_THREADS) void k_conv_dg(DgArgs a) {
           LDS_BARRIER();
         }
         DSTAMP(ta); DACC(2, ta, tb);
-        // ---- P2: Y(k) x W, then T(k+1)
-        run_d(B0); load_t(B0, kn, 0);
-        run_v(B1); load_t(B1, kn, 1);
-        if (has_next) {
-          zero_t();
-          run_t(B0, 0); load_t(B0, kn, 2);
-          run_t(B1, 1); load_t(B1, kn, 3);
-          run_t(B0, 2); load_x(B0, kn, 0);
-          run_t(B1, 3); load_x(B1, kn, 1);
-          if constexpr (!ALT) store_t();
-        }
+        // ---- P2: Y(k) x W; T slots of k+1 (nobody reads T during P2)
+        if (has_next) load_tslots(kn);
+        run_d(B0); load_x(B0, kn, 0);
+        run_v(B1); load_x(B1, kn, 1);
+        if (has_next) store_tslots(kn);
         DSTAMP(tb); DACC(3, tb, ta);
         LDS_BARRIER();
         if constexpr (ALT) {
-          if (has_next) { stage_x1(); store_t(); }
+          if (has_next) { stage_x1(kn); }
           LDS_BARRIER();
         }
         DSTAMP(ta); DACC(4, ta, tb);
@@ -657,7 +621,7 @@ __global__ __launch_bounds__(DG_THREADS) void k_conv_dg(DgArgs a) {
       form_x();
       LDS_BARRIER();
       if constexpr (ALT) {
-        stage_x1();
+        stage_x1(k_of(0));
         LDS_BARRIER();
       }
       DSTAMP(tb); DACC(0, tb, ta);
@@ -682,7 +646,7 @@ __global__ __launch_bounds__(DG_THREADS) void k_conv_dg(DgArgs a) {
         DSTAMP(tb); DACC(3, tb, ta);
         LDS_BARRIER();
         if constexpr (ALT) {
-          if (has_next) { stage_x1(); }
+          if (has_next) { stage_x1(k_of(it + 1)); }
           LDS_BARRIER();
         }
         DSTAMP(ta); DACC(4, ta, tb);
@@ -743,12 +707,61 @@ void conv_dg_print_stamps() {
 #endif
 }
 
+// ------------------------------------------------------------------------------------------------------------------------
+// k_tprod — pre-pass of a hidden layer: T[k][j][w'] = sum_u x0_j[u] W~[(k,u)][w'] for every atom j and hidden unit k (the
+// scalar-input -> vector-row weights; k_conv_dg applies  out_m[i][w'] += sum_e (c_e v_m) T_k[j_e][w']).  Computing it once per
+// source atom costs 2*120*32 FLOP per (atom, k); inside k_conv_dg it was recomputed for every tile whose span contains the atom
+// (x1.6 for 17-atom molecules, x5 for a 166-atom molecule: 352 of 828 MFMA units per (tile, k)).
+// One wave = 32 atoms x a subset of the hidden units: the A operand (32 x 120 inputs) is loaded into registers once, per k the
+// 15 weight blocks stream from L2 and 60 v_mfma_f32_32x32x2 produce a 32 x 32 tile that goes straight to HBM.
+// grid = (ceil(n_atoms / 32), TP_KG); 4 waves per workgroup, no LDS, no barriers; ~4 waves per SIMD hide the load latency
+// (measured on cfg2: 2 k-groups 59 us, 8 k-groups 36 us; a double-buffered single-wave variant 42 us).
+#define TP_WAVES 4
+#define TP_KG 8
+__global__ __launch_bounds__(64 * TP_WAVES) void k_tprod(const float* __restrict__ x, int XS, int n_atoms, int n_k,
+                                                         const float4* __restrict__ wt, float* __restrict__ T) {
+  const int lane = threadIdx.x & 63, wave = RFL(threadIdx.x >> 6);
+  const int r = lane & 31, hh = lane >> 5;
+  const int a0 = blockIdx.x * 32;
+  const int row = min(a0 + r, n_atoms - 1);
+  float4 av[15];
+#pragma unroll
+  for (int g = 0; g < 15; ++g) av[g] = *reinterpret_cast<const float4*>(x + (size_t)row * XS + 8 * g + 4 * hh);
+  const int slot = blockIdx.y * TP_WAVES + wave, n_slots = TP_KG * TP_WAVES;
+  for (int k = slot; k < n_k; k += n_slots) {
+    const float4* __restrict__ wk = wt + (size_t)k * 15 * 64;
+    float4 bv[15];
+#pragma unroll
+    for (int g = 0; g < 15; ++g) bv[g] = wk[g * 64 + lane];
+    f32x16 acc;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc[q] = 0.f;
+#pragma unroll
+    for (int g = 0; g < 15; ++g) {
+      acc = MFMA32(av[g].x, bv[g].x, acc);
+      acc = MFMA32(av[g].y, bv[g].y, acc);
+      acc = MFMA32(av[g].z, bv[g].z, acc);
+      acc = MFMA32(av[g].w, bv[g].w, acc);
+    }
+    float* __restrict__ tk = T + ((size_t)k * n_atoms + a0) * 32;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int rr = (q & 3) + 8 * (q >> 2) + 4 * hh;
+      if (a0 + rr < n_atoms) tk[rr * 32 + r] = acc[q];
+    }
+  }
+}
+
+void launch_tprod(const float* x, int XS, int n_atoms, int n_k, const float4* wt, float* T, hipStream_t st) {
+  hipLaunchKernelGGL(k_tprod, dim3((n_atoms + 31) / 32, TP_KG), dim3(64 * TP_WAVES), 0, st, x, XS, n_atoms, n_k, wt, T);
+}
+
 size_t conv_dg_lds_bytes(int rs, int pmax, int alt) { return sizeof(float) * ((dg_lds_floats(rs, pmax, alt) + 3) & ~(size_t)3); }
 
 int launch_conv_dg(const DgArgs& a, int grid, hipStream_t st) {
   const size_t smem = conv_dg_lds_bytes(a.RS, a.PMAX, a.alt);
   if (smem > JAMUN_MAX_DYN_LDS) return -2;
-  if (a.RS > 64 * (a.alt ? DG_NP_ALT : DG_NP_RES) || (a.RS & 15) || a.XS != 216 || a.nt0 != 5) return -1;
+  if (a.RS > (a.alt ? DG_RS_MAX_ALT : DG_RS_MAX_RES) || a.XS != 216 || a.nt0 != 5) return -1;
   if (a.alt) hipLaunchKernelGGL(k_conv_dg<true>, dim3(grid), dim3(DG_THREADS), smem, st, a);
   else hipLaunchKernelGGL(k_conv_dg<false>, dim3(grid), dim3(DG_THREADS), smem, st, a);
   return 0;

@@ -88,7 +88,8 @@ struct DgArgs {
   const float4* wx;  // [k][5 output tiles][16 groups (15 = zeros)]   scalar inputs -> scalar rows   (32x32x2: u = 8g + 4hh + st)
   const float4* wd;  // [k][5][4]                                      dot(x1, v)    -> scalar rows
   const float4* wv;  // [k][2 column halves][4]   x1 | cross -> vector rows                          (16x16x4: kappa = 16g + 4kq + st)
-  const float4* wt;  // [k][8 groups][2 column halves]   scalar inputs -> T                             (16x16x4: u = 16g + 4kq + st)
+  const float* T;    // [k][n_atoms][32]  T_k[j][w'] = sum_u x0_j[u] W[(k,u)][w'] from the pre-pass k_tprod (scalar inputs -> vector rows)
+  int n_atoms;
   float* partial0;   // [slab][n_pad][nt0*32]
   float* partial1;   // [slab][n_pad][3][32]
 };
@@ -189,6 +190,7 @@ int launch_conv_dg(const DgArgs& a, int grid, hipStream_t st);
 int conv_dg_set_max_lds();
 void conv_dg_print_stamps();
 size_t conv_dg_lds_bytes(int rs, int pmax, int alt);
+void launch_tprod(const float* x, int XS, int n_atoms, int n_k, const float4* wt, float* T, hipStream_t st);
 int launch_conv_init(const InitArgs& a, int grid, hipStream_t st);
 int conv_init_set_max_lds();
 size_t conv_init_lds_bytes(int JR);
