@@ -286,7 +286,8 @@ struct jamun_sampler {
   bool row_blocks = false;            // some molecule exceeds the per-tile source budget
   int* atom_nslab = nullptr;          // [n_atoms] partial slabs of the tile the atom belongs to
   // destination-grouped VALU-forming conv kernel (jamun_conv_dg.hip; hidden layers): own tile plan (larger source spans)
-  bool dg_on = false, dg_row_blocks = false, dg_alt = false;
+  bool dg_on = false, dg_row_blocks = false;
+  int dg_mode = 0;  // 0 two-phase resident, 1 alternating residency, 2 single phase (see jamun_sampler_create)
   int dg_RS = 0, dg_grid = 0, dg_max_segs = 0, dg_n_slabs = 0, dg_n_tiles = 0;
   int2 *dg_tile_atoms = nullptr, *dg_tile_span = nullptr;
   int4* dg_segs = nullptr;
@@ -798,7 +799,7 @@ void forward(jamun_sampler* s, float* y, float* xhat, float* score, hipStream_t 
       f.deg = s->deg; f.esrc = s->esrc; f.egeo = s->egeo; f.h = h_l; f.h_kstride = s->h_kstride; f.x = x_in;
       f.n_pad = s->n_pad; f.S = s->S; f.XS = XSin; f.RS = s->dg_RS; f.PMAX = (s->S + 3) & ~3;  // multiple of the forming batch
       f.tile_span = s->dg_tile_span; f.tile_atoms = s->dg_tile_atoms; f.segs = s->dg_segs; f.max_segs = s->dg_max_segs;
-      f.row_blocks = s->dg_row_blocks ? 1 : 0; f.nt0 = L.p0.nt; f.alt = s->dg_alt ? 1 : 0;
+      f.row_blocks = s->dg_row_blocks ? 1 : 0; f.nt0 = L.p0.nt; f.alt = s->dg_mode;
       f.wx = L.dg.wx; f.wd = L.dg.wd; f.wv = L.dg.wv; f.T = s->dg_T; f.n_atoms = s->n_atoms;
       f.partial0 = s->partial0; f.partial1 = s->partial1;
       static const int dg_dbg = getenv("JAMUN_DG_DBG") ? atoi(getenv("JAMUN_DG_DBG")) : 0;
@@ -1270,28 +1271,44 @@ int jamun_sampler_create(const jamun_model* m, float sigma, const jamun_topology
       // otherwise the alternating-residency mode of the kernel (rows re-staged per phase: spans up to ~170 rows), and only
       // molecules above THAT are cut into source row blocks.
       const int pmax = (s->S + 3) & ~3;
-      auto cap_of = [&](int alt) {
-        for (int rs = alt ? 192 : 128; rs >= 16; rs -= 4)
-          if (conv_dg_lds_bytes(rs, pmax, alt) <= JAMUN_MAX_DYN_LDS) return rs;
+      auto cap_of = [&](int mode) {
+        for (int rs = mode == 1 ? 192 : 128; rs >= 16; rs -= 4)
+          if (conv_dg_lds_bytes(rs, pmax, mode) <= JAMUN_MAX_DYN_LDS) return rs;
         return 0;
       };
+      // Modes of k_conv_dg: 0 two phases per k, source rows resident (spans up to ~80 rows); 1 alternating residency (molecules
+      // above that, up to ~176 atoms; only larger ones are cut into source row blocks); 2 single phase with double-buffered A
+      // tiles (spans up to ~52 rows) — chosen when the smaller span budget does not cost tiles (17-atom molecules: three per
+      // tile either way; a 40-atom molecule would fall from straddling tiles to 32 + 8 destinations).
       int cap = ok ? cap_of(0) : 0;
+      std::vector<int2> t_atoms, t_span;
+      std::vector<int> t_chunk;
+      int n_chunks = 0, span_max = 0;
       if (ok && nmax > cap && getenv("JAMUN_DG_NO_ALT") == nullptr) {
         const int cap_alt = cap_of(1);
-        if (cap_alt > cap) { cap = cap_alt; s->dg_alt = true; }
+        if (cap_alt > cap) { cap = cap_alt; s->dg_mode = 1; }
       }
       if (ok && cap > 0) {
-        std::vector<int2> t_atoms, t_span;
-        std::vector<int> t_chunk;
-        int n_chunks = 0, span_max = 0;
         plan_tiles(topo->ptr, graph_of, N, cap, t_atoms, t_span, t_chunk, n_chunks, span_max, s->dg_row_blocks);
+        const int cap_sp = cap_of(2);
+        if (s->dg_mode == 0 && cap_sp >= 16 && getenv("JAMUN_DG_NO_SP") == nullptr) {
+          std::vector<int2> a2, s2;
+          std::vector<int> c2;
+          int nc2 = 0, sm2 = 0;
+          bool rb2 = false;
+          plan_tiles(topo->ptr, graph_of, N, cap_sp, a2, s2, c2, nc2, sm2, rb2);
+          if (!rb2 && 100 * a2.size() <= 103 * t_atoms.size()) {
+            t_atoms.swap(a2); t_span.swap(s2); t_chunk.swap(c2);
+            n_chunks = nc2; span_max = sm2; s->dg_row_blocks = false; s->dg_mode = 2;
+          }
+        }
         s->dg_RS = std::max((span_max + 3) & ~3, 16);  // (>= 16 rows: the segment-end staging tile of the forming waves aliases the source rows)
         s->dg_n_tiles = (int)t_atoms.size();
         // k-slices over XCD groups (JAMUN_DG_KGROUPS = 1, 2, 4, 8).  Measured on MI355X (cfg2, profiles/r2*): 1 slice 0.317 ms per
         // launch, 2: 0.318, 4: 0.328, 8: 0.343 and the node update slows from 25 to 71 us (more partial slabs per tile): the
         // ~7.7 MB of weight blocks per layer are served from L2 / Infinity Cache fast enough, longer runs of k per segment win.
         const int ng = k_groups("JAMUN_DG_KGROUPS", 1);
-        auto weight = [&](int t) -> int64_t { return 476 + (s->dg_alt ? 24 : 2) * ((t_span[t].y - t_span[t].x + 15) / 16); };
+        auto weight = [&](int t) -> int64_t { return 476 + (s->dg_mode == 1 ? 24 : 2) * ((t_span[t].y - t_span[t].x + 15) / 16); };
         SegPlan P = plan_segments(cus, ng, n_k, N, t_atoms, t_chunk, n_chunks, weight);
         s->dg_grid = cus;
         s->dg_max_segs = P.max_segs;

@@ -68,9 +68,11 @@ __device__ unsigned long long g_dgstamp[2][8];  // [role][prologue, P1 work, P1 
 #define DACC(slot, t1, t0) do { } while (0)
 #endif
 
-__host__ __device__ inline size_t dg_lds_floats(int rs, int pmax, int alt) {
-  // xs | X (+4: the dummy quarter group reads 4 floats past the last row) | Yd | Yv | tabA | tabJ | deg
-  return (size_t)rs * (alt ? DG_XST_ALT : DG_XST_RES) + 32 * DG_XS0 + 8 + 32 * DG_YD + 3 * 32 * DG_YV + (size_t)32 * pmax * 4 +
+#define DG_ABUF (32 * DG_XS0 + 8 + 32 * DG_YD + 3 * 32 * DG_YV)  // floats of one set of A tiles (X | Yd | Yv)
+// mode: 0 two-phase with resident source rows, 1 two-phase with alternating residency, 2 single phase (double-buffered A tiles)
+__host__ __device__ inline size_t dg_lds_floats(int rs, int pmax, int mode) {
+  // xs | A tiles: X (+8: the dummy quarter group reads 4 floats past the last row) | Yd | Yv | tabA | tabJ | deg
+  return (size_t)rs * (mode == 1 ? DG_XST_ALT : DG_XST_RES) + (size_t)(mode == 2 ? 2 : 1) * DG_ABUF + (size_t)32 * pmax * 4 +
          (size_t)32 * pmax + 32;
 }
 
@@ -80,8 +82,13 @@ __host__ __device__ inline size_t dg_lds_floats(int rs, int pmax, int alt) {
 // rows from global memory (L2) at both phase boundaries of every hidden unit: 2 x rows x ~0.5 KB per k and two more barriers,
 // instead of cutting the sources into row blocks whose (destination chunk, block) tiles each pay the full contraction.
 // T(k+1) stays in the matrix waves' accumulators across the re-staging and is written into the freshly staged vector block.
-template <bool ALT>
+// MODE 2 (SP, spans up to ~52 rows: 2AA-size molecules): ONE phase per hidden unit.  The A tiles are double buffered (93 KB), the
+// matrix waves run X(k) W and Y(k) W back to back while the forming waves build X(k+1) and Y(k+1) in ONE pass over the edges
+// (one table read, one row address and 9 packed + 1 scalar FMA per edge instead of two passes with their own reads), one
+// barrier per k plus a short second one around the copy of T(k+2) into its slots.
+template <int MODE>
 __global__ __launch_bounds__(DG_THREADS) void k_conv_dg(DgArgs a) {
+  constexpr bool ALT = MODE == 1, SP = MODE == 2;
   constexpr int DG_XST = ALT ? DG_XST_ALT : DG_XST_RES;
   constexpr int OFFY = ALT ? 0 : 480;    // byte offset of the vector block inside a row
   constexpr int TCOL = ALT ? 0 : 120;    // float column of the vector block
@@ -91,7 +98,7 @@ __global__ __launch_bounds__(DG_THREADS) void k_conv_dg(DgArgs a) {
   float* __restrict__ Xt = xs + (size_t)a.RS * DG_XST;           // [32][DG_XS0] (+8)
   float* __restrict__ Yd = Xt + 32 * DG_XS0 + 8;                 // [32][DG_YD]
   float* __restrict__ Yv = Yd + 32 * DG_YD;                      // [3][32][DG_YV]
-  float4* __restrict__ tabA = reinterpret_cast<float4*>(Yv + 3 * 32 * DG_YV);  // [32][PMAX] (c, c vx, c vy, c vz)
+  float4* __restrict__ tabA = reinterpret_cast<float4*>(Xt + (SP ? 2 : 1) * DG_ABUF);  // [32][PMAX] (c, c vx, c vy, c vz)
   int* __restrict__ tabJ = reinterpret_cast<int*>(tabA + 32 * a.PMAX);          // [32][PMAX] byte offset of the source row in xs
   int* __restrict__ deg_lds = tabJ + 32 * a.PMAX;                               // [32]
   // segment end: the output tile is staged in LDS (dead A tiles / source rows) and stored by ALL threads as coalesced float4 rows
@@ -193,7 +200,7 @@ __global__ __launch_bounds__(DG_THREADS) void k_conv_dg(DgArgs a) {
         }
       }
     }
-    for (int idx = tid; idx < 32 * DG_XS0 + 8 + 32 * DG_YD + 3 * 32 * DG_YV; idx += DG_THREADS) Xt[idx] = 0.f;
+    for (int idx = tid; idx < (SP ? 2 : 1) * DG_ABUF; idx += DG_THREADS) Xt[idx] = 0.f;
     if (tid < 32) deg_lds[tid] = (tid < n_dst) ? a.deg[n0 + tid] : 0;
     LDS_BARRIER();  // (LDS-only: the previous segment's slab stores keep draining in the background)
 
@@ -209,9 +216,9 @@ __global__ __launch_bounds__(DG_THREADS) void k_conv_dg(DgArgs a) {
       for (int q = 0; q < 16; ++q) { accM[q] = 0.f; acc4[q] = 0.f; }
 #pragma unroll
       for (int m = 0; m < 3; ++m) accP[m] = f32x4{0.f, 0.f, 0.f, 0.f};
-      const float* __restrict__ Xa = Xt + r * DG_XS0 + 4 * hh;
-      const float* __restrict__ Da = Yd + r * DG_YD + 4 * hh;
-      const float* __restrict__ Va = Yv + (16 * rh + r16) * DG_YV + 4 * kq;
+      const float* Xa = Xt + r * DG_XS0 + 4 * hh;  // (SP: re-pointed to the A buffer of the hidden unit at hand)
+      const float* Da = Yd + r * DG_YD + 4 * hh;
+      const float* Va = Yv + (16 * rh + r16) * DG_YV + 4 * kq;
 
       // weight blocks (64 lanes x float4) of one hidden unit, in the order this wave consumes them:
       //   P1: WX[w][g], g = 0..14, with WX[4][4 s + w] after g = 3, 7, 11, 14          (19 blocks: chunks 5 5 5 4)
@@ -337,48 +344,87 @@ __global__ __launch_bounds__(DG_THREADS) void k_conv_dg(DgArgs a) {
         __syncthreads();
         continue;
       }
+      if constexpr (SP) {
+        // ---- single phase per hidden unit
+        {
+          const int k0 = k_of(0);
+          load_tslots(k0);
+          load_x(B0, k0, 0);
+          load_x(B1, k0, 1);
+          store_tslots(k0);
+        }
+        LDS_BARRIER();                    // T(k0) in its slots: the forming waves build A(k0) into buffer 0
+        if (nk > 1) load_tslots(k_of(1));
+        LDS_BARRIER();                    // A(k0) complete
+        if (nk > 1) store_tslots(k_of(1));
+        LDS_BARRIER();                    // T(k1) in its slots
+        DSTAMP(tb); DACC(0, tb, ta);
+        for (int it = 0; it < nk; ++it) {
+          const int k = k_of(it), kn = k_of(it + 1);
+          DSTAMP(ta);
+          const int bo = (it & 1) * DG_ABUF;
+          Xa = Xt + bo + r * DG_XS0 + 4 * hh;
+          Da = Yd + bo + r * DG_YD + 4 * hh;
+          Va = Yv + bo + (16 * rh + r16) * DG_YV + 4 * kq;
+          if (it + 2 < nk) load_tslots(k_of(it + 2));
+          run_x(B0, 0); load_x(B0, k, 2);
+          run_x(B1, 1); load_x(B1, k, 3);
+          run_x(B0, 2); load_d(B0, k);
+          run_x(B1, 3); load_v(B1, k);
+          run_d(B0); load_x(B0, kn, 0);
+          run_v(B1); load_x(B1, kn, 1);
+          DSTAMP(tb); DACC(1, tb, ta);
+          LDS_BARRIER();                  // A(k+1) complete; nobody reads A(k) or T(k+1) any more
+          DSTAMP(ta); DACC(2, ta, tb);
+          if (it + 2 < nk) store_tslots(k_of(it + 2));
+          DSTAMP(tb); DACC(3, tb, ta);
+          LDS_BARRIER();
+          DSTAMP(ta); DACC(4, ta, tb);
+        }
+      } else {
       // "P2(-1)": T slots of the first hidden unit (no Y yet); first weight chunks
-      {
-        const int k0 = k_of(0);
-        load_tslots(k0);
-        load_x(B0, k0, 0);
-        load_x(B1, k0, 1);
-        store_tslots(k0);
-      }
-      LDS_BARRIER();
-      if constexpr (ALT) {  // swap the scalar channels for the vector blocks (+ T of the first hidden unit)
-        stage_x1(k_of(0));
+        {
+          const int k0 = k_of(0);
+          load_tslots(k0);
+          load_x(B0, k0, 0);
+          load_x(B1, k0, 1);
+          store_tslots(k0);
+        }
         LDS_BARRIER();
-      }
-      DSTAMP(tb); DACC(0, tb, ta);
-      for (int it = 0; it < nk; ++it) {
-        const int k = k_of(it), kn = k_of(it + 1);
-        DSTAMP(ta);
-        const bool has_next = it + 1 < nk;
-        // ---- P1: X(k) x W  (B0 = chunk 0, B1 = chunk 1 already in flight)
-        run_x(B0, 0); load_x(B0, k, 2);
-        run_x(B1, 1); load_x(B1, k, 3);
-        run_x(B0, 2); load_d(B0, k);
-        run_x(B1, 3); load_v(B1, k);
-        DSTAMP(tb); DACC(1, tb, ta);
-        LDS_BARRIER();
-        if constexpr (ALT) {
-          if (has_next) { stage_x0(); }
+        if constexpr (ALT) {  // swap the scalar channels for the vector blocks (+ T of the first hidden unit)
+          stage_x1(k_of(0));
           LDS_BARRIER();
         }
-        DSTAMP(ta); DACC(2, ta, tb);
-        // ---- P2: Y(k) x W; T slots of k+1 (nobody reads T during P2)
-        if (has_next) load_tslots(kn);
-        run_d(B0); load_x(B0, kn, 0);
-        run_v(B1); load_x(B1, kn, 1);
-        if (has_next) store_tslots(kn);
-        DSTAMP(tb); DACC(3, tb, ta);
-        LDS_BARRIER();
-        if constexpr (ALT) {
-          if (has_next) { stage_x1(kn); }
+        DSTAMP(tb); DACC(0, tb, ta);
+        for (int it = 0; it < nk; ++it) {
+          const int k = k_of(it), kn = k_of(it + 1);
+          DSTAMP(ta);
+          const bool has_next = it + 1 < nk;
+          // ---- P1: X(k) x W  (B0 = chunk 0, B1 = chunk 1 already in flight)
+          run_x(B0, 0); load_x(B0, k, 2);
+          run_x(B1, 1); load_x(B1, k, 3);
+          run_x(B0, 2); load_d(B0, k);
+          run_x(B1, 3); load_v(B1, k);
+          DSTAMP(tb); DACC(1, tb, ta);
           LDS_BARRIER();
+          if constexpr (ALT) {
+            if (has_next) { stage_x0(); }
+            LDS_BARRIER();
+          }
+          DSTAMP(ta); DACC(2, ta, tb);
+          // ---- P2: Y(k) x W; T slots of k+1 (nobody reads T during P2)
+          if (has_next) load_tslots(kn);
+          run_d(B0); load_x(B0, kn, 0);
+          run_v(B1); load_x(B1, kn, 1);
+          if (has_next) store_tslots(kn);
+          DSTAMP(tb); DACC(3, tb, ta);
+          LDS_BARRIER();
+          if constexpr (ALT) {
+            if (has_next) { stage_x1(kn); }
+            LDS_BARRIER();
+          }
+          DSTAMP(ta); DACC(4, ta, tb);
         }
-        DSTAMP(ta); DACC(4, ta, tb);
       }
       DSTAMP(ta);
       // ---- segment end: accumulators -> LDS staging tile (the A tiles are dead after the last barrier)
@@ -614,42 +660,141 @@ __global__ __launch_bounds__(DG_THREADS) void k_conv_dg(DgArgs a) {
         }
       };
 
+      // SP: X and Y of one hidden unit in ONE pass over the edges, into A buffer `buf`
+      auto form_xy = [&](int buf) {
+        float* __restrict__ Xo = Xt + buf * DG_ABUF;
+        float* __restrict__ Ydo = Yd + buf * DG_ABUF;
+        float* __restrict__ Yvo = Yv + buf * DG_ABUF;
+#pragma unroll
+        for (int dp = 0; dp < DG_NDP; ++dp) {
+          const int i = 2 * DG_NDP * fw + 2 * dp + h;
+          f32x2 ax01 = {0.f, 0.f}, ax23 = {0.f, 0.f};
+          f32x2 p_a1x_o0 = {0.f, O[dp][0]}, p_a1yz = {0.f, 0.f}, p_o12 = {O[dp][1], O[dp][2]}, n3 = {0.f, 0.f}, n5 = {0.f, 0.f},
+                n7 = {0.f, 0.f}, p_d = {0.f, 0.f};
+          float d2 = 0.f;
+          const float4* __restrict__ ta = tabA + i * PMAX;
+          const int* __restrict__ tj = tabJ + i * PMAX;
+          const int nb = dbg_noform ? 0 : (P[dp] + DG_U - 1) / DG_U;
+          float4 cA[DG_U], cB[DG_U], xA[DG_U], xB[DG_U], z[DG_U];
+          int jA[DG_U], jB[DG_U];
+          auto ld_j = [&](int (&J)[DG_U], int bb) {
+            bb = bb < nb ? bb : nb - 1;
+#pragma unroll
+            for (int q = 0; q < DG_U; ++q) J[q] = tj[DG_U * bb + q];
+          };
+          auto ld_cx = [&](float4 (&c)[DG_U], float4 (&x)[DG_U], const int (&J)[DG_U], int bb) {
+            bb = bb < nb ? bb : nb - 1;
+#pragma unroll
+            for (int q = 0; q < DG_U; ++q) {
+              c[q] = ta[DG_U * bb + q];                                             // c, c vx | c vy, c vz
+              x[q] = *reinterpret_cast<const float4*>(xsb + (J[q] + offy));         // x1_j[u].x, T_k[j][u] | .y, .z
+            }
+          };
+          // the scalar channels of a batch are requested at the top of its FMA block and consumed at its end (behind the 32
+          // packed FMAs of the vector part): single-buffered, 16 registers instead of 32
+          auto fm = [&](const float4 (&c)[DG_U], const float4 (&x)[DG_U], const int (&J)[DG_U]) {
+#pragma unroll
+            for (int q = 0; q < DG_U; ++q) z[q] = *reinterpret_cast<const float4*>(xsb + (J[q] + offx));  // x0_j[4u..4u+3]
+#pragma unroll
+            for (int q = 0; q < DG_U; ++q) {
+              const float4 cf = c[q], xv = x[q];
+              p_a1x_o0 = pk(f32x2{cf.x, cf.y}, f32x2{xv.x, xv.y}, p_a1x_o0);    // (c x, cx T)
+              p_a1yz = pk(f32x2{cf.x, cf.x}, f32x2{xv.z, xv.w}, p_a1yz);        // (c y, c z)
+              p_o12 = pk(f32x2{cf.z, cf.w}, f32x2{xv.y, xv.y}, p_o12);          // (cy T, cz T)
+              n3 = pk(f32x2{cf.y, cf.y}, f32x2{xv.z, xv.w}, n3);                // (cx y, cx z)
+              n5 = pk(f32x2{cf.z, cf.w}, f32x2{xv.x, xv.x}, n5);                // (cy x, cz x)
+              n7 = pk(f32x2{cf.z, cf.w}, f32x2{xv.w, xv.z}, n7);                // (cy z, cz y)
+              p_d = pk(f32x2{cf.z, cf.w}, f32x2{xv.z, xv.w}, p_d);              // (cy y, cz z)
+              d2 = fmaf(cf.y, xv.x, d2);                                          // cx x
+            }
+#pragma unroll
+            for (int q = 0; q < DG_U; ++q) {
+              const f32x2 cc = {c[q].x, c[q].x};
+              ax01 = pk(cc, f32x2{z[q].x, z[q].y}, ax01);
+              ax23 = pk(cc, f32x2{z[q].z, z[q].w}, ax23);
+            }
+          };
+          if (nb > 0) {
+            ld_j(jA, 0); ld_cx(cA, xA, jA, 0); ld_j(jB, 1);
+            for (int bb = 0; bb < nb; bb += 2) {
+              ld_cx(cB, xB, jB, bb + 1);
+              fm(cA, xA, jA);
+              ld_j(jA, bb + 2);
+              if (bb + 1 < nb) {
+                ld_cx(cA, xA, jA, bb + 2);
+                fm(cB, xB, jB);
+                ld_j(jB, bb + 3);
+              }
+            }
+          }
+          O[dp][0] = p_a1x_o0.y; O[dp][1] = p_o12.x; O[dp][2] = p_o12.y;
+          if (u < 30) *reinterpret_cast<float4*>(Xo + i * DG_XS0 + 4 * u) = make_float4(ax01.x, ax01.y, ax23.x, ax23.y);
+          Ydo[i * DG_YD + u] = (p_d.x + p_d.y) + d2;
+          Yvo[(0 * 32 + i) * DG_YV + u] = p_a1x_o0.x; Yvo[(1 * 32 + i) * DG_YV + u] = p_a1yz.x; Yvo[(2 * 32 + i) * DG_YV + u] = p_a1yz.y;
+          Yvo[(0 * 32 + i) * DG_YV + 32 + u] = n7.y - n7.x; Yvo[(1 * 32 + i) * DG_YV + 32 + u] = n3.y - n5.y; Yvo[(2 * 32 + i) * DG_YV + 32 + u] = n5.x - n3.x;
+        }
+      };
+
+      if constexpr (SP) {
+        load_h(k_of(0));
+        write_tab();
+        load_h(k_of(1));
+        LDS_BARRIER();                    // T(k0) in its slots
+        form_xy(0);
+        if (nk > 1) { write_tab(); load_h(k_of(2)); }
+        LDS_BARRIER();                    // A(k0) complete
+        LDS_BARRIER();                    // T(k1) in its slots
+        DSTAMP(tb); DACC(0, tb, ta);
+        for (int it = 0; it < nk; ++it) {
+          DSTAMP(ta);
+          if (it + 1 < nk) {
+            form_xy((it + 1) & 1);
+            if (it + 2 < nk) { write_tab(); load_h(k_of(it + 3)); }
+          }
+          DSTAMP(tb); DACC(1, tb, ta);
+          LDS_BARRIER();
+          DSTAMP(ta); DACC(2, ta, tb);
+          LDS_BARRIER();
+          DSTAMP(tb); DACC(4, tb, ta);
+        }
+      } else {
       // "P2(-1)": coefficients and X of the first hidden unit
-      load_h(k_of(0));
-      write_tab();
-      load_h(k_of(1));
-      form_x();
-      LDS_BARRIER();
-      if constexpr (ALT) {
-        stage_x1(k_of(0));
-        LDS_BARRIER();
-      }
-      DSTAMP(tb); DACC(0, tb, ta);
-      for (int it = 0; it < nk; ++it) {
-        const bool has_next = it + 1 < nk;
-        // ---- P1: Y(k) with the table of k (written in the previous P2) and T(k)
-        DSTAMP(ta);
-        form_y();
-        DSTAMP(tb); DACC(1, tb, ta);
+        load_h(k_of(0));
+        write_tab();
+        load_h(k_of(1));
+        form_x();
         LDS_BARRIER();
         if constexpr (ALT) {
-          if (has_next) { stage_x0(); }
+          stage_x1(k_of(0));
           LDS_BARRIER();
         }
-        DSTAMP(ta); DACC(2, ta, tb);
-        // ---- P2: table of k+1, X(k+1)
-        if (has_next) {
-          write_tab();
-          load_h(k_of(it + 2));
-          form_x();
-        }
-        DSTAMP(tb); DACC(3, tb, ta);
-        LDS_BARRIER();
-        if constexpr (ALT) {
-          if (has_next) { stage_x1(k_of(it + 1)); }
+        DSTAMP(tb); DACC(0, tb, ta);
+        for (int it = 0; it < nk; ++it) {
+          const bool has_next = it + 1 < nk;
+          // ---- P1: Y(k) with the table of k (written in the previous P2) and T(k)
+          DSTAMP(ta);
+          form_y();
+          DSTAMP(tb); DACC(1, tb, ta);
           LDS_BARRIER();
+          if constexpr (ALT) {
+            if (has_next) { stage_x0(); }
+            LDS_BARRIER();
+          }
+          DSTAMP(ta); DACC(2, ta, tb);
+          // ---- P2: table of k+1, X(k+1)
+          if (has_next) {
+            write_tab();
+            load_h(k_of(it + 2));
+            form_x();
+          }
+          DSTAMP(tb); DACC(3, tb, ta);
+          LDS_BARRIER();
+          if constexpr (ALT) {
+            if (has_next) { stage_x1(k_of(it + 1)); }
+            LDS_BARRIER();
+          }
+          DSTAMP(ta); DACC(4, ta, tb);
         }
-        DSTAMP(ta); DACC(4, ta, tb);
       }
       DSTAMP(ta);
       // ---- segment end: the accumulated vector rows (T term) join the staging tile (OL aliases the source rows: dead by now)
@@ -756,20 +901,22 @@ void launch_tprod(const float* x, int XS, int n_atoms, int n_k, const float4* wt
   hipLaunchKernelGGL(k_tprod, dim3((n_atoms + 31) / 32, TP_KG), dim3(64 * TP_WAVES), 0, st, x, XS, n_atoms, n_k, wt, T);
 }
 
-size_t conv_dg_lds_bytes(int rs, int pmax, int alt) { return sizeof(float) * ((dg_lds_floats(rs, pmax, alt) + 3) & ~(size_t)3); }
+size_t conv_dg_lds_bytes(int rs, int pmax, int mode) { return sizeof(float) * ((dg_lds_floats(rs, pmax, mode) + 3) & ~(size_t)3); }
 
 int launch_conv_dg(const DgArgs& a, int grid, hipStream_t st) {
   const size_t smem = conv_dg_lds_bytes(a.RS, a.PMAX, a.alt);
   if (smem > JAMUN_MAX_DYN_LDS) return -2;
-  if (a.RS > (a.alt ? DG_RS_MAX_ALT : DG_RS_MAX_RES) || a.XS != 216 || a.nt0 != 5) return -1;
-  if (a.alt) hipLaunchKernelGGL(k_conv_dg<true>, dim3(grid), dim3(DG_THREADS), smem, st, a);
-  else hipLaunchKernelGGL(k_conv_dg<false>, dim3(grid), dim3(DG_THREADS), smem, st, a);
+  if (a.RS > (a.alt == 1 ? DG_RS_MAX_ALT : DG_RS_MAX_RES) || a.XS != 216 || a.nt0 != 5) return -1;
+  if (a.alt == 1) hipLaunchKernelGGL(k_conv_dg<1>, dim3(grid), dim3(DG_THREADS), smem, st, a);
+  else if (a.alt == 2) hipLaunchKernelGGL(k_conv_dg<2>, dim3(grid), dim3(DG_THREADS), smem, st, a);
+  else hipLaunchKernelGGL(k_conv_dg<0>, dim3(grid), dim3(DG_THREADS), smem, st, a);
   return 0;
 }
 
 int conv_dg_set_max_lds() {
-  return (hipFuncSetAttribute((const void*)k_conv_dg<false>, hipFuncAttributeMaxDynamicSharedMemorySize, JAMUN_MAX_DYN_LDS) == hipSuccess &&
-          hipFuncSetAttribute((const void*)k_conv_dg<true>, hipFuncAttributeMaxDynamicSharedMemorySize, JAMUN_MAX_DYN_LDS) == hipSuccess)
+  return (hipFuncSetAttribute((const void*)k_conv_dg<0>, hipFuncAttributeMaxDynamicSharedMemorySize, JAMUN_MAX_DYN_LDS) == hipSuccess &&
+          hipFuncSetAttribute((const void*)k_conv_dg<1>, hipFuncAttributeMaxDynamicSharedMemorySize, JAMUN_MAX_DYN_LDS) == hipSuccess &&
+          hipFuncSetAttribute((const void*)k_conv_dg<2>, hipFuncAttributeMaxDynamicSharedMemorySize, JAMUN_MAX_DYN_LDS) == hipSuccess)
              ? 0
              : -1;
 }

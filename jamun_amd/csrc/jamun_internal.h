@@ -82,7 +82,7 @@ struct DgArgs {
   const int2* tile_atoms;  // [n_tiles] {first destination atom, number of destination atoms (<= 32)}
   const int4* segs;        // [grid][max_segs][2]: as FusedArgs
   int max_segs, row_blocks, nt0;
-  int alt;  // 1: alternating residency of the source rows (molecules above the resident span budget), see jamun_conv_dg.hip
+  int alt;  // kernel mode: 0 two-phase resident, 1 alternating residency of the source rows (large molecules), 2 single phase (small spans)
   int dbg;  // tuning aid (JAMUN_DG_DBG): 1 forming waves skip their edge loops, 2 matrix waves skip their MFMAs
   // weights, 64-lane x float4 blocks (one block = the B operand of 4 consecutive MFMAs):
   const float4* wx;  // [k][5 output tiles][16 groups (15 = zeros)]   scalar inputs -> scalar rows   (32x32x2: u = 8g + 4hh + st)
@@ -189,7 +189,7 @@ int conv_fused_read_stamps(unsigned long long* out8);
 int launch_conv_dg(const DgArgs& a, int grid, hipStream_t st);
 int conv_dg_set_max_lds();
 void conv_dg_print_stamps();
-size_t conv_dg_lds_bytes(int rs, int pmax, int alt);
+size_t conv_dg_lds_bytes(int rs, int pmax, int mode);
 void launch_tprod(const float* x, int XS, int n_atoms, int n_k, const float4* wt, float* T, hipStream_t st);
 int launch_conv_init(const InitArgs& a, int grid, hipStream_t st);
 int conv_init_set_max_lds();
