@@ -111,7 +111,7 @@ __global__ __launch_bounds__(DG_THREADS) void k_conv_dg(DgArgs a) {
   const int wave = RFL(tid0 >> 6);
   const bool is_mat = wave < 4;
   const int PMAX = a.PMAX;
-  const bool dbg_noform = a.dbg & 1, dbg_nomfma = a.dbg & 2;
+  const bool dbg_noform = a.dbg & 1, dbg_nomfma = a.dbg & 2, dbg_noweights = a.dbg & 4;
   unsigned long long st_acc[6] = {0, 0, 0, 0, 0, 0}, ta = 0, tb = 0;
   (void)st_acc; (void)ta; (void)tb;
 
@@ -229,7 +229,10 @@ __global__ __launch_bounds__(DG_THREADS) void k_conv_dg(DgArgs a) {
       auto WV = [&](int k, int c, int g) { return (a.wv + ((size_t)k * 2 * 4 + c * 4 + g) * 64)[lane]; };
 
       float4 B0[5], B1[5];
+#pragma unroll
+      for (int i = 0; i < 5; ++i) B0[i] = B1[i] = make_float4(1.f, 1.f, 1.f, 1.f);  // (defined values for the JAMUN_DG_DBG=4 experiment)
       auto load_x = [&](float4 (&B)[5], int k, int c) {  // chunk c of P1: groups 4c..4c+3 (+ the quarter group 4c + w)
+        if (dbg_noweights) return;
 #pragma unroll
         for (int i = 0; i < 4; ++i) B[i] = WX(k, w, (4 * c + i) < 15 ? 4 * c + i : 15);
         B[4] = WX(k, 4, 4 * c + w);  // group 15 (wave 3, chunk 3) is a zero block
@@ -256,6 +259,7 @@ __global__ __launch_bounds__(DG_THREADS) void k_conv_dg(DgArgs a) {
         acc4 = MFMA32(av.w, B[4].w, acc4);
       };
       auto load_d = [&](float4 (&B)[5], int k) {
+        if (dbg_noweights) return;
 #pragma unroll
         for (int i = 0; i < 4; ++i) B[i] = WD(k, w, i);
         B[4] = WD(k, 4, w);
@@ -278,6 +282,7 @@ __global__ __launch_bounds__(DG_THREADS) void k_conv_dg(DgArgs a) {
         acc4 = MFMA32(av.w, B[4].w, acc4);
       };
       auto load_v = [&](float4 (&B)[5], int k) {
+        if (dbg_noweights) return;
 #pragma unroll
         for (int i = 0; i < 4; ++i) B[i] = WV(k, ch, i);
       };
@@ -860,7 +865,8 @@ void conv_dg_print_stamps() {
 // One wave = 32 atoms x a subset of the hidden units: the A operand (32 x 120 inputs) is loaded into registers once, per k the
 // 15 weight blocks stream from L2 and 60 v_mfma_f32_32x32x2 produce a 32 x 32 tile that goes straight to HBM.
 // grid = (ceil(n_atoms / 32), TP_KG); 4 waves per workgroup, no LDS, no barriers; ~4 waves per SIMD hide the load latency
-// (measured on cfg2: 2 k-groups 59 us, 8 k-groups 36 us; a double-buffered single-wave variant 42 us).
+// (measured on cfg2: 2 k-groups 59 us, 8 k-groups 36 us; a double-buffered single-wave variant 42 us; weight blocks shared
+// through LDS by 4 waves with one barrier per k 55 us).
 #define TP_WAVES 4
 #define TP_KG 8
 __global__ __launch_bounds__(64 * TP_WAVES) void k_tprod(const float* __restrict__ x, int XS, int n_atoms, int n_k,
