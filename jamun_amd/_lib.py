@@ -77,7 +77,7 @@ class jamun_stats(C.Structure):
         ("edge_stride", C.c_int32),
         ("n_slices", C.c_int32),
         ("conv_path", C.c_int32),
-        ("reserved", C.c_int32),
+        ("dg_mode", C.c_int32),
     ]
 
 

@@ -1555,7 +1555,7 @@ int jamun_sampler_stats(jamun_sampler* s, jamun_stats* out, void* stream) {
     out->edge_stride = s->S;
     out->n_slices = s->dg_on ? s->dg_n_slabs : (s->fused_JR > 0 ? s->n_slabs : s->n_slices);
     out->conv_path = s->dg_on ? 2 : (s->fused_JR > 0 ? 1 : 0);
-    out->reserved = 0;
+    out->dg_mode = s->dg_on ? s->dg_mode : -1;
   });
 }
 

@@ -209,6 +209,21 @@ def test_fused_and_fallback_conv_agree(dev, golden_dir, kind, monkeypatch):
             assert (a - b).abs().max().item() <= 2e-5 * max(b.abs().max().item(), 1e-6), l
     monkeypatch.delenv("JAMUN_NO_DG")
     monkeypatch.delenv("JAMUN_NO_FUSED")
+    # jamun_conv_dg.hip has three variants, chosen by the span of the tiles: single phase (small molecules), two phases with
+    # resident source rows, alternating residency (large molecules).  Switch the chosen one off and the next one must give
+    # the same features.
+    mode = dg.stats()["dg_mode"]
+    expect = {"ag4": 2, "chain17x6": 2, "ragged_small": 2, "ragged": 0, "dense70": 0, "chig93x2": 1, "chig166x2": 1}[kind]
+    assert mode == expect, (kind, mode)
+    if mode in (1, 2):
+        monkeypatch.setenv("JAMUN_DG_NO_SP" if mode == 2 else "JAMUN_DG_NO_ALT", "1")
+        other = NativeSampler(model._native, 0.04, batch, dev)
+        monkeypatch.delenv("JAMUN_DG_NO_SP" if mode == 2 else "JAMUN_DG_NO_ALT")
+        assert other.stats()["dg_mode"] == 0
+        assert rmsd(other.xhat(y), xg) <= RMSD_TOL_NM
+        for l in range(6):
+            a2, b2 = other.debug_read(0, l).cpu(), general.debug_read(0, l).cpu()
+            assert (a2 - b2).abs().max().item() <= 2e-5 * max(b2.abs().max().item(), 1e-6), l
     # the initial projector has a third implementation (input-times-weight table, jamun_conv_init.hip): switch it off and
     # the fused kernel takes that layer as well — same result
     monkeypatch.setenv("JAMUN_NO_INIT_TABLE", "1")
