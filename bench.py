@@ -211,7 +211,7 @@ def _pmc_traffic(kernel: str):
         except Exception:
             continue
         for k, v in d.items():
-            if isinstance(v, dict) and k.startswith(kernel) and "FETCH_SIZE_KB_per_dispatch" in v:
+            if isinstance(v, dict) and kernel in k and "FETCH_SIZE_KB_per_dispatch" in v:
                 return (2.0 * v["FETCH_SIZE_KB_per_dispatch"] + v.get("WRITE_SIZE_KB_per_dispatch", 0.0)) * 1024.0, os.path.basename(f)
     return None
 

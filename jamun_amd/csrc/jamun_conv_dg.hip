@@ -685,21 +685,21 @@ __global__ __launch_bounds__(DG_THREADS) void k_conv_dg(DgArgs a) {
           auto ld_j = [&](int (&J)[DG_U], int bb) {
             bb = bb < nb ? bb : nb - 1;
 #pragma unroll
-            for (int q = 0; q < DG_U; ++q) J[q] = tj[DG_U * bb + q];
+            for (int q = 0; q < DG_U; ++q) J[q] = tj[DG_U * bb + q] + offx;  // ONE row address per edge: scalar channels at +0, vector block at +480
           };
           auto ld_cx = [&](float4 (&c)[DG_U], float4 (&x)[DG_U], const int (&J)[DG_U], int bb) {
             bb = bb < nb ? bb : nb - 1;
 #pragma unroll
             for (int q = 0; q < DG_U; ++q) {
               c[q] = ta[DG_U * bb + q];                                             // c, c vx | c vy, c vz
-              x[q] = *reinterpret_cast<const float4*>(xsb + (J[q] + offy));         // x1_j[u].x, T_k[j][u] | .y, .z
+              x[q] = *reinterpret_cast<const float4*>(xsb + J[q] + 480);            // x1_j[u].x, T_k[j][u] | .y, .z
             }
           };
           // the scalar channels of a batch are requested at the top of its FMA block and consumed at its end (behind the 32
           // packed FMAs of the vector part): single-buffered, 16 registers instead of 32
           auto fm = [&](const float4 (&c)[DG_U], const float4 (&x)[DG_U], const int (&J)[DG_U]) {
 #pragma unroll
-            for (int q = 0; q < DG_U; ++q) z[q] = *reinterpret_cast<const float4*>(xsb + (J[q] + offx));  // x0_j[4u..4u+3]
+            for (int q = 0; q < DG_U; ++q) z[q] = *reinterpret_cast<const float4*>(xsb + J[q]);  // x0_j[4u..4u+3]
 #pragma unroll
             for (int q = 0; q < DG_U; ++q) {
               const float4 cf = c[q], xv = x[q];
