@@ -68,6 +68,35 @@ __device__ unsigned long long g_dgstamp[2][8];  // [role][prologue, P1 work, P1 
 #define DACC(slot, t1, t0) do { } while (0)
 #endif
 
+// v_pk_fma_f32 with the two source-1 selections LLVM does not emit (it materialises the pair with v_mov instead, 3 extra VALU
+// instructions per edge in the forming loops): both result lanes read the HIGH dword of b / the lanes read b swapped.
+__device__ __forceinline__ f32x2 pk_bhi(f32x2 a2, f32x2 b2, f32x2 c2) {  // (a.x b.y + c.x, a.y b.y + c.y)
+  asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "+v"(c2) : "v"(a2), "v"(b2));
+  return c2;
+}
+__device__ __forceinline__ f32x2 pk_bswap(f32x2 a2, f32x2 b2, f32x2 c2) {  // (a.x b.y + c.x, a.y b.x + c.y)
+  asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[1,0,1]" : "+v"(c2) : "v"(a2), "v"(b2));
+  return c2;
+}
+
+__device__ __forceinline__ float4 lds_read_f4(int addr) {  // ds_read_b128 from an absolute LDS address
+#if defined(__HIP_DEVICE_COMPILE__)
+  const f32x4 v = *(const __attribute__((address_space(3))) f32x4*)(unsigned)addr;
+  return make_float4(v.x, v.y, v.z, v.w);
+#else
+  (void)addr;
+  return make_float4(0.f, 0.f, 0.f, 0.f);
+#endif
+}
+__device__ __forceinline__ int lds_address(const void* p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return (int)(unsigned)(uintptr_t)(const __attribute__((address_space(3))) char*)p;
+#else
+  (void)p;
+  return 0;
+#endif
+}
+
 #define DG_ABUF (32 * DG_XS0 + 8 + 32 * DG_YD + 3 * 32 * DG_YV)  // floats of one set of A tiles (X | Yd | Yv)
 // mode: 0 two-phase with resident source rows, 1 two-phase with alternating residency, 2 single phase (double-buffered A tiles)
 __host__ __device__ inline size_t dg_lds_floats(int rs, int pmax, int mode) {
@@ -237,26 +266,37 @@ __global__ __launch_bounds__(DG_THREADS) void k_conv_dg(DgArgs a) {
         for (int i = 0; i < 4; ++i) B[i] = WX(k, w, (4 * c + i) < 15 ? 4 * c + i : 15);
         B[4] = WX(k, 4, 4 * c + w);  // group 15 (wave 3, chunk 3) is a zero block
       };
-      // (A fragments are requested one group ahead of the MFMAs that consume them: a 32x32x2 MFMA leaves the pipe after 64
-      // cycles, an LDS read under load takes longer, so reading right before use leaves the matrix pipe idle at every group)
+      // (A fragments are requested two groups ahead of the MFMAs that consume them and the scheduler is told to keep it that
+      // way: left alone, the compiler reads each fragment into the register of the previous one right before its use, and
+      // the matrix pipe drains at every group of four MFMAs while the LDS read returns — about a quarter of the matrix
+      // waves' time.  Two fragments in flight is what the register budget of 168 allows without spilling weight pointers.)
+#define DG_SB() __builtin_amdgcn_sched_barrier(0)
+#define DG_M4(ACC, A, Bv)                                                                                                    \
+  ACC = MFMA32(A.x, Bv.x, ACC);                                                                                              \
+  ACC = MFMA32(A.y, Bv.y, ACC);                                                                                              \
+  ACC = MFMA32(A.z, Bv.z, ACC);                                                                                              \
+  ACC = MFMA32(A.w, Bv.w, ACC)
       auto run_x = [&](const float4 (&B)[5], int c) {
         if (dbg_nomfma) return;
-        float4 av = *reinterpret_cast<const float4*>(Xa + 8 * (4 * c));
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          if (4 * c + i >= 15) break;
-          const int gn = (i < 3 && 4 * c + i + 1 < 15) ? 4 * c + i + 1 : 4 * c + w;  // next main group, or this wave's quarter group
-          const float4 an = *reinterpret_cast<const float4*>(Xa + 8 * gn);
-          accM = MFMA32(av.x, B[i].x, accM);
-          accM = MFMA32(av.y, B[i].y, accM);
-          accM = MFMA32(av.z, B[i].z, accM);
-          accM = MFMA32(av.w, B[i].w, accM);
-          av = an;
+        const bool last = (c == 3);  // chunk 3 holds groups 12..14 only
+        float4 a0 = *reinterpret_cast<const float4*>(Xa + 8 * (4 * c));
+        float4 a1 = *reinterpret_cast<const float4*>(Xa + 8 * (4 * c + 1));
+        DG_SB();
+        DG_M4(accM, a0, B[0]);
+        a0 = *reinterpret_cast<const float4*>(Xa + 8 * (4 * c + 2));
+        DG_SB();
+        DG_M4(accM, a1, B[1]);
+        a1 = *reinterpret_cast<const float4*>(Xa + 8 * (last ? 4 * c + w : 4 * c + 3));
+        DG_SB();
+        DG_M4(accM, a0, B[2]);
+        if (!last) {
+          a0 = *reinterpret_cast<const float4*>(Xa + 8 * (4 * c + w));  // this wave's quarter group of scalar tile 4
+          DG_SB();
+          DG_M4(accM, a1, B[3]);
+          DG_M4(acc4, a0, B[4]);
+        } else {
+          DG_M4(acc4, a1, B[4]);
         }
-        acc4 = MFMA32(av.x, B[4].x, acc4);
-        acc4 = MFMA32(av.y, B[4].y, acc4);
-        acc4 = MFMA32(av.z, B[4].z, acc4);
-        acc4 = MFMA32(av.w, B[4].w, acc4);
       };
       auto load_d = [&](float4 (&B)[5], int k) {
         if (dbg_noweights) return;
@@ -266,20 +306,20 @@ __global__ __launch_bounds__(DG_THREADS) void k_conv_dg(DgArgs a) {
       };
       auto run_d = [&](const float4 (&B)[5]) {
         if (dbg_nomfma) return;
-        float4 av = *reinterpret_cast<const float4*>(Da);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const float4 an = *reinterpret_cast<const float4*>(Da + 8 * (i < 3 ? i + 1 : w));  // (last: this wave's K quarter of scalar tile 4)
-          accM = MFMA32(av.x, B[i].x, accM);
-          accM = MFMA32(av.y, B[i].y, accM);
-          accM = MFMA32(av.z, B[i].z, accM);
-          accM = MFMA32(av.w, B[i].w, accM);
-          av = an;
-        }
-        acc4 = MFMA32(av.x, B[4].x, acc4);
-        acc4 = MFMA32(av.y, B[4].y, acc4);
-        acc4 = MFMA32(av.z, B[4].z, acc4);
-        acc4 = MFMA32(av.w, B[4].w, acc4);
+        float4 a0 = *reinterpret_cast<const float4*>(Da);
+        float4 a1 = *reinterpret_cast<const float4*>(Da + 8);
+        DG_SB();
+        DG_M4(accM, a0, B[0]);
+        a0 = *reinterpret_cast<const float4*>(Da + 16);
+        DG_SB();
+        DG_M4(accM, a1, B[1]);
+        a1 = *reinterpret_cast<const float4*>(Da + 24);
+        DG_SB();
+        DG_M4(accM, a0, B[2]);
+        a0 = *reinterpret_cast<const float4*>(Da + 8 * w);  // this wave's K quarter of scalar tile 4
+        DG_SB();
+        DG_M4(accM, a1, B[3]);
+        DG_M4(acc4, a0, B[4]);
       };
       auto load_v = [&](float4 (&B)[5], int k) {
         if (dbg_noweights) return;
@@ -288,23 +328,27 @@ __global__ __launch_bounds__(DG_THREADS) void k_conv_dg(DgArgs a) {
       };
       auto run_v = [&](const float4 (&B)[5]) {
         if (dbg_nomfma) return;
-        float4 av[3], an[3];
+        float4 av[2][3];
 #pragma unroll
-        for (int m = 0; m < 3; ++m) av[m] = *reinterpret_cast<const float4*>(Va + m * 32 * DG_YV);
+        for (int m = 0; m < 3; ++m) av[0][m] = *reinterpret_cast<const float4*>(Va + m * 32 * DG_YV);
+        DG_SB();
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
+          if (i < 3) {
 #pragma unroll
-          for (int m = 0; m < 3; ++m) an[m] = *reinterpret_cast<const float4*>(Va + m * 32 * DG_YV + 16 * (i < 3 ? i + 1 : 3));
+            for (int m = 0; m < 3; ++m) av[(i + 1) & 1][m] = *reinterpret_cast<const float4*>(Va + m * 32 * DG_YV + 16 * (i + 1));
+            DG_SB();
+          }
+          float4(&A)[3] = av[i & 1];
 #pragma unroll
-          for (int m = 0; m < 3; ++m) accP[m] = MFMA16(av[m].x, B[i].x, accP[m]);
+          for (int m = 0; m < 3; ++m) accP[m] = MFMA16(A[m].x, B[i].x, accP[m]);
 #pragma unroll
-          for (int m = 0; m < 3; ++m) accP[m] = MFMA16(av[m].y, B[i].y, accP[m]);
+          for (int m = 0; m < 3; ++m) accP[m] = MFMA16(A[m].y, B[i].y, accP[m]);
 #pragma unroll
-          for (int m = 0; m < 3; ++m) accP[m] = MFMA16(av[m].z, B[i].z, accP[m]);
+          for (int m = 0; m < 3; ++m) accP[m] = MFMA16(A[m].z, B[i].z, accP[m]);
 #pragma unroll
-          for (int m = 0; m < 3; ++m) accP[m] = MFMA16(av[m].w, B[i].w, accP[m]);
-#pragma unroll
-          for (int m = 0; m < 3; ++m) av[m] = an[m];
+          for (int m = 0; m < 3; ++m) accP[m] = MFMA16(A[m].w, B[i].w, accP[m]);
+          if (i < 3) DG_SB();
         }
       };
       // T_k[j][w'] = sum_u x0_j[u] W[(k,u)][w'] comes from the pre-pass k_tprod (once per source atom and layer, not once
@@ -448,6 +492,7 @@ __global__ __launch_bounds__(DG_THREADS) void k_conv_dg(DgArgs a) {
       // =========================================== FORMING waves ===========================================
       const int fw = wave - 4;                    // forming wave index: destinations 2 DG_NDP fw .. 2 DG_NDP (fw + 1) - 1
       const int h = lane >> 5, u = lane & 31;
+      const int xs_lds = lds_address(xs);  // LDS address of the source rows
       // per destination pair dp: this lane's edge slots t = u (page 0) and u + 32 (page 1) of destination i = 4 fw + 2 dp + h
       float evx[DG_NDP][2], evy[DG_NDP][2], evz[DG_NDP][2];
       int hidx[DG_NDP][2];
@@ -479,7 +524,7 @@ __global__ __launch_bounds__(DG_THREADS) void k_conv_dg(DgArgs a) {
               jofs = jl * DG_XST * 4;  // byte offset of the source row inside xs
             }
           }
-          if (t < PMAX) tabJ[i * PMAX + t] = jofs;
+          if (t < PMAX) tabJ[i * PMAX + t] = jofs + xs_lds;
         }
         if (!two_pages) {
           // A bonded pair inside the cutoff appears twice in the edge table (radial edge + bonded edge, same source and unit
@@ -547,7 +592,9 @@ __global__ __launch_bounds__(DG_THREADS) void k_conv_dg(DgArgs a) {
           }
         }
       };
-      const char* __restrict__ xsb = reinterpret_cast<const char*>(xs);
+      // (row addresses in tabJ are absolute LDS addresses, so that the row reads are one VGPR + an immediate offset: with a
+      // generic base pointer the compiler adds the base of the dynamic LDS block to every address, one v_add per read)
+      auto LDSF4 = [](int addr) -> float4 { return lds_read_f4(addr); };
       // The edge loops run in batches of DG_U edges, software pipelined by one batch: while the FMAs of batch b issue, the
       // coefficients and source-row fragments of batch b+1 and the row offsets of batch b+2 are in flight.  Table entries past
       // a destination's degree are zero (PMAX is a multiple of DG_U), so the loads are unconditional and the tail batch needs
@@ -579,7 +626,7 @@ __global__ __launch_bounds__(DG_THREADS) void k_conv_dg(DgArgs a) {
 #pragma unroll
             for (int q = 0; q < DG_U; ++q) {
               c[q] = ta[DG_U * bb + q].x;
-              x[q] = *reinterpret_cast<const float4*>(xsb + (J[q] + offx));
+              x[q] = LDSF4(J[q] + offx);
             }
           };
           auto fm = [&](const float (&c)[DG_U], const float4 (&x)[DG_U]) {
@@ -629,7 +676,7 @@ __global__ __launch_bounds__(DG_THREADS) void k_conv_dg(DgArgs a) {
 #pragma unroll
             for (int q = 0; q < DG_U; ++q) {
               c[q] = ta[DG_U * bb + q];                                            // c, c vx | c vy, c vz
-              x[q] = *reinterpret_cast<const float4*>(xsb + (J[q] + offy));         // T_k[j][u], x1_j[u].x | .y, .z
+              x[q] = LDSF4(J[q] + offy);         // T_k[j][u], x1_j[u].x | .y, .z
             }
           };
           auto fm = [&](const float4 (&c)[DG_U], const float4 (&x)[DG_U]) {
@@ -638,10 +685,10 @@ __global__ __launch_bounds__(DG_THREADS) void k_conv_dg(DgArgs a) {
               const float4 cf = c[q], xv = x[q];  // cf = (c, cx | cy, cz), xv = (x, T | y, z)
               p_a1x_o0 = pk(f32x2{cf.x, cf.y}, f32x2{xv.x, xv.y}, p_a1x_o0);    // (c x, cx T)
               p_a1yz = pk(f32x2{cf.x, cf.x}, f32x2{xv.z, xv.w}, p_a1yz);        // (c y, c z)
-              p_o12 = pk(f32x2{cf.z, cf.w}, f32x2{xv.y, xv.y}, p_o12);          // (cy T, cz T)
+              p_o12 = pk_bhi(f32x2{cf.z, cf.w}, f32x2{xv.x, xv.y}, p_o12);          // (cy T, cz T)
               n3 = pk(f32x2{cf.y, cf.y}, f32x2{xv.z, xv.w}, n3);                // (cx y, cx z)
               n5 = pk(f32x2{cf.z, cf.w}, f32x2{xv.x, xv.x}, n5);                // (cy x, cz x)
-              n7 = pk(f32x2{cf.z, cf.w}, f32x2{xv.w, xv.z}, n7);                // (cy z, cz y)
+              n7 = pk_bswap(f32x2{cf.z, cf.w}, f32x2{xv.z, xv.w}, n7);                // (cy z, cz y)
               p_d = pk(f32x2{cf.z, cf.w}, f32x2{xv.z, xv.w}, p_d);              // (cy y, cz z)
               d2 = fmaf(cf.y, xv.x, d2);                                          // cx x
             }
@@ -692,23 +739,23 @@ __global__ __launch_bounds__(DG_THREADS) void k_conv_dg(DgArgs a) {
 #pragma unroll
             for (int q = 0; q < DG_U; ++q) {
               c[q] = ta[DG_U * bb + q];                                             // c, c vx | c vy, c vz
-              x[q] = *reinterpret_cast<const float4*>(xsb + J[q] + 480);            // x1_j[u].x, T_k[j][u] | .y, .z
+              x[q] = LDSF4(J[q] + 480);            // x1_j[u].x, T_k[j][u] | .y, .z
             }
           };
           // the scalar channels of a batch are requested at the top of its FMA block and consumed at its end (behind the 32
           // packed FMAs of the vector part): single-buffered, 16 registers instead of 32
           auto fm = [&](const float4 (&c)[DG_U], const float4 (&x)[DG_U], const int (&J)[DG_U]) {
 #pragma unroll
-            for (int q = 0; q < DG_U; ++q) z[q] = *reinterpret_cast<const float4*>(xsb + J[q]);  // x0_j[4u..4u+3]
+            for (int q = 0; q < DG_U; ++q) z[q] = LDSF4(J[q]);  // x0_j[4u..4u+3]
 #pragma unroll
             for (int q = 0; q < DG_U; ++q) {
               const float4 cf = c[q], xv = x[q];
               p_a1x_o0 = pk(f32x2{cf.x, cf.y}, f32x2{xv.x, xv.y}, p_a1x_o0);    // (c x, cx T)
               p_a1yz = pk(f32x2{cf.x, cf.x}, f32x2{xv.z, xv.w}, p_a1yz);        // (c y, c z)
-              p_o12 = pk(f32x2{cf.z, cf.w}, f32x2{xv.y, xv.y}, p_o12);          // (cy T, cz T)
+              p_o12 = pk_bhi(f32x2{cf.z, cf.w}, f32x2{xv.x, xv.y}, p_o12);          // (cy T, cz T)
               n3 = pk(f32x2{cf.y, cf.y}, f32x2{xv.z, xv.w}, n3);                // (cx y, cx z)
               n5 = pk(f32x2{cf.z, cf.w}, f32x2{xv.x, xv.x}, n5);                // (cy x, cz x)
-              n7 = pk(f32x2{cf.z, cf.w}, f32x2{xv.w, xv.z}, n7);                // (cy z, cz y)
+              n7 = pk_bswap(f32x2{cf.z, cf.w}, f32x2{xv.z, xv.w}, n7);                // (cy z, cz y)
               p_d = pk(f32x2{cf.z, cf.w}, f32x2{xv.z, xv.w}, p_d);              // (cy y, cz z)
               d2 = fmaf(cf.y, xv.x, d2);                                          // cx x
             }
