@@ -204,8 +204,23 @@ __global__ __launch_bounds__(DG_THREADS) void k_conv_dg(DgArgs a) {
         }
       }
     };
+    auto stage_t = [&](int k) {  // ALT, forming waves only (512 threads): T_k of every source row into the T slots
+      const int total = rows * 32, ftid = tid - 4 * 64;
+      const float* __restrict__ tk = a.T + ((size_t)k * a.n_atoms + s_lo) * 32;
+      constexpr int NB = 6;
+      for (int base = ftid; base < total; base += NB * 512) {
+        float v[NB];
+#pragma unroll
+        for (int q8 = 0; q8 < NB; ++q8) v[q8] = tk[min(base + q8 * 512, total - 1)];
+#pragma unroll
+        for (int q8 = 0; q8 < NB; ++q8) {
+          const int idx = base + q8 * 512;
+          if (idx < total) xs[(size_t)(idx >> 5) * DG_XST_ALT + 4 * (idx & 31) + 1] = v[q8];
+        }
+      }
+    };
     if constexpr (ALT) {
-      stage_x0();
+      stage_x1(k_of(0));
     } else {
       const int total = rows16 * (DG_XST / 4);
       for (int base = tid; base < total; base += DG_SB * DG_THREADS) {
@@ -430,6 +445,45 @@ __global__ __launch_bounds__(DG_THREADS) void k_conv_dg(DgArgs a) {
           LDS_BARRIER();
           DSTAMP(ta); DACC(4, ta, tb);
         }
+      } else if constexpr (ALT) {
+        // ---- two passes over the hidden units of the segment (the sum over k is linear, the accumulators stay in registers):
+        // pass A with the VECTOR blocks resident:  Y(k) formed | barrier | Y(k) x W, T(k+1) staged by the forming waves | barrier
+        load_d(B0, k_of(0));
+        load_v(B1, k_of(0));
+        DSTAMP(tb); DACC(0, tb, ta);
+        for (int it = 0; it < nk; ++it) {
+          const int kn = k_of(it + 1);
+          DSTAMP(ta);
+          LDS_BARRIER();                  // Y(k) complete
+          DSTAMP(tb); DACC(2, tb, ta);
+          run_d(B0);
+          run_v(B1);
+          if (it + 1 < nk) { load_d(B0, kn); load_v(B1, kn); }
+          DSTAMP(ta); DACC(3, ta, tb);
+          LDS_BARRIER();                  // Y(k) consumed; T(k+1) in its slots
+          DSTAMP(tb); DACC(4, tb, ta);
+        }
+        // pass B with the SCALAR channels resident (one re-staging per segment): X double buffered (second buffer = the dead Y
+        // tiles), X(k+1) formed while X(k) x W runs, one barrier per hidden unit
+        DSTAMP(ta);
+        stage_x0();
+        load_x(B0, k_of(0), 0);
+        load_x(B1, k_of(0), 1);
+        LDS_BARRIER();                    // scalar channels resident
+        LDS_BARRIER();                    // X(k0) complete
+        DSTAMP(tb); DACC(0, tb, ta);
+        for (int it = 0; it < nk; ++it) {
+          const int k = k_of(it), kn = k_of(it + 1);
+          DSTAMP(ta);
+          Xa = ((it & 1) ? Yd : Xt) + r * DG_XS0 + 4 * hh;
+          run_x(B0, 0); load_x(B0, k, 2);
+          run_x(B1, 1); load_x(B1, k, 3);
+          run_x(B0, 2); load_x(B0, kn, 0);
+          run_x(B1, 3); load_x(B1, kn, 1);
+          DSTAMP(tb); DACC(1, tb, ta);
+          LDS_BARRIER();                  // X(k+1) complete; X(k) consumed
+          DSTAMP(ta); DACC(2, ta, tb);
+        }
       } else {
       // "P2(-1)": T slots of the first hidden unit (no Y yet); first weight chunks
         {
@@ -440,10 +494,6 @@ __global__ __launch_bounds__(DG_THREADS) void k_conv_dg(DgArgs a) {
           store_tslots(k0);
         }
         LDS_BARRIER();
-        if constexpr (ALT) {  // swap the scalar channels for the vector blocks (+ T of the first hidden unit)
-          stage_x1(k_of(0));
-          LDS_BARRIER();
-        }
         DSTAMP(tb); DACC(0, tb, ta);
         for (int it = 0; it < nk; ++it) {
           const int k = k_of(it), kn = k_of(it + 1);
@@ -456,10 +506,6 @@ __global__ __launch_bounds__(DG_THREADS) void k_conv_dg(DgArgs a) {
           run_x(B1, 3); load_v(B1, k);
           DSTAMP(tb); DACC(1, tb, ta);
           LDS_BARRIER();
-          if constexpr (ALT) {
-            if (has_next) { stage_x0(); }
-            LDS_BARRIER();
-          }
           DSTAMP(ta); DACC(2, ta, tb);
           // ---- P2: Y(k) x W; T slots of k+1 (nobody reads T during P2)
           if (has_next) load_tslots(kn);
@@ -468,10 +514,6 @@ __global__ __launch_bounds__(DG_THREADS) void k_conv_dg(DgArgs a) {
           if (has_next) store_tslots(kn);
           DSTAMP(tb); DACC(3, tb, ta);
           LDS_BARRIER();
-          if constexpr (ALT) {
-            if (has_next) { stage_x1(kn); }
-            LDS_BARRIER();
-          }
           DSTAMP(ta); DACC(4, ta, tb);
         }
       }
@@ -605,7 +647,7 @@ __global__ __launch_bounds__(DG_THREADS) void k_conv_dg(DgArgs a) {
       auto pk = [](f32x2 a2, f32x2 b2, f32x2 c2) -> f32x2 { return __builtin_elementwise_fma(a2, b2, c2); };
       const int offx = u * 16, offy = OFFY + u * 16;
       // X(k): scalar inputs, lanes u < 30 own channels 4u..4u+3 (lanes 30, 31 compute on x1 data and are not stored)
-      auto form_x = [&]() {
+      auto form_x = [&](float* __restrict__ Xo) {
 #pragma unroll
         for (int dp = 0; dp < DG_NDP; ++dp) {
           const int i = 2 * DG_NDP * fw + 2 * dp + h;
@@ -648,7 +690,7 @@ __global__ __launch_bounds__(DG_THREADS) void k_conv_dg(DgArgs a) {
               }
             }
           }
-          if (u < 30) *reinterpret_cast<float4*>(Xt + i * DG_XS0 + 4 * u) = make_float4(ax01.x, ax01.y, ax23.x, ax23.y);
+          if (u < 30) *reinterpret_cast<float4*>(Xo + i * DG_XS0 + 4 * u) = make_float4(ax01.x, ax01.y, ax23.x, ax23.y);
         }
       };
       // Y(k): vector inputs (lane u = channel u) + the T term (lane u = output channel w')
@@ -809,17 +851,55 @@ __global__ __launch_bounds__(DG_THREADS) void k_conv_dg(DgArgs a) {
           LDS_BARRIER();
           DSTAMP(tb); DACC(4, tb, ta);
         }
+      } else if constexpr (ALT) {
+        // ---- pass A (vector blocks resident)
+        load_h(k_of(0));
+        write_tab();
+        load_h(k_of(1));
+        DSTAMP(tb); DACC(0, tb, ta);
+        for (int it = 0; it < nk; ++it) {
+          DSTAMP(ta);
+          form_y();                       // Y(k): table and T slots of k
+          DSTAMP(tb); DACC(1, tb, ta);
+          LDS_BARRIER();
+          DSTAMP(ta); DACC(2, ta, tb);
+          if (it + 1 < nk) {              // (the matrix waves contract Y(k) meanwhile)
+            write_tab();
+            load_h(k_of(it + 2));
+            stage_t(k_of(it + 1));
+          }
+          DSTAMP(tb); DACC(3, tb, ta);
+          LDS_BARRIER();
+          DSTAMP(ta); DACC(4, ta, tb);
+        }
+        // ---- pass B (scalar channels resident)
+        DSTAMP(ta);
+        load_h(k_of(0));
+        stage_x0();
+        write_tab();
+        load_h(k_of(1));
+        LDS_BARRIER();                    // scalar channels resident
+        form_x(Xt);
+        if (nk > 1) { write_tab(); load_h(k_of(2)); }
+        LDS_BARRIER();                    // X(k0) complete
+        DSTAMP(tb); DACC(0, tb, ta);
+        for (int it = 0; it < nk; ++it) {
+          DSTAMP(ta);
+          if (it + 1 < nk) {
+            form_x((it & 1) ? Xt : Yd);   // X(k+1) into the other buffer
+            if (it + 2 < nk) { write_tab(); load_h(k_of(it + 3)); }
+          }
+          DSTAMP(tb); DACC(1, tb, ta);
+          LDS_BARRIER();
+          DSTAMP(ta); DACC(2, ta, tb);
+        }
       } else {
       // "P2(-1)": coefficients and X of the first hidden unit
         load_h(k_of(0));
         write_tab();
         load_h(k_of(1));
-        form_x();
+        form_x(Xt);
         LDS_BARRIER();
-        if constexpr (ALT) {
-          stage_x1(k_of(0));
-          LDS_BARRIER();
-        }
         DSTAMP(tb); DACC(0, tb, ta);
         for (int it = 0; it < nk; ++it) {
           const bool has_next = it + 1 < nk;
@@ -828,23 +908,15 @@ __global__ __launch_bounds__(DG_THREADS) void k_conv_dg(DgArgs a) {
           form_y();
           DSTAMP(tb); DACC(1, tb, ta);
           LDS_BARRIER();
-          if constexpr (ALT) {
-            if (has_next) { stage_x0(); }
-            LDS_BARRIER();
-          }
           DSTAMP(ta); DACC(2, ta, tb);
           // ---- P2: table of k+1, X(k+1)
           if (has_next) {
             write_tab();
             load_h(k_of(it + 2));
-            form_x();
+            form_x(Xt);
           }
           DSTAMP(tb); DACC(3, tb, ta);
           LDS_BARRIER();
-          if constexpr (ALT) {
-            if (has_next) { stage_x1(k_of(it + 1)); }
-            LDS_BARRIER();
-          }
           DSTAMP(ta); DACC(4, ta, tb);
         }
       }
