@@ -106,11 +106,15 @@ __host__ __device__ inline size_t dg_lds_floats(int rs, int pmax, int mode) {
 }
 
 // ALT = false: the source rows of a tile stay in LDS for the whole segment (spans up to ~80 rows).
-// ALT = true (molecules above that): LDS holds only what the CURRENT PHASE reads — the vector block (x, T, y, z)[32] of every
-// source row during P1 (Y forming), the 120 scalar channels during P2 (X forming, T product) — and all threads re-stage the
-// rows from global memory (L2) at both phase boundaries of every hidden unit: 2 x rows x ~0.5 KB per k and two more barriers,
-// instead of cutting the sources into row blocks whose (destination chunk, block) tiles each pay the full contraction.
-// T(k+1) stays in the matrix waves' accumulators across the re-staging and is written into the freshly staged vector block.
+// ALT = true (molecules above that): LDS holds HALF of every source row at a time and the segment makes TWO PASSES over its
+// hidden units (the sum over k is linear; the accumulators stay in the matrix waves' registers across both):
+//   pass A, vector blocks (x, T, y, z)[32] resident:  Y(k) formed | barrier | Y(k) x W while T(k+1) is staged | barrier
+//   pass B, the 120 scalar channels resident (one re-staging per segment):  X(k+1) formed while X(k) x W runs, X double
+//           buffered in the dead Y tiles, one barrier per k
+// instead of re-staging both halves at the phase boundaries of every hidden unit (measured on the 166-atom batch: 1.47 ms per
+// launch with per-k re-staging, 1.21 ms with two passes), and instead of cutting the sources into row blocks whose
+// (destination chunk, block) tiles each pay the full contraction.  Y is single buffered in pass A (LDS is full): forming and
+// contraction alternate there, which costs little because fp32 MFMA and VALU work of a SIMD do not overlap anyway.
 // MODE 2 (SP, spans up to ~52 rows: 2AA-size molecules): ONE phase per hidden unit.  The A tiles are double buffered (93 KB), the
 // matrix waves run X(k) W and Y(k) W back to back while the forming waves build X(k+1) and Y(k+1) in ONE pass over the edges
 // (one table read, one row address and 9 packed + 1 scalar FMA per edge instead of two passes with their own reads), one
@@ -207,7 +211,7 @@ __global__ __launch_bounds__(DG_THREADS) void k_conv_dg(DgArgs a) {
     auto stage_t = [&](int k) {  // ALT, forming waves only (512 threads): T_k of every source row into the T slots
       const int total = rows * 32, ftid = tid - 4 * 64;
       const float* __restrict__ tk = a.T + ((size_t)k * a.n_atoms + s_lo) * 32;
-      constexpr int NB = 6;
+      constexpr int NB = 11;  // 512 x 11 elements = 176 rows in ONE round trip (the forming waves hold nothing else here)
       for (int base = ftid; base < total; base += NB * 512) {
         float v[NB];
 #pragma unroll
@@ -451,9 +455,16 @@ __global__ __launch_bounds__(DG_THREADS) void k_conv_dg(DgArgs a) {
         load_d(B0, k_of(0));
         load_v(B1, k_of(0));
         DSTAMP(tb); DACC(0, tb, ta);
+        float t_sink = 0.f;
         for (int it = 0; it < nk; ++it) {
           const int kn = k_of(it + 1);
           DSTAMP(ta);
+          if (it + 1 < nk && !(a.dbg & 16)) {
+            // The matrix waves idle while Y(k) is formed: they pull T(k+1) of the span (HBM / Infinity Cache: the T buffer of
+            // a large batch is tens of MB) into L2, where the forming waves' staging loads find it after the barrier.
+            const float* __restrict__ tk = a.T + ((size_t)kn * a.n_atoms + s_lo) * 32;
+            for (int idx = 32 * (w * 64 + lane); idx < rows * 32; idx += 32 * 256) t_sink += tk[idx];  // one load per 128-byte line
+          }
           LDS_BARRIER();                  // Y(k) complete
           DSTAMP(tb); DACC(2, tb, ta);
           run_d(B0);
@@ -463,6 +474,7 @@ __global__ __launch_bounds__(DG_THREADS) void k_conv_dg(DgArgs a) {
           LDS_BARRIER();                  // Y(k) consumed; T(k+1) in its slots
           DSTAMP(tb); DACC(4, tb, ta);
         }
+        if (t_sink == 1.2345e30f) accM[0] += t_sink;  // (keeps the touch loads alive)
         // pass B with the SCALAR channels resident (one re-staging per segment): X double buffered (second buffer = the dead Y
         // tiles), X(k+1) formed while X(k) x W runs, one barrier per hidden unit
         DSTAMP(ta);
@@ -864,9 +876,9 @@ __global__ __launch_bounds__(DG_THREADS) void k_conv_dg(DgArgs a) {
           LDS_BARRIER();
           DSTAMP(ta); DACC(2, ta, tb);
           if (it + 1 < nk) {              // (the matrix waves contract Y(k) meanwhile)
+            if (!(a.dbg & 8)) stage_t(k_of(it + 1));        // (first: its wait would otherwise cover the h loads as well)
             write_tab();
             load_h(k_of(it + 2));
-            stage_t(k_of(it + 1));
           }
           DSTAMP(tb); DACC(3, tb, ta);
           LDS_BARRIER();
