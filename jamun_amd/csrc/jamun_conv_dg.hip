@@ -30,6 +30,7 @@
 //
 // Work distribution, partial slabs, fixed summation order: as jamun_conv_fused.hip (host-built segment lists).
 #include <hip/hip_runtime.h>
+#include <algorithm>
 #include <stdint.h>
 #include <stdio.h>
 
@@ -993,49 +994,67 @@ void conv_dg_print_stamps() {
 // scalar-input -> vector-row weights; k_conv_dg applies  out_m[i][w'] += sum_e (c_e v_m) T_k[j_e][w']).  Computing it once per
 // source atom costs 2*120*32 FLOP per (atom, k); inside k_conv_dg it was recomputed for every tile whose span contains the atom
 // (x1.6 for 17-atom molecules, x5 for a 166-atom molecule: 352 of 828 MFMA units per (tile, k)).
-// One wave = 32 atoms x a subset of the hidden units: the A operand (32 x 120 inputs) is loaded into registers once, per k the
-// 15 weight blocks stream from L2 and 60 v_mfma_f32_32x32x2 produce a 32 x 32 tile that goes straight to HBM.
-// grid = (ceil(n_atoms / 32), TP_KG); 4 waves per workgroup, no LDS, no barriers; ~4 waves per SIMD hide the load latency
-// (measured on cfg2: 2 k-groups 59 us, 8 k-groups 36 us; a double-buffered single-wave variant 42 us; weight blocks shared
-// through LDS by 4 waves with one barrier per k 55 us).
+// One wave = 32 atoms x a contiguous run of hidden units: the inputs (32 atoms x 120 channels) are loaded into registers once,
+// the 15 weight blocks of hidden unit k+1 are in flight (second register buffer) while the 60 v_mfma_f32_32x32x2 of k run.
+// The MFMA computes the TRANSPOSED tile (weights as the A operand, inputs as B: both fragments have the same lane layout, so
+// this is only the operand order): lane (atom r, half hh) then holds 4 consecutive output channels per accumulator quad and
+// the 32 x 32 tile goes to HBM as four 16-byte stores per lane instead of sixteen 4-byte stores with their address and
+// predicate arithmetic (VALU work that the matrix pipe of the SIMD waits for).  No LDS, no barriers.
+// The launch is sized to ONE wave per SIMD (1024 waves: k-groups = 1024 / row tiles).  Measured on MI355X, 4352 atoms:
+// 4352 short waves of ~2 hidden units 36 us; 2040 waves (two per SIMD) 38 us; 952 waves 27 us (standalone, scratch bench).
 #define TP_WAVES 4
-#define TP_KG 8
-__global__ __launch_bounds__(64 * TP_WAVES) void k_tprod(const float* __restrict__ x, int XS, int n_atoms, int n_k,
-                                                         const float4* __restrict__ wt, float* __restrict__ T) {
+__global__ __launch_bounds__(64 * TP_WAVES) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_tprod(
+    const float* __restrict__ x, int XS, int n_atoms, int n_k, int kg, const float4* __restrict__ wt, float* __restrict__ T) {
   const int lane = threadIdx.x & 63, wave = RFL(threadIdx.x >> 6);
   const int r = lane & 31, hh = lane >> 5;
-  const int a0 = blockIdx.x * 32;
+  const int gid = blockIdx.x * TP_WAVES + wave;
+  const int tile = RFL(gid / kg), g = RFL(gid - tile * kg);
+  const int a0 = tile * 32;
+  if (a0 >= n_atoms) return;
+  const int k_lo = RFL((g * n_k) / kg), k_hi = RFL(((g + 1) * n_k) / kg);
+  if (k_lo >= k_hi) return;
   const int row = min(a0 + r, n_atoms - 1);
-  float4 av[15];
+  float4 xv[15], w0[15], w1[15];
+  auto load_w = [&](float4 (&wv)[15], int k) {
+    const float4* __restrict__ wk = wt + (size_t)min(k, n_k - 1) * 15 * 64;
 #pragma unroll
-  for (int g = 0; g < 15; ++g) av[g] = *reinterpret_cast<const float4*>(x + (size_t)row * XS + 8 * g + 4 * hh);
-  const int slot = blockIdx.y * TP_WAVES + wave, n_slots = TP_KG * TP_WAVES;
-  for (int k = slot; k < n_k; k += n_slots) {
-    const float4* __restrict__ wk = wt + (size_t)k * 15 * 64;
-    float4 bv[15];
+    for (int q = 0; q < 15; ++q) wv[q] = wk[q * 64 + lane];
+  };
 #pragma unroll
-    for (int g = 0; g < 15; ++g) bv[g] = wk[g * 64 + lane];
+  for (int q = 0; q < 15; ++q) xv[q] = *reinterpret_cast<const float4*>(x + (size_t)row * XS + 8 * q + 4 * hh);
+  load_w(w0, k_lo);
+  auto step = [&](const float4 (&wv)[15], int k) {
     f32x16 acc;
 #pragma unroll
     for (int q = 0; q < 16; ++q) acc[q] = 0.f;
 #pragma unroll
-    for (int g = 0; g < 15; ++g) {
-      acc = MFMA32(av[g].x, bv[g].x, acc);
-      acc = MFMA32(av[g].y, bv[g].y, acc);
-      acc = MFMA32(av[g].z, bv[g].z, acc);
-      acc = MFMA32(av[g].w, bv[g].w, acc);
+    for (int q = 0; q < 15; ++q) {  // acc[row = output channel][column = atom]
+      acc = MFMA32(wv[q].x, xv[q].x, acc);
+      acc = MFMA32(wv[q].y, xv[q].y, acc);
+      acc = MFMA32(wv[q].z, xv[q].z, acc);
+      acc = MFMA32(wv[q].w, xv[q].w, acc);
     }
     float* __restrict__ tk = T + ((size_t)k * n_atoms + a0) * 32;
+    if (a0 + r < n_atoms) {
 #pragma unroll
-    for (int q = 0; q < 16; ++q) {
-      const int rr = (q & 3) + 8 * (q >> 2) + 4 * hh;
-      if (a0 + rr < n_atoms) tk[rr * 32 + r] = acc[q];
+      for (int g4 = 0; g4 < 4; ++g4)  // accumulator register 4 g4 + i  <->  output channel 8 g4 + 4 hh + i
+        *reinterpret_cast<float4*>(tk + r * 32 + 8 * g4 + 4 * hh) = make_float4(acc[4 * g4], acc[4 * g4 + 1], acc[4 * g4 + 2], acc[4 * g4 + 3]);
+    }
+  };
+  for (int k = k_lo; k < k_hi; k += 2) {
+    load_w(w1, k + 1);
+    step(w0, k);
+    if (k + 1 < k_hi) {
+      load_w(w0, k + 2);
+      step(w1, k + 1);
     }
   }
 }
 
 void launch_tprod(const float* x, int XS, int n_atoms, int n_k, const float4* wt, float* T, hipStream_t st) {
-  hipLaunchKernelGGL(k_tprod, dim3((n_atoms + 31) / 32, TP_KG), dim3(64 * TP_WAVES), 0, st, x, XS, n_atoms, n_k, wt, T);
+  const int tiles = (n_atoms + 31) / 32;
+  const int kg = std::min(n_k, std::max(1, 1024 / tiles));
+  hipLaunchKernelGGL(k_tprod, dim3((tiles * kg + TP_WAVES - 1) / TP_WAVES), dim3(64 * TP_WAVES), 0, st, x, XS, n_atoms, n_k, kg, wt, T);
 }
 
 size_t conv_dg_lds_bytes(int rs, int pmax, int mode) { return sizeof(float) * ((dg_lds_floats(rs, pmax, mode) + 3) & ~(size_t)3); }
