@@ -63,9 +63,12 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 #ifdef JAMUN_STAMP
 __device__ unsigned long long g_dgstamp[2][8];  // [role][prologue, P1 work, P1 wait, P2 work, P2 wait, epilogue]
 #define DSTAMP(t) do { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory"); } while (0)
+__device__ unsigned long long g_dgtrace[12][48][4];  // workgroup 7, SP mode: per wave and k-step: start, arrival at barrier A, release, end
+#define DTRACE(slot, t) do { if (blockIdx.x == 7 && trc < 48) g_dgtrace[wave][trc][slot] = (t); } while (0)
 #define DACC(slot, t1, t0) do { st_acc[slot] += (t1) - (t0); } while (0)
 #else
 #define DSTAMP(t) do { } while (0)
+#define DTRACE(slot, t) do { } while (0)
 #define DACC(slot, t1, t0) do { } while (0)
 #endif
 
@@ -147,6 +150,8 @@ __global__ __launch_bounds__(DG_THREADS) void k_conv_dg(DgArgs a) {
   const int PMAX = a.PMAX;
   const bool dbg_noform = a.dbg & 1, dbg_nomfma = a.dbg & 2, dbg_noweights = a.dbg & 4;
   unsigned long long st_acc[6] = {0, 0, 0, 0, 0, 0}, ta = 0, tb = 0;
+  int trc = 0;
+  (void)trc;
   (void)st_acc; (void)ta; (void)tb;
 
   for (int sgi = 0; sgi < a.max_segs; ++sgi) {
@@ -442,13 +447,18 @@ __global__ __launch_bounds__(DG_THREADS) void k_conv_dg(DgArgs a) {
           run_x(B1, 3); load_v(B1, k);
           run_d(B0); load_x(B0, kn, 0);
           run_v(B1); load_x(B1, kn, 1);
+          DTRACE(0, ta);
           DSTAMP(tb); DACC(1, tb, ta);
+          DTRACE(1, tb);
           LDS_BARRIER();                  // A(k+1) complete; nobody reads A(k) or T(k+1) any more
           DSTAMP(ta); DACC(2, ta, tb);
+          DTRACE(2, ta);
           if (it + 2 < nk) store_tslots(k_of(it + 2));
           DSTAMP(tb); DACC(3, tb, ta);
           LDS_BARRIER();
           DSTAMP(ta); DACC(4, ta, tb);
+          DTRACE(3, ta);
+          ++trc;
         }
       } else if constexpr (ALT) {
         // ---- two passes over the hidden units of the segment (the sum over k is linear, the accumulators stay in registers):
@@ -545,6 +555,11 @@ __global__ __launch_bounds__(DG_THREADS) void k_conv_dg(DgArgs a) {
       DSTAMP(tb); DACC(5, tb, ta);
     } else {
       // =========================================== FORMING waves ===========================================
+      // Forming waves run at raised priority: left to the default oldest-first arbitration the matrix wave of a SIMD issues its
+      // whole MFMA chain first (fp32 MFMA and VALU of a SIMD exclude each other) and the two forming waves then finish one
+      // after the other, bound by LDS latency; with priority their VALU instructions go first and the MFMAs fill their
+      // latency gaps (measured timeline: matrix waves done at 10.2k cycles of a 15.1k step, forming waves at 11.7k .. 13.9k).
+      if (!(a.dbg & 32)) __builtin_amdgcn_s_setprio(3);
       const int fw = wave - 4;                    // forming wave index: destinations 2 DG_NDP fw .. 2 DG_NDP (fw + 1) - 1
       const int h = lane >> 5, u = lane & 31;
       const int xs_lds = lds_address(xs);  // LDS address of the source rows
@@ -858,11 +873,16 @@ __global__ __launch_bounds__(DG_THREADS) void k_conv_dg(DgArgs a) {
             form_xy((it + 1) & 1);
             if (it + 2 < nk) { write_tab(); load_h(k_of(it + 3)); }
           }
+          DTRACE(0, ta);
           DSTAMP(tb); DACC(1, tb, ta);
+          DTRACE(1, tb);
           LDS_BARRIER();
           DSTAMP(ta); DACC(2, ta, tb);
+          DTRACE(2, ta);
           LDS_BARRIER();
           DSTAMP(tb); DACC(4, tb, ta);
+          DTRACE(3, tb);
+          ++trc;
         }
       } else if constexpr (ALT) {
         // ---- pass A (vector blocks resident)
@@ -986,6 +1006,16 @@ void conv_dg_print_stamps() {
     fprintf(stderr, "\n");
   }
   (void)hipMemcpyToSymbol(HIP_SYMBOL(g_dgstamp), z, sizeof(z));
+  static unsigned long long tr[12][48][4];
+  if (hipMemcpyFromSymbol(tr, HIP_SYMBOL(g_dgtrace), sizeof(tr)) == hipSuccess && tr[0][0][0] != 0) {
+    const unsigned long long t0 = tr[0][0][0];
+    fprintf(stderr, "dg trace (workgroup 7): per k-step, per wave (0-3 matrix, 4-11 forming): start / arrive A / release A / end, cycles since first start\n");
+    for (int st = 0; st < 12; ++st) {
+      for (int w = 0; w < 12; ++w)
+        fprintf(stderr, "  step %2d wave %2d: %7lld %7lld %7lld %7lld\n", st, w, (long long)(tr[w][st][0] - t0), (long long)(tr[w][st][1] - t0),
+                (long long)(tr[w][st][2] - t0), (long long)(tr[w][st][3] - t0));
+    }
+  }
 #endif
 }
 
