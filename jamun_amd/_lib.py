@@ -78,6 +78,7 @@ class jamun_stats(C.Structure):
         ("n_slices", C.c_int32),
         ("conv_path", C.c_int32),
         ("dg_mode", C.c_int32),
+        ("init_path", C.c_int32),
     ]
 
 

@@ -13,7 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 PKG = os.path.dirname(HERE)
 ROOT = os.path.dirname(PKG)
 OUT = os.path.join(PKG, "libjamun_hip.so")
-SOURCES = ["jamun_kernels.hip", "jamun_conv.hip", "jamun_conv_fused.hip", "jamun_conv_init.hip", "jamun_conv_dg.hip", "jamun_api.cpp"]
+SOURCES = ["jamun_kernels.hip", "jamun_conv.hip", "jamun_conv_fused.hip", "jamun_conv_init.hip", "jamun_conv_initv.hip", "jamun_conv_dg.hip", "jamun_api.cpp"]
 DEPS = SOURCES + ["jamun_internal.h", os.path.join(ROOT, "include", "jamun_hip.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-x", "hip", "-ffp-contract=off", "-fno-slp-vectorize",

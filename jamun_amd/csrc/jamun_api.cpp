@@ -113,6 +113,7 @@ struct LayerDev {
   std::vector<float> w1r_h, cmask_h;  // radial MLP first layer (uploaded for all layers together: jamun_sampler::w1r_all)
   float* tt = nullptr;  // initial projector only: [k][distinct embedding row][32 (nt0 + 1)] input-times-weight table
   int tt_row = 0, tt_U = 0;
+  float* tt2 = nullptr;  // the same table re-laid for k_conv_init_v: [k][U][192]
   float4 *wcat0 = nullptr, *wcat1 = nullptr;  // node update: [W_self ; W_skip] as MFMA fragments
   int K0p = 0, K1p = 0;
   float* mix = nullptr;
@@ -278,6 +279,7 @@ struct jamun_sampler {
   int fused_JR = 0, fused_grid = 0, fused_max_segs = 0, n_slabs = 0, n_ftiles = 0;
   int4* fused_segs = nullptr;
   int2* tile_atoms = nullptr;         // [n_ftiles] {first atom, atoms (<= 32)} of each fused-kernel tile
+  bool initv_on = false;              // initial projector on k_conv_init_v (tiles / segments of the dg kernel)
   int* atom_uid = nullptr;            // [n_atoms] index of the atom's distinct (scaled) embedding row
   std::vector<int2> ftile_atoms_h;
   std::vector<int> ftile_chunk_h;     // destination chunk of each tile
@@ -319,7 +321,7 @@ struct jamun_sampler {
     hipFree(dg_tile_atoms); hipFree(dg_tile_span); hipFree(dg_segs); hipFree(dg_atom_nslab); hipFree(dg_T);
     for (auto& L : layers) {
       free_problem(L.p0); free_problem(L.p1); free_fused(L.fu); free_dg(L.dg);
-      hipFree(L.wcat0); hipFree(L.wcat1); hipFree(L.mix); hipFree(L.tt);
+      hipFree(L.wcat0); hipFree(L.wcat1); hipFree(L.mix); hipFree(L.tt); hipFree(L.tt2);
     }
     hipFree(w_gate); hipFree(w_vec); hipFree(w_out);
     hipFree(yc); hipFree(h); hipFree(partial0); hipFree(partial1); hipFree(g); hipFree(tmp);
@@ -672,6 +674,20 @@ LayerDev build_layer(const jamun_model& m, const std::string& prefix, const std:
       L.tt = dev_upload(tt);
       L.tt_row = tt_row;
       L.tt_U = U;
+      if (NT0 == 5 && G0 <= 152 && G1 <= 32) {  // scalar columns 0..127 as they are, then per lane u (column 128+u, vector column u)
+        std::vector<float> tt2((size_t)(H + 1) * U * 192, 0.f);
+        for (int k = 0; k <= H; ++k)
+          for (int uid = 0; uid < U; ++uid) {
+            const float* in = tt.data() + ((size_t)k * U + uid) * tt_row;
+            float* out = tt2.data() + ((size_t)k * U + uid) * 192;
+            for (int c = 0; c < 128; ++c) out[c] = in[c];
+            for (int u = 0; u < 32; ++u) {
+              out[128 + 2 * u] = u < 24 ? in[128 + u] : 0.f;
+              out[128 + 2 * u + 1] = in[32 * NT0 + u];
+            }
+          }
+        L.tt2 = dev_upload(tt2);
+      }
     }
   }
 
@@ -784,7 +800,18 @@ void forward(jamun_sampler* s, float* y, float* xhat, float* score, hipStream_t 
       launch_edge_h(s->deg, s->esrc, s->egeo, s->n_atoms, s->S, s->w1r_all + l * 64 * 32, s->cmask_all + l * 128, (int)NL,
                     s->mu, s->rb_step, s->h, s->h_stride, s->h_kstride, st);
     }
-    if (l == 0 && L.tt) {
+    if (l == 0 && s->initv_on) {
+      InitVArgs f{};
+      f.deg = s->deg; f.esrc = s->esrc; f.egeo = s->egeo; f.h = h_l; f.h_kstride = s->h_kstride;
+      f.n_pad = s->n_pad; f.S = s->S; f.PMAX = (s->S + 3) & ~3; f.RS = s->dg_RS; f.nt0 = L.p0.nt;
+      f.tile_span = s->dg_tile_span; f.tile_atoms = s->dg_tile_atoms; f.segs = s->dg_segs; f.max_segs = s->dg_max_segs;
+      f.atom_uid = s->atom_uid; f.tt2 = L.tt2; f.tt2_kstride = (size_t)L.tt_U * 192;
+      static const int iv_dbg = getenv("JAMUN_IV_DBG") ? atoi(getenv("JAMUN_IV_DBG")) : 0;
+      f.dbg = iv_dbg;
+      f.partial0 = s->partial0; f.partial1 = s->partial1;
+      ProfScope ps(s, JAMUN_PROF_CONV0_INIT, st);
+      if (launch_conv_initv(f, s->dg_grid, st) != 0) throw Err(JAMUN_ERR_INVALID, "initial-projector conv launch failed (configuration not supported)");
+    } else if (l == 0 && L.tt) {
       InitArgs f{};
       f.deg = s->deg; f.esrc = s->esrc; f.egeo = s->egeo; f.h = h_l; f.h_kstride = s->h_kstride;
       f.n_pad = s->n_pad; f.S = s->S; f.JR = s->fused_JR; f.nt0 = L.fu.nt0; f.row_blocks = s->row_blocks ? 1 : 0;
@@ -840,7 +867,7 @@ void forward(jamun_sampler* s, float* y, float* xhat, float* score, hipStream_t 
     n.cL = s->hp.act_scalar_const; n.cS = s->hp.act_gate_const;
     n.n_atoms = s->n_atoms; n.n_pad = s->n_pad; n.n_slices = s->n_slices; n.nt0 = L.p0.nt; n.nt1 = L.p1.nt;
     n.mul0 = s->hp.mul0; n.mul1 = s->hp.mul1; n.in0 = L.in0; n.in1 = L.in1; n.XSin = XSin;
-    const bool dg_layer = l > 0 && s->dg_on;
+    const bool dg_layer = (l > 0 && s->dg_on) || (l == 0 && s->initv_on);  // (slabs of the dg tile plan)
     n.atom_nslab = dg_layer ? s->dg_atom_nslab : (L.fu.wpack ? s->atom_nslab : nullptr);
     n.max_slabs = dg_layer ? s->dg_n_slabs : (L.fu.wpack ? s->n_slabs : s->n_slices);
     {
@@ -1082,7 +1109,7 @@ int jamun_sampler_create(const jamun_model* m, float sigma, const jamun_topology
     s->S = std::min(std::max(nmax - 1, 0), JAMUN_MAX_NEIGHBORS + 1) + max_in;
     if (s->S < 1) s->S = 1;
     s->n_tiles = s->n_pad / 32;
-    if (conv_set_max_lds() != 0 || conv_fused_set_max_lds() != 0 || node_update_set_max_lds() != 0 || conv_init_set_max_lds() != 0 ||
+    if (conv_set_max_lds() != 0 || conv_fused_set_max_lds() != 0 || node_update_set_max_lds() != 0 || conv_init_set_max_lds() != 0 || conv_initv_set_max_lds() != 0 ||
         conv_dg_set_max_lds() != 0)
       throw Err(JAMUN_ERR_HIP, "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed");
     {
@@ -1319,6 +1346,9 @@ int jamun_sampler_create(const jamun_model* m, float sigma, const jamun_topology
         s->dg_tile_span = dev_upload(t_span);
         s->dg_T = dev_alloc<float>((size_t)n_k * N * 32);
         s->dg_on = true;
+        // initial projector on the same tiles when two buffers of table rows fit LDS (spans up to ~66 rows)
+        s->initv_on = getenv("JAMUN_NO_INIT_V") == nullptr && !s->dg_row_blocks && s->dg_mode != 1 && s->layers[0].tt2 != nullptr &&
+                      s->layers[0].p0.nt == 5 && conv_initv_lds_bytes(s->dg_RS, pmax) <= JAMUN_MAX_DYN_LDS;
       }
       if (!s->dg_on)
         for (auto& L : s->layers) free_dg(L.dg);
@@ -1556,6 +1586,7 @@ int jamun_sampler_stats(jamun_sampler* s, jamun_stats* out, void* stream) {
     out->n_slices = s->dg_on ? s->dg_n_slabs : (s->fused_JR > 0 ? s->n_slabs : s->n_slices);
     out->conv_path = s->dg_on ? 2 : (s->fused_JR > 0 ? 1 : 0);
     out->dg_mode = s->dg_on ? s->dg_mode : -1;
+    out->init_path = s->initv_on ? 2 : (s->layers[0].tt ? 1 : 0);
   });
 }
 
@@ -1589,6 +1620,7 @@ int jamun_debug_stamps(unsigned long long* out8) {
     if (!out8) throw Err(JAMUN_ERR_INVALID, "null argument");
     HIPCHECK(hipDeviceSynchronize());
     conv_dg_print_stamps();
+    conv_initv_print_stamps();
     const int r = conv_fused_read_stamps(out8);
     if (r == -2) throw Err(JAMUN_ERR_INVALID, "library was not built with -DJAMUN_STAMP");
     if (r != 0) throw Err(JAMUN_ERR_HIP, "reading stamp counters failed");

@@ -115,6 +115,26 @@ struct InitArgs {
   float* partial1;      // [slab][n_pad][3][32]
 };
 
+// k_conv_init_v (jamun_conv_initv.hip): the initial projector edge by edge on the VALU, on the tiles / segments of k_conv_dg
+struct InitVArgs {
+  const int* deg;
+  const int* esrc;
+  const float4* egeo;
+  const float* h;  // [hidden unit k (65 rows)][h_kstride]
+  size_t h_kstride;
+  int n_pad, S, PMAX, RS, nt0;
+  const int2* tile_span;
+  const int2* tile_atoms;
+  const int4* segs;
+  int max_segs;
+  const int* atom_uid;  // [n_atoms] index of the atom's distinct embedding row
+  const float* tt2;     // [k][U][192]: scalar columns 0..127 | per lane u (column 128+u, vector column u)
+  size_t tt2_kstride;   // U * 192
+  int dbg;              // timing experiment (JAMUN_IV_DBG): 1 no edge loops (outputs zero)
+  float* partial0;      // [slab][n_pad][nt0*32]
+  float* partial1;      // [slab][n_pad][3][32]
+};
+
 struct NodeArgs {
   const float* partial0;  // [n_slices][n_pad][nt0*32]
   const float* partial1;  // [n_slices][n_pad][3][nt1*32]
@@ -189,9 +209,13 @@ int conv_fused_read_stamps(unsigned long long* out8);
 int launch_conv_dg(const DgArgs& a, int grid, hipStream_t st);
 int conv_dg_set_max_lds();
 void conv_dg_print_stamps();
+void conv_initv_print_stamps();
 size_t conv_dg_lds_bytes(int rs, int pmax, int mode);
 void launch_tprod(const float* x, int XS, int n_atoms, int n_k, const float4* wt, float* T, hipStream_t st);
 int launch_conv_init(const InitArgs& a, int grid, hipStream_t st);
+int launch_conv_initv(const InitVArgs& a, int grid, hipStream_t st);
+int conv_initv_set_max_lds();
+size_t conv_initv_lds_bytes(int rs, int pmax);
 int conv_init_set_max_lds();
 size_t conv_init_lds_bytes(int JR);
 size_t fused_lds_bytes(int XS, int JR, int n_p, int n_t, int max_a);

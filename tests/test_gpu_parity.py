@@ -224,6 +224,18 @@ def test_fused_and_fallback_conv_agree(dev, golden_dir, kind, monkeypatch):
         for l in range(6):
             a2, b2 = other.debug_read(0, l).cpu(), general.debug_read(0, l).cpu()
             assert (a2 - b2).abs().max().item() <= 2e-5 * max(b2.abs().max().item(), 1e-6), l
+    # the initial projector of the default path runs edge by edge on the tiles of the dg kernel when the spans fit two LDS row
+    # buffers (jamun_conv_initv.hip); switched off, the MFMA table kernel takes the layer — same features
+    expect_init = {"ag4": 2, "chain17x6": 2, "ragged_small": 2, "ragged": 1, "dense70": 2, "chig93x2": 1, "chig166x2": 1}[kind]  # (ragged: edge tables + two row buffers exceed LDS)
+    assert dg.stats()["init_path"] == expect_init, (kind, dg.stats()["init_path"])
+    if expect_init == 2:
+        monkeypatch.setenv("JAMUN_NO_INIT_V", "1")
+        no_v = NativeSampler(model._native, 0.04, batch, dev)
+        monkeypatch.delenv("JAMUN_NO_INIT_V")
+        assert no_v.stats()["init_path"] == 1
+        assert rmsd(no_v.xhat(y), xd) <= RMSD_TOL_NM
+        a1, b1 = dg.debug_read(0, 0).cpu(), no_v.debug_read(0, 0).cpu()
+        assert (a1 - b1).abs().max().item() <= 2e-5 * max(b1.abs().max().item(), 1e-6)
     # the initial projector has a third implementation (input-times-weight table, jamun_conv_init.hip): switch it off and
     # the fused kernel takes that layer as well — same result
     monkeypatch.setenv("JAMUN_NO_INIT_TABLE", "1")
