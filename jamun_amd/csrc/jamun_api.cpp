@@ -280,6 +280,7 @@ struct jamun_sampler {
   int4* fused_segs = nullptr;
   int2* tile_atoms = nullptr;         // [n_ftiles] {first atom, atoms (<= 32)} of each fused-kernel tile
   bool initv_on = false;              // initial projector on k_conv_init_v (tiles / segments of the dg kernel)
+  int initv_nbuf = 2;                 // its row buffers in LDS
   int* atom_uid = nullptr;            // [n_atoms] index of the atom's distinct (scaled) embedding row
   std::vector<int2> ftile_atoms_h;
   std::vector<int> ftile_chunk_h;     // destination chunk of each tile
@@ -803,7 +804,7 @@ void forward(jamun_sampler* s, float* y, float* xhat, float* score, hipStream_t 
     if (l == 0 && s->initv_on) {
       InitVArgs f{};
       f.deg = s->deg; f.esrc = s->esrc; f.egeo = s->egeo; f.h = h_l; f.h_kstride = s->h_kstride;
-      f.n_pad = s->n_pad; f.S = s->S; f.PMAX = (s->S + 3) & ~3; f.RS = s->dg_RS; f.nt0 = L.p0.nt;
+      f.n_pad = s->n_pad; f.S = s->S; f.PMAX = (s->S + 3) & ~3; f.RS = s->dg_RS; f.nt0 = L.p0.nt; f.nbuf = s->initv_nbuf;
       f.tile_span = s->dg_tile_span; f.tile_atoms = s->dg_tile_atoms; f.segs = s->dg_segs; f.max_segs = s->dg_max_segs;
       f.atom_uid = s->atom_uid; f.tt2 = L.tt2; f.tt2_kstride = (size_t)L.tt_U * 192;
       static const int iv_dbg = getenv("JAMUN_IV_DBG") ? atoi(getenv("JAMUN_IV_DBG")) : 0;
@@ -1346,9 +1347,14 @@ int jamun_sampler_create(const jamun_model* m, float sigma, const jamun_topology
         s->dg_tile_span = dev_upload(t_span);
         s->dg_T = dev_alloc<float>((size_t)n_k * N * 32);
         s->dg_on = true;
-        // initial projector on the same tiles when two buffers of table rows fit LDS (spans up to ~66 rows)
-        s->initv_on = getenv("JAMUN_NO_INIT_V") == nullptr && !s->dg_row_blocks && s->dg_mode != 1 && s->layers[0].tt2 != nullptr &&
-                      s->layers[0].p0.nt == 5 && conv_initv_lds_bytes(s->dg_RS, pmax) <= JAMUN_MAX_DYN_LDS;
+        // initial projector on the same tiles: two LDS buffers of table rows when they fit (spans up to ~90 rows), else one
+        // (up to ~170 rows)
+        if (getenv("JAMUN_NO_INIT_V") == nullptr && !s->dg_row_blocks && s->layers[0].tt2 != nullptr && s->layers[0].p0.nt == 5 && s->dg_RS <= 170) {
+          // (one buffer only for the large-molecule plan: measured on the ragged 17-57 atom batch the MFMA table kernel is 10 %
+          // faster than the one-buffer variant, on 166-atom molecules — where it falls back to source row blocks — 2.1x slower)
+          for (int nbuf = 2; nbuf >= (s->dg_mode == 1 ? 1 : 2) && !s->initv_on; --nbuf)
+            if (conv_initv_lds_bytes(s->dg_RS, pmax, nbuf) <= JAMUN_MAX_DYN_LDS) { s->initv_on = true; s->initv_nbuf = nbuf; }
+        }
       }
       if (!s->dg_on)
         for (auto& L : s->layers) free_dg(L.dg);

@@ -18,7 +18,8 @@
 //     are staged into LDS by all threads, double buffered: the loads of k+1 are issued before the edge loops of k and stored
 //     after them; one LDS-only barrier per k;
 //   * the accumulators stay in registers over the k run of the segment and go straight to the partial slab.
-// Used when the spans of the batch fit two row buffers (<= ~90 source rows); larger molecules keep jamun_conv_init.hip.
+// Two row buffers when they fit (spans up to ~90 source rows), one buffer above that (up to ~170 rows: a 166-atom molecule);
+// only batches with source row blocks keep jamun_conv_init.hip.
 // Measured on MI355X (initial-projector launch): 17 atoms x 256 walkers 0.123 -> 0.113 ms, 33 x 256: 0.398 -> 0.328 ms.  The kernel is
 // LDS-bound (3 reads per edge, destination pair and k); the staged rows are a native vector array — as HIP float4 structs kept
 // across the loop they were not promoted to registers and went through scratch memory.
@@ -33,11 +34,9 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define IV_WAVES 8
 #define IV_THREADS (64 * IV_WAVES)
 #define IV_NDP 2
-#define IV_U 4          // edges per batch of the edge loops
 #define IV_ROW 192      // floats per staged table row: [u][4] scalar columns 4u..4u+3 | [u][2] (column 128+u, vector column u)
 #define IV_LROW 196     // LDS row stride in floats (784 B: consecutive rows start 4 banks apart; at 768 B every row starts on bank 0 and
                         // the two halves of a wave, which read different rows, collide)
-#define IV_SB 8         // staged float4 per thread held in registers over the edge loops (8 x 512 x 16 B = 85 rows)
 #define LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 #define RFL(v) __builtin_amdgcn_readfirstlane(v)
 
@@ -72,9 +71,9 @@ __device__ __forceinline__ int iv_lds_address(const void* p) {
 #endif
 }
 
-__host__ __device__ inline size_t iv_lds_floats(int rs, int pmax) {
-  // rows [2][rs][196] | tabA [32][pmax] float4 | tabJ [32][pmax] | deg [32] | uid [rs]
-  return (size_t)2 * rs * IV_LROW + (size_t)32 * pmax * 4 + (size_t)32 * pmax + 32 + rs;
+__host__ __device__ inline size_t iv_lds_floats(int rs, int pmax, int nbuf) {
+  // rows [nbuf][rs][196] | tabA [32][pmax] float4 | tabJ [32][pmax] | deg [32] | uid [rs]
+  return (size_t)nbuf * rs * IV_LROW + (size_t)32 * pmax * 4 + (size_t)32 * pmax + 32 + rs;
 }
 
 #ifdef JAMUN_STAMP
@@ -86,13 +85,18 @@ __device__ unsigned long long g_ivstamp[8];  // load issue, edge loops, wait + s
 #define ISTAMP(t) do { } while (0)
 #define IACC(slot, t1, t0) do { } while (0)
 #endif
+// IV_SB: staged float4 per thread held in registers over the edge loops (8 x 512 x 16 B = 85 rows, 16: 170 rows).
+// DBL: two row buffers (one barrier per k); otherwise ONE buffer (molecules whose rows fill LDS: the store of the next rows
+// waits behind a second barrier, the loads are still issued before the edge loops).
+template <int IV_SB, bool DBL>
 __global__ __launch_bounds__(IV_THREADS) void k_conv_init_v(InitVArgs a) {
+  constexpr int IV_U = IV_SB > 8 ? 2 : 4;  // edges per batch of the edge loops (the 16 staging registers of large spans leave room for 2)
   unsigned long long iv_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t0 = 0, t1 = 0;
   (void)iv_acc; (void)t0; (void)t1;
   extern __shared__ float4 lds4[];
   float* __restrict__ lds = reinterpret_cast<float*>(lds4);
   float* __restrict__ rows_lds = lds;                                                       // [2][RS][196]
-  float4* __restrict__ tabA = reinterpret_cast<float4*>(rows_lds + (size_t)2 * a.RS * IV_LROW);  // [32][PMAX]
+  float4* __restrict__ tabA = reinterpret_cast<float4*>(rows_lds + (size_t)(DBL ? 2 : 1) * a.RS * IV_LROW);  // [32][PMAX]
   int* __restrict__ tabJ = reinterpret_cast<int*>(tabA + 32 * a.PMAX);                        // [32][PMAX] LDS address of the row in buffer 0
   int* __restrict__ deg_lds = tabJ + 32 * a.PMAX;                                            // [32]
   int* __restrict__ uid_lds = deg_lds + 32;                                                  // [RS]
@@ -301,12 +305,13 @@ __global__ __launch_bounds__(IV_THREADS) void k_conv_init_v(InitVArgs a) {
       ISTAMP(t0);
       if (it + 1 < nk) IV_STAGE_LOAD(k_of(it + 1));
       ISTAMP(t1); IACC(0, t1, t0);
-      form(it & 1);
+      form(DBL ? (it & 1) : 0);
       ISTAMP(t0); IACC(1, t0, t1);
       if (it + 1 < nk) {
-        IV_STAGE_STORE(k_of(it + 1), (it + 1) & 1);
+        if constexpr (!DBL) LDS_BARRIER();  // every wave is done with the rows of k
+        // (DBL: nobody reads the other buffer: its hidden unit was finished before the last barrier)
+        IV_STAGE_STORE(k_of(it + 1), DBL ? ((it + 1) & 1) : 0);
         ISTAMP(t1); IACC(2, t1, t0);
-        // (nobody reads that buffer: its hidden unit was finished before the last barrier)
         write_tab();                               // this wave's private rows, read only by itself
         load_h(k_of(it + 2));
         ISTAMP(t0); IACC(3, t0, t1);
@@ -350,15 +355,23 @@ void conv_initv_print_stamps() {
 #endif
 }
 
-size_t conv_initv_lds_bytes(int rs, int pmax) { return sizeof(float) * ((iv_lds_floats(rs, pmax) + 3) & ~(size_t)3); }
+size_t conv_initv_lds_bytes(int rs, int pmax, int nbuf) { return sizeof(float) * ((iv_lds_floats(rs, pmax, nbuf) + 3) & ~(size_t)3); }
 
 int launch_conv_initv(const InitVArgs& a, int grid, hipStream_t st) {
-  const size_t smem = conv_initv_lds_bytes(a.RS, a.PMAX);
+  const size_t smem = conv_initv_lds_bytes(a.RS, a.PMAX, a.nbuf);
   if (smem > JAMUN_MAX_DYN_LDS || a.nt0 != 5) return -1;
-  hipLaunchKernelGGL(k_conv_init_v, dim3(grid), dim3(IV_THREADS), smem, st, a);
+  if (a.nbuf == 2 && a.RS <= 85) hipLaunchKernelGGL((k_conv_init_v<8, true>), dim3(grid), dim3(IV_THREADS), smem, st, a);
+  else if (a.nbuf == 2) hipLaunchKernelGGL((k_conv_init_v<16, true>), dim3(grid), dim3(IV_THREADS), smem, st, a);
+  else if (a.RS <= 85) hipLaunchKernelGGL((k_conv_init_v<8, false>), dim3(grid), dim3(IV_THREADS), smem, st, a);
+  else hipLaunchKernelGGL((k_conv_init_v<16, false>), dim3(grid), dim3(IV_THREADS), smem, st, a);
   return 0;
 }
 
 int conv_initv_set_max_lds() {
-  return hipFuncSetAttribute((const void*)k_conv_init_v, hipFuncAttributeMaxDynamicSharedMemorySize, JAMUN_MAX_DYN_LDS) == hipSuccess ? 0 : -1;
+  return (hipFuncSetAttribute((const void*)k_conv_init_v<8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, JAMUN_MAX_DYN_LDS) == hipSuccess &&
+          hipFuncSetAttribute((const void*)k_conv_init_v<16, true>, hipFuncAttributeMaxDynamicSharedMemorySize, JAMUN_MAX_DYN_LDS) == hipSuccess &&
+          hipFuncSetAttribute((const void*)k_conv_init_v<8, false>, hipFuncAttributeMaxDynamicSharedMemorySize, JAMUN_MAX_DYN_LDS) == hipSuccess &&
+          hipFuncSetAttribute((const void*)k_conv_init_v<16, false>, hipFuncAttributeMaxDynamicSharedMemorySize, JAMUN_MAX_DYN_LDS) == hipSuccess)
+             ? 0
+             : -1;
 }

@@ -123,6 +123,7 @@ struct InitVArgs {
   const float* h;  // [hidden unit k (65 rows)][h_kstride]
   size_t h_kstride;
   int n_pad, S, PMAX, RS, nt0;
+  int nbuf;  // row buffers in LDS: 2 (one barrier per k) or 1
   const int2* tile_span;
   const int2* tile_atoms;
   const int4* segs;
@@ -215,7 +216,7 @@ void launch_tprod(const float* x, int XS, int n_atoms, int n_k, const float4* wt
 int launch_conv_init(const InitArgs& a, int grid, hipStream_t st);
 int launch_conv_initv(const InitVArgs& a, int grid, hipStream_t st);
 int conv_initv_set_max_lds();
-size_t conv_initv_lds_bytes(int rs, int pmax);
+size_t conv_initv_lds_bytes(int rs, int pmax, int nbuf);
 int conv_init_set_max_lds();
 size_t conv_init_lds_bytes(int JR);
 size_t fused_lds_bytes(int XS, int JR, int n_p, int n_t, int max_a);
