@@ -1330,6 +1330,21 @@ int jamun_sampler_create(const jamun_model* m, float sigma, const jamun_topology
             n_chunks = nc2; span_max = sm2; s->dg_row_blocks = false; s->dg_mode = 2;
           }
         }
+        // single phase with a double-buffered X tile and ONE Y tile (spans up to ~73 rows: two 33-atom molecules per tile) when the
+        // fully double-buffered variant does not fit: a k-step of the two-phase kernel takes 25 k cycles on such tiles, of this
+        // one ~17 k, so up to 15 % more tiles are accepted
+        const int cap_sph = cap_of(3);
+        if (s->dg_mode == 0 && cap_sph >= 16 && getenv("JAMUN_DG_NO_SPH") == nullptr) {
+          std::vector<int2> a2, s2;
+          std::vector<int> c2;
+          int nc2 = 0, sm2 = 0;
+          bool rb2 = false;
+          plan_tiles(topo->ptr, graph_of, N, cap_sph, a2, s2, c2, nc2, sm2, rb2);
+          if (!rb2 && 100 * a2.size() <= 115 * t_atoms.size()) {
+            t_atoms.swap(a2); t_span.swap(s2); t_chunk.swap(c2);
+            n_chunks = nc2; span_max = sm2; s->dg_row_blocks = false; s->dg_mode = 3;
+          }
+        }
         s->dg_RS = std::max((span_max + 3) & ~3, 16);  // (>= 16 rows: the segment-end staging tile of the forming waves aliases the source rows)
         s->dg_n_tiles = (int)t_atoms.size();
         // k-slices over XCD groups (JAMUN_DG_KGROUPS = 1, 2, 4, 8).  Measured on MI355X (cfg2, profiles/r2*): 1 slice 0.317 ms per
@@ -1349,7 +1364,10 @@ int jamun_sampler_create(const jamun_model* m, float sigma, const jamun_topology
         s->dg_on = true;
         // initial projector on the same tiles: two LDS buffers of table rows when they fit (spans up to ~90 rows), else one
         // (up to ~170 rows)
-        if (getenv("JAMUN_NO_INIT_V") == nullptr && !s->dg_row_blocks && s->layers[0].tt2 != nullptr && s->layers[0].p0.nt == 5 && s->dg_RS <= 170) {
+        // (mid-size ragged batches keep the MFMA table kernel: on 17-57 atom molecules, mean in-degree 11, it takes 0.283 ms
+        // against 0.312 — the per-k staging of ~76 table rows outweighs the few edges; 33-atom molecules: 0.398 against 0.328)
+        if (getenv("JAMUN_NO_INIT_V") == nullptr && !s->dg_row_blocks && s->layers[0].tt2 != nullptr && s->layers[0].p0.nt == 5 && s->dg_RS <= 170 &&
+            (s->dg_mode == 1 || nmax <= 40)) {
           // (one buffer only for the large-molecule plan: measured on the ragged 17-57 atom batch the MFMA table kernel is 10 %
           // faster than the one-buffer variant, on 166-atom molecules — where it falls back to source row blocks — 2.1x slower)
           for (int nbuf = 2; nbuf >= (s->dg_mode == 1 ? 1 : 2) && !s->initv_on; --nbuf)

@@ -102,11 +102,13 @@ __device__ __forceinline__ int lds_address(const void* p) {
 }
 
 #define DG_ABUF (32 * DG_XS0 + 8 + 32 * DG_YD + 3 * 32 * DG_YV)  // floats of one set of A tiles (X | Yd | Yv)
-// mode: 0 two-phase with resident source rows, 1 two-phase with alternating residency, 2 single phase (double-buffered A tiles)
+#define DG_XBUF (32 * DG_XS0 + 8)                                 // floats of one X tile (mode 3: a second one behind the A tiles)
+// mode: 0 two-phase with resident source rows, 1 two passes (large molecules), 2 single phase (double-buffered A tiles),
+// 3 single phase with a double-buffered X tile and a single Y tile (mid-size spans)
 __host__ __device__ inline size_t dg_lds_floats(int rs, int pmax, int mode) {
   // xs | A tiles: X (+8: the dummy quarter group reads 4 floats past the last row) | Yd | Yv | tabA | tabJ | deg
-  return (size_t)rs * (mode == 1 ? DG_XST_ALT : DG_XST_RES) + (size_t)(mode == 2 ? 2 : 1) * DG_ABUF + (size_t)32 * pmax * 4 +
-         (size_t)32 * pmax + 32;
+  return (size_t)rs * (mode == 1 ? DG_XST_ALT : DG_XST_RES) + (size_t)(mode == 2 ? 2 : 1) * DG_ABUF + (mode == 3 ? DG_XBUF : 0) +
+         (size_t)32 * pmax * 4 + (size_t)32 * pmax + 32;
 }
 
 // ALT = false: the source rows of a tile stay in LDS for the whole segment (spans up to ~80 rows).
@@ -123,9 +125,14 @@ __host__ __device__ inline size_t dg_lds_floats(int rs, int pmax, int mode) {
 // matrix waves run X(k) W and Y(k) W back to back while the forming waves build X(k+1) and Y(k+1) in ONE pass over the edges
 // (one table read, one row address and 9 packed + 1 scalar FMA per edge instead of two passes with their own reads), one
 // barrier per k plus a short second one around the copy of T(k+2) into its slots.
+// MODE 3 (SPH, spans up to ~73 rows: 33-atom molecules, two per tile): the single-phase schedule with what LDS allows — X double
+// buffered (16 KB), Y single.  The matrix waves contract Y(k) FIRST; the forming waves run the merged edge pass of their first
+// destination pair meanwhile, store its X rows, and meet the matrix waves at a mid-step barrier before any Y(k+1) row is
+// written; then X(k) x W runs against the rest of the forming work.  Three barriers per k instead of two phases of unequal
+// weight with two passes over the edges (measured on 33 atoms x 256: 25.2 k -> see DESIGN.md cycles per k-step).
 template <int MODE>
 __global__ __launch_bounds__(DG_THREADS) void k_conv_dg(DgArgs a) {
-  constexpr bool ALT = MODE == 1, SP = MODE == 2;
+  constexpr bool ALT = MODE == 1, SPH = MODE == 3, SP = MODE == 2 || SPH;  // (SP: the single-phase schedule, both variants)
   constexpr int DG_XST = ALT ? DG_XST_ALT : DG_XST_RES;
   constexpr int OFFY = ALT ? 0 : 480;    // byte offset of the vector block inside a row
   constexpr int TCOL = ALT ? 0 : 120;    // float column of the vector block
@@ -135,7 +142,8 @@ __global__ __launch_bounds__(DG_THREADS) void k_conv_dg(DgArgs a) {
   float* __restrict__ Xt = xs + (size_t)a.RS * DG_XST;           // [32][DG_XS0] (+8)
   float* __restrict__ Yd = Xt + 32 * DG_XS0 + 8;                 // [32][DG_YD]
   float* __restrict__ Yv = Yd + 32 * DG_YD;                      // [3][32][DG_YV]
-  float4* __restrict__ tabA = reinterpret_cast<float4*>(Xt + (SP ? 2 : 1) * DG_ABUF);  // [32][PMAX] (c, c vx, c vy, c vz)
+  float* __restrict__ X1 = Xt + DG_ABUF;                        // second X tile (SPH) / second set of A tiles (MODE 2)
+  float4* __restrict__ tabA = reinterpret_cast<float4*>(Xt + (SPH ? DG_ABUF + DG_XBUF : (SP ? 2 : 1) * DG_ABUF));  // [32][PMAX] (c, c vx, c vy, c vz)
   int* __restrict__ tabJ = reinterpret_cast<int*>(tabA + 32 * a.PMAX);          // [32][PMAX] byte offset of the source row in xs
   int* __restrict__ deg_lds = tabJ + 32 * a.PMAX;                               // [32]
   // segment end: the output tile is staged in LDS (dead A tiles / source rows) and stored by ALL threads as coalesced float4 rows
@@ -254,7 +262,7 @@ __global__ __launch_bounds__(DG_THREADS) void k_conv_dg(DgArgs a) {
         }
       }
     }
-    for (int idx = tid; idx < (SP ? 2 : 1) * DG_ABUF; idx += DG_THREADS) Xt[idx] = 0.f;
+    for (int idx = tid; idx < (SPH ? DG_ABUF + DG_XBUF : (SP ? 2 : 1) * DG_ABUF); idx += DG_THREADS) Xt[idx] = 0.f;
     if (tid < 32) deg_lds[tid] = (tid < n_dst) ? a.deg[n0 + tid] : 0;
     LDS_BARRIER();  // (LDS-only: the previous segment's slab stores keep draining in the background)
 
@@ -418,7 +426,42 @@ __global__ __launch_bounds__(DG_THREADS) void k_conv_dg(DgArgs a) {
         __syncthreads();
         continue;
       }
-      if constexpr (SP) {
+      if constexpr (SPH) {
+        // ---- single phase per hidden unit, Y single buffered: Y(k) x W first, mid-step barrier, then X(k) x W
+        {
+          const int k0 = k_of(0);
+          load_tslots(k0);
+          load_d(B0, k0);
+          load_v(B1, k0);
+          store_tslots(k0);
+        }
+        LDS_BARRIER();                    // T(k0) in its slots: the forming waves build A(k0) (X into buffer 0)
+        if (nk > 1) load_tslots(k_of(1));
+        LDS_BARRIER();                    // A(k0) complete
+        if (nk > 1) store_tslots(k_of(1));
+        LDS_BARRIER();                    // T(k1) in its slots
+        DSTAMP(tb); DACC(0, tb, ta);
+        for (int it = 0; it < nk; ++it) {
+          const int k = k_of(it), kn = k_of(it + 1);
+          DSTAMP(ta);
+          Xa = ((it & 1) ? X1 : Xt) + r * DG_XS0 + 4 * hh;
+          if (it + 2 < nk) load_tslots(k_of(it + 2));
+          run_d(B0); load_x(B0, k, 0);
+          run_v(B1); load_x(B1, k, 1);
+          DSTAMP(tb); DACC(3, tb, ta);
+          LDS_BARRIER();                  // Y(k) consumed: the forming waves may write Y(k+1)
+          DSTAMP(ta); DACC(4, ta, tb);
+          run_x(B0, 0); load_x(B0, k, 2);
+          run_x(B1, 1); load_x(B1, k, 3);
+          run_x(B0, 2); load_d(B0, kn);
+          run_x(B1, 3); load_v(B1, kn);
+          DSTAMP(tb); DACC(1, tb, ta);
+          LDS_BARRIER();                  // A(k+1) complete; nobody reads X(k) or T(k+1) any more
+          DSTAMP(ta); DACC(2, ta, tb);
+          if (it + 2 < nk) store_tslots(k_of(it + 2));
+          LDS_BARRIER();
+        }
+      } else if constexpr (SP) {
         // ---- single phase per hidden unit
         {
           const int k0 = k_of(0);
@@ -560,7 +603,7 @@ __global__ __launch_bounds__(DG_THREADS) void k_conv_dg(DgArgs a) {
       // after the other, bound by LDS latency; with priority their VALU instructions go first and the MFMAs fill their
       // latency gaps (measured timeline: matrix waves done at 10.2k cycles of a 15.1k step, forming waves at 11.7k .. 13.9k).
       if (!(a.dbg & 32)) __builtin_amdgcn_s_setprio(3);
-      const int fw = wave - 4;                    // forming wave index: destinations 2 DG_NDP fw .. 2 DG_NDP (fw + 1) - 1
+      const int fw = wave - 4;                    // forming wave index
       const int h = lane >> 5, u = lane & 31;
       const int xs_lds = lds_address(xs);  // LDS address of the source rows
       // per destination pair dp: this lane's edge slots t = u (page 0) and u + 32 (page 1) of destination i = 4 fw + 2 dp + h
@@ -783,10 +826,10 @@ __global__ __launch_bounds__(DG_THREADS) void k_conv_dg(DgArgs a) {
       };
 
       // SP: X and Y of one hidden unit in ONE pass over the edges, into A buffer `buf`
-      auto form_xy = [&](int buf) {
-        float* __restrict__ Xo = Xt + buf * DG_ABUF;
-        float* __restrict__ Ydo = Yd + buf * DG_ABUF;
-        float* __restrict__ Yvo = Yv + buf * DG_ABUF;
+      auto form_xy = [&](int buf, bool mid) {
+        float* __restrict__ Xo = SPH ? (buf ? X1 : Xt) : Xt + buf * DG_ABUF;
+        float* __restrict__ Ydo = SPH ? Yd : Yd + buf * DG_ABUF;
+        float* __restrict__ Yvo = SPH ? Yv : Yv + buf * DG_ABUF;
 #pragma unroll
         for (int dp = 0; dp < DG_NDP; ++dp) {
           const int i = 2 * DG_NDP * fw + 2 * dp + h;
@@ -851,6 +894,9 @@ __global__ __launch_bounds__(DG_THREADS) void k_conv_dg(DgArgs a) {
           }
           O[dp][0] = p_a1x_o0.y; O[dp][1] = p_o12.x; O[dp][2] = p_o12.y;
           if (u < 30) *reinterpret_cast<float4*>(Xo + i * DG_XS0 + 4 * u) = make_float4(ax01.x, ax01.y, ax23.x, ax23.y);
+          if constexpr (SPH) {
+            if (dp == 0 && mid) LDS_BARRIER();  // the matrix waves have finished Y(k) x W: the single Y tile may be rewritten
+          }
           Ydo[i * DG_YD + u] = (p_d.x + p_d.y) + d2;
           Yvo[(0 * 32 + i) * DG_YV + u] = p_a1x_o0.x; Yvo[(1 * 32 + i) * DG_YV + u] = p_a1yz.x; Yvo[(2 * 32 + i) * DG_YV + u] = p_a1yz.y;
           Yvo[(0 * 32 + i) * DG_YV + 32 + u] = n7.y - n7.x; Yvo[(1 * 32 + i) * DG_YV + 32 + u] = n3.y - n5.y; Yvo[(2 * 32 + i) * DG_YV + 32 + u] = n5.x - n3.x;
@@ -862,7 +908,7 @@ __global__ __launch_bounds__(DG_THREADS) void k_conv_dg(DgArgs a) {
         write_tab();
         load_h(k_of(1));
         LDS_BARRIER();                    // T(k0) in its slots
-        form_xy(0);
+        form_xy(0, false);
         if (nk > 1) { write_tab(); load_h(k_of(2)); }
         LDS_BARRIER();                    // A(k0) complete
         LDS_BARRIER();                    // T(k1) in its slots
@@ -870,8 +916,10 @@ __global__ __launch_bounds__(DG_THREADS) void k_conv_dg(DgArgs a) {
         for (int it = 0; it < nk; ++it) {
           DSTAMP(ta);
           if (it + 1 < nk) {
-            form_xy((it + 1) & 1);
+            form_xy((it + 1) & 1, true);
             if (it + 2 < nk) { write_tab(); load_h(k_of(it + 3)); }
+          } else if constexpr (SPH) {
+            LDS_BARRIER();                // (the mid-step barrier of the last hidden unit: nothing left to form)
           }
           DTRACE(0, ta);
           DSTAMP(tb); DACC(1, tb, ta);
@@ -1093,7 +1141,8 @@ int launch_conv_dg(const DgArgs& a, int grid, hipStream_t st) {
   const size_t smem = conv_dg_lds_bytes(a.RS, a.PMAX, a.alt);
   if (smem > JAMUN_MAX_DYN_LDS) return -2;
   if (a.RS > (a.alt == 1 ? DG_RS_MAX_ALT : DG_RS_MAX_RES) || a.XS != 216 || a.nt0 != 5) return -1;
-  if (a.alt == 1) hipLaunchKernelGGL(k_conv_dg<1>, dim3(grid), dim3(DG_THREADS), smem, st, a);
+  if (a.alt == 3) hipLaunchKernelGGL(k_conv_dg<3>, dim3(grid), dim3(DG_THREADS), smem, st, a);
+  else if (a.alt == 1) hipLaunchKernelGGL(k_conv_dg<1>, dim3(grid), dim3(DG_THREADS), smem, st, a);
   else if (a.alt == 2) hipLaunchKernelGGL(k_conv_dg<2>, dim3(grid), dim3(DG_THREADS), smem, st, a);
   else hipLaunchKernelGGL(k_conv_dg<0>, dim3(grid), dim3(DG_THREADS), smem, st, a);
   return 0;
@@ -1102,7 +1151,8 @@ int launch_conv_dg(const DgArgs& a, int grid, hipStream_t st) {
 int conv_dg_set_max_lds() {
   return (hipFuncSetAttribute((const void*)k_conv_dg<0>, hipFuncAttributeMaxDynamicSharedMemorySize, JAMUN_MAX_DYN_LDS) == hipSuccess &&
           hipFuncSetAttribute((const void*)k_conv_dg<1>, hipFuncAttributeMaxDynamicSharedMemorySize, JAMUN_MAX_DYN_LDS) == hipSuccess &&
-          hipFuncSetAttribute((const void*)k_conv_dg<2>, hipFuncAttributeMaxDynamicSharedMemorySize, JAMUN_MAX_DYN_LDS) == hipSuccess)
+          hipFuncSetAttribute((const void*)k_conv_dg<2>, hipFuncAttributeMaxDynamicSharedMemorySize, JAMUN_MAX_DYN_LDS) == hipSuccess &&
+          hipFuncSetAttribute((const void*)k_conv_dg<3>, hipFuncAttributeMaxDynamicSharedMemorySize, JAMUN_MAX_DYN_LDS) == hipSuccess)
              ? 0
              : -1;
 }

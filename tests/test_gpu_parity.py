@@ -209,25 +209,38 @@ def test_fused_and_fallback_conv_agree(dev, golden_dir, kind, monkeypatch):
             assert (a - b).abs().max().item() <= 2e-5 * max(b.abs().max().item(), 1e-6), l
     monkeypatch.delenv("JAMUN_NO_DG")
     monkeypatch.delenv("JAMUN_NO_FUSED")
-    # jamun_conv_dg.hip has three variants, chosen by the span of the tiles: single phase (small molecules), two phases with
-    # resident source rows, alternating residency (large molecules).  Switch the chosen one off and the next one must give
-    # the same features.
+    # jamun_conv_dg.hip has four variants, chosen by the span of the tiles: single phase (small molecules), single phase with one
+    # Y tile (mid-size spans), two phases with resident source rows, two passes (large molecules).  Switch the chosen one off
+    # and the two-phase kernel must give the same features.
     mode = dg.stats()["dg_mode"]
-    expect = {"ag4": 2, "chain17x6": 2, "ragged_small": 2, "ragged": 0, "dense70": 0, "chig93x2": 1, "chig166x2": 1}[kind]
+    expect = {"ag4": 2, "chain17x6": 2, "ragged_small": 2, "ragged": 3, "dense70": 3, "chig93x2": 1, "chig166x2": 1}[kind]
     assert mode == expect, (kind, mode)
-    if mode in (1, 2):
-        monkeypatch.setenv("JAMUN_DG_NO_SP" if mode == 2 else "JAMUN_DG_NO_ALT", "1")
+    if mode in (1, 2, 3):
+        off = {1: "JAMUN_DG_NO_ALT", 2: "JAMUN_DG_NO_SP", 3: "JAMUN_DG_NO_SPH"}[mode]
+        monkeypatch.setenv(off, "1")
+        if mode == 2:
+            monkeypatch.setenv("JAMUN_DG_NO_SPH", "1")
         other = NativeSampler(model._native, 0.04, batch, dev)
-        monkeypatch.delenv("JAMUN_DG_NO_SP" if mode == 2 else "JAMUN_DG_NO_ALT")
+        monkeypatch.delenv(off)
+        monkeypatch.delenv("JAMUN_DG_NO_SPH", raising=False)
         assert other.stats()["dg_mode"] == 0
         assert rmsd(other.xhat(y), xg) <= RMSD_TOL_NM
         for l in range(6):
             a2, b2 = other.debug_read(0, l).cpu(), general.debug_read(0, l).cpu()
             assert (a2 - b2).abs().max().item() <= 2e-5 * max(b2.abs().max().item(), 1e-6), l
+    if mode == 2:  # ... and the one-Y-tile variant on the same small batch
+        monkeypatch.setenv("JAMUN_DG_NO_SP", "1")
+        sph = NativeSampler(model._native, 0.04, batch, dev)
+        monkeypatch.delenv("JAMUN_DG_NO_SP")
+        assert sph.stats()["dg_mode"] == 3
+        assert rmsd(sph.xhat(y), xg) <= RMSD_TOL_NM
+        for l in range(6):
+            a3, b3 = sph.debug_read(0, l).cpu(), general.debug_read(0, l).cpu()
+            assert (a3 - b3).abs().max().item() <= 2e-5 * max(b3.abs().max().item(), 1e-6), l
     # the initial projector of the default path runs edge by edge on the tiles of the dg kernel when the spans fit two LDS row
     # buffers (jamun_conv_initv.hip); switched off, the MFMA table kernel takes the layer — same features
-    # (two LDS row buffers for the small cases, one for chignolin-size spans; the ragged case would need one buffer at mid-size spans)
-    expect_init = {"ag4": 2, "chain17x6": 2, "ragged_small": 2, "ragged": 1, "dense70": 2, "chig93x2": 2, "chig166x2": 2}[kind]
+    # (two LDS row buffers for molecules up to 40 atoms, one for chignolin-size spans; mid-size molecules keep the MFMA table kernel)
+    expect_init = {"ag4": 2, "chain17x6": 2, "ragged_small": 2, "ragged": 1, "dense70": 1, "chig93x2": 2, "chig166x2": 2}[kind]
     assert dg.stats()["init_path"] == expect_init, (kind, dg.stats()["init_path"])
     if expect_init == 2:
         monkeypatch.setenv("JAMUN_NO_INIT_V", "1")
