@@ -448,7 +448,9 @@ __global__ __launch_bounds__(DG_THREADS) void k_conv_dg(DgArgs a) {
           if (it + 2 < nk) load_tslots(k_of(it + 2));
           run_d(B0); load_x(B0, k, 0);
           run_v(B1); load_x(B1, k, 1);
+          DTRACE(0, ta);
           DSTAMP(tb); DACC(3, tb, ta);
+          DTRACE(1, tb);
           LDS_BARRIER();                  // Y(k) consumed: the forming waves may write Y(k+1)
           DSTAMP(ta); DACC(4, ta, tb);
           run_x(B0, 0); load_x(B0, k, 2);
@@ -456,10 +458,14 @@ __global__ __launch_bounds__(DG_THREADS) void k_conv_dg(DgArgs a) {
           run_x(B0, 2); load_d(B0, kn);
           run_x(B1, 3); load_v(B1, kn);
           DSTAMP(tb); DACC(1, tb, ta);
+          DTRACE(2, tb);
           LDS_BARRIER();                  // A(k+1) complete; nobody reads X(k) or T(k+1) any more
           DSTAMP(ta); DACC(2, ta, tb);
           if (it + 2 < nk) store_tslots(k_of(it + 2));
           LDS_BARRIER();
+          DSTAMP(tb);
+          DTRACE(3, tb);
+          ++trc;
         }
       } else if constexpr (SP) {
         // ---- single phase per hidden unit
@@ -895,7 +901,10 @@ __global__ __launch_bounds__(DG_THREADS) void k_conv_dg(DgArgs a) {
           O[dp][0] = p_a1x_o0.y; O[dp][1] = p_o12.x; O[dp][2] = p_o12.y;
           if (u < 30) *reinterpret_cast<float4*>(Xo + i * DG_XS0 + 4 * u) = make_float4(ax01.x, ax01.y, ax23.x, ax23.y);
           if constexpr (SPH) {
-            if (dp == 0 && mid) LDS_BARRIER();  // the matrix waves have finished Y(k) x W: the single Y tile may be rewritten
+            if (dp == 0 && mid) {
+              DSTAMP(tb); DTRACE(1, tb);
+              LDS_BARRIER();  // the matrix waves have finished Y(k) x W: the single Y tile may be rewritten
+            }
           }
           Ydo[i * DG_YD + u] = (p_d.x + p_d.y) + d2;
           Yvo[(0 * 32 + i) * DG_YV + u] = p_a1x_o0.x; Yvo[(1 * 32 + i) * DG_YV + u] = p_a1yz.x; Yvo[(2 * 32 + i) * DG_YV + u] = p_a1yz.y;
@@ -923,10 +932,10 @@ __global__ __launch_bounds__(DG_THREADS) void k_conv_dg(DgArgs a) {
           }
           DTRACE(0, ta);
           DSTAMP(tb); DACC(1, tb, ta);
-          DTRACE(1, tb);
+          DTRACE(SPH ? 2 : 1, tb);
           LDS_BARRIER();
           DSTAMP(ta); DACC(2, ta, tb);
-          DTRACE(2, ta);
+          if constexpr (!SPH) DTRACE(2, ta);
           LDS_BARRIER();
           DSTAMP(tb); DACC(4, tb, ta);
           DTRACE(3, tb);
@@ -1057,7 +1066,7 @@ void conv_dg_print_stamps() {
   static unsigned long long tr[12][48][4];
   if (hipMemcpyFromSymbol(tr, HIP_SYMBOL(g_dgtrace), sizeof(tr)) == hipSuccess && tr[0][0][0] != 0) {
     const unsigned long long t0 = tr[0][0][0];
-    fprintf(stderr, "dg trace (workgroup 7): per k-step, per wave (0-3 matrix, 4-11 forming): start / arrive A / release A / end, cycles since first start\n");
+    fprintf(stderr, "dg trace (workgroup 7): per k-step, per wave (0-3 matrix, 4-11 forming): start / arrive A / release A / end (mode 3: start / arrive mid / arrive A / end), cycles since first start\n");
     for (int st = 0; st < 12; ++st) {
       for (int w = 0; w < 12; ++w)
         fprintf(stderr, "  step %2d wave %2d: %7lld %7lld %7lld %7lld\n", st, w, (long long)(tr[w][st][0] - t0), (long long)(tr[w][st][1] - t0),
