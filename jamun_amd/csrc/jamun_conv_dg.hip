@@ -1,5 +1,5 @@
 // jamun_conv_dg.hip — conv contraction of a hidden layer, destination-grouped, with the A operand formed on the VECTOR
-// ALUs by dedicated waves while other waves keep the matrix cores busy.
+// ALUs by dedicated waves while other waves run the contraction on the matrix cores.
 //
 // Same mathematics as jamun_conv.hip / jamun_conv_fused.hip (src/jamun/e3tools/nn/_conv.py:93-119, re-associated by
 // destination):   m[(i,c)][w] = sum_k sum_u A_k[(i,c)][u] W~[(k,u)][w],   A_k[(i,c)][u] = sum_{e->i} h~_e[k] zeta_e[c][u].
@@ -10,23 +10,28 @@
 //
 //   12 waves per workgroup (one persistent workgroup per CU), two roles:
 //   * waves 0..3  (one per SIMD)  MATRIX waves.  Wave w owns scalar-output tile w (32 of the 152 columns), a quarter of the
-//     K range of scalar-output tile 4, the 16x16 sub-tiles (rh = w&1, ch = w>>1) of the three vector planes, and the
-//     row tiles {w, w+4, ..} of the T product.  All four run the same program on different addresses.
+//     K range of scalar-output tile 4 and the 16x16 sub-tiles (rh = w&1, ch = w>>1) of the three vector planes.  All four
+//     run the same program on different addresses.
 //   * waves 4..11 (two per SIMD)  FORMING waves.  Each owns 4 destination atoms, two at a time: lane = (half h -> which of
 //     the two destinations, u = channel).  Per edge e = (j -> i) of its destination the half-wave reads the source row
 //     x_j from LDS (coalesced: the lanes of a half read consecutive channels of ONE row, so no bank conflict and no
 //     per-lane gather) and accumulates  c x0_j[u],  c x1_j[u][m],  sum_m (c v_m) x1_j[u][m],  c (x1_j[u] x v)[m]  with the
 //     per-edge coefficients c = h~_e[k], c v_m broadcast from a small per-wave LDS table, plus the vector-row
 //     contribution of the scalar inputs through the re-association  out_m[i][w] += sum_e (c v_m) T_k[j][w],
-//     T_k[j][w] = sum_u x0_j[u] W~[(k,u)][w]  (T_k is formed by the matrix waves: 2 x 120 x 32 FLOP per source atom instead
-//     of 3 x per destination).
-//   The VALU of a SIMD is otherwise idle under an MFMA-bound kernel, so the forming work hides behind the contraction.
+//     T_k[j][w] = sum_u x0_j[u] W~[(k,u)][w]  (T_k comes from the pre-pass k_tprod at the end of this file: 2 x 120 x 32 FLOP
+//     per source atom and k, once per layer, instead of 3 x per destination).
+//   MFMA and VALU instructions of a SIMD exclude each other in time on gfx950 (measured: DESIGN.md 3.3), so the forming work is
+//   NOT hidden behind the contraction — a k-step costs the sum of both — but it is proportional to the real edges, and the
+//   LDS latency of the forming waves is filled with MFMAs.
 //
-//   Per hidden unit k, two phases separated by LDS-only barriers (single-buffered A tiles: 46 KB instead of 92 KB, which
-//   leaves LDS for source spans of ~90 atoms):
-//     P1(k): matrix waves  X(k) x W  (scalar inputs -> scalar rows, K = 120);        forming waves write Y(k)
-//     P2(k): matrix waves  Y(k) x W  (dot -> scalar rows; x1, cross -> vector rows) and T(k+1);   forming waves write X(k+1)
-//   MFMA work per (32-destination tile, k): 300 + 304 units of v_mfma_f32_32x32x2 (64 cycles), against 637 algorithmic.
+//   Four schedules of the hidden units of a segment (template parameter MODE, chosen by the host from the tile spans):
+//     0  two phases per k, single-buffered A tiles (spans up to ~80 rows):
+//          P1(k): matrix waves  X(k) x W  (scalar inputs -> scalar rows, K = 120);        forming waves write Y(k)
+//          P2(k): matrix waves  Y(k) x W  (dot -> scalar rows; x1, cross -> vector rows);   forming waves write X(k+1)
+//     2  one phase per k, double-buffered A tiles, X and Y formed in ONE pass over the edges (spans up to ~52 rows)
+//     3  as 2 with a double-buffered X tile and ONE Y tile: Y(k) x W first, mid-step barrier, then X(k) x W (up to ~73 rows)
+//     1  large molecules (up to ~176 rows): two passes over the k run, vector blocks resident, then scalar channels
+//   MFMA work per (32-destination tile, k): 476 units of v_mfma_f32_32x32x2 (64 cycles), against 637 algorithmic.
 //
 // Work distribution, partial slabs, fixed summation order: as jamun_conv_fused.hip (host-built segment lists).
 #include <hip/hip_runtime.h>
