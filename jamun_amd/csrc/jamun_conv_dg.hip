@@ -1093,7 +1093,7 @@ void conv_dg_print_stamps() {
 // the 32 x 32 tile goes to HBM as four 16-byte stores per lane instead of sixteen 4-byte stores with their address and
 // predicate arithmetic (VALU work that the matrix pipe of the SIMD waits for).  No LDS, no barriers.
 // The launch is sized to ONE wave per SIMD (1024 waves: k-groups = 1024 / row tiles).  Measured on MI355X, 4352 atoms:
-// 4352 short waves of ~2 hidden units 36 us; 2040 waves (two per SIMD) 38 us; 952 waves 27 us (standalone, scratch bench).
+// 4352 short waves of ~2 hidden units 36 us; 2040 waves (two per SIMD) 38 us; 952 waves 27 us (standalone: profiles/microbench/tprod_bench.hip).
 #define TP_WAVES 4
 __global__ __launch_bounds__(64 * TP_WAVES) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_tprod(
     const float* __restrict__ x, int XS, int n_atoms, int n_k, int kg, const float4* __restrict__ wt, float* __restrict__ T) {
