@@ -301,6 +301,40 @@ def test_fused_and_fallback_conv_agree_on_random_ragged_batches(dev, seed, monke
                 assert (a - b).abs().max().item() <= 2e-5 * max(b.abs().max().item(), 1e-6), (trial, l)
 
 
+@pytest.mark.parametrize("atoms,walkers,dg_mode,init_path", [(17, 64, 2, 2), (33, 64, 3, 2), (57, 32, 3, 1), (166, 4, 1, 2)])
+def test_kernel_variants_chosen_for_the_baseline_shapes(dev, atoms, walkers, dg_mode, init_path):
+    """BASELINE configs[1..4] shapes (fewer walkers): which variant of the hidden-layer conv kernel (jamun_stats.dg_mode) and of
+    the initial projector (init_path) the sampler picks, and that the forward through them is finite and rotation-equivariant."""
+    from jamun_amd import synth
+    from jamun_amd.data import WalkerBatch
+    from jamun_amd.model import Denoiser
+    from jamun_amd.native import NativeSampler
+
+    model = Denoiser.from_checkpoint_dict(_ckpt("strong")).to(dev)
+    batch = WalkerBatch.from_molecules([synth.random_chain(atoms, seed=0)] * walkers).to(dev)
+    smp = NativeSampler(model._native, 0.04, batch, dev)
+    st = smp.stats()
+    assert (st["conv_path"], st["dg_mode"], st["init_path"]) == (2, dg_mode, init_path), st
+    torch.manual_seed(11)
+    y = batch.pos + 0.04 * torch.randn(batch.pos.shape).to(dev)
+    x = smp.xhat(y)
+    assert torch.isfinite(x).all()
+    # rotate every walker by the same proper rotation about its own centre: xhat must rotate with it
+    q, _ = torch.linalg.qr(torch.randn(3, 3, dtype=torch.float64))
+    if torch.det(q) < 0:
+        q[:, 0] = -q[:, 0]
+    rot = q.to(torch.float32).to(dev)
+    yw = y.view(walkers, atoms, 3)
+    c = yw.mean(dim=1, keepdim=True)
+    y_rot = ((yw - c) @ rot.T + c).reshape(-1, 3).contiguous()
+    x_rot = smp.xhat(y_rot).view(walkers, atoms, 3)
+    xw = x.view(walkers, atoms, 3)
+    # (compared about the walkers' own centres: with mean_center the output is centred, without it it carries the input centre)
+    x_exp = (xw - xw.mean(dim=1, keepdim=True)) @ rot.T
+    x_got = x_rot - x_rot.mean(dim=1, keepdim=True)
+    assert rmsd(x_got.reshape(-1, 3), x_exp.reshape(-1, 3)) <= 5 * RMSD_TOL_NM
+
+
 def test_walkers_are_independent_at_baseline_batch_size(dev, golden_dir):
     """BASELINE configs[1] shape (17-atom molecule x 256 walkers = 136 tiles, ~2.5 segments per workgroup, 2-3 partial
     slabs per tile): the denoised coordinates of a walker must not depend on which walkers share its batch.  Walkers 0, 1,
