@@ -319,6 +319,7 @@ def test_kernel_variants_chosen_for_the_baseline_shapes(dev, atoms, walkers, dg_
     y = batch.pos + 0.04 * torch.randn(batch.pos.shape).to(dev)
     x = smp.xhat(y)
     assert torch.isfinite(x).all()
+    assert torch.equal(smp.xhat(y), x)  # fixed summation order (host-built segment lists, slabs summed in order): bit-reproducible
     # rotate every walker by the same proper rotation about its own centre: xhat must rotate with it
     q, _ = torch.linalg.qr(torch.randn(3, 3, dtype=torch.float64))
     if torch.det(q) < 0:
