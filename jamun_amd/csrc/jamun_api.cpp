@@ -105,6 +105,9 @@ struct FusedDev {
 };
 struct DgDev {
   float4 *wx = nullptr, *wd = nullptr, *wv = nullptr, *wt = nullptr;  // null: the layer cannot use jamun_conv_dg.hip
+  float4* wxh = nullptr;  // f16x3 contraction: hi / lo planes of the scaled weights, one stream per (hidden unit, matrix wave)
+  int sB = 0;
+  float hmax2 = 2.f;
 };
 struct LayerDev {
   ConvProblemDev p0, p1;
@@ -127,12 +130,53 @@ void free_fused(FusedDev& f) {
 }
 
 void free_dg(DgDev& d) {
-  hipFree(d.wx); hipFree(d.wd); hipFree(d.wv); hipFree(d.wt);
+  hipFree(d.wx); hipFree(d.wd); hipFree(d.wv); hipFree(d.wt); hipFree(d.wxh);
   d = DgDev{};
 }
 
 void free_problem(ConvProblemDev& p) {
   hipFree(p.wpack); hipFree(p.chunks); hipFree(p.slice_ptr); hipFree(p.ublk); hipFree(p.lane_xoff);
+}
+
+// fp32 -> IEEE binary16, round to nearest even (the device side uses v_cvt_pk_f16_f32 in the default rounding mode); values
+// beyond the f16 range do not occur (the caller scales into [-2^14, 2^14])
+uint16_t f32_to_f16_rne(float f) {
+  uint32_t x;
+  std::memcpy(&x, &f, 4);
+  const uint32_t sign = (x >> 16) & 0x8000u;
+  x &= 0x7fffffffu;
+  if (x >= 0x47800000u) return (uint16_t)(sign | 0x7c00u);  // >= 65536 (or inf / nan): inf
+  if (x < 0x38800000u) {                                     // below the smallest normal half (2^-14): subnormal or zero
+    if (x < 0x33000000u) return (uint16_t)sign;              // < 2^-25: rounds to zero
+    const int e = (int)(x >> 23);                             // biased exponent, 102 .. 112
+    const uint32_t mant = (x & 0x7fffffu) | 0x800000u;        // 24-bit significand
+    const int shift = 126 - e;                                // result = mant >> shift, in units of 2^-24
+    const uint32_t q = mant >> shift, rem = mant & ((1u << shift) - 1u), half = 1u << (shift - 1);
+    return (uint16_t)(sign | (q + ((rem > half || (rem == half && (q & 1u))) ? 1u : 0u)));
+  }
+  const uint32_t mant = x & 0x7fffffu, e = (x >> 23) - 112u;  // half exponent field 1 .. 30
+  uint32_t h = (e << 10) | (mant >> 13);
+  const uint32_t rem = mant & 0x1fffu;
+  if (rem > 0x1000u || (rem == 0x1000u && (h & 1u))) ++h;     // (a carry into the exponent is the correct result)
+  return (uint16_t)(sign | h);
+}
+float f16_to_f32(uint16_t h) {
+  const uint32_t sign = (uint32_t)(h & 0x8000u) << 16, e = (h >> 10) & 0x1fu, m = h & 0x3ffu;
+  float out;
+  if (e == 0) {
+    out = std::ldexp((float)m, -24);
+    if (sign) out = -out;
+    return out;
+  }
+  const uint32_t x = sign | ((e == 31 ? 255u : e + 112u) << 23) | (m << 13);
+  std::memcpy(&out, &x, 4);
+  return out;
+}
+// value -> (hi, lo) halves with hi = rne16(v), lo = rne16(v - hi)
+inline void split_f16(double v, uint16_t& hi, uint16_t& lo) {
+  const float f = (float)v;
+  hi = f32_to_f16_rne(f);
+  lo = f32_to_f16_rne(f - f16_to_f32(hi));
 }
 
 std::vector<double> noise_mlp(const jamun_model& m, const std::string& prefix, int k, double c_noise) {
@@ -291,10 +335,12 @@ struct jamun_sampler {
   // destination-grouped VALU-forming conv kernel (jamun_conv_dg.hip; hidden layers): own tile plan (larger source spans)
   bool dg_on = false, dg_row_blocks = false;
   int dg_mode = 0;  // 0 two-phase resident, 1 alternating residency, 2 single phase (see jamun_sampler_create)
+  int dg_emu = 1;   // 1: f16x3 contraction (three f16 MFMAs per fp32 product); 0 (JAMUN_DG_FP32=1): v_mfma_f32_32x32x2_f32
   int dg_RS = 0, dg_grid = 0, dg_max_segs = 0, dg_n_slabs = 0, dg_n_tiles = 0;
   int2 *dg_tile_atoms = nullptr, *dg_tile_span = nullptr;
   int4* dg_segs = nullptr;
   int* dg_atom_nslab = nullptr;
+  float* dg_dump = nullptr;  // diagnostic A-tile dump (JAMUN_DG_DUMP, -DJAMUN_DUMP builds)
   float* dg_T = nullptr;  // [n_k][n_atoms][32] pre-pass product of a hidden layer (k_tprod), reused by every layer
   float *x_emb = nullptr, *mu = nullptr;
   std::vector<LayerDev> layers;
@@ -319,7 +365,7 @@ struct jamun_sampler {
   ~jamun_sampler() {
     hipFree(ptr); hipFree(bond_in_ptr); hipFree(bond_in_src); hipFree(x_emb); hipFree(mu); hipFree(tile_span);
     hipFree(fused_segs); hipFree(atom_nslab); hipFree(tile_atoms); hipFree(atom_uid); hipFree(w1r_all); hipFree(cmask_all);
-    hipFree(dg_tile_atoms); hipFree(dg_tile_span); hipFree(dg_segs); hipFree(dg_atom_nslab); hipFree(dg_T);
+    hipFree(dg_dump); hipFree(dg_tile_atoms); hipFree(dg_tile_span); hipFree(dg_segs); hipFree(dg_atom_nslab); hipFree(dg_T);
     for (auto& L : layers) {
       free_problem(L.p0); free_problem(L.p1); free_fused(L.fu); free_dg(L.dg);
       hipFree(L.wcat0); hipFree(L.wcat1); hipFree(L.mix); hipFree(L.tt); hipFree(L.tt2);
@@ -641,6 +687,93 @@ LayerDev build_layer(const jamun_model& m, const std::string& prefix, const std:
     L.dg.wd = dev_upload(wd);
     L.dg.wv = dev_upload(wv);
     L.dg.wt = dev_upload(wt);
+    // f16x3 contraction: the same weights scaled by 2^sB (largest magnitude just below 2^14) and split into hi + lo halves;
+    // one block = 64 lanes x 8 halves = the B fragment of one v_mfma_f32_32x32x16_f16 (lane (c, hh): inputs 16 g + 8 hh + j,
+    // column 32 t + c) or v_mfma_f32_16x16x32_f16 (lane (c16, kq): kappa = 32 G + 8 kq + j, column 16 ch + c16)
+    {
+      double wmax = 0;
+      for (int k = 0; k < n_k; ++k) {
+        for (const UEntry& e : x0e) for (int col = 0; col < G0; ++col) wmax = std::max(wmax, std::fabs(Wk(k, e.wbase + col) * e.scale));
+        for (const UEntry& e : dote) for (int col = 0; col < G0; ++col) wmax = std::max(wmax, std::fabs(Wk(k, e.wbase + col) * e.scale));
+        for (const UEntry& e : x1e) for (int col = 0; col < G1; ++col) wmax = std::max(wmax, std::fabs(Wk(k, e.wbase + col) * e.scale));
+        for (const UEntry& e : crosse) for (int col = 0; col < G1; ++col) wmax = std::max(wmax, std::fabs(Wk(k, e.wbase + col) * e.scale));
+      }
+      int ex = 0;
+      if (wmax > 0 && std::isfinite(wmax)) std::frexp(wmax, &ex);  // wmax < 2^ex
+      const int sB = std::max(-60, std::min(60, 14 - ex));
+      L.dg.sB = sB;
+      const double sc = std::ldexp(1.0, sB);
+      auto pack8 = [&](const double (&v)[8], float4& hi, float4& lo) {
+        uint32_t h[4], l[4];
+        for (int i = 0; i < 4; ++i) {
+          uint16_t h0, l0, h1, l1;
+          split_f16(v[2 * i] * sc, h0, l0);
+          split_f16(v[2 * i + 1] * sc, h1, l1);
+          h[i] = (uint32_t)h0 | ((uint32_t)h1 << 16);
+          l[i] = (uint32_t)l0 | ((uint32_t)l1 << 16);
+        }
+        std::memcpy(&hi, h, 16);
+        std::memcpy(&lo, l, 16);
+      };
+      std::vector<float4> wxh((size_t)n_k * 5 * 8 * 2 * 64), wdh((size_t)n_k * 5 * 2 * 2 * 64), wvh((size_t)n_k * 2 * 2 * 2 * 64);
+      for (int k = 0; k < n_k; ++k) {
+        for (int t = 0; t < 5; ++t)
+          for (int lane = 0; lane < 64; ++lane) {
+            const int hh = lane >> 5, c = lane & 31, col = 32 * t + c;
+            for (int g = 0; g < 8; ++g) {
+              double v[8];
+              for (int j = 0; j < 8; ++j) {
+                const int u = 16 * g + 8 * hh + j;
+                v[j] = (u < 120 && col < G0) ? Wk(k, x0e[u].wbase + col) * x0e[u].scale : 0.0;
+              }
+              const size_t b = ((((size_t)k * 5 + t) * 8 + g) * 2) * 64 + lane;
+              pack8(v, wxh[b], wxh[b + 64]);
+            }
+            for (int g = 0; g < 2; ++g) {
+              double v[8];
+              for (int j = 0; j < 8; ++j) {
+                const int u = 16 * g + 8 * hh + j;
+                v[j] = col < G0 ? Wk(k, dote[u].wbase + col) * dote[u].scale : 0.0;
+              }
+              const size_t b = ((((size_t)k * 5 + t) * 2 + g) * 2) * 64 + lane;
+              pack8(v, wdh[b], wdh[b + 64]);
+            }
+          }
+        for (int ch = 0; ch < 2; ++ch)
+          for (int G = 0; G < 2; ++G)
+            for (int lane = 0; lane < 64; ++lane) {
+              const int kq = lane >> 4, c = lane & 15, col = 16 * ch + c;
+              double v[8];
+              for (int j = 0; j < 8; ++j) {
+                const int kap = 32 * G + 8 * kq + j;  // input order of the vector planes' A tiles: 2 u + {x1, cross}
+                const UEntry& e = (kap & 1) ? crosse[kap >> 1] : x1e[kap >> 1];
+                v[j] = Wk(k, e.wbase + col) * e.scale;
+              }
+              const size_t b = ((((size_t)k * 2 + ch) * 2 + G) * 2) * 64 + lane;
+              pack8(v, wvh[b], wvh[b + 64]);
+            }
+      }
+      // one stream per (hidden unit, matrix wave) in the order the wave consumes it — 34 blocks: four chunks of the scalar inputs
+      // (own tile: groups 2c, 2c+1 as hi, lo, hi, lo; then the wave's group of scalar tile 4, w + 4 (c >> 1), when it falls into this
+      // chunk — (c & 1) == (w >> 1) — else unused), the dot inputs (own tile groups 0, 1; tile 4: group w for w < 2), the vector
+      // planes (column half w >> 1: groups 0, 1): every load is (uniform base of (k, w)) + constant + lane
+      std::vector<float4> wh((size_t)n_k * 4 * 34 * 64, make_float4(0.f, 0.f, 0.f, 0.f));
+      auto copy_blocks = [&](const std::vector<float4>& src, size_t src_block, size_t dst_block) {  // hi and lo block
+        std::copy(src.begin() + src_block * 64, src.begin() + (src_block + 2) * 64, wh.begin() + dst_block * 64);
+      };
+      for (int k = 0; k < n_k; ++k)
+        for (int w = 0; w < 4; ++w) {
+          const size_t base = ((size_t)k * 4 + w) * 34;
+          for (int c = 0; c < 4; ++c) {
+            for (int gi = 0; gi < 2; ++gi) copy_blocks(wxh, (((size_t)k * 5 + w) * 8 + 2 * c + gi) * 2, base + 6 * c + 2 * gi);
+            if ((w >> 1) == (c & 1)) copy_blocks(wxh, (((size_t)k * 5 + 4) * 8 + w + 4 * (c >> 1)) * 2, base + 6 * c + 4);
+          }
+          for (int g = 0; g < 2; ++g) copy_blocks(wdh, (((size_t)k * 5 + w) * 2 + g) * 2, base + 24 + 2 * g);
+          if (w < 2) copy_blocks(wdh, (((size_t)k * 5 + 4) * 2 + w) * 2, base + 28);
+          for (int G = 0; G < 2; ++G) copy_blocks(wvh, (((size_t)k * 2 + (w >> 1)) * 2 + G) * 2, base + 30 + 2 * G);
+        }
+      L.dg.wxh = dev_upload(wh);
+    }
   }
 
   // ---- initial projector: input-times-weight table for jamun_conv_init.hip (inputs are constant per distinct embedding row)
@@ -708,6 +841,18 @@ LayerDev build_layer(const jamun_model& m, const std::string& prefix, const std:
   }
   L.w1r_h = w1r;
   L.cmask_h = cmask;
+  {
+    // static bound of |h~| = |SiLU(c_mask + W1[:, radial part] . radial(d))| over the layer: the Gaussian basis values are
+    // positive and sum to at most sqrt(pi) / 1.12 < 1.6 at any distance, |SiLU(z)| <= max(|z|, 0.2785); the bias row is 1
+    double hm = 1.0;
+    for (int k = 0; k < H; ++k) {
+      double wm = 0;
+      for (int r = 0; r < nr; ++r) wm = std::max(wm, std::fabs((double)W1[(size_t)k * H + nb + r]));
+      const double z = std::max(std::fabs((double)cmask[k]), std::fabs((double)cmask[(size_t)H + k])) + 1.6 * wm;
+      hm = std::max(hm, z);
+    }
+    L.dg.hmax2 = (float)(2.0 * hm * 1.0001);
+  }
 
   // ---- o3.Linear skip (in -> hidden) and self-interaction (hidden -> hidden)  (_interaction.py:23-30)
   int64_t n_skip = 0;
@@ -829,9 +974,16 @@ void forward(jamun_sampler* s, float* y, float* xhat, float* score, hipStream_t 
       f.tile_span = s->dg_tile_span; f.tile_atoms = s->dg_tile_atoms; f.segs = s->dg_segs; f.max_segs = s->dg_max_segs;
       f.row_blocks = s->dg_row_blocks ? 1 : 0; f.nt0 = L.p0.nt; f.alt = s->dg_mode;
       f.wx = L.dg.wx; f.wd = L.dg.wd; f.wv = L.dg.wv; f.T = s->dg_T; f.n_atoms = s->n_atoms;
+      f.emu = s->dg_emu; f.wh = L.dg.wxh; f.sB = L.dg.sB; f.hmax2 = L.dg.hmax2;
       f.partial0 = s->partial0; f.partial1 = s->partial1;
       static const int dg_dbg = getenv("JAMUN_DG_DBG") ? atoi(getenv("JAMUN_DG_DBG")) : 0;
       f.dbg = dg_dbg;
+      f.dump = nullptr;
+      if (l == 1 && getenv("JAMUN_DG_DUMP")) {
+        if (!s->dg_dump) s->dg_dump = dev_alloc<float>(32 * 12288);
+        f.dbg = atoi(getenv("JAMUN_DG_DUMP"));
+        f.dump = s->dg_dump;
+      }
       ProfScope ps(s, JAMUN_PROF_CONV0, st);  // (the T pre-pass is part of the hidden-layer conv: timed with it)
       launch_tprod(x_in, XSin, s->n_atoms, s->hp.edge_attr_dim + 1, L.dg.wt, s->dg_T, st);
       const int rcode = launch_conv_dg(f, s->dg_grid, st);
@@ -1299,9 +1451,10 @@ int jamun_sampler_create(const jamun_model* m, float sigma, const jamun_topology
       // otherwise the alternating-residency mode of the kernel (rows re-staged per phase: spans up to ~170 rows), and only
       // molecules above THAT are cut into source row blocks.
       const int pmax = (s->S + 3) & ~3;
+      s->dg_emu = getenv("JAMUN_DG_FP32") == nullptr ? 1 : 0;
       auto cap_of = [&](int mode) {
         for (int rs = mode == 1 ? 192 : 128; rs >= 16; rs -= 4)
-          if (conv_dg_lds_bytes(rs, pmax, mode) <= JAMUN_MAX_DYN_LDS) return rs;
+          if (conv_dg_lds_bytes(rs, pmax, mode, s->dg_emu) <= JAMUN_MAX_DYN_LDS) return rs;
         return 0;
       };
       // Modes of k_conv_dg: 0 two phases per k, source rows resident (spans up to ~80 rows); 1 alternating residency (molecules
@@ -1662,6 +1815,9 @@ int jamun_debug_read(jamun_sampler* s, int32_t what, int32_t layer, float* out, 
       launch_deg_to_float(s->deg, out, s->n_atoms, st);
     } else if (what == 2) {
       launch_copy(s->g, out, s->n_atoms * 3, st);
+    } else if (what == 3) {
+      if (!s->dg_dump) throw Err(JAMUN_ERR_INVALID, "no A-tile dump (JAMUN_DG_DUMP unset)");
+      launch_copy(s->dg_dump, out, 32 * 12288, st);
     } else {
       throw Err(JAMUN_ERR_INVALID, "unknown debug buffer");
     }

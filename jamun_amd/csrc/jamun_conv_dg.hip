@@ -44,6 +44,8 @@
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h2 __attribute__((ext_vector_type(2)));
 
 #define DG_WAVES 12   // 4 matrix waves + 8 forming waves (two forming waves per SIMD co-issue VALU and LDS instructions; with one
                       // per SIMD the forming phases took 25 % longer)
@@ -54,6 +56,8 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 #define DG_RS_MAX_RES 128
 #define DG_RS_MAX_ALT 192
 #define DG_XS0 124   // X tile row stride (120 + 4):  4 * 31
+#define DG_XS0H 124  // f16x3 path: 120 inputs as 15 chunks of [8 hi halves | 8 lo halves] = 480 B, + 16 B of zeros: rows 16 B apart mod 256.  The
+                     // last group of 16 inputs reads "chunk 15" = the zero pad + the first 16 B of the next row (finite halves; zero weights)
 #define DG_YD 36     // Yd tile row stride (32 + 4):   4 * 9
 #define DG_YV 68     // Yv tile row stride (64 + 4):   4 * 17
 #define DG_U 4       // edges per batch of the forming loops
@@ -63,6 +67,8 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 #define LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 #define MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+#define MFMA32H(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8, (a)), __builtin_bit_cast(h8, (b)), (c), 0, 0, 0)
+#define MFMA16H(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8, (a)), __builtin_bit_cast(h8, (b)), (c), 0, 0, 0)
 #define RFL(v) __builtin_amdgcn_readfirstlane(v)
 
 #ifdef JAMUN_STAMP
@@ -106,14 +112,35 @@ __device__ __forceinline__ int lds_address(const void* p) {
 #endif
 }
 
-#define DG_ABUF (32 * DG_XS0 + 8 + 32 * DG_YD + 3 * 32 * DG_YV)  // floats of one set of A tiles (X | Yd | Yv)
-#define DG_XBUF (32 * DG_XS0 + 8)                                 // floats of one X tile (mode 3: a second one behind the A tiles)
+// f16x3 split helpers: (a, b) -> packed halves with round-to-nearest-even; residual of a value against one half of a packed pair
+// (v_fma_mix_f32: fma with per-operand f16 / f32 selection; a - hi is exact: hi holds the leading 11 bits of a)
+__device__ __forceinline__ unsigned cvt_pk_f16(float a, float b) {
+  unsigned r;
+  asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ float resid_lo(float a, unsigned pk) {  // a - float(pk[15:0])
+  float r;
+  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r) : "v"(pk), "v"(a));
+  return r;
+}
+__device__ __forceinline__ float resid_hi(float a, unsigned pk) {  // a - float(pk[31:16])
+  float r;
+  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(pk), "v"(a));
+  return r;
+}
+__device__ __forceinline__ float pow2f(int e) { return __uint_as_float((unsigned)(e + 127) << 23); }  // 2^e, -126 <= e <= 127
+
+__host__ __device__ constexpr int dg_xs0(bool h) { return h ? DG_XS0H : DG_XS0; }
+__host__ __device__ constexpr int dg_xbuf(bool h) { return 32 * dg_xs0(h) + 8; }                         // floats of one X tile (mode 3: a second one behind the A tiles)
+__host__ __device__ constexpr int dg_abuf(bool h) { return dg_xbuf(h) + 32 * DG_YD + 3 * 32 * DG_YV; }  // floats of one set of A tiles (X | Yd | Yv)
 // mode: 0 two-phase with resident source rows, 1 two passes (large molecules), 2 single phase (double-buffered A tiles),
 // 3 single phase with a double-buffered X tile and a single Y tile (mid-size spans)
-__host__ __device__ inline size_t dg_lds_floats(int rs, int pmax, int mode) {
-  // xs | A tiles: X (+8: the dummy quarter group reads 4 floats past the last row) | Yd | Yv | tabA | tabJ | deg
-  return (size_t)rs * (mode == 1 ? DG_XST_ALT : DG_XST_RES) + (size_t)(mode == 2 ? 2 : 1) * DG_ABUF + (mode == 3 ? DG_XBUF : 0) +
-         (size_t)32 * pmax * 4 + (size_t)32 * pmax + 32;
+__host__ __device__ inline size_t dg_lds_floats(int rs, int pmax, int mode, bool h) {
+  // xs | A tiles: X (+8: the dummy quarter group reads 4 floats past the last row) | Yd | Yv | tabA | tabJ | deg | f16x3: per-destination
+  // scales (2 x 32) and the per-source-row magnitudes
+  return (size_t)rs * (mode == 1 ? DG_XST_ALT : DG_XST_RES) + (size_t)(mode == 2 ? 2 : 1) * dg_abuf(h) + (mode == 3 ? dg_xbuf(h) : 0) +
+         (size_t)32 * pmax * 4 + (size_t)32 * pmax + 32 + (h ? 64 + rs : 0);
 }
 
 // ALT = false: the source rows of a tile stay in LDS for the whole segment (spans up to ~80 rows).
@@ -135,22 +162,36 @@ __host__ __device__ inline size_t dg_lds_floats(int rs, int pmax, int mode) {
 // destination pair meanwhile, store its X rows, and meet the matrix waves at a mid-step barrier before any Y(k+1) row is
 // written; then X(k) x W runs against the rest of the forming work.  Three barriers per k instead of two phases of unequal
 // weight with two passes over the edges (measured on 33 atoms x 256: 25.2 k -> see DESIGN.md cycles per k-step).
-template <int MODE>
+// H (f16x3 contraction): the forming waves write every A tile as two f16 planes (hi = rne16(a), lo = rne16(a - hi); chunks of
+// [8 hi | 8 lo] halves = one lane's fragments of 8 consecutive inputs) and the matrix waves run three v_mfma_f32_*_f16 per
+// product (lo hi + hi lo + hi hi, fp32 accumulate) against weights split the same way on the host: the error of a product is
+// ~3 x 2^-24 of its magnitude, the level of one fp32 rounding, at 3/16 of the matrix-pipe time of v_mfma_f32_32x32x2_f32 — and,
+// unlike fp32 MFMAs (which run on the vector FMA lanes and exclude EVERY VALU instruction of the SIMD while they execute;
+// profiles/microbench/mfma_overlap.hip), f16 MFMAs leave ~3/4 of the vector issue slots to the forming waves.  To stay inside
+// the f16 range the coefficients of destination i carry a power of two 2^sA_i chosen from a rigorous bound of its A rows
+// (in-degree x max |h~| (static, a.hmax2) x max |x| over its source rows (measured while the rows are staged)), the weights carry
+// 2^sB, and the accumulators are scaled back by 2^-(sA_i + sB) at the segment end: all exact.
+template <int MODE, bool H>
 __global__ __launch_bounds__(DG_THREADS) void k_conv_dg(DgArgs a) {
   constexpr bool ALT = MODE == 1, SPH = MODE == 3, SP = MODE == 2 || SPH;  // (SP: the single-phase schedule, both variants)
+  constexpr int XS0 = dg_xs0(H), DG_ABUF = dg_abuf(H), DG_XBUF = dg_xbuf(H);
+  constexpr int AH = H ? 8 : 4;  // floats between the two K halves (32x32) / four K quarters (16x16) of a fragment row
   constexpr int DG_XST = ALT ? DG_XST_ALT : DG_XST_RES;
   constexpr int OFFY = ALT ? 0 : 480;    // byte offset of the vector block inside a row
   constexpr int TCOL = ALT ? 0 : 120;    // float column of the vector block
   extern __shared__ float4 lds4[];
   float* __restrict__ lds = reinterpret_cast<float*>(lds4);
   float* __restrict__ xs = lds;                                  // [RS][DG_XST]
-  float* __restrict__ Xt = xs + (size_t)a.RS * DG_XST;           // [32][DG_XS0] (+8)
-  float* __restrict__ Yd = Xt + 32 * DG_XS0 + 8;                 // [32][DG_YD]
+  float* __restrict__ Xt = xs + (size_t)a.RS * DG_XST;           // [32][XS0] (+8)
+  float* __restrict__ Yd = Xt + DG_XBUF;                         // [32][DG_YD]
   float* __restrict__ Yv = Yd + 32 * DG_YD;                      // [3][32][DG_YV]
   float* __restrict__ X1 = Xt + DG_ABUF;                        // second X tile (SPH) / second set of A tiles (MODE 2)
   float4* __restrict__ tabA = reinterpret_cast<float4*>(Xt + (SPH ? DG_ABUF + DG_XBUF : (SP ? 2 : 1) * DG_ABUF));  // [32][PMAX] (c, c vx, c vy, c vz)
   int* __restrict__ tabJ = reinterpret_cast<int*>(tabA + 32 * a.PMAX);          // [32][PMAX] byte offset of the source row in xs
   int* __restrict__ deg_lds = tabJ + 32 * a.PMAX;                               // [32]
+  float* __restrict__ sc_lds = reinterpret_cast<float*>(deg_lds + 32);          // H: [32] 2^sA_i
+  float* __restrict__ isc_lds = sc_lds + 32;                                    // H: [32] 2^-(sA_i + sB)
+  unsigned* __restrict__ rowmax = reinterpret_cast<unsigned*>(isc_lds + 32);    // H: [RS] max |x| of each source row (float bits)
   // segment end: the output tile is staged in LDS (dead A tiles / source rows) and stored by ALL threads as coalesced float4 rows
   float* __restrict__ OM = Xt;               // [32][128]    scalar tiles 0..3
   float* __restrict__ OQ = OM + 32 * 128;    // [4][32][32]  the four K-quarter partials of scalar tile 4
@@ -161,12 +202,22 @@ __global__ __launch_bounds__(DG_THREADS) void k_conv_dg(DgArgs a) {
   const int wave = RFL(tid0 >> 6);
   const bool is_mat = wave < 4;
   const int PMAX = a.PMAX;
-  const bool dbg_noform = a.dbg & 1, dbg_nomfma = a.dbg & 2, dbg_noweights = a.dbg & 4;
+#ifdef JAMUN_STAMP  // timing experiments (JAMUN_DG_DBG) exist in the diagnostic build only
+  const bool dbg_noform = a.dbg & 1, dbg_nomfma = a.dbg & 2, dbg_noweights = a.dbg & 4, dbg_notouch = a.dbg & 16, dbg_noprio = a.dbg & 32, dbg_nostage = a.dbg & 8;
+#else
+  constexpr bool dbg_noform = false, dbg_nomfma = false, dbg_noweights = false, dbg_notouch = false, dbg_noprio = false, dbg_nostage = false;
+#endif
   unsigned long long st_acc[6] = {0, 0, 0, 0, 0, 0}, ta = 0, tb = 0;
   int trc = 0;
   (void)trc;
   (void)st_acc; (void)ta; (void)tb;
 
+  if constexpr (H) {
+    for (int i = tid0; i < a.RS; i += DG_THREADS) rowmax[i] = 0u;
+    LDS_BARRIER();
+  }
+  auto absmax4 = [](float4 v) { return __float_as_uint(fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)))); };
+  (void)absmax4;
   for (int sgi = 0; sgi < a.max_segs; ++sgi) {
     const int4 sg0 = a.segs[((size_t)blockIdx.x * a.max_segs + sgi) * 2];
     const int4 sg1 = a.segs[((size_t)blockIdx.x * a.max_segs + sgi) * 2 + 1];
@@ -208,6 +259,8 @@ __global__ __launch_bounds__(DG_THREADS) void k_conv_dg(DgArgs a) {
           if (idx < total) *reinterpret_cast<float4*>(xs + (size_t)j * DG_XST_ALT + 4 * q) = v[q8];
         }
       }
+      if constexpr (H)  // row pads of the second X buffer (it aliases the Y tiles) are read as inputs 120..127: zero halves, not stale bits
+        for (int i = tid; i < 33 * 4; i += DG_THREADS) Yd[i < 128 ? (i >> 2) * XS0 + 120 + (i & 3) : 32 * XS0 + (i & 3)] = 0.f;
     };
     auto stage_x1 = [&](int k) {  // ALT: vector block (x, T_k, y, z) of every source row (T from the pre-pass buffer)
       const int total = rows * 32;
@@ -243,6 +296,13 @@ __global__ __launch_bounds__(DG_THREADS) void k_conv_dg(DgArgs a) {
       }
     };
     if constexpr (ALT) {
+      if constexpr (H) {  // magnitudes of the source rows (both halves of a row share the destination's scale)
+        const int total = rows * 54;  // 216 floats = 54 x 16 bytes per row
+        for (int idx = tid; idx < total; idx += DG_THREADS) {
+          const int j = idx / 54, q = idx - j * 54;
+          atomicMax(&rowmax[j], absmax4(*reinterpret_cast<const float4*>(a.x + (size_t)(s_lo + j) * a.XS + 4 * q)));
+        }
+      }
       stage_x1(k_of(0));
     } else {
       const int total = rows16 * (DG_XST / 4);
@@ -264,6 +324,9 @@ __global__ __launch_bounds__(DG_THREADS) void k_conv_dg(DgArgs a) {
           const int idx = base + q8 * DG_THREADS;
           const int j = idx / (DG_XST / 4), q = idx - j * (DG_XST / 4);
           if (idx < total) *reinterpret_cast<float4*>(xs + (size_t)j * DG_XST + 4 * q) = v[q8];
+          if constexpr (H) {
+            if (idx < total && j < rows && q < 62) atomicMax(&rowmax[j], absmax4(v[q8]));
+          }
         }
       }
     }
@@ -283,9 +346,11 @@ __global__ __launch_bounds__(DG_THREADS) void k_conv_dg(DgArgs a) {
       for (int q = 0; q < 16; ++q) { accM[q] = 0.f; acc4[q] = 0.f; }
 #pragma unroll
       for (int m = 0; m < 3; ++m) accP[m] = f32x4{0.f, 0.f, 0.f, 0.f};
-      const float* Xa = Xt + r * DG_XS0 + 4 * hh;  // (SP: re-pointed to the A buffer of the hidden unit at hand)
-      const float* Da = Yd + r * DG_YD + 4 * hh;
-      const float* Va = Yv + (16 * rh + r16) * DG_YV + 4 * kq;
+      // fragment rows of this lane.  fp32: 4 consecutive K steps per 16-byte read; H: chunk (2 g + hh) / (4 G + kq) of 8 inputs,
+      // hi halves at +0, lo halves at +4 floats
+      const float* Xa = Xt + r * XS0 + AH * hh;  // (SP: re-pointed to the A buffer of the hidden unit at hand)
+      const float* Da = Yd + r * DG_YD + AH * hh;
+      const float* Va = Yv + (16 * rh + r16) * DG_YV + AH * kq;
 
       // weight blocks (64 lanes x float4) of one hidden unit, in the order this wave consumes them:
       //   P1: WX[w][g], g = 0..14, with WX[4][4 s + w] after g = 3, 7, 11, 14          (19 blocks: chunks 5 5 5 4)
@@ -295,11 +360,21 @@ __global__ __launch_bounds__(DG_THREADS) void k_conv_dg(DgArgs a) {
       auto WD = [&](int k, int t, int g) { return (a.wd + ((size_t)k * 5 * 4 + t * 4 + g) * 64)[lane]; };
       auto WV = [&](int k, int c, int g) { return (a.wv + ((size_t)k * 2 * 4 + c * 4 + g) * 64)[lane]; };
 
-      float4 B0[5], B1[5];
+      // H: blocks of 8 halves per lane; chunk c of the scalar inputs = groups 2c, 2c+1 of 16 inputs (own tile: hi, lo, hi, lo) + this
+      // wave's share of scalar tile 4 — groups w and w + 4, i.e. one group in the chunks with (c & 1) == (w >> 1)
+      auto WH = [&](int k, int n) { return (a.wh + (((size_t)k * 4 + w) * 34 + n) * 64)[lane]; };  // block n of this wave's stream of hidden unit k
+      auto LDF = [](const float* p_) { return *reinterpret_cast<const float4*>(p_); };
+      float4 B0[6], B1[6];
 #pragma unroll
-      for (int i = 0; i < 5; ++i) B0[i] = B1[i] = make_float4(1.f, 1.f, 1.f, 1.f);  // (defined values for the JAMUN_DG_DBG=4 experiment)
-      auto load_x = [&](float4 (&B)[5], int k, int c) {  // chunk c of P1: groups 4c..4c+3 (+ the quarter group 4c + w)
+      for (int i = 0; i < 6; ++i) B0[i] = B1[i] = make_float4(1.f, 1.f, 1.f, 1.f);  // (defined values for the JAMUN_DG_DBG=4 experiment)
+      auto load_x = [&](float4 (&B)[6], int k, int c) {  // chunk c of P1: groups 4c..4c+3 (+ the quarter group 4c + w)
         if (dbg_noweights) return;
+        if constexpr (H) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) B[i] = WH(k, 6 * c + i);
+          if ((w >> 1) == (c & 1)) { B[4] = WH(k, 6 * c + 4); B[5] = WH(k, 6 * c + 5); }
+          return;
+        }
 #pragma unroll
         for (int i = 0; i < 4; ++i) B[i] = WX(k, w, (4 * c + i) < 15 ? 4 * c + i : 15);
         B[4] = WX(k, 4, 4 * c + w);  // group 15 (wave 3, chunk 3) is a zero block
@@ -314,8 +389,23 @@ __global__ __launch_bounds__(DG_THREADS) void k_conv_dg(DgArgs a) {
   ACC = MFMA32(A.y, Bv.y, ACC);                                                                                              \
   ACC = MFMA32(A.z, Bv.z, ACC);                                                                                              \
   ACC = MFMA32(A.w, Bv.w, ACC)
-      auto run_x = [&](const float4 (&B)[5], int c) {
+#define DG_M3(ACC, AH_, AL_, BH_, BL_)                                                                                         \
+  ACC = MFMA32H(AL_, BH_, ACC);                                                                                              \
+  ACC = MFMA32H(AH_, BL_, ACC);                                                                                              \
+  ACC = MFMA32H(AH_, BH_, ACC)
+      auto run_x = [&](const float4 (&B)[6], int c) {
         if (dbg_nomfma) return;
+        if constexpr (H) {
+          const float4 h0 = LDF(Xa + 32 * c), l0 = LDF(Xa + 32 * c + 4), h1 = LDF(Xa + 32 * c + 16), l1 = LDF(Xa + 32 * c + 20);
+          DG_SB();
+          DG_M3(accM, h0, l0, B[0], B[1]);
+          DG_M3(accM, h1, l1, B[2], B[3]);
+          if ((w >> 1) == (c & 1)) {  // this wave's group of scalar tile 4: the (w & 1)-th group of the chunk
+            if (w & 1) { DG_M3(acc4, h1, l1, B[4], B[5]); }
+            else { DG_M3(acc4, h0, l0, B[4], B[5]); }
+          }
+          return;
+        }
         const bool last = (c == 3);  // chunk 3 holds groups 12..14 only
         float4 a0 = *reinterpret_cast<const float4*>(Xa + 8 * (4 * c));
         float4 a1 = *reinterpret_cast<const float4*>(Xa + 8 * (4 * c + 1));
@@ -336,14 +426,40 @@ __global__ __launch_bounds__(DG_THREADS) void k_conv_dg(DgArgs a) {
           DG_M4(acc4, a1, B[4]);
         }
       };
-      auto load_d = [&](float4 (&B)[5], int k) {
+      auto load_d = [&](float4 (&B)[6], int k) {
         if (dbg_noweights) return;
+        if constexpr (H) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) B[i] = WH(k, 24 + i);
+          if (w < 2) { B[4] = WH(k, 28); B[5] = WH(k, 29); }  // scalar tile 4: group w
+          return;
+        }
 #pragma unroll
         for (int i = 0; i < 4; ++i) B[i] = WD(k, w, i);
         B[4] = WD(k, 4, w);
       };
-      auto run_d = [&](const float4 (&B)[5]) {
+      auto run_d = [&](const float4 (&B)[6]) {
         if (dbg_nomfma) return;
+        if constexpr (H) {
+          // (the dot-input tile is fp32: 8 consecutive inputs of a row = two 16-byte reads, split here into hi / lo halves)
+          auto split8 = [&](float4 f0, float4 f1, float4& hi, float4& lo) {
+            const unsigned p0 = cvt_pk_f16(f0.x, f0.y), p1 = cvt_pk_f16(f0.z, f0.w), p2 = cvt_pk_f16(f1.x, f1.y), p3 = cvt_pk_f16(f1.z, f1.w);
+            const unsigned q0 = cvt_pk_f16(resid_lo(f0.x, p0), resid_hi(f0.y, p0)), q1 = cvt_pk_f16(resid_lo(f0.z, p1), resid_hi(f0.w, p1)),
+                           q2 = cvt_pk_f16(resid_lo(f1.x, p2), resid_hi(f1.y, p2)), q3 = cvt_pk_f16(resid_lo(f1.z, p3), resid_hi(f1.w, p3));
+            hi = make_float4(__uint_as_float(p0), __uint_as_float(p1), __uint_as_float(p2), __uint_as_float(p3));
+            lo = make_float4(__uint_as_float(q0), __uint_as_float(q1), __uint_as_float(q2), __uint_as_float(q3));
+          };
+          const float4 f00 = LDF(Da), f01 = LDF(Da + 4), f10 = LDF(Da + 16), f11 = LDF(Da + 20);
+          float4 h0, l0, h1, l1;
+          split8(f00, f01, h0, l0);
+          split8(f10, f11, h1, l1);
+          DG_SB();
+          DG_M3(accM, h0, l0, B[0], B[1]);
+          DG_M3(accM, h1, l1, B[2], B[3]);
+          if (w == 0) { DG_M3(acc4, h0, l0, B[4], B[5]); }
+          else if (w == 1) { DG_M3(acc4, h1, l1, B[4], B[5]); }
+          return;
+        }
         float4 a0 = *reinterpret_cast<const float4*>(Da);
         float4 a1 = *reinterpret_cast<const float4*>(Da + 8);
         DG_SB();
@@ -359,13 +475,38 @@ __global__ __launch_bounds__(DG_THREADS) void k_conv_dg(DgArgs a) {
         DG_M4(accM, a1, B[3]);
         DG_M4(acc4, a0, B[4]);
       };
-      auto load_v = [&](float4 (&B)[5], int k) {
+      auto load_v = [&](float4 (&B)[6], int k) {
         if (dbg_noweights) return;
+        if constexpr (H) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) B[i] = WH(k, 30 + i);
+          return;
+        }
 #pragma unroll
         for (int i = 0; i < 4; ++i) B[i] = WV(k, ch, i);
       };
-      auto run_v = [&](const float4 (&B)[5]) {
+      auto run_v = [&](const float4 (&B)[6]) {
         if (dbg_nomfma) return;
+        if constexpr (H) {
+#pragma unroll
+          for (int g = 0; g < 2; ++g) {  // (the three planes are independent accumulators: their MFMAs alternate)
+            float4 fh[3], fl[3];
+#pragma unroll
+            for (int m = 0; m < 3; ++m) {
+              fh[m] = LDF(Va + m * 32 * DG_YV + 32 * g);
+              fl[m] = LDF(Va + m * 32 * DG_YV + 32 * g + 4);
+            }
+            DG_SB();
+#pragma unroll
+            for (int m = 0; m < 3; ++m) accP[m] = MFMA16H(fl[m], B[2 * g], accP[m]);
+#pragma unroll
+            for (int m = 0; m < 3; ++m) accP[m] = MFMA16H(fh[m], B[2 * g + 1], accP[m]);
+#pragma unroll
+            for (int m = 0; m < 3; ++m) accP[m] = MFMA16H(fh[m], B[2 * g], accP[m]);
+            DG_SB();
+          }
+          return;
+        }
         float4 av[2][3];
 #pragma unroll
         for (int m = 0; m < 3; ++m) av[0][m] = *reinterpret_cast<const float4*>(Va + m * 32 * DG_YV);
@@ -428,6 +569,8 @@ __global__ __launch_bounds__(DG_THREADS) void k_conv_dg(DgArgs a) {
             if (w < 3) a.partial1[(((size_t)slab * a.n_pad + n0 + row) * 3 + w) * 32 + r] = 0.f;
           }
         }
+        if constexpr (H)
+          for (int i = tid; i < a.RS; i += DG_THREADS) rowmax[i] = 0u;
         __syncthreads();
         continue;
       }
@@ -449,7 +592,7 @@ __global__ __launch_bounds__(DG_THREADS) void k_conv_dg(DgArgs a) {
         for (int it = 0; it < nk; ++it) {
           const int k = k_of(it), kn = k_of(it + 1);
           DSTAMP(ta);
-          Xa = ((it & 1) ? X1 : Xt) + r * DG_XS0 + 4 * hh;
+          Xa = ((it & 1) ? X1 : Xt) + r * XS0 + AH * hh;
           if (it + 2 < nk) load_tslots(k_of(it + 2));
           run_d(B0); load_x(B0, k, 0);
           run_v(B1); load_x(B1, k, 1);
@@ -491,9 +634,9 @@ __global__ __launch_bounds__(DG_THREADS) void k_conv_dg(DgArgs a) {
           const int k = k_of(it), kn = k_of(it + 1);
           DSTAMP(ta);
           const int bo = (it & 1) * DG_ABUF;
-          Xa = Xt + bo + r * DG_XS0 + 4 * hh;
-          Da = Yd + bo + r * DG_YD + 4 * hh;
-          Va = Yv + bo + (16 * rh + r16) * DG_YV + 4 * kq;
+          Xa = Xt + bo + r * XS0 + AH * hh;
+          Da = Yd + bo + r * DG_YD + AH * hh;
+          Va = Yv + bo + (16 * rh + r16) * DG_YV + AH * kq;
           if (it + 2 < nk) load_tslots(k_of(it + 2));
           run_x(B0, 0); load_x(B0, k, 2);
           run_x(B1, 1); load_x(B1, k, 3);
@@ -505,6 +648,15 @@ __global__ __launch_bounds__(DG_THREADS) void k_conv_dg(DgArgs a) {
           DSTAMP(tb); DACC(1, tb, ta);
           DTRACE(1, tb);
           LDS_BARRIER();                  // A(k+1) complete; nobody reads A(k) or T(k+1) any more
+#ifdef JAMUN_DUMP
+          if (a.dump && blockIdx.x < 32 && sgi == 0 && it == a.dbg) {
+            const float* src = Xt + ((it + 1) & 1) * DG_ABUF;
+            float* dst = a.dump + (size_t)blockIdx.x * 12288;
+            for (int idx = tid; idx < DG_ABUF; idx += 256) dst[idx] = src[idx];
+            if (tid < 32) dst[DG_ABUF + tid] = H ? sc_lds[tid] : 1.f;
+            if (tid == 0) { dst[DG_ABUF + 32] = (float)k_of(it + 1); dst[DG_ABUF + 33] = (float)n0; dst[DG_ABUF + 34] = (float)n_dst; dst[DG_ABUF + 35] = (float)nk; }
+          }
+#endif
           DSTAMP(ta); DACC(2, ta, tb);
           DTRACE(2, ta);
           if (it + 2 < nk) store_tslots(k_of(it + 2));
@@ -524,7 +676,7 @@ __global__ __launch_bounds__(DG_THREADS) void k_conv_dg(DgArgs a) {
         for (int it = 0; it < nk; ++it) {
           const int kn = k_of(it + 1);
           DSTAMP(ta);
-          if (it + 1 < nk && !(a.dbg & 16)) {
+          if (it + 1 < nk && !dbg_notouch) {
             // The matrix waves idle while Y(k) is formed: they pull T(k+1) of the span (HBM / Infinity Cache: the T buffer of
             // a large batch is tens of MB) into L2, where the forming waves' staging loads find it after the barrier.
             const float* __restrict__ tk = a.T + ((size_t)kn * a.n_atoms + s_lo) * 32;
@@ -552,7 +704,7 @@ __global__ __launch_bounds__(DG_THREADS) void k_conv_dg(DgArgs a) {
         for (int it = 0; it < nk; ++it) {
           const int k = k_of(it), kn = k_of(it + 1);
           DSTAMP(ta);
-          Xa = ((it & 1) ? Yd : Xt) + r * DG_XS0 + 4 * hh;
+          Xa = ((it & 1) ? Yd : Xt) + r * XS0 + AH * hh;
           run_x(B0, 0); load_x(B0, k, 2);
           run_x(B1, 1); load_x(B1, k, 3);
           run_x(B0, 2); load_x(B0, kn, 0);
@@ -595,6 +747,20 @@ __global__ __launch_bounds__(DG_THREADS) void k_conv_dg(DgArgs a) {
         }
       }
       DSTAMP(ta);
+      if constexpr (H) {  // back to true scale: row i carries 2^(sA_i + sB)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+          const float sI = isc_lds[(q & 3) + 8 * (q >> 2) + 4 * hh];
+          accM[q] *= sI;
+          acc4[q] *= sI;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float sI = isc_lds[16 * rh + 4 * kq + q];
+#pragma unroll
+          for (int m = 0; m < 3; ++m) accP[m][q] *= sI;
+        }
+      }
       // ---- segment end: accumulators -> LDS staging tile (the A tiles are dead after the last barrier)
 #pragma unroll
       for (int q = 0; q < 16; ++q) {
@@ -613,12 +779,13 @@ __global__ __launch_bounds__(DG_THREADS) void k_conv_dg(DgArgs a) {
       // whole MFMA chain first (fp32 MFMA and VALU of a SIMD exclude each other) and the two forming waves then finish one
       // after the other, bound by LDS latency; with priority their VALU instructions go first and the MFMAs fill their
       // latency gaps (measured timeline: matrix waves done at 10.2k cycles of a 15.1k step, forming waves at 11.7k .. 13.9k).
-      if (!(a.dbg & 32)) __builtin_amdgcn_s_setprio(3);
+      if (!dbg_noprio) __builtin_amdgcn_s_setprio(3);
       const int fw = wave - 4;                    // forming wave index
       const int h = lane >> 5, u = lane & 31;
       const int xs_lds = lds_address(xs);  // LDS address of the source rows
       // per destination pair dp: this lane's edge slots t = u (page 0) and u + 32 (page 1) of destination i = 4 fw + 2 dp + h
       float evx[DG_NDP][2], evy[DG_NDP][2], evz[DG_NDP][2];
+      float scA[DG_NDP], iscA[DG_NDP];  // H: 2^sA_i of this lane's destination and its inverse
       int hidx[DG_NDP][2];
       int hidx2[DG_NDP];  // page 0 only: slot of the bonded edge merged into this lane's radial edge (same source), or -1
       int P[DG_NDP];
@@ -629,6 +796,7 @@ __global__ __launch_bounds__(DG_THREADS) void k_conv_dg(DgArgs a) {
         const int dg = deg_lds[i];
         hidx2[dp] = -1;
         int sj0 = 0;
+        float xm = 0.f;  // H: largest |x| over the source rows of this lane's edges
 #pragma unroll
         for (int pg = 0; pg < 2; ++pg) {
           evx[dp][pg] = evy[dp][pg] = evz[dp][pg] = 0.f;
@@ -646,9 +814,24 @@ __global__ __launch_bounds__(DG_THREADS) void k_conv_dg(DgArgs a) {
               evx[dp][pg] = ge.x; evy[dp][pg] = ge.y; evz[dp][pg] = ge.z;
               hidx[dp][pg] = slot;
               jofs = jl * DG_XST * 4;  // byte offset of the source row inside xs
+              if constexpr (H) xm = fmaxf(xm, __uint_as_float(rowmax[jl]));
             }
           }
           if (t < PMAX) tabJ[i * PMAX + t] = jofs + xs_lds;
+        }
+        scA[dp] = iscA[dp] = 1.f;
+        if constexpr (H) {
+          // |A rows of destination i| <= sum_e |c_e| max |zeta_e| <= deg_i * 2 max|h~| * max|x| (dot and cross products of a unit
+          // vector with x1: <= sqrt(3) max|x|): scaled below 2^14, a factor 4 inside the f16 range
+#pragma unroll
+          for (int off = 16; off >= 1; off >>= 1) xm = fmaxf(xm, __shfl_xor(xm, off, 32));
+          const float bound = (float)dg * a.hmax2 * xm;
+          int sA = 0;
+          if (bound > 0.f) sA = 14 - ((int)((__float_as_uint(bound) >> 23) & 0xffu) - 126);  // bound < 2^(exponent field - 126)
+          sA = max(-60, min(60, sA));
+          scA[dp] = pow2f(sA);
+          iscA[dp] = pow2f(-sA);
+          if (u == 0) { sc_lds[i] = scA[dp]; isc_lds[i] = pow2f(-sA - a.sB); }
         }
         if (!two_pages) {
           // A bonded pair inside the cutoff appears twice in the edge table (radial edge + bonded edge, same source and unit
@@ -684,6 +867,8 @@ __global__ __launch_bounds__(DG_THREADS) void k_conv_dg(DgArgs a) {
 #pragma unroll
         for (int pg = 0; pg < 2; ++pg) any_edge |= hidx[dp][pg] >= 0;
       if (a.row_blocks && !__syncthreads_or(any_edge)) {  // (only batches with row-block tiles pay for the vote)
+        if constexpr (H)
+          for (int i = tid; i < a.RS; i += DG_THREADS) rowmax[i] = 0u;
         __syncthreads();
         continue;
       }
@@ -712,6 +897,7 @@ __global__ __launch_bounds__(DG_THREADS) void k_conv_dg(DgArgs a) {
             const int t = u + 32 * pg;
             float c = hidx[dp][pg] >= 0 ? hv[dp][pg] : 0.f;
             if (pg == 0 && hidx2[dp] >= 0) c += hv2[dp];  // radial + bonded edge of the same pair
+            if constexpr (H) c *= scA[dp];
             if (t < PMAX) tabA[i * PMAX + t] = make_float4(c, c * evx[dp][pg], c * evy[dp][pg], c * evz[dp][pg]);
           }
         }
@@ -726,8 +912,59 @@ __global__ __launch_bounds__(DG_THREADS) void k_conv_dg(DgArgs a) {
       // saturate it, so the arithmetic is written as PACKED FMAs (v_pk_fma_f32: two products per lane per instruction) on the
       // register pairs the loads deliver: coefficients (c, c vx | c vy, c vz), row fragment (x, T | y, z) — 15 products per edge
       // in 7 packed + 1 scalar FMA with no sign flips inside the loop (negative terms have their own accumulators), and one address add per edge and phase.
-      auto pk = [](f32x2 a2, f32x2 b2, f32x2 c2) -> f32x2 { return __builtin_elementwise_fma(a2, b2, c2); };
+// H: plain v_fma_f32, NOT v_pk_fma_f32.  Measured on MI355X (profiles/microbench/README.md, "packed fp32 beside f16 MFMAs"): packed
+      // fp32 FMAs of a forming wave occasionally return wrong values in lanes 48..63 while another wave of the SIMD runs
+      // v_mfma_f32_*_f16 (about one forward in two had one wrong A-tile row; never with plain FMAs, never beside fp32 MFMAs, which
+      // exclude VALU work in time) — and they would not overlap with the MFMAs anyway (valu_rate.hip: zero progress while the
+      // matrix pipe is busy, against one plain VALU instruction per ~5.6 cycles).
+      auto pk = [](f32x2 a2, f32x2 b2, f32x2 c2) -> f32x2 {
+        if constexpr (H) return f32x2{fmaf(a2.x, b2.x, c2.x), fmaf(a2.y, b2.y, c2.y)};
+        else return __builtin_elementwise_fma(a2, b2, c2);
+      };
+      auto pkbhi = [](f32x2 a2, f32x2 b2, f32x2 c2) -> f32x2 {  // (a.x b.y + c.x, a.y b.y + c.y)
+        if constexpr (H) return f32x2{fmaf(a2.x, b2.y, c2.x), fmaf(a2.y, b2.y, c2.y)};
+        else return pk_bhi(a2, b2, c2);
+      };
+      auto pkbswap = [](f32x2 a2, f32x2 b2, f32x2 c2) -> f32x2 {  // (a.x b.y + c.x, a.y b.x + c.y)
+        if constexpr (H) return f32x2{fmaf(a2.x, b2.y, c2.x), fmaf(a2.y, b2.x, c2.y)};
+        else return pk_bswap(a2, b2, c2);
+      };
       const int offx = u * 16, offy = OFFY + u * 16;
+      // A-tile stores.  fp32: as they are.  H: every value is split hi = rne16(v), lo = rne16(v - hi) (two values per v_cvt_pk) and
+      // written to its chunk of [8 hi | 8 lo] halves
+      auto store_x = [&](float* __restrict__ Xo, int i, f32x2 a01, f32x2 a23) {
+        if (u < 30) {
+          if constexpr (H) {
+            const unsigned p01 = cvt_pk_f16(a01.x, a01.y), p23 = cvt_pk_f16(a23.x, a23.y);
+            const unsigned q01 = cvt_pk_f16(resid_lo(a01.x, p01), resid_hi(a01.y, p01)), q23 = cvt_pk_f16(resid_lo(a23.x, p23), resid_hi(a23.y, p23));
+            float* __restrict__ d = Xo + i * XS0 + 8 * (u >> 1) + 2 * (u & 1);  // chunk u / 2; this lane's 4 halves of its hi and lo parts
+            *reinterpret_cast<uint2*>(d) = make_uint2(p01, p23);
+            *reinterpret_cast<uint2*>(d + 4) = make_uint2(q01, q23);
+          } else {
+            *reinterpret_cast<float4*>(Xo + i * XS0 + 4 * u) = make_float4(a01.x, a01.y, a23.x, a23.y);
+          }
+        }
+      };
+      auto store_y = [&](float* __restrict__ Ydo, float* __restrict__ Yvo, int i, float dv, float x1x, float x1y, float x1z, float cx, float cy, float cz) {
+        if constexpr (H) {
+          // dot inputs: fp32 as they are (the matrix waves split their fragments of this small tile themselves); vector planes:
+          // input order kappa = 2 u + {x1, cross} (the weights are packed in the same order), so that lane u owns ONE dword of
+          // the hi part and one of the lo part of chunk u / 4 — whole-dword stores only
+          Ydo[i * DG_YD + u] = dv;
+          unsigned* __restrict__ yv = reinterpret_cast<unsigned*>(Yvo) + i * DG_YV + 8 * (u >> 2) + (u & 3);
+          const float xs_[3] = {x1x, x1y, x1z}, cs_[3] = {cx, cy, cz};
+#pragma unroll
+          for (int m = 0; m < 3; ++m) {
+            const unsigned ph = cvt_pk_f16(xs_[m], cs_[m]), pl = cvt_pk_f16(resid_lo(xs_[m], ph), resid_hi(cs_[m], ph));
+            yv[m * 32 * DG_YV] = ph;
+            yv[m * 32 * DG_YV + 4] = pl;
+          }
+        } else {
+          Ydo[i * DG_YD + u] = dv;
+          Yvo[(0 * 32 + i) * DG_YV + u] = x1x; Yvo[(1 * 32 + i) * DG_YV + u] = x1y; Yvo[(2 * 32 + i) * DG_YV + u] = x1z;
+          Yvo[(0 * 32 + i) * DG_YV + 32 + u] = cx; Yvo[(1 * 32 + i) * DG_YV + 32 + u] = cy; Yvo[(2 * 32 + i) * DG_YV + 32 + u] = cz;
+        }
+      };
       // X(k): scalar inputs, lanes u < 30 own channels 4u..4u+3 (lanes 30, 31 compute on x1 data and are not stored)
       auto form_x = [&](float* __restrict__ Xo) {
 #pragma unroll
@@ -772,7 +1009,7 @@ __global__ __launch_bounds__(DG_THREADS) void k_conv_dg(DgArgs a) {
               }
             }
           }
-          if (u < 30) *reinterpret_cast<float4*>(Xo + i * DG_XS0 + 4 * u) = make_float4(ax01.x, ax01.y, ax23.x, ax23.y);
+          store_x(Xo, i, ax01, ax23);
         }
       };
       // Y(k): vector inputs (lane u = channel u) + the T term (lane u = output channel w')
@@ -809,10 +1046,10 @@ __global__ __launch_bounds__(DG_THREADS) void k_conv_dg(DgArgs a) {
               const float4 cf = c[q], xv = x[q];  // cf = (c, cx | cy, cz), xv = (x, T | y, z)
               p_a1x_o0 = pk(f32x2{cf.x, cf.y}, f32x2{xv.x, xv.y}, p_a1x_o0);    // (c x, cx T)
               p_a1yz = pk(f32x2{cf.x, cf.x}, f32x2{xv.z, xv.w}, p_a1yz);        // (c y, c z)
-              p_o12 = pk_bhi(f32x2{cf.z, cf.w}, f32x2{xv.x, xv.y}, p_o12);          // (cy T, cz T)
+              p_o12 = pkbhi(f32x2{cf.z, cf.w}, f32x2{xv.x, xv.y}, p_o12);          // (cy T, cz T)
               n3 = pk(f32x2{cf.y, cf.y}, f32x2{xv.z, xv.w}, n3);                // (cx y, cx z)
               n5 = pk(f32x2{cf.z, cf.w}, f32x2{xv.x, xv.x}, n5);                // (cy x, cz x)
-              n7 = pk_bswap(f32x2{cf.z, cf.w}, f32x2{xv.z, xv.w}, n7);                // (cy z, cz y)
+              n7 = pkbswap(f32x2{cf.z, cf.w}, f32x2{xv.z, xv.w}, n7);                // (cy z, cz y)
               p_d = pk(f32x2{cf.z, cf.w}, f32x2{xv.z, xv.w}, p_d);              // (cy y, cz z)
               d2 = fmaf(cf.y, xv.x, d2);                                          // cx x
             }
@@ -829,10 +1066,8 @@ __global__ __launch_bounds__(DG_THREADS) void k_conv_dg(DgArgs a) {
             }
           }
           O[dp][0] = p_a1x_o0.y; O[dp][1] = p_o12.x; O[dp][2] = p_o12.y;
-          Yd[i * DG_YD + u] = (p_d.x + p_d.y) + d2;
-          Yv[(0 * 32 + i) * DG_YV + u] = p_a1x_o0.x; Yv[(1 * 32 + i) * DG_YV + u] = p_a1yz.x; Yv[(2 * 32 + i) * DG_YV + u] = p_a1yz.y;
           // (x1 x v)[m] = x1[m+1] v[m+2] - x1[m+2] v[m+1]
-          Yv[(0 * 32 + i) * DG_YV + 32 + u] = n7.y - n7.x; Yv[(1 * 32 + i) * DG_YV + 32 + u] = n3.y - n5.y; Yv[(2 * 32 + i) * DG_YV + 32 + u] = n5.x - n3.x;
+          store_y(Yd, Yv, i, (p_d.x + p_d.y) + d2, p_a1x_o0.x, p_a1yz.x, p_a1yz.y, n7.y - n7.x, n3.y - n5.y, n5.x - n3.x);
         }
       };
 
@@ -876,10 +1111,10 @@ __global__ __launch_bounds__(DG_THREADS) void k_conv_dg(DgArgs a) {
               const float4 cf = c[q], xv = x[q];
               p_a1x_o0 = pk(f32x2{cf.x, cf.y}, f32x2{xv.x, xv.y}, p_a1x_o0);    // (c x, cx T)
               p_a1yz = pk(f32x2{cf.x, cf.x}, f32x2{xv.z, xv.w}, p_a1yz);        // (c y, c z)
-              p_o12 = pk_bhi(f32x2{cf.z, cf.w}, f32x2{xv.x, xv.y}, p_o12);          // (cy T, cz T)
+              p_o12 = pkbhi(f32x2{cf.z, cf.w}, f32x2{xv.x, xv.y}, p_o12);          // (cy T, cz T)
               n3 = pk(f32x2{cf.y, cf.y}, f32x2{xv.z, xv.w}, n3);                // (cx y, cx z)
               n5 = pk(f32x2{cf.z, cf.w}, f32x2{xv.x, xv.x}, n5);                // (cy x, cz x)
-              n7 = pk_bswap(f32x2{cf.z, cf.w}, f32x2{xv.z, xv.w}, n7);                // (cy z, cz y)
+              n7 = pkbswap(f32x2{cf.z, cf.w}, f32x2{xv.z, xv.w}, n7);                // (cy z, cz y)
               p_d = pk(f32x2{cf.z, cf.w}, f32x2{xv.z, xv.w}, p_d);              // (cy y, cz z)
               d2 = fmaf(cf.y, xv.x, d2);                                          // cx x
             }
@@ -904,16 +1139,14 @@ __global__ __launch_bounds__(DG_THREADS) void k_conv_dg(DgArgs a) {
             }
           }
           O[dp][0] = p_a1x_o0.y; O[dp][1] = p_o12.x; O[dp][2] = p_o12.y;
-          if (u < 30) *reinterpret_cast<float4*>(Xo + i * DG_XS0 + 4 * u) = make_float4(ax01.x, ax01.y, ax23.x, ax23.y);
+          store_x(Xo, i, ax01, ax23);
           if constexpr (SPH) {
             if (dp == 0 && mid) {
               DSTAMP(tb); DTRACE(1, tb);
               LDS_BARRIER();  // the matrix waves have finished Y(k) x W: the single Y tile may be rewritten
             }
           }
-          Ydo[i * DG_YD + u] = (p_d.x + p_d.y) + d2;
-          Yvo[(0 * 32 + i) * DG_YV + u] = p_a1x_o0.x; Yvo[(1 * 32 + i) * DG_YV + u] = p_a1yz.x; Yvo[(2 * 32 + i) * DG_YV + u] = p_a1yz.y;
-          Yvo[(0 * 32 + i) * DG_YV + 32 + u] = n7.y - n7.x; Yvo[(1 * 32 + i) * DG_YV + 32 + u] = n3.y - n5.y; Yvo[(2 * 32 + i) * DG_YV + 32 + u] = n5.x - n3.x;
+          store_y(Ydo, Yvo, i, (p_d.x + p_d.y) + d2, p_a1x_o0.x, p_a1yz.x, p_a1yz.y, n7.y - n7.x, n3.y - n5.y, n5.x - n3.x);
         }
       };
 
@@ -959,7 +1192,7 @@ __global__ __launch_bounds__(DG_THREADS) void k_conv_dg(DgArgs a) {
           LDS_BARRIER();
           DSTAMP(ta); DACC(2, ta, tb);
           if (it + 1 < nk) {              // (the matrix waves contract Y(k) meanwhile)
-            if (!(a.dbg & 8)) stage_t(k_of(it + 1));        // (first: its wait would otherwise cover the h loads as well)
+            if (!dbg_nostage) stage_t(k_of(it + 1));        // (first: its wait would otherwise cover the h loads as well)
             write_tab();
             load_h(k_of(it + 2));
           }
@@ -1021,7 +1254,7 @@ __global__ __launch_bounds__(DG_THREADS) void k_conv_dg(DgArgs a) {
       for (int dp = 0; dp < DG_NDP; ++dp) {
         const int i = 2 * DG_NDP * fw + 2 * dp + h;
 #pragma unroll
-        for (int m = 0; m < 3; ++m) OL[i * 96 + m * 32 + u] = O[dp][m];
+        for (int m = 0; m < 3; ++m) OL[i * 96 + m * 32 + u] = H ? O[dp][m] * iscA[dp] : O[dp][m];
       }
       DSTAMP(tb); DACC(5, tb, ta);
     }
@@ -1049,6 +1282,8 @@ __global__ __launch_bounds__(DG_THREADS) void k_conv_dg(DgArgs a) {
         if (row < n_dst) *reinterpret_cast<float4*>(p1 + row * 96 + 4 * c4) = make_float4(pv.x + ov.x, pv.y + ov.y, pv.z + ov.z, pv.w + ov.w);
       }
     }
+    if constexpr (H)
+      for (int i = tid; i < a.RS; i += DG_THREADS) rowmax[i] = 0u;  // (its readers finished in the segment prologue)
     LDS_BARRIER();  // the next segment rewrites the tiles
   }
 #ifdef JAMUN_STAMP
@@ -1149,24 +1384,30 @@ void launch_tprod(const float* x, int XS, int n_atoms, int n_k, const float4* wt
   hipLaunchKernelGGL(k_tprod, dim3((tiles * kg + TP_WAVES - 1) / TP_WAVES), dim3(64 * TP_WAVES), 0, st, x, XS, n_atoms, n_k, kg, wt, T);
 }
 
-size_t conv_dg_lds_bytes(int rs, int pmax, int mode) { return sizeof(float) * ((dg_lds_floats(rs, pmax, mode) + 3) & ~(size_t)3); }
+size_t conv_dg_lds_bytes(int rs, int pmax, int mode, int emu) { return sizeof(float) * ((dg_lds_floats(rs, pmax, mode, emu != 0) + 3) & ~(size_t)3); }
 
 int launch_conv_dg(const DgArgs& a, int grid, hipStream_t st) {
-  const size_t smem = conv_dg_lds_bytes(a.RS, a.PMAX, a.alt);
+  const size_t smem = conv_dg_lds_bytes(a.RS, a.PMAX, a.alt, a.emu);
   if (smem > JAMUN_MAX_DYN_LDS) return -2;
   if (a.RS > (a.alt == 1 ? DG_RS_MAX_ALT : DG_RS_MAX_RES) || a.XS != 216 || a.nt0 != 5) return -1;
-  if (a.alt == 3) hipLaunchKernelGGL(k_conv_dg<3>, dim3(grid), dim3(DG_THREADS), smem, st, a);
-  else if (a.alt == 1) hipLaunchKernelGGL(k_conv_dg<1>, dim3(grid), dim3(DG_THREADS), smem, st, a);
-  else if (a.alt == 2) hipLaunchKernelGGL(k_conv_dg<2>, dim3(grid), dim3(DG_THREADS), smem, st, a);
-  else hipLaunchKernelGGL(k_conv_dg<0>, dim3(grid), dim3(DG_THREADS), smem, st, a);
+  if (a.emu) {
+    if (a.alt == 3) hipLaunchKernelGGL((k_conv_dg<3, true>), dim3(grid), dim3(DG_THREADS), smem, st, a);
+    else if (a.alt == 1) hipLaunchKernelGGL((k_conv_dg<1, true>), dim3(grid), dim3(DG_THREADS), smem, st, a);
+    else if (a.alt == 2) hipLaunchKernelGGL((k_conv_dg<2, true>), dim3(grid), dim3(DG_THREADS), smem, st, a);
+    else hipLaunchKernelGGL((k_conv_dg<0, true>), dim3(grid), dim3(DG_THREADS), smem, st, a);
+  } else {
+    if (a.alt == 3) hipLaunchKernelGGL((k_conv_dg<3, false>), dim3(grid), dim3(DG_THREADS), smem, st, a);
+    else if (a.alt == 1) hipLaunchKernelGGL((k_conv_dg<1, false>), dim3(grid), dim3(DG_THREADS), smem, st, a);
+    else if (a.alt == 2) hipLaunchKernelGGL((k_conv_dg<2, false>), dim3(grid), dim3(DG_THREADS), smem, st, a);
+    else hipLaunchKernelGGL((k_conv_dg<0, false>), dim3(grid), dim3(DG_THREADS), smem, st, a);
+  }
   return 0;
 }
 
 int conv_dg_set_max_lds() {
-  return (hipFuncSetAttribute((const void*)k_conv_dg<0>, hipFuncAttributeMaxDynamicSharedMemorySize, JAMUN_MAX_DYN_LDS) == hipSuccess &&
-          hipFuncSetAttribute((const void*)k_conv_dg<1>, hipFuncAttributeMaxDynamicSharedMemorySize, JAMUN_MAX_DYN_LDS) == hipSuccess &&
-          hipFuncSetAttribute((const void*)k_conv_dg<2>, hipFuncAttributeMaxDynamicSharedMemorySize, JAMUN_MAX_DYN_LDS) == hipSuccess &&
-          hipFuncSetAttribute((const void*)k_conv_dg<3>, hipFuncAttributeMaxDynamicSharedMemorySize, JAMUN_MAX_DYN_LDS) == hipSuccess)
-             ? 0
-             : -1;
+  const void* fns[8] = {(const void*)k_conv_dg<0, false>, (const void*)k_conv_dg<1, false>, (const void*)k_conv_dg<2, false>, (const void*)k_conv_dg<3, false>,
+                        (const void*)k_conv_dg<0, true>,  (const void*)k_conv_dg<1, true>,  (const void*)k_conv_dg<2, true>,  (const void*)k_conv_dg<3, true>};
+  for (const void* f : fns)
+    if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, JAMUN_MAX_DYN_LDS) != hipSuccess) return -1;
+  return 0;
 }

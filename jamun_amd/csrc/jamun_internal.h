@@ -9,7 +9,7 @@
 // conv kernel geometry (jamun_conv.hip)
 #define JAMUN_KSUB0 5  // hidden units per k-subgroup, scalar-output rows (subgroups of 4 or 5)
 #define JAMUN_KSUB1 2  // hidden units per k-subgroup, vector-output rows (3 planes per workgroup; subgroups of 1 or 2)
-#define JAMUN_MAX_DYN_LDS (159 * 1024)  // dynamic LDS per workgroup: 160 KiB minus room for the kernels' few static words
+#define JAMUN_MAX_DYN_LDS (160 * 1024 - 256)  // dynamic LDS per workgroup: 160 KiB minus the kernels' static words (at most 256 B: the vote of __syncthreads_or)
 #define JAMUN_FUSED_WAVES 8   // waves per workgroup of the fused conv kernel; every wave owns at most one output tile
 #define JAMUN_FUSED_MAX_B 6   // stage-B entries (formed tiles consumed) per owner wave
 #define JAMUN_MAX_BATCH 128  // edge batches (of 4) per wave: 8 atoms x ceil(S / 4); limits the edge stride S to 64
@@ -84,12 +84,25 @@ struct DgArgs {
   int max_segs, row_blocks, nt0;
   int alt;  // kernel mode: 0 two-phase resident, 1 alternating residency of the source rows (large molecules), 2 single phase (small spans)
   int dbg;  // tuning aid (JAMUN_DG_DBG): 1 forming waves skip their edge loops, 2 matrix waves skip their MFMAs
+  float* dump;  // diagnostic builds (-DJAMUN_DUMP): workgroup 0 copies the A tiles of its second hidden unit here
   // weights, 64-lane x float4 blocks (one block = the B operand of 4 consecutive MFMAs):
   const float4* wx;  // [k][5 output tiles][16 groups (15 = zeros)]   scalar inputs -> scalar rows   (32x32x2: u = 8g + 4hh + st)
   const float4* wd;  // [k][5][4]                                      dot(x1, v)    -> scalar rows
   const float4* wv;  // [k][2 column halves][4]   x1 | cross -> vector rows                          (16x16x4: kappa = 16g + 4kq + st)
   const float* T;    // [k][n_atoms][32]  T_k[j][w'] = sum_u x0_j[u] W[(k,u)][w'] from the pre-pass k_tprod (scalar inputs -> vector rows)
   int n_atoms;
+  // f16x3 contraction (emu = 1): every fp32 operand is split into two f16 terms (hi + lo, 22+ bits) and a product is three
+  // v_mfma_f32_*_f16 (hi hi + hi lo + lo hi, fp32 accumulate).  Weights are split on the host after scaling by 2^sB; 64-lane x
+  // 16-byte blocks (8 halves = one lane's B fragment of one 32x32x16 / 16x16x32 MFMA), planes p = 0 (hi), 1 (lo):
+  int emu;
+  // wh [k][matrix wave w][34 blocks] in the wave's consumption order:
+  //   6 c + {0..3}  scalar inputs, chunk c = 0..3: own output tile w, groups 2c and 2c+1 of 16 inputs (hi, lo, hi, lo; inputs 120..127 zeros)
+  //   6 c + {4, 5}  the wave's group w + 4 (c >> 1) of output tile 4 when (c & 1) == (w >> 1) (else unused)
+  //   24..27 dot(x1, v) inputs, own tile, groups 0, 1;  28, 29 output tile 4, group w (w < 2)
+  //   30..33 x1 | cross inputs of the vector planes (16x16x32: kappa = 32 G + 8 kq + j), column half w >> 1, groups 0, 1
+  const float4* wh;
+  int sB;             // weights were scaled by 2^sB before the split
+  float hmax2;        // 2 * upper bound of |h~| over the layer (static, from the radial MLP's first layer): bounds the A tiles
   float* partial0;   // [slab][n_pad][nt0*32]
   float* partial1;   // [slab][n_pad][3][32]
 };
@@ -211,7 +224,7 @@ int launch_conv_dg(const DgArgs& a, int grid, hipStream_t st);
 int conv_dg_set_max_lds();
 void conv_dg_print_stamps();
 void conv_initv_print_stamps();
-size_t conv_dg_lds_bytes(int rs, int pmax, int mode);
+size_t conv_dg_lds_bytes(int rs, int pmax, int mode, int emu);
 void launch_tprod(const float* x, int XS, int n_atoms, int n_k, const float4* wt, float* T, hipStream_t st);
 int launch_conv_init(const InitArgs& a, int grid, hipStream_t st);
 int launch_conv_initv(const InitVArgs& a, int grid, hipStream_t st);
