@@ -202,7 +202,7 @@ __global__ __launch_bounds__(DG_THREADS) void k_conv_dg(DgArgs a) {
   const int wave = RFL(tid0 >> 6);
   const bool is_mat = wave < 4;
   const int PMAX = a.PMAX;
-#ifdef JAMUN_STAMP  // timing experiments (JAMUN_DG_DBG) exist in the diagnostic build only
+#if defined(JAMUN_STAMP) || defined(JAMUN_DGDBG)  // timing experiments (JAMUN_DG_DBG) exist in the diagnostic builds only
   const bool dbg_noform = a.dbg & 1, dbg_nomfma = a.dbg & 2, dbg_noweights = a.dbg & 4, dbg_notouch = a.dbg & 16, dbg_noprio = a.dbg & 32, dbg_nostage = a.dbg & 8;
 #else
   constexpr bool dbg_noform = false, dbg_nomfma = false, dbg_noweights = false, dbg_notouch = false, dbg_noprio = false, dbg_nostage = false;
@@ -1079,6 +1079,10 @@ __global__ __launch_bounds__(DG_THREADS) void k_conv_dg(DgArgs a) {
 #pragma unroll
         for (int dp = 0; dp < DG_NDP; ++dp) {
           const int i = 2 * DG_NDP * fw + 2 * dp + h;
+#if defined(JAMUN_STAMP) || defined(JAMUN_DGDBG)
+          if (a.dbg & 64) { if ((dp ^ (fw >> 2)) & 1) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(3); }
+          if (a.dbg & 128) { if ((dp ^ (fw >> 2)) & 1) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(1); }
+#endif
           f32x2 ax01 = {0.f, 0.f}, ax23 = {0.f, 0.f};
           f32x2 p_a1x_o0 = {0.f, O[dp][0]}, p_a1yz = {0.f, 0.f}, p_o12 = {O[dp][1], O[dp][2]}, n3 = {0.f, 0.f}, n5 = {0.f, 0.f},
                 n7 = {0.f, 0.f}, p_d = {0.f, 0.f};
@@ -1087,6 +1091,10 @@ __global__ __launch_bounds__(DG_THREADS) void k_conv_dg(DgArgs a) {
           const int* __restrict__ tj = tabJ + i * PMAX;
           const int nb = dbg_noform ? 0 : (P[dp] + DG_U - 1) / DG_U;
           float4 cA[DG_U], cB[DG_U], xA[DG_U], xB[DG_U], z[DG_U];
+#if defined(JAMUN_STAMP) || defined(JAMUN_DGDBG)
+          if (a.dbg & 256)
+            for (int q = 0; q < DG_U; ++q) cA[q] = cB[q] = xA[q] = xB[q] = z[q] = make_float4(1.f + q, 0.5f, 0.25f, 2.f);
+#endif
           int jA[DG_U], jB[DG_U];
           auto ld_j = [&](int (&J)[DG_U], int bb) {
             bb = bb < nb ? bb : nb - 1;
@@ -1095,6 +1103,9 @@ __global__ __launch_bounds__(DG_THREADS) void k_conv_dg(DgArgs a) {
           };
           auto ld_cx = [&](float4 (&c)[DG_U], float4 (&x)[DG_U], const int (&J)[DG_U], int bb) {
             bb = bb < nb ? bb : nb - 1;
+#if defined(JAMUN_STAMP) || defined(JAMUN_DGDBG)
+            if (a.dbg & 256) return;
+#endif
 #pragma unroll
             for (int q = 0; q < DG_U; ++q) {
               c[q] = ta[DG_U * bb + q];                                             // c, c vx | c vy, c vz
@@ -1103,9 +1114,32 @@ __global__ __launch_bounds__(DG_THREADS) void k_conv_dg(DgArgs a) {
           };
           // the scalar channels of a batch are requested at the top of its FMA block and consumed at its end (behind the 32
           // packed FMAs of the vector part): single-buffered, 16 registers instead of 32
-          auto fm = [&](const float4 (&c)[DG_U], const float4 (&x)[DG_U], const int (&J)[DG_U]) {
+          // (H: plain C++ FMAs leave the compiler free to reorder, and it moves the four FMAs that consume z right behind the z
+          // loads — a full LDS round trip exposed per batch; scheduling barriers keep "all loads of the next batch, then the 60
+          // FMAs of the vector part, then the 16 of the scalar part")
+          auto fm = [&](const float4 (&c)[DG_U], const float4 (&x)[DG_U], const int (&J)[DG_U], int (&Jn)[DG_U], int bn) {
+#if defined(JAMUN_STAMP) || defined(JAMUN_DGDBG)
+            if (!(a.dbg & 256))
+#endif
 #pragma unroll
             for (int q = 0; q < DG_U; ++q) z[q] = LDSF4(J[q]);  // x0_j[4u..4u+3]
+            int raw[DG_U];
+            if constexpr (H) {  // row offsets of the batch after next (J itself is dead after the z requests); the lane's column
+                                // offset is added behind the FMAs — adding it here would wait for every read issued above
+              const int bc = bn < nb ? bn : nb - 1;
+#pragma unroll
+              for (int q = 0; q < DG_U; ++q) raw[q] = tj[DG_U * bc + q];
+              __builtin_amdgcn_sched_barrier(0);
+            }
+#if defined(JAMUN_STAMP) || defined(JAMUN_DGDBG)
+            if (a.dbg & 512) {
+#pragma unroll
+              for (int q = 0; q < DG_U; ++q) { d2 += c[q].x + x[q].y + z[q].z; }
+#pragma unroll
+              for (int q = 0; q < DG_U; ++q) Jn[q] = raw[q] + offx;
+              return;
+            }
+#endif
 #pragma unroll
             for (int q = 0; q < DG_U; ++q) {
               const float4 cf = c[q], xv = x[q];
@@ -1118,23 +1152,30 @@ __global__ __launch_bounds__(DG_THREADS) void k_conv_dg(DgArgs a) {
               p_d = pk(f32x2{cf.z, cf.w}, f32x2{xv.z, xv.w}, p_d);              // (cy y, cz z)
               d2 = fmaf(cf.y, xv.x, d2);                                          // cx x
             }
+            if constexpr (H) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int q = 0; q < DG_U; ++q) {
               const f32x2 cc = {c[q].x, c[q].x};
               ax01 = pk(cc, f32x2{z[q].x, z[q].y}, ax01);
               ax23 = pk(cc, f32x2{z[q].z, z[q].w}, ax23);
             }
+            if constexpr (H) {
+              __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+              for (int q = 0; q < DG_U; ++q) Jn[q] = raw[q] + offx;
+              __builtin_amdgcn_sched_barrier(0);
+            }
           };
           if (nb > 0) {
             ld_j(jA, 0); ld_cx(cA, xA, jA, 0); ld_j(jB, 1);
             for (int bb = 0; bb < nb; bb += 2) {
               ld_cx(cB, xB, jB, bb + 1);
-              fm(cA, xA, jA);
-              ld_j(jA, bb + 2);
+              fm(cA, xA, jA, jA, bb + 2);
+              if constexpr (!H) ld_j(jA, bb + 2);
               if (bb + 1 < nb) {
                 ld_cx(cA, xA, jA, bb + 2);
-                fm(cB, xB, jB);
-                ld_j(jB, bb + 3);
+                fm(cB, xB, jB, jB, bb + 3);
+                if constexpr (!H) ld_j(jB, bb + 3);
               }
             }
           }
