@@ -15,8 +15,10 @@ checkpoints are reachable offline):
     cfg3  configs[2]                uncapped-4AA shape: 33 atoms x 256 walkers per GPU (2048 on 8)
     cfg4  configs[3]                MDGen-4AA-like ragged batch: 256 walkers of 17..57 atoms
     cfg5  configs[4]                chignolin size with hydrogens: 166 atoms x 64 walkers per GPU (512 on 8)
-Arithmetic is fp32 end to end (exact-fp32 MFMA): the reference's sampling precision is "32-true" and its bf16 mode is
-undefined, and the 1e-5 nm parity bar needs fp32.
+Arithmetic is fp32 end to end — VALU work in fp32, the dominant contraction either on v_mfma_f32_32x32x2_f32 (JAMUN_DG_FP32=1) or, by
+default, as "f16x3": each fp32 operand split exactly into two f16 terms, three f16 MFMAs per product with fp32 accumulation, error at
+the level of one fp32 rounding per product.  The reference's sampling precision is "32-true" and its bf16 mode is
+undefined, and the 1e-5 nm parity bar needs fp32-level accuracy.
 
 Timing: W untimed warm-up steps, then the K-step walk is timed R times back to back — each repeat bracketed by a barrier +
 torch.cuda.synchronize() on both sides and taken as the MAX over ranks — until >= ~2 s of timed work have accumulated
@@ -45,6 +47,7 @@ if ROOT not in sys.path:
 SIGMA = 0.04
 MCMC = dict(delta=0.04, friction=1.0, M=1.0, inverse_temperature=1.0, score_fn_clip=100.0)
 F32_MFMA_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+F16_MFMA_PEAK_TFLOPS = 2500.0  # same guide, "Peak BF16/FP16 MFMA ~2.5 PF dense"
 HBM_PEAK_GBS = 8000.0         # same guide, "HBM3E peak BW" (spec; ~6.3 TB/s measured on a float4 copy)
 MIN_TIMED_S = 2.0
 
@@ -219,26 +222,60 @@ def _pmc_traffic(kernel: str):
 # ---- self-launch ---------------------------------------------------------------------------------------------------------
 
 
-def spawn_ranks(n: int) -> int:
+def spawn_ranks(n: int, timeout_s: float = 1700.0) -> int:
     """`python bench.py --gpus N` without a launcher: start N copies of this script, one per GPU, with the torchrun environment
-    (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT), relay rank 0's stdout, return the worst exit code.  Called
-    before this process has made any GPU call (children are ordinary subprocesses; nothing is exec'ed over a GPU process)."""
+    (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT), relay rank 0's stdout, return the first non-zero exit code.
+    Called before this process has made any GPU call (children are ordinary subprocesses; nothing is exec'ed over a GPU
+    process).  All children are supervised: when one exits with an error — or the whole job exceeds `timeout_s` — the others are
+    terminated (a rank left alone would sit in the rendezvous or in its first collective for ever), and the stderr tail of the
+    rank that failed is relayed."""
+    import tempfile
+
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
-    procs = []
+    procs, logs = [], []
+    out0 = tempfile.TemporaryFile()
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        logs.append(tempfile.TemporaryFile())
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out0, _ = procs[0].communicate()
-    rc = procs[0].returncode
-    for p in procs[1:]:
-        p.wait()
-        rc = rc or p.returncode
-    for line in out0.decode().splitlines():  # stdout carries the ONE JSON line; library chatter (gloo / RCCL banners) goes to stderr
+                                      stdout=out0 if r == 0 else subprocess.DEVNULL, stderr=logs[r]))
+    t0 = time.monotonic()
+    rc, failed = 0, None
+    while True:
+        codes = [p.poll() for p in procs]
+        bad = [r for r, c in enumerate(codes) if c not in (None, 0)]
+        if bad:
+            failed, rc = bad[0], codes[bad[0]]
+            break
+        if all(c == 0 for c in codes):
+            break
+        if time.monotonic() - t0 > timeout_s:
+            failed, rc = -1, 124
+            break
+        time.sleep(0.05)
+    if failed is not None:
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()
+        for p in procs:
+            try:
+                p.wait(timeout=10)
+            except subprocess.TimeoutExpired:
+                p.kill()
+        who = "timeout" if failed < 0 else f"rank {failed} exited with code {rc}"
+        sys.stderr.write(f"bench.py: {who}; the other ranks were terminated\n")
+        if failed >= 0:
+            logs[failed].seek(0)
+            sys.stderr.write(logs[failed].read().decode(errors="replace")[-4000:])
+    else:
+        logs[0].seek(0)
+        sys.stderr.write(logs[0].read().decode(errors="replace"))
+    out0.seek(0)
+    for line in out0.read().decode().splitlines():  # stdout carries the ONE JSON line; library chatter (gloo / RCCL banners) goes to stderr
         (sys.stdout if line.lstrip().startswith("{") else sys.stderr).write(line + "\n")
     sys.stdout.flush()
     return rc
@@ -258,6 +295,8 @@ def main():
     ap.add_argument("--no-secondary", action="store_true", help="skip the scatter-mean / Langevin-kernel bandwidth measurements")
     ap.add_argument("--no-profile", action="store_true", help="do not record per-kernel HIP events in the timed region")
     ap.add_argument("--dry-run", action="store_true", help="rank plumbing only (gloo, no kernels): used by the CPU test of the self-launch")
+    ap.add_argument("--dry-run-fail-rank", type=int, default=-1, help="with --dry-run: this rank exits with an error before the rendezvous (tests the supervision of the self-launch)")
+    ap.add_argument("--strong", action="store_true", help="strong scaling: the config's walker count x 8 (2048 for cfg2/3/4) is the TOTAL, split over the ranks")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -268,6 +307,8 @@ def main():
     from jamun_amd import dist
 
     if args.dry_run:
+        if args.dry_run_fail_rank >= 0 and int(os.environ.get("RANK", 0)) == args.dry_run_fail_rank:
+            raise SystemExit(f"rank {args.dry_run_fail_rank}: simulated failure before the rendezvous")
         rank, world = dist.init_process_group(backend="gloo")
         t = torch.tensor([float(rank + 1)], dtype=torch.float64)
         if world > 1:
@@ -292,6 +333,13 @@ def main():
 
     cfg = CONFIGS[args.config]
     walkers = args.walkers if args.walkers is not None else cfg["walkers"]
+    total_walkers = None
+    if args.strong:  # north_star's "2048 parallel walkers" at every N: the total is fixed, each rank takes a contiguous share
+        total_walkers = args.walkers if args.walkers is not None else 8 * cfg["walkers"]
+        lo, hi = dist.shard_range(total_walkers, rank, world)
+        walkers = hi - lo
+        if walkers < 1:
+            raise SystemExit(f"--strong: rank {rank} of {world} has no walkers ({total_walkers} in total)")
     mols = workload_molecules(args.config, walkers, args.atoms, rank)
     batch = WalkerBatch.from_molecules(mols).to(dev)
     model = Denoiser.from_checkpoint_dict(synth.synthetic_checkpoint()).to(dev)
@@ -375,7 +423,7 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": 1e3 * dt_med / args.steps,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if args.strong else "weak",
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
@@ -416,6 +464,19 @@ def main():
                 "flop_per_launch": flop,
                 "mfma_flop_executed_per_forward": stats["flop_executed"],  # all conv launches of one forward, padding included
             }
+            if stats.get("dg_emu", -1) == 1 and fused:
+                # f16x3: every fp32 product of the contraction is three v_mfma_f32_*_f16 (hi hi + hi lo + lo hi of operands split into
+                # two f16 terms, fp32 accumulate; error ~ one fp32 rounding per product).  `achieved` / `frac` stay the
+                # ALGORITHMIC fp32 FLOP rate against the fp32-MFMA peak (comparable with earlier rounds; it may exceed what
+                # v_mfma_f32_32x32x2_f32 could deliver); `frac_executed` prices the instructions actually issued against the f16 peak.
+                ex = stats["conv_flop_exec_launch"] / (avg0 * 1e-3) / 1e12 if avg0 > 0 else 0.0
+                out["roofline"].update({"mfma_scheme": "f16x3 (fp32 operands split hi+lo into f16, 3 MFMAs per product, fp32 accumulate)",
+                                        "executed": ex, "peak_executed": F16_MFMA_PEAK_TFLOPS, "frac_executed": ex / F16_MFMA_PEAK_TFLOPS,
+                                        "flop_executed_per_launch": stats["conv_flop_exec_launch"]})
+            elif fused and stats.get("conv_flop_exec_launch", 0) > 0:
+                ex = stats["conv_flop_exec_launch"] / (avg0 * 1e-3) / 1e12 if avg0 > 0 else 0.0
+                out["roofline"].update({"mfma_scheme": "v_mfma_f32_32x32x2_f32", "executed": ex, "peak_executed": F32_MFMA_PEAK_TFLOPS,
+                                        "frac_executed": ex / F32_MFMA_PEAK_TFLOPS, "flop_executed_per_launch": stats["conv_flop_exec_launch"]})
             # HBM-side bytes per launch from the committed PMC passes of the cfg2 command (profiles/collect.sh); rocprofv3
             # cannot run inside the timed process, so the newest committed summary is quoted, with its file name
             if args.config == "cfg2" and args.atoms is None and args.walkers is None:

@@ -187,6 +187,11 @@ typedef struct jamun_stats {
   int32_t init_path;      /* initial projector: 2 edge-by-edge VALU kernel on the tiles of jamun_conv_dg.hip (jamun_conv_initv.hip),
                              1 input-times-weight table applied with MFMAs (jamun_conv_init.hip), 0 the hidden layers' fused /
                              general kernel */
+  int32_t dg_row_blocks;  /* jamun_conv_dg.hip: 1 when some molecule exceeds the span budget and its sources are cut into row blocks */
+  int32_t dg_emu;         /* jamun_conv_dg.hip contraction: 1 f16x3 (three v_mfma_f32_*_f16 per fp32 product, operands split hi + lo),
+                             0 v_mfma_f32_32x32x2_f32 (JAMUN_DG_FP32=1); -1: not in use */
+  int64_t conv_flop_exec_launch; /* matrix-core FLOPs EXECUTED by one hidden-layer conv launch (k_tprod + k_conv_dg, padding and the
+                             three products of the f16x3 scheme included); 0 when another conv path is in use */
 } jamun_stats;
 /* Synchronises `stream`. */
 int jamun_sampler_stats(jamun_sampler* s, jamun_stats* out, void* stream);

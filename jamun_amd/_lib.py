@@ -79,6 +79,9 @@ class jamun_stats(C.Structure):
         ("conv_path", C.c_int32),
         ("dg_mode", C.c_int32),
         ("init_path", C.c_int32),
+        ("dg_row_blocks", C.c_int32),
+        ("dg_emu", C.c_int32),
+        ("conv_flop_exec_launch", C.c_int64),
     ]
 
 

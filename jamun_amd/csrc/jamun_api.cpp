@@ -355,7 +355,7 @@ struct jamun_sampler {
   float4* egeo = nullptr;
   std::vector<float*> x;  // per block output [n_atoms][XS]
   unsigned long long* counter = nullptr;
-  int64_t flop_ref_per_edge = 0, flop_exec = 0;
+  int64_t flop_ref_per_edge = 0, flop_exec = 0, conv_flop_exec_launch = 0;
   // optional per-kernel-class timing with HIP events on the launch stream (jamun_profile_*)
   unsigned prof_mask = 0;  // bit c: record HIP events around launches of profile class c
   std::vector<hipEvent_t> ev_pool;
@@ -1566,8 +1566,14 @@ int jamun_sampler_create(const jamun_model* m, float sigma, const jamun_topology
     s->flop_exec = 0;
     for (auto& L : s->layers) {
       s->flop_ref_per_edge += 2LL * 64 * 64 + 130LL * L.tp_numel;  // SURVEY.md §8 d
-      if (s->dg_on && &L != &s->layers[0])  // MFMA units (4096 FLOP) per (tile, k) in k_conv_dg + per (32 atoms, k) in the T pre-pass
-        s->flop_exec += ((int64_t)s->dg_n_tiles * 476 + (int64_t)((s->n_atoms + 31) / 32) * 60) * (hp.edge_attr_dim + 1) * 4096;
+      if (s->dg_on && &L != &s->layers[0]) {
+        // per (tile, k) in k_conv_dg: fp32 path 476 units of v_mfma_f32_32x32x2 (4096 FLOP); f16x3 path 150 v_mfma_f32_32x32x16_f16
+        // (32768 FLOP: 50 groups of 16 inputs x 3 products) + 72 v_mfma_f32_16x16x32_f16 (16384 FLOP); + 60 fp32 units per (32 atoms, k)
+        // in the T pre-pass
+        const int64_t per_tile_k = s->dg_emu ? (150LL * 32768 + 72LL * 16384) : 476LL * 4096;
+        s->conv_flop_exec_launch = ((int64_t)s->dg_n_tiles * per_tile_k + (int64_t)((s->n_atoms + 31) / 32) * 60 * 4096) * (hp.edge_attr_dim + 1);
+        s->flop_exec += s->conv_flop_exec_launch;
+      }
       else if (L.fu.wpack) s->flop_exec += (int64_t)s->n_ftiles * (hp.edge_attr_dim + 1) * L.fu.mfma_per_k * 4096;  // 32x32x2 MFMA = 4096 FLOP
       else s->flop_exec += 2LL * s->n_pad * (1LL * L.p0.K * L.p0.nt * 32 + 3LL * L.p1.K * L.p1.nt * 32);
     }
@@ -1764,6 +1770,9 @@ int jamun_sampler_stats(jamun_sampler* s, jamun_stats* out, void* stream) {
     out->conv_path = s->dg_on ? 2 : (s->fused_JR > 0 ? 1 : 0);
     out->dg_mode = s->dg_on ? s->dg_mode : -1;
     out->init_path = s->initv_on ? 2 : (s->layers[0].tt ? 1 : 0);
+    out->dg_row_blocks = s->dg_on && s->dg_row_blocks ? 1 : 0;
+    out->dg_emu = s->dg_on ? s->dg_emu : -1;
+    out->conv_flop_exec_launch = s->conv_flop_exec_launch;
   });
 }
 

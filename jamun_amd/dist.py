@@ -81,23 +81,40 @@ def gather_ragged(block: Optional[torch.Tensor], dst: int = 0, group=None, devic
     rank, world = rank_world()
     if world == 1:
         return [block] if block is not None and block.shape[0] > 0 else []
+    backend = dist.get_backend(group)
     if device is None:
-        device = block.device if block is not None else (local_device() if dist.get_backend(group) == "nccl" else torch.device("cpu"))
-    meta = torch.zeros(_MAX_NDIM + 2, dtype=torch.int64, device=device)
+        # nccl (RCCL) moves device memory only: a CPU block (e.g. a trajectory kept on the host by cpu_offload) is staged on
+        # this rank's GPU; gloo takes either
+        if backend == "nccl":
+            device = block.device if block is not None and block.is_cuda else local_device()
+        else:
+            device = block.device if block is not None else torch.device("cpu")
+    if block is not None and block.device != device:
+        block = block.to(device)
+    # metadata: [ndim, shape..., dtype code, error code].  Local problems (too many dimensions, unsupported dtype) are
+    # REPORTED through the all-gather and raised on every rank afterwards — raising here would leave the others in the collective
+    codes = {torch.float32: 0, torch.float64: 1, torch.int64: 2, torch.int32: 3}
+    meta = torch.zeros(_MAX_NDIM + 3, dtype=torch.int64)
     if block is not None and block.shape[0] > 0:
         if block.ndim > _MAX_NDIM:
-            raise ValueError("gather_ragged: too many dimensions")
-        meta[0] = block.ndim
-        meta[1 : 1 + block.ndim] = torch.tensor(list(block.shape), dtype=torch.int64)
-        meta[-1] = {torch.float32: 0, torch.float64: 1, torch.int64: 2, torch.int32: 3}[block.dtype]
+            meta[-1] = 1
+        elif block.dtype not in codes:
+            meta[-1] = 2
+        else:
+            meta[0] = block.ndim
+            meta[1 : 1 + block.ndim] = torch.tensor(list(block.shape), dtype=torch.int64)
+            meta[-2] = codes[block.dtype]
+    meta = meta.to(device)
     metas = [torch.zeros_like(meta) for _ in range(world)]
     dist.all_gather(metas, meta, group=group)
-    shapes = []
-    for m in metas:
-        m = m.tolist()
-        shapes.append(tuple(m[1 : 1 + m[0]]) if m[0] > 0 else None)
+    metas = [m.tolist() for m in metas]
+    errs = {r: m[-1] for r, m in enumerate(metas) if m[-1] != 0}
+    if errs:
+        what = {1: f"more than {_MAX_NDIM} dimensions", 2: "unsupported dtype (float32, float64, int64, int32 only)"}
+        raise ValueError("gather_ragged: " + "; ".join(f"rank {r}: {what[c]}" for r, c in errs.items()))
+    shapes = [tuple(m[1 : 1 + m[0]]) if m[0] > 0 else None for m in metas]
     trailing = {sh[1:] for sh in shapes if sh is not None}
-    dtypes = {int(m[-1]) for m, sh in zip(metas, shapes) if sh is not None}
+    dtypes = {int(m[-2]) for m, sh in zip(metas, shapes) if sh is not None}
     if len(trailing) > 1 or len(dtypes) > 1:
         raise ValueError(f"gather_ragged: ranks disagree on the block's trailing shape / dtype: {shapes}")
     senders = [r for r, sh in enumerate(shapes) if sh is not None and r != dst]
@@ -134,4 +151,7 @@ def broadcast_object(obj, src: int = 0):
 
 def barrier():
     if dist.is_available() and dist.is_initialized():
-        dist.barrier()
+        if dist.get_backend() == "nccl":  # name the device: without it RCCL guesses from the rank and warns (or picks a GPU another rank owns)
+            dist.barrier(device_ids=[local_device().index])
+        else:
+            dist.barrier()

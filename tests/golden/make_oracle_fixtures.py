@@ -46,6 +46,16 @@ def molecules(kind):
         return [synth.random_chain(93, seed=5)] * 2
     if kind == "chig166x2":
         return [synth.random_chain(166, seed=5)] * 2
+    # per-GPU shapes of BASELINE configs[2] / configs[3] (bench.py cfg3 / cfg4): the 33-atom molecule of the 4AA workload, and
+    # the eight distinct sequences (17..57 atoms) of the ragged MDGen-like batch — embedded into full-size batches by
+    # tests/test_gpu_parity.py::test_full_size_batches_of_the_multi_gpu_configs_match_the_oracle
+    if kind == "chain33x4":
+        return [synth.random_chain(33, seed=0)] * 4
+    if kind == "cfg4kinds":
+        import random
+
+        rng = random.Random(1234)
+        return [synth.random_chain(rng.randint(17, 57), seed=100 + i) for i in range(8)]
     raise KeyError(kind)
 
 
@@ -100,7 +110,10 @@ CASES = {
     "oracle_forward_dense70": lambda **kw: forward_case("dense70", False),
     "oracle_forward_chig93x2": lambda **kw: forward_case("chig93x2", False),
     "oracle_forward_chig166x2": lambda **kw: forward_case("chig166x2", False),
+    "oracle_forward_chain33x4": lambda **kw: forward_case("chain33x4", False),
+    "oracle_forward_cfg4kinds": lambda **kw: forward_case("cfg4kinds", False),
     "oracle_walk_baoab_chig93_6": lambda max_steps=None, **kw: walk_case("chig93x2", "baoab", 6, "stable", max_steps),
+    "oracle_walk_baoab_chig166_4": lambda max_steps=None, **kw: walk_case("chig166x2", "baoab", 4, "stable", max_steps),
     "oracle_walk_baoab_ag4_50_mid": lambda max_steps=None, **kw: walk_case("ag4", "baoab", 50, "mid", max_steps),
     "oracle_walk_baoab_ag4_50_g02": lambda max_steps=None, **kw: walk_case("ag4", "baoab", 50, "g02", max_steps),
     "oracle_walk_baoab_ag4_50": lambda max_steps=None, **kw: walk_case("ag4", "baoab", 50, "stable", max_steps),

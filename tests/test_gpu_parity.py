@@ -43,6 +43,13 @@ def _mols(kind):
         return [synth.random_chain(17, seed=0)] * 6
     if kind == "ragged":
         return [synth.random_chain(n, seed=s) for s, n in enumerate([5, 17, 33, 9, 57, 2, 1, 29])]
+    if kind == "chain33x4":
+        return [synth.random_chain(33, seed=0)] * 4
+    if kind == "cfg4kinds":
+        import random
+
+        rng = random.Random(1234)
+        return [synth.random_chain(rng.randint(17, 57), seed=100 + i) for i in range(8)]
     if kind == "dense70":  # > 32 neighbours inside the cutoff: exercises the neighbour cap
         return [synth.random_chain(70, seed=3, bond=0.12, min_dist=0.13)] * 2
     # BASELINE configs[4]: chignolin size, with hydrogens (~166 atoms) and as the reference feeds it (93 heavy atoms)
@@ -365,6 +372,118 @@ def test_walkers_are_independent_at_baseline_batch_size(dev, golden_dir):
         assert rmsd(x6, ref["xhat"]) <= RMSD_TOL_NM
 
 
+@pytest.mark.parametrize("cfg", ["cfg3", "cfg4", "cfg5"])
+def test_full_size_batches_of_the_multi_gpu_configs_match_the_oracle(dev, golden_dir, cfg):
+    """Per-GPU shapes of BASELINE configs[2..4] at FULL size — 33 atoms x 256 walkers, the ragged 17..57-atom batch of 256
+    walkers, 166 atoms x 64 walkers: multi-segment work lists, 2-3 partial slabs per tile, every CU busy.  The cached oracle
+    inputs are embedded as walkers of the big batch and must come out within 1e-5 nm of the oracle's denoised coordinates;
+    walkers from the first, a middle and the last tile must not depend on the rest of the batch."""
+    from jamun_amd import synth
+    from jamun_amd.data import WalkerBatch
+    from jamun_amd.model import Denoiser
+    from jamun_amd.native import NativeSampler
+
+    model = Denoiser.from_checkpoint_dict(_ckpt("strong")).to(dev)
+    if cfg == "cfg3":
+        fixture, mols = "chain33x4", [synth.random_chain(33, seed=0)] * 256
+        slots, expect_modes = [0, 1, 2, 3], (3,)
+    elif cfg == "cfg4":  # bench.py's cfg4 workload: eight sequences, 32 consecutive walkers each
+        kinds = _mols("cfg4kinds")
+        fixture, mols = "cfg4kinds", [m for m in kinds for _ in range(32)]
+        slots, expect_modes = [32 * i for i in range(8)], (0, 3)
+    else:
+        fixture, mols = "chig166x2", [synth.random_chain(166, seed=5)] * 64
+        slots, expect_modes = [0, 1], (1,)
+    ref = _golden(golden_dir, f"oracle_forward_{fixture}")
+    big = WalkerBatch.from_molecules(mols).to(dev)
+    smp = NativeSampler(model._native, 0.04, big, dev)
+    st = smp.stats()
+    assert st["conv_path"] == 2 and st["dg_mode"] in expect_modes, st
+    ptr = [0]
+    for m in mols:
+        ptr.append(ptr[-1] + m["pos"].shape[0])
+    torch.manual_seed(3)
+    y = big.pos + 0.04 * torch.randn(big.pos.shape).to(dev)
+    # the oracle's walkers (same molecules, the oracle's noisy input) at their slots of the big batch
+    ofs = 0
+    for w in slots:
+        n = ptr[w + 1] - ptr[w]
+        y[ptr[w] : ptr[w + 1]] = ref["y"][ofs : ofs + n].to(dev)
+        ofs += n
+    assert ofs == ref["y"].shape[0]
+    x = smp.xhat(y)
+    assert torch.isfinite(x).all()
+    got = torch.cat([x[ptr[w] : ptr[w + 1]] for w in slots])
+    assert rmsd(got, ref["xhat"]) <= RMSD_TOL_NM, rmsd(got, ref["xhat"])
+    # batch independence across the work list: walkers of the first, a middle and the last tile, sampled alone
+    W = len(mols)
+    pick = sorted({0, W // 2 - 1, W // 2, W - 1})
+    small = WalkerBatch.from_molecules([mols[w] for w in pick]).to(dev)
+    y_small = torch.cat([y[ptr[w] : ptr[w + 1]] for w in pick])
+    x_small = model.xhat(small.with_pos(y_small), 0.04).pos
+    x_pick = torch.cat([x[ptr[w] : ptr[w + 1]] for w in pick])
+    assert rmsd(x_pick, x_small) <= RMSD_TOL_NM / 10, rmsd(x_pick, x_small)
+
+
+@pytest.mark.parametrize("case", ["alone200", "mixed260", "alone400", "sparse300"])
+def test_source_row_blocks_of_the_default_conv_kernel(dev, monkeypatch, case):
+    """Molecules above the span budget of k_conv_dg's large-molecule mode (~170 atoms) are cut into source ROW BLOCKS: every
+    (destination chunk, row block) pair is a tile of its own, edges to sources outside the block are skipped, the blocks'
+    results are extra partial slabs, and a tile without any edge writes a zero slab after a workgroup-wide vote.  200-, 260-
+    and 400-atom molecules — alone, mixed with small molecules in one batch, and a stretched chain whose far row blocks share
+    no edge with a destination chunk — against the general kernel (no tiling by molecule), in the two-pass mode and, with it
+    switched off, in the resident two-phase mode."""
+    from jamun_amd import synth
+    from jamun_amd.data import WalkerBatch
+    from jamun_amd.model import Denoiser
+    from jamun_amd.native import NativeSampler
+
+    model = Denoiser.from_checkpoint_dict(_ckpt("strong")).to(dev)
+    if case == "alone200":
+        mols = [synth.random_chain(200, seed=21)]
+    elif case == "mixed260":
+        mols = [synth.random_chain(9, seed=1), synth.random_chain(260, seed=22), synth.random_chain(17, seed=2), synth.random_chain(40, seed=3)]
+    elif case == "alone400":
+        mols = [synth.random_chain(400, seed=23)] * 2
+    else:  # a nearly straight chain: atoms 0..31 have no neighbour among atoms 200..299 -> edge-less (chunk, block) tiles
+        m = synth.random_chain(300, seed=24)
+        pos = m["pos"].clone()
+        pos[:, 0] = 0.14 * torch.arange(300, dtype=pos.dtype)
+        pos[:, 1:] *= 0.05
+        m = dict(m, pos=pos)
+        mols = [m]
+    batch = WalkerBatch.from_molecules(mols).to(dev)
+    torch.manual_seed(9)
+    y = batch.pos + 0.04 * torch.randn(batch.pos.shape).to(dev)
+    monkeypatch.delenv("JAMUN_NO_FUSED", raising=False)
+    monkeypatch.delenv("JAMUN_NO_DG", raising=False)
+    dg = NativeSampler(model._native, 0.04, batch, dev)
+    st = dg.stats()
+    assert st["conv_path"] == 2 and st["dg_mode"] == 1 and st["dg_row_blocks"] == 1, st
+    monkeypatch.setenv("JAMUN_DG_NO_ALT", "1")
+    dg0 = NativeSampler(model._native, 0.04, batch, dev)
+    monkeypatch.delenv("JAMUN_DG_NO_ALT")
+    st0 = dg0.stats()
+    assert st0["conv_path"] == 2 and st0["dg_mode"] == 0 and st0["dg_row_blocks"] == 1, st0
+    monkeypatch.setenv("JAMUN_NO_DG", "1")
+    monkeypatch.setenv("JAMUN_NO_FUSED", "1")
+    general = NativeSampler(model._native, 0.04, batch, dev)
+    monkeypatch.delenv("JAMUN_NO_FUSED")
+    monkeypatch.delenv("JAMUN_NO_DG")
+    assert general.stats()["conv_path"] == 0
+    xg = general.xhat(y)
+    for other in (dg, dg0):
+        xo = other.xhat(y)
+        assert torch.isfinite(xo).all()
+        assert rmsd(xo, xg) <= RMSD_TOL_NM, (case, rmsd(xo, xg))
+        for l in range(6):
+            a, b = other.debug_read(0, l).cpu(), general.debug_read(0, l).cpu()
+            assert (a - b).abs().max().item() <= 2e-5 * max(b.abs().max().item(), 1e-6), (case, l)
+    if case == "sparse300":  # the stretched chain really has (chunk, block) tiles without edges
+        deg = dg.debug_read(1).cpu().flatten()
+        assert deg.max() < 12
+
+
 def test_forward_matches_live_oracle(dev, ckpt):
     """Same comparison with the oracle run live on this box (small case), so the cache is not the only witness."""
     from jamun_amd.data import WalkerBatch
@@ -572,6 +691,7 @@ def test_fused_integrator_halves_equal_standalone_update_kernels(dev):
     ("oracle_walk_baoab_ragged_12", "baoab", "ragged", "stable"),
     ("oracle_walk_aboba_ag4_20", "aboba", "ag4", "stable"),
     ("oracle_walk_baoab_chig93_6", "baoab", "chig93x2", "stable"),  # configs[4] size: 93 heavy atoms, neighbour cap active
+    ("oracle_walk_baoab_chig166_4", "baoab", "chig166x2", "stable"),  # configs[4] with hydrogens: 166 atoms (two-pass conv kernel)
 ])
 def test_fused_walk_matches_oracle(dev, golden_dir, case, integrator, kind, preset):
     """Fused native walk vs the oracle's walk_jump on the identical noise stream: every saved frame's denoised

@@ -458,6 +458,17 @@ try:  # trailing shapes that disagree raise on EVERY rank, before any payload mo
     raise SystemExit("expected ValueError")
 except ValueError:
     pass
+try:  # a problem only ONE rank can see (unsupported dtype on rank 1) is reported through the metadata exchange and raised on both
+    dist.gather_ragged(torch.zeros(2, 3, dtype=torch.float16 if rank == 1 else torch.float32), dst=0)
+    raise SystemExit("expected ValueError")
+except ValueError as e:
+    assert "rank 1" in str(e) and "dtype" in str(e), str(e)
+try:  # ... and so are too many dimensions on rank 0
+    dist.gather_ragged(torch.zeros([1] * (10 if rank == 0 else 2)), dst=0)
+    raise SystemExit("expected ValueError")
+except ValueError as e:
+    assert "rank 0" in str(e), str(e)
+dist.barrier()
 # ---- (2) Sampler.sample(shard_walkers=True) end to end with a stub model / batch sampler, two dataset labels, ragged sizes
 mol_a, mol_b = synth.random_chain(6, seed=0), synth.random_chain(9, seed=1)
 class DS:
@@ -537,6 +548,23 @@ def test_bench_self_launches_ranks(tmp_path):
     r1 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--dry-run"], env=dict(env, WORLD_SIZE="1", RANK="0"),
                         capture_output=True, text=True, timeout=240)
     assert r1.returncode == 0 and json.loads([l for l in r1.stdout.splitlines() if l.startswith("{")][-1])["n_gpus"] == 1
+
+
+def test_bench_self_launch_supervises_its_ranks():
+    """A rank that dies before the rendezvous must not leave the parent (or the surviving rank, which waits in the rendezvous)
+    hanging: the parent notices the non-zero exit, terminates the other rank, relays the failed rank's stderr and returns its
+    code within seconds."""
+    import time
+
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    t0 = time.monotonic()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run", "--dry-run-fail-rank", "1"],
+                       env=env, capture_output=True, text=True, timeout=120)
+    dt = time.monotonic() - t0
+    assert r.returncode != 0
+    assert dt < 60, dt
+    assert "rank 1 exited" in r.stderr and "simulated failure" in r.stderr, r.stderr[-1500:]
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
 
 
 def test_unpickler_reads_omegaconf_shaped_hparams(tmp_path):
