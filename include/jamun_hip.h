@@ -169,6 +169,35 @@ int jamun_aboba_a(float* y_dev, const float* v_dev, int32_t n, const jamun_mcmc_
 int jamun_aboba_b(float* y_dev, float* v_dev, const float* score_dev, const float* noise_dev, int32_t n,
                   const jamun_mcmc_params* p, void* stream);
 
+/* Edge geometry of E3Conv.forward (src/jamun/model/arch/e3conv.py:114-123) for an explicit edge list: per edge e = (src -> dst),
+ * from positions ALREADY scaled by c_in (as E3Conv receives them, src/jamun/model/denoiser.py:198):
+ *   sh_dev     [n_edges, 4]        o3.SphericalHarmonics("1x0e+1x1e", normalize=True, normalization="component") = [1, sqrt(3) v/|v|]
+ *   radial_dev [n_edges, n_basis]  e3nn soft_one_hot_linspace(|v|, 0, radial_cutoff, n_basis, basis="gaussian", cutoff=True)
+ * (the radial half of edge_attr; the bonded half is an embedding lookup).  src_dev / dst_dev: int64 device arrays (edge_index). */
+int jamun_edge_geometry(const float* pos_dev, const int64_t* src_dev, const int64_t* dst_dev, int32_t n_edges, float radial_cutoff,
+                        int32_t n_basis, float* sh_dev, float* radial_dev, void* stream);
+
+/* e3nn o3.Linear on node features between irreps (in0 x0e + in1 x1e) and (out0 x0e + out1 x1e): the skip / self-interaction /
+ * head Linears of the path (src/jamun/e3tools/nn/_interaction.py:23-24, _mlp.py:69,109).  w_dev: the flat e3nn weight
+ * [in0 x out0 | in1 x out1] on the device (instruction order i_in outer, i_out inner; path normalisation 1/sqrt(fan_in) applied
+ * here).  x_dev [n_atoms, in0 + 3 in1] -> out_dev [n_atoms, out0 + 3 out1], e3nn layout (channel-major, m fastest). */
+int jamun_node_linear(const float* x_dev, int32_t n_atoms, int32_t in0, int32_t in1, int32_t out0, int32_t out1, const float* w_dev,
+                      float* out_dev, void* stream);
+
+/* The graph half of a forward on its own: Denoiser.add_edges + the edge geometry + the radial MLPs' hidden layer
+ * (src/jamun/model/denoiser.py:138-166, arch/e3conv.py:110-127, e3tools/nn/_conv.py:112) for positions y_dev [n_atoms,3]; the
+ * result stays inside the sampler as the edge table the blocks below run on. */
+int jamun_build_edges(jamun_sampler* s, const float* y_dev, void* stream);
+
+/* ONE block of E3Conv on caller-owned node features and the sampler's current edge table (jamun_build_edges, or the last forward):
+ *   layer 0      x_out = ConvBlock_initial(noise-scaled atom embedding)                     x_in_dev must be NULL (the input is the
+ *                                                                                           sampler's own constant embedding)
+ *   layer l >= 1 x_out = w_l * x_in + (1 - w_l) * ConvBlock_l(s_l * x_in)                   x_in_dev [n_atoms, mul0 + 3 mul1]
+ * i.e. ConvBlock = LinearSelfInteraction(Gated(Conv)) (src/jamun/e3tools/nn/_conv.py:147-221: gather, radial-MLP weights, tensor
+ * product, scatter-mean, gate, self-interaction + skip Linear) with the noise-conditional scaling and skip of
+ * src/jamun/model/arch/e3conv.py:129-133 around it.  x_out_dev [n_atoms, mul0 + 3 mul1]; must not alias x_in_dev. */
+int jamun_conv_block(jamun_sampler* s, int32_t layer, const float* x_in_dev, float* x_out_dev, void* stream);
+
 /* Introspection for tests / benchmarks. */
 typedef struct jamun_stats {
   int64_t n_edges;        /* directed edges (radial + bonded) in the last forward             */

@@ -106,6 +106,10 @@ SYMBOLS = {
     "jamun_baoab_post": (C.c_int, [_P, _P, _P, C.c_int32, C.POINTER(jamun_mcmc_params), _P]),
     "jamun_aboba_a": (C.c_int, [_P, _P, C.c_int32, C.POINTER(jamun_mcmc_params), _P]),
     "jamun_aboba_b": (C.c_int, [_P, _P, _P, _P, C.c_int32, C.POINTER(jamun_mcmc_params), _P]),
+    "jamun_edge_geometry": (C.c_int, [_P, _P, _P, C.c_int32, C.c_float, C.c_int32, _P, _P, _P]),
+    "jamun_node_linear": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P]),
+    "jamun_build_edges": (C.c_int, [_P, _P, _P]),
+    "jamun_conv_block": (C.c_int, [_P, C.c_int32, _P, _P, _P]),
     "jamun_sampler_stats": (C.c_int, [_P, C.POINTER(jamun_stats), _P]),
     "jamun_profile_enable": (C.c_int, [_P, C.c_int32]),
     "jamun_profile_read": (C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(C.c_int64), _P]),

@@ -348,7 +348,7 @@ struct jamun_sampler {
   // work buffers
   float *w1r_all = nullptr, *cmask_all = nullptr;  // [layers][64][32], [layers][2][64]
   size_t h_stride = 0, h_kstride = 0;  // per layer: [65 hidden rows][h_kstride edge slots]
-  bool h_batched = false;
+  bool h_batched = false, edges_built = false;
   float *yc = nullptr, *h = nullptr, *partial0 = nullptr, *partial1 = nullptr, *g = nullptr, *tmp = nullptr;
   float *xhat_buf = nullptr, *score_buf = nullptr, *psi = nullptr;
   int *deg = nullptr, *esrc = nullptr;
@@ -927,25 +927,33 @@ struct ProfScope {
 
 // One denoiser forward.  `pre` / `post`: the two halves of a BAOAB iteration fused into the first and the last kernel of the
 // forward (y is then advanced in place before the geometry is built).
-void forward(jamun_sampler* s, float* y, float* xhat, float* score, hipStream_t st, const LangevinPre& pre = LangevinPre(),
-             const LangevinPost& post = LangevinPost()) {
+// Geometry of one forward: centring, radius graph + bonded edges, unit vectors and distances (k_geom; `pre`: the first half of a
+// BAOAB iteration fused in front of it), and — when the buffer holds all layers — the radial MLPs' hidden activations of every
+// layer (k_edge_h; they depend on the geometry only).
+void build_edges(jamun_sampler* s, float* y, hipStream_t st, const LangevinPre& pre = LangevinPre()) {
   {
     ProfScope ps(s, JAMUN_PROF_GEOM, st);
     launch_geom(y, s->ptr, s->n_graphs, s->c_in, s->r2, s->S, s->bond_in_ptr, s->bond_in_src, s->hp.mean_center, s->yc,
                 s->deg, s->esrc, s->egeo, pre, st);
   }
-  const float* x_in = s->x_emb;
-  int XSin = s->n_emb;
-  for (size_t l = 0; l < s->layers.size(); ++l) {
-    LayerDev& L = s->layers[l];
-    const float* h_l = s->h + (s->h_batched ? l * s->h_stride : 0);
-    if (!s->h_batched || l == 0) {
-      // the radial MLPs depend only on the edge geometry: one launch covers every layer when the buffer fits
-      const size_t NL = s->h_batched ? s->layers.size() : 1;
-      ProfScope ps(s, JAMUN_PROF_EDGE_H, st);
-      launch_edge_h(s->deg, s->esrc, s->egeo, s->n_atoms, s->S, s->w1r_all + l * 64 * 32, s->cmask_all + l * 128, (int)NL,
-                    s->mu, s->rb_step, s->h, s->h_stride, s->h_kstride, st);
-    }
+  if (s->h_batched) {
+    ProfScope ps(s, JAMUN_PROF_EDGE_H, st);
+    launch_edge_h(s->deg, s->esrc, s->egeo, s->n_atoms, s->S, s->w1r_all, s->cmask_all, (int)s->layers.size(), s->mu, s->rb_step, s->h,
+                  s->h_stride, s->h_kstride, st);
+  }
+  s->edges_built = true;
+}
+
+// One block of the network on the current edge table: ConvBlock l (conv contraction + gate + self-interaction + skip Linear)
+// and, for the hidden layers, the noise-conditional input scaling and skip mix around it (e3conv.py:129-133).
+void run_layer(jamun_sampler* s, size_t l, const float* x_in, int XSin, float* x_out, hipStream_t st) {
+  LayerDev& L = s->layers[l];
+  const float* h_l = s->h + (s->h_batched ? l * s->h_stride : 0);
+  if (!s->h_batched) {  // (batches above 4 GiB of activations: one layer's radial MLP at a time)
+    ProfScope ps(s, JAMUN_PROF_EDGE_H, st);
+    launch_edge_h(s->deg, s->esrc, s->egeo, s->n_atoms, s->S, s->w1r_all + l * 64 * 32, s->cmask_all + l * 128, 1, s->mu, s->rb_step, s->h,
+                  s->h_stride, s->h_kstride, st);
+  }
     if (l == 0 && s->initv_on) {
       InitVArgs f{};
       f.deg = s->deg; f.esrc = s->esrc; f.egeo = s->egeo; f.h = h_l; f.h_kstride = s->h_kstride;
@@ -1015,7 +1023,7 @@ void forward(jamun_sampler* s, float* y, float* xhat, float* score, hipStream_t 
     }
     }
     NodeArgs n{};
-    n.partial0 = s->partial0; n.partial1 = s->partial1; n.deg = s->deg; n.x_in = x_in; n.x_out = s->x[l];
+    n.partial0 = s->partial0; n.partial1 = s->partial1; n.deg = s->deg; n.x_in = x_in; n.x_out = x_out;
     n.wcat0 = L.wcat0; n.wcat1 = L.wcat1; n.K0p = L.K0p; n.K1p = L.K1p; n.mix = L.mix;
     n.cL = s->hp.act_scalar_const; n.cS = s->hp.act_gate_const;
     n.n_atoms = s->n_atoms; n.n_pad = s->n_pad; n.n_slices = s->n_slices; n.nt0 = L.p0.nt; n.nt1 = L.p1.nt;
@@ -1027,6 +1035,17 @@ void forward(jamun_sampler* s, float* y, float* xhat, float* score, hipStream_t 
       ProfScope ps(s, JAMUN_PROF_NODE, st);
       launch_node_update(n, st);
     }
+}
+
+// One denoiser forward.  `pre` / `post`: the two halves of a BAOAB iteration fused into the first and the last kernel of the
+// forward (y is then advanced in place before the geometry is built).
+void forward(jamun_sampler* s, float* y, float* xhat, float* score, hipStream_t st, const LangevinPre& pre = LangevinPre(),
+             const LangevinPost& post = LangevinPost()) {
+  build_edges(s, y, st, pre);
+  const float* x_in = s->x_emb;
+  int XSin = s->n_emb;
+  for (size_t l = 0; l < s->layers.size(); ++l) {
+    run_layer(s, l, x_in, XSin, s->x[l], st);
     x_in = s->x[l];
     XSin = s->XS;
   }
@@ -1742,6 +1761,54 @@ int jamun_aboba_b(float* y, float* v, const float* score, const float* noise, in
     if (!y || !v || !score || !noise || !p) throw Err(JAMUN_ERR_INVALID, "null argument");
     if (n == 0) return;
     launch_aboba_b(y, v, score, noise, 0, 0, n, make_consts(p), nullptr, nullptr, (hipStream_t)stream);
+    HIPCHECK(hipGetLastError());
+  });
+}
+
+int jamun_edge_geometry(const float* pos, const int64_t* src, const int64_t* dst, int32_t n_edges, float radial_cutoff, int32_t n_basis,
+                        float* sh, float* radial, void* stream) {
+  return guarded([&] {
+    if (!pos || !src || !dst || !sh || !radial || n_edges < 0) throw Err(JAMUN_ERR_INVALID, "bad argument");
+    if (n_basis < 1 || !(radial_cutoff > 0)) throw Err(JAMUN_ERR_INVALID, "n_basis must be >= 1 and radial_cutoff positive");
+    if (n_edges == 0) return;
+    launch_edge_geometry(pos, (const long long*)src, (const long long*)dst, n_edges, radial_cutoff, n_basis, sh, radial, (hipStream_t)stream);
+    HIPCHECK(hipGetLastError());
+  });
+}
+
+int jamun_node_linear(const float* x, int32_t n_atoms, int32_t in0, int32_t in1, int32_t out0, int32_t out1, const float* w, float* out,
+                      void* stream) {
+  return guarded([&] {
+    if (!x || !w || !out || n_atoms < 0 || in0 < 0 || in1 < 0 || out0 < 0 || out1 < 0 || in0 + in1 < 1 || out0 + out1 < 1)
+      throw Err(JAMUN_ERR_INVALID, "bad argument");
+    if (n_atoms == 0) return;
+    if (launch_node_linear(x, n_atoms, in0, in1, out0, out1, w, out, (hipStream_t)stream) != 0)
+      throw Err(JAMUN_ERR_INVALID, "input irreps too wide (8 feature rows must fit 60 KiB of LDS)");
+    HIPCHECK(hipGetLastError());
+  });
+}
+
+int jamun_build_edges(jamun_sampler* s, const float* y_dev, void* stream) {
+  return guarded([&] {
+    if (!s || !y_dev) throw Err(JAMUN_ERR_INVALID, "null argument");
+    build_edges(s, const_cast<float*>(y_dev), (hipStream_t)stream);  // (y is written only with a fused pre-update)
+    HIPCHECK(hipGetLastError());
+  });
+}
+
+int jamun_conv_block(jamun_sampler* s, int32_t layer, const float* x_in_dev, float* x_out_dev, void* stream) {
+  return guarded([&] {
+    if (!s || !x_out_dev) throw Err(JAMUN_ERR_INVALID, "null argument");
+    if (layer < 0 || layer >= (int)s->layers.size()) throw Err(JAMUN_ERR_INVALID, "layer out of range");
+    if (!s->edges_built) throw Err(JAMUN_ERR_INVALID, "no edge table yet: call jamun_build_edges (or a forward) first");
+    if (layer == 0) {
+      if (x_in_dev) throw Err(JAMUN_ERR_INVALID, "block 0 (initial projector) takes the sampler's own noise-scaled atom embedding: pass x_in = NULL");
+      run_layer(s, 0, s->x_emb, s->n_emb, x_out_dev, (hipStream_t)stream);
+    } else {
+      if (!x_in_dev) throw Err(JAMUN_ERR_INVALID, "null x_in");
+      if (x_in_dev == x_out_dev) throw Err(JAMUN_ERR_INVALID, "x_in and x_out must not alias (the skip path reads x_in after the conv)");
+      run_layer(s, (size_t)layer, x_in_dev, s->XS, x_out_dev, (hipStream_t)stream);
+    }
     HIPCHECK(hipGetLastError());
   });
 }

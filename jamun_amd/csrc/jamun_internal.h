@@ -251,3 +251,6 @@ void launch_copy(const float* src, float* dst, int n, hipStream_t st);
 void launch_deg_to_float(const int* deg, float* out, int n, hipStream_t st);
 void launch_count_edges(const int* deg, int n, unsigned long long* out, hipStream_t st);
 void launch_scatter_mean(const float* src, const int* seg_ptr, int n_out, int width, float* out, hipStream_t st);
+void launch_edge_geometry(const float* pos, const long long* src, const long long* dst, int n_edges, float cutoff, int n_basis, float* sh,
+                          float* radial, hipStream_t st);
+int launch_node_linear(const float* x, int n_atoms, int in0, int in1, int out0, int out1, const float* w, float* out, hipStream_t st);

@@ -772,3 +772,82 @@ void launch_count_edges(const int* deg, int n, unsigned long long* out, hipStrea
 void launch_scatter_mean(const float* src, const int* seg_ptr, int n_out, int width, float* out, hipStream_t st) {
   hipLaunchKernelGGL(k_scatter_mean, dim3((n_out + 3) / 4), dim3(256), 0, st, src, seg_ptr, n_out, width, out);
 }
+
+// ------------------------------------------------------------------------------------------------------------------------
+// Stand-alone operators of the path for foreign callers (include/jamun_hip.h): edge geometry and o3.Linear on node features.
+// Inside the sampler the same arithmetic lives in k_geom / k_edge_h and in k_node_update / k_head.
+
+// jamun_edge_geometry: per edge (src -> dst) of an edge list, from already scaled positions (src/jamun/model/arch/e3conv.py:114-123):
+//   sh = [1, sqrt(3) v / max(|v|, 1e-12)]   (o3.SphericalHarmonics "1x0e+1x1e", normalize=True, component normalisation)
+//   radial[k] = exp(-((|v| - mu_k) / step)^2) / 1.12,  mu = linspace(0, cutoff, n_basis + 2)[1:-1]   (soft_one_hot_linspace, gaussian)
+// One thread per edge; the basis row is written by the same thread (n_basis floats: 128 B for the default 32).
+__global__ __launch_bounds__(256) void k_edge_geometry(const float* __restrict__ pos, const long long* __restrict__ src, const long long* __restrict__ dst,
+                                                       int n_edges, float cutoff, int n_basis, float* __restrict__ sh, float* __restrict__ radial) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= n_edges) return;
+  const long long j = src[e], i = dst[e];
+  const float vx = pos[3 * j] - pos[3 * i], vy = pos[3 * j + 1] - pos[3 * i + 1], vz = pos[3 * j + 2] - pos[3 * i + 2];
+  const float d = sqrtf(__fadd_rn(__fadd_rn(__fmul_rn(vx, vx), __fmul_rn(vy, vy)), __fmul_rn(vz, vz)));
+  const float inv = 1.f / fmaxf(d, 1e-12f), s3 = 1.7320508075688772f;
+  float4 o = make_float4(1.f, s3 * (vx * inv), s3 * (vy * inv), s3 * (vz * inv));
+  reinterpret_cast<float4*>(sh)[e] = o;
+  const float step = cutoff / (float)(n_basis + 1);
+  for (int k = 0; k < n_basis; ++k) {
+    const int i1 = k + 1;  // torch.linspace: lower half counted from the start, upper half from the end
+    const float mu = i1 < (n_basis + 2) / 2 ? __fmul_rn(step, (float)i1) : __fsub_rn(cutoff, __fmul_rn(step, (float)(n_basis + 1 - i1)));
+    const float t = __fdiv_rn(__fsub_rn(d, mu), step);
+    radial[(size_t)e * n_basis + k] = expf(-(t * t)) / 1.12f;
+  }
+}
+void launch_edge_geometry(const float* pos, const long long* src, const long long* dst, int n_edges, float cutoff, int n_basis, float* sh,
+                          float* radial, hipStream_t st) {
+  hipLaunchKernelGGL(k_edge_geometry, dim3((n_edges + 255) / 256), dim3(256), 0, st, pos, src, dst, n_edges, cutoff, n_basis, sh, radial);
+}
+
+// jamun_node_linear: e3nn o3.Linear between irreps (in0 x0e + in1 x1e) and (out0 x0e + out1 x1e) with the flat e3nn weight
+// [in0 x out0 | in1 x out1], path normalisation 1 / sqrt(fan_in) (src/jamun/e3tools/nn/_interaction.py:23-24, _mlp.py:69,109).
+// One workgroup = 8 atoms; the feature rows are staged in LDS, thread t owns output element t of every atom of the group.
+__global__ __launch_bounds__(256) void k_node_linear(const float* __restrict__ x, int n_atoms, int in0, int in1, int out0, int out1,
+                                                     const float* __restrict__ w, float* __restrict__ out) {
+  extern __shared__ float xs_nl[];  // [8][in0 + 3 in1]
+  const int win = in0 + 3 * in1, wout = out0 + 3 * out1, a0 = blockIdx.x * 8;
+  for (int idx = threadIdx.x; idx < 8 * win; idx += 256) {
+    const int a = a0 + idx / win;
+    xs_nl[idx] = a < n_atoms ? x[(size_t)a * win + idx % win] : 0.f;
+  }
+  __syncthreads();
+  const float n0 = in0 > 0 ? 1.f / sqrtf((float)in0) : 0.f, n1 = in1 > 0 ? 1.f / sqrtf((float)in1) : 0.f;
+  const float* __restrict__ w1 = w + (size_t)in0 * out0;
+  for (int o = threadIdx.x; o < wout; o += 256) {
+    float acc[8];
+#pragma unroll
+    for (int a = 0; a < 8; ++a) acc[a] = 0.f;
+    if (o < out0) {
+      for (int u = 0; u < in0; ++u) {
+        const float wv = w[(size_t)u * out0 + o];
+#pragma unroll
+        for (int a = 0; a < 8; ++a) acc[a] = fmaf(wv, xs_nl[a * win + u], acc[a]);
+      }
+#pragma unroll
+      for (int a = 0; a < 8; ++a) acc[a] *= n0;
+    } else {
+      const int wv_i = (o - out0) / 3, m = (o - out0) % 3;
+      for (int u = 0; u < in1; ++u) {
+        const float wv = w1[(size_t)u * out1 + wv_i];
+#pragma unroll
+        for (int a = 0; a < 8; ++a) acc[a] = fmaf(wv, xs_nl[a * win + in0 + 3 * u + m], acc[a]);
+      }
+#pragma unroll
+      for (int a = 0; a < 8; ++a) acc[a] *= n1;
+    }
+#pragma unroll
+    for (int a = 0; a < 8; ++a)
+      if (a0 + a < n_atoms) out[(size_t)(a0 + a) * wout + o] = acc[a];
+  }
+}
+int launch_node_linear(const float* x, int n_atoms, int in0, int in1, int out0, int out1, const float* w, float* out, hipStream_t st) {
+  const size_t smem = (size_t)8 * (in0 + 3 * in1) * sizeof(float);
+  if (smem > 60 * 1024) return -1;
+  hipLaunchKernelGGL(k_node_linear, dim3((n_atoms + 7) / 8), dim3(256), smem, st, x, n_atoms, in0, in1, out0, out1, w, out);
+  return 0;
+}

@@ -223,6 +223,27 @@ class NativeSampler:
             _lib.check(self._lib.jamun_profile_read(self._h, ms, cnt, _stream()))
         return {name: (ms[i], cnt[i]) for i, name in enumerate(_lib.PROF_CLASSES)}
 
+    def build_edges(self, y: torch.Tensor) -> None:
+        """``jamun_build_edges``: radius graph + bonded edges, edge geometry and the radial MLPs' hidden layer for positions
+        ``y`` (``Denoiser.add_edges`` + ``E3Conv.forward`` up to the blocks); the edge table stays inside the sampler."""
+        y = _dev_f32(y, "y")
+        assert y.shape == (self.n_atoms, 3)
+        with torch.cuda.device(self.device):
+            _lib.check(self._lib.jamun_build_edges(self._h, _ptr(y), _stream()))
+
+    def conv_block(self, layer: int, x_in: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """``jamun_conv_block``: one block of ``E3Conv`` on caller-owned node features and the current edge table — layer 0: the
+        initial projector on the sampler's own noise-scaled embedding (``x_in`` must be None); layer l >= 1:
+        ``w_l x + (1 - w_l) ConvBlock_l(s_l x)`` for ``x_in [n_atoms, mul0 + 3 mul1]``."""
+        hp = self._model.hparams_struct
+        out = self._new(self.n_atoms, hp.mul0 + 3 * hp.mul1)
+        if x_in is not None:
+            x_in = _dev_f32(x_in, "x_in")
+            assert x_in.shape == out.shape, x_in.shape
+        with torch.cuda.device(self.device):
+            _lib.check(self._lib.jamun_conv_block(self._h, int(layer), _ptr(x_in), _ptr(out), _stream()))
+        return out
+
     def debug_read(self, what: int, layer: int = 0) -> torch.Tensor:
         width = {0: None, 1: 1, 2: 3}[what]
         if what == 0:
@@ -269,6 +290,33 @@ def radius_graph_edge_index(pos: torch.Tensor, r: float, ptr: torch.Tensor) -> t
     dst = torch.arange(n, device=nbr.device)[:, None].expand(n, s)[mask]
     src = nbr[mask].long()
     return torch.stack([src, dst.long()])
+
+
+def edge_geometry(pos_scaled: torch.Tensor, edge_index: torch.Tensor, radial_cutoff: float, n_basis: int = 32):
+    """``(edge_sh [E,4], radial [E,n_basis])`` of ``E3Conv.forward`` (``arch/e3conv.py:114-123``) for an explicit edge list
+    ``edge_index [2,E]`` (src, dst) and positions already scaled by ``c_in``; see ``jamun_edge_geometry``."""
+    lib = _lib.load()
+    pos = _dev_f32(pos_scaled, "pos_scaled")
+    ei = edge_index.to(pos.device, torch.int64).contiguous()
+    E = int(ei.shape[1])
+    sh = torch.empty((E, 4), dtype=torch.float32, device=pos.device)
+    radial = torch.empty((E, n_basis), dtype=torch.float32, device=pos.device)
+    with torch.cuda.device(pos.device):
+        _lib.check(lib.jamun_edge_geometry(_ptr(pos), _ptr(ei[0].contiguous()), _ptr(ei[1].contiguous()), E, C.c_float(radial_cutoff), n_basis,
+                                           _ptr(sh), _ptr(radial), _stream()))
+    return sh, radial
+
+
+def node_linear(x: torch.Tensor, weight: torch.Tensor, in0: int, in1: int, out0: int, out1: int) -> torch.Tensor:
+    """e3nn ``o3.Linear`` between ``in0 x0e + in1 x1e`` and ``out0 x0e + out1 x1e`` with the flat e3nn weight; see ``jamun_node_linear``."""
+    lib = _lib.load()
+    x = _dev_f32(x, "x")
+    w = _dev_f32(weight, "weight")
+    assert x.shape[1] == in0 + 3 * in1 and w.numel() == in0 * out0 + in1 * out1, (x.shape, w.numel())
+    out = torch.empty((x.shape[0], out0 + 3 * out1), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        _lib.check(lib.jamun_node_linear(_ptr(x), x.shape[0], in0, in1, out0, out1, _ptr(w), _ptr(out), _stream()))
+    return out
 
 
 def scatter_mean(src: torch.Tensor, seg_ptr: torch.Tensor, n_out: int) -> torch.Tensor:

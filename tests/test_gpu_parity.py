@@ -127,6 +127,78 @@ def test_scatter_mean(dev, width):
     assert torch.equal(out, ref)  # fixed row order on both sides -> bit-exact
 
 
+def test_edge_geometry_export_matches_oracle(dev):
+    """``jamun_edge_geometry`` (stand-alone C-ABI operator) vs the oracle's e3nn restatement of
+    ``E3Conv.forward``'s edge features (``arch/e3conv.py:114-123``): spherical harmonics and the Gaussian radial basis."""
+    from jamun_amd import native, synth
+    from oracle import e3
+
+    torch.manual_seed(0)
+    mol = synth.random_chain(40, seed=4)
+    pos = 1.7 * mol["pos"]  # "scaled" positions
+    n = pos.shape[0]
+    src = torch.randint(0, n, (700,))
+    dst = torch.randint(0, n, (700,))
+    src[5] = dst[5]  # a zero-length edge: v / max(|v|, 1e-12) = 0
+    ei = torch.stack([src, dst])
+    cutoff = 0.587
+    sh, radial = native.edge_geometry(pos.to(dev), ei.to(dev), cutoff, 32)
+    vec = pos[src] - pos[dst]
+    sh_ref = e3.spherical_harmonics_01(vec)
+    rad_ref = e3.soft_one_hot_linspace_gaussian(vec.norm(dim=1), 0.0, cutoff, 32)
+    assert sh.shape == (700, 4) and radial.shape == (700, 32)
+    assert (sh.cpu() - sh_ref).abs().max().item() <= 2e-6
+    assert (radial.cpu() - rad_ref).abs().max().item() <= 2e-6
+    assert torch.equal(sh[5].cpu(), torch.tensor([1.0, 0.0, 0.0, 0.0]))
+
+
+@pytest.mark.parametrize("in0,in1,out0,out1", [(120, 32, 120, 32), (56, 0, 120, 32), (120, 32, 152, 32), (0, 32, 0, 1)])
+def test_node_linear_export_matches_oracle(dev, in0, in1, out0, out1):
+    """``jamun_node_linear`` vs the oracle's ``o3.Linear`` (flat e3nn weight, 1/sqrt(fan_in)): the shapes of the path — self
+    interaction, the initial skip (scalars only in, the 1e half of the output stays zero), the head's Linear, the 32x1e -> 1x1e output."""
+    from jamun_amd import native
+    from oracle import e3
+
+    torch.manual_seed(1)
+    n = 77
+    x = torch.randn(n, in0 + 3 * in1)
+    numel = in0 * out0 + in1 * out1
+    w = torch.randn(numel)
+    irr = lambda a, b: [t for t in ((a, 0), (b, 1)) if t[0] > 0]
+    ref = e3.linear(x, w, irr(in0, in1), irr(out0, out1))
+    out = native.node_linear(x.to(dev), w.to(dev), in0, in1, out0, out1).cpu()
+    if in1 == 0 and out1 > 0:  # no path into the 1e outputs: zeros (e3nn leaves outputs without an instruction at zero)
+        assert torch.equal(out[:, out0:], torch.zeros(n, 3 * out1))
+        ref = torch.cat([ref, torch.zeros(n, 3 * out1)], dim=1) if ref.shape[1] == out0 else ref
+    assert out.shape == ref.shape
+    assert (out - ref).abs().max().item() <= 2e-5 * max(ref.abs().max().item(), 1e-6)
+
+
+@pytest.mark.parametrize("kind", ["ag4", "chain17x6"])
+def test_conv_block_export_matches_oracle(dev, golden_dir, kind):
+    """``jamun_build_edges`` + ``jamun_conv_block``: ONE block of the network on caller-owned features — fed with the ORACLE's
+    features of the previous block it must reproduce the oracle's features of this block (cached per-layer outputs)."""
+    from jamun_amd.data import WalkerBatch
+    from jamun_amd.model import Denoiser
+
+    ref = _golden(golden_dir, f"oracle_forward_{kind}")
+    model = Denoiser.from_checkpoint_dict(_ckpt("strong")).to(dev)
+    smp = model.sampler_for(WalkerBatch.from_molecules(_mols(kind)).to(dev), 0.04)
+    with pytest.raises(RuntimeError, match="no edge table"):
+        smp.conv_block(1, ref["x0"].to(dev))
+    smp.build_edges(ref["y"].to(dev))
+    assert torch.equal(smp.debug_read(1).cpu().flatten().long(), ref["deg"])
+    x0 = smp.conv_block(0)
+    assert (x0.cpu() - ref["x0"]).abs().max().item() <= 2e-5 * ref["x0"].abs().max().item()
+    for l in range(1, 6):
+        xl = smp.conv_block(l, ref[f"x{l - 1}"].to(dev))
+        assert (xl.cpu() - ref[f"x{l}"]).abs().max().item() <= 2e-5 * ref[f"x{l}"].abs().max().item(), l
+    with pytest.raises(RuntimeError, match="x_in = NULL"):
+        smp.conv_block(0, ref["x0"].to(dev))
+    with pytest.raises(RuntimeError, match="layer out of range"):
+        smp.conv_block(6, ref["x0"].to(dev))
+
+
 # ---- denoiser forward -----------------------------------------------------------------------------------------------
 
 
