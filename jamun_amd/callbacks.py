@@ -45,8 +45,17 @@ def validate_sample(sample, dataset) -> None:
 
 
 class SaveTrajectoryCallback:
+    """The file set of the reference's ``SaveTrajectory`` metric (``metrics/_save_trajectory.py:17-97``) under
+    ``<output_dir>/<label>/``: ``topology.pdb``; ``predicted_samples/{npy,pdb,dcd}/<i>.*`` per chain and ``joined.*``; with
+    ``save_true_trajectory`` also ``true_samples/{pdb,dcd}/0.*`` = the dataset's own frames (``:22-26,58-62``).
+
+    One deliberate deviation: the reference numbers the ``.pdb`` / ``.dcd`` files of a batch from the running chain count but
+    restarts the ``.npy`` numbering at 0 in every batch (``enumerate(samples_np)`` at ``:81`` against ``start=self.num_chains_seen``
+    at ``:89``), so its ``<i>.npy`` files of batch b overwrite those of batch b-1 and only ``joined.npy`` keeps everything.  Here all
+    three use the running index; ``npy_index_restarts_per_batch=True`` reproduces the reference's files exactly."""
+
     def __init__(self, datasets: Sequence, sample_key: str = "xhat_traj", output_dir: str = "sampler", write_pdb: bool = True,
-                 write_dcd: bool = True, **_):
+                 write_dcd: bool = True, save_true_trajectory: bool = False, npy_index_restarts_per_batch: bool = False, **_):
         labels = []
         self.datasets = {}
         for d in datasets:
@@ -58,6 +67,8 @@ class SaveTrajectoryCallback:
         self.output_dir = output_dir
         self.write_pdb = write_pdb
         self.write_dcd = write_dcd
+        self.save_true_trajectory = save_true_trajectory
+        self.npy_index_restarts_per_batch = npy_index_restarts_per_batch
         self.chains: Dict[str, List[np.ndarray]] = {l: [] for l in self.labels}  # per label: list of [n, T, 3]
         self.num_chains_seen = {l: 0 for l in self.labels}
 
@@ -86,12 +97,24 @@ class SaveTrajectoryCallback:
             mol = self._mol(label)
             if mol is not None and self.write_pdb:  # topology from the dataset's first frame (_save_trajectory.py:53-56)
                 save_pdb(os.path.join(self.output_dir, label, "topology.pdb"), mol, mol["pos"][None])
+            if self.save_true_trajectory:  # the dataset's own frames as true_samples/{pdb,dcd}/0.* (_save_trajectory.py:22-26,58-62)
+                from .pdb import save_dcd
 
-    def _write_chain(self, label: str, index, arr: np.ndarray) -> None:
+                ds = self.datasets[label]
+                xyz = getattr(ds, "xyz", None)
+                frames = (xyz if xyz is not None else mol["pos"][None]).detach().cpu().numpy() if mol is not None or xyz is not None else None
+                if frames is not None:
+                    for ext in ("pdb", "dcd"):
+                        os.makedirs(os.path.join(self.output_dir, label, "true_samples", ext), exist_ok=True)
+                    if mol is not None:
+                        save_pdb(os.path.join(self.output_dir, label, "true_samples", "pdb", "0.pdb"), mol, frames)
+                    save_dcd(os.path.join(self.output_dir, label, "true_samples", "dcd", "0.dcd"), frames)
+
+    def _write_chain(self, label: str, index, arr: np.ndarray, npy_index=None) -> None:
         """arr [n, T, 3] nm -> <index>.npy / .pdb / .dcd"""
         from .pdb import save_dcd, save_pdb
 
-        np.save(self.filename_pred(label, index, "npy"), arr)
+        np.save(self.filename_pred(label, index if npy_index is None else npy_index, "npy"), arr)
         frames = np.transpose(arr, (1, 0, 2))  # "atoms frames coords -> frames atoms coords" (utils/mdtraj.py:17-21)
         mol = self._mol(label)
         if self.write_pdb and mol is not None:
@@ -118,7 +141,7 @@ class SaveTrajectoryCallback:
             start = len(self.chains[label])
             self.chains[label].extend(new)
             for i, arr in enumerate(new, start=start):
-                self._write_chain(label, i, arr)
+                self._write_chain(label, i, arr, npy_index=(i - start) if self.npy_index_restarts_per_batch else None)
             if self.chains[label]:
                 self._write_chain(label, "joined", np.concatenate(self.chains[label], axis=1))  # "b n t c -> n (b t) c"
             self.num_chains_seen[label] = len(self.chains[label])

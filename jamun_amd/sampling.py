@@ -411,6 +411,7 @@ class Sampler:
             for batch_idx in range(num_batches):
                 self.global_step = batch_idx
                 self.call("on_after_sample_batch", sample=[], sampler=self)
+                self.log("sampler/global_step", batch_idx)
             self.call("on_sample_end", sampler=self)
             return
         init_graphs = init_graphs.to(self.device)
@@ -433,4 +434,5 @@ class Sampler:
                     y_init = model_wrapped.sample_initial_noisy_positions()
                     v_init = "gaussian"
                 self.call("on_after_sample_batch", sample=samples, sampler=self)
+                self.log("sampler/global_step", batch_idx)  # (_sampler.py:96)
         self.call("on_sample_end", sampler=self)

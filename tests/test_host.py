@@ -438,6 +438,41 @@ def test_save_trajectory_writes_reference_file_set(tmp_path):
         cb.on_after_sample_batch([SampleGraph(dataset_label="other", xhat_traj=torch.zeros(10, T, 3))], FakeSampler())
 
 
+def test_save_trajectory_true_samples_and_reference_npy_numbering(tmp_path):
+    """``save_true_trajectory`` writes the dataset's own frames as true_samples/{pdb,dcd}/0.* (_save_trajectory.py:22-26,58-62);
+    ``npy_index_restarts_per_batch`` reproduces the reference's per-batch restart of the .npy numbering (:81 vs :89): after two
+    batches of three chains the reference has 0..2.npy (holding batch 1) but 0..5.pdb / .dcd."""
+    from jamun_amd import pdb, synth
+    from jamun_amd.callbacks import SaveTrajectoryCallback
+    from jamun_amd.sampling import SampleGraph
+
+    mol = dict(synth.ag_dipeptide(), elements=["N", "C", "C", "C", "O", "N", "C", "C", "O", "O"], residue_ids=[1] * 5 + [2] * 5)
+    src = str(tmp_path / "uncapped_AG.pdb")
+    pdb.save_pdb(src, mol, mol["pos"][None])
+    ds = pdb.create_dataset_from_pdbs([src])
+
+    class FakeSampler:
+        device = torch.device("cpu"); is_global_zero = True; world_size = 1; global_step = 0
+
+    out = str(tmp_path / "sampler")
+    cb = SaveTrajectoryCallback(ds, output_dir=out, save_true_trajectory=True, npy_index_restarts_per_batch=True)
+    cb.on_sample_start(FakeSampler())
+    base = ds[0].molecule
+    mk = lambda w: SampleGraph(dataset_label="uncapped_AG", atom_type_index=base["atom_type_index"], xhat_traj=base["pos"][:, None, :] + torch.full((10, 2, 3), float(w)))
+    cb.on_after_sample_batch([mk(0), mk(1), mk(2)], FakeSampler())
+    cb.on_after_sample_batch([mk(3), mk(4), mk(5)], FakeSampler())
+    root = os.path.join(out, "uncapped_AG")
+    have = sorted(os.path.relpath(os.path.join(dp, f), root) for dp, _, fs in os.walk(root) for f in fs)
+    want = (["topology.pdb", "true_samples/pdb/0.pdb", "true_samples/dcd/0.dcd"]
+            + [f"predicted_samples/{e}/{i}.{e}" for e in ("dcd", "pdb") for i in list(range(6)) + ["joined"]]
+            + [f"predicted_samples/npy/{i}.npy" for i in [0, 1, 2, "joined"]])
+    assert have == sorted(want)
+    assert np.allclose(np.load(os.path.join(root, "predicted_samples/npy/1.npy")), mk(4)["xhat_traj"].numpy())  # batch 1 overwrote batch 0
+    assert np.load(os.path.join(root, "predicted_samples/npy/joined.npy")).shape == (10, 12, 3)
+    true = _read_dcd(os.path.join(root, "true_samples/dcd/0.dcd"))
+    assert true.shape == (1, 10, 3) and np.allclose(true[0], 10.0 * base["pos"].numpy(), atol=1e-4)
+
+
 _WORKER2 = r'''
 import os, sys, json
 sys.path.insert(0, sys.argv[1])
