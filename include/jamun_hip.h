@@ -51,6 +51,9 @@ typedef struct jamun_hparams {
   float act_scalar_const;         /* e3nn normalize2mom(LeakyReLU(0.01))  = 1.4162684 */
   float act_gate_const;           /* e3nn normalize2mom(sigmoid)          = 1.8467055 */
   float w3j_111_sign;             /* +1: wigner_3j(1,1,1) = +eps/sqrt(6) (e3nn 0.5.4)   */
+  int32_t separable;              /* hidden_layer_factory.conv: 0 jamun.e3tools.nn.Conv (e3conv.yaml), 1 SeparableConv
+                                     (e3conv_separable.yaml; src/jamun/e3tools/nn/_conv.py:122-135, _tensor_product.py:8-58):
+                                     expects <block>.gated_conv.f.f.tp.lin.weight and a radial_nn.3 of 2 n0 + 3 n1 rows */
 } jamun_hparams;
 
 /* Static description of the walker batch — what torch_geometric's Batch.from_data_list gives the

@@ -33,6 +33,7 @@ class jamun_hparams(C.Structure):
         ("act_scalar_const", C.c_float),
         ("act_gate_const", C.c_float),
         ("w3j_111_sign", C.c_float),
+        ("separable", C.c_int32),
     ]
 
 

@@ -109,10 +109,15 @@ struct DgDev {
   int sB = 0;
   float hmax2 = 2.f;
 };
+struct SepDev {
+  float *w2p = nullptr, *wl0 = nullptr, *wl1 = nullptr;  // null: not a SeparableConv layer
+  int n0 = 0, n1 = 0, NWp = 0;
+};
 struct LayerDev {
   ConvProblemDev p0, p1;
   FusedDev fu;
   DgDev dg;
+  SepDev sep;
   std::vector<float> w1r_h, cmask_h;  // radial MLP first layer (uploaded for all layers together: jamun_sampler::w1r_all)
   float* tt = nullptr;  // initial projector only: [k][distinct embedding row][32 (nt0 + 1)] input-times-weight table
   int tt_row = 0, tt_U = 0;
@@ -340,6 +345,7 @@ struct jamun_sampler {
   int2 *dg_tile_atoms = nullptr, *dg_tile_span = nullptr;
   int4* dg_segs = nullptr;
   int* dg_atom_nslab = nullptr;
+  float* sep_w = nullptr;  // SeparableConv: [n_atoms * S][NWp] per-edge depth-wise weights of the layer at hand
   float* dg_dump = nullptr;  // diagnostic A-tile dump (JAMUN_DG_DUMP, -DJAMUN_DUMP builds)
   float* dg_T = nullptr;  // [n_k][n_atoms][32] pre-pass product of a hidden layer (k_tprod), reused by every layer
   float *x_emb = nullptr, *mu = nullptr;
@@ -368,18 +374,181 @@ struct jamun_sampler {
     hipFree(dg_dump); hipFree(dg_tile_atoms); hipFree(dg_tile_span); hipFree(dg_segs); hipFree(dg_atom_nslab); hipFree(dg_T);
     for (auto& L : layers) {
       free_problem(L.p0); free_problem(L.p1); free_fused(L.fu); free_dg(L.dg);
+      hipFree(L.sep.w2p); hipFree(L.sep.wl0); hipFree(L.sep.wl1);
       hipFree(L.wcat0); hipFree(L.wcat1); hipFree(L.mix); hipFree(L.tt); hipFree(L.tt2);
     }
     hipFree(w_gate); hipFree(w_vec); hipFree(w_out);
     hipFree(yc); hipFree(h); hipFree(partial0); hipFree(partial1); hipFree(g); hipFree(tmp);
     hipFree(xhat_buf); hipFree(score_buf); hipFree(psi); hipFree(deg); hipFree(esrc); hipFree(egeo);
     for (float* p : x) hipFree(p);
-    hipFree(counter);
+    hipFree(counter); hipFree(sep_w);
     for (hipEvent_t e : ev_pool) hipEventDestroy(e);
   }
 };
 
 namespace {
+
+void build_layer_common(const jamun_model& m, const std::string& prefix, const std::vector<InBlock>& in_blocks, const std::vector<double>& s_in,
+                        LayerDev& L, int in0, int in1) {
+  const jamun_hparams& hp = m.hp;
+  const int mul0 = hp.mul0, mul1 = hp.mul1, H = hp.edge_attr_dim;
+  // ---- radial MLP first layer: split into the constant bonded part and the radial part
+  const auto& W1 = m.get(prefix + ".gated_conv.f.f.radial_nn.0.weight", (int64_t)H * H);
+  const auto& b1 = m.get(prefix + ".gated_conv.f.f.radial_nn.0.bias", H);
+  const int nb = H / 2, nr = (H + 1) / 2;
+  const auto& Eb = m.get("embed_bondedness.weight", 2 * nb);
+  std::vector<float> w1r((size_t)H * nr), cmask(2 * (size_t)H);
+  for (int k = 0; k < H; ++k) {
+    for (int r = 0; r < nr; ++r) w1r[(size_t)r * H + k] = W1[(size_t)k * H + nb + r];  // [basis][hidden]: lane = hidden unit
+    for (int mk = 0; mk < 2; ++mk) {
+      double s = b1[k];
+      for (int c = 0; c < nb; ++c) s += (double)W1[(size_t)k * H + c] * Eb[(size_t)mk * nb + c];
+      cmask[(size_t)mk * H + k] = (float)s;
+    }
+  }
+  L.w1r_h = w1r;
+  L.cmask_h = cmask;
+  {
+    // static bound of |h~| = |SiLU(c_mask + W1[:, radial part] . radial(d))| over the layer: the Gaussian basis values are
+    // positive and sum to at most sqrt(pi) / 1.12 < 1.6 at any distance, |SiLU(z)| <= max(|z|, 0.2785); the bias row is 1
+    double hm = 1.0;
+    for (int k = 0; k < H; ++k) {
+      double wm = 0;
+      for (int r = 0; r < nr; ++r) wm = std::max(wm, std::fabs((double)W1[(size_t)k * H + nb + r]));
+      const double z = std::max(std::fabs((double)cmask[k]), std::fabs((double)cmask[(size_t)H + k])) + 1.6 * wm;
+      hm = std::max(hm, z);
+    }
+    L.dg.hmax2 = (float)(2.0 * hm * 1.0001);
+  }
+
+  // ---- o3.Linear skip (in -> hidden) and self-interaction (hidden -> hidden)  (_interaction.py:23-30)
+  int64_t n_skip = 0;
+  for (auto& ib : in_blocks) n_skip += (int64_t)ib.mul * (ib.l == 0 ? mul0 : mul1);
+  const auto& Wskip = m.get(prefix + ".gated_conv.skip_connection.weight", n_skip);
+  const auto& Wself = m.get(prefix + ".gated_conv.self_interaction.weight", (int64_t)mul0 * mul0 + (int64_t)mul1 * mul1);
+  std::vector<float> ws0((size_t)std::max(in0, 1) * mul0, 0.f), ws1((size_t)std::max(in1, 1) * std::max(mul1, 1), 0.f);
+  {
+    int64_t o = 0;
+    int u0 = 0, u1 = 0;
+    for (auto& ib : in_blocks) {
+      if (ib.l == 0) {
+        for (int u = 0; u < ib.mul; ++u, ++u0)
+          for (int w = 0; w < mul0; ++w)
+            ws0[(size_t)u0 * mul0 + w] = (float)((double)Wskip[o + (int64_t)u * mul0 + w] / std::sqrt((double)in0) * s_in[ib.ch0 + u]);
+        o += (int64_t)ib.mul * mul0;
+      } else {
+        for (int u = 0; u < ib.mul; ++u, ++u1)
+          for (int w = 0; w < mul1; ++w)
+            ws1[(size_t)u1 * mul1 + w] = (float)((double)Wskip[o + (int64_t)u * mul1 + w] / std::sqrt((double)in1) * s_in[ib.ch0 + u]);
+        o += (int64_t)ib.mul * mul1;
+      }
+    }
+  }
+  std::vector<float> wf0((size_t)mul0 * mul0), wf1((size_t)std::max(mul1 * mul1, 1));
+  for (int i = 0; i < mul0 * mul0; ++i) wf0[i] = (float)((double)Wself[i] / std::sqrt((double)mul0));
+  for (int i = 0; i < mul1 * mul1; ++i) wf1[i] = (float)((double)Wself[(size_t)mul0 * mul0 + i] / std::sqrt((double)mul1));
+  // concatenate along K ([self ; skip]) and pack as MFMA B fragments for k_node_update
+  auto pack_cat = [](const std::vector<float>& wself, int ks, const std::vector<float>& wskip, int kk, int ncol, int& Kp) {
+    Kp = (ks + kk + 7) & ~7;
+    const int nt = (ncol + 31) / 32, nsg = Kp / 8;
+    std::vector<float4> out((size_t)nt * nsg * 64, make_float4(0.f, 0.f, 0.f, 0.f));
+    for (int t = 0; t < nt; ++t)
+      for (int sg = 0; sg < nsg; ++sg)
+        for (int lane = 0; lane < 64; ++lane) {
+          const int hh = lane >> 5, c = t * 32 + (lane & 31);
+          float v[4] = {0.f, 0.f, 0.f, 0.f};
+          for (int st = 0; st < 4; ++st) {
+            const int row = 2 * (4 * sg + st) + hh;
+            if (c >= ncol) continue;
+            if (row < ks) v[st] = wself[(size_t)row * ncol + c];
+            else if (row < ks + kk) v[st] = wskip[(size_t)(row - ks) * ncol + c];
+          }
+          out[((size_t)t * nsg + sg) * 64 + lane] = make_float4(v[0], v[1], v[2], v[3]);
+        }
+    return out;
+  };
+  L.wcat0 = dev_upload(pack_cat(wf0, mul0, ws0, in0, mul0, L.K0p));
+  L.wcat1 = dev_upload(pack_cat(wf1, mul1, ws1, in1, std::max(mul1, 1), L.K1p));
+}
+
+// SeparableConv block (src/jamun/e3tools/nn/_tensor_product.py:27-47): depth-wise "uvu" instructions in e3nn order — for every
+// input block, for sh in (0e, 1e), for l_out = |l1 - l2| .. l1 + l2 kept when it occurs in the output irreps or is 0e — each with
+// mul_in weights and its own block of irreps_out_dtp; then o3.Linear(irreps_out_dtp -> G0 x0e + G1 x1e).  Packed in the canonical
+// order of jamun_sepconv.hip: weights [A | B | C | D | E], Linear rows scalars [D0 | D3], vectors [D1 | D2 | D4].
+LayerDev build_layer_separable(const jamun_model& m, const std::string& prefix, const std::vector<InBlock>& in_blocks, const std::vector<double>& s_in,
+                               LayerDev& L) {
+  const jamun_hparams& hp = m.hp;
+  const int mul0 = hp.mul0, mul1 = hp.mul1, G0 = mul0 + mul1, G1 = mul1, H = hp.edge_attr_dim;
+  int n0 = 0, n1 = 0;
+  for (auto& ib : in_blocks) (ib.l == 0 ? n0 : n1) += ib.mul;
+  struct Tri { int kind, u0, mul; int64_t woff, loff; };  // kind: 0 A, 1 B, 2 C, 3 D, 4 E; u0: first canonical channel; offsets: radial_nn.3 row, lin weight
+  std::vector<Tri> tri;
+  int64_t woff = 0, loff = 0;
+  int u0 = 0, u1 = 0;
+  for (auto& ib : in_blocks) {
+    if (ib.l == 0) {
+      tri.push_back({0, u0, ib.mul, woff, loff}); woff += ib.mul; loff += (int64_t)ib.mul * G0;
+      tri.push_back({1, u0, ib.mul, woff, loff}); woff += ib.mul; loff += (int64_t)ib.mul * G1;
+      u0 += ib.mul;
+    } else {
+      tri.push_back({2, u1, ib.mul, woff, loff}); woff += ib.mul; loff += (int64_t)ib.mul * G1;
+      tri.push_back({3, u1, ib.mul, woff, loff}); woff += ib.mul; loff += (int64_t)ib.mul * G0;
+      tri.push_back({4, u1, ib.mul, woff, loff}); woff += ib.mul; loff += (int64_t)ib.mul * G1;
+      u1 += ib.mul;
+    }
+  }
+  const auto& W3 = m.get(prefix + ".gated_conv.f.f.radial_nn.3.weight", woff * H);
+  const auto& b3 = m.get(prefix + ".gated_conv.f.f.radial_nn.3.bias", woff);
+  const auto& WL = m.get(prefix + ".gated_conv.f.f.tp.lin.weight", loff);
+  // input noise scaling per canonical channel
+  std::vector<double> s0(n0, 1.0), s1(n1, 1.0);
+  {
+    int a0 = 0, a1 = 0;
+    for (auto& ib : in_blocks)
+      for (int u = 0; u < ib.mul; ++u) (ib.l == 0 ? s0[a0++] : s1[a1++]) = s_in[ib.ch0 + u];
+  }
+  const int NW = 2 * n0 + 3 * n1, NWp = (NW + 31) & ~31, n_ct = NWp / 32;
+  const int base[5] = {0, n0, 2 * n0, 2 * n0 + n1, 2 * n0 + 2 * n1};
+  // path weight sqrt(2 l_out + 1) x Clebsch-Gordan factor x the sqrt(3) of Y_1 = sqrt(3) v:  A 1, B sqrt(3) (delta/sqrt(3) sqrt(3) sqrt(3)),
+  // C 1 (sqrt(3) delta/sqrt(3)), D 1 (delta/sqrt(3) sqrt(3)), E sign sqrt(3) (eps/sqrt(6)) sqrt(3) = sign sqrt(3/2)
+  const double fac[5] = {1.0, std::sqrt(3.0), 1.0, 1.0, (double)hp.w3j_111_sign * std::sqrt(1.5)};
+  std::vector<double> w2c((size_t)(H + 1) * NWp, 0.0);
+  for (const Tri& t : tri)
+    for (int u = 0; u < t.mul; ++u) {
+      const double sc = fac[t.kind] * (t.kind < 2 ? s0[t.u0 + u] : s1[t.u0 + u]);
+      const int col = base[t.kind] + t.u0 + u;
+      for (int k = 0; k <= H; ++k)
+        w2c[(size_t)k * NWp + col] = sc * (k < H ? (double)W3[(size_t)(t.woff + u) * H + k] : (double)b3[t.woff + u]);
+    }
+  std::vector<float> w2p((size_t)33 * n_ct * 64, 0.f);
+  for (int s = 0; s < 33; ++s)
+    for (int ct = 0; ct < n_ct; ++ct)
+      for (int lane = 0; lane < 64; ++lane) {
+        const int k = 2 * s + (lane >> 5), col = 32 * ct + (lane & 31);
+        if (k <= H) w2p[((size_t)s * n_ct + ct) * 64 + lane] = (float)w2c[(size_t)k * NWp + col];
+      }
+  const int K0 = n0 + n1, K1 = n0 + 2 * n1;
+  std::vector<float> wl0((size_t)K0 * G0, 0.f), wl1((size_t)std::max(K1 * G1, 1), 0.f);
+  for (const Tri& t : tri)
+    for (int u = 0; u < t.mul; ++u) {
+      const bool scalar_out = t.kind == 0 || t.kind == 3;
+      const int G = scalar_out ? G0 : G1;
+      const int row = t.kind == 0 ? t.u0 + u : t.kind == 3 ? n0 + t.u0 + u : t.kind == 1 ? t.u0 + u : t.kind == 2 ? n0 + t.u0 + u : n0 + n1 + t.u0 + u;
+      const double nrm = 1.0 / std::sqrt((double)(scalar_out ? K0 : K1));
+      for (int w = 0; w < G; ++w) (scalar_out ? wl0 : wl1)[(size_t)row * G + w] = (float)((double)WL[t.loff + (int64_t)u * G + w] * nrm);
+    }
+  L.sep.w2p = dev_upload(w2p);
+  L.sep.wl0 = dev_upload(wl0);
+  L.sep.wl1 = dev_upload(wl1);
+  L.sep.n0 = n0; L.sep.n1 = n1; L.sep.NWp = NWp;
+  L.p0.nt = (G0 + 31) / 32;  // (the node update reads the slab widths from here)
+  L.p1.nt = (G1 + 31) / 32;
+  L.p0.planes = 1; L.p1.planes = 3;
+  L.in0 = n0; L.in1 = n1; L.XSin = n0 + 3 * n1;
+  L.tp_numel = woff;
+  build_layer_common(m, prefix, in_blocks, s_in, L, n0, n1);
+  return L;
+}
 
 LayerDev build_layer(const jamun_model& m, const std::string& prefix, const std::vector<InBlock>& in_blocks,
                      const std::vector<double>& s_in, int n_slices, int fused_JR, int fused_span,
@@ -404,6 +573,7 @@ LayerDev build_layer(const jamun_model& m, const std::string& prefix, const std:
         (lo == 0 ? sum0 : sum1) += in_blocks[b].mul;
       }
   L.tp_numel = off;
+  if (hp.separable) return build_layer_separable(m, prefix, in_blocks, s_in, L);
   const auto& W3 = m.get(prefix + ".gated_conv.f.f.radial_nn.3.weight", off * H);
   const auto& b3 = m.get(prefix + ".gated_conv.f.f.radial_nn.3.bias", off);
   const double c0 = std::sqrt(1.0 / sum0), c1 = sum1 > 0 ? std::sqrt(3.0 / sum1) : 0.0;
@@ -825,83 +995,7 @@ LayerDev build_layer(const jamun_model& m, const std::string& prefix, const std:
     }
   }
 
-  // ---- radial MLP first layer: split into the constant bonded part and the radial part
-  const auto& W1 = m.get(prefix + ".gated_conv.f.f.radial_nn.0.weight", (int64_t)H * H);
-  const auto& b1 = m.get(prefix + ".gated_conv.f.f.radial_nn.0.bias", H);
-  const int nb = H / 2, nr = (H + 1) / 2;
-  const auto& Eb = m.get("embed_bondedness.weight", 2 * nb);
-  std::vector<float> w1r((size_t)H * nr), cmask(2 * (size_t)H);
-  for (int k = 0; k < H; ++k) {
-    for (int r = 0; r < nr; ++r) w1r[(size_t)r * H + k] = W1[(size_t)k * H + nb + r];  // [basis][hidden]: lane = hidden unit
-    for (int mk = 0; mk < 2; ++mk) {
-      double s = b1[k];
-      for (int c = 0; c < nb; ++c) s += (double)W1[(size_t)k * H + c] * Eb[(size_t)mk * nb + c];
-      cmask[(size_t)mk * H + k] = (float)s;
-    }
-  }
-  L.w1r_h = w1r;
-  L.cmask_h = cmask;
-  {
-    // static bound of |h~| = |SiLU(c_mask + W1[:, radial part] . radial(d))| over the layer: the Gaussian basis values are
-    // positive and sum to at most sqrt(pi) / 1.12 < 1.6 at any distance, |SiLU(z)| <= max(|z|, 0.2785); the bias row is 1
-    double hm = 1.0;
-    for (int k = 0; k < H; ++k) {
-      double wm = 0;
-      for (int r = 0; r < nr; ++r) wm = std::max(wm, std::fabs((double)W1[(size_t)k * H + nb + r]));
-      const double z = std::max(std::fabs((double)cmask[k]), std::fabs((double)cmask[(size_t)H + k])) + 1.6 * wm;
-      hm = std::max(hm, z);
-    }
-    L.dg.hmax2 = (float)(2.0 * hm * 1.0001);
-  }
-
-  // ---- o3.Linear skip (in -> hidden) and self-interaction (hidden -> hidden)  (_interaction.py:23-30)
-  int64_t n_skip = 0;
-  for (auto& ib : in_blocks) n_skip += (int64_t)ib.mul * (ib.l == 0 ? mul0 : mul1);
-  const auto& Wskip = m.get(prefix + ".gated_conv.skip_connection.weight", n_skip);
-  const auto& Wself = m.get(prefix + ".gated_conv.self_interaction.weight", (int64_t)mul0 * mul0 + (int64_t)mul1 * mul1);
-  std::vector<float> ws0((size_t)std::max(in0, 1) * mul0, 0.f), ws1((size_t)std::max(in1, 1) * std::max(mul1, 1), 0.f);
-  {
-    int64_t o = 0;
-    int u0 = 0, u1 = 0;
-    for (auto& ib : in_blocks) {
-      if (ib.l == 0) {
-        for (int u = 0; u < ib.mul; ++u, ++u0)
-          for (int w = 0; w < mul0; ++w)
-            ws0[(size_t)u0 * mul0 + w] = (float)((double)Wskip[o + (int64_t)u * mul0 + w] / std::sqrt((double)in0) * s_in[ib.ch0 + u]);
-        o += (int64_t)ib.mul * mul0;
-      } else {
-        for (int u = 0; u < ib.mul; ++u, ++u1)
-          for (int w = 0; w < mul1; ++w)
-            ws1[(size_t)u1 * mul1 + w] = (float)((double)Wskip[o + (int64_t)u * mul1 + w] / std::sqrt((double)in1) * s_in[ib.ch0 + u]);
-        o += (int64_t)ib.mul * mul1;
-      }
-    }
-  }
-  std::vector<float> wf0((size_t)mul0 * mul0), wf1((size_t)std::max(mul1 * mul1, 1));
-  for (int i = 0; i < mul0 * mul0; ++i) wf0[i] = (float)((double)Wself[i] / std::sqrt((double)mul0));
-  for (int i = 0; i < mul1 * mul1; ++i) wf1[i] = (float)((double)Wself[(size_t)mul0 * mul0 + i] / std::sqrt((double)mul1));
-  // concatenate along K ([self ; skip]) and pack as MFMA B fragments for k_node_update
-  auto pack_cat = [](const std::vector<float>& wself, int ks, const std::vector<float>& wskip, int kk, int ncol, int& Kp) {
-    Kp = (ks + kk + 7) & ~7;
-    const int nt = (ncol + 31) / 32, nsg = Kp / 8;
-    std::vector<float4> out((size_t)nt * nsg * 64, make_float4(0.f, 0.f, 0.f, 0.f));
-    for (int t = 0; t < nt; ++t)
-      for (int sg = 0; sg < nsg; ++sg)
-        for (int lane = 0; lane < 64; ++lane) {
-          const int hh = lane >> 5, c = t * 32 + (lane & 31);
-          float v[4] = {0.f, 0.f, 0.f, 0.f};
-          for (int st = 0; st < 4; ++st) {
-            const int row = 2 * (4 * sg + st) + hh;
-            if (c >= ncol) continue;
-            if (row < ks) v[st] = wself[(size_t)row * ncol + c];
-            else if (row < ks + kk) v[st] = wskip[(size_t)(row - ks) * ncol + c];
-          }
-          out[((size_t)t * nsg + sg) * 64 + lane] = make_float4(v[0], v[1], v[2], v[3]);
-        }
-    return out;
-  };
-  L.wcat0 = dev_upload(pack_cat(wf0, mul0, ws0, in0, mul0, L.K0p));
-  L.wcat1 = dev_upload(pack_cat(wf1, mul1, ws1, in1, std::max(mul1, 1), L.K1p));
+  build_layer_common(m, prefix, in_blocks, s_in, L, in0, in1);
   return L;
 }
 
@@ -954,7 +1048,16 @@ void run_layer(jamun_sampler* s, size_t l, const float* x_in, int XSin, float* x
     launch_edge_h(s->deg, s->esrc, s->egeo, s->n_atoms, s->S, s->w1r_all + l * 64 * 32, s->cmask_all + l * 128, 1, s->mu, s->rb_step, s->h,
                   s->h_stride, s->h_kstride, st);
   }
-    if (l == 0 && s->initv_on) {
+    if (L.sep.w2p) {
+      SepArgs f{};
+      f.deg = s->deg; f.esrc = s->esrc; f.egeo = s->egeo; f.h = h_l; f.h_kstride = s->h_kstride; f.x = x_in;
+      f.n_atoms = s->n_atoms; f.S = s->S; f.XS = XSin; f.n_slots = (int64_t)s->n_atoms * s->S;
+      f.n0 = L.sep.n0; f.n1 = L.sep.n1; f.NWp = L.sep.NWp; f.w2p = L.sep.w2p; f.w = s->sep_w; f.wl0 = L.sep.wl0; f.wl1 = L.sep.wl1;
+      f.G0 = s->hp.mul0 + s->hp.mul1; f.G1 = s->hp.mul1; f.nt0 = L.p0.nt; f.nt1 = L.p1.nt;
+      f.partial0 = s->partial0; f.partial1 = s->partial1;
+      ProfScope ps(s, l == 0 ? JAMUN_PROF_CONV0_INIT : JAMUN_PROF_CONV0, st);
+      if (launch_sep_conv(f, st) != 0) throw Err(JAMUN_ERR_INVALID, "separable conv launch failed (irreps not supported)");
+    } else if (l == 0 && s->initv_on) {
       InitVArgs f{};
       f.deg = s->deg; f.esrc = s->esrc; f.egeo = s->egeo; f.h = h_l; f.h_kstride = s->h_kstride;
       f.n_pad = s->n_pad; f.S = s->S; f.PMAX = (s->S + 3) & ~3; f.RS = s->dg_RS; f.nt0 = L.p0.nt; f.nbuf = s->initv_nbuf;
@@ -1031,6 +1134,7 @@ void run_layer(jamun_sampler* s, size_t l, const float* x_in, int XSin, float* x
     const bool dg_layer = (l > 0 && s->dg_on) || (l == 0 && s->initv_on);  // (slabs of the dg tile plan)
     n.atom_nslab = dg_layer ? s->dg_atom_nslab : (L.fu.wpack ? s->atom_nslab : nullptr);
     n.max_slabs = dg_layer ? s->dg_n_slabs : (L.fu.wpack ? s->n_slabs : s->n_slices);
+    if (L.sep.w2p) { n.n_slices = 1; n.atom_nslab = nullptr; n.max_slabs = 1; }  // SeparableConv writes the summed messages as ONE slab
     {
       ProfScope ps(s, JAMUN_PROF_NODE, st);
       launch_node_update(n, st);
@@ -1200,7 +1304,7 @@ SegPlan plan_segments(int cus, int ng, int n_k, int N, const std::vector<int2>& 
 extern "C" {
 
 const char* jamun_last_error(void) { return g_err.c_str(); }
-int jamun_version(void) { return 1; }
+int jamun_version(void) { return 2; }
 
 int jamun_model_create(const jamun_hparams* hp, const jamun_tensor* tensors, int32_t n_tensors, jamun_model** out) {
   return guarded([&] {
@@ -1573,6 +1677,11 @@ int jamun_sampler_create(const jamun_model* m, float sigma, const jamun_topology
     const size_t n_part = (size_t)std::max(std::max(s->n_slices, s->n_slabs), s->dg_n_slabs);
     s->partial0 = dev_alloc<float>(n_part * s->n_pad * nt0 * 32);
     s->partial1 = dev_alloc<float>(n_part * s->n_pad * 3 * nt1 * 32);
+    {
+      int nwp = 0;
+      for (auto& L : s->layers) nwp = std::max(nwp, L.sep.NWp);
+      if (nwp > 0) s->sep_w = dev_alloc<float>(NS * (size_t)nwp);
+    }
     s->g = dev_alloc<float>((size_t)N * 3);
     s->tmp = dev_alloc<float>((size_t)N * 3);
     s->xhat_buf = dev_alloc<float>((size_t)N * 3);
@@ -1584,7 +1693,7 @@ int jamun_sampler_create(const jamun_model* m, float sigma, const jamun_topology
     s->flop_ref_per_edge = 0;
     s->flop_exec = 0;
     for (auto& L : s->layers) {
-      s->flop_ref_per_edge += 2LL * 64 * 64 + 130LL * L.tp_numel;  // SURVEY.md §8 d
+      s->flop_ref_per_edge += 2LL * 64 * 64 + 130LL * L.tp_numel;  // SURVEY.md §8 d (SeparableConv: tp_numel = the 336 depth-wise weights)
       if (s->dg_on && &L != &s->layers[0]) {
         // per (tile, k) in k_conv_dg: fp32 path 476 units of v_mfma_f32_32x32x2 (4096 FLOP); f16x3 path 150 v_mfma_f32_32x32x16_f16
         // (32768 FLOP: 50 groups of 16 inputs x 3 products) + 72 v_mfma_f32_16x16x32_f16 (16384 FLOP); + 60 fp32 units per (32 atoms, k)
@@ -1593,6 +1702,7 @@ int jamun_sampler_create(const jamun_model* m, float sigma, const jamun_topology
         s->conv_flop_exec_launch = ((int64_t)s->dg_n_tiles * per_tile_k + (int64_t)((s->n_atoms + 31) / 32) * 60 * 4096) * (hp.edge_attr_dim + 1);
         s->flop_exec += s->conv_flop_exec_launch;
       }
+      else if (L.sep.w2p) s->flop_exec += 2LL * (int64_t)NS * 66 * L.sep.NWp;  // the per-edge weight GEMM (the rest is VALU work per edge)
       else if (L.fu.wpack) s->flop_exec += (int64_t)s->n_ftiles * (hp.edge_attr_dim + 1) * L.fu.mfma_per_k * 4096;  // 32x32x2 MFMA = 4096 FLOP
       else s->flop_exec += 2LL * s->n_pad * (1LL * L.p0.K * L.p0.nt * 32 + 3LL * L.p1.K * L.p1.nt * 32);
     }

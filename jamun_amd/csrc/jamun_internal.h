@@ -149,6 +149,28 @@ struct InitVArgs {
   float* partial1;      // [slab][n_pad][3][32]
 };
 
+// SeparableConv (jamun_sepconv.hip): per-edge depth-wise weights from one GEMM, per-destination sums, point-wise Linear
+struct SepArgs {
+  const int* deg;
+  const int* esrc;
+  const float4* egeo;
+  const float* h;  // [hidden unit k (65 rows)][h_kstride]
+  size_t h_kstride;
+  const float* x;  // [n_atoms][XS] input features (scalars first, then vectors [u][3])
+  int n_atoms, S, XS;
+  int64_t n_slots;  // n_atoms * S
+  int n0, n1;       // scalar / vector input channels
+  int NWp;          // depth-wise weights per edge (2 n0 + 3 n1) padded to a multiple of 32
+  const float* w2p;  // [33 pairs of hidden units][NWp / 32 column tiles][64 lanes]: lane (c, hh) -> W2~[k = 2 s + hh][32 ct + c]
+  float* w;          // [n_slots][NWp] per-edge weights (work buffer)
+  const float* wl0;  // [n0 + n1][G0]      point-wise Linear, scalar outputs (1 / sqrt(fan_in) folded)
+  const float* wl1;  // [n0 + 2 n1][G1]    vector outputs
+  int G0, G1, nt0, nt1;
+  float* partial0;  // [n_pad][nt0 * 32]  (one slab)
+  float* partial1;  // [n_pad][3][nt1 * 32]
+};
+int launch_sep_conv(const SepArgs& a, hipStream_t st);
+
 struct NodeArgs {
   const float* partial0;  // [n_slices][n_pad][nt0*32]
   const float* partial1;  // [n_slices][n_pad][3][nt1*32]

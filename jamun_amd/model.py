@@ -70,18 +70,23 @@ class Denoiser:
 
         hp = to_plain(ckpt["hyper_parameters"])
         arch = _kw(hp["arch"])
-        # the output-head / hidden-layer factories are fixed for the default architecture (e3conv.yaml:15-33); the
-        # separable-convolution variant (e3conv_separable.yaml:14-19) has a different tensor product and is not built
+        # the output-head factory is fixed (e3conv.yaml:24-33); the hidden-layer factory's conv is Conv (e3conv.yaml) or SeparableConv
+        # (e3conv_separable.yaml)
         try:
             conv = _kw(arch.get("hidden_layer_factory", {})).get("conv")
             conv_name = repr(getattr(conv, "func", None) or (conv.get("_target_") if hasattr(conv, "get") else conv))
         except TypeError:
             conv_name = ""
-        if "Separable" in conv_name or "Experimental" in conv_name:
-            raise NotImplementedError(f"hidden_layer_factory.conv = {conv_name}: only jamun.e3tools.nn.Conv is implemented")
+        if "Experimental" in conv_name:
+            raise NotImplementedError(f"hidden_layer_factory.conv = {conv_name}: jamun.e3tools.nn.Conv and SeparableConv are implemented")
+        state = strip_prefix(ckpt["state_dict"])
+        # SeparableConv (e3conv_separable.yaml:14-19; e3tools/nn/_conv.py:122-135): named by the factory and recognisable by the
+        # point-wise Linear of its tensor product among the parameters
+        separable = "Separable" in conv_name or any(k.endswith("gated_conv.f.f.tp.lin.weight") for k in state)
         arch = {k: v for k, v in arch.items() if k not in ("hidden_layer_factory", "output_head_factory", "_target_", "_partial_")}
+        arch["separable_conv"] = bool(separable)
         return cls(
-            strip_prefix(ckpt["state_dict"]),
+            state,
             arch=arch,
             max_radius=hp["max_radius"],
             average_squared_distance=hp["average_squared_distance"],

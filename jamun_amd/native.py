@@ -93,6 +93,7 @@ class NativeModel:
         from .checkpoint import w3j_111_sign_from_state_dict
 
         hp.w3j_111_sign = w3j_111_sign_from_state_dict(state_dict)  # +1 unless the checkpoint's e3nn buffers say otherwise
+        hp.separable = int(bool(arch.get("separable_conv", False)))
         self.hparams_struct = hp
         keep = []  # keep host buffers alive during the call
         arr = (_lib.jamun_tensor * len(state_dict))()

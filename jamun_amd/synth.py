@@ -129,7 +129,8 @@ def _irreps_muls(s: str):
     return m0, m1
 
 
-def synthetic_state_dict(arch: Optional[dict] = None, seed: int = 0, output_gain: float = 0.5, tp_weight_scale: float = 13.0) -> Dict[str, torch.Tensor]:
+def synthetic_state_dict(arch: Optional[dict] = None, seed: int = 0, output_gain: float = 0.5, tp_weight_scale: float = 13.0,
+                         separable: bool = False) -> Dict[str, torch.Tensor]:
     """Random-init parameters with the reference's names/shapes (no ``g.`` prefix).
 
     ``o3.Linear`` weights ~ N(0,1) (e3nn default); ``nn.Linear`` / ``nn.Embedding`` use torch's default
@@ -186,8 +187,15 @@ def synthetic_state_dict(arch: Optional[dict] = None, seed: int = 0, output_gain
             numel += mul * g0 + mul * g1
         if mul1_in:
             numel += mul1_in * g1 + mul1_in * g0 + mul1_in * g1
+        lin_numel = numel
+        if separable:
+            # SeparableTensorProduct (e3tools/nn/_tensor_product.py:27-47): depth-wise "uvu" weights — one per input channel and kept
+            # (in1 x sh -> out) triple — and the point-wise o3.Linear(irreps_out_dtp -> gate input irreps), whose weight count equals
+            # the fully connected product's
+            numel = 2 * n0_in + 3 * mul1_in
+            sd[prefix + ".gated_conv.f.f.tp.lin.weight"] = randn(lin_numel)
         w0, b0 = lin(E, E)
-        w3, b3 = lin(numel, E, scale=tp_weight_scale)
+        w3, b3 = lin(numel, E, scale=(1.0 if separable else tp_weight_scale) * (8.0 if separable else 1.0))
         sd[prefix + ".gated_conv.f.f.radial_nn.0.weight"], sd[prefix + ".gated_conv.f.f.radial_nn.0.bias"] = w0, b0
         sd[prefix + ".gated_conv.f.f.radial_nn.3.weight"], sd[prefix + ".gated_conv.f.f.radial_nn.3.bias"] = w3, b3
 
@@ -212,10 +220,14 @@ def synthetic_checkpoint(
     average_squared_distance: float = 0.332,
     output_gain: float = 0.5,
     prefix: str = "g.",
+    separable: bool = False,
 ) -> dict:
     """A Lightning-shaped checkpoint dict: ``{"state_dict": {"g.<name>": ...}, "hyper_parameters": {...}}``."""
     arch = arch or default_arch()
-    sd = synthetic_state_dict(arch, seed=seed, output_gain=output_gain)
+    sd = synthetic_state_dict(arch, seed=seed, output_gain=output_gain, separable=separable)
+    if separable:  # as e3conv_separable.yaml:14-19 reaches the checkpoint's hyper-parameters (a partial of ConvBlock with conv = SeparableConv)
+        arch = dict(arch, hidden_layer_factory={"_target_": "jamun.e3tools.nn.ConvBlock", "_partial_": True,
+                                                "conv": {"_target_": "jamun.e3tools.nn.SeparableConv", "_partial_": True}})
     return {
         "state_dict": {prefix + k: v for k, v in sd.items()},
         "hyper_parameters": dict(

@@ -42,6 +42,7 @@ def default_hparams(**over) -> dict:
         max_radius=1.0,
         average_squared_distance=0.332,
         mean_center=True,
+        conv="conv",  # hidden_layer_factory.conv: "conv" = e3tools.nn.Conv (e3conv.yaml), "separable" = SeparableConv (e3conv_separable.yaml)
     )
     hp.update(over)
     return hp
@@ -97,21 +98,26 @@ def gate_in_irreps(irreps_out: e3.Irreps) -> e3.Irreps:
     return [(a + b, 0), (b, 1)] if b else [(a, 0)]
 
 
-def conv(x, edge_index, edge_attr, edge_sh, p, prefix, irreps_in, irreps_sh, irreps_out):
-    """``Conv.forward`` (``src/jamun/e3tools/nn/_conv.py:96-119``) with ``ScalarMLP(64->[64]->P)`` radial net (``_mlp.py:10-34``)."""
+def conv(x, edge_index, edge_attr, edge_sh, p, prefix, irreps_in, irreps_sh, irreps_out, kind="conv"):
+    """``Conv.forward`` (``src/jamun/e3tools/nn/_conv.py:96-119``) with ``ScalarMLP(64->[64]->P)`` radial net (``_mlp.py:10-34``);
+    ``kind="separable"``: ``SeparableConv`` (``_conv.py:122-135``) — the same forward with ``SeparableTensorProduct`` as ``self.tp``
+    (its point-wise Linear is the parameter ``tp.lin.weight``)."""
     N = x.shape[0]
     src, dst = edge_index
     h = F.silu(F.linear(edge_attr, p[prefix + ".radial_nn.0.weight"], p[prefix + ".radial_nn.0.bias"]))
     w = F.linear(h, p[prefix + ".radial_nn.3.weight"], p[prefix + ".radial_nn.3.bias"])  # [E, weight_numel] materialised
-    out_ij = e3.fctp(x[src], edge_sh, w, irreps_in, irreps_sh, irreps_out)
+    if kind == "separable":
+        out_ij = e3.separable_tp(x[src], edge_sh, w, p[prefix + ".tp.lin.weight"], irreps_in, irreps_sh, irreps_out)
+    else:
+        out_ij = e3.fctp(x[src], edge_sh, w, irreps_in, irreps_sh, irreps_out)
     return scatter_mean(out_ij, dst, N)
 
 
-def conv_block(x, edge_index, edge_attr, edge_sh, p, prefix, irreps_in, irreps_sh, irreps_out):
+def conv_block(x, edge_index, edge_attr, edge_sh, p, prefix, irreps_in, irreps_sh, irreps_out, kind="conv"):
     """``ConvBlock`` = ``LinearSelfInteraction(Gated(Conv))`` (``_conv.py:204-221``, ``_interaction.py:26-30``, ``_gate.py:107-110``)."""
     gin = gate_in_irreps(irreps_out)
     s = e3.linear(x, p[prefix + ".gated_conv.skip_connection.weight"], irreps_in, irreps_out)
-    m = conv(x, edge_index, edge_attr, edge_sh, p, prefix + ".gated_conv.f.f", irreps_in, irreps_sh, gin)
+    m = conv(x, edge_index, edge_attr, edge_sh, p, prefix + ".gated_conv.f.f", irreps_in, irreps_sh, gin, kind)
     mul0 = sum(mm for mm, l in irreps_out if l == 0)
     mul1 = sum(mm for mm, l in irreps_out if l == 1)
     g = e3.gate(m, mul0, mul1)
@@ -138,11 +144,12 @@ def e3conv_forward(pos_scaled, topo, edge_index, bond_mask, c_noise, radial_cuto
     emb_irreps = atom_embedding_irreps(hp)
     x = atom_embedding(topo, p, hp)
     x = noise_scaling(x, c_noise, p, "initial_noise_scaling", emb_irreps)
-    x = conv_block(x, edge_index, edge_attr, edge_sh, p, "initial_projector", emb_irreps, irreps_sh, irreps_hidden)
+    kind = hp.get("conv", "conv")
+    x = conv_block(x, edge_index, edge_attr, edge_sh, p, "initial_projector", emb_irreps, irreps_sh, irreps_hidden, kind)
     inter["x0"] = x
     for i in range(hp["n_layers"]):
         xs = noise_scaling(x, c_noise, p, f"noise_scalings.{i}", irreps_hidden)
-        y = conv_block(xs, edge_index, edge_attr, edge_sh, p, f"layers.{i}", irreps_hidden, irreps_sh, irreps_hidden)
+        y = conv_block(xs, edge_index, edge_attr, edge_sh, p, f"layers.{i}", irreps_hidden, irreps_sh, irreps_hidden, kind)
         x = noise_skip(x, y, c_noise, p, f"skip_connections.{i}", irreps_hidden)
         inter[f"x{i + 1}"] = x
     # EquivariantMLP head (src/jamun/e3tools/nn/_mlp.py:84-114)

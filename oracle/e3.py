@@ -270,6 +270,54 @@ def fctp(
 
 
 # ---------------------------------------------------------------------------
+# SeparableTensorProduct = depth-wise o3.TensorProduct("uvu") + point-wise o3.Linear
+# (src/jamun/e3tools/nn/_tensor_product.py:8-58; used by SeparableConv, _conv.py:122-135)
+# ---------------------------------------------------------------------------
+
+
+def separable_instructions(irreps_in1: Irreps, irreps_in2: Irreps, irreps_out: Irreps):
+    """``_tensor_product.py:27-37``: for i (in1) for j (in2) for ir_out in ir_in1 * ir_in2 (l = |l1-l2| .. l1+l2), kept when
+    ``ir_out`` occurs in ``irreps_out`` or is 0e; every kept triple gets its OWN output block ``(mul_in1, ir_out)`` and the
+    instruction ``(i, j, k, "uvu", has_weight=True)``.  Returns ([(i, j, l_out, weight offset, path coefficient)], irreps_out_dtp,
+    weight_numel).  e3nn normalisation (component / element): ``alpha = dim(ir_out) / (num_elements = mul_in2)`` per output block
+    — each block has exactly one instruction — so the coefficient is ``sqrt((2 l_out + 1) / mul_in2)``."""
+    ls_out = {l for _, l in irreps_out}
+    ins, irreps_dtp, off = [], [], 0
+    for i, (mul, l1) in enumerate(irreps_in1):
+        for j, (mul2, l2) in enumerate(irreps_in2):
+            for lo in range(abs(l1 - l2), l1 + l2 + 1):
+                if lo in ls_out or lo == 0:
+                    ins.append((i, j, lo, off, math.sqrt((2 * lo + 1) / mul2)))
+                    irreps_dtp.append((mul, lo))
+                    off += mul * mul2  # "uvu" weights: [mul_in1, mul_in2]
+    return ins, irreps_dtp, off
+
+
+def separable_weight_numel(irreps_in1: Irreps, irreps_in2: Irreps, irreps_out: Irreps) -> int:
+    return separable_instructions(irreps_in1, irreps_in2, irreps_out)[2]
+
+
+def separable_tp(x1, x2, weight, lin_weight, irreps_in1: Irreps, irreps_in2: Irreps, irreps_out: Irreps) -> torch.Tensor:
+    """``SeparableTensorProduct.forward``: ``lin(dtp(x, y, weight))`` with per-sample ``weight [batch, weight_numel]`` for the
+    depth-wise product and the shared flat ``lin_weight`` of the point-wise ``o3.Linear(irreps_out_dtp -> irreps_out)``."""
+    ins, irreps_dtp, numel = separable_instructions(irreps_in1, irreps_in2, irreps_out)
+    assert weight.shape[-1] == numel, (weight.shape, numel)
+    s1, s2, sd = irreps_slices(irreps_in1), irreps_slices(irreps_in2), irreps_slices(irreps_dtp)
+    Z = x1.shape[0]
+    mid = x1.new_zeros(Z, irreps_dim(irreps_dtp))
+    for k, (i, j, lo, off, coef) in enumerate(ins):
+        m1, l1 = irreps_in1[i]
+        m2, l2 = irreps_in2[j]
+        w = weight[:, off : off + m1 * m2].reshape(Z, m1, m2)
+        a = x1[:, s1[i]].reshape(Z, m1, 2 * l1 + 1)
+        b = x2[:, s2[j]].reshape(Z, m2, 2 * l2 + 1)
+        C = wigner_3j(l1, l2, lo, dtype=x1.dtype)
+        r = torch.einsum("zuv,ijk,zui,zvj->zuk", w, C, a, b) * coef
+        mid[:, sd[k]] = r.reshape(Z, m1 * (2 * lo + 1))
+    return linear(mid, lin_weight, irreps_dtp, irreps_out)
+
+
+# ---------------------------------------------------------------------------
 # nn.Gate with normalize2mom activations (call site: src/jamun/e3tools/nn/_gate.py:53-64)
 # ---------------------------------------------------------------------------
 

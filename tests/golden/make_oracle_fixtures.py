@@ -59,16 +59,16 @@ def molecules(kind):
     raise KeyError(kind)
 
 
-def setup(kind, preset, dtype=torch.float32):
+def setup(kind, preset, dtype=torch.float32, separable=False):
     mols = molecules(kind)
     topo = og.collate([{k: v for k, v in m.items() if torch.is_tensor(v)} for m in mols])
-    sd = synth.synthetic_state_dict(output_gain=GAINS[preset])
+    sd = synth.synthetic_state_dict(output_gain=GAINS[preset], separable=separable)
     p = {k: v.to(dtype) for k, v in sd.items()}
-    return mols, topo, p, od.default_hparams()
+    return mols, topo, p, od.default_hparams(conv="separable" if separable else "conv")
 
 
-def forward_case(kind, with_layers):
-    mols, topo, p, hp = setup(kind, "strong")
+def forward_case(kind, with_layers, separable=False):
+    mols, topo, p, hp = setup(kind, "strong", separable=separable)
     torch.manual_seed(2)
     y = topo["pos"] + SIGMA * torch.randn_like(topo["pos"])
     x, inter = od.xhat(y, topo, SIGMA, p, hp, return_intermediates=True)
@@ -111,6 +111,10 @@ CASES = {
     "oracle_forward_chig93x2": lambda **kw: forward_case("chig93x2", False),
     "oracle_forward_chig166x2": lambda **kw: forward_case("chig166x2", False),
     "oracle_forward_chain33x4": lambda **kw: forward_case("chain33x4", False),
+    # SeparableConv architecture (hydra_config/model/arch/e3conv_separable.yaml): small, ragged, chignolin-size
+    "oracle_forward_sep_ag4": lambda **kw: forward_case("ag4", True, separable=True),
+    "oracle_forward_sep_ragged": lambda **kw: forward_case("ragged", False, separable=True),
+    "oracle_forward_sep_chig93x2": lambda **kw: forward_case("chig93x2", False, separable=True),
     "oracle_forward_cfg4kinds": lambda **kw: forward_case("cfg4kinds", False),
     "oracle_walk_baoab_chig93_6": lambda max_steps=None, **kw: walk_case("chig93x2", "baoab", 6, "stable", max_steps),
     "oracle_walk_baoab_chig166_4": lambda max_steps=None, **kw: walk_case("chig166x2", "baoab", 4, "stable", max_steps),

@@ -556,6 +556,39 @@ def test_source_row_blocks_of_the_default_conv_kernel(dev, monkeypatch, case):
         assert deg.max() < 12
 
 
+@pytest.mark.parametrize("kind", ["ag4", "ragged", "chig93x2"])
+def test_separable_conv_forward_matches_oracle(dev, golden_dir, kind):
+    """The SeparableConv architecture (``hydra_config/model/arch/e3conv_separable.yaml``; ``e3tools/nn/_conv.py:122-135``,
+    ``_tensor_product.py:8-58``): depth-wise "uvu" tensor product + point-wise ``o3.Linear`` in every ConvBlock.  A checkpoint of
+    that architecture is recognised at load (factory name / ``tp.lin.weight`` parameters) and dispatched to
+    ``jamun_sepconv.hip``; one forward against the cached oracle outputs: per-block features, xhat <= 1e-5 nm, score."""
+    from jamun_amd import synth
+    from jamun_amd.data import WalkerBatch
+    from jamun_amd.model import Denoiser
+
+    ref = _golden(golden_dir, f"oracle_forward_sep_{kind}")
+    model = Denoiser.from_checkpoint_dict(synth.synthetic_checkpoint(output_gain=0.5, separable=True)).to(dev)
+    assert model.arch["separable_conv"] is True
+    smp = model.sampler_for(WalkerBatch.from_molecules(_mols(kind)).to(dev), 0.04)
+    y = ref["y"].to(dev)
+    x = smp.xhat(y)
+    assert torch.equal(smp.debug_read(1).cpu().flatten().long(), ref["deg"])
+    l = 0
+    while f"x{l}" in ref:
+        xl, r = smp.debug_read(0, l).cpu(), ref[f"x{l}"]
+        assert (xl - r).abs().max().item() <= 2e-5 * max(r.abs().max().item(), 1e-6), l
+        l += 1
+    assert rmsd(x, ref["xhat"]) <= RMSD_TOL_NM, rmsd(x, ref["xhat"])
+    assert rmsd(smp.score(y), ref["score"]) <= RMSD_TOL_NM / 0.04**2
+    assert torch.equal(smp.xhat(y), x)  # fixed summation order
+    # the state dict without the factory entry is still recognised by its parameters
+    ck = synth.synthetic_checkpoint(output_gain=0.5, separable=True)
+    ck["hyper_parameters"]["arch"].pop("hidden_layer_factory")
+    m2 = Denoiser.from_checkpoint_dict(ck).to(dev)
+    assert m2.arch["separable_conv"] is True
+    assert rmsd(m2.sampler_for(WalkerBatch.from_molecules(_mols(kind)).to(dev), 0.04).xhat(y), ref["xhat"]) <= RMSD_TOL_NM
+
+
 def test_forward_matches_live_oracle(dev, ckpt):
     """Same comparison with the oracle run live on this box (small case), so the cache is not the only witness."""
     from jamun_amd.data import WalkerBatch

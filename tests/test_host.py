@@ -228,8 +228,10 @@ def test_parameter_schedule_callbacks():
     assert ip.on_after_sample(m4, 4) is m4
 
 
-def test_separable_conv_checkpoint_is_rejected():
-    """e3conv_separable.yaml swaps the tensor product; that variant is not built and must fail loudly at load."""
+def test_separable_conv_checkpoint_is_recognised_and_experimental_rejected():
+    """e3conv_separable.yaml swaps the ConvBlock's conv for SeparableConv: recognised at load by the factory's name (a pickled
+    partial of the class) or by the ``tp.lin.weight`` parameters; a checkpoint that names SeparableConv but carries the default
+    conv's parameters fails loudly when the native model is built (missing tensor); ExperimentalConv is refused by name."""
     import functools
 
     from jamun_amd import synth
@@ -238,11 +240,22 @@ def test_separable_conv_checkpoint_is_rejected():
     class SeparableConv:  # stands in for jamun.e3tools.nn.SeparableConv inside the pickled partial
         pass
 
-    ck = synth.synthetic_checkpoint()
-    ck["hyper_parameters"]["arch"] = dict(ck["hyper_parameters"]["arch"])
+    class ExperimentalConv:
+        pass
+
+    ck = synth.synthetic_checkpoint(separable=True)
     ck["hyper_parameters"]["arch"]["hidden_layer_factory"] = functools.partial(dict, conv=functools.partial(SeparableConv))
-    with pytest.raises(NotImplementedError, match="Separable"):
-        Denoiser.from_checkpoint_dict(ck)
+    m = Denoiser.from_checkpoint_dict(ck)
+    assert m.arch["separable_conv"] is True and m._native.hparams_struct.separable == 1
+    assert Denoiser.from_checkpoint_dict(synth.synthetic_checkpoint()).arch["separable_conv"] is False
+    bad = synth.synthetic_checkpoint()  # default parameters under a SeparableConv factory: radial_nn.3 has the wrong size
+    bad["hyper_parameters"]["arch"] = dict(bad["hyper_parameters"]["arch"], hidden_layer_factory=functools.partial(dict, conv=functools.partial(SeparableConv)))
+    m_bad = Denoiser.from_checkpoint_dict(bad)  # (tensors are checked when a sampler packs them, on the GPU)
+    assert m_bad.arch["separable_conv"] is True
+    ex = synth.synthetic_checkpoint()
+    ex["hyper_parameters"]["arch"] = dict(ex["hyper_parameters"]["arch"], hidden_layer_factory=functools.partial(dict, conv=functools.partial(ExperimentalConv)))
+    with pytest.raises(NotImplementedError, match="Experimental"):
+        Denoiser.from_checkpoint_dict(ex)
 
 
 def test_trajectory_metric_callback_dispatches_by_label():

@@ -194,6 +194,41 @@ def test_scatter_mean_empty_rows_are_zero():
     assert torch.equal(out, torch.tensor([[1.0, 1], [0, 0], [1, 1], [0, 0]]))
 
 
+def test_separable_tensor_product_counts_and_equivariance():
+    """SeparableTensorProduct (e3tools/nn/_tensor_product.py:27-47) for the path's irreps: 336 depth-wise weights per edge for
+    120x0e + 32x1e (112 for the atom embedding), a point-wise Linear with as many weights as the fully connected product
+    (28 992 / 10 304); the product is SO(3)-equivariant and, through the 1e x 1e -> 1e cross product, not reflection-invariant."""
+    hid, sh = e3.parse_irreps("120x0e + 32x1e"), e3.parse_irreps("1x0e + 1x1e")
+    gate_in = e3.parse_irreps("152x0e + 32x1e")
+    emb = e3.parse_irreps("8x0e + 8x0e + 32x0e + 8x0e")
+    ins, dtp, numel = e3.separable_instructions(hid, sh, gate_in)
+    assert numel == 336 and dtp == [(120, 0), (120, 1), (32, 1), (32, 0), (32, 1)]
+    assert e3.linear_weight_numel(dtp, gate_in) == 28992 == e3.fctp_weight_numel(hid, sh, gate_in)
+    ins0, dtp0, numel0 = e3.separable_instructions(emb, sh, gate_in)
+    assert numel0 == 112 and e3.linear_weight_numel(dtp0, gate_in) == 10304
+    torch.manual_seed(0)
+    Z = 5
+    x = torch.randn(Z, 216, dtype=torch.float64)
+    v = torch.randn(Z, 3, dtype=torch.float64)
+    w = torch.randn(Z, 336, dtype=torch.float64)
+    lw = torch.randn(28992, dtype=torch.float64)
+    q, _ = torch.linalg.qr(torch.randn(3, 3, dtype=torch.float64))
+    if torch.det(q) < 0:
+        q[:, 0] = -q[:, 0]
+
+    def rot(feat, n0, n1, R):
+        out = feat.clone()
+        out[:, n0:] = (feat[:, n0:].reshape(-1, n1, 3) @ R.T).reshape(-1, 3 * n1)
+        return out
+
+    f = lambda xx, vv: e3.separable_tp(xx, e3.spherical_harmonics_01(vv), w, lw, hid, sh, gate_in)
+    out = f(x, v)
+    assert out.shape == (Z, 152 + 96)
+    assert (f(rot(x, 120, 32, q), v @ q.T) - rot(out, 152, 32, q)).abs().max() < 1e-10
+    P = -torch.eye(3, dtype=torch.float64)  # x1 are 1e (even) vectors: a point reflection of the geometry alone is NOT a symmetry
+    assert (f(x, v @ P.T) - out).abs().max() > 1e-3
+
+
 def test_cached_oracle_fixtures_are_fresh(golden_dir):
     """The GPU tests read cached oracle outputs; re-run a prefix of each kind here and compare bit for bit."""
     import importlib.util
@@ -203,6 +238,7 @@ def test_cached_oracle_fixtures_are_fresh(golden_dir):
     spec.loader.exec_module(mk)
     for name, kw, keys in [
         ("oracle_forward_ag4", {}, ["xhat", "score", "x3", "deg"]),
+        ("oracle_forward_sep_ag4", {}, ["xhat", "x2", "deg"]),
         ("oracle_walk_baoab_ag4_50", {"max_steps": 3}, ["xhat_traj", "y_traj"]),
         ("oracle_walk_baoab_ag4_50_mid", {"max_steps": 3}, ["xhat_traj", "y_traj"]),
         ("oracle_walk_aboba_ag4_20", {"max_steps": 3}, ["xhat_traj", "y_traj"]),
