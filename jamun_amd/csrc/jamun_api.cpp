@@ -106,7 +106,8 @@ struct FusedDev {
 struct DgDev {
   float4 *wx = nullptr, *wd = nullptr, *wv = nullptr, *wt = nullptr;  // null: the layer cannot use jamun_conv_dg.hip
   float4* wxh = nullptr;  // f16x3 contraction: hi / lo planes of the scaled weights, one stream per (hidden unit, matrix wave)
-  int sB = 0;
+  float4* wth = nullptr;  // f16x3 T pre-pass: [k][8 groups of 16 inputs][hi, lo][64 lanes], A operand (lane (w', hh): inputs 16 g + 8 hh + j)
+  int sB = 0, sBt = 0;
   float hmax2 = 2.f;
 };
 struct SepDev {
@@ -135,7 +136,7 @@ void free_fused(FusedDev& f) {
 }
 
 void free_dg(DgDev& d) {
-  hipFree(d.wx); hipFree(d.wd); hipFree(d.wv); hipFree(d.wt); hipFree(d.wxh);
+  hipFree(d.wx); hipFree(d.wd); hipFree(d.wv); hipFree(d.wt); hipFree(d.wxh); hipFree(d.wth);
   d = DgDev{};
 }
 
@@ -943,6 +944,31 @@ LayerDev build_layer(const jamun_model& m, const std::string& prefix, const std:
           for (int G = 0; G < 2; ++G) copy_blocks(wvh, (((size_t)k * 2 + (w >> 1)) * 2 + G) * 2, base + 30 + 2 * G);
         }
       L.dg.wxh = dev_upload(wh);
+      // T pre-pass (k_tprod_h): scalar inputs -> vector rows, weights as the A operand of v_mfma_f32_32x32x16_f16
+      {
+        double tmax = 0;
+        for (int k = 0; k < n_k; ++k)
+          for (const UEntry& e : x0ve)
+            for (int c = 0; c < G1; ++c) tmax = std::max(tmax, std::fabs(Wk(k, e.wbase + c) * e.scale));
+        int ext = 0;
+        if (tmax > 0 && std::isfinite(tmax)) std::frexp(tmax, &ext);
+        L.dg.sBt = std::max(-60, std::min(60, 14 - ext));
+        const double sct = std::ldexp(1.0, L.dg.sBt);
+        std::vector<float4> wth((size_t)n_k * 16 * 64);
+        for (int k = 0; k < n_k; ++k)
+          for (int g = 0; g < 8; ++g)
+            for (int lane = 0; lane < 64; ++lane) {
+              const int hh = lane >> 5, c = lane & 31;
+              double v[8];
+              for (int j = 0; j < 8; ++j) {
+                const int u = 16 * g + 8 * hh + j;
+                v[j] = (u < 120 && c < G1) ? Wk(k, x0ve[u].wbase + c) * x0ve[u].scale * sct / sc : 0.0;
+              }
+              const size_t b = ((size_t)k * 16 + 2 * g) * 64 + lane;
+              pack8(v, wth[b], wth[b + 64]);
+            }
+        L.dg.wth = dev_upload(wth);
+      }
     }
   }
 
@@ -1096,7 +1122,7 @@ void run_layer(jamun_sampler* s, size_t l, const float* x_in, int XSin, float* x
         f.dump = s->dg_dump;
       }
       ProfScope ps(s, JAMUN_PROF_CONV0, st);  // (the T pre-pass is part of the hidden-layer conv: timed with it)
-      launch_tprod(x_in, XSin, s->n_atoms, s->hp.edge_attr_dim + 1, L.dg.wt, s->dg_T, st);
+      launch_tprod(x_in, XSin, s->n_atoms, s->hp.edge_attr_dim + 1, L.dg.wt, s->dg_emu ? L.dg.wth : nullptr, L.dg.sBt, s->dg_T, st);
       const int rcode = launch_conv_dg(f, s->dg_grid, st);
       if (rcode != 0) throw Err(JAMUN_ERR_INVALID, "destination-grouped conv launch failed (configuration not supported)");
     } else if (L.fu.wpack) {

@@ -337,6 +337,10 @@ __global__ __launch_bounds__(DG_THREADS) void k_conv_dg(DgArgs a) {
     if (is_mat) {
       // =========================================== MATRIX waves ===========================================
       const int w = wave;
+#if defined(JAMUN_STAMP) || defined(JAMUN_DGDBG)
+      if (a.dbg & 1024) __builtin_amdgcn_s_setprio(3);
+      if (a.dbg & 2048) __builtin_amdgcn_s_setprio(2);
+#endif
       const int r = lane & 31, hh = lane >> 5;      // 32x32x2 fragments: row / column r, K half hh
       const int r16 = lane & 15, kq = lane >> 4;    // 16x16x4 fragments: row / column r16, K quarter kq
       const int rh = w & 1, ch = w >> 1;            // this wave's 16x16 sub-tiles of the vector planes
@@ -780,6 +784,10 @@ __global__ __launch_bounds__(DG_THREADS) void k_conv_dg(DgArgs a) {
       // after the other, bound by LDS latency; with priority their VALU instructions go first and the MFMAs fill their
       // latency gaps (measured timeline: matrix waves done at 10.2k cycles of a 15.1k step, forming waves at 11.7k .. 13.9k).
       if (!dbg_noprio) __builtin_amdgcn_s_setprio(3);
+#if defined(JAMUN_STAMP) || defined(JAMUN_DGDBG)
+      if (a.dbg & 1024) __builtin_amdgcn_s_setprio(1);
+      if (a.dbg & 2048) __builtin_amdgcn_s_setprio(2);
+#endif
       const int fw = wave - 4;                    // forming wave index
       const int h = lane >> 5, u = lane & 31;
       const int xs_lds = lds_address(xs);  // LDS address of the source rows
@@ -1419,10 +1427,98 @@ __global__ __launch_bounds__(64 * TP_WAVES) __attribute__((amdgpu_waves_per_eu(2
   }
 }
 
-void launch_tprod(const float* x, int XS, int n_atoms, int n_k, const float4* wt, float* T, hipStream_t st) {
+// The same product as f16x3 (as the contraction of k_conv_dg<.., true>): the 120 scalar inputs of the wave's 32 atoms are scaled by a
+// power of two per atom (largest |x| below 2^14), split ONCE into hi + lo halves and held in registers as the B operands of
+// v_mfma_f32_32x32x16_f16 (lane (atom, hh): inputs 16 g + 8 hh + j); per hidden unit the 16 weight blocks (8 groups x hi, lo; split
+// on the host after scaling by 2^sBt) stream through a double buffer and 24 MFMAs of 32 cycles replace 60 of 64.  The kernel turns
+// from MFMA-bound to bound by its weight stream (16 KB per wave and hidden unit from L2).
+__global__ __launch_bounds__(64 * TP_WAVES) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_tprod_h(
+    const float* __restrict__ x, int XS, int n_atoms, int n_k, int kg, const float4* __restrict__ wth, int sBt, float* __restrict__ T) {
+  const int lane = threadIdx.x & 63, wave = RFL(threadIdx.x >> 6);
+  const int r = lane & 31, hh = lane >> 5;
+  const int gid = blockIdx.x * TP_WAVES + wave;
+  const int tile = RFL(gid / kg), g = RFL(gid - tile * kg);
+  const int a0 = tile * 32;
+  if (a0 >= n_atoms) return;
+  const int k_lo = RFL((g * n_k) / kg), k_hi = RFL(((g + 1) * n_k) / kg);
+  if (k_lo >= k_hi) return;
+  const int row = min(a0 + r, n_atoms - 1);
+  float4 xh[8], xl[8], w0[16], w1[16];
+  float isc;
+  {
+    float4 xf[8][2];
+    float mx = 0.f;
+#pragma unroll
+    for (int q = 0; q < 8; ++q)
+#pragma unroll
+      for (int p2 = 0; p2 < 2; ++p2) {
+        const int u = 16 * q + 8 * hh + 4 * p2;  // inputs u .. u + 3 (120..127: beyond the scalar block -> zeros)
+        float4 v = *reinterpret_cast<const float4*>(x + (size_t)row * XS + u);
+        if (u >= 120) v = make_float4(0.f, 0.f, 0.f, 0.f);
+        xf[q][p2] = v;
+        mx = fmaxf(mx, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
+      }
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));  // both input halves of the atom
+    int sA = 0;
+    if (mx > 0.f) sA = 14 - ((int)((__float_as_uint(mx) >> 23) & 0xffu) - 126);
+    sA = max(-60, min(60, sA));
+    const float sc = pow2f(sA);
+    isc = pow2f(-sA - sBt);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const float4 a4 = xf[q][0], b4 = xf[q][1];
+      const float e[8] = {a4.x * sc, a4.y * sc, a4.z * sc, a4.w * sc, b4.x * sc, b4.y * sc, b4.z * sc, b4.w * sc};
+      unsigned ph[4], pl[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        ph[i] = cvt_pk_f16(e[2 * i], e[2 * i + 1]);
+        pl[i] = cvt_pk_f16(resid_lo(e[2 * i], ph[i]), resid_hi(e[2 * i + 1], ph[i]));
+      }
+      xh[q] = make_float4(__uint_as_float(ph[0]), __uint_as_float(ph[1]), __uint_as_float(ph[2]), __uint_as_float(ph[3]));
+      xl[q] = make_float4(__uint_as_float(pl[0]), __uint_as_float(pl[1]), __uint_as_float(pl[2]), __uint_as_float(pl[3]));
+    }
+  }
+  auto load_w = [&](float4 (&wv)[16], int k) {
+    const float4* __restrict__ wk = wth + (size_t)min(k, n_k - 1) * 16 * 64;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) wv[q] = wk[q * 64 + lane];
+  };
+  load_w(w0, k_lo);
+  auto step = [&](const float4 (&wv)[16], int k) {
+    f32x16 acc;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc[q] = 0.f;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {  // acc[row = output channel][column = atom]; blocks 2q (hi), 2q + 1 (lo) of the weights
+      acc = MFMA32H(wv[2 * q + 1], xh[q], acc);
+      acc = MFMA32H(wv[2 * q], xl[q], acc);
+      acc = MFMA32H(wv[2 * q], xh[q], acc);
+    }
+    float* __restrict__ tk = T + ((size_t)k * n_atoms + a0) * 32;
+    if (a0 + r < n_atoms) {
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4)  // accumulator register 4 g4 + i  <->  output channel 8 g4 + 4 hh + i
+        *reinterpret_cast<float4*>(tk + r * 32 + 8 * g4 + 4 * hh) =
+            make_float4(acc[4 * g4] * isc, acc[4 * g4 + 1] * isc, acc[4 * g4 + 2] * isc, acc[4 * g4 + 3] * isc);
+    }
+  };
+  for (int k = k_lo; k < k_hi; k += 2) {
+    load_w(w1, k + 1);
+    step(w0, k);
+    if (k + 1 < k_hi) {
+      load_w(w0, k + 2);
+      step(w1, k + 1);
+    }
+  }
+}
+
+void launch_tprod(const float* x, int XS, int n_atoms, int n_k, const float4* wt, const float4* wth, int sBt, float* T, hipStream_t st) {
   const int tiles = (n_atoms + 31) / 32;
   const int kg = std::min(n_k, std::max(1, 1024 / tiles));
-  hipLaunchKernelGGL(k_tprod, dim3((tiles * kg + TP_WAVES - 1) / TP_WAVES), dim3(64 * TP_WAVES), 0, st, x, XS, n_atoms, n_k, kg, wt, T);
+  if (wth)
+    hipLaunchKernelGGL(k_tprod_h, dim3((tiles * kg + TP_WAVES - 1) / TP_WAVES), dim3(64 * TP_WAVES), 0, st, x, XS, n_atoms, n_k, kg, wth, sBt, T);
+  else
+    hipLaunchKernelGGL(k_tprod, dim3((tiles * kg + TP_WAVES - 1) / TP_WAVES), dim3(64 * TP_WAVES), 0, st, x, XS, n_atoms, n_k, kg, wt, T);
 }
 
 size_t conv_dg_lds_bytes(int rs, int pmax, int mode, int emu) { return sizeof(float) * ((dg_lds_floats(rs, pmax, mode, emu != 0) + 3) & ~(size_t)3); }

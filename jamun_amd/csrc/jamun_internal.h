@@ -247,7 +247,7 @@ int conv_dg_set_max_lds();
 void conv_dg_print_stamps();
 void conv_initv_print_stamps();
 size_t conv_dg_lds_bytes(int rs, int pmax, int mode, int emu);
-void launch_tprod(const float* x, int XS, int n_atoms, int n_k, const float4* wt, float* T, hipStream_t st);
+void launch_tprod(const float* x, int XS, int n_atoms, int n_k, const float4* wt, const float4* wth, int sBt, float* T, hipStream_t st);
 int launch_conv_init(const InitArgs& a, int grid, hipStream_t st);
 int launch_conv_initv(const InitVArgs& a, int grid, hipStream_t st);
 int conv_initv_set_max_lds();
