@@ -200,7 +200,13 @@ __global__ __launch_bounds__(DG_THREADS) void k_conv_dg(DgArgs a) {
 
   const int tid0 = threadIdx.x, lane0 = tid0 & 63;
   const int wave = RFL(tid0 >> 6);
+#if defined(DG_STUB) && DG_STUB == 1  // register-pressure experiments: one role compiled out
+  const bool is_mat = false;
+#elif defined(DG_STUB) && DG_STUB == 2
+  const bool is_mat = true;
+#else
   const bool is_mat = wave < 4;
+#endif
   const int PMAX = a.PMAX;
 #if defined(JAMUN_STAMP) || defined(JAMUN_DGDBG)  // timing experiments (JAMUN_DG_DBG) exist in the diagnostic builds only
   const bool dbg_noform = a.dbg & 1, dbg_nomfma = a.dbg & 2, dbg_noweights = a.dbg & 4, dbg_notouch = a.dbg & 16, dbg_noprio = a.dbg & 32, dbg_nostage = a.dbg & 8;
