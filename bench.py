@@ -108,11 +108,12 @@ def _cpu_walk(mols, steps):
     return time.perf_counter() - t0
 
 
-def cpu_baseline(cfg: str, sample_walkers=8, frames=3, cfg1_exact=True):
+def cpu_baseline(cfg: str, sample_walkers=8, frames=20, cfg1_exact=True):
     """The CPU oracle (op-for-op PyTorch restatement of the reference path, kind="port") timed on this box's host cores:
-    a bounded sample of the benchmarked workload (`sample_walkers` walkers x `frames` walk-jump frames; each frame costs two
-    forwards, as the reference) and — BASELINE.md section 2 — BASELINE.json configs[0] EXACTLY: AG dipeptide, 4 walkers x 50
-    walk-jump steps."""
+    a BOUNDED SAMPLE of the benchmarked workload — `sample_walkers` walkers (not the 256 of the GPU line: at ~2.5
+    conformations/s the full batch would take half an hour) x `frames` walk-jump frames after a warm-up forward; each frame
+    costs two forwards, as the reference — and, BASELINE.md section 2, BASELINE.json configs[0] EXACTLY: AG dipeptide,
+    4 walkers x 50 walk-jump steps."""
     from jamun_amd import synth
 
     cores = _cpu_threads()
@@ -161,17 +162,18 @@ def secondary_rooflines(dev):
 
     out = []
     params = native.make_mcmc_params(2, **MCMC)
-    # the Langevin update at a size where it is bandwidth- and not launch-bound (the bench shape, 4352 atoms = 0.3 MB per launch,
-    # is pure launch latency; the path fuses nothing around it yet)
+    # the STAND-ALONE Langevin update operators (jamun_baoab_pre / jamun_baoab_post) at a size where they are bandwidth- and not
+    # launch-bound.  They are exported and parity-pinned, but OFF the hot path: in the walk both halves run inside k_geom / k_finalize
+    # (at the bench shape, 4352 atoms = 0.3 MB, a separate launch would be pure latency)
     n_big = 1 << 24  # 201 MB per [n,3] array: far beyond the 256 MiB Infinity Cache in total
     y, v, psi, R, sc = (torch.randn(n_big, 3, device=dev) for _ in range(5))
     dt = _time_launches(lambda: native.baoab_pre(y, v, psi, R, params), 20)
     b = n_big * 3 * 4 * 6
-    out.append({"kernel": "k_baoab_pre", "shape": f"{n_big} atoms (bandwidth-bound size; host-supplied noise)", "bound": "hbm", "bytes": b,
+    out.append({"kernel": "k_baoab_pre", "shape": f"stand-alone operator (fused into k_geom in the walk), {n_big} atoms, host-supplied noise", "bound": "hbm", "bytes": b,
                 "avg_launch_ms": dt * 1e3, "achieved": b / dt / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": b / dt / 1e9 / HBM_PEAK_GBS})
     dt = _time_launches(lambda: native.baoab_post(v, psi, sc, params), 20)
     b = n_big * 3 * 4 * 4
-    out.append({"kernel": "k_baoab_post", "shape": f"{n_big} atoms (bandwidth-bound size; no frame save)", "bound": "hbm", "bytes": b,
+    out.append({"kernel": "k_baoab_post", "shape": f"stand-alone operator (fused into k_finalize in the walk), {n_big} atoms, no frame save", "bound": "hbm", "bytes": b,
                 "avg_launch_ms": dt * 1e3, "achieved": b / dt / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": b / dt / 1e9 / HBM_PEAK_GBS})
     del y, v, psi, R, sc
     for walkers in (256, 2048):
@@ -204,10 +206,12 @@ def secondary_rooflines(dev):
     return out
 
 
-def _pmc_traffic(kernel: str):
+def _pmc_traffic(kernel: str, cfg: str = "cfg2"):
     import glob
 
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")))
+    # summaries of a config carry its name (r3b_cfg3_pmc_traffic.json); older cfg2 summaries carry none
+    files = [f for f in files if f"_{cfg}_" in os.path.basename(f)] or ([f for f in files if "_cfg" not in os.path.basename(f)] if cfg == "cfg2" else [])
     for f in reversed(files):
         try:
             d = json.load(open(f))
@@ -479,8 +483,8 @@ def main():
                                         "frac_executed": ex / F32_MFMA_PEAK_TFLOPS, "flop_executed_per_launch": stats["conv_flop_exec_launch"]})
             # HBM-side bytes per launch from the committed PMC passes of the cfg2 command (profiles/collect.sh); rocprofv3
             # cannot run inside the timed process, so the newest committed summary is quoted, with its file name
-            if args.config == "cfg2" and args.atoms is None and args.walkers is None:
-                tr = _pmc_traffic({2: "k_conv_dg", 1: "k_conv_fused"}.get(stats["conv_path"], "k_conv<"))
+            if args.atoms is None and args.walkers is None and not args.strong:
+                tr = _pmc_traffic({2: "k_conv_dg", 1: "k_conv_fused"}.get(stats["conv_path"], "k_conv<"), args.config)
                 if tr is not None:
                     out["roofline"]["traffic"] = tr[0]
                     out["roofline"]["traffic_source"] = tr[1]
