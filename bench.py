@@ -298,6 +298,7 @@ def main():
     ap.add_argument("--no-cfg1-cpu", action="store_true", help="skip the exact configs[0] CPU run (~1 min) inside cpu_baseline")
     ap.add_argument("--no-secondary", action="store_true", help="skip the scatter-mean / Langevin-kernel bandwidth measurements")
     ap.add_argument("--no-profile", action="store_true", help="do not record per-kernel HIP events in the timed region")
+    ap.add_argument("--separable", action="store_true", help="SeparableConv architecture (e3conv_separable.yaml) instead of the default e3conv; not the metric's config")
     ap.add_argument("--dry-run", action="store_true", help="rank plumbing only (gloo, no kernels): used by the CPU test of the self-launch")
     ap.add_argument("--dry-run-fail-rank", type=int, default=-1, help="with --dry-run: this rank exits with an error before the rendezvous (tests the supervision of the self-launch)")
     ap.add_argument("--strong", action="store_true", help="strong scaling: the config's walker count x 8 (2048 for cfg2/3/4) is the TOTAL, split over the ranks")
@@ -346,7 +347,7 @@ def main():
             raise SystemExit(f"--strong: rank {rank} of {world} has no walkers ({total_walkers} in total)")
     mols = workload_molecules(args.config, walkers, args.atoms, rank)
     batch = WalkerBatch.from_molecules(mols).to(dev)
-    model = Denoiser.from_checkpoint_dict(synth.synthetic_checkpoint()).to(dev)
+    model = Denoiser.from_checkpoint_dict(synth.synthetic_checkpoint(separable=args.separable)).to(dev)
     smp = model.sampler_for(batch, SIGMA)
     n = batch.num_nodes
 
@@ -444,6 +445,7 @@ def main():
                 "mean_in_degree": stats["n_edges"] / n,
                 "parallelism": f"walkers sharded over {world} GPU(s), no data-path collective",
                 "rng": "philox (in-kernel)",
+                **({"arch": "SeparableConv (e3conv_separable.yaml) — NOT the metric's architecture"} if args.separable else {}),
             },
         }
         if prof is not None:

@@ -68,37 +68,55 @@ __global__ __launch_bounds__(256) void k_sep_apply(SepArgs a) {
     float d0[2] = {0.f, 0.f}, d1[2][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}}, d2[3] = {0.f, 0.f, 0.f}, d3 = 0.f, d4[3] = {0.f, 0.f, 0.f};
     if (i < a.n_atoms) {
       const int dg = a.deg[i];
-      for (int t = 0; t < dg; ++t) {
-        const size_t slot = (size_t)i * a.S + t;
-        const int j = a.esrc[slot] & 0x7fffffff;
-        const float4 ge = a.egeo[slot];  // unit vector (x, y, z), distance
-        const float* __restrict__ wr = a.w + slot * a.NWp;
+      // edge slot t of this destination lives in lane t (source index, unit vector): one coalesced read each, then broadcasts — and
+      // the operands of edge t + 1 are requested before the FMAs of edge t (the loop is a chain of dependent global reads otherwise)
+      const size_t slot_l = (size_t)i * a.S + (lane < dg ? lane : 0);
+      const int j_l = a.esrc[slot_l] & 0x7fffffff;
+      const float4 ge_l = a.egeo[slot_l];
+      struct Ops { float x0[2], wa[2], wb[2], x1[3], wc, wd, we, gx, gy, gz; };
+      auto fetch = [&](int t) {
+        Ops o;
+        const int tt = t < dg ? t : 0;
+        const int j = __shfl(j_l, tt, 64);
+        o.gx = __shfl(ge_l.x, tt, 64); o.gy = __shfl(ge_l.y, tt, 64); o.gz = __shfl(ge_l.z, tt, 64);
+        const float* __restrict__ wr = a.w + ((size_t)i * a.S + tt) * a.NWp;
         const float* __restrict__ xr = a.x + (size_t)j * a.XS;
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
           const int u = lane + 64 * c;
-          if (u < n0) {
-            const float x0 = xr[u], wa = wr[u], wb = wr[n0 + u];
-            d0[c] = fmaf(wa, x0, d0[c]);
-            const float bx = wb * x0;
-            d1[c][0] = fmaf(bx, ge.x, d1[c][0]);
-            d1[c][1] = fmaf(bx, ge.y, d1[c][1]);
-            d1[c][2] = fmaf(bx, ge.z, d1[c][2]);
-          }
+          const bool ok = u < n0;
+          o.x0[c] = ok ? xr[u] : 0.f; o.wa[c] = ok ? wr[u] : 0.f; o.wb[c] = ok ? wr[n0 + u] : 0.f;
         }
-        if (lane < n1) {
-          const float* __restrict__ x1 = xr + n0 + 3 * lane;
-          const float vx = x1[0], vy = x1[1], vz = x1[2];
-          const float wc = wr[2 * n0 + lane], wd = wr[2 * n0 + n1 + lane], we = wr[2 * n0 + 2 * n1 + lane];
-          d2[0] = fmaf(wc, vx, d2[0]);
-          d2[1] = fmaf(wc, vy, d2[1]);
-          d2[2] = fmaf(wc, vz, d2[2]);
-          d3 = fmaf(wd, fmaf(vz, ge.z, fmaf(vy, ge.y, vx * ge.x)), d3);
+        const bool ok1 = lane < n1;
+        const float* __restrict__ x1 = xr + n0 + 3 * (ok1 ? lane : 0);
+        o.x1[0] = ok1 ? x1[0] : 0.f; o.x1[1] = ok1 ? x1[1] : 0.f; o.x1[2] = ok1 ? x1[2] : 0.f;
+        o.wc = ok1 ? wr[2 * n0 + lane] : 0.f; o.wd = ok1 ? wr[2 * n0 + n1 + lane] : 0.f; o.we = ok1 ? wr[2 * n0 + 2 * n1 + lane] : 0.f;
+        return o;
+      };
+      Ops cur{};
+      if (dg > 0) cur = fetch(0);  // (the slots of an atom without in-edges hold no valid source index)
+      for (int t = 0; t < dg; ++t) {
+        const Ops nxt = fetch(t + 1);
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+          d0[c] = fmaf(cur.wa[c], cur.x0[c], d0[c]);
+          const float bx = cur.wb[c] * cur.x0[c];
+          d1[c][0] = fmaf(bx, cur.gx, d1[c][0]);
+          d1[c][1] = fmaf(bx, cur.gy, d1[c][1]);
+          d1[c][2] = fmaf(bx, cur.gz, d1[c][2]);
+        }
+        {
+          const float vx = cur.x1[0], vy = cur.x1[1], vz = cur.x1[2];
+          d2[0] = fmaf(cur.wc, vx, d2[0]);
+          d2[1] = fmaf(cur.wc, vy, d2[1]);
+          d2[2] = fmaf(cur.wc, vz, d2[2]);
+          d3 = fmaf(cur.wd, fmaf(vz, cur.gz, fmaf(vy, cur.gy, vx * cur.gx)), d3);
           // (x1 x v)[m] = x1[m+1] v[m+2] - x1[m+2] v[m+1]
-          d4[0] = fmaf(we, vy * ge.z - vz * ge.y, d4[0]);
-          d4[1] = fmaf(we, vz * ge.x - vx * ge.z, d4[1]);
-          d4[2] = fmaf(we, vx * ge.y - vy * ge.x, d4[2]);
+          d4[0] = fmaf(cur.we, vy * cur.gz - vz * cur.gy, d4[0]);
+          d4[1] = fmaf(cur.we, vz * cur.gx - vx * cur.gz, d4[1]);
+          d4[2] = fmaf(cur.we, vx * cur.gy - vy * cur.gx, d4[2]);
         }
+        cur = nxt;
       }
     }
     // rows of the Linear's inputs: scalars [D0 (n0) | D3 (n1)], vectors per component m: [D1 (n0) | D2 (n1) | D4 (n1)]
@@ -159,7 +177,7 @@ __global__ __launch_bounds__(256) void k_sep_apply(SepArgs a) {
 }
 
 int launch_sep_conv(const SepArgs& a, hipStream_t st) {
-  if (a.n0 > 128 || a.n1 > 32 || a.NWp % 32 != 0 || a.NWp < 2 * a.n0 + 3 * a.n1) return -1;
+  if (a.n0 > 128 || a.n1 > 32 || a.NWp % 32 != 0 || a.NWp < 2 * a.n0 + 3 * a.n1 || a.S > 64) return -1;  // (edge slot t of a destination lives in lane t)
   const size_t smem = (size_t)16 * (a.n0 + a.n1 + 3 * (a.n0 + 2 * a.n1)) * sizeof(float);
   if (smem > 64 * 1024) return -1;
   const int64_t tiles = (a.n_slots + 31) / 32;
