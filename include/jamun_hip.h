@@ -211,11 +211,13 @@ typedef struct jamun_stats {
   int64_t conv1_flop_alg;   /* useful FLOPs of ONE hidden-layer vector-row conv launch: 2*3*n_atoms*65*(mul0+2*mul1)*mul1   */
   int32_t edge_stride;
   int32_t n_slices;       /* partial slabs per tile summed by the node update (max over tiles)          */
-  int32_t conv_path;      /* hidden layers: 2 destination-grouped VALU-forming kernel (jamun_conv_dg.hip), 1 fused
-                             matrix-core-forming kernel, 0 general k_conv */
-  int32_t dg_mode;        /* jamun_conv_dg.hip variant: 0 two phases per hidden unit with resident source rows, 1 two passes
-                             over the hidden units (molecules above ~80 atoms), 2 single phase (source spans up to ~52 atoms), 3 single phase with one Y tile
-                             (spans up to ~73 atoms); -1: not in use */
+  int32_t conv_path;      /* hidden layers: 2 destination-grouped kernels on host-planned tiles (jamun_conv_mf.hip / jamun_conv_dg.hip),
+                             1 fused matrix-core-forming kernel, 0 general k_conv */
+  int32_t dg_mode;        /* destination-grouped kernel: 4 jamun_conv_mf.hip (A operand formed on the matrix cores and chained into the
+                             contraction; source spans up to 62 atoms); jamun_conv_dg.hip (A operand formed edge by edge on the vector ALUs):
+                             0 two phases per hidden unit with resident source rows, 1 two passes over the hidden units (molecules above
+                             ~80 atoms), 2 single phase (spans up to ~52 atoms), 3 single phase with one Y tile (spans up to ~73 atoms);
+                             -1: not in use */
   int32_t init_path;      /* initial projector: 2 edge-by-edge VALU kernel on the tiles of jamun_conv_dg.hip (jamun_conv_initv.hip),
                              1 input-times-weight table applied with MFMAs (jamun_conv_init.hip), 0 the hidden layers' fused /
                              general kernel */

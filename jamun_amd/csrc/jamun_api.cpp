@@ -107,7 +107,8 @@ struct DgDev {
   float4 *wx = nullptr, *wd = nullptr, *wv = nullptr, *wt = nullptr;  // null: the layer cannot use jamun_conv_dg.hip
   float4* wxh = nullptr;  // f16x3 contraction: hi / lo planes of the scaled weights, one stream per (hidden unit, matrix wave)
   float4* wth = nullptr;  // f16x3 T pre-pass: [k][8 groups of 16 inputs][hi, lo][64 lanes], A operand (lane (w', hh): inputs 16 g + 8 hh + j)
-  int sB = 0, sBt = 0;
+  float4* wm = nullptr;   // jamun_conv_mf.hip: [k][4 matrix waves][40 blocks], K index permuted to the forming MFMA's accumulator layout
+  int sB = 0, sBt = 0, sTw = 0;
   float hmax2 = 2.f;
 };
 struct SepDev {
@@ -136,7 +137,7 @@ void free_fused(FusedDev& f) {
 }
 
 void free_dg(DgDev& d) {
-  hipFree(d.wx); hipFree(d.wd); hipFree(d.wv); hipFree(d.wt); hipFree(d.wxh); hipFree(d.wth);
+  hipFree(d.wx); hipFree(d.wd); hipFree(d.wv); hipFree(d.wt); hipFree(d.wxh); hipFree(d.wth); hipFree(d.wm);
   d = DgDev{};
 }
 
@@ -349,6 +350,9 @@ struct jamun_sampler {
   float* sep_w = nullptr;  // SeparableConv: [n_atoms * S][NWp] per-edge depth-wise weights of the layer at hand
   float* dg_dump = nullptr;  // diagnostic A-tile dump (JAMUN_DG_DUMP, -DJAMUN_DUMP builds)
   float* dg_T = nullptr;  // [n_k][n_atoms][32] pre-pass product of a hidden layer (k_tprod), reused by every layer
+  int dg_tstride = 0;     // mode 4 (jamun_conv_mf.hip): dg_T is [n_k][32][dg_tstride], transposed
+  int* mf_err = nullptr;  // device flag of k_conv_mf
+  int* mf_err_host = nullptr;  // pinned copy, refreshed after every forward
   float *x_emb = nullptr, *mu = nullptr;
   std::vector<LayerDev> layers;
   float *w_gate = nullptr, *w_vec = nullptr, *w_out = nullptr;
@@ -372,7 +376,8 @@ struct jamun_sampler {
   ~jamun_sampler() {
     hipFree(ptr); hipFree(bond_in_ptr); hipFree(bond_in_src); hipFree(x_emb); hipFree(mu); hipFree(tile_span);
     hipFree(fused_segs); hipFree(atom_nslab); hipFree(tile_atoms); hipFree(atom_uid); hipFree(w1r_all); hipFree(cmask_all);
-    hipFree(dg_dump); hipFree(dg_tile_atoms); hipFree(dg_tile_span); hipFree(dg_segs); hipFree(dg_atom_nslab); hipFree(dg_T);
+    hipFree(dg_dump); hipFree(dg_tile_atoms); hipFree(dg_tile_span); hipFree(dg_segs); hipFree(dg_atom_nslab); hipFree(dg_T); hipFree(mf_err);
+    if (mf_err_host) hipHostFree(mf_err_host);
     for (auto& L : layers) {
       free_problem(L.p0); free_problem(L.p1); free_fused(L.fu); free_dg(L.dg);
       hipFree(L.sep.w2p); hipFree(L.sep.wl0); hipFree(L.sep.wl1);
@@ -969,6 +974,63 @@ LayerDev build_layer(const jamun_model& m, const std::string& prefix, const std:
             }
         L.dg.wth = dev_upload(wth);
       }
+      // jamun_conv_mf.hip: the A operand of the contraction is the ACCUMULATOR of the forming MFMA (lane = destination, registers =
+      // channels), so half p of lane (column c, hh) in K-step s2 is input u = 16 s2 + (p & 3) + 8 (p >> 2) + 4 hh of the wave's 32
+      // channels.  Same scale 2^sB as the stream of k_conv_dg.  sTw: 2^sTw x (largest column sum of the T weights) < 1, so that
+      // T_k = x0 W times 2^(sX + sTw) stays below 2^14 with |x| 2^sX < 2^14.
+      {
+        double wcs = 0;
+        for (int k = 0; k < n_k; ++k)
+          for (int c = 0; c < G1; ++c) {
+            double cs = 0;
+            for (const UEntry& e : x0ve) cs += std::fabs(Wk(k, e.wbase + c) * e.scale);
+            wcs = std::max(wcs, cs);
+          }
+        int exs = 0;
+        if (wcs > 0 && std::isfinite(wcs)) std::frexp(wcs, &exs);
+        L.dg.sTw = std::max(-40, std::min(40, -exs));
+        auto pack8m = [&](const double (&v)[8], float4& hi, float4& lo) { pack8(v, hi, lo); };
+        auto u_of = [](int s2, int hh, int p) { return 16 * s2 + (p & 3) + 8 * (p >> 2) + 4 * hh; };
+        std::vector<float4> wm((size_t)n_k * 4 * 40 * 64, make_float4(0.f, 0.f, 0.f, 0.f));
+        for (int k = 0; k < n_k; ++k)
+          for (int w = 0; w < 4; ++w) {
+            const size_t base = (((size_t)k * 4 + w) * 40) * 64;
+            for (int lane = 0; lane < 64; ++lane) {
+              const int hh = lane >> 5, c = lane & 31;
+              for (int n = 0; n < 5; ++n)
+                for (int s2 = 0; s2 < 2; ++s2) {
+                  const int col = 32 * n + c;
+                  double v[8];
+                  for (int p = 0; p < 8; ++p) {
+                    const int u = 32 * w + u_of(s2, hh, p);
+                    v[p] = (u < 120 && col < G0) ? Wk(k, x0e[u].wbase + col) * x0e[u].scale : 0.0;
+                  }
+                  const size_t b = base + (size_t)(2 * (2 * n + s2)) * 64 + lane;
+                  pack8m(v, wm[b], wm[b + 64]);
+                  if (w == 0) {
+                    for (int p = 0; p < 8; ++p) {
+                      const int u = u_of(s2, hh, p);
+                      v[p] = col < G0 ? Wk(k, dote[u].wbase + col) * dote[u].scale : 0.0;
+                    }
+                    const size_t bd = base + (size_t)(20 + 2 * (2 * n + s2)) * 64 + lane;
+                    pack8m(v, wm[bd], wm[bd + 64]);
+                  }
+                }
+              if (w > 0)
+                for (int part = 0; part < 2; ++part)  // x1 inputs, then cross inputs -> vector rows (32 columns)
+                  for (int s2 = 0; s2 < 2; ++s2) {
+                    double v[8];
+                    for (int p = 0; p < 8; ++p) {
+                      const UEntry& e = part == 0 ? x1e[u_of(s2, hh, p)] : crosse[u_of(s2, hh, p)];
+                      v[p] = c < G1 ? Wk(k, e.wbase + c) * e.scale : 0.0;
+                    }
+                    const size_t b = base + (size_t)(20 + 4 * part + 2 * s2) * 64 + lane;
+                    pack8m(v, wm[b], wm[b + 64]);
+                  }
+            }
+          }
+        L.dg.wm = dev_upload(wm);
+      }
     }
   }
 
@@ -1104,6 +1166,21 @@ void run_layer(jamun_sampler* s, size_t l, const float* x_in, int XSin, float* x
       ProfScope ps(s, JAMUN_PROF_CONV0_INIT, st);
       const int rcode = launch_conv_init(f, s->fused_grid, st);
       if (rcode != 0) throw Err(JAMUN_ERR_INVALID, "initial-projector conv launch failed (configuration not supported)");
+    } else if (l > 0 && s->dg_on && s->dg_mode == 4) {
+      MfArgs f{};
+      f.deg = s->deg; f.esrc = s->esrc; f.egeo = s->egeo; f.h = h_l; f.h_kstride = s->h_kstride; f.x = x_in;
+      f.n_pad = s->n_pad; f.S = s->S; f.XS = XSin; f.n_atoms = s->n_atoms;
+      f.tile_span = s->dg_tile_span; f.tile_atoms = s->dg_tile_atoms; f.segs = s->dg_segs; f.max_segs = s->dg_max_segs; f.nt0 = L.p0.nt;
+      f.wm = L.dg.wm; f.Tt = s->dg_T; f.t_stride = s->dg_tstride; f.sB = L.dg.sB; f.sTw = L.dg.sTw;
+      {
+        int e3 = 0;
+        std::frexp(1.5 * (double)L.dg.hmax2, &e3);  // 3 max|h~| < 2^e3
+        f.sC = std::max(-40, std::min(40, 14 - e3));
+      }
+      f.partial0 = s->partial0; f.partial1 = s->partial1; f.err = s->mf_err;
+      ProfScope ps(s, JAMUN_PROF_CONV0, st);  // (the T pre-pass is part of the hidden-layer conv: timed with it)
+      launch_tprod(x_in, XSin, s->n_atoms, s->hp.edge_attr_dim + 1, L.dg.wt, L.dg.wth, L.dg.sBt, s->dg_T, s->dg_tstride, st);
+      if (launch_conv_mf(f, s->dg_grid, st) != 0) throw Err(JAMUN_ERR_INVALID, "matrix-formed conv launch failed (configuration not supported)");
     } else if (l > 0 && s->dg_on) {
       DgArgs f{};
       f.deg = s->deg; f.esrc = s->esrc; f.egeo = s->egeo; f.h = h_l; f.h_kstride = s->h_kstride; f.x = x_in;
@@ -1122,7 +1199,7 @@ void run_layer(jamun_sampler* s, size_t l, const float* x_in, int XSin, float* x
         f.dump = s->dg_dump;
       }
       ProfScope ps(s, JAMUN_PROF_CONV0, st);  // (the T pre-pass is part of the hidden-layer conv: timed with it)
-      launch_tprod(x_in, XSin, s->n_atoms, s->hp.edge_attr_dim + 1, L.dg.wt, s->dg_emu ? L.dg.wth : nullptr, L.dg.sBt, s->dg_T, st);
+      launch_tprod(x_in, XSin, s->n_atoms, s->hp.edge_attr_dim + 1, L.dg.wt, s->dg_emu ? L.dg.wth : nullptr, L.dg.sBt, s->dg_T, 0, st);
       const int rcode = launch_conv_dg(f, s->dg_grid, st);
       if (rcode != 0) throw Err(JAMUN_ERR_INVALID, "destination-grouped conv launch failed (configuration not supported)");
     } else if (L.fu.wpack) {
@@ -1412,7 +1489,7 @@ int jamun_sampler_create(const jamun_model* m, float sigma, const jamun_topology
     if (s->S < 1) s->S = 1;
     s->n_tiles = s->n_pad / 32;
     if (conv_set_max_lds() != 0 || conv_fused_set_max_lds() != 0 || node_update_set_max_lds() != 0 || conv_init_set_max_lds() != 0 || conv_initv_set_max_lds() != 0 ||
-        conv_dg_set_max_lds() != 0)
+        conv_dg_set_max_lds() != 0 || conv_mf_set_max_lds() != 0)
       throw Err(JAMUN_ERR_HIP, "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed");
     {
       // ---- fused conv kernel: eligibility and tiling.  A tile = up to 32 consecutive destination atoms whose source
@@ -1647,6 +1724,31 @@ int jamun_sampler_create(const jamun_model* m, float sigma, const jamun_topology
             n_chunks = nc2; span_max = sm2; s->dg_row_blocks = false; s->dg_mode = 3;
           }
         }
+        // A operand formed on the matrix cores (jamun_conv_mf.hip): spans that fit one K = 64 window of source rows (from an even
+        // atom: 62 rows), when that budget costs no tiles; f16x3 only
+        if ((s->dg_mode == 0 || s->dg_mode == 2 || s->dg_mode == 3) && s->dg_emu && getenv("JAMUN_DG_NO_MF") == nullptr && s->layers.size() > 1 && s->layers[1].dg.wm) {
+          std::vector<int2> a2, s2;
+          std::vector<int> c2;
+          int nc2 = 0, sm2 = 0;
+          bool rb2 = false;
+          plan_tiles(topo->ptr, graph_of, N, 62, a2, s2, c2, nc2, sm2, rb2);
+          // (the edges of one ordered pair share one coefficient entry, owned by the first with up to two more added: radial edge +
+          // at most two listings of the bond)
+          int mult = 0;
+          {
+            std::vector<std::pair<int64_t, int64_t>> bb;
+            for (int b = 0; b < topo->n_bonds; ++b) bb.push_back({topo->bond_src[b], topo->bond_dst[b]});
+            std::sort(bb.begin(), bb.end());
+            for (size_t i = 0, j = 0; i < bb.size(); i = j) {
+              while (j < bb.size() && bb[j] == bb[i]) ++j;
+              mult = std::max(mult, (int)(j - i));
+            }
+          }
+          if (!rb2 && sm2 <= 62 && mult <= 2 && 100 * a2.size() <= 103 * t_atoms.size()) {
+            t_atoms.swap(a2); t_span.swap(s2); t_chunk.swap(c2);
+            n_chunks = nc2; span_max = sm2; s->dg_row_blocks = false; s->dg_mode = 4;
+          }
+        }
         s->dg_RS = std::max((span_max + 3) & ~3, 16);  // (>= 16 rows: the segment-end staging tile of the forming waves aliases the source rows)
         s->dg_n_tiles = (int)t_atoms.size();
         // k-slices over XCD groups (JAMUN_DG_KGROUPS = 1, 2, 4, 8).  Measured on MI355X (cfg2, profiles/r2*): 1 slice 0.317 ms per
@@ -1662,7 +1764,17 @@ int jamun_sampler_create(const jamun_model* m, float sigma, const jamun_topology
         s->dg_atom_nslab = dev_upload(P.atom_nslab);
         s->dg_tile_atoms = dev_upload(t_atoms);
         s->dg_tile_span = dev_upload(t_span);
-        s->dg_T = dev_alloc<float>((size_t)n_k * N * 32);
+        if (s->dg_mode == 4) {
+          s->dg_tstride = ((N + 31) & ~31) + 64;
+          s->dg_T = dev_alloc<float>((size_t)n_k * 32 * s->dg_tstride);
+          HIPCHECK(hipMemset(s->dg_T, 0, sizeof(float) * (size_t)n_k * 32 * s->dg_tstride));
+          s->mf_err = dev_alloc<int>(1);
+          HIPCHECK(hipMemset(s->mf_err, 0, sizeof(int)));
+          HIPCHECK(hipHostMalloc((void**)&s->mf_err_host, sizeof(int), hipHostMallocDefault));
+          *s->mf_err_host = 0;
+        } else {
+          s->dg_T = dev_alloc<float>((size_t)n_k * N * 32);
+        }
         s->dg_on = true;
         // initial projector on the same tiles: two LDS buffers of table rows when they fit (spans up to ~90 rows), else one
         // (up to ~170 rows)
@@ -1724,7 +1836,8 @@ int jamun_sampler_create(const jamun_model* m, float sigma, const jamun_topology
         // per (tile, k) in k_conv_dg: fp32 path 476 units of v_mfma_f32_32x32x2 (4096 FLOP); f16x3 path 150 v_mfma_f32_32x32x16_f16
         // (32768 FLOP: 50 groups of 16 inputs x 3 products) + 72 v_mfma_f32_16x16x32_f16 (16384 FLOP); + 60 fp32 units per (32 atoms, k)
         // in the T pre-pass
-        const int64_t per_tile_k = s->dg_emu ? (150LL * 32768 + 72LL * 16384) : 476LL * 4096;
+        // (mode 4, jamun_conv_mf.hip: 414 v_mfma_f32_32x32x16_f16 per (tile, k): 228 forming + 186 contraction)
+        const int64_t per_tile_k = s->dg_mode == 4 ? 414LL * 32768 : s->dg_emu ? (150LL * 32768 + 72LL * 16384) : 476LL * 4096;
         s->conv_flop_exec_launch = ((int64_t)s->dg_n_tiles * per_tile_k + (int64_t)((s->n_atoms + 31) / 32) * 60 * 4096) * (hp.edge_attr_dim + 1);
         s->flop_exec += s->conv_flop_exec_launch;
       }

@@ -393,7 +393,7 @@ __global__ __launch_bounds__(DG_THREADS) void k_conv_dg(DgArgs a) {
       // way: left alone, the compiler reads each fragment into the register of the previous one right before its use, and
       // the matrix pipe drains at every group of four MFMAs while the LDS read returns — about a quarter of the matrix
       // waves' time.  Two fragments in flight is what the register budget of 168 allows without spilling weight pointers.)
-#define DG_SB() __builtin_amdgcn_sched_barrier(0)
+#define DG_SCHB() __builtin_amdgcn_sched_barrier(0)
 #define DG_M4(ACC, A, Bv)                                                                                                    \
   ACC = MFMA32(A.x, Bv.x, ACC);                                                                                              \
   ACC = MFMA32(A.y, Bv.y, ACC);                                                                                              \
@@ -407,7 +407,7 @@ __global__ __launch_bounds__(DG_THREADS) void k_conv_dg(DgArgs a) {
         if (dbg_nomfma) return;
         if constexpr (H) {
           const float4 h0 = LDF(Xa + 32 * c), l0 = LDF(Xa + 32 * c + 4), h1 = LDF(Xa + 32 * c + 16), l1 = LDF(Xa + 32 * c + 20);
-          DG_SB();
+          DG_SCHB();
           DG_M3(accM, h0, l0, B[0], B[1]);
           DG_M3(accM, h1, l1, B[2], B[3]);
           if ((w >> 1) == (c & 1)) {  // this wave's group of scalar tile 4: the (w & 1)-th group of the chunk
@@ -419,17 +419,17 @@ __global__ __launch_bounds__(DG_THREADS) void k_conv_dg(DgArgs a) {
         const bool last = (c == 3);  // chunk 3 holds groups 12..14 only
         float4 a0 = *reinterpret_cast<const float4*>(Xa + 8 * (4 * c));
         float4 a1 = *reinterpret_cast<const float4*>(Xa + 8 * (4 * c + 1));
-        DG_SB();
+        DG_SCHB();
         DG_M4(accM, a0, B[0]);
         a0 = *reinterpret_cast<const float4*>(Xa + 8 * (4 * c + 2));
-        DG_SB();
+        DG_SCHB();
         DG_M4(accM, a1, B[1]);
         a1 = *reinterpret_cast<const float4*>(Xa + 8 * (last ? 4 * c + w : 4 * c + 3));
-        DG_SB();
+        DG_SCHB();
         DG_M4(accM, a0, B[2]);
         if (!last) {
           a0 = *reinterpret_cast<const float4*>(Xa + 8 * (4 * c + w));  // this wave's quarter group of scalar tile 4
-          DG_SB();
+          DG_SCHB();
           DG_M4(accM, a1, B[3]);
           DG_M4(acc4, a0, B[4]);
         } else {
@@ -463,7 +463,7 @@ __global__ __launch_bounds__(DG_THREADS) void k_conv_dg(DgArgs a) {
           float4 h0, l0, h1, l1;
           split8(f00, f01, h0, l0);
           split8(f10, f11, h1, l1);
-          DG_SB();
+          DG_SCHB();
           DG_M3(accM, h0, l0, B[0], B[1]);
           DG_M3(accM, h1, l1, B[2], B[3]);
           if (w == 0) { DG_M3(acc4, h0, l0, B[4], B[5]); }
@@ -472,16 +472,16 @@ __global__ __launch_bounds__(DG_THREADS) void k_conv_dg(DgArgs a) {
         }
         float4 a0 = *reinterpret_cast<const float4*>(Da);
         float4 a1 = *reinterpret_cast<const float4*>(Da + 8);
-        DG_SB();
+        DG_SCHB();
         DG_M4(accM, a0, B[0]);
         a0 = *reinterpret_cast<const float4*>(Da + 16);
-        DG_SB();
+        DG_SCHB();
         DG_M4(accM, a1, B[1]);
         a1 = *reinterpret_cast<const float4*>(Da + 24);
-        DG_SB();
+        DG_SCHB();
         DG_M4(accM, a0, B[2]);
         a0 = *reinterpret_cast<const float4*>(Da + 8 * w);  // this wave's K quarter of scalar tile 4
-        DG_SB();
+        DG_SCHB();
         DG_M4(accM, a1, B[3]);
         DG_M4(acc4, a0, B[4]);
       };
@@ -506,27 +506,27 @@ __global__ __launch_bounds__(DG_THREADS) void k_conv_dg(DgArgs a) {
               fh[m] = LDF(Va + m * 32 * DG_YV + 32 * g);
               fl[m] = LDF(Va + m * 32 * DG_YV + 32 * g + 4);
             }
-            DG_SB();
+            DG_SCHB();
 #pragma unroll
             for (int m = 0; m < 3; ++m) accP[m] = MFMA16H(fl[m], B[2 * g], accP[m]);
 #pragma unroll
             for (int m = 0; m < 3; ++m) accP[m] = MFMA16H(fh[m], B[2 * g + 1], accP[m]);
 #pragma unroll
             for (int m = 0; m < 3; ++m) accP[m] = MFMA16H(fh[m], B[2 * g], accP[m]);
-            DG_SB();
+            DG_SCHB();
           }
           return;
         }
         float4 av[2][3];
 #pragma unroll
         for (int m = 0; m < 3; ++m) av[0][m] = *reinterpret_cast<const float4*>(Va + m * 32 * DG_YV);
-        DG_SB();
+        DG_SCHB();
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           if (i < 3) {
 #pragma unroll
             for (int m = 0; m < 3; ++m) av[(i + 1) & 1][m] = *reinterpret_cast<const float4*>(Va + m * 32 * DG_YV + 16 * (i + 1));
-            DG_SB();
+            DG_SCHB();
           }
           float4(&A)[3] = av[i & 1];
 #pragma unroll
@@ -537,7 +537,7 @@ __global__ __launch_bounds__(DG_THREADS) void k_conv_dg(DgArgs a) {
           for (int m = 0; m < 3; ++m) accP[m] = MFMA16(A[m].z, B[i].z, accP[m]);
 #pragma unroll
           for (int m = 0; m < 3; ++m) accP[m] = MFMA16(A[m].w, B[i].w, accP[m]);
-          if (i < 3) DG_SB();
+          if (i < 3) DG_SCHB();
         }
       };
       // T_k[j][w'] = sum_u x0_j[u] W[(k,u)][w'] comes from the pre-pass k_tprod (once per source atom and layer, not once
@@ -1439,7 +1439,7 @@ __global__ __launch_bounds__(64 * TP_WAVES) __attribute__((amdgpu_waves_per_eu(2
 // on the host after scaling by 2^sBt) stream through a double buffer and 24 MFMAs of 32 cycles replace 60 of 64.  The kernel turns
 // from MFMA-bound to bound by its weight stream (16 KB per wave and hidden unit from L2).
 __global__ __launch_bounds__(64 * TP_WAVES) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_tprod_h(
-    const float* __restrict__ x, int XS, int n_atoms, int n_k, int kg, const float4* __restrict__ wth, int sBt, float* __restrict__ T) {
+    const float* __restrict__ x, int XS, int n_atoms, int n_k, int kg, const float4* __restrict__ wth, int sBt, float* __restrict__ T, int t_stride) {
   const int lane = threadIdx.x & 63, wave = RFL(threadIdx.x >> 6);
   const int r = lane & 31, hh = lane >> 5;
   const int gid = blockIdx.x * TP_WAVES + wave;
@@ -1500,6 +1500,14 @@ __global__ __launch_bounds__(64 * TP_WAVES) __attribute__((amdgpu_waves_per_eu(2
       acc = MFMA32H(wv[2 * q], xl[q], acc);
       acc = MFMA32H(wv[2 * q], xh[q], acc);
     }
+    if (t_stride > 0) {  // transposed for k_conv_mf: [k][w'][atom], 128 contiguous bytes per (channel, half-wave)
+      float* __restrict__ tk = T + (size_t)k * 32 * t_stride + a0 + r;
+      if (a0 + r < n_atoms) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) tk[(size_t)((q & 3) + 8 * (q >> 2) + 4 * hh) * t_stride] = acc[q] * isc;
+      }
+      return;
+    }
     float* __restrict__ tk = T + ((size_t)k * n_atoms + a0) * 32;
     if (a0 + r < n_atoms) {
 #pragma unroll
@@ -1518,11 +1526,11 @@ __global__ __launch_bounds__(64 * TP_WAVES) __attribute__((amdgpu_waves_per_eu(2
   }
 }
 
-void launch_tprod(const float* x, int XS, int n_atoms, int n_k, const float4* wt, const float4* wth, int sBt, float* T, hipStream_t st) {
+void launch_tprod(const float* x, int XS, int n_atoms, int n_k, const float4* wt, const float4* wth, int sBt, float* T, int t_stride, hipStream_t st) {
   const int tiles = (n_atoms + 31) / 32;
   const int kg = std::min(n_k, std::max(1, 1024 / tiles));
   if (wth)
-    hipLaunchKernelGGL(k_tprod_h, dim3((tiles * kg + TP_WAVES - 1) / TP_WAVES), dim3(64 * TP_WAVES), 0, st, x, XS, n_atoms, n_k, kg, wth, sBt, T);
+    hipLaunchKernelGGL(k_tprod_h, dim3((tiles * kg + TP_WAVES - 1) / TP_WAVES), dim3(64 * TP_WAVES), 0, st, x, XS, n_atoms, n_k, kg, wth, sBt, T, t_stride);
   else
     hipLaunchKernelGGL(k_tprod, dim3((tiles * kg + TP_WAVES - 1) / TP_WAVES), dim3(64 * TP_WAVES), 0, st, x, XS, n_atoms, n_k, kg, wt, T);
 }

@@ -107,6 +107,37 @@ struct DgArgs {
   float* partial1;   // [slab][n_pad][3][32]
 };
 
+// conv with the A operand formed on the matrix cores and chained into the contraction (jamun_conv_mf.hip): hidden layers with
+// irreps 120x0e + 32x1e, tiles whose source span fits a K = 64 window
+struct MfArgs {
+  const int* deg;
+  const int* esrc;
+  const float4* egeo;
+  const float* h;  // [hidden unit k (65 rows)][h_kstride]
+  size_t h_kstride;
+  const float* x;  // [n_atoms][XS = 216]
+  int n_pad, S, XS, n_atoms;
+  const int2* tile_span;   // [n_tiles] {lo, hi} source atoms of the tile (hi - lo <= 62)
+  const int2* tile_atoms;  // [n_tiles] {first destination atom, number of destination atoms (<= 32)}
+  const int4* segs;        // [grid][max_segs][2]: as FusedArgs
+  int max_segs, nt0;
+  // wm [k][matrix wave w][40 blocks of 64 lanes x 8 halves] in the wave's consumption order, (hi, lo) pairs; B fragments of
+  // v_mfma_f32_32x32x16_f16 with the K index of a step permuted to the accumulator layout of the forming MFMA: half p of lane
+  // (column c, hh) <-> input 16 s2 + (p & 3) + 8 (p >> 2) + 4 hh of the wave's 32 channels:
+  //   2 (2 n + s2) + {0, 1}        the wave's scalar channels 32 w .. 32 w + 31 -> scalar-output tile n
+  //   wave 0: 20 + 2 (2 n + s2)    dot(x1, v) inputs -> scalar-output tile n
+  //   wave 1 + m: 20 + 2 s2        x1 inputs -> vector rows;   24 + 2 s2   cross inputs -> vector rows
+  const float4* wm;
+  const float* Tt;   // [k][32 w'][t_stride] TRANSPOSED pre-pass product (k_tprod_h): T_k[j][w'] at Tt[(k * 32 + w') * t_stride + j]
+  int t_stride;      // even, >= n_atoms + 64
+  int sB;            // weights were scaled by 2^sB before the split (largest below 2^14)
+  int sC;            // coefficients are scaled by 2^sC: 3 max|h~| (an entry may sum three edges of one pair) below 2^14
+  int sTw;           // 2^sTw x (largest column sum of |T weights|) < 1: T_k = x0 W is scaled by 2^(sX + sTw)
+  float* partial0;   // [slab][n_pad][nt0*32]
+  float* partial1;   // [slab][n_pad][3][32]
+  int* err;          // device flag: bit 0 = more than three edges of one (source, destination) pair
+};
+
 // initial-projector conv (jamun_conv_init.hip): apply-only contraction against the precomputed input-times-weight table
 struct InitArgs {
   const int* deg;
@@ -247,7 +278,10 @@ int conv_dg_set_max_lds();
 void conv_dg_print_stamps();
 void conv_initv_print_stamps();
 size_t conv_dg_lds_bytes(int rs, int pmax, int mode, int emu);
-void launch_tprod(const float* x, int XS, int n_atoms, int n_k, const float4* wt, const float4* wth, int sBt, float* T, hipStream_t st);
+void launch_tprod(const float* x, int XS, int n_atoms, int n_k, const float4* wt, const float4* wth, int sBt, float* T, int t_stride, hipStream_t st);
+int launch_conv_mf(const MfArgs& a, int grid, hipStream_t st);
+int conv_mf_set_max_lds();
+size_t conv_mf_lds_bytes();
 int launch_conv_init(const InitArgs& a, int grid, hipStream_t st);
 int launch_conv_initv(const InitVArgs& a, int grid, hipStream_t st);
 int conv_initv_set_max_lds();

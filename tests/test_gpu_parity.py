@@ -292,30 +292,35 @@ def test_fused_and_fallback_conv_agree(dev, golden_dir, kind, monkeypatch):
     # Y tile (mid-size spans), two phases with resident source rows, two passes (large molecules).  Switch the chosen one off
     # and the two-phase kernel must give the same features.
     mode = dg.stats()["dg_mode"]
-    expect = {"ag4": 2, "chain17x6": 2, "ragged_small": 2, "ragged": 3, "dense70": 3, "chig93x2": 1, "chig166x2": 1}[kind]
+    # Spans up to 62 source rows take jamun_conv_mf.hip (A operand formed on the matrix cores, dg_mode 4).  jamun_conv_dg.hip, the
+    # VALU-forming kernel for everything larger, has four variants chosen by the span of the tiles: single phase (2), single phase
+    # with one Y tile (3), two phases with resident source rows (0), two passes (large molecules, 1).  Each variant that can take
+    # this batch is switched on in turn and must give the same features.
+    expect = {"ag4": 4, "chain17x6": 4, "ragged_small": 4, "ragged": 4, "dense70": 3, "chig93x2": 1, "chig166x2": 1}[kind]
     assert mode == expect, (kind, mode)
-    if mode in (1, 2, 3):
-        off = {1: "JAMUN_DG_NO_ALT", 2: "JAMUN_DG_NO_SP", 3: "JAMUN_DG_NO_SPH"}[mode]
-        monkeypatch.setenv(off, "1")
-        if mode == 2:
-            monkeypatch.setenv("JAMUN_DG_NO_SPH", "1")
+    small = kind in ("ag4", "chain17x6", "ragged_small")  # spans within the single-phase budget of jamun_conv_dg.hip (~52 rows)
+    variants = {4: [("JAMUN_DG_NO_MF",)], 1: [("JAMUN_DG_NO_ALT",)], 2: [], 3: []}[mode]
+    if mode == 4:
+        variants.append(("JAMUN_DG_NO_MF", "JAMUN_DG_NO_SP") if small else ("JAMUN_DG_NO_MF", "JAMUN_DG_NO_SPH"))
+        if small:
+            variants.append(("JAMUN_DG_NO_MF", "JAMUN_DG_NO_SP", "JAMUN_DG_NO_SPH"))
+    if mode == 3:
+        variants.append(("JAMUN_DG_NO_SPH",))
+    seen = {mode}
+    for envs in variants:
+        for e in envs:
+            monkeypatch.setenv(e, "1")
         other = NativeSampler(model._native, 0.04, batch, dev)
-        monkeypatch.delenv(off)
-        monkeypatch.delenv("JAMUN_DG_NO_SPH", raising=False)
-        assert other.stats()["dg_mode"] == 0
+        for e in envs:
+            monkeypatch.delenv(e)
+        seen.add(other.stats()["dg_mode"])
+        assert other.stats()["conv_path"] == 2 and other.stats()["dg_mode"] != mode, (envs, other.stats()["dg_mode"])
         assert rmsd(other.xhat(y), xg) <= RMSD_TOL_NM
         for l in range(6):
             a2, b2 = other.debug_read(0, l).cpu(), general.debug_read(0, l).cpu()
-            assert (a2 - b2).abs().max().item() <= 2e-5 * max(b2.abs().max().item(), 1e-6), l
-    if mode == 2:  # ... and the one-Y-tile variant on the same small batch
-        monkeypatch.setenv("JAMUN_DG_NO_SP", "1")
-        sph = NativeSampler(model._native, 0.04, batch, dev)
-        monkeypatch.delenv("JAMUN_DG_NO_SP")
-        assert sph.stats()["dg_mode"] == 3
-        assert rmsd(sph.xhat(y), xg) <= RMSD_TOL_NM
-        for l in range(6):
-            a3, b3 = sph.debug_read(0, l).cpu(), general.debug_read(0, l).cpu()
-            assert (a3 - b3).abs().max().item() <= 2e-5 * max(b3.abs().max().item(), 1e-6), l
+            assert (a2 - b2).abs().max().item() <= 2e-5 * max(b2.abs().max().item(), 1e-6), (envs, l)
+    assert seen == {"ag4": {4, 2, 3, 0}, "chain17x6": {4, 2, 3, 0}, "ragged_small": {4, 2, 3, 0}, "ragged": {4, 3, 0}, "dense70": {3, 0},
+                    "chig93x2": {1, 0}, "chig166x2": {1, 0}}[kind], seen
     # the initial projector of the default path runs edge by edge on the tiles of the dg kernel when the spans fit two LDS row
     # buffers (jamun_conv_initv.hip); switched off, the MFMA table kernel takes the layer — same features
     # (two LDS row buffers for molecules up to 40 atoms, one for chignolin-size spans; mid-size molecules keep the MFMA table kernel)
@@ -380,7 +385,7 @@ def test_fused_and_fallback_conv_agree_on_random_ragged_batches(dev, seed, monke
                 assert (a - b).abs().max().item() <= 2e-5 * max(b.abs().max().item(), 1e-6), (trial, l)
 
 
-@pytest.mark.parametrize("atoms,walkers,dg_mode,init_path", [(17, 64, 2, 2), (33, 64, 3, 2), (57, 32, 3, 1), (166, 4, 1, 2)])
+@pytest.mark.parametrize("atoms,walkers,dg_mode,init_path", [(17, 64, 4, 2), (33, 64, 3, 2), (57, 32, 4, 1), (166, 4, 1, 2)])
 def test_kernel_variants_chosen_for_the_baseline_shapes(dev, atoms, walkers, dg_mode, init_path):
     """BASELINE configs[1..4] shapes (fewer walkers): which variant of the hidden-layer conv kernel (jamun_stats.dg_mode) and of
     the initial projector (init_path) the sampler picks, and that the forward through them is finite and rotation-equivariant."""
@@ -462,7 +467,7 @@ def test_full_size_batches_of_the_multi_gpu_configs_match_the_oracle(dev, golden
     elif cfg == "cfg4":  # bench.py's cfg4 workload: eight sequences, 32 consecutive walkers each
         kinds = _mols("cfg4kinds")
         fixture, mols = "cfg4kinds", [m for m in kinds for _ in range(32)]
-        slots, expect_modes = [32 * i for i in range(8)], (0, 3)
+        slots, expect_modes = [32 * i for i in range(8)], (4,)
     else:
         fixture, mols = "chig166x2", [synth.random_chain(166, seed=5)] * 64
         slots, expect_modes = [0, 1], (1,)
