@@ -991,44 +991,39 @@ LayerDev build_layer(const jamun_model& m, const std::string& prefix, const std:
         L.dg.sTw = std::max(-40, std::min(40, -exs));
         auto pack8m = [&](const double (&v)[8], float4& hi, float4& lo) { pack8(v, hi, lo); };
         auto u_of = [](int s2, int hh, int p) { return 16 * s2 + (p & 3) + 8 * (p >> 2) + 4 * hh; };
-        std::vector<float4> wm((size_t)n_k * 4 * 40 * 64, make_float4(0.f, 0.f, 0.f, 0.f));
-        for (int k = 0; k < n_k; ++k)
-          for (int w = 0; w < 4; ++w) {
-            const size_t base = (((size_t)k * 4 + w) * 40) * 64;
-            for (int lane = 0; lane < 64; ++lane) {
-              const int hh = lane >> 5, c = lane & 31;
+        // stream of hidden unit k: 124 blocks = waves 0..3 (scalar channels 32 w ..: 20 blocks, (hi, lo) per (output tile n, K-step s2)),
+        // wave 4 (dot inputs: 20), waves 5..7 (vector plane: x1 inputs 4 blocks, cross inputs 4 — the same for every plane)
+        std::vector<float4> wm((size_t)n_k * 124 * 64, make_float4(0.f, 0.f, 0.f, 0.f));
+        for (int k = 0; k < n_k; ++k) {
+          const size_t kb = (size_t)k * 124 * 64;
+          for (int lane = 0; lane < 64; ++lane) {
+            const int hh = lane >> 5, c = lane & 31;
+            for (int w = 0; w < 5; ++w)
               for (int n = 0; n < 5; ++n)
                 for (int s2 = 0; s2 < 2; ++s2) {
                   const int col = 32 * n + c;
                   double v[8];
                   for (int p = 0; p < 8; ++p) {
                     const int u = 32 * w + u_of(s2, hh, p);
-                    v[p] = (u < 120 && col < G0) ? Wk(k, x0e[u].wbase + col) * x0e[u].scale : 0.0;
+                    if (w < 4) v[p] = (u < 120 && col < G0) ? Wk(k, x0e[u].wbase + col) * x0e[u].scale : 0.0;
+                    else v[p] = col < G0 ? Wk(k, dote[u - 128].wbase + col) * dote[u - 128].scale : 0.0;
                   }
-                  const size_t b = base + (size_t)(2 * (2 * n + s2)) * 64 + lane;
+                  const size_t b = kb + (size_t)(20 * w + 2 * (2 * n + s2)) * 64 + lane;
                   pack8m(v, wm[b], wm[b + 64]);
-                  if (w == 0) {
-                    for (int p = 0; p < 8; ++p) {
-                      const int u = u_of(s2, hh, p);
-                      v[p] = col < G0 ? Wk(k, dote[u].wbase + col) * dote[u].scale : 0.0;
-                    }
-                    const size_t bd = base + (size_t)(20 + 2 * (2 * n + s2)) * 64 + lane;
-                    pack8m(v, wm[bd], wm[bd + 64]);
-                  }
                 }
-              if (w > 0)
-                for (int part = 0; part < 2; ++part)  // x1 inputs, then cross inputs -> vector rows (32 columns)
-                  for (int s2 = 0; s2 < 2; ++s2) {
-                    double v[8];
-                    for (int p = 0; p < 8; ++p) {
-                      const UEntry& e = part == 0 ? x1e[u_of(s2, hh, p)] : crosse[u_of(s2, hh, p)];
-                      v[p] = c < G1 ? Wk(k, e.wbase + c) * e.scale : 0.0;
-                    }
-                    const size_t b = base + (size_t)(20 + 4 * part + 2 * s2) * 64 + lane;
-                    pack8m(v, wm[b], wm[b + 64]);
+            for (int m = 0; m < 3; ++m)
+              for (int part = 0; part < 2; ++part)  // x1 inputs, then cross inputs -> vector rows (32 columns)
+                for (int s2 = 0; s2 < 2; ++s2) {
+                  double v[8];
+                  for (int p = 0; p < 8; ++p) {
+                    const UEntry& e = part == 0 ? x1e[u_of(s2, hh, p)] : crosse[u_of(s2, hh, p)];
+                    v[p] = c < G1 ? Wk(k, e.wbase + c) * e.scale : 0.0;
                   }
-            }
+                  const size_t b = kb + (size_t)(100 + 8 * m + 4 * part + 2 * s2) * 64 + lane;
+                  pack8m(v, wm[b], wm[b + 64]);
+                }
           }
+        }
         L.dg.wm = dev_upload(wm);
       }
     }
@@ -1808,7 +1803,9 @@ int jamun_sampler_create(const jamun_model* m, float sigma, const jamun_topology
       s->h_kstride = (NS + 63) & ~(size_t)63;
       s->h_stride = s->h_kstride * JAMUN_HROWS;
       s->h_batched = s->h_stride * s->layers.size() * sizeof(float) <= ((size_t)4 << 30);  // all layers' h~ at once, up to 4 GiB
-      s->h = dev_alloc<float>(s->h_stride * (s->h_batched ? s->layers.size() : 1));
+      // (+ slack: k_conv_mf reads h~ at slot0 + p * stride without a bounds test; lanes past the last atom's slots read up to
+      // 32 * S + 128 floats beyond the table and never use them)
+      s->h = dev_alloc<float>(s->h_stride * (s->h_batched ? s->layers.size() : 1) + 32 * (size_t)s->S + 256);
     }
     int nt0 = 0, nt1 = 0;
     for (auto& L : s->layers) { nt0 = std::max(nt0, L.p0.nt); nt1 = std::max(nt1, L.p1.nt); }
@@ -2123,6 +2120,7 @@ int jamun_debug_stamps(unsigned long long* out8) {
     HIPCHECK(hipDeviceSynchronize());
     conv_dg_print_stamps();
     conv_initv_print_stamps();
+    conv_mf_print_stamps();
     const int r = conv_fused_read_stamps(out8);
     if (r == -2) throw Err(JAMUN_ERR_INVALID, "library was not built with -DJAMUN_STAMP");
     if (r != 0) throw Err(JAMUN_ERR_HIP, "reading stamp counters failed");

@@ -64,6 +64,13 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 #define RFL(v) __builtin_amdgcn_readfirstlane(v)
 #define LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 
+#ifdef MF_TRACE  // per-wave timeline of workgroup 7 (diagnostic builds): [wave][k-step][stamp]
+__device__ unsigned long long g_mftrace[8][40][8];
+#define MSTAMP(slot) do { if (blockIdx.x == 7 && trc < 40) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); g_mftrace[wave][trc][slot] = t_; } } while (0)
+#else
+#define MSTAMP(slot) do { } while (0)
+#endif
+
 namespace {
 
 __device__ __forceinline__ float4 lds_f4(int addr) {
@@ -114,13 +121,19 @@ __global__ __launch_bounds__(MF_THREADS) void k_conv_mf(MfArgs a) {
   const int L0 = lds_addr(lds);
   int* __restrict__ deg_lds = reinterpret_cast<int*>(lds + MF_MISC);
   unsigned* __restrict__ xmax_lds = reinterpret_cast<unsigned*>(lds + MF_MISC + 128);
-  float* __restrict__ ST0 = reinterpret_cast<float*>(lds + MF_TT);  // segment end: [4 waves][32][160] partial scalar-output tiles
-  float* __restrict__ ST1 = reinterpret_cast<float*>(lds);          //              [32][96] vector planes
 
   const int tid0 = threadIdx.x, lane0 = tid0 & 63;
   const int wave = RFL(tid0 >> 6);
-  const bool is_mat = wave < 4;
+#if defined(MF_EXP)  // timing experiments, compile-time (-DMF_EXP=bits; results are wrong): 1 no weight loads in the k loop, 2 no forming
+                     // MFMAs, 4 no contraction MFMAs, 8 helpers build nothing, 16 no split, 32 no forming LDS reads
+  constexpr int dbg = MF_EXP;
+#else
+  constexpr int dbg = 0;
+#endif
 
+#ifdef MF_TRACE
+  int trc = 0;
+#endif
   for (int sgi = 0; sgi < a.max_segs; ++sgi) {
     const int4 sg0 = a.segs[((size_t)blockIdx.x * a.max_segs + sgi) * 2];
     const int4 sg1 = a.segs[((size_t)blockIdx.x * a.max_segs + sgi) * 2 + 1];
@@ -191,302 +204,417 @@ __global__ __launch_bounds__(MF_THREADS) void k_conv_mf(MfArgs a) {
     }
 
     const int r = lane & 31, hh = lane >> 5;
-    if (is_mat) {
-      // =========================================== MATRIX waves ===========================================
-      const int w = wave;
-      f32x16 accS[5], accP, accT;
-#pragma unroll
-      for (int n = 0; n < 5; ++n)
-#pragma unroll
-        for (int q = 0; q < 16; ++q) accS[n][q] = 0.f;
-#pragma unroll
-      for (int q = 0; q < 16; ++q) accP[q] = accT[q] = 0.f;
-      // formed values are below in-degree x 2^28: x 2^-(14 + e(in-degree)) of this lane's destination -> below 2^14
-      const int edeg_r = deg_lds[r] > 0 ? exp_above((float)deg_lds[r]) : 1;
-      const float rs = pow2f(-14 - edeg_r);
-      const int fo = r * MF_ROWB + 16 * hh + L0;            // this lane's fragment offset inside a 32-row tile
-      const int x0a = MF_X0H + 32 * w * MF_ROWB + fo;       // its row of the wave's 32 scalar channels (lo plane: + MF_X0L)
-      // weight blocks: buffer loads with ONE address register (the lane's 16 bytes) and the block offset in a scalar register
-      const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float4*>(a.wm), 0, 0x7fffffff, 0x00020000);
-      const int wvo = lane * 16;
-      auto wstream = [&](int k) { return (k * 4 + w) * (40 * 1024); };  // byte offset of this wave's stream of hidden unit k
-      auto wload = [&](int so) { return __builtin_amdgcn_raw_buffer_load_b128(wrs, wvo, so, 0); };
-      // forming: F[u][i] += sum_j x^T[u][j] C[i][j] over the four K-steps (x fragment at xa / xa + xlo, C at ca / ca + MF_PL)
-      auto form = [&](f32x16& F, int xa, int xlo, int ca) {
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-          const float4 ah = lds_f4(xa + 32 * s), al = lds_f4(xa + xlo + 32 * s), bh = lds_f4(ca + 32 * s), bl = lds_f4(ca + MF_PL + 32 * s);
-          M3(F, ah, al, bh, bl);
-        }
-      };
-      auto split = [&](const f32x16& F, float4 (&Ah)[2], float4 (&Al)[2]) {
-#pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2) {
-          unsigned ph[4], pl[4];
-#pragma unroll
-          for (int p2 = 0; p2 < 4; ++p2) {
-            const float v0 = F[8 * s2 + 2 * p2] * rs, v1 = F[8 * s2 + 2 * p2 + 1] * rs;
-            ph[p2] = cvt_pk_f16(v0, v1);
-            pl[p2] = cvt_pk_f16(resid_lo(v0, ph[p2]), resid_hi(v1, ph[p2]));
-          }
-          Ah[s2] = make_float4(__uint_as_float(ph[0]), __uint_as_float(ph[1]), __uint_as_float(ph[2]), __uint_as_float(ph[3]));
-          Al[s2] = make_float4(__uint_as_float(pl[0]), __uint_as_float(pl[1]), __uint_as_float(pl[2]), __uint_as_float(pl[3]));
-        }
-      };
-      const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 
-      if (w == 0) {
-        // ---- wave 0: scalar channels 0..31 and the dot inputs; weight stream of 40 blocks per k, ring of 20
-        constexpr int NB = 40, R = 20;
-        u32x4 RB[R];
-        {
-          const int c0 = wstream(k_of(0));
+    // ---- builder lanes: their share of the coefficient-tile entries (edge slots) and of the T tile.  Edge strides up to 32: waves
+    // 0..3 (the lighter matrix role), four passes of 8 destinations x 32 slots; above: all eight waves, four passes of 8 x 64
+    constexpr int BT = SPD == 32 ? 256 : 512;        // builder threads
+    constexpr int DPP = BT / SPD, NP = 32 / DPP;     // destinations per pass, passes
+    constexpr int NTV = 1024 / BT;                   // T elements (pairs of source rows) per builder lane
+    const bool builder = tid < BT;
+    const int gsh = (SPD == 32) ? 32 * (lane >> 5) : 0;  // this lane group's bit offset inside the wave's ballot
+    // per pass ONE packed word: bits 0..12 byte offset of the entry inside a coefficient plane (i * 144 + 2 jl), 13..18 / 19..24 the
+    // slot distance to a second / third edge of the same pair (0: none), bit 31 set: no entry.  The slot of pass p is slot0 + p * DPP * S.
+    int ent[NP];
+    const int slot0 = (n0 + (tid & (BT - 1)) / SPD) * a.S + (tid & (BT - 1)) % SPD, pstride = DPP * a.S;
+    float evx[NP], evy[NP], evz[NP];
+    bool any_tw = false;
 #pragma unroll
-          for (int p = 0; p < R; ++p) RB[p] = wload(c0 + p * 1024);
-        }
-        LDS_BARRIER();  // C(k0), T(k0) complete
-        for (int it = 0; it < nk; ++it) {
-          const int cur = wstream(k_of(it)), nxt = wstream(k_of(it + 1));
-          const int cb = MF_C + (it & 1) * MF_CB + fo;
-          auto refill = [&](int p) {  // stream position p + R into the slot of position p
-            RB[p % R] = (p + R < NB) ? wload(cur + (p + R) * 1024) : wload(nxt + (p + R - NB) * 1024);
-          };
-          float4 Ah[2], Al[2];
-          {
-            f32x16 FX = zero16;
-            form(FX, x0a, MF_X0L - MF_X0H, cb);
-            split(FX, Ah, Al);
+    for (int p = 0; p < NP; ++p) {
+      const int g = (tid & (BT - 1)) + BT * p, i = g / SPD, t = g % SPD;
+      const int dg = deg_lds[i];
+      const int slot = (n0 + i) * a.S + t;
+      const bool in = builder && t < dg && t < a.S;
+      const int sj = in ? a.esrc[slot] : 0;
+      float4 ge = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (in) ge = a.egeo[slot];
+      const bool bonded = in && sj < 0;  // bit 31
+      const int jraw = sj & 0x7fffffff, jl = jraw - s_base;
+      const bool valid = in && jl >= 0 && jl < 64;
+      bool active = valid;
+      int d0 = 0, d1 = 0;
+      // Several edges of one (source, destination) pair (a bonded pair inside the cutoff has a radial and a bonded edge:
+      // src/jamun/model/denoiser.py:152) share ONE entry of the coefficient tile: the first slot of the pair owns it and adds
+      // the h~ of the others (bonded edges are the last slots of a destination: k_geom).
+      const unsigned long long balb = __ballot(bonded);
+      const unsigned long long gmask = (SPD == 32) ? 0xffffffffull : ~0ull;
+      const int nb = __popcll((balb >> gsh) & gmask);
+      const int nb_max = RFL(SPD == 32 ? max(__popcll(balb & 0xffffffffull), __popcll(balb >> 32)) : __popcll(balb));
+      for (int b = 0; b < nb_max; ++b) {
+        const int lb = dg - nb + b;  // slot of this group's b-th bonded edge
+        const int jb = __shfl(jraw, (lb & (SPD - 1)) + gsh, 64);
+        const bool match = b < nb && valid && t < lb && jraw == jb;
+        const unsigned long long mb = (__ballot(match) >> gsh) & gmask;
+        if (b < nb && mb != 0ull) {
+          const int first = __ffsll((long long)mb) - 1;
+          if (t == lb) active = false;
+          if (t == first) {
+            if (d0 == 0) d0 = lb - t;
+            else if (d1 == 0) d1 = lb - t;
+            else atomicOr(a.err, 1);  // more than three edges of one pair: not representable here (excluded by the host)
           }
-#pragma unroll
-          for (int n = 0; n < 5; ++n)
-#pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2) {
-              const int p = 2 * (2 * n + s2);
-              M3(accS[n], Ah[s2], Al[s2], RB[p % R], RB[(p + 1) % R]);
-              refill(p); refill(p + 1);
-            }
-          {
-            f32x16 FD = zero16;
-#pragma unroll
-            for (int m = 0; m < 3; ++m) form(FD, MF_X1H + (m * 32) * MF_ROWB + fo, MF_X1L - MF_X1H, cb + (1 + m) * 2 * MF_PL);
-            split(FD, Ah, Al);
-          }
-#pragma unroll
-          for (int n = 0; n < 5; ++n)
-#pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2) {
-              const int p = 20 + 2 * (2 * n + s2);
-              M3(accS[n], Ah[s2], Al[s2], RB[p % R], RB[(p + 1) % R]);
-              refill(p); refill(p + 1);
-            }
-          LDS_BARRIER();
-        }
-      } else {
-        // ---- waves 1..3: scalar channels 32 w.., vector plane m = w - 1; weight stream of 28 blocks per k, ring of 14
-        constexpr int NB = 28, R = 14;
-        const int m = w - 1, m1 = (m + 1) % 3, m2 = (m + 2) % 3;
-        u32x4 RB[R];
-        {
-          const int c0 = wstream(k_of(0));
-#pragma unroll
-          for (int p = 0; p < R; ++p) RB[p] = wload(c0 + p * 1024);
-        }
-        const int x1a = MF_X1H + fo;  // + plane * 32 rows
-        LDS_BARRIER();  // C(k0), T(k0) complete
-        for (int it = 0; it < nk; ++it) {
-          const int cur = wstream(k_of(it)), nxt = wstream(k_of(it + 1));
-          const int cb = MF_C + (it & 1) * MF_CB + fo;
-          const int tb = MF_TT + (it & 1) * MF_TTB + fo;
-          auto refill = [&](int p) { RB[p % R] = (p + R < NB) ? wload(cur + (p + R) * 1024) : wload(nxt + (p + R - NB) * 1024); };
-          float4 Ah[2], Al[2];
-          {
-            f32x16 FX = zero16;
-            form(FX, x0a, MF_X0L - MF_X0H, cb);
-            split(FX, Ah, Al);
-          }
-#pragma unroll
-          for (int n = 0; n < 5; ++n)
-#pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2) {
-              const int p = 2 * (2 * n + s2);
-              M3(accS[n], Ah[s2], Al[s2], RB[p % R], RB[(p + 1) % R]);
-              refill(p); refill(p + 1);
-            }
-          {
-            f32x16 FA = zero16;
-            form(FA, x1a + m * 32 * MF_ROWB, MF_X1L - MF_X1H, cb);
-            split(FA, Ah, Al);
-          }
-#pragma unroll
-          for (int s2 = 0; s2 < 2; ++s2) {
-            const int p = 20 + 2 * s2;
-            M3(accP, Ah[s2], Al[s2], RB[p % R], RB[(p + 1) % R]);
-            refill(p); refill(p + 1);
-          }
-          {
-            // (x1 x v)[m] = x1[m+1] v[m+2] - x1[m+2] v[m+1]
-            f32x16 F1 = zero16, F2 = zero16;
-            form(F1, x1a + m1 * 32 * MF_ROWB, MF_X1L - MF_X1H, cb + (1 + m2) * 2 * MF_PL);
-            form(F2, x1a + m2 * 32 * MF_ROWB, MF_X1L - MF_X1H, cb + (1 + m1) * 2 * MF_PL);
-#pragma unroll
-            for (int q = 0; q < 16; ++q) F1[q] -= F2[q];
-            split(F1, Ah, Al);
-          }
-#pragma unroll
-          for (int s2 = 0; s2 < 2; ++s2) {
-            const int p = 24 + 2 * s2;
-            M3(accP, Ah[s2], Al[s2], RB[p % R], RB[(p + 1) % R]);
-            refill(p); refill(p + 1);
-          }
-          // T term: out_m[i][w'] += sum_j C[v_m][i][j] T_k[j][w']  (A = coefficient rows, B = T^T rows; own accumulator: scale 2^(sC + sT))
-#pragma unroll
-          for (int s = 0; s < 4; ++s) {
-            const int ca = cb + (1 + m) * 2 * MF_PL;
-            const float4 ch = lds_f4(ca + 32 * s), cl = lds_f4(ca + MF_PL + 32 * s), th = lds_f4(tb + 32 * s), tl = lds_f4(tb + MF_PL + 32 * s);
-            M3(accT, ch, cl, th, tl);
-          }
-          LDS_BARRIER();
         }
       }
-      // ---- segment end: back to true scale, partial tiles -> LDS staging (the coefficient / T / x tiles are dead)
-      // (row i of the contraction carries 2^(sX + sC + sB - 14 - e(in-degree_i)), the T term 2^(sX + sC + sTw); two factors each, so
-      // that no intermediate power of two leaves the fp32 range)
-      const float i1 = pow2f(clamp100(-(sX + a.sC))), iT2 = pow2f(clamp100(-a.sTw));
+      any_tw = any_tw || d0 > 0;
+      ent[p] = active ? (i * MF_ROWB + 2 * jl) | (d0 << 13) | (d1 << 19) : (int)0x80000000;
+      evx[p] = ge.x; evy[p] = ge.y; evz[p] = ge.z;
+    }
+    const bool wave_tw = __ballot(any_tw) != 0ull;
+    const float scC = pow2f(a.sC), scT = pow2f(clamp100(sX + a.sTw));
+    float hv[NP], ht0[NP], ht1[NP];
+    float2 tv[NTV];
+#pragma unroll
+    for (int p = 0; p < NP; ++p) ht0[p] = ht1[p] = 0.f;
+    // (loads only, nothing consumed here: a use would wait for EVERY vector load in flight, the weight ring included)
+    auto load_k = [&](int k) {  // h~ of this lane's edges and this lane's T elements of hidden unit k
+      if (!builder) return;
+      const float* __restrict__ hk = a.h + (size_t)k * a.h_kstride;
+#pragma unroll
+      for (int p = 0; p < NP; ++p) hv[p] = hk[slot0 + p * pstride];  // (inactive lanes read a slot of the table's slack: never used)
+      if (wave_tw) {
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+          ht0[p] = hk[slot0 + p * pstride + ((ent[p] >> 13) & 63)];
+          ht1[p] = hk[slot0 + p * pstride + ((ent[p] >> 19) & 63)];
+        }
+      }
+      const float* __restrict__ tk = a.Tt + (size_t)k * 32 * a.t_stride + s_base;
+#pragma unroll
+      for (int q = 0; q < NTV; ++q) {
+        const int item = tid + BT * q, wp = item >> 5, jp = item & 31;
+        tv[q] = *reinterpret_cast<const float2*>(tk + (size_t)wp * a.t_stride + 2 * jp);
+      }
+    };
+    auto build = [&](int buf) {  // the loaded hidden unit -> coefficient tiles and T tile of buffer `buf`
+      if constexpr ((dbg & 8) != 0) return;
+      if (!builder) return;
+      char* __restrict__ cbuf = lds + MF_C + buf * MF_CB;
+#pragma unroll
+      for (int p = 0; p < NP; ++p) {
+        if (ent[p] >= 0) {
+          const float c0 = ((hv[p] + ((ent[p] & (63 << 13)) ? ht0[p] : 0.f)) + ((ent[p] & (63 << 19)) ? ht1[p] : 0.f)) * scC, c1 = c0 * evx[p], c2 = c0 * evy[p], c3 = c0 * evz[p];
+          const unsigned h01 = cvt_pk_f16(c0, c1), h23 = cvt_pk_f16(c2, c3);
+          const unsigned l01 = cvt_pk_f16(resid_lo(c0, h01), resid_hi(c1, h01)), l23 = cvt_pk_f16(resid_lo(c2, h23), resid_hi(c3, h23));
+          char* __restrict__ d = cbuf + (ent[p] & 0x1fff);
+          *reinterpret_cast<unsigned short*>(d) = (unsigned short)(h01 & 0xffffu);
+          *reinterpret_cast<unsigned short*>(d + MF_PL) = (unsigned short)(l01 & 0xffffu);
+          *reinterpret_cast<unsigned short*>(d + 2 * MF_PL) = (unsigned short)(h01 >> 16);
+          *reinterpret_cast<unsigned short*>(d + 3 * MF_PL) = (unsigned short)(l01 >> 16);
+          *reinterpret_cast<unsigned short*>(d + 4 * MF_PL) = (unsigned short)(h23 & 0xffffu);
+          *reinterpret_cast<unsigned short*>(d + 5 * MF_PL) = (unsigned short)(l23 & 0xffffu);
+          *reinterpret_cast<unsigned short*>(d + 6 * MF_PL) = (unsigned short)(h23 >> 16);
+          *reinterpret_cast<unsigned short*>(d + 7 * MF_PL) = (unsigned short)(l23 >> 16);
+        }
+      }
+      char* __restrict__ tbuf = lds + MF_TT + buf * MF_TTB;
+#pragma unroll
+      for (int q = 0; q < NTV; ++q) {
+        const int item = tid + BT * q, wp = item >> 5, jp = item & 31;
+        const int j0 = 2 * jp - off;
+        const float t0 = (j0 >= 0 && j0 < rows) ? tv[q].x * scT : 0.f, t1 = (j0 + 1 >= 0 && j0 + 1 < rows) ? tv[q].y * scT : 0.f;
+        const unsigned ph = cvt_pk_f16(t0, t1), pl = cvt_pk_f16(resid_lo(t0, ph), resid_hi(t1, ph));
+        *reinterpret_cast<unsigned*>(tbuf + wp * MF_ROWB + 4 * jp) = ph;
+        *reinterpret_cast<unsigned*>(tbuf + MF_PL + wp * MF_ROWB + 4 * jp) = pl;
+      }
+    };
+
+    // ---- matrix work.  Waves w and w + 4 share a SIMD (waves are dealt to the SIMDs cyclically): two independent streams per
+    // matrix pipe, so that the LDS reads, the splits and the weight loads of one fill behind the MFMAs of the other.
+    //   wave w < 4:  scalar channels 32 w .. 32 w + 31: form, split, contract into all five scalar-output tiles   (42 MFMAs per k)
+    //   wave 4:      dot(x1, v): form over 3 x 64 source rows, split, contract into the five scalar-output tiles (66)
+    //   wave 5 + m:  vector plane m: x1[m] and (x1 x v)[m] -> contract into the plane; T term                     (60)
+    // Formed values are below in-degree x 2^28: x 2^-(14 + e(in-degree)) of this lane's destination -> below 2^14.
+    const int edeg_r = deg_lds[r] > 0 ? exp_above((float)deg_lds[r]) : 1;
+    const float rs = pow2f(-14 - edeg_r);
+    const int fo = r * MF_ROWB + 16 * hh + L0;  // this lane's fragment offset inside a 32-row tile
+    // weight blocks: buffer loads with ONE address register (the lane's 16 bytes) and the block offset in a scalar register
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float4*>(a.wm), 0, 0x7fffffff, 0x00020000);
+    const int wvo = lane * 16;
+    auto wload = [&](int so) { return __builtin_amdgcn_raw_buffer_load_b128(wrs, wvo, so, 0); };
+    // forming: F[u][i] += sum_j x^T[u][j] C[i][j] (M3: f16x3) over K-steps of 16 source rows; one step reads four fragments (x hi, x lo
+    // at xa, xa + xlo; C hi, C lo at ca, ca + MF_PL).  The reads of a step are issued TWO steps ahead of its MFMAs (an LDS round trip is
+    // ~2 steps of 3 MFMAs) and pinned there with scheduling barriers.
+    struct Frag { float4 ah, al, bh, bl; };
+    auto ldf = [&](int xa, int xlo, int ca) -> Frag {
+      if constexpr ((dbg & 32) != 0) { const float4 c1 = make_float4(1.f, 1.f, 1.f, 1.f); return Frag{c1, c1, c1, c1}; }
+      return Frag{lds_f4(xa), lds_f4(xa + xlo), lds_f4(ca), lds_f4(ca + MF_PL)};
+    };
+    auto mm = [&](f32x16& F, const Frag& f) {
+      if constexpr (!(dbg & 2)) { M3(F, f.ah, f.al, f.bh, f.bl); }
+      else { F[0] += f.ah.x + f.al.x + f.bh.x + f.bl.x; }
+    };
+    auto split = [&](const f32x16& F, float4 (&Ah)[2], float4 (&Al)[2]) {
+      if constexpr ((dbg & 16) != 0) { Ah[0] = Ah[1] = Al[0] = Al[1] = make_float4(0.f, 0.f, 0.f, 0.f); return; }
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        unsigned ph[4], pl[4];
+#pragma unroll
+        for (int p2 = 0; p2 < 4; ++p2) {
+          const float v0 = F[8 * s2 + 2 * p2] * rs, v1 = F[8 * s2 + 2 * p2 + 1] * rs;
+          ph[p2] = cvt_pk_f16(v0, v1);
+          pl[p2] = cvt_pk_f16(resid_lo(v0, ph[p2]), resid_hi(v1, ph[p2]));
+        }
+        Ah[s2] = make_float4(__uint_as_float(ph[0]), __uint_as_float(ph[1]), __uint_as_float(ph[2]), __uint_as_float(ph[3]));
+        Al[s2] = make_float4(__uint_as_float(pl[0]), __uint_as_float(pl[1]), __uint_as_float(pl[2]), __uint_as_float(pl[3]));
+      }
+    };
+    const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    // segment end: row i of the contraction carries 2^(sX + sC + sB - 14 - e(in-degree_i)), the T term 2^(sX + sC + sTw); two
+    // factors each, so that no intermediate power of two leaves the fp32 range
+    const float i1 = pow2f(clamp100(-(sX + a.sC))), iT2 = pow2f(clamp100(-a.sTw));
+    auto i2_of = [&](int row) {
+      const int edeg = deg_lds[row] > 0 ? exp_above((float)deg_lds[row]) : 1;
+      return pow2f(clamp100(14 + edeg - a.sB));
+    };
+#define MF_SCHED() __builtin_amdgcn_sched_barrier(0)
+
+    if (wave < 5) {
+      // ---- scalar-output waves: 20 weight blocks per k ((hi, lo) per (output tile n, K-step s2)), ring of 10
+      constexpr int NB = 20, R = 10;
+      const int w = wave;
+      f32x16 accS[5];
+#pragma unroll
+      for (int n = 0; n < 5; ++n) accS[n] = zero16;
+      auto wstream = [&](int k) { return (k * 124 + 20 * w) * 1024; };  // byte offset of this wave's stream of hidden unit k
+      u32x4 RB[R];
+      auto contract = [&](const float4 (&Ah)[2], const float4 (&Al)[2], int cur, int nxt) {
+#pragma unroll
+        for (int n = 0; n < 5; ++n)
+#pragma unroll
+          for (int s2 = 0; s2 < 2; ++s2) {
+            const int p = 2 * (2 * n + s2);
+            if constexpr (!(dbg & 4)) { M3(accS[n], Ah[s2], Al[s2], RB[p % R], RB[(p + 1) % R]); }
+            if constexpr (!(dbg & 1)) {
+#pragma unroll
+              for (int e = 0; e < 2; ++e) RB[(p + e) % R] = (p + e + R < NB) ? wload(cur + (p + e + R) * 1024) : wload(nxt + (p + e + R - NB) * 1024);
+              MF_SCHED();  // (pins the ring: left alone, the scheduler sinks each load to just before its use)
+            }
+          }
+      };
+      if (w < 4) {
+        // (issue order as in the loop — h~ / T of the next hidden unit, then weight blocks — so that the wait in front of build()
+        // counts the same loads on the way into the loop as around it)
+        load_k(k_of(0));
+        build(0);
+        load_k(k_of(1));
+        MF_SCHED();
+        {
+          const int c0 = wstream(k_of(0));
+#pragma unroll
+          for (int p = 0; p < R; ++p) RB[p] = wload(c0 + p * 1024);
+        }
+        LDS_BARRIER();  // x rows, C(k0), T(k0) complete
+        const int xa = MF_X0H + 32 * w * MF_ROWB + fo;
+        for (int it = 0; it < nk; ++it) {
+          const int cur = wstream(k_of(it)), nxt = wstream(k_of(it + 1));
+          const int cb = MF_C + (it & 1) * MF_CB + fo;
+          MSTAMP(0);
+          float4 Ah[2], Al[2];
+          Frag f0 = ldf(xa, MF_X0L - MF_X0H, cb), f1 = ldf(xa + 32, MF_X0L - MF_X0H, cb + 32);
+          MF_SCHED();
+          MSTAMP(1);
+          {
+            f32x16 F = zero16;
+            mm(F, f0);
+            MF_SCHED();
+            f0 = ldf(xa + 64, MF_X0L - MF_X0H, cb + 64);
+            MF_SCHED();
+            mm(F, f1);
+            MF_SCHED();
+            f1 = ldf(xa + 96, MF_X0L - MF_X0H, cb + 96);
+            MF_SCHED();
+            mm(F, f0);
+            mm(F, f1);
+            MSTAMP(2);
+            split(F, Ah, Al);
+          }
+          MSTAMP(3);
+          contract(Ah, Al, cur, nxt);
+          MSTAMP(4);
+          // the coefficient and T tiles of the next hidden unit LAST: this wave's MFMAs run beside those of wave w + 4 first (full
+          // matrix pipe), its vector work then fills under the rest of that wave's longer MFMA stream
+          if (it + 1 < nk) {
+#ifdef MF_VM0
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+            build((it + 1) & 1);
+            load_k(k_of(it + 2));
+          }
+          MF_SCHED();
+          LDS_BARRIER();
+          MSTAMP(5);
+#ifdef MF_TRACE
+          ++trc;
+#endif
+        }
+      } else {
+        if constexpr (BT == 512) {
+          load_k(k_of(0));
+          build(0);
+          load_k(k_of(1));
+          MF_SCHED();
+        }
+        {
+          const int c0 = wstream(k_of(0));
+#pragma unroll
+          for (int p = 0; p < R; ++p) RB[p] = wload(c0 + p * 1024);
+        }
+        LDS_BARRIER();  // x rows, C(k0), T(k0) complete
+        for (int it = 0; it < nk; ++it) {
+          const int cur = wstream(k_of(it)), nxt = wstream(k_of(it + 1));
+          const int cb = MF_C + (it & 1) * MF_CB + fo;
+          MSTAMP(0);
+          MSTAMP(1);
+          float4 Ah[2], Al[2];
+          {
+            auto fr = [&](int st) { const int m = st >> 2, s4 = st & 3; return ldf(MF_X1H + (m * 32) * MF_ROWB + fo + 32 * s4, MF_X1L - MF_X1H, cb + (1 + m) * 2 * MF_PL + 32 * s4); };
+            f32x16 F = zero16;
+            constexpr int QD = BT == 512 ? 2 : 3;  // fragment sets in flight (this role also carries builder registers when all waves build)
+            Frag fq[QD];
+#pragma unroll
+            for (int st = 0; st < QD - 1; ++st) fq[st] = fr(st);
+#pragma unroll
+            for (int st = 0; st < 12; ++st) {
+              if (st + QD - 1 < 12) fq[(st + QD - 1) % QD] = fr(st + QD - 1);
+              MF_SCHED();
+              mm(F, fq[st % QD]);
+              MF_SCHED();
+            }
+            MSTAMP(2);
+            split(F, Ah, Al);
+          }
+          MSTAMP(3);
+          contract(Ah, Al, cur, nxt);
+          MSTAMP(4);
+          if constexpr (BT == 512) {
+            if (it + 1 < nk) {
+              build((it + 1) & 1);
+              load_k(k_of(it + 2));
+            }
+            MF_SCHED();
+          }
+          LDS_BARRIER();
+          MSTAMP(5);
+#ifdef MF_TRACE
+          ++trc;
+#endif
+        }
+      }
+      float* __restrict__ ST0 = reinterpret_cast<float*>(lds);  // [5 waves][32][160] partial scalar-output tiles (every tile of the segment is dead)
 #pragma unroll
       for (int q = 0; q < 16; ++q) {
         const int row = (q & 3) + 8 * (q >> 2) + 4 * hh;
-        const int edeg = deg_lds[row] > 0 ? exp_above((float)deg_lds[row]) : 1;
-        const float i2 = pow2f(clamp100(14 + edeg - a.sB));
+        const float i2 = i2_of(row);
 #pragma unroll
         for (int n = 0; n < 5; ++n) ST0[(w * 32 + row) * 160 + 32 * n + r] = (accS[n][q] * i1) * i2;
-        if (w > 0) ST1[row * 96 + (w - 1) * 32 + r] = (accP[q] * i1) * i2 + (accT[q] * i1) * iT2;
       }
     } else {
-      // =========================================== HELPER waves ===========================================
-      constexpr int DPP = 256 / SPD, NP = 32 / DPP;  // destinations per pass, passes
-      const int hl = tid - 256, grp = hl / SPD, t = hl % SPD;
-      const int gsh = (SPD == 32) ? 32 * (lane >> 5) : 0;  // this group's bit offset inside the wave's ballot
-      int coff[NP], hsl[NP], tw0[NP], tw1[NP];
-      float evx[NP], evy[NP], evz[NP];
-      bool any_tw = false;
-#pragma unroll
-      for (int p = 0; p < NP; ++p) {
-        const int i = p * DPP + grp;
-        const int dg = deg_lds[i];
-        const int slot = (n0 + i) * a.S + t;
-        const bool in = t < dg && t < a.S;
-        const int sj = in ? a.esrc[slot] : 0;
-        float4 ge = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (in) ge = a.egeo[slot];
-        const bool bonded = in && sj < 0;  // bit 31
-        const int jraw = sj & 0x7fffffff, jl = jraw - s_base;
-        const bool valid = in && jl >= 0 && jl < 64;
-        bool active = valid;
-        tw0[p] = tw1[p] = -1;
-        // Several edges of one (source, destination) pair (a bonded pair inside the cutoff has a radial and a bonded edge:
-        // src/jamun/model/denoiser.py:152) share ONE entry of the coefficient tile: the first slot of the pair owns it and adds
-        // the h~ of the others (bonded edges are the last slots of a destination: k_geom).
-        const unsigned long long balb = __ballot(bonded);
-        const unsigned long long gmask = (SPD == 32) ? 0xffffffffull : ~0ull;
-        const int nb = __popcll((balb >> gsh) & gmask);
-        const int nb_max = RFL(max(__popcll(balb & 0xffffffffull), SPD == 32 ? __popcll(balb >> 32) : __popcll(balb)));
-        for (int b = 0; b < nb_max; ++b) {
-          const int lb = dg - nb + b;  // slot of this group's b-th bonded edge
-          const int jb = __shfl(jraw, (lb & (SPD - 1)) + gsh, 64);
-          const bool match = b < nb && valid && t < lb && jraw == jb;
-          const unsigned long long mb = (__ballot(match) >> gsh) & gmask;
-          if (b < nb && mb != 0ull) {
-            const int first = __ffsll((long long)mb) - 1;
-            if (t == lb) active = false;
-            if (t == first) {
-              const int sl = (n0 + i) * a.S + lb;
-              if (tw0[p] < 0) tw0[p] = sl;
-              else if (tw1[p] < 0) tw1[p] = sl;
-              else atomicOr(a.err, 1);  // more than three edges of one pair: not representable here
-            }
-          }
-        }
-        any_tw = any_tw || tw0[p] >= 0;
-        coff[p] = active ? i * MF_ROWB + 2 * jl : -1;
-        hsl[p] = active ? slot : n0 * a.S;
-        evx[p] = ge.x; evy[p] = ge.y; evz[p] = ge.z;
+      // ---- plane waves: 8 weight blocks per k (x1 inputs, cross inputs: (hi, lo) per K-step), ring of 4
+      constexpr int NB = 8, R = 4;
+      const int m = wave - 5, m1 = (m + 1) % 3, m2 = (m + 2) % 3;
+      f32x16 accP = zero16, accT = zero16;
+      auto wstream = [&](int k) { return (k * 124 + 100 + 8 * m) * 1024; };
+      u32x4 RB[R];
+      const int x1a = MF_X1H + fo;  // + plane * 32 rows
+      if constexpr (BT == 512) {
+        load_k(k_of(0));
+        build(0);
+        load_k(k_of(1));
+        MF_SCHED();
       }
-      const bool wave_tw = __ballot(any_tw) != 0ull;
-      const float scC = pow2f(a.sC), scT = pow2f(clamp100(sX + a.sTw));
-      float hv[NP];
-      float2 tv[4];
-      auto load_k = [&](int k) {  // h~ of this lane's edges and this lane's T elements of hidden unit k
-        const float* __restrict__ hk = a.h + (size_t)k * a.h_kstride;
+      {
+        const int c0 = wstream(k_of(0));
 #pragma unroll
-        for (int p = 0; p < NP; ++p) {
-          float c = hk[hsl[p]];
-          if (wave_tw) {
-            if (tw0[p] >= 0) c += hk[tw0[p]];
-            if (tw1[p] >= 0) c += hk[tw1[p]];
-          }
-          hv[p] = c;
-        }
-        const float* __restrict__ tk = a.Tt + (size_t)k * 32 * a.t_stride + s_base;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int item = hl + 256 * q, wp = item >> 5, jp = item & 31;
-          tv[q] = *reinterpret_cast<const float2*>(tk + (size_t)wp * a.t_stride + 2 * jp);
-        }
-      };
-      auto build = [&](int buf) {  // the loaded hidden unit -> coefficient tiles and T tile of buffer `buf`
-        char* __restrict__ cbuf = lds + MF_C + buf * MF_CB;
-#pragma unroll
-        for (int p = 0; p < NP; ++p) {
-          if (coff[p] >= 0) {
-            const float c0 = hv[p] * scC, c1 = c0 * evx[p], c2 = c0 * evy[p], c3 = c0 * evz[p];
-            const unsigned h01 = cvt_pk_f16(c0, c1), h23 = cvt_pk_f16(c2, c3);
-            const unsigned l01 = cvt_pk_f16(resid_lo(c0, h01), resid_hi(c1, h01)), l23 = cvt_pk_f16(resid_lo(c2, h23), resid_hi(c3, h23));
-            char* __restrict__ d = cbuf + coff[p];
-            *reinterpret_cast<unsigned short*>(d) = (unsigned short)(h01 & 0xffffu);
-            *reinterpret_cast<unsigned short*>(d + MF_PL) = (unsigned short)(l01 & 0xffffu);
-            *reinterpret_cast<unsigned short*>(d + 2 * MF_PL) = (unsigned short)(h01 >> 16);
-            *reinterpret_cast<unsigned short*>(d + 3 * MF_PL) = (unsigned short)(l01 >> 16);
-            *reinterpret_cast<unsigned short*>(d + 4 * MF_PL) = (unsigned short)(h23 & 0xffffu);
-            *reinterpret_cast<unsigned short*>(d + 5 * MF_PL) = (unsigned short)(l23 & 0xffffu);
-            *reinterpret_cast<unsigned short*>(d + 6 * MF_PL) = (unsigned short)(h23 >> 16);
-            *reinterpret_cast<unsigned short*>(d + 7 * MF_PL) = (unsigned short)(l23 >> 16);
-          }
-        }
-        char* __restrict__ tbuf = lds + MF_TT + buf * MF_TTB;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int item = hl + 256 * q, wp = item >> 5, jp = item & 31;
-          const int j0 = 2 * jp - off;
-          const float t0 = (j0 >= 0 && j0 < rows) ? tv[q].x * scT : 0.f, t1 = (j0 + 1 >= 0 && j0 + 1 < rows) ? tv[q].y * scT : 0.f;
-          const unsigned ph = cvt_pk_f16(t0, t1), pl = cvt_pk_f16(resid_lo(t0, ph), resid_hi(t1, ph));
-          *reinterpret_cast<unsigned*>(tbuf + wp * MF_ROWB + 4 * jp) = ph;
-          *reinterpret_cast<unsigned*>(tbuf + MF_PL + wp * MF_ROWB + 4 * jp) = pl;
-        }
-      };
-      load_k(k_of(0));
-      build(0);
-      load_k(k_of(1));
-      LDS_BARRIER();  // C(k0), T(k0) complete
+        for (int p = 0; p < R; ++p) RB[p] = wload(c0 + p * 1024);
+      }
+      LDS_BARRIER();  // x rows, C(k0), T(k0) complete
       for (int it = 0; it < nk; ++it) {
-        if (it + 1 < nk) {
-          build((it + 1) & 1);
-          load_k(k_of(it + 2));
+        const int cur = wstream(k_of(it)), nxt = wstream(k_of(it + 1));
+        const int cb = MF_C + (it & 1) * MF_CB + fo;
+        const int tb = MF_TT + (it & 1) * MF_TTB + fo;
+        MSTAMP(0);
+        MSTAMP(1);
+        // steps 0..3 x1[m] C[1] | 4..7 x1[m+1] C[v_(m+2)] | 8..11 x1[m+2] C[v_(m+1)] ((x1 x v)[m] = x1[m+1] v[m+2] - x1[m+2] v[m+1]) |
+        // 12..15 the T term: out_m[i][w'] += sum_j C[v_m][i][j] T_k[j][w'] (A = coefficient rows, B = T^T rows; own accumulator: scale 2^(sC + sT))
+        auto fr = [&](int st) {
+          const int g = st >> 2, s4 = 32 * (st & 3);
+          if (g == 0) return ldf(x1a + m * 32 * MF_ROWB + s4, MF_X1L - MF_X1H, cb + s4);
+          if (g == 1) return ldf(x1a + m1 * 32 * MF_ROWB + s4, MF_X1L - MF_X1H, cb + (1 + m2) * 2 * MF_PL + s4);
+          if (g == 2) return ldf(x1a + m2 * 32 * MF_ROWB + s4, MF_X1L - MF_X1H, cb + (1 + m1) * 2 * MF_PL + s4);
+          return ldf(cb + (1 + m) * 2 * MF_PL + s4, MF_PL, tb + s4);
+        };
+        float4 Ah[2], Al[2];
+        f32x16 FA = zero16, F1 = zero16, F2 = zero16;
+        Frag fq[3];
+        fq[0] = fr(0); fq[1] = fr(1);
+#pragma unroll
+        for (int st = 0; st < 16; ++st) {
+          if (st + 2 < 16) fq[(st + 2) % 3] = fr(st + 2);
+          MF_SCHED();
+          mm(st < 4 ? FA : st < 8 ? F1 : st < 12 ? F2 : accT, fq[st % 3]);
+          MF_SCHED();
+          if (st == 3) MSTAMP(2);
+        }
+        split(FA, Ah, Al);
+        MSTAMP(3);
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+          const int p = 2 * s2;
+          if constexpr (!(dbg & 4)) { M3(accP, Ah[s2], Al[s2], RB[p % R], RB[(p + 1) % R]); }
+          if constexpr (!(dbg & 1)) {
+#pragma unroll
+            for (int e = 0; e < 2; ++e) RB[(p + e) % R] = (p + e + R < NB) ? wload(cur + (p + e + R) * 1024) : wload(nxt + (p + e + R - NB) * 1024);
+            MF_SCHED();
+          }
+        }
+#pragma unroll
+        for (int q = 0; q < 16; ++q) F1[q] -= F2[q];
+        split(F1, Ah, Al);
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+          const int p = 4 + 2 * s2;
+          if constexpr (!(dbg & 4)) { M3(accP, Ah[s2], Al[s2], RB[p % R], RB[(p + 1) % R]); }
+          if constexpr (!(dbg & 1)) {
+#pragma unroll
+            for (int e = 0; e < 2; ++e) RB[(p + e) % R] = (p + e + R < NB) ? wload(cur + (p + e + R) * 1024) : wload(nxt + (p + e + R - NB) * 1024);
+            MF_SCHED();
+          }
+        }
+        MSTAMP(4);
+        if constexpr (BT == 512) {
+          if (it + 1 < nk) {
+            build((it + 1) & 1);
+            load_k(k_of(it + 2));
+          }
+          MF_SCHED();
         }
         LDS_BARRIER();
+        MSTAMP(5);
+#ifdef MF_TRACE
+        ++trc;
+#endif
+      }
+      float* __restrict__ ST1 = reinterpret_cast<float*>(lds + 5 * 32 * 160 * 4);  // [32][96] vector planes
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int row = (q & 3) + 8 * (q >> 2) + 4 * hh;
+        ST1[row * 96 + m * 32 + r] = (accP[q] * i1) * i2_of(row) + (accT[q] * i1) * iT2;
       }
     }
-    // ---- all threads: sum of the four K-partial tiles -> partial slab of this segment, coalesced 16-byte stores
+    // ---- all threads: sum of the five K-partial tiles -> partial slab of this segment, coalesced 16-byte stores
     LDS_BARRIER();
     {
+      const float* __restrict__ ST0 = reinterpret_cast<const float*>(lds);
+      const float* __restrict__ ST1 = reinterpret_cast<const float*>(lds + 5 * 32 * 160 * 4);
       float* __restrict__ p0 = a.partial0 + ((size_t)slab * a.n_pad + n0) * (size_t)(a.nt0 * 32);
       float* __restrict__ p1 = a.partial1 + ((size_t)slab * a.n_pad + n0) * 96;
       for (int idx = tid; idx < 32 * 40; idx += MF_THREADS) {
         const int row = idx / 40, c4 = idx - row * 40;
         const float* __restrict__ q0 = ST0 + row * 160 + 4 * c4;
         const float4 a0 = *reinterpret_cast<const float4*>(q0), a1 = *reinterpret_cast<const float4*>(q0 + 5120),
-                     a2 = *reinterpret_cast<const float4*>(q0 + 10240), a3 = *reinterpret_cast<const float4*>(q0 + 15360);
-        const float4 v = make_float4(((a0.x + a1.x) + a2.x) + a3.x, ((a0.y + a1.y) + a2.y) + a3.y, ((a0.z + a1.z) + a2.z) + a3.z,
-                                     ((a0.w + a1.w) + a2.w) + a3.w);
+                     a2 = *reinterpret_cast<const float4*>(q0 + 10240), a3 = *reinterpret_cast<const float4*>(q0 + 15360),
+                     a4 = *reinterpret_cast<const float4*>(q0 + 20480);
+        const float4 v = make_float4((((a0.x + a1.x) + a2.x) + a3.x) + a4.x, (((a0.y + a1.y) + a2.y) + a3.y) + a4.y,
+                                     (((a0.z + a1.z) + a2.z) + a3.z) + a4.z, (((a0.w + a1.w) + a2.w) + a3.w) + a4.w);
         if (row < n_dst) *reinterpret_cast<float4*>(p0 + row * 160 + 4 * c4) = v;
       }
       for (int idx = tid; idx < 32 * 24; idx += MF_THREADS) {
@@ -496,6 +624,21 @@ __global__ __launch_bounds__(MF_THREADS) void k_conv_mf(MfArgs a) {
     }
     LDS_BARRIER();  // the next segment rewrites the tiles
   }
+}
+
+void conv_mf_print_stamps() {
+#ifdef MF_TRACE
+  static unsigned long long tr[8][40][8];
+  if (hipMemcpyFromSymbol(tr, HIP_SYMBOL(g_mftrace), sizeof(tr)) != hipSuccess || tr[0][0][0] == 0) return;
+  const unsigned long long t0 = tr[0][0][0];
+  fprintf(stderr, "mf trace (workgroup 7): per k-step and wave: start / built / formed / split / contracted / released, cycles since first start\n");
+  for (int st = 0; st < 40; ++st)
+    for (int w = 0; w < 8; ++w) {
+      fprintf(stderr, "  step %2d wave %d:", st, w);
+      for (int i = 0; i < 6; ++i) fprintf(stderr, " %7lld", (long long)(tr[w][st][i] - t0));
+      fprintf(stderr, "\n");
+    }
+#endif
 }
 
 size_t conv_mf_lds_bytes() { return MF_LDS_BYTES; }

@@ -121,12 +121,11 @@ struct MfArgs {
   const int2* tile_atoms;  // [n_tiles] {first destination atom, number of destination atoms (<= 32)}
   const int4* segs;        // [grid][max_segs][2]: as FusedArgs
   int max_segs, nt0;
-  // wm [k][matrix wave w][40 blocks of 64 lanes x 8 halves] in the wave's consumption order, (hi, lo) pairs; B fragments of
-  // v_mfma_f32_32x32x16_f16 with the K index of a step permuted to the accumulator layout of the forming MFMA: half p of lane
-  // (column c, hh) <-> input 16 s2 + (p & 3) + 8 (p >> 2) + 4 hh of the wave's 32 channels:
-  //   2 (2 n + s2) + {0, 1}        the wave's scalar channels 32 w .. 32 w + 31 -> scalar-output tile n
-  //   wave 0: 20 + 2 (2 n + s2)    dot(x1, v) inputs -> scalar-output tile n
-  //   wave 1 + m: 20 + 2 s2        x1 inputs -> vector rows;   24 + 2 s2   cross inputs -> vector rows
+  // wm [k][124 blocks of 64 lanes x 8 halves] in consumption order, (hi, lo) pairs; B fragments of v_mfma_f32_32x32x16_f16 with the
+  // K index of a step permuted to the accumulator layout of the forming MFMA: half p of lane (column c, hh) <-> input
+  // 16 s2 + (p & 3) + 8 (p >> 2) + 4 hh of the wave's 32 channels:
+  //   20 w + 2 (2 n + s2) + {0, 1}   wave w < 4: scalar channels 32 w .. 32 w + 31 -> scalar-output tile n;  w = 4: dot(x1, v) inputs
+  //   100 + 8 m + 2 s2 + {0, 1}      wave 5 + m: x1 inputs -> vector rows;   104 + 8 m + 2 s2: cross inputs -> vector rows
   const float4* wm;
   const float* Tt;   // [k][32 w'][t_stride] TRANSPOSED pre-pass product (k_tprod_h): T_k[j][w'] at Tt[(k * 32 + w') * t_stride + j]
   int t_stride;      // even, >= n_atoms + 64
@@ -277,6 +276,7 @@ int launch_conv_dg(const DgArgs& a, int grid, hipStream_t st);
 int conv_dg_set_max_lds();
 void conv_dg_print_stamps();
 void conv_initv_print_stamps();
+void conv_mf_print_stamps();
 size_t conv_dg_lds_bytes(int rs, int pmax, int mode, int emu);
 void launch_tprod(const float* x, int XS, int n_atoms, int n_k, const float4* wt, const float4* wth, int sBt, float* T, int t_stride, hipStream_t st);
 int launch_conv_mf(const MfArgs& a, int grid, hipStream_t st);
