@@ -213,7 +213,8 @@ __global__ __launch_bounds__(MF_THREADS) void k_conv_mf(MfArgs a) {
     const bool builder = tid < BT;
     const int gsh = (SPD == 32) ? 32 * (lane >> 5) : 0;  // this lane group's bit offset inside the wave's ballot
     // per pass ONE packed word: bits 0..12 byte offset of the entry inside a coefficient plane (i * 144 + 2 jl), 13..18 / 19..24 the
-    // slot distance to a second / third edge of the same pair (0: none), bit 31 set: no entry.  The slot of pass p is slot0 + p * DPP * S.
+    // slot distance to a second / third edge of the same pair (0: none).  Lanes without an entry point at the pad bytes of row 0 (offset
+    // 128 of every plane; never read), so that build() is straight-line code.  The slot of pass p is slot0 + p * DPP * S.
     int ent[NP];
     const int slot0 = (n0 + (tid & (BT - 1)) / SPD) * a.S + (tid & (BT - 1)) % SPD, pstride = DPP * a.S;
     float evx[NP], evy[NP], evz[NP];
@@ -255,7 +256,7 @@ __global__ __launch_bounds__(MF_THREADS) void k_conv_mf(MfArgs a) {
         }
       }
       any_tw = any_tw || d0 > 0;
-      ent[p] = active ? (i * MF_ROWB + 2 * jl) | (d0 << 13) | (d1 << 19) : (int)0x80000000;
+      ent[p] = active ? (i * MF_ROWB + 2 * jl) | (d0 << 13) | (d1 << 19) : 128;
       evx[p] = ge.x; evy[p] = ge.y; evz[p] = ge.z;
     }
     const bool wave_tw = __ballot(any_tw) != 0ull;
@@ -290,7 +291,7 @@ __global__ __launch_bounds__(MF_THREADS) void k_conv_mf(MfArgs a) {
       char* __restrict__ cbuf = lds + MF_C + buf * MF_CB;
 #pragma unroll
       for (int p = 0; p < NP; ++p) {
-        if (ent[p] >= 0) {
+        {
           const float c0 = ((hv[p] + ((ent[p] & (63 << 13)) ? ht0[p] : 0.f)) + ((ent[p] & (63 << 19)) ? ht1[p] : 0.f)) * scC, c1 = c0 * evx[p], c2 = c0 * evy[p], c3 = c0 * evz[p];
           const unsigned h01 = cvt_pk_f16(c0, c1), h23 = cvt_pk_f16(c2, c3);
           const unsigned l01 = cvt_pk_f16(resid_lo(c0, h01), resid_hi(c1, h01)), l23 = cvt_pk_f16(resid_lo(c2, h23), resid_hi(c3, h23));
@@ -369,7 +370,7 @@ __global__ __launch_bounds__(MF_THREADS) void k_conv_mf(MfArgs a) {
 
     if (wave < 5) {
       // ---- scalar-output waves: 20 weight blocks per k ((hi, lo) per (output tile n, K-step s2)), ring of 10
-      constexpr int NB = 20, R = 10;
+      constexpr int NB = 20, R = BT == 512 ? 5 : 10;  // (all waves build: the shorter ring leaves room for the builder registers)
       const int w = wave;
       f32x16 accS[5];
 #pragma unroll
@@ -428,17 +429,76 @@ __global__ __launch_bounds__(MF_THREADS) void k_conv_mf(MfArgs a) {
             split(F, Ah, Al);
           }
           MSTAMP(3);
-          contract(Ah, Al, cur, nxt);
-          MSTAMP(4);
-          // the coefficient and T tiles of the next hidden unit LAST: this wave's MFMAs run beside those of wave w + 4 first (full
-          // matrix pipe), its vector work then fills under the rest of that wave's longer MFMA stream
-          if (it + 1 < nk) {
-#ifdef MF_VM0
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
-            build((it + 1) & 1);
-            load_k(k_of(it + 2));
+          // The coefficient and T tiles of the next hidden unit are built BETWEEN the MFMAs of the contraction: an MFMA holds the
+          // vector issue of the SIMD for 8 of its 32 cycles, so ~5 vector instructions per MFMA ride along.  build() cut into 28 pieces
+          // of 4..6 instructions (bstep), one behind each MFMA, the order pinned with scheduling barriers (the split helpers are inline
+          // assembly, which scheduling GROUP barriers cannot classify).  On the last hidden unit the unused buffer is rebuilt from
+          // clamped loads: straight-line code throughout.
+          {
+            char* __restrict__ cbuf = lds + MF_C + ((it + 1) & 1) * MF_CB;
+            char* __restrict__ tbuf = lds + MF_TT + ((it + 1) & 1) * MF_TTB;
+            float cc = 0.f, c1 = 0.f, c2 = 0.f, c3 = 0.f, t0 = 0.f, t1 = 0.f;
+            unsigned h01 = 0u, h23 = 0u, l01 = 0u, l23 = 0u, ph = 0u;
+            char* __restrict__ d = cbuf;
+            auto bstep = [&](int i) {
+              if constexpr ((dbg & 8) != 0) return;
+              if (i < 5 * NP) {
+                const int p = i / 5, j = i % 5;
+                if (j == 0) cc = ((hv[p] + ((ent[p] & (63 << 13)) ? ht0[p] : 0.f)) + ((ent[p] & (63 << 19)) ? ht1[p] : 0.f)) * scC;
+                else if (j == 1) { c1 = cc * evx[p]; c2 = cc * evy[p]; c3 = cc * evz[p]; h01 = cvt_pk_f16(cc, c1); h23 = cvt_pk_f16(c2, c3); }
+                else if (j == 2) { l01 = cvt_pk_f16(resid_lo(cc, h01), resid_hi(c1, h01)); l23 = cvt_pk_f16(resid_lo(c2, h23), resid_hi(c3, h23)); }
+                else if (j == 3) {
+                  d = cbuf + (ent[p] & 0x1fff);
+                  *reinterpret_cast<unsigned short*>(d) = (unsigned short)(h01 & 0xffffu);
+                  *reinterpret_cast<unsigned short*>(d + MF_PL) = (unsigned short)(l01 & 0xffffu);
+                  *reinterpret_cast<unsigned short*>(d + 2 * MF_PL) = (unsigned short)(h01 >> 16);
+                  *reinterpret_cast<unsigned short*>(d + 3 * MF_PL) = (unsigned short)(l01 >> 16);
+                } else {
+                  *reinterpret_cast<unsigned short*>(d + 4 * MF_PL) = (unsigned short)(h23 & 0xffffu);
+                  *reinterpret_cast<unsigned short*>(d + 5 * MF_PL) = (unsigned short)(l23 & 0xffffu);
+                  *reinterpret_cast<unsigned short*>(d + 6 * MF_PL) = (unsigned short)(h23 >> 16);
+                  *reinterpret_cast<unsigned short*>(d + 7 * MF_PL) = (unsigned short)(l23 >> 16);
+                }
+              } else if (i < 5 * NP + 2 * NTV) {
+                const int q = (i - 5 * NP) / 2, j = (i - 5 * NP) % 2;
+                const int item = tid + BT * q, wp = item >> 5, jp = item & 31, j0 = 2 * jp - off;
+                if (j == 0) {
+                  t0 = (j0 >= 0 && j0 < rows) ? tv[q].x * scT : 0.f;
+                  t1 = (j0 + 1 >= 0 && j0 + 1 < rows) ? tv[q].y * scT : 0.f;
+                  ph = cvt_pk_f16(t0, t1);
+                } else {
+                  const unsigned pl = cvt_pk_f16(resid_lo(t0, ph), resid_hi(t1, ph));
+                  *reinterpret_cast<unsigned*>(tbuf + wp * MF_ROWB + 4 * jp) = ph;
+                  *reinterpret_cast<unsigned*>(tbuf + MF_PL + wp * MF_ROWB + 4 * jp) = pl;
+                }
+              }
+            };
+            MF_SCHED();
+#pragma unroll
+            for (int n = 0; n < 5; ++n)
+#pragma unroll
+              for (int s2 = 0; s2 < 2; ++s2) {
+                const int g = 2 * n + s2, p = 2 * g;
+                if constexpr (!(dbg & 4)) accS[n] = MFMA32H(Al[s2], RB[p % R], accS[n]);
+                MF_SCHED();
+                bstep(3 * g);
+                MF_SCHED();
+                if constexpr (!(dbg & 4)) accS[n] = MFMA32H(Ah[s2], RB[(p + 1) % R], accS[n]);
+                MF_SCHED();
+                bstep(3 * g + 1);
+                MF_SCHED();
+                if constexpr (!(dbg & 4)) accS[n] = MFMA32H(Ah[s2], RB[p % R], accS[n]);
+                if constexpr (!(dbg & 1)) {
+#pragma unroll
+                  for (int e = 0; e < 2; ++e) RB[(p + e) % R] = (p + e + R < NB) ? wload(cur + (p + e + R) * 1024) : wload(nxt + (p + e + R - NB) * 1024);
+                }
+                MF_SCHED();
+                bstep(3 * g + 2);
+                MF_SCHED();
+              }
           }
+          MSTAMP(4);
+          load_k(k_of(it + 2));
           MF_SCHED();
           LDS_BARRIER();
           MSTAMP(5);
