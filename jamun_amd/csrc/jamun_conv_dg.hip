@@ -1465,6 +1465,10 @@ __global__ __launch_bounds__(64 * TP_WAVES) __attribute__((amdgpu_waves_per_eu(2
         mx = fmaxf(mx, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
       }
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));  // both input halves of the atom
+    if (t_stride > 0) {  // transposed output: one scale for the wave's 32 atoms (a register of the accumulator then holds four ATOMS)
+#pragma unroll
+      for (int o = 16; o >= 1; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    }
     int sA = 0;
     if (mx > 0.f) sA = 14 - ((int)((__float_as_uint(mx) >> 23) & 0xffu) - 126);
     sA = max(-60, min(60, sA));
@@ -1494,19 +1498,27 @@ __global__ __launch_bounds__(64 * TP_WAVES) __attribute__((amdgpu_waves_per_eu(2
     f32x16 acc;
 #pragma unroll
     for (int q = 0; q < 16; ++q) acc[q] = 0.f;
+    if (t_stride > 0) {
+      // transposed for k_conv_mf, [k][w'][atom]: the operands swap roles (both fragments have the same lane layout), acc[row = atom][column
+      // = output channel], so lane (channel r, hh) holds four consecutive atoms per accumulator quad: 16-byte stores (rows past the
+      // last atom land in the slack of the buffer)
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        acc = MFMA32H(xh[q], wv[2 * q + 1], acc);
+        acc = MFMA32H(xl[q], wv[2 * q], acc);
+        acc = MFMA32H(xh[q], wv[2 * q], acc);
+      }
+      float* __restrict__ tk = T + ((size_t)k * 32 + r) * t_stride + a0 + 4 * hh;
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4)
+        *reinterpret_cast<float4*>(tk + 8 * g4) = make_float4(acc[4 * g4] * isc, acc[4 * g4 + 1] * isc, acc[4 * g4 + 2] * isc, acc[4 * g4 + 3] * isc);
+      return;
+    }
 #pragma unroll
     for (int q = 0; q < 8; ++q) {  // acc[row = output channel][column = atom]; blocks 2q (hi), 2q + 1 (lo) of the weights
       acc = MFMA32H(wv[2 * q + 1], xh[q], acc);
       acc = MFMA32H(wv[2 * q], xl[q], acc);
       acc = MFMA32H(wv[2 * q], xh[q], acc);
-    }
-    if (t_stride > 0) {  // transposed for k_conv_mf: [k][w'][atom], 128 contiguous bytes per (channel, half-wave)
-      float* __restrict__ tk = T + (size_t)k * 32 * t_stride + a0 + r;
-      if (a0 + r < n_atoms) {
-#pragma unroll
-        for (int q = 0; q < 16; ++q) tk[(size_t)((q & 3) + 8 * (q >> 2) + 4 * hh) * t_stride] = acc[q] * isc;
-      }
-      return;
     }
     float* __restrict__ tk = T + ((size_t)k * n_atoms + a0) * 32;
     if (a0 + r < n_atoms) {

@@ -370,23 +370,24 @@ __global__ __launch_bounds__(MF_THREADS) void k_conv_mf(MfArgs a) {
 
     if (wave < 5) {
       // ---- scalar-output waves: 20 weight blocks per k ((hi, lo) per (output tile n, K-step s2)), ring of 10
-      constexpr int NB = 20, R = BT == 512 ? 5 : 10;  // (all waves build: the shorter ring leaves room for the builder registers)
+      // ring: half a hidden unit ahead (all waves build: a quarter; the builder registers need the room)
+      constexpr int NB = 20, R = BT == 512 ? 5 : 10, RD = R;
       const int w = wave;
       f32x16 accS[5];
 #pragma unroll
       for (int n = 0; n < 5; ++n) accS[n] = zero16;
       auto wstream = [&](int k) { return (k * 124 + 20 * w) * 1024; };  // byte offset of this wave's stream of hidden unit k
-      u32x4 RB[R];
+      u32x4 RB[RD > R ? RD : R];
       auto contract = [&](const float4 (&Ah)[2], const float4 (&Al)[2], int cur, int nxt) {
 #pragma unroll
         for (int n = 0; n < 5; ++n)
 #pragma unroll
           for (int s2 = 0; s2 < 2; ++s2) {
             const int p = 2 * (2 * n + s2);
-            if constexpr (!(dbg & 4)) { M3(accS[n], Ah[s2], Al[s2], RB[p % R], RB[(p + 1) % R]); }
+            if constexpr (!(dbg & 4)) { M3(accS[n], Ah[s2], Al[s2], RB[p % RD], RB[(p + 1) % RD]); }
             if constexpr (!(dbg & 1)) {
 #pragma unroll
-              for (int e = 0; e < 2; ++e) RB[(p + e) % R] = (p + e + R < NB) ? wload(cur + (p + e + R) * 1024) : wload(nxt + (p + e + R - NB) * 1024);
+              for (int e = 0; e < 2; ++e) RB[(p + e) % RD] = (p + e + RD < NB) ? wload(cur + (p + e + RD) * 1024) : wload(nxt + (p + e + RD - NB) * 1024);
               MF_SCHED();  // (pins the ring: left alone, the scheduler sinks each load to just before its use)
             }
           }
@@ -516,7 +517,7 @@ __global__ __launch_bounds__(MF_THREADS) void k_conv_mf(MfArgs a) {
         {
           const int c0 = wstream(k_of(0));
 #pragma unroll
-          for (int p = 0; p < R; ++p) RB[p] = wload(c0 + p * 1024);
+          for (int p = 0; p < RD; ++p) RB[p] = wload(c0 + p * 1024);
         }
         LDS_BARRIER();  // x rows, C(k0), T(k0) complete
         for (int it = 0; it < nk; ++it) {
@@ -569,7 +570,7 @@ __global__ __launch_bounds__(MF_THREADS) void k_conv_mf(MfArgs a) {
       }
     } else {
       // ---- plane waves: 8 weight blocks per k (x1 inputs, cross inputs: (hi, lo) per K-step), ring of 4
-      constexpr int NB = 8, R = 4;
+      constexpr int NB = 8, R = BT == 512 ? 4 : 8;
       const int m = wave - 5, m1 = (m + 1) % 3, m2 = (m + 2) % 3;
       f32x16 accP = zero16, accT = zero16;
       auto wstream = [&](int k) { return (k * 124 + 100 + 8 * m) * 1024; };
