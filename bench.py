@@ -457,7 +457,9 @@ def main():
             ach = flop / (avg0 * 1e-3) / 1e12 if avg0 > 0 else 0.0
             out["roofline"] = {
                 "kernel": ("hidden-layer conv contraction, scalar + vector rows in one launch (destination-grouped; conv_path "
-                           f"{stats['conv_path']})" if fused else "k_conv<RC=1,NT=5,NK=5> (scalar-output conv contraction, hidden layers)"),
+                           f"{stats['conv_path']}, " + ("k_conv_mf: A operand formed on the matrix cores" if stats.get("dg_mode") == 4 else
+                                                         f"k_conv_dg mode {stats.get('dg_mode')}: A operand formed on the vector ALUs") + "; with its T pre-pass k_tprod)"
+                           if fused else "k_conv<RC=1,NT=5,NK=5> (scalar-output conv contraction, hidden layers)"),
                 "bound": "mfma",
                 "achieved": ach,
                 "peak": F32_MFMA_PEAK_TFLOPS,
@@ -478,7 +480,10 @@ def main():
                 ex = stats["conv_flop_exec_launch"] / (avg0 * 1e-3) / 1e12 if avg0 > 0 else 0.0
                 out["roofline"].update({"mfma_scheme": "f16x3 (fp32 operands split hi+lo into f16, 3 MFMAs per product, fp32 accumulate)",
                                         "executed": ex, "peak_executed": F16_MFMA_PEAK_TFLOPS, "frac_executed": ex / F16_MFMA_PEAK_TFLOPS,
-                                        "flop_executed_per_launch": stats["conv_flop_exec_launch"]})
+                                        "flop_executed_per_launch": stats["conv_flop_exec_launch"],
+                                        "note": "peak / frac: algorithmic fp32 FLOP against the fp32-MFMA roof (the roof of an fp32 implementation; a value above 1 "
+                                                "means the f16x3 path beats it); executed / frac_executed: the f16 MFMA instructions issued (forming on the "
+                                                "matrix cores included for k_conv_mf) against the dense f16 roof — the utilisation of the matrix pipe"})
             elif fused and stats.get("conv_flop_exec_launch", 0) > 0:
                 ex = stats["conv_flop_exec_launch"] / (avg0 * 1e-3) / 1e12 if avg0 > 0 else 0.0
                 out["roofline"].update({"mfma_scheme": "v_mfma_f32_32x32x2_f32", "executed": ex, "peak_executed": F32_MFMA_PEAK_TFLOPS,
@@ -486,7 +491,8 @@ def main():
             # HBM-side bytes per launch from the committed PMC passes of the cfg2 command (profiles/collect.sh); rocprofv3
             # cannot run inside the timed process, so the newest committed summary is quoted, with its file name
             if args.atoms is None and args.walkers is None and not args.strong:
-                tr = _pmc_traffic({2: "k_conv_dg", 1: "k_conv_fused"}.get(stats["conv_path"], "k_conv<"), args.config)
+                tr = _pmc_traffic(("k_conv_mf" if stats.get("dg_mode") == 4 else "k_conv_dg") if stats["conv_path"] == 2 else
+                                  {1: "k_conv_fused"}.get(stats["conv_path"], "k_conv<"), args.config)
                 if tr is not None:
                     out["roofline"]["traffic"] = tr[0]
                     out["roofline"]["traffic_source"] = tr[1]
