@@ -126,6 +126,8 @@ struct LayerDev {
   float* tt2 = nullptr;  // the same table re-laid for k_conv_init_v: [k][U][192]
   float4 *wcat0 = nullptr, *wcat1 = nullptr;  // node update: [W_self ; W_skip] as MFMA fragments
   int K0p = 0, K1p = 0;
+  float4 *wh0 = nullptr, *wh1 = nullptr;      // ... and scaled, split hi + lo for the f16x3 kernel (jamun_node.hip)
+  int K0h = 0, K1h = 0, sW0 = 0, sW1 = 0;
   float* mix = nullptr;
   int in0 = 0, in1 = 0, XSin = 0;
   int64_t tp_numel = 0;
@@ -381,7 +383,7 @@ struct jamun_sampler {
     for (auto& L : layers) {
       free_problem(L.p0); free_problem(L.p1); free_fused(L.fu); free_dg(L.dg);
       hipFree(L.sep.w2p); hipFree(L.sep.wl0); hipFree(L.sep.wl1);
-      hipFree(L.wcat0); hipFree(L.wcat1); hipFree(L.mix); hipFree(L.tt); hipFree(L.tt2);
+      hipFree(L.wcat0); hipFree(L.wcat1); hipFree(L.wh0); hipFree(L.wh1); hipFree(L.mix); hipFree(L.tt); hipFree(L.tt2);
     }
     hipFree(w_gate); hipFree(w_vec); hipFree(w_out);
     hipFree(yc); hipFree(h); hipFree(partial0); hipFree(partial1); hipFree(g); hipFree(tmp);
@@ -475,6 +477,45 @@ void build_layer_common(const jamun_model& m, const std::string& prefix, const s
   };
   L.wcat0 = dev_upload(pack_cat(wf0, mul0, ws0, in0, mul0, L.K0p));
   L.wcat1 = dev_upload(pack_cat(wf1, mul1, ws1, in1, std::max(mul1, 1), L.K1p));
+  // f16x3 node update: the same matrices scaled to the top of the f16 range and split; K padded to 16
+  auto pack_cat_h = [](const std::vector<float>& wself, int ks, const std::vector<float>& wskip, int kk, int ncol, int& Kh, int& sW) {
+    Kh = (ks + kk + 15) & ~15;
+    double wmax = 0;
+    for (int r = 0; r < ks; ++r) for (int c = 0; c < ncol; ++c) wmax = std::max(wmax, std::fabs((double)wself[(size_t)r * ncol + c]));
+    for (int r = 0; r < kk; ++r) for (int c = 0; c < ncol; ++c) wmax = std::max(wmax, std::fabs((double)wskip[(size_t)r * ncol + c]));
+    int ex = 0;
+    if (wmax > 0 && std::isfinite(wmax)) std::frexp(wmax, &ex);
+    sW = std::max(-40, std::min(40, 14 - ex));
+    const double sc = std::ldexp(1.0, sW);
+    const int nt = (ncol + 31) / 32, nst = Kh / 16;
+    std::vector<float4> out((size_t)nt * nst * 2 * 64, make_float4(0.f, 0.f, 0.f, 0.f));
+    for (int t = 0; t < nt; ++t)
+      for (int st = 0; st < nst; ++st)
+        for (int lane = 0; lane < 64; ++lane) {
+          const int hh = lane >> 5, c = t * 32 + (lane & 31);
+          uint32_t h[4], l[4];
+          for (int i = 0; i < 4; ++i) {
+            uint16_t hp[2], lp[2];
+            for (int e = 0; e < 2; ++e) {
+              const int row = 16 * st + 8 * hh + 2 * i + e;
+              double v = 0.0;
+              if (c < ncol) {
+                if (row < ks) v = wself[(size_t)row * ncol + c];
+                else if (row < ks + kk) v = wskip[(size_t)(row - ks) * ncol + c];
+              }
+              split_f16(v * sc, hp[e], lp[e]);
+            }
+            h[i] = (uint32_t)hp[0] | ((uint32_t)hp[1] << 16);
+            l[i] = (uint32_t)lp[0] | ((uint32_t)lp[1] << 16);
+          }
+          const size_t b = (((size_t)t * nst + st) * 2) * 64 + lane;
+          std::memcpy(&out[b], h, 16);
+          std::memcpy(&out[b + 64], l, 16);
+        }
+    return out;
+  };
+  L.wh0 = dev_upload(pack_cat_h(wf0, mul0, ws0, in0, mul0, L.K0h, L.sW0));
+  L.wh1 = dev_upload(pack_cat_h(wf1, mul1, ws1, in1, std::max(mul1, 1), L.K1h, L.sW1));
 }
 
 // SeparableConv block (src/jamun/e3tools/nn/_tensor_product.py:27-47): depth-wise "uvu" instructions in e3nn order — for every
@@ -1233,9 +1274,12 @@ void run_layer(jamun_sampler* s, size_t l, const float* x_in, int XSin, float* x
     n.atom_nslab = dg_layer ? s->dg_atom_nslab : (L.fu.wpack ? s->atom_nslab : nullptr);
     n.max_slabs = dg_layer ? s->dg_n_slabs : (L.fu.wpack ? s->n_slabs : s->n_slices);
     if (L.sep.w2p) { n.n_slices = 1; n.atom_nslab = nullptr; n.max_slabs = 1; }  // SeparableConv writes the summed messages as ONE slab
+    n.wh0 = L.wh0; n.wh1 = L.wh1; n.K0h = L.K0h; n.K1h = L.K1h; n.sW0 = L.sW0; n.sW1 = L.sW1;
     {
       ProfScope ps(s, JAMUN_PROF_NODE, st);
-      launch_node_update(n, st);
+      static const bool nu_fp32 = getenv("JAMUN_NODE_FP32") != nullptr;  // (A/B aid: the v_mfma_f32_32x32x2_f32 kernel)
+      if (!nu_fp32 && node_update_h_supported(n)) launch_node_update_h(n, st);
+      else launch_node_update(n, st);
     }
 }
 

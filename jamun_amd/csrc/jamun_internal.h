@@ -212,6 +212,11 @@ struct NodeArgs {
   const float4* wcat0;
   const float4* wcat1;
   int K0p, K1p;
+  // f16x3 node update (jamun_node.hip): the same matrices scaled by 2^sW0 / 2^sW1, split hi + lo, as B fragments of
+  // v_mfma_f32_32x32x16_f16: wh0 [nt][K0h/16][hi, lo][64 lanes] (lane (c, hh): rows 16 s + 8 hh + p, column 32 nt + c), wh1 [K1h/16][hi, lo][64]
+  const float4* wh0;
+  const float4* wh1;
+  int K0h, K1h, sW0, sW1;
   const float* mix;      // [mul0+mul1] or nullptr (initial projector)
   float cL, cS;
   int n_atoms, n_pad, n_slices, nt0, nt1;
@@ -290,6 +295,8 @@ int conv_init_set_max_lds();
 size_t conv_init_lds_bytes(int JR);
 size_t fused_lds_bytes(int XS, int JR, int n_p, int n_t, int max_a);
 void launch_node_update(const NodeArgs& a, hipStream_t st);
+void launch_node_update_h(const NodeArgs& a, hipStream_t st);
+bool node_update_h_supported(const NodeArgs& a);
 size_t node_update_lds_bytes(const NodeArgs& a);
 int node_update_set_max_lds();
 void launch_head(const HeadArgs& a, hipStream_t st);

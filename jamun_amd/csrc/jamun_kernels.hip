@@ -370,6 +370,9 @@ __global__ __launch_bounds__(NU_T) void k_node_update(NodeArgs a) {
   // ---- phase 2: out = [act | x_in] . [W_self ; W_skip] on the matrix cores, then the noise-conditional skip mix
   const int XSo = a.mul0 + 3 * a.mul1;
   const int nts = (a.mul0 + 31) >> 5, nsg0 = K0 >> 3, nsg1 = K1 >> 3;
+#if defined(NU_EXP) && (NU_EXP & 2)
+  if (a.mix) return;
+#endif
   for (int job = wave; job < nts + 3; job += NU_T / 64) {
     const bool scalar = job < nts;
     const int nsg = scalar ? nsg0 : nsg1;
@@ -388,6 +391,9 @@ __global__ __launch_bounds__(NU_T) void k_node_update(NodeArgs a) {
           const float4 w = ring[i];
           if (sg + i + 4 < nsg) ring[i] = wp[(sg + i + 4) * 64];
           const float* __restrict__ as = ap + 8 * (sg + i) * NU_LD;
+#if defined(NU_EXP) && (NU_EXP & 1)
+          continue;
+#endif
           acc = __builtin_amdgcn_mfma_f32_32x32x2f32(as[0], w.x, acc, 0, 0, 0);
           acc = __builtin_amdgcn_mfma_f32_32x32x2f32(as[2 * NU_LD], w.y, acc, 0, 0, 0);
           acc = __builtin_amdgcn_mfma_f32_32x32x2f32(as[4 * NU_LD], w.z, acc, 0, 0, 0);

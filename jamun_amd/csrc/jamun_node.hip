@@ -1,0 +1,300 @@
+// jamun_node.hip — node update of a ConvBlock with both o3.Linear layers as f16x3 MFMAs.
+//
+// Same arithmetic as k_node_update (jamun_kernels.hip; src/jamun/e3tools/nn/_conv.py:117, _gate.py:53-64, _interaction.py:26-30,
+// model/noise_conditioning.py:69-73): sum the partial slabs of the conv (fixed order), mean over the in-edges, leaky-relu / sigmoid gate,
+// out = [act | x_in] . [W_self ; W_skip] (one contraction per irrep block), noise-conditional skip mix.  What changes is the shape:
+//   * phase 1 works on 16-byte pieces (16 threads per atom; 19 loads per thread instead of 62) and writes the Linear inputs ROW-major
+//     ([atom][K] halves, hi and lo planes: the A fragments of v_mfma_f32_32x32x16_f16 are 16-byte reads of a row), scaled per atom
+//     by a power of two so that its largest input sits below 2^14 (one scale for the scalar K range, one for the vector planes);
+//   * phase 2 runs 15 (scalar tile, K = 240) or 4 (vector plane, K = 64) K-steps of three f16 MFMAs — 1.4 k matrix cycles for a scalar
+//     tile against 7.7 k with v_mfma_f32_32x32x2_f32 — against weights split hi + lo on the host (scaled by 2^sW).
+// Measured on MI355X (cfg2, 4352 atoms, 3 slabs): k_node_update 24.4 us = 13.8 phase 1 + 10.6 phase 2; see DESIGN.md 3.4 for this kernel.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "jamun_internal.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+
+#define NH_T 512
+#define NH_S 3  // partial slabs fetched at once (more are summed in a loop)
+#define MFMA32H(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8, (a)), __builtin_bit_cast(h8, (b)), (c), 0, 0, 0)
+#define RFL(v) __builtin_amdgcn_readfirstlane(v)
+
+namespace {
+
+__device__ __forceinline__ unsigned cvt_pk_f16(float a, float b) {
+  unsigned r;
+  asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ float resid_lo(float a, unsigned pk) {  // a - float(pk[15:0])
+  float r;
+  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r) : "v"(pk), "v"(a));
+  return r;
+}
+__device__ __forceinline__ float resid_hi(float a, unsigned pk) {  // a - float(pk[31:16])
+  float r;
+  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(pk), "v"(a));
+  return r;
+}
+__device__ __forceinline__ float pow2f(int e) { return __uint_as_float((unsigned)(e + 127) << 23); }
+__device__ __forceinline__ int scale_of(float mx) {  // largest magnitude -> [2^13, 2^14)
+  int s = 0;
+  if (mx > 0.f) s = 14 - ((int)((__float_as_uint(mx) >> 23) & 0xffu) - 126);
+  return max(-60, min(60, s));
+}
+__device__ __forceinline__ float max4(float4 v) { return fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))); }
+__device__ __forceinline__ float4 f4add(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+// four consecutive K values of one row -> their hi halves (8 bytes) and lo halves, scaled by sc
+__device__ __forceinline__ void put4(char* hi_row, int lo_off, int k, float4 v, float sc) {
+  const float e0 = v.x * sc, e1 = v.y * sc, e2 = v.z * sc, e3 = v.w * sc;
+  const unsigned p0 = cvt_pk_f16(e0, e1), p1 = cvt_pk_f16(e2, e3);
+  const unsigned q0 = cvt_pk_f16(resid_lo(e0, p0), resid_hi(e1, p0)), q1 = cvt_pk_f16(resid_lo(e2, p1), resid_hi(e3, p1));
+  *reinterpret_cast<uint2*>(hi_row + 2 * k) = make_uint2(p0, p1);
+  *reinterpret_cast<uint2*>(hi_row + lo_off + 2 * k) = make_uint2(q0, q1);
+}
+__device__ __forceinline__ void put1(char* hi_row, int lo_off, int k, float v, float sc) {
+  const float e = v * sc;
+  const unsigned p = cvt_pk_f16(e, 0.f), q = cvt_pk_f16(resid_lo(e, p), 0.f);
+  *reinterpret_cast<unsigned short*>(hi_row + 2 * k) = (unsigned short)(p & 0xffffu);
+  *reinterpret_cast<unsigned short*>(hi_row + lo_off + 2 * k) = (unsigned short)(q & 0xffffu);
+}
+
+}  // namespace
+
+// One workgroup = 32 atoms, 8 waves; 16 threads per atom in phase 1.  Requires nt0 <= 5 (partial0 rows of <= 160 floats), nt1 == 1,
+// XSin a multiple of 4 and <= 224, in0 a multiple of 4, mul0 a multiple of 4, K0h / K1h multiples of 16.
+__global__ __launch_bounds__(NH_T) void k_node_update_h(NodeArgs a) {
+  extern __shared__ float4 nh_lds[];
+  char* __restrict__ sm = reinterpret_cast<char*>(nh_lds);
+  const int RB0 = RFL(a.K0h * 2 + 16), RB1 = RFL(a.K1h * 2 + 16);  // row bytes: K halves + 16 (rows 16 B apart mod 32: conflict-free b128 reads)
+  const int L0 = 32 * RB0, L1 = 96 * RB1;                          // hi -> lo plane
+  char* __restrict__ A0 = sm;                                      // [32 atoms][K0h] hi | lo
+  char* __restrict__ A1 = A0 + 2 * L0;                             // [3 planes][32 atoms][K1h] hi | lo
+  float* __restrict__ s_gate = reinterpret_cast<float*>(A1 + 2 * L1);  // [32][mul1 <= 32]
+  float* __restrict__ isc0 = s_gate + 32 * 32;                     // [32] 2^-(sS_atom + sW0)
+  float* __restrict__ isc1 = isc0 + 32;                            // [32] 2^-(sV_atom + sW1)
+  const int n0 = blockIdx.x * 32;
+  const int tid = threadIdx.x, lane = tid & 63, wave = RFL(tid >> 6);
+  const int il = tid >> 4, c16 = tid & 15;
+  const int i = n0 + il;
+  const bool ok = i < a.n_atoms;
+  const int ns = ok ? (a.atom_nslab ? a.atom_nslab[i] : a.n_slices) : 0;
+  const int ns_max = a.atom_nslab ? a.max_slabs : a.n_slices;
+  const int dgi = ok ? a.deg[i] : 1;
+  const float degf = (float)(dgi < 1 ? 1 : dgi);
+  const int w0 = a.nt0 * 32, G0 = a.mul0 + a.mul1;
+  const size_t slab0 = (size_t)a.n_pad * w0, slab1 = (size_t)a.n_pad * 96;
+  const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+
+  // ---- loads: scalar rows (<= 40 pieces of 16 bytes per atom and slab), vector rows (24), input features (<= 56); the first NH_S
+  // slabs of everything are in flight together, summation order stays s = 0, 1, 2, ...
+  float4 ms[3], mv[2], xv[4];
+  {
+    float4 ls[NH_S][3], lv[NH_S][2];
+    const float* __restrict__ p0 = a.partial0 + (size_t)(n0 + il) * w0;
+    const float* __restrict__ p1 = a.partial1 + (size_t)(n0 + il) * 96;
+#pragma unroll
+    for (int s = 0; s < NH_S; ++s) {
+#pragma unroll
+      for (int q = 0; q < 3; ++q) {
+        const int j = c16 + 16 * q;
+        ls[s][q] = 4 * j < w0 ? *reinterpret_cast<const float4*>(p0 + (s < ns_max ? s : 0) * slab0 + 4 * j) : z4;
+      }
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const int j = c16 + 16 * q;
+        lv[s][q] = j < 24 ? *reinterpret_cast<const float4*>(p1 + (s < ns_max ? s : 0) * slab1 + 4 * j) : z4;
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int j = c16 + 16 * q;
+      xv[q] = (ok && 4 * j < a.XSin) ? *reinterpret_cast<const float4*>(a.x_in + (size_t)i * a.XSin + 4 * j) : z4;
+    }
+    // (the loads above do not wait for this atom's slab count: slab indices are clamped to the batch's maximum, results masked here)
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      ms[q] = 0 < ns ? ls[0][q] : z4;
+#pragma unroll
+      for (int s = 1; s < NH_S; ++s) ms[q] = f4add(ms[q], s < ns ? ls[s][q] : z4);
+    }
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      mv[q] = 0 < ns ? lv[0][q] : z4;
+#pragma unroll
+      for (int s = 1; s < NH_S; ++s) mv[q] = f4add(mv[q], s < ns ? lv[s][q] : z4);
+    }
+    for (int s = NH_S; s < ns_max; ++s) {
+      if (s < ns) {
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+          const int j = c16 + 16 * q;
+          if (4 * j < w0) ms[q] = f4add(ms[q], *reinterpret_cast<const float4*>(p0 + s * slab0 + 4 * j));
+        }
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          const int j = c16 + 16 * q;
+          if (j < 24) mv[q] = f4add(mv[q], *reinterpret_cast<const float4*>(p1 + s * slab1 + 4 * j));
+        }
+      }
+    }
+  }
+
+#if defined(NH_EXP) && (NH_EXP & 2)
+  if (a.mix) { if (ms[0].x + ms[1].x + ms[2].x + mv[0].x + mv[1].x + xv[0].x + xv[1].x + xv[2].x + xv[3].x == 1.2345f) a.x_out[0] = 0.f; return; }
+#endif
+  // ---- phase 1a: mean over in-edges, activation (scalar K range) / gate; the scalar channels of x_in extend the scalar K range
+  float mxS = 0.f;
+#pragma unroll
+  for (int q = 0; q < 3; ++q) {
+    const int c = 4 * (c16 + 16 * q);
+    float e[4] = {ms[q].x / degf, ms[q].y / degf, ms[q].z / degf, ms[q].w / degf};
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int w = c + t;
+      if (w < a.mul0) { e[t] = a.cL * (e[t] > 0.f ? e[t] : 0.01f * e[t]); mxS = fmaxf(mxS, fabsf(e[t])); }
+      else if (w < G0) s_gate[il * 32 + (w - a.mul0)] = a.cS / (1.f + expf(-e[t]));
+    }
+    ms[q] = make_float4(e[0], e[1], e[2], e[3]);
+  }
+  float mxV = 0.f;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int c = 4 * (c16 + 16 * q);
+    if (c < a.in0) mxS = fmaxf(mxS, max4(xv[q]));          // (in0 is a multiple of 4: a piece is all scalar or all vector)
+    else if (c < a.XSin) mxV = fmaxf(mxV, max4(xv[q]));
+  }
+#pragma unroll
+  for (int o = 8; o >= 1; o >>= 1) mxS = fmaxf(mxS, __shfl_xor(mxS, o, 16));
+  const int sS = scale_of(mxS);
+  {
+    const float sc = pow2f(sS);
+    char* __restrict__ row = A0 + il * RB0;
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      const int c = 4 * (c16 + 16 * q);
+      if (c < a.mul0) put4(row, L0, c, ms[q], sc);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int c = 4 * (c16 + 16 * q);
+      if (c < a.in0) put4(row, L0, a.mul0 + c, xv[q], sc);
+    }
+    for (int k = a.mul0 + a.in0 + 4 * c16; k < a.K0h; k += 64) put4(row, L0, k, z4, 1.f);  // pad rows of the K range
+    if (c16 == 0) isc0[il] = pow2f(-sS - a.sW0);
+  }
+  __syncthreads();  // gates
+
+  // ---- phase 1b: gated vectors and the vector channels of x_in (K range of a plane: [gate * m1 (mul1) | x_in vectors (in1) | pad])
+  float gv[2][4];
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int j = c16 + 16 * q, c = 4 * (j & 7);  // piece j: plane j / 8, channels c .. c + 3
+    const float e[4] = {mv[q].x / degf, mv[q].y / degf, mv[q].z / degf, mv[q].w / degf};
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      gv[q][t] = (j < 24 && c + t < a.mul1) ? e[t] * s_gate[il * 32 + c + t] : 0.f;
+      mxV = fmaxf(mxV, fabsf(gv[q][t]));
+    }
+  }
+#pragma unroll
+  for (int o = 8; o >= 1; o >>= 1) mxV = fmaxf(mxV, __shfl_xor(mxV, o, 16));
+  const int sV = scale_of(mxV);
+  {
+    const float sc = pow2f(sV);
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int j = c16 + 16 * q, m = j >> 3, c = 4 * (j & 7);
+      if (j < 24 && c < a.mul1) put4(A1 + (m * 32 + il) * RB1, L1, c, make_float4(gv[q][0], gv[q][1], gv[q][2], gv[q][3]), sc);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int c = 4 * (c16 + 16 * q);
+      if (c >= a.in0 && c < a.XSin) {
+        const float e[4] = {xv[q].x, xv[q].y, xv[q].z, xv[q].w};
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const int v = c + t - a.in0, u = v / 3, m = v - 3 * u;  // x_in vectors are stored [u][m]
+          put1(A1 + (m * 32 + il) * RB1, L1, a.mul1 + u, e[t], sc);
+        }
+      }
+    }
+    for (int idx = c16; idx < 3 * ((a.K1h - a.mul1 - a.in1) >> 2); idx += 16) {  // pad rows of the planes' K range
+      const int per = (a.K1h - a.mul1 - a.in1) >> 2, m = idx / per, k = a.mul1 + a.in1 + 4 * (idx - m * per);
+      put4(A1 + (m * 32 + il) * RB1, L1, k, z4, 1.f);
+    }
+    if (c16 == 0) isc1[il] = pow2f(-sV - a.sW1);
+  }
+  __syncthreads();
+
+  // ---- phase 2: one job per wave: scalar-output tile (32 columns, K0h / 16 steps) or vector plane (K1h / 16 steps); weight blocks of
+  // 64 lanes x 8 halves, (hi, lo) per step, four steps in flight
+#if defined(NH_EXP) && (NH_EXP & 1)
+  if (a.mix) return;
+#endif
+  const int XSo = a.mul0 + 3 * a.mul1;
+  const int nts = (a.mul0 + 31) >> 5, nst0 = a.K0h >> 4, nst1 = a.K1h >> 4;
+  const int r = lane & 31, hh = lane >> 5;
+  for (int job = wave; job < nts + 3; job += NH_T / 64) {
+    const bool scalar = job < nts;
+    const int nst = scalar ? nst0 : nst1;
+    const float4* __restrict__ wp = (scalar ? a.wh0 + (size_t)job * nst0 * 128 : a.wh1) + lane;
+    const char* __restrict__ ap = (scalar ? A0 + r * RB0 : A1 + ((job - nts) * 32 + r) * RB1) + 16 * hh;
+    const int lo = scalar ? L0 : L1;
+    f32x16 acc;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc[q] = 0.f;
+    float4 wh[4], wl[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int s = t < nst ? t : nst - 1;
+      wh[t] = wp[(2 * s) * 64];
+      wl[t] = wp[(2 * s + 1) * 64];
+    }
+    for (int s0 = 0; s0 < nst; s0 += 4) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        if (s0 + t < nst) {  // wave-uniform
+          const float4 bh = wh[t], bl = wl[t];
+          if (s0 + t + 4 < nst) {
+            wh[t] = wp[(2 * (s0 + t + 4)) * 64];
+            wl[t] = wp[(2 * (s0 + t + 4) + 1) * 64];
+          }
+          const float4 ah = *reinterpret_cast<const float4*>(ap + 32 * (s0 + t)), al = *reinterpret_cast<const float4*>(ap + lo + 32 * (s0 + t));
+          acc = MFMA32H(al, bh, acc);
+          acc = MFMA32H(ah, bl, acc);
+          acc = MFMA32H(ah, bh, acc);
+        }
+      }
+    }
+    const int col = scalar ? job * 32 + r : r;                    // output channel within the irrep block
+    const bool col_ok = scalar ? col < a.mul0 : col < a.mul1;
+    const int o = scalar ? col : a.mul0 + 3 * col + (job - nts);  // column of x_out
+    const float mw = (a.mix && col_ok) ? a.mix[scalar ? col : a.mul0 + col] : 0.f;
+    const float* __restrict__ isc = scalar ? isc0 : isc1;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int rl = (q & 3) + 8 * (q >> 2) + 4 * hh, ii = n0 + rl;
+      if (col_ok && ii < a.n_atoms) {
+        float v = acc[q] * isc[rl];
+        if (a.mix) v = mw * a.x_in[(size_t)ii * a.XSin + o] + (1.f - mw) * v;  // hidden layers: XSin == XSo, x_in is x_old
+        a.x_out[(size_t)ii * XSo + o] = v;
+      }
+    }
+  }
+}
+
+size_t node_update_h_lds_bytes(const NodeArgs& a) {
+  return (size_t)2 * 32 * (a.K0h * 2 + 16) + (size_t)2 * 96 * (a.K1h * 2 + 16) + sizeof(float) * (32 * 32 + 64);
+}
+bool node_update_h_supported(const NodeArgs& a) {
+  return a.wh0 != nullptr && a.wh1 != nullptr && a.nt0 <= 5 && a.nt1 == 1 && a.mul1 <= 32 && (a.mul0 & 3) == 0 && (a.in0 & 3) == 0 && (a.XSin & 3) == 0 &&
+         a.XSin <= 256 && (a.K0h & 15) == 0 && (a.K1h & 15) == 0 && a.K0h >= a.mul0 + a.in0 && a.K1h >= a.mul1 + a.in1 &&
+         ((a.K0h - a.mul0 - a.in0) & 3) == 0 && ((a.K1h - a.mul1 - a.in1) & 3) == 0 && node_update_h_lds_bytes(a) <= 64 * 1024;
+}
+void launch_node_update_h(const NodeArgs& a, hipStream_t st) {
+  hipLaunchKernelGGL(k_node_update_h, dim3(a.n_pad / 32), dim3(NH_T), node_update_h_lds_bytes(a), st, a);
+}
