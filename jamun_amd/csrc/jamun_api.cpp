@@ -124,6 +124,8 @@ struct LayerDev {
   float* tt = nullptr;  // initial projector only: [k][distinct embedding row][32 (nt0 + 1)] input-times-weight table
   int tt_row = 0, tt_U = 0;
   float* tt2 = nullptr;  // the same table re-laid for k_conv_init_v: [k][U][192]
+  float4* tabw = nullptr;  // ... and scaled by 2^tab_sB, split hi + lo, as MFMA B fragments for k_conv_mfi (U <= 32): [k][24 blocks][64 lanes]
+  int tab_sB = 0, tab_ut = 0;
   float4 *wcat0 = nullptr, *wcat1 = nullptr;  // node update: [W_self ; W_skip] as MFMA fragments
   int K0p = 0, K1p = 0;
   float4 *wh0 = nullptr, *wh1 = nullptr;      // ... and scaled, split hi + lo for the f16x3 kernel (jamun_node.hip)
@@ -353,6 +355,7 @@ struct jamun_sampler {
   float* dg_dump = nullptr;  // diagnostic A-tile dump (JAMUN_DG_DUMP, -DJAMUN_DUMP builds)
   float* dg_T = nullptr;  // [n_k][n_atoms][32] pre-pass product of a hidden layer (k_tprod), reused by every layer
   int dg_tstride = 0;     // mode 4 (jamun_conv_mf.hip): dg_T is [n_k][32][dg_tstride], transposed
+  bool mfi_on = false;    // initial projector on k_conv_mfi (mode 4 tiles, at most 32 distinct embedding rows)
   int* mf_err = nullptr;  // device flag of k_conv_mf
   int* mf_err_host = nullptr;  // pinned copy, refreshed after every forward
   float *x_emb = nullptr, *mu = nullptr;
@@ -383,7 +386,7 @@ struct jamun_sampler {
     for (auto& L : layers) {
       free_problem(L.p0); free_problem(L.p1); free_fused(L.fu); free_dg(L.dg);
       hipFree(L.sep.w2p); hipFree(L.sep.wl0); hipFree(L.sep.wl1);
-      hipFree(L.wcat0); hipFree(L.wcat1); hipFree(L.wh0); hipFree(L.wh1); hipFree(L.mix); hipFree(L.tt); hipFree(L.tt2);
+      hipFree(L.wcat0); hipFree(L.wcat1); hipFree(L.wh0); hipFree(L.wh1); hipFree(L.mix); hipFree(L.tt); hipFree(L.tt2); hipFree(L.tabw);
     }
     hipFree(w_gate); hipFree(w_vec); hipFree(w_out);
     hipFree(yc); hipFree(h); hipFree(partial0); hipFree(partial1); hipFree(g); hipFree(tmp);
@@ -1116,6 +1119,44 @@ LayerDev build_layer(const jamun_model& m, const std::string& prefix, const std:
           }
         L.tt2 = dev_upload(tt2);
       }
+      if (getenv("JAMUN_DEBUG_UNITS")) fprintf(stderr, "[jamun] %s: %d distinct embedding rows\n", prefix.c_str(), U);
+      if (NT0 == 5 && G0 <= 160 && G1 <= 32 && U <= 128) {
+        const int UT = U <= 32 ? 1 : (U <= 64 ? 2 : 4);
+        L.tab_ut = UT;
+        // k_conv_mfi: blocks 4 r + 2 s2 + {hi, lo}; half p of lane (column c, hh) <-> uid 16 s2 + (p & 3) + 8 (p >> 2) + 4 hh (the
+        // accumulator layout of the forming MFMA); r < 5: scalar-output columns 32 r + c, r = 5: the vector columns
+        double tmax = 0;
+        for (float v : tt) tmax = std::max(tmax, (double)std::fabs(v));
+        int ex = 0;
+        if (tmax > 0 && std::isfinite(tmax)) std::frexp(tmax, &ex);
+        L.tab_sB = std::max(-40, std::min(40, 14 - ex));
+        const double sc = std::ldexp(1.0, L.tab_sB);
+        std::vector<float4> tw((size_t)(H + 1) * 6 * 4 * UT * 64, make_float4(0.f, 0.f, 0.f, 0.f));
+        for (int k = 0; k <= H; ++k)
+          for (int r = 0; r < 6; ++r)
+            for (int ts = 0; ts < 2 * UT; ++ts)
+              for (int lane = 0; lane < 64; ++lane) {
+                const int s2 = ts & 1, ut = ts >> 1;
+                const int hh = lane >> 5, c = lane & 31;
+                const int col = r < 5 ? 32 * r + c : 32 * NT0 + c;
+                const bool col_ok = r < 5 ? col < G0 : c < G1;
+                uint32_t h[4], l[4];
+                for (int i = 0; i < 4; ++i) {
+                  uint16_t hp[2], lp[2];
+                  for (int e = 0; e < 2; ++e) {
+                    const int pp = 2 * i + e, uid = 32 * ut + 16 * s2 + (pp & 3) + 8 * (pp >> 2) + 4 * hh;
+                    const double v = (col_ok && uid < U) ? (double)tt[((size_t)k * U + uid) * tt_row + col] : 0.0;
+                    split_f16(v * sc, hp[e], lp[e]);
+                  }
+                  h[i] = (uint32_t)hp[0] | ((uint32_t)hp[1] << 16);
+                  l[i] = (uint32_t)lp[0] | ((uint32_t)lp[1] << 16);
+                }
+                const size_t b = (((size_t)k * 6 + r) * 4 * UT + 4 * ut + 2 * s2) * 64 + lane;
+                std::memcpy(&tw[b], h, 16);
+                std::memcpy(&tw[b + 64], l, 16);
+              }
+        L.tabw = dev_upload(tw);
+      }
     }
   }
 
@@ -1181,6 +1222,20 @@ void run_layer(jamun_sampler* s, size_t l, const float* x_in, int XSin, float* x
       f.partial0 = s->partial0; f.partial1 = s->partial1;
       ProfScope ps(s, l == 0 ? JAMUN_PROF_CONV0_INIT : JAMUN_PROF_CONV0, st);
       if (launch_sep_conv(f, st) != 0) throw Err(JAMUN_ERR_INVALID, "separable conv launch failed (irreps not supported)");
+    } else if (l == 0 && s->mfi_on) {
+      MfiArgs f{};
+      f.deg = s->deg; f.esrc = s->esrc; f.egeo = s->egeo; f.h = h_l; f.h_kstride = s->h_kstride;
+      f.n_pad = s->n_pad; f.S = s->S; f.nt0 = L.p0.nt;
+      f.tile_span = s->dg_tile_span; f.tile_atoms = s->dg_tile_atoms; f.segs = s->dg_segs; f.max_segs = s->dg_max_segs;
+      f.atom_uid = s->atom_uid; f.tabw = L.tabw; f.sB = L.tab_sB; f.ut = L.tab_ut;
+      {
+        int e3 = 0;
+        std::frexp(1.5 * (double)L.dg.hmax2, &e3);
+        f.sC = std::max(-40, std::min(40, 14 - e3));
+      }
+      f.partial0 = s->partial0; f.partial1 = s->partial1; f.err = s->mf_err;
+      ProfScope ps(s, JAMUN_PROF_CONV0_INIT, st);
+      if (launch_conv_mfi(f, s->dg_grid, st) != 0) throw Err(JAMUN_ERR_INVALID, "initial-projector conv launch failed (configuration not supported)");
     } else if (l == 0 && s->initv_on) {
       InitVArgs f{};
       f.deg = s->deg; f.esrc = s->esrc; f.egeo = s->egeo; f.h = h_l; f.h_kstride = s->h_kstride;
@@ -1270,7 +1325,7 @@ void run_layer(jamun_sampler* s, size_t l, const float* x_in, int XSin, float* x
     n.cL = s->hp.act_scalar_const; n.cS = s->hp.act_gate_const;
     n.n_atoms = s->n_atoms; n.n_pad = s->n_pad; n.n_slices = s->n_slices; n.nt0 = L.p0.nt; n.nt1 = L.p1.nt;
     n.mul0 = s->hp.mul0; n.mul1 = s->hp.mul1; n.in0 = L.in0; n.in1 = L.in1; n.XSin = XSin;
-    const bool dg_layer = (l > 0 && s->dg_on) || (l == 0 && s->initv_on);  // (slabs of the dg tile plan)
+    const bool dg_layer = (l > 0 && s->dg_on) || (l == 0 && (s->initv_on || s->mfi_on));  // (slabs of the dg tile plan)
     n.atom_nslab = dg_layer ? s->dg_atom_nslab : (L.fu.wpack ? s->atom_nslab : nullptr);
     n.max_slabs = dg_layer ? s->dg_n_slabs : (L.fu.wpack ? s->n_slabs : s->n_slices);
     if (L.sep.w2p) { n.n_slices = 1; n.atom_nslab = nullptr; n.max_slabs = 1; }  // SeparableConv writes the summed messages as ONE slab
@@ -1826,6 +1881,10 @@ int jamun_sampler_create(const jamun_model* m, float sigma, const jamun_topology
           for (int nbuf = 2; nbuf >= (s->dg_mode == 1 ? 1 : 2) && !s->initv_on; --nbuf)
             if (conv_initv_lds_bytes(s->dg_RS, pmax, nbuf) <= JAMUN_MAX_DYN_LDS) { s->initv_on = true; s->initv_nbuf = nbuf; }
         }
+        // ... or, on the tiles of k_conv_mf (spans within one K = 64 window) and with at most 32 distinct embedding rows, the same
+        // scheme with a one-hot selector in place of the feature rows (k_conv_mfi)
+        if (s->dg_mode == 4 && s->layers[0].tabw != nullptr && s->atom_uid != nullptr && s->layers[0].p0.nt == 5 && getenv("JAMUN_NO_MFI") == nullptr)
+          s->mfi_on = true;
       }
       if (!s->dg_on)
         for (auto& L : s->layers) free_dg(L.dg);
@@ -2126,7 +2185,7 @@ int jamun_sampler_stats(jamun_sampler* s, jamun_stats* out, void* stream) {
     out->n_slices = s->dg_on ? s->dg_n_slabs : (s->fused_JR > 0 ? s->n_slabs : s->n_slices);
     out->conv_path = s->dg_on ? 2 : (s->fused_JR > 0 ? 1 : 0);
     out->dg_mode = s->dg_on ? s->dg_mode : -1;
-    out->init_path = s->initv_on ? 2 : (s->layers[0].tt ? 1 : 0);
+    out->init_path = s->mfi_on ? 3 : s->initv_on ? 2 : (s->layers[0].tt ? 1 : 0);
     out->dg_row_blocks = s->dg_on && s->dg_row_blocks ? 1 : 0;
     out->dg_emu = s->dg_on ? s->dg_emu : -1;
     out->conv_flop_exec_launch = s->conv_flop_exec_launch;

@@ -687,6 +687,224 @@ __global__ __launch_bounds__(MF_THREADS) void k_conv_mf(MfArgs a) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------
+// k_conv_mfi — the INITIAL projector on the same scheme.  Its inputs are atom embeddings: a handful of distinct rows (U <= 32 per
+// batch), so the input-times-weight table Tab_k[uid][w] is static (host: jamun_api.cpp, as for jamun_conv_init.hip) and the layer is
+//   m[i][w] = sum_k sum_uid G_k[c][i][uid] Tab_k[uid][w],   G_k[c][i][uid] = sum_{j -> i, uid_j = uid} h~_(j->i)[k] (1, vx, vy, vz)_c
+// (component 0 for the 152 scalar outputs, v_m for vector plane m).  G_k is FORMED like the hidden layers' A tiles, with the one-hot
+// selector S[uid][j] = (uid_j == uid) in place of the feature rows (exact in f16: two MFMAs per K-step, C hi and C lo), split in
+// registers and contracted with the table blocks streamed from L2: per (tile, k) 8 x (8 + 6) MFMAs against 414 of a hidden layer.
+// Eight equal waves: wave r < 5 owns scalar-output tile r, wave 5 + m vector plane m; every wave forms the G it needs itself (8
+// MFMAs: cheaper than sharing it), holds ONE 32 x 32 accumulator for the whole segment and stores it straight into the slab.
+// All eight waves build the coefficient tiles of the next hidden unit (same code as k_conv_mf, no T tile).
+// UT: tiles of 32 distinct embedding rows (1, 2 or 4)
+template <int SPD, int UT>
+__global__ __launch_bounds__(MF_THREADS) void k_conv_mfi(MfiArgs a) {
+  extern __shared__ float4 lds4[];
+  char* __restrict__ lds = reinterpret_cast<char*>(lds4);
+  const int L0 = lds_addr(lds);
+  // LDS: selector [32 uid][64 j] halves (one plane) | coefficient tiles as k_conv_mf | deg
+  constexpr int I_S = 0, I_C = UT * 32 * MF_ROWB, I_MISC = I_C + 2 * MF_CB;
+  int* __restrict__ deg_lds = reinterpret_cast<int*>(lds + I_MISC);
+  const int tid0 = threadIdx.x, lane0 = tid0 & 63;
+  const int wave = RFL(tid0 >> 6);
+  for (int sgi = 0; sgi < a.max_segs; ++sgi) {
+    const int4 sg0 = a.segs[((size_t)blockIdx.x * a.max_segs + sgi) * 2];
+    const int4 sg1 = a.segs[((size_t)blockIdx.x * a.max_segs + sgi) * 2 + 1];
+    const int tile = RFL(sg0.x);
+    if (tile < 0) break;
+    int lane = lane0;
+    asm volatile("" : "+v"(lane));
+    const int tid = wave * 64 + lane;
+    const int slab = RFL(sg0.y), k_begin = RFL(sg0.z), k_run = RFL(sg0.w) - k_begin, k_extra = RFL(sg1.x);
+    const int nk = k_run + (k_extra >= 0 ? 1 : 0);
+    auto k_of = [&](int kk) { kk = kk < 0 ? 0 : (kk < nk ? kk : nk - 1); return kk < k_run ? k_begin + kk : k_extra; };
+    const int2 t_at = a.tile_atoms[tile];
+    const int n0 = RFL(t_at.x), n_dst = RFL(t_at.y);
+    const int2 span = a.tile_span[tile];
+    const int s_lo = RFL(span.x), rows = RFL(span.y) - s_lo;
+    const int s_base = s_lo;
+
+    // ---- segment prologue: zero the coefficient tiles, the selector
+    for (int idx = tid; idx < 2 * MF_CB / 16; idx += MF_THREADS) reinterpret_cast<float4*>(lds + I_C)[idx] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int idx = tid; idx < UT * 32 * 32; idx += MF_THREADS) {  // (uid, pair of source rows)
+      const int uid = idx >> 5, jp = idx & 31;
+      const int j0 = 2 * jp, j1 = j0 + 1;
+      const int u0 = j0 < rows ? a.atom_uid[s_lo + j0] : -1, u1 = j1 < rows ? a.atom_uid[s_lo + j1] : -1;
+      *reinterpret_cast<unsigned*>(lds + I_S + uid * MF_ROWB + 4 * jp) = (u0 == uid ? 0x3c00u : 0u) | (u1 == uid ? 0x3c000000u : 0u);
+    }
+    if (tid < 32) deg_lds[tid] = (tid < n_dst) ? a.deg[n0 + tid] : 0;
+    LDS_BARRIER();
+
+    // ---- builder state (all eight waves): as k_conv_mf
+    constexpr int BT = MF_THREADS, DPP = BT / SPD, NP = 32 / DPP;
+    const int gsh = (SPD == 32) ? 32 * (lane >> 5) : 0;
+    int ent[NP];
+    const int slot0 = (n0 + tid / SPD) * a.S + tid % SPD, pstride = DPP * a.S;
+    float evx[NP], evy[NP], evz[NP];
+    bool any_tw = false;
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+      const int g = tid + BT * p, i = g / SPD, t = g % SPD;
+      const int dg = deg_lds[i];
+      const int slot = (n0 + i) * a.S + t;
+      const bool in = t < dg && t < a.S;
+      const int sj = in ? a.esrc[slot] : 0;
+      float4 ge = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (in) ge = a.egeo[slot];
+      const bool bonded = in && sj < 0;
+      const int jraw = sj & 0x7fffffff, jl = jraw - s_base;
+      const bool valid = in && jl >= 0 && jl < 64;
+      bool active = valid;
+      int d0 = 0, d1 = 0;
+      const unsigned long long balb = __ballot(bonded);
+      const unsigned long long gmask = (SPD == 32) ? 0xffffffffull : ~0ull;
+      const int nb = __popcll((balb >> gsh) & gmask);
+      const int nb_max = RFL(SPD == 32 ? max(__popcll(balb & 0xffffffffull), __popcll(balb >> 32)) : __popcll(balb));
+      for (int b = 0; b < nb_max; ++b) {
+        const int lb = dg - nb + b;
+        const int jb = __shfl(jraw, (lb & (SPD - 1)) + gsh, 64);
+        const bool match = b < nb && valid && t < lb && jraw == jb;
+        const unsigned long long mb = (__ballot(match) >> gsh) & gmask;
+        if (b < nb && mb != 0ull) {
+          const int first = __ffsll((long long)mb) - 1;
+          if (t == lb) active = false;
+          if (t == first) {
+            if (d0 == 0) d0 = lb - t;
+            else if (d1 == 0) d1 = lb - t;
+            else atomicOr(a.err, 1);
+          }
+        }
+      }
+      any_tw = any_tw || d0 > 0;
+      ent[p] = active ? (i * MF_ROWB + 2 * jl) | (d0 << 13) | (d1 << 19) : 128;
+      evx[p] = ge.x; evy[p] = ge.y; evz[p] = ge.z;
+    }
+    const bool wave_tw = __ballot(any_tw) != 0ull;
+    const float scC = pow2f(a.sC);
+    float hv[NP], ht0[NP], ht1[NP];
+#pragma unroll
+    for (int p = 0; p < NP; ++p) ht0[p] = ht1[p] = 0.f;
+    auto load_k = [&](int k) {
+      const float* __restrict__ hk = a.h + (size_t)k * a.h_kstride;
+#pragma unroll
+      for (int p = 0; p < NP; ++p) hv[p] = hk[slot0 + p * pstride];
+      if (wave_tw) {
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+          ht0[p] = hk[slot0 + p * pstride + ((ent[p] >> 13) & 63)];
+          ht1[p] = hk[slot0 + p * pstride + ((ent[p] >> 19) & 63)];
+        }
+      }
+    };
+    auto build = [&](int buf) {
+      char* __restrict__ cbuf = lds + I_C + buf * MF_CB;
+#pragma unroll
+      for (int p = 0; p < NP; ++p) {
+        const float c0 = ((hv[p] + ((ent[p] & (63 << 13)) ? ht0[p] : 0.f)) + ((ent[p] & (63 << 19)) ? ht1[p] : 0.f)) * scC, c1 = c0 * evx[p], c2 = c0 * evy[p], c3 = c0 * evz[p];
+        const unsigned h01 = cvt_pk_f16(c0, c1), h23 = cvt_pk_f16(c2, c3);
+        const unsigned l01 = cvt_pk_f16(resid_lo(c0, h01), resid_hi(c1, h01)), l23 = cvt_pk_f16(resid_lo(c2, h23), resid_hi(c3, h23));
+        char* __restrict__ d = cbuf + (ent[p] & 0x1fff);
+        *reinterpret_cast<unsigned short*>(d) = (unsigned short)(h01 & 0xffffu);
+        *reinterpret_cast<unsigned short*>(d + MF_PL) = (unsigned short)(l01 & 0xffffu);
+        *reinterpret_cast<unsigned short*>(d + 2 * MF_PL) = (unsigned short)(h01 >> 16);
+        *reinterpret_cast<unsigned short*>(d + 3 * MF_PL) = (unsigned short)(l01 >> 16);
+        *reinterpret_cast<unsigned short*>(d + 4 * MF_PL) = (unsigned short)(h23 & 0xffffu);
+        *reinterpret_cast<unsigned short*>(d + 5 * MF_PL) = (unsigned short)(l23 & 0xffffu);
+        *reinterpret_cast<unsigned short*>(d + 6 * MF_PL) = (unsigned short)(h23 >> 16);
+        *reinterpret_cast<unsigned short*>(d + 7 * MF_PL) = (unsigned short)(l23 >> 16);
+      }
+    };
+
+    // ---- matrix work: role = wave
+    const int r = lane & 31, hh = lane >> 5;
+    const int comp = wave < 5 ? 0 : wave - 4;  // coefficient component this wave contracts
+    const int edeg_r = deg_lds[r] > 0 ? exp_above((float)deg_lds[r]) : 1;
+    const float rs = pow2f(-edeg_r);            // formed values (a sum of <= in-degree coefficients below 2^14) -> below 2^14
+    const int fo = r * MF_ROWB + 16 * hh + L0;
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float4*>(a.tabw), 0, 0x7fffffff, 0x00020000);
+    const int wvo = lane * 16;
+    auto wload = [&](int so) { return __builtin_amdgcn_raw_buffer_load_b128(wrs, wvo, so, 0); };
+    constexpr int NBW = 4 * UT;  // blocks per role and hidden unit: (hi, lo) x 2 UT K-steps of 16 uids
+    auto wstream = [&](int k) { return (k * 6 + (wave < 5 ? wave : 5)) * NBW * 1024; };
+    f32x16 acc;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc[q] = 0.f;
+    u32x4 RB[NBW];
+    load_k(k_of(0));
+    build(0);
+    load_k(k_of(1));
+    __builtin_amdgcn_sched_barrier(0);
+    {
+      const int c0 = wstream(k_of(0));
+#pragma unroll
+      for (int p = 0; p < NBW; ++p) RB[p] = wload(c0 + p * 1024);
+    }
+    LDS_BARRIER();  // selector, C(k0) complete
+    for (int it = 0; it < nk; ++it) {
+      const int nxt = wstream(k_of(it + 1));
+      const int cb = I_C + (it & 1) * MF_CB + comp * 2 * MF_PL + fo;
+      // G^T[uid][i] = sum_j S[uid][j] C[i][j]: A = selector rows (exact halves), B = coefficient rows hi, lo
+      float4 bh[4], bl[4];
+#pragma unroll
+      for (int s = 0; s < 4; ++s) { bh[s] = lds_f4(cb + 32 * s); bl[s] = lds_f4(cb + MF_PL + 32 * s); }
+#pragma unroll
+      for (int ut = 0; ut < UT; ++ut) {
+        f32x16 G;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) G[q] = 0.f;
+        float4 sa[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) sa[s] = lds_f4(I_S + ut * 32 * MF_ROWB + fo + 32 * s);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) { G = MFMA32H(sa[s], bl[s], G); G = MFMA32H(sa[s], bh[s], G); }
+        float4 Ah[2], Al[2];
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+          unsigned ph[4], pl[4];
+#pragma unroll
+          for (int p2 = 0; p2 < 4; ++p2) {
+            const float v0 = G[8 * s2 + 2 * p2] * rs, v1 = G[8 * s2 + 2 * p2 + 1] * rs;
+            ph[p2] = cvt_pk_f16(v0, v1);
+            pl[p2] = cvt_pk_f16(resid_lo(v0, ph[p2]), resid_hi(v1, ph[p2]));
+          }
+          Ah[s2] = make_float4(__uint_as_float(ph[0]), __uint_as_float(ph[1]), __uint_as_float(ph[2]), __uint_as_float(ph[3]));
+          Al[s2] = make_float4(__uint_as_float(pl[0]), __uint_as_float(pl[1]), __uint_as_float(pl[2]), __uint_as_float(pl[3]));
+        }
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+          const int b = 4 * ut + 2 * s2;
+          M3(acc, Ah[s2], Al[s2], RB[b], RB[b + 1]);
+          RB[b] = wload(nxt + b * 1024);
+          RB[b + 1] = wload(nxt + (b + 1) * 1024);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      build((it + 1) & 1);  // (on the last hidden unit: the unused buffer, from clamped loads)
+      load_k(k_of(it + 2));
+      __builtin_amdgcn_sched_barrier(0);
+      LDS_BARRIER();
+    }
+    // ---- segment end: this wave's tile straight into the slab (rows carry 2^(sC - e(in-degree) + sB))
+    {
+      const float i1 = pow2f(clamp100(-(a.sC + a.sB)));
+      float* __restrict__ p0 = a.partial0 + ((size_t)slab * a.n_pad + n0) * (size_t)(a.nt0 * 32);
+      float* __restrict__ p1 = a.partial1 + ((size_t)slab * a.n_pad + n0) * 96;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int row = (q & 3) + 8 * (q >> 2) + 4 * hh;
+        const int edeg = deg_lds[row] > 0 ? exp_above((float)deg_lds[row]) : 1;
+        const float v = (acc[q] * i1) * pow2f(edeg);
+        if (row < n_dst) {
+          if (wave < 5) p0[row * 160 + 32 * wave + r] = v;
+          else p1[row * 96 + (wave - 5) * 32 + r] = v;
+        }
+      }
+    }
+    LDS_BARRIER();  // the next segment rewrites the tiles
+  }
+}
+
 void conv_mf_print_stamps() {
 #ifdef MF_TRACE
   static unsigned long long tr[8][40][8];
@@ -711,7 +929,26 @@ int launch_conv_mf(const MfArgs& a, int grid, hipStream_t st) {
   return 0;
 }
 
+int launch_conv_mfi(const MfiArgs& a, int grid, hipStream_t st) {
+  if (a.nt0 != 5 || a.S > 64 || (a.ut != 1 && a.ut != 2 && a.ut != 4)) return -1;
+  const size_t smem = a.ut * 32 * MF_ROWB + 2 * MF_CB + 144;
+  if (a.S <= 32) {
+    if (a.ut == 1) hipLaunchKernelGGL((k_conv_mfi<32, 1>), dim3(grid), dim3(MF_THREADS), smem, st, a);
+    else if (a.ut == 2) hipLaunchKernelGGL((k_conv_mfi<32, 2>), dim3(grid), dim3(MF_THREADS), smem, st, a);
+    else hipLaunchKernelGGL((k_conv_mfi<32, 4>), dim3(grid), dim3(MF_THREADS), smem, st, a);
+  } else {
+    if (a.ut == 1) hipLaunchKernelGGL((k_conv_mfi<64, 1>), dim3(grid), dim3(MF_THREADS), smem, st, a);
+    else if (a.ut == 2) hipLaunchKernelGGL((k_conv_mfi<64, 2>), dim3(grid), dim3(MF_THREADS), smem, st, a);
+    else hipLaunchKernelGGL((k_conv_mfi<64, 4>), dim3(grid), dim3(MF_THREADS), smem, st, a);
+  }
+  return 0;
+}
+
 int conv_mf_set_max_lds() {
+  const void* fi[6] = {(const void*)k_conv_mfi<32, 1>, (const void*)k_conv_mfi<64, 1>, (const void*)k_conv_mfi<32, 2>, (const void*)k_conv_mfi<64, 2>,
+                       (const void*)k_conv_mfi<32, 4>, (const void*)k_conv_mfi<64, 4>};
+  for (const void* f : fi)
+    if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, JAMUN_MAX_DYN_LDS) != hipSuccess) return -1;
   const void* fns[2] = {(const void*)k_conv_mf<32>, (const void*)k_conv_mf<64>};
   for (const void* f : fns)
     if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, JAMUN_MAX_DYN_LDS) != hipSuccess) return -1;

@@ -137,6 +137,31 @@ struct MfArgs {
   int* err;          // device flag: bit 0 = more than three edges of one (source, destination) pair
 };
 
+// initial projector on the scheme of k_conv_mf (k_conv_mfi in jamun_conv_mf.hip): selector-formed coefficient sums per distinct
+// embedding row, contracted with the input-times-weight table
+struct MfiArgs {
+  const int* deg;
+  const int* esrc;
+  const float4* egeo;
+  const float* h;  // [hidden unit k (65 rows)][h_kstride]
+  size_t h_kstride;
+  int n_pad, S;
+  const int2* tile_span;
+  const int2* tile_atoms;
+  const int4* segs;
+  int max_segs, nt0;
+  const int* atom_uid;  // [n_atoms] index of the atom's distinct embedding row (< 32 ut)
+  int ut;               // tiles of 32 distinct embedding rows: 1, 2 or 4
+  // tabw [k][6 roles][4 ut blocks of 64 lanes x 8 halves]: the table Tab_k[uid][w] scaled by 2^sB, split hi + lo, as B fragments with the
+  // K index (uid) permuted as in MfArgs::wm: block 4 t + 2 s2 + {0 hi, 1 lo} of role r = 0..4 (scalar-output tile r, columns 32 r ..)
+  // or r = 5 (the vector rows): uids 32 t + 16 s2 + ...
+  const float4* tabw;
+  int sB, sC;
+  float* partial0;  // [slab][n_pad][nt0*32]
+  float* partial1;  // [slab][n_pad][3][32]
+  int* err;
+};
+
 // initial-projector conv (jamun_conv_init.hip): apply-only contraction against the precomputed input-times-weight table
 struct InitArgs {
   const int* deg;
@@ -285,6 +310,7 @@ void conv_mf_print_stamps();
 size_t conv_dg_lds_bytes(int rs, int pmax, int mode, int emu);
 void launch_tprod(const float* x, int XS, int n_atoms, int n_k, const float4* wt, const float4* wth, int sBt, float* T, int t_stride, hipStream_t st);
 int launch_conv_mf(const MfArgs& a, int grid, hipStream_t st);
+int launch_conv_mfi(const MfiArgs& a, int grid, hipStream_t st);
 int conv_mf_set_max_lds();
 size_t conv_mf_lds_bytes();
 int launch_conv_init(const InitArgs& a, int grid, hipStream_t st);

@@ -321,18 +321,29 @@ def test_fused_and_fallback_conv_agree(dev, golden_dir, kind, monkeypatch):
             assert (a2 - b2).abs().max().item() <= 2e-5 * max(b2.abs().max().item(), 1e-6), (envs, l)
     assert seen == {"ag4": {4, 2, 3, 0}, "chain17x6": {4, 2, 3, 0}, "ragged_small": {4, 2, 3, 0}, "ragged": {4, 3, 0}, "dense70": {3, 0},
                     "chig93x2": {1, 0}, "chig166x2": {1, 0}}[kind], seen
-    # the initial projector of the default path runs edge by edge on the tiles of the dg kernel when the spans fit two LDS row
-    # buffers (jamun_conv_initv.hip); switched off, the MFMA table kernel takes the layer — same features
-    # (two LDS row buffers for molecules up to 40 atoms, one for chignolin-size spans; mid-size molecules keep the MFMA table kernel)
-    expect_init = {"ag4": 2, "chain17x6": 2, "ragged_small": 2, "ragged": 1, "dense70": 1, "chig93x2": 2, "chig166x2": 2}[kind]
+    # The initial projector of the default path: on the tiles of k_conv_mf (spans up to 62 rows) and with at most 128 distinct
+    # embedding rows, k_conv_mfi (selector-formed coefficient sums on the matrix cores, init_path 3); else edge by edge on the tiles of
+    # the dg kernel when the spans fit two LDS row buffers (jamun_conv_initv.hip, 2: molecules up to 40 atoms, one buffer for
+    # chignolin-size spans); mid-size molecules keep the MFMA table kernel (1).  Each is switched off in turn: same features.
+    expect_init = {"ag4": 3, "chain17x6": 3, "ragged_small": 3, "ragged": 3, "dense70": 1, "chig93x2": 2, "chig166x2": 2}[kind]
     assert dg.stats()["init_path"] == expect_init, (kind, dg.stats()["init_path"])
-    if expect_init == 2:
+    a1 = dg.debug_read(0, 0).cpu()
+    if expect_init == 3:
+        monkeypatch.setenv("JAMUN_NO_MFI", "1")
+        no_mfi = NativeSampler(model._native, 0.04, batch, dev)
+        assert no_mfi.stats()["init_path"] == (1 if kind == "ragged" else 2), no_mfi.stats()["init_path"]
+        assert rmsd(no_mfi.xhat(y), xd) <= RMSD_TOL_NM
+        b1 = no_mfi.debug_read(0, 0).cpu()
+        assert (a1 - b1).abs().max().item() <= 2e-5 * max(b1.abs().max().item(), 1e-6)
+    if expect_init >= 2:
+        monkeypatch.setenv("JAMUN_NO_MFI", "1")
         monkeypatch.setenv("JAMUN_NO_INIT_V", "1")
         no_v = NativeSampler(model._native, 0.04, batch, dev)
         monkeypatch.delenv("JAMUN_NO_INIT_V")
+        monkeypatch.delenv("JAMUN_NO_MFI")
         assert no_v.stats()["init_path"] == 1
         assert rmsd(no_v.xhat(y), xd) <= RMSD_TOL_NM
-        a1, b1 = dg.debug_read(0, 0).cpu(), no_v.debug_read(0, 0).cpu()
+        b1 = no_v.debug_read(0, 0).cpu()
         assert (a1 - b1).abs().max().item() <= 2e-5 * max(b1.abs().max().item(), 1e-6)
     # the initial projector has a third implementation (input-times-weight table, jamun_conv_init.hip): switch it off and
     # the fused kernel takes that layer as well — same result
@@ -385,7 +396,7 @@ def test_fused_and_fallback_conv_agree_on_random_ragged_batches(dev, seed, monke
                 assert (a - b).abs().max().item() <= 2e-5 * max(b.abs().max().item(), 1e-6), (trial, l)
 
 
-@pytest.mark.parametrize("atoms,walkers,dg_mode,init_path", [(17, 64, 4, 2), (33, 64, 3, 2), (57, 32, 4, 1), (166, 4, 1, 2)])
+@pytest.mark.parametrize("atoms,walkers,dg_mode,init_path", [(17, 64, 4, 3), (33, 64, 3, 2), (57, 32, 4, 3), (166, 4, 1, 2)])
 def test_kernel_variants_chosen_for_the_baseline_shapes(dev, atoms, walkers, dg_mode, init_path):
     """BASELINE configs[1..4] shapes (fewer walkers): which variant of the hidden-layer conv kernel (jamun_stats.dg_mode) and of
     the initial projector (init_path) the sampler picks, and that the forward through them is finite and rotation-equivariant."""
