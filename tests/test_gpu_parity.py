@@ -396,6 +396,62 @@ def test_fused_and_fallback_conv_agree_on_random_ragged_batches(dev, seed, monke
                 assert (a - b).abs().max().item() <= 2e-5 * max(b.abs().max().item(), 1e-6), (trial, l)
 
 
+@pytest.mark.parametrize("case", ["span62", "single62", "odd_start", "double_bonds", "many_rows"])
+def test_matrix_formed_conv_edge_cases(dev, case, monkeypatch):
+    """k_conv_mf / k_conv_mfi (jamun_conv_mf.hip) against the general kernel on the shapes that stress their bookkeeping: a tile span of
+    exactly 62 source rows over two molecules; one 62-atom molecule (edge stride above 32: all eight waves build); tiles whose span starts
+    at an odd atom (the window of 64 rows starts one atom earlier: 8-byte T loads); every bond listed twice in both directions (a bonded
+    pair inside the cutoff then has THREE edges sharing one coefficient entry); more than 64 distinct embedding rows (two selector tiles).
+    A 63-atom molecule does not fit the window and must fall back to jamun_conv_dg.hip."""
+    import dataclasses
+
+    from jamun_amd import synth
+    from jamun_amd.data import WalkerBatch
+    from jamun_amd.model import Denoiser
+    from jamun_amd.native import NativeSampler
+
+    model = Denoiser.from_checkpoint_dict(_ckpt("strong")).to(dev)
+    if case == "span62":
+        mols = [synth.random_chain(31, seed=s) for s in (1, 2, 3, 4)]
+    elif case == "single62":
+        mols = [synth.random_chain(62, seed=5), synth.random_chain(62, seed=6)]
+    elif case == "odd_start":
+        mols = [synth.random_chain(n, seed=10 + i) for i, n in enumerate([1, 17, 3, 21, 5, 19, 17, 7, 25, 9])]
+    elif case == "double_bonds":
+        mols = []
+        for i, n in enumerate([17, 20, 9, 17]):
+            m = synth.random_chain(n, seed=20 + i)
+            b = m["bonds"]
+            m["bonds"] = torch.cat([b, b, b.flip(0), b.flip(0)], dim=1)  # both directions, each twice
+            mols.append(m)
+    else:  # many distinct (type, code, residue) rows: residue indices keep growing along a 60-atom chain
+        mols = [synth.random_chain(60, seed=30 + i) for i in range(3)]
+        for i, m in enumerate(mols):
+            m["residue_sequence_index"] = m["residue_sequence_index"] + 12 * i
+            m["residue_code_index"] = (m["residue_code_index"] + 7 * i) % 20
+    batch = WalkerBatch.from_molecules(mols).to(dev)
+    torch.manual_seed(3)
+    y = batch.pos + 0.04 * torch.randn(batch.pos.shape).to(dev)
+    mf = NativeSampler(model._native, 0.04, batch, dev)
+    st = mf.stats()
+    assert (st["conv_path"], st["dg_mode"], st["init_path"]) == (2, 4, 3), st
+    monkeypatch.setenv("JAMUN_NO_DG", "1")
+    monkeypatch.setenv("JAMUN_NO_FUSED", "1")
+    general = NativeSampler(model._native, 0.04, batch, dev)
+    monkeypatch.delenv("JAMUN_NO_DG")
+    monkeypatch.delenv("JAMUN_NO_FUSED")
+    assert general.stats()["conv_path"] == 0
+    xm, xg = mf.xhat(y), general.xhat(y)
+    assert torch.isfinite(xm).all() and rmsd(xm, xg) <= RMSD_TOL_NM, rmsd(xm, xg)
+    assert torch.equal(mf.xhat(y), xm)  # bit-reproducible
+    for l in range(6):
+        a, b = mf.debug_read(0, l).cpu(), general.debug_read(0, l).cpu()
+        assert (a - b).abs().max().item() <= 2e-5 * max(b.abs().max().item(), 1e-6), l
+    if case == "single62":  # one atom more: the span no longer fits the K = 64 window
+        big = WalkerBatch.from_molecules([synth.random_chain(63, seed=5)]).to(dev)
+        assert NativeSampler(model._native, 0.04, big, dev).stats()["dg_mode"] != 4
+
+
 @pytest.mark.parametrize("atoms,walkers,dg_mode,init_path", [(17, 64, 4, 3), (33, 64, 4, 3), (57, 32, 4, 3), (70, 16, 3, 1), (166, 4, 1, 2)])
 def test_kernel_variants_chosen_for_the_baseline_shapes(dev, atoms, walkers, dg_mode, init_path):
     """BASELINE configs[1..4] shapes (fewer walkers): which variant of the hidden-layer conv kernel (jamun_stats.dg_mode) and of
