@@ -1074,7 +1074,8 @@ LayerDev build_layer(const jamun_model& m, const std::string& prefix, const std:
   }
 
   // ---- initial projector: input-times-weight table for jamun_conv_init.hip (inputs are constant per distinct embedding row)
-  if (uniq_rows && L.fu.wpack && G0 <= 32 * NT0 && G1 <= 32) {
+  // (the table itself does not depend on the fused kernel's packing: k_conv_mfi uses it on the tiles of k_conv_mf)
+  if (uniq_rows && G0 <= 32 * NT0 && G1 <= 32) {
     bool scalar_only = true;
     for (auto& ib : in_blocks) scalar_only = scalar_only && ib.l == 0;
     const int U = (int)(uniq_rows->size() / (size_t)row_len);
@@ -1102,10 +1103,12 @@ LayerDev build_layer(const jamun_model& m, const std::string& prefix, const std:
             out[32 * NT0 + w] = (float)acc;
           }
         }
-      L.tt = dev_upload(tt);
-      L.tt_row = tt_row;
-      L.tt_U = U;
-      if (NT0 == 5 && G0 <= 152 && G1 <= 32) {  // scalar columns 0..127 as they are, then per lane u (column 128+u, vector column u)
+      if (L.fu.wpack) {
+        L.tt = dev_upload(tt);
+        L.tt_row = tt_row;
+        L.tt_U = U;
+      }
+      if (L.fu.wpack && NT0 == 5 && G0 <= 152 && G1 <= 32) {  // scalar columns 0..127 as they are, then per lane u (column 128+u, vector column u)
         std::vector<float> tt2((size_t)(H + 1) * U * 192, 0.f);
         for (int k = 0; k <= H; ++k)
           for (int uid = 0; uid < U; ++uid) {
@@ -1691,8 +1694,8 @@ int jamun_sampler_create(const jamun_model* m, float sigma, const jamun_topology
       }
       const bool no_init = getenv("JAMUN_NO_INIT_TABLE") != nullptr;  // debugging / A-B aid
       s->layers.push_back(build_layer(*m, "initial_projector", ib, ones, s->n_slices, s->fused_JR, s->span_max,
-                                      (s->fused_JR > 0 && !no_init) ? &uniq : nullptr, s->n_emb));
-      if (s->layers.back().tt) s->atom_uid = dev_upload(uid);
+                                      !no_init ? &uniq : nullptr, s->n_emb));
+      if (s->layers.back().tt || s->layers.back().tabw) s->atom_uid = dev_upload(uid);
     }
     for (int l = 0; l < hp.n_layers; ++l) {
       std::vector<InBlock> ib = {{hp.mul0, 0, 0, 0}, {hp.mul1, 1, hp.mul0, hp.mul0}};

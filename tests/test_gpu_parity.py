@@ -396,7 +396,7 @@ def test_fused_and_fallback_conv_agree_on_random_ragged_batches(dev, seed, monke
                 assert (a - b).abs().max().item() <= 2e-5 * max(b.abs().max().item(), 1e-6), (trial, l)
 
 
-@pytest.mark.parametrize("case", ["span62", "single62", "odd_start", "double_bonds", "many_rows"])
+@pytest.mark.parametrize("case", ["span62", "single62", "odd_start", "double_bonds", "rows100", "many_rows"])
 def test_matrix_formed_conv_edge_cases(dev, case, monkeypatch):
     """k_conv_mf / k_conv_mfi (jamun_conv_mf.hip) against the general kernel on the shapes that stress their bookkeeping: a tile span of
     exactly 62 source rows over two molecules; one 62-atom molecule (edge stride above 32: all eight waves build); tiles whose span starts
@@ -417,6 +417,9 @@ def test_matrix_formed_conv_edge_cases(dev, case, monkeypatch):
         mols = [synth.random_chain(62, seed=5), synth.random_chain(62, seed=6)]
     elif case == "odd_start":
         mols = [synth.random_chain(n, seed=10 + i) for i, n in enumerate([1, 17, 3, 21, 5, 19, 17, 7, 25, 9])]
+    elif case == "rows100":  # 65..128 distinct embedding rows: four selector tiles in k_conv_mfi
+        mols = [synth.random_chain(40, seed=40 + i) for i in range(2)]
+        mols[1]["residue_sequence_index"] = mols[1]["residue_sequence_index"] + 8
     elif case == "double_bonds":
         mols = []
         for i, n in enumerate([17, 20, 9, 17]):
@@ -424,7 +427,7 @@ def test_matrix_formed_conv_edge_cases(dev, case, monkeypatch):
             b = m["bonds"]
             m["bonds"] = torch.cat([b, b, b.flip(0), b.flip(0)], dim=1)  # both directions, each twice
             mols.append(m)
-    else:  # many distinct (type, code, residue) rows: residue indices keep growing along a 60-atom chain
+    else:  # many distinct (type, code, residue) rows: residue indices keep growing along the chains (> 128 rows in all)
         mols = [synth.random_chain(60, seed=30 + i) for i in range(3)]
         for i, m in enumerate(mols):
             m["residue_sequence_index"] = m["residue_sequence_index"] + 12 * i
@@ -434,7 +437,8 @@ def test_matrix_formed_conv_edge_cases(dev, case, monkeypatch):
     y = batch.pos + 0.04 * torch.randn(batch.pos.shape).to(dev)
     mf = NativeSampler(model._native, 0.04, batch, dev)
     st = mf.stats()
-    assert (st["conv_path"], st["dg_mode"], st["init_path"]) == (2, 4, 3), st
+    # (more than 128 distinct embedding rows: the initial projector stays on the table kernel of the fused tile plan)
+    assert (st["conv_path"], st["dg_mode"], st["init_path"]) == (2, 4, 1 if case == "many_rows" else 3), st
     monkeypatch.setenv("JAMUN_NO_DG", "1")
     monkeypatch.setenv("JAMUN_NO_FUSED", "1")
     general = NativeSampler(model._native, 0.04, batch, dev)
