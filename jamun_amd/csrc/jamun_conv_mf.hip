@@ -218,16 +218,23 @@ __global__ __launch_bounds__(MF_THREADS) void k_conv_mf(MfArgs a) {
     int ent[NP];
     const int slot0 = (n0 + (tid & (BT - 1)) / SPD) * a.S + (tid & (BT - 1)) % SPD, pstride = DPP * a.S;
     float evx[NP], evy[NP], evz[NP];
-    bool any_tw = false;
+    int sjv[NP];
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {  // (all passes' edge records requested before the first is looked at: one round trip, not NP)
+      const int g = (tid & (BT - 1)) + BT * p, i = g / SPD, t = g % SPD;
+      const int slot = (n0 + i) * a.S + t;
+      const bool in = builder && t < deg_lds[i] && t < a.S;
+      sjv[p] = in ? a.esrc[slot] : 0;
+      float4 ge = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (in) ge = a.egeo[slot];
+      evx[p] = ge.x; evy[p] = ge.y; evz[p] = ge.z;
+    }
 #pragma unroll
     for (int p = 0; p < NP; ++p) {
       const int g = (tid & (BT - 1)) + BT * p, i = g / SPD, t = g % SPD;
       const int dg = deg_lds[i];
-      const int slot = (n0 + i) * a.S + t;
       const bool in = builder && t < dg && t < a.S;
-      const int sj = in ? a.esrc[slot] : 0;
-      float4 ge = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (in) ge = a.egeo[slot];
+      const int sj = sjv[p];
       const bool bonded = in && sj < 0;  // bit 31
       const int jraw = sj & 0x7fffffff, jl = jraw - s_base;
       const bool valid = in && jl >= 0 && jl < 64;
@@ -255,35 +262,30 @@ __global__ __launch_bounds__(MF_THREADS) void k_conv_mf(MfArgs a) {
           }
         }
       }
-      any_tw = any_tw || d0 > 0;
       ent[p] = active ? (i * MF_ROWB + 2 * jl) | (d0 << 13) | (d1 << 19) : 128;
-      evx[p] = ge.x; evy[p] = ge.y; evz[p] = ge.z;
     }
-    const bool wave_tw = __ballot(any_tw) != 0ull;
     const float scC = pow2f(a.sC), scT = pow2f(clamp100(sX + a.sTw));
-    float hv[NP], ht0[NP], ht1[NP];
+    float hv[NP];
     float2 tv[NTV];
-#pragma unroll
-    for (int p = 0; p < NP; ++p) ht0[p] = ht1[p] = 0.f;
     // (loads only, nothing consumed here: a use would wait for EVERY vector load in flight, the weight ring included)
+    // Every lane loads the h~ of its OWN slot, the lanes of a pair's second / third edge included: the owner of the entry fetches
+    // theirs with a lane shuffle (same wave: slot distance = lane distance) instead of two more loads per pass.
     auto load_k = [&](int k) {  // h~ of this lane's edges and this lane's T elements of hidden unit k
       if (!builder) return;
       const float* __restrict__ hk = a.h + (size_t)k * a.h_kstride;
 #pragma unroll
-      for (int p = 0; p < NP; ++p) hv[p] = hk[slot0 + p * pstride];  // (inactive lanes read a slot of the table's slack: never used)
-      if (wave_tw) {
-#pragma unroll
-        for (int p = 0; p < NP; ++p) {
-          ht0[p] = hk[slot0 + p * pstride + ((ent[p] >> 13) & 63)];
-          ht1[p] = hk[slot0 + p * pstride + ((ent[p] >> 19) & 63)];
-        }
-      }
+      for (int p = 0; p < NP; ++p) hv[p] = hk[slot0 + p * pstride];  // (lanes past the in-degree read a neighbouring slot or the table's slack: never used)
       const float* __restrict__ tk = a.Tt + (size_t)k * 32 * a.t_stride + s_base;
 #pragma unroll
       for (int q = 0; q < NTV; ++q) {
         const int item = tid + BT * q, wp = item >> 5, jp = item & 31;
         tv[q] = *reinterpret_cast<const float2*>(tk + (size_t)wp * a.t_stride + 2 * jp);
       }
+    };
+    auto coef = [&](int p) {  // h~ of pass p's entry: this lane's edge + the pair's other edges
+      const int d0 = (ent[p] >> 13) & 63, d1 = (ent[p] >> 19) & 63;
+      const float t0 = __shfl(hv[p], lane + d0, 64), t1 = __shfl(hv[p], lane + d1, 64);
+      return (hv[p] + (d0 ? t0 : 0.f)) + (d1 ? t1 : 0.f);
     };
     auto build = [&](int buf) {  // the loaded hidden unit -> coefficient tiles and T tile of buffer `buf`
       if constexpr ((dbg & 8) != 0) return;
@@ -292,7 +294,7 @@ __global__ __launch_bounds__(MF_THREADS) void k_conv_mf(MfArgs a) {
 #pragma unroll
       for (int p = 0; p < NP; ++p) {
         {
-          const float c0 = ((hv[p] + ((ent[p] & (63 << 13)) ? ht0[p] : 0.f)) + ((ent[p] & (63 << 19)) ? ht1[p] : 0.f)) * scC, c1 = c0 * evx[p], c2 = c0 * evy[p], c3 = c0 * evz[p];
+          const float c0 = coef(p) * scC, c1 = c0 * evx[p], c2 = c0 * evy[p], c3 = c0 * evz[p];
           const unsigned h01 = cvt_pk_f16(c0, c1), h23 = cvt_pk_f16(c2, c3);
           const unsigned l01 = cvt_pk_f16(resid_lo(c0, h01), resid_hi(c1, h01)), l23 = cvt_pk_f16(resid_lo(c2, h23), resid_hi(c3, h23));
           char* __restrict__ d = cbuf + (ent[p] & 0x1fff);
@@ -445,7 +447,7 @@ __global__ __launch_bounds__(MF_THREADS) void k_conv_mf(MfArgs a) {
               if constexpr ((dbg & 8) != 0) return;
               if (i < 5 * NP) {
                 const int p = i / 5, j = i % 5;
-                if (j == 0) cc = ((hv[p] + ((ent[p] & (63 << 13)) ? ht0[p] : 0.f)) + ((ent[p] & (63 << 19)) ? ht1[p] : 0.f)) * scC;
+                if (j == 0) cc = coef(p) * scC;
                 else if (j == 1) { c1 = cc * evx[p]; c2 = cc * evy[p]; c3 = cc * evz[p]; h01 = cvt_pk_f16(cc, c1); h23 = cvt_pk_f16(c2, c3); }
                 else if (j == 2) { l01 = cvt_pk_f16(resid_lo(cc, h01), resid_hi(c1, h01)); l23 = cvt_pk_f16(resid_lo(c2, h23), resid_hi(c3, h23)); }
                 else if (j == 3) {
