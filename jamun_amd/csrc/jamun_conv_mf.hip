@@ -106,6 +106,25 @@ __device__ __forceinline__ float resid_hi(float a, unsigned pk) {  // a - float(
   asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(pk), "v"(a));
   return r;
 }
+// uniform loads through the constant address space: scalar loads into scalar registers
+__device__ __forceinline__ int4 ld_const(const int4* p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  typedef int i32x4 __attribute__((ext_vector_type(4)));
+  const i32x4 v = *(const __attribute__((address_space(4))) i32x4*)(uintptr_t)p;
+  return make_int4(v.x, v.y, v.z, v.w);
+#else
+  return *p;
+#endif
+}
+__device__ __forceinline__ int2 ld_const(const int2* p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  typedef int i32x2 __attribute__((ext_vector_type(2)));
+  const i32x2 v = *(const __attribute__((address_space(4))) i32x2*)(uintptr_t)p;
+  return make_int2(v.x, v.y);
+#else
+  return *p;
+#endif
+}
 __device__ __forceinline__ float pow2f(int e) { return __uint_as_float((unsigned)(e + 127) << 23); }
 __device__ __forceinline__ int exp_above(float v) { return (int)((__float_as_uint(v) >> 23) & 0xffu) - 126; }  // v < 2^exp_above(v)
 __device__ __forceinline__ int clamp40(int s) { return max(-40, min(40, s)); }
@@ -134,20 +153,24 @@ __global__ __launch_bounds__(MF_THREADS) void k_conv_mf(MfArgs a) {
 #ifdef MF_TRACE
   int trc = 0;
 #endif
+  // (the descriptors of segment s + 1 — list entry, then its tile's atoms and span — are requested during segment s: three dependent
+  // global round trips off the critical path of every segment but the first)
+  const int4* __restrict__ my_segs = a.segs + (size_t)blockIdx.x * a.max_segs * 2;
+  int4 sg0 = ld_const(my_segs), sg1 = ld_const(my_segs + 1);
+  int2 t_at = make_int2(0, 0), span = make_int2(0, 0);
+  if (RFL(sg0.x) >= 0) { t_at = ld_const(a.tile_atoms + RFL(sg0.x)); span = ld_const(a.tile_span + RFL(sg0.x)); }
   for (int sgi = 0; sgi < a.max_segs; ++sgi) {
-    const int4 sg0 = a.segs[((size_t)blockIdx.x * a.max_segs + sgi) * 2];
-    const int4 sg1 = a.segs[((size_t)blockIdx.x * a.max_segs + sgi) * 2 + 1];
     const int tile = RFL(sg0.x);
     if (tile < 0) break;
+    int4 nsg0 = make_int4(-1, 0, 0, 0), nsg1 = make_int4(-1, 0, 0, 0);
+    if (sgi + 1 < a.max_segs) { nsg0 = ld_const(my_segs + 2 * (sgi + 1)); nsg1 = ld_const(my_segs + 2 * (sgi + 1) + 1); }
     int lane = lane0;
     asm volatile("" : "+v"(lane));  // (keeps lane-derived addresses from being hoisted out of the segment loop and spilled)
     const int tid = wave * 64 + lane;
     const int slab = RFL(sg0.y), k_begin = RFL(sg0.z), k_run = RFL(sg0.w) - k_begin, k_extra = RFL(sg1.x);
     const int nk = k_run + (k_extra >= 0 ? 1 : 0);
     auto k_of = [&](int kk) { kk = kk < 0 ? 0 : (kk < nk ? kk : nk - 1); return kk < k_run ? k_begin + kk : k_extra; };
-    const int2 t_at = a.tile_atoms[tile];
     const int n0 = RFL(t_at.x), n_dst = RFL(t_at.y);
-    const int2 span = a.tile_span[tile];
     const int s_lo = RFL(span.x), rows = RFL(span.y) - s_lo;
     const int s_base = s_lo & ~1, off = s_lo - s_base;  // window of 64 source rows from an even atom (8-byte T loads)
 
@@ -217,6 +240,24 @@ __global__ __launch_bounds__(MF_THREADS) void k_conv_mf(MfArgs a) {
     // 128 of every plane; never read), so that build() is straight-line code.  The slot of pass p is slot0 + p * DPP * S.
     int ent[NP];
     const int slot0 = (n0 + (tid & (BT - 1)) / SPD) * a.S + (tid & (BT - 1)) % SPD, pstride = DPP * a.S;
+    float hv[NP];
+    float2 tv[NTV];
+    // (loads only, nothing consumed here: a use would wait for EVERY vector load in flight, the weight ring included)
+    // Every lane loads the h~ of its OWN slot, the lanes of a pair's second / third edge included: the owner of the entry fetches
+    // theirs with a lane shuffle (same wave: slot distance = lane distance) instead of two more loads per pass.
+    auto load_k = [&](int k) {  // h~ of this lane's edges and this lane's T elements of hidden unit k
+      if (!builder) return;
+      const float* __restrict__ hk = a.h + (size_t)k * a.h_kstride;
+#pragma unroll
+      for (int p = 0; p < NP; ++p) hv[p] = hk[slot0 + p * pstride];  // (lanes past the in-degree read a neighbouring slot or the table's slack: never used)
+      const float* __restrict__ tk = a.Tt + (size_t)k * 32 * a.t_stride + s_base;
+#pragma unroll
+      for (int q = 0; q < NTV; ++q) {
+        const int item = tid + BT * q, wp = item >> 5, jp = item & 31;
+        tv[q] = *reinterpret_cast<const float2*>(tk + (size_t)wp * a.t_stride + 2 * jp);
+      }
+    };
+    load_k(k_of(0));  // (first of all: its round trip hides behind the edge records)
     float evx[NP], evy[NP], evz[NP];
     int sjv[NP];
 #pragma unroll
@@ -265,23 +306,6 @@ __global__ __launch_bounds__(MF_THREADS) void k_conv_mf(MfArgs a) {
       ent[p] = active ? (i * MF_ROWB + 2 * jl) | (d0 << 13) | (d1 << 19) : 128;
     }
     const float scC = pow2f(a.sC), scT = pow2f(clamp100(sX + a.sTw));
-    float hv[NP];
-    float2 tv[NTV];
-    // (loads only, nothing consumed here: a use would wait for EVERY vector load in flight, the weight ring included)
-    // Every lane loads the h~ of its OWN slot, the lanes of a pair's second / third edge included: the owner of the entry fetches
-    // theirs with a lane shuffle (same wave: slot distance = lane distance) instead of two more loads per pass.
-    auto load_k = [&](int k) {  // h~ of this lane's edges and this lane's T elements of hidden unit k
-      if (!builder) return;
-      const float* __restrict__ hk = a.h + (size_t)k * a.h_kstride;
-#pragma unroll
-      for (int p = 0; p < NP; ++p) hv[p] = hk[slot0 + p * pstride];  // (lanes past the in-degree read a neighbouring slot or the table's slack: never used)
-      const float* __restrict__ tk = a.Tt + (size_t)k * 32 * a.t_stride + s_base;
-#pragma unroll
-      for (int q = 0; q < NTV; ++q) {
-        const int item = tid + BT * q, wp = item >> 5, jp = item & 31;
-        tv[q] = *reinterpret_cast<const float2*>(tk + (size_t)wp * a.t_stride + 2 * jp);
-      }
-    };
     auto coef = [&](int p) {  // h~ of pass p's entry: this lane's edge + the pair's other edges
       const int d0 = (ent[p] >> 13) & 63, d1 = (ent[p] >> 19) & 63;
       const float t0 = __shfl(hv[p], lane + d0, 64), t1 = __shfl(hv[p], lane + d1, 64);
@@ -397,7 +421,6 @@ __global__ __launch_bounds__(MF_THREADS) void k_conv_mf(MfArgs a) {
       if (w < 4) {
         // (issue order as in the loop — h~ / T of the next hidden unit, then weight blocks — so that the wait in front of build()
         // counts the same loads on the way into the loop as around it)
-        load_k(k_of(0));
         build(0);
         load_k(k_of(1));
         MF_SCHED();
@@ -511,7 +534,6 @@ __global__ __launch_bounds__(MF_THREADS) void k_conv_mf(MfArgs a) {
         }
       } else {
         if constexpr (BT == 512) {
-          load_k(k_of(0));
           build(0);
           load_k(k_of(1));
           MF_SCHED();
@@ -579,7 +601,6 @@ __global__ __launch_bounds__(MF_THREADS) void k_conv_mf(MfArgs a) {
       u32x4 RB[R];
       const int x1a = MF_X1H + fo;  // + plane * 32 rows
       if constexpr (BT == 512) {
-        load_k(k_of(0));
         build(0);
         load_k(k_of(1));
         MF_SCHED();
@@ -664,6 +685,8 @@ __global__ __launch_bounds__(MF_THREADS) void k_conv_mf(MfArgs a) {
       }
     }
     // ---- all threads: sum of the five K-partial tiles -> partial slab of this segment, coalesced 16-byte stores
+    sg0 = nsg0; sg1 = nsg1;
+    if (RFL(sg0.x) >= 0) { t_at = ld_const(a.tile_atoms + RFL(sg0.x)); span = ld_const(a.tile_span + RFL(sg0.x)); }
     LDS_BARRIER();
     {
       const float* __restrict__ ST0 = reinterpret_cast<const float*>(lds);
