@@ -491,7 +491,7 @@ def main():
             # HBM-side bytes per launch from the committed PMC passes of the cfg2 command (profiles/collect.sh); rocprofv3
             # cannot run inside the timed process, so the newest committed summary is quoted, with its file name
             if args.atoms is None and args.walkers is None and not args.strong:
-                tr = _pmc_traffic(("k_conv_mf" if stats.get("dg_mode") == 4 else "k_conv_dg") if stats["conv_path"] == 2 else
+                tr = _pmc_traffic(("k_conv_mf<" if stats.get("dg_mode") == 4 else "k_conv_dg<") if stats["conv_path"] == 2 else
                                   {1: "k_conv_fused"}.get(stats["conv_path"], "k_conv<"), args.config)
                 if tr is not None:
                     out["roofline"]["traffic"] = tr[0]
