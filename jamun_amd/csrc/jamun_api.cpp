@@ -2176,7 +2176,12 @@ int jamun_sampler_stats(jamun_sampler* s, jamun_stats* out, void* stream) {
     launch_count_edges(s->deg, s->n_atoms, s->counter, st);
     unsigned long long e = 0;
     HIPCHECK(hipMemcpyAsync(&e, s->counter, sizeof(e), hipMemcpyDeviceToHost, st));
+    int mf_flag = 0;
+    if (s->mf_err) HIPCHECK(hipMemcpyAsync(&mf_flag, s->mf_err, sizeof(int), hipMemcpyDeviceToHost, st));
     HIPCHECK(hipStreamSynchronize(st));
+    // (k_conv_mf / k_conv_mfi: an ordered pair with more than three edges cannot share one coefficient entry; the host excludes such
+    // topologies at create time, the kernels still flag what they see)
+    if (mf_flag != 0) throw Err(JAMUN_ERR_INVALID, "k_conv_mf: more than three edges of one (source, destination) pair");
     out->n_edges = (int64_t)e;
     out->flop_ref_assoc = (int64_t)e * s->flop_ref_per_edge;
     out->flop_executed = s->flop_exec;
