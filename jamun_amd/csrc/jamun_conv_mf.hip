@@ -626,37 +626,63 @@ __global__ __launch_bounds__(MF_THREADS) void k_conv_mf(MfArgs a) {
           if (g == 2) return ldf(x1a + m2 * 32 * MF_ROWB + s4, MF_X1L - MF_X1H, cb + (1 + m1) * 2 * MF_PL + s4);
           return ldf(cb + (1 + m) * 2 * MF_PL + s4, MF_PL, tb + s4);
         };
-        float4 Ah[2], Al[2];
         f32x16 FA = zero16, F1 = zero16, F2 = zero16;
         Frag fq[3];
         fq[0] = fr(0); fq[1] = fr(1);
 #pragma unroll
-        for (int st = 0; st < 16; ++st) {
-          if (st + 2 < 16) fq[(st + 2) % 3] = fr(st + 2);
+        for (int st = 0; st < 12; ++st) {
+          fq[(st + 2) % 3] = fr(st + 2);
           MF_SCHED();
-          mm(st < 4 ? FA : st < 8 ? F1 : st < 12 ? F2 : accT, fq[st % 3]);
+          mm(st < 4 ? FA : st < 8 ? F1 : F2, fq[st % 3]);
           MF_SCHED();
           if (st == 3) MSTAMP(2);
         }
-        split(FA, Ah, Al);
-        MSTAMP(3);
-#pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2) {
-          const int p = 2 * s2;
-          if constexpr (!(dbg & 4)) { M3(accP, Ah[s2], Al[s2], RB[p % R], RB[(p + 1) % R]); }
-          if constexpr (!(dbg & 1)) {
-#pragma unroll
-            for (int e = 0; e < 2; ++e) RB[(p + e) % R] = (p + e + R < NB) ? wload(cur + (p + e + R) * 1024) : wload(nxt + (p + e + R - NB) * 1024);
-            MF_SCHED();
+        // The 12 MFMAs of the T term (steps 12..15; their own accumulator) carry the vector work of BOTH splits between them — 16 pairs
+        // of values (x1[m] tile, then the cross-product tile F1 - F2), one or two pairs behind each MFMA, pinned with scheduling
+        // barriers: left in program order the two splits are ~130 vector instructions with an idle matrix pipe.
+        unsigned ahA[2][4], alA[2][4], ahC[2][4], alC[2][4];
+        auto split_pair = [&](int i) {  // i = 0..7: x1[m] tile, 8..15: cross-product tile; pair (s2, p2) of the tile
+          const int s2 = (i >> 2) & 1, p2 = i & 3, q = 8 * s2 + 2 * p2;
+          if constexpr ((dbg & 16) != 0) { ahA[s2][p2] = alA[s2][p2] = ahC[s2][p2] = alC[s2][p2] = 0u; return; }
+          if (i < 8) {
+            const float v0 = FA[q] * rs, v1 = FA[q + 1] * rs;
+            const unsigned ph = cvt_pk_f16(v0, v1);
+            ahA[s2][p2] = ph;
+            alA[s2][p2] = cvt_pk_f16(resid_lo(v0, ph), resid_hi(v1, ph));
+          } else {
+            const float v0 = (F1[q] - F2[q]) * rs, v1 = (F1[q + 1] - F2[q + 1]) * rs;
+            const unsigned ph = cvt_pk_f16(v0, v1);
+            ahC[s2][p2] = ph;
+            alC[s2][p2] = cvt_pk_f16(resid_lo(v0, ph), resid_hi(v1, ph));
           }
+        };
+#pragma unroll
+        for (int st = 12; st < 16; ++st) {
+          if (st + 2 < 16) fq[(st + 2) % 3] = fr(st + 2);
+          MF_SCHED();
+          const Frag& f = fq[st % 3];
+          const int e = 4 * (st - 12);  // pairs e .. e + 3 ride on this step's three MFMAs (1 + 1 + 2)
+          if constexpr (!(dbg & 2)) accT = MFMA32H(f.al, f.bh, accT);
+          MF_SCHED();
+          split_pair(e);
+          MF_SCHED();
+          if constexpr (!(dbg & 2)) accT = MFMA32H(f.ah, f.bl, accT);
+          MF_SCHED();
+          split_pair(e + 1);
+          MF_SCHED();
+          if constexpr (!(dbg & 2)) accT = MFMA32H(f.ah, f.bh, accT);
+          MF_SCHED();
+          split_pair(e + 2);
+          split_pair(e + 3);
+          MF_SCHED();
         }
+        MSTAMP(3);
+        auto f4 = [](const unsigned (&v)[4]) { return make_float4(__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3])); };
 #pragma unroll
-        for (int q = 0; q < 16; ++q) F1[q] -= F2[q];
-        split(F1, Ah, Al);
-#pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2) {
-          const int p = 4 + 2 * s2;
-          if constexpr (!(dbg & 4)) { M3(accP, Ah[s2], Al[s2], RB[p % R], RB[(p + 1) % R]); }
+        for (int g = 0; g < 4; ++g) {  // x1 inputs (blocks 0..3), then cross inputs (4..7): (hi, lo) per K-step
+          const int s2 = g & 1, p = 2 * g;
+          const float4 Ah_ = g < 2 ? f4(ahA[s2]) : f4(ahC[s2]), Al_ = g < 2 ? f4(alA[s2]) : f4(alC[s2]);
+          if constexpr (!(dbg & 4)) { M3(accP, Ah_, Al_, RB[p % R], RB[(p + 1) % R]); }
           if constexpr (!(dbg & 1)) {
 #pragma unroll
             for (int e = 0; e < 2; ++e) RB[(p + e) % R] = (p + e + R < NB) ? wload(cur + (p + e + R) * 1024) : wload(nxt + (p + e + R - NB) * 1024);
