@@ -228,9 +228,10 @@ __global__ __launch_bounds__(MF_THREADS) void k_conv_mf(MfArgs a) {
 
     const int r = lane & 31, hh = lane >> 5;
 
-    // ---- builder lanes: their share of the coefficient-tile entries (edge slots) and of the T tile.  Edge strides up to 32: waves
-    // 0..3 (the lighter matrix role), four passes of 8 destinations x 32 slots; above: all eight waves, four passes of 8 x 64
-    constexpr int BT = SPD == 32 ? 256 : 512;        // builder threads
+    // ---- builder lanes (waves 0..3, the lighter matrix role): their share of the coefficient-tile entries (edge slots) and of the T
+    // tile.  Edge strides up to 32: four passes of 8 destinations x 32 slots; above: eight passes of 4 destinations x 64 slots (a
+    // destination's slots stay within one wave: the pair bookkeeping uses ballots and shuffles)
+    constexpr int BT = 256;                          // builder threads
     constexpr int DPP = BT / SPD, NP = 32 / DPP;     // destinations per pass, passes
     constexpr int NTV = 1024 / BT;                   // T elements (pairs of source rows) per builder lane
     const bool builder = tid < BT;
@@ -395,15 +396,16 @@ __global__ __launch_bounds__(MF_THREADS) void k_conv_mf(MfArgs a) {
 #define MF_SCHED() __builtin_amdgcn_sched_barrier(0)
 
     if (wave < 5) {
-      // ---- scalar-output waves: 20 weight blocks per k ((hi, lo) per (output tile n, K-step s2)), ring of 10
-      // ring: half a hidden unit ahead (all waves build: a quarter; the builder registers need the room)
-      constexpr int NB = 20, R = BT == 512 ? 5 : 10, RD = R;
+      // ---- scalar-output waves: 20 weight blocks per k ((hi, lo) per (output tile n, K-step s2)); ring: half a hidden unit ahead
+      // (edge strides above 32: eight builder passes per lane instead of four — their registers come out of the ring of waves 0..3,
+      // whose contraction is bound by the vector work riding on it, not by the weight latency)
+      constexpr int NB = 20, R = SPD == 64 ? 5 : 10, RD = 10;
       const int w = wave;
       f32x16 accS[5];
 #pragma unroll
       for (int n = 0; n < 5; ++n) accS[n] = zero16;
       auto wstream = [&](int k) { return (k * 124 + 20 * w) * 1024; };  // byte offset of this wave's stream of hidden unit k
-      u32x4 RB[RD > R ? RD : R];
+      u32x4 RB[RD];
       auto contract = [&](const float4 (&Ah)[2], const float4 (&Al)[2], int cur, int nxt) {
 #pragma unroll
         for (int n = 0; n < 5; ++n)
@@ -436,10 +438,10 @@ __global__ __launch_bounds__(MF_THREADS) void k_conv_mf(MfArgs a) {
           const int cb = MF_C + (it & 1) * MF_CB + fo;
           MSTAMP(0);
           float4 Ah[2], Al[2];
-          Frag f0 = ldf(xa, MF_X0L - MF_X0H, cb), f1 = ldf(xa + 32, MF_X0L - MF_X0H, cb + 32);
-          MF_SCHED();
-          MSTAMP(1);
-          {
+          if constexpr (SPD == 32) {
+            Frag f0 = ldf(xa, MF_X0L - MF_X0H, cb), f1 = ldf(xa + 32, MF_X0L - MF_X0H, cb + 32);
+            MF_SCHED();
+            MSTAMP(1);
             f32x16 F = zero16;
             mm(F, f0);
             MF_SCHED();
@@ -451,6 +453,17 @@ __global__ __launch_bounds__(MF_THREADS) void k_conv_mf(MfArgs a) {
             MF_SCHED();
             mm(F, f0);
             mm(F, f1);
+            MSTAMP(2);
+            split(F, Ah, Al);
+          } else {  // (one fragment set: the eight builder passes need the registers; this wave is not the longest stream of its SIMD)
+            MSTAMP(1);
+            f32x16 F = zero16;
+#pragma unroll
+            for (int st = 0; st < 4; ++st) {
+              const Frag f0 = ldf(xa + 32 * st, MF_X0L - MF_X0H, cb + 32 * st);
+              mm(F, f0);
+              MF_SCHED();
+            }
             MSTAMP(2);
             split(F, Ah, Al);
           }
@@ -499,6 +512,13 @@ __global__ __launch_bounds__(MF_THREADS) void k_conv_mf(MfArgs a) {
                 }
               }
             };
+            // (30 MFMA slots; with eight builder passes there are 48 pieces: the first 18 slots carry two CONSECUTIVE pieces — the pieces of
+            // a pass share their temporaries and must run in order)
+            auto bslot = [&](int sl) {
+              constexpr int EXTRA = 5 * NP + 2 * NTV > 30 ? 5 * NP + 2 * NTV - 30 : 0;
+              if (sl < EXTRA) { bstep(2 * sl); bstep(2 * sl + 1); }
+              else bstep(sl + EXTRA);
+            };
             MF_SCHED();
 #pragma unroll
             for (int n = 0; n < 5; ++n)
@@ -507,11 +527,11 @@ __global__ __launch_bounds__(MF_THREADS) void k_conv_mf(MfArgs a) {
                 const int g = 2 * n + s2, p = 2 * g;
                 if constexpr (!(dbg & 4)) accS[n] = MFMA32H(Al[s2], RB[p % R], accS[n]);
                 MF_SCHED();
-                bstep(3 * g);
+                bslot(3 * g);
                 MF_SCHED();
                 if constexpr (!(dbg & 4)) accS[n] = MFMA32H(Ah[s2], RB[(p + 1) % R], accS[n]);
                 MF_SCHED();
-                bstep(3 * g + 1);
+                bslot(3 * g + 1);
                 MF_SCHED();
                 if constexpr (!(dbg & 4)) accS[n] = MFMA32H(Ah[s2], RB[p % R], accS[n]);
                 if constexpr (!(dbg & 1)) {
@@ -519,7 +539,7 @@ __global__ __launch_bounds__(MF_THREADS) void k_conv_mf(MfArgs a) {
                   for (int e = 0; e < 2; ++e) RB[(p + e) % R] = (p + e + R < NB) ? wload(cur + (p + e + R) * 1024) : wload(nxt + (p + e + R - NB) * 1024);
                 }
                 MF_SCHED();
-                bstep(3 * g + 2);
+                bslot(3 * g + 2);
                 MF_SCHED();
               }
           }
@@ -533,11 +553,6 @@ __global__ __launch_bounds__(MF_THREADS) void k_conv_mf(MfArgs a) {
 #endif
         }
       } else {
-        if constexpr (BT == 512) {
-          build(0);
-          load_k(k_of(1));
-          MF_SCHED();
-        }
         {
           const int c0 = wstream(k_of(0));
 #pragma unroll
@@ -553,7 +568,7 @@ __global__ __launch_bounds__(MF_THREADS) void k_conv_mf(MfArgs a) {
           {
             auto fr = [&](int st) { const int m = st >> 2, s4 = st & 3; return ldf(MF_X1H + (m * 32) * MF_ROWB + fo + 32 * s4, MF_X1L - MF_X1H, cb + (1 + m) * 2 * MF_PL + 32 * s4); };
             f32x16 F = zero16;
-            constexpr int QD = BT == 512 ? 2 : 3;  // fragment sets in flight (this role also carries builder registers when all waves build)
+            constexpr int QD = SPD == 64 ? 2 : 3;  // fragment sets in flight (edge strides above 32: register allocation of the kernel is at its limit)
             Frag fq[QD];
 #pragma unroll
             for (int st = 0; st < QD - 1; ++st) fq[st] = fr(st);
@@ -570,13 +585,6 @@ __global__ __launch_bounds__(MF_THREADS) void k_conv_mf(MfArgs a) {
           MSTAMP(3);
           contract(Ah, Al, cur, nxt);
           MSTAMP(4);
-          if constexpr (BT == 512) {
-            if (it + 1 < nk) {
-              build((it + 1) & 1);
-              load_k(k_of(it + 2));
-            }
-            MF_SCHED();
-          }
           LDS_BARRIER();
           MSTAMP(5);
 #ifdef MF_TRACE
@@ -594,17 +602,12 @@ __global__ __launch_bounds__(MF_THREADS) void k_conv_mf(MfArgs a) {
       }
     } else {
       // ---- plane waves: 8 weight blocks per k (x1 inputs, cross inputs: (hi, lo) per K-step), ring of 4
-      constexpr int NB = 8, R = BT == 512 ? 4 : 8;
+      constexpr int NB = 8, R = 8;
       const int m = wave - 5, m1 = (m + 1) % 3, m2 = (m + 2) % 3;
       f32x16 accP = zero16, accT = zero16;
       auto wstream = [&](int k) { return (k * 124 + 100 + 8 * m) * 1024; };
       u32x4 RB[R];
       const int x1a = MF_X1H + fo;  // + plane * 32 rows
-      if constexpr (BT == 512) {
-        build(0);
-        load_k(k_of(1));
-        MF_SCHED();
-      }
       {
         const int c0 = wstream(k_of(0));
 #pragma unroll
@@ -690,13 +693,6 @@ __global__ __launch_bounds__(MF_THREADS) void k_conv_mf(MfArgs a) {
           }
         }
         MSTAMP(4);
-        if constexpr (BT == 512) {
-          if (it + 1 < nk) {
-            build((it + 1) & 1);
-            load_k(k_of(it + 2));
-          }
-          MF_SCHED();
-        }
         LDS_BARRIER();
         MSTAMP(5);
 #ifdef MF_TRACE
