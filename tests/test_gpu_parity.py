@@ -199,6 +199,35 @@ def test_conv_block_export_matches_oracle(dev, golden_dir, kind):
         smp.conv_block(6, ref["x0"].to(dev))
 
 
+@pytest.mark.parametrize("log2_scale", [-24, 24])
+def test_matrix_formed_conv_block_at_extreme_feature_scales(dev, golden_dir, log2_scale, monkeypatch):
+    """The f16x3 kernels scale every operand into the f16 range by powers of two measured on the data (span maxima, in-degrees,
+    per-atom maxima in the node update): a ConvBlock on features 2^-24 / 2^24 times their usual size must agree with the general
+    fp32 kernel on the same input (the block is not homogeneous — gates — so the comparison is kernel against kernel)."""
+    from jamun_amd.data import WalkerBatch
+    from jamun_amd.model import Denoiser
+    from jamun_amd.native import NativeSampler
+
+    ref = _golden(golden_dir, "oracle_forward_chain17x6")
+    model = Denoiser.from_checkpoint_dict(_ckpt("strong")).to(dev)
+    batch = WalkerBatch.from_molecules(_mols("chain17x6")).to(dev)
+    mf = NativeSampler(model._native, 0.04, batch, dev)
+    assert mf.stats()["dg_mode"] == 4
+    monkeypatch.setenv("JAMUN_NO_DG", "1")
+    monkeypatch.setenv("JAMUN_NO_FUSED", "1")
+    monkeypatch.setenv("JAMUN_NODE_FP32", "1")
+    general = NativeSampler(model._native, 0.04, batch, dev)
+    assert general.stats()["conv_path"] == 0
+    y = ref["y"].to(dev)
+    mf.build_edges(y)
+    general.build_edges(y)
+    for l in (1, 3, 5):
+        x_in = (ref[f"x{l - 1}"] * 2.0**log2_scale).to(dev)
+        a, b = mf.conv_block(l, x_in).cpu(), general.conv_block(l, x_in).cpu()
+        assert torch.isfinite(a).all() and torch.isfinite(b).all()
+        assert (a - b).abs().max().item() <= 2e-5 * b.abs().max().item(), (l, log2_scale)
+
+
 # ---- denoiser forward -----------------------------------------------------------------------------------------------
 
 
