@@ -363,6 +363,8 @@ struct jamun_sampler {
   float *w_gate = nullptr, *w_vec = nullptr, *w_out = nullptr;
   // work buffers
   float *w1r_all = nullptr, *cmask_all = nullptr;  // [layers][64][32], [layers][2][64]
+  float4* w1h_all = nullptr;                        // k_edge_h16: [layers][2 k-tiles][2 K-steps][hi, lo][64 lanes]
+  float* w1isc_all = nullptr;                       // [layers] 2^-(14 + sW)
   size_t h_stride = 0, h_kstride = 0;  // per layer: [65 hidden rows][h_kstride edge slots]
   bool h_batched = false, edges_built = false;
   float *yc = nullptr, *h = nullptr, *partial0 = nullptr, *partial1 = nullptr, *g = nullptr, *tmp = nullptr;
@@ -380,7 +382,7 @@ struct jamun_sampler {
 
   ~jamun_sampler() {
     hipFree(ptr); hipFree(bond_in_ptr); hipFree(bond_in_src); hipFree(x_emb); hipFree(mu); hipFree(tile_span);
-    hipFree(fused_segs); hipFree(atom_nslab); hipFree(tile_atoms); hipFree(atom_uid); hipFree(w1r_all); hipFree(cmask_all);
+    hipFree(fused_segs); hipFree(atom_nslab); hipFree(tile_atoms); hipFree(atom_uid); hipFree(w1r_all); hipFree(cmask_all); hipFree(w1h_all); hipFree(w1isc_all);
     hipFree(dg_dump); hipFree(dg_tile_atoms); hipFree(dg_tile_span); hipFree(dg_segs); hipFree(dg_atom_nslab); hipFree(dg_T); hipFree(mf_err);
     if (mf_err_host) hipHostFree(mf_err_host);
     for (auto& L : layers) {
@@ -1201,7 +1203,7 @@ void build_edges(jamun_sampler* s, float* y, hipStream_t st, const LangevinPre& 
   if (s->h_batched) {
     ProfScope ps(s, JAMUN_PROF_EDGE_H, st);
     launch_edge_h(s->deg, s->esrc, s->egeo, s->n_atoms, s->S, s->w1r_all, s->cmask_all, (int)s->layers.size(), s->mu, s->rb_step, s->h,
-                  s->h_stride, s->h_kstride, st);
+                  s->h_stride, s->h_kstride, st, s->w1h_all, s->w1isc_all);
   }
   s->edges_built = true;
 }
@@ -1214,7 +1216,7 @@ void run_layer(jamun_sampler* s, size_t l, const float* x_in, int XSin, float* x
   if (!s->h_batched) {  // (batches above 4 GiB of activations: one layer's radial MLP at a time)
     ProfScope ps(s, JAMUN_PROF_EDGE_H, st);
     launch_edge_h(s->deg, s->esrc, s->egeo, s->n_atoms, s->S, s->w1r_all + l * 64 * 32, s->cmask_all + l * 128, 1, s->mu, s->rb_step, s->h,
-                  s->h_stride, s->h_kstride, st);
+                  s->h_stride, s->h_kstride, st, s->w1h_all ? s->w1h_all + l * 8 * 64 : nullptr, s->w1isc_all ? s->w1isc_all + l : nullptr);
   }
     if (L.sep.w2p) {
       SepArgs f{};
@@ -1908,6 +1910,43 @@ int jamun_sampler_create(const jamun_model* m, float sigma, const jamun_topology
         cmask_all.insert(cmask_all.end(), L.cmask_h.begin(), L.cmask_h.end());
       }
       s->w1r_all = dev_upload(w1r_all);
+      if (hp.edge_attr_dim == 64 && getenv("JAMUN_EDGE_H_FP32") == nullptr) {
+        // f16x3 radial MLP (k_edge_h16): W1's radial part per layer scaled to the top of the f16 range and split hi + lo, as A fragments
+        std::vector<float4> w1h;
+        std::vector<float> isc;
+        for (auto& L : s->layers) {
+          double wmax = 0;
+          for (float v : L.w1r_h) wmax = std::max(wmax, (double)std::fabs(v));
+          int ex = 0;
+          if (wmax > 0 && std::isfinite(wmax)) std::frexp(wmax, &ex);
+          const int sW = std::max(-40, std::min(40, 14 - ex));
+          isc.push_back((float)std::ldexp(1.0, -14 - sW));
+          const double sc = std::ldexp(1.0, sW);
+          for (int mt = 0; mt < 2; ++mt)
+            for (int s2 = 0; s2 < 2; ++s2) {
+              std::vector<float4> hi(64), lo(64);
+              for (int lane = 0; lane < 64; ++lane) {
+                const int hh = lane >> 5, k = 32 * mt + (lane & 31);
+                uint32_t h[4], l[4];
+                for (int i = 0; i < 4; ++i) {
+                  uint16_t hp2[2], lp2[2];
+                  for (int e = 0; e < 2; ++e) {
+                    const int r = 16 * s2 + 8 * hh + 2 * i + e;
+                    split_f16((double)L.w1r_h[(size_t)r * 64 + k] * sc, hp2[e], lp2[e]);  // w1r: [basis][hidden]
+                  }
+                  h[i] = (uint32_t)hp2[0] | ((uint32_t)hp2[1] << 16);
+                  l[i] = (uint32_t)lp2[0] | ((uint32_t)lp2[1] << 16);
+                }
+                std::memcpy(&hi[lane], h, 16);
+                std::memcpy(&lo[lane], l, 16);
+              }
+              w1h.insert(w1h.end(), hi.begin(), hi.end());
+              w1h.insert(w1h.end(), lo.begin(), lo.end());
+            }
+        }
+        s->w1h_all = dev_upload(w1h);
+        s->w1isc_all = dev_upload(isc);
+      }
       s->cmask_all = dev_upload(cmask_all);
       s->h_kstride = (NS + 63) & ~(size_t)63;
       s->h_stride = s->h_kstride * JAMUN_HROWS;

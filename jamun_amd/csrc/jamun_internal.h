@@ -294,9 +294,10 @@ void launch_radius_graph(const float* pos, const int* ptr, int n_graphs, float r
 void launch_geom(float* y, const int* ptr, int n_graphs, float c_in, float r2, int S, const int* bip,
                  const int* bis, int mean_center, float* yc, int* deg, int* esrc, float4* egeo, const LangevinPre& pre,
                  hipStream_t st);
+// (w1h / isc_all non-null: the f16x3 kernel k_edge_h16 — W1's radial part as scaled hi + lo A fragments [layer][2][2][2][64], 2^-(14 + sW) per layer)
 void launch_edge_h(const int* deg, const int* esrc, const float4* egeo, int n_atoms, int S, const float* w1r_all,
                    const float* cmask_all, int n_layers, const float* mu, float step, float* h_all, size_t h_layer_stride,
-                   size_t h_kstride, hipStream_t st);
+                   size_t h_kstride, hipStream_t st, const float4* w1h = nullptr, const float* isc_all = nullptr);
 int launch_conv(const ConvArgs& a, int rc, int nt, hipStream_t st);
 int conv_set_max_lds();
 int launch_conv_fused(const FusedArgs& a, int grid, hipStream_t st);

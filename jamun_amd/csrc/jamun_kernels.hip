@@ -208,12 +208,97 @@ __global__ __launch_bounds__(256) void k_edge_h(const int* __restrict__ deg, con
     for (int q = 0; q < 16; ++q) {
       const int k = 32 * mt + (q & 3) + 8 * (q >> 2) + 4 * hh;
       const float pre = acc[q];
-      const float hv = pre / (1.f + expf(-pre));
+      // SiLU with the hardware exponential and reciprocal (v_exp_f32 / v_rcp_f32: ~1 ulp each; expf and the IEEE division were 2/3 of
+      // this kernel's vector instructions: 62 -> see DESIGN.md 3.2)
+      const float hv = pre * __frcp_rn(1.f + __expf(-pre));
       if (valid) h[(size_t)k * h_kstride] = hv;
     }
     if (mt == 1 && valid && hh == 0) h[(size_t)64 * h_kstride] = 1.f;  // bias row of the second radial-MLP layer
 #pragma unroll
     for (int s = 0; s < 16; ++s) av[s] = an[s];
+  }
+}
+
+// The same product as f16x3 (three v_mfma_f32_32x32x16_f16 per K-step of 16 basis functions instead of eight v_mfma_f32_32x32x2_f32:
+// 192 matrix cycles per (layer, k-tile) instead of 1024 — the fp32 MFMAs were most of this kernel).  The Gaussian basis values
+// (<= 1 / 1.12) are scaled by 2^14 and split hi + lo in the lane that computes them; W1's radial part is scaled by 2^sW per layer and
+// split on the host (w1h: [layer][k-tile][K-step][hi, lo][64 lanes] A fragments: lane (k, hh), halves p <-> basis 16 s2 + 8 hh + p);
+// the bias (c_mask) joins after the accumulator is scaled back (isc[layer] = 2^-(14 + sW)).
+typedef _Float16 eh_h8 __attribute__((ext_vector_type(8)));
+__global__ __launch_bounds__(256) void k_edge_h16(const int* __restrict__ deg, const int* __restrict__ esrc,
+                                                  const float4* __restrict__ egeo, int n_atoms, int S,
+                                                  const float4* __restrict__ w1h, const float* __restrict__ isc_all,
+                                                  const float* __restrict__ cmask_all,  // [layers][2][64]
+                                                  int n_layers, const float* __restrict__ mu, float step,
+                                                  float* __restrict__ h_all, size_t h_layer_stride, size_t h_kstride) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int e_l = lane & 31, hh = lane >> 5;
+  const long n_slots = (long)n_atoms * S;
+  const long slot = ((long)blockIdx.x * 4 + wave) * 32 + e_l;
+  const int i = slot < n_slots ? (int)(slot / S) : 0;
+  const int t = (int)(slot - (long)i * S);
+  const bool valid = slot < n_slots && t < deg[i];
+  if (__ballot(valid) == 0) return;  // wave-uniform: no edge in these 32 slots
+  float d = 0.f;
+  int bonded = 0;
+  if (valid) {
+    d = egeo[slot].w;
+    bonded = esrc[slot] < 0 ? 1 : 0;
+  }
+  float4 Rh[2], Rl[2];  // B fragments: lane (slot, hh), halves p <-> basis 16 s2 + 8 hh + p
+#pragma unroll
+  for (int s2 = 0; s2 < 2; ++s2) {
+    unsigned ph[4], pl[4];
+#pragma unroll
+    for (int p2 = 0; p2 < 4; ++p2) {
+      float v[2];
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const float diff = FSUB(d, mu[16 * s2 + 8 * hh + 2 * p2 + e]) / step;
+        v[e] = (expf(-FMUL(diff, diff)) / 1.12f) * 16384.f;
+      }
+      asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(ph[p2]) : "v"(v[0]), "v"(v[1]));
+      float r0, r1;
+      asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r0) : "v"(ph[p2]), "v"(v[0]));
+      asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r1) : "v"(ph[p2]), "v"(v[1]));
+      asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(pl[p2]) : "v"(r0), "v"(r1));
+    }
+    Rh[s2] = make_float4(__uint_as_float(ph[0]), __uint_as_float(ph[1]), __uint_as_float(ph[2]), __uint_as_float(ph[3]));
+    Rl[s2] = make_float4(__uint_as_float(pl[0]), __uint_as_float(pl[1]), __uint_as_float(pl[2]), __uint_as_float(pl[3]));
+  }
+  const int l_per = (n_layers + gridDim.y - 1) / gridDim.y, l_begin = blockIdx.y * l_per;
+  const int l_end = l_begin + l_per < n_layers ? l_begin + l_per : n_layers;
+  float4 av[4], an[4];  // (s2, hi / lo)
+#pragma unroll
+  for (int b = 0; b < 4; ++b) av[b] = w1h[((size_t)(2 * l_begin) * 4 + b) * 64 + lane];
+  const int n_jobs = 2 * l_end;
+  for (int j = 2 * l_begin; j < n_jobs; ++j) {
+    const int l = j >> 1, mt = j & 1;
+    const int jn = j + 1 < n_jobs ? j + 1 : j;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) an[b] = w1h[((size_t)jn * 4 + b) * 64 + lane];
+    const float* __restrict__ c = cmask_all + (size_t)l * 128 + bonded * 64 + 4 * hh;  // c_mask[mask of this lane's slot][k]
+    const float isc = isc_all[l];
+    float* __restrict__ h = h_all + (size_t)l * h_layer_stride + slot;
+    eh_f32x16 acc;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc[q] = 0.f;
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(eh_h8, av[2 * s2 + 1]), __builtin_bit_cast(eh_h8, Rh[s2]), acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(eh_h8, av[2 * s2]), __builtin_bit_cast(eh_h8, Rl[s2]), acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(eh_h8, av[2 * s2]), __builtin_bit_cast(eh_h8, Rh[s2]), acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int k = 32 * mt + (q & 3) + 8 * (q >> 2) + 4 * hh;
+      const float pre = fmaf(acc[q], isc, c[32 * mt + (q & 3) + 8 * (q >> 2)]);
+      const float hv = pre * __frcp_rn(1.f + __expf(-pre));
+      if (valid) h[(size_t)k * h_kstride] = hv;
+    }
+    if (mt == 1 && valid && hh == 0) h[(size_t)64 * h_kstride] = 1.f;  // bias row of the second radial-MLP layer
+#pragma unroll
+    for (int b = 0; b < 4; ++b) av[b] = an[b];
   }
 }
 
@@ -756,9 +841,14 @@ void launch_geom(float* y, const int* ptr, int n_graphs, float c_in, float r2, i
 }
 void launch_edge_h(const int* deg, const int* esrc, const float4* egeo, int n_atoms, int S, const float* w1r_all,
                    const float* cmask_all, int n_layers, const float* mu, float step, float* h_all, size_t h_layer_stride,
-                   size_t h_kstride, hipStream_t st) {
+                   size_t h_kstride, hipStream_t st, const float4* w1h, const float* isc_all) {
   const long tiles = ((long)n_atoms * S + 31) / 32;
   const int groups = n_layers >= 6 ? 3 : (n_layers >= 2 ? 2 : 1);
+  if (w1h) {
+    hipLaunchKernelGGL(k_edge_h16, dim3((unsigned)((tiles + 3) / 4), groups), dim3(256), 0, st, deg, esrc, egeo, n_atoms, S, w1h, isc_all,
+                       cmask_all, n_layers, mu, step, h_all, h_layer_stride, h_kstride);
+    return;
+  }
   hipLaunchKernelGGL(k_edge_h, dim3((unsigned)((tiles + 3) / 4), groups), dim3(256), 0, st, deg, esrc, egeo, n_atoms, S, w1r_all,
                      cmask_all, n_layers, mu, step, h_all, h_layer_stride, h_kstride);
 }
