@@ -79,8 +79,9 @@ def gather_ragged(block: Optional[torch.Tensor], dst: int = 0, group=None, devic
     ``dst`` and ``None`` elsewhere.  Mismatching trailing shapes raise on EVERY rank (before any payload moves), so no
     rank is left waiting in a collective."""
     rank, world = rank_world()
-    if world == 1:
+    if world == 1 and not (dist.is_available() and dist.is_initialized()):
         return [block] if block is not None and block.shape[0] > 0 else []
+    # (a one-rank group that IS initialised — torchrun --nproc-per-node 1 — runs the same metadata exchange as N ranks)
     backend = dist.get_backend(group)
     if device is None:
         # nccl (RCCL) moves device memory only: a CPU block (e.g. a trajectory kept on the host by cpu_offload) is staged on
@@ -142,7 +143,7 @@ def gather_ragged(block: Optional[torch.Tensor], dst: int = 0, group=None, devic
 def broadcast_object(obj, src: int = 0):
     """``obj`` of rank ``src`` on every rank (small Python objects: index lists)."""
     rank, world = rank_world()
-    if world == 1 or not (dist.is_available() and dist.is_initialized()):
+    if not (dist.is_available() and dist.is_initialized()):
         return obj
     box = [obj if rank == src else None]
     dist.broadcast_object_list(box, src=src, device=local_device() if dist.get_backend() == "nccl" else None)

@@ -41,3 +41,71 @@ def test_jamun_sample_cfg1_end_to_end(tmp_path, monkeypatch):
     with pytest.raises(RuntimeError, match="no CPU path"):
         cmdline.main(["--config-dir=" + os.path.join(ROOT, "configs"), "experiment=sample_custom", f"++init_pdbs=[{pdb_path}]",
                       f"++checkpoint_dir={ck_dir}", "checkpoint_type=best_so_far", "num_sampling_steps_per_batch=3", "++trainer.accelerator=cpu"])
+
+
+_RCCL_WORKER = r'''
+import os, sys, json
+sys.path.insert(0, sys.argv[1])
+import numpy as np, torch
+import torch.distributed as td
+from jamun_amd import dist, synth
+from jamun_amd.callbacks import SaveTrajectoryCallback
+from jamun_amd.data import WalkerBatch
+from jamun_amd.model import Denoiser
+from jamun_amd.sampling import BAOAB, Sampler, SingleMeasurementSampler
+torch.cuda.set_device(0)
+td.init_process_group("nccl", init_method="tcp://127.0.0.1:" + sys.argv[3], rank=0, world_size=1)
+assert td.get_backend() == "nccl" and dist.rank_world() == (0, 1)
+dev = dist.local_device()
+# the collectives of the gather path on RCCL: device metadata all-gather, a CPU block staged on the GPU, an empty rank, the
+# object broadcast and the barrier with a named device
+got = dist.gather_ragged(torch.full((3, 2, 3), 7.0, device=dev))
+assert len(got) == 1 and got[0].is_cuda and float(got[0].mean()) == 7.0
+got = dist.gather_ragged(torch.ones(2, 3))  # cpu_offload keeps trajectories on the host
+assert len(got) == 1 and got[0].is_cuda
+assert dist.gather_ragged(None) == []
+assert dist.broadcast_object([3, 1, 2]) == [3, 1, 2]
+dist.barrier()
+try:
+    dist.gather_ragged(torch.zeros(2, 3, dtype=torch.float16, device=dev))
+    raise SystemExit("expected ValueError")
+except ValueError as e:
+    assert "dtype" in str(e)
+# Sampler.sample(shard_walkers=True) with the real denoiser inside the initialised group -> files
+mol = synth.random_chain(9, seed=3)
+class DS:
+    molecule = dict(mol)
+    def label(self): return "m"
+model = Denoiser.from_checkpoint_dict(synth.synthetic_checkpoint(output_gain=0.05))
+batch = WalkerBatch.from_molecules([mol] * 3, labels=["m"] * 3)
+out_dir = os.path.join(sys.argv[2], "sampler")
+cb = SaveTrajectoryCallback([DS()], output_dir=out_dir, write_pdb=False)
+bs = SingleMeasurementSampler(mcmc=BAOAB(delta=0.04, friction=1.0, steps=6, save_trajectory=True), sigma=0.04)
+Sampler(callbacks=[cb], shard_walkers=True).sample(model=model, batch_sampler=bs, num_batches=2, init_graphs=batch, continue_chain=True)
+dist.barrier()
+j = np.load(os.path.join(out_dir, "m", "predicted_samples", "npy", "joined.npy"))
+assert j.shape == (9, 3 * 2 * 6, 3) and np.isfinite(j).all(), j.shape
+print(json.dumps({"ok": True}))
+td.destroy_process_group()
+'''
+
+
+def test_sharded_sampler_inside_an_rccl_group(tmp_path):
+    """The N > 1 plumbing on the backend the GPUs use: a one-rank RCCL ("nccl") group — a 1-GPU box cannot host two ranks,
+    RCCL refuses two ranks on one device — runs the metadata all-gather, the host-block staging, the object broadcast, the
+    device-named barrier and Sampler.sample(shard_walkers=True) through to the written files.  (The two-rank logic is covered on
+    gloo in tests/test_host.py.)"""
+    import socket
+    import subprocess
+    import sys
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    script = tmp_path / "rccl_worker.py"
+    script.write_text(_RCCL_WORKER)
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, str(script), ROOT, str(tmp_path), str(port)], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])["ok"], r.stdout[-1000:]
