@@ -559,33 +559,38 @@ __global__ __launch_bounds__(MF_THREADS) void k_conv_mf(MfArgs a) {
           for (int p = 0; p < RD; ++p) RB[p] = wload(c0 + p * 1024);
         }
         LDS_BARRIER();  // x rows, C(k0), T(k0) complete
+        // The barrier of a step sits right after this wave's LAST read of the step's coefficient tile (end of forming), not at the end
+        // of its work: split and contraction need registers only and run past it, next to the scalar waves' start of the next step
+        // (whose first fragment reads would otherwise leave the matrix pipe idle).  The barrier still orders both hazards: the
+        // builders arrive with C(k + 1) complete, every reader arrives after its last read of C(k).
+        constexpr int QD = SPD == 64 ? 2 : 3;  // fragment sets in flight (edge strides above 32: register allocation of the kernel is at its limit)
+        auto fr = [&](int st, int cb) { const int m = st >> 2, s4 = st & 3; return ldf(MF_X1H + (m * 32) * MF_ROWB + fo + 32 * s4, MF_X1L - MF_X1H, cb + (1 + m) * 2 * MF_PL + 32 * s4); };
+        Frag fq[QD];
+#pragma unroll
+        for (int st = 0; st < QD - 1; ++st) fq[st] = fr(st, MF_C + fo);
         for (int it = 0; it < nk; ++it) {
           const int cur = wstream(k_of(it)), nxt = wstream(k_of(it + 1));
-          const int cb = MF_C + (it & 1) * MF_CB + fo;
+          const int cb = MF_C + (it & 1) * MF_CB + fo, cbn = MF_C + ((it + 1) & 1) * MF_CB + fo;
           MSTAMP(0);
           MSTAMP(1);
           float4 Ah[2], Al[2];
-          {
-            auto fr = [&](int st) { const int m = st >> 2, s4 = st & 3; return ldf(MF_X1H + (m * 32) * MF_ROWB + fo + 32 * s4, MF_X1L - MF_X1H, cb + (1 + m) * 2 * MF_PL + 32 * s4); };
-            f32x16 F = zero16;
-            constexpr int QD = SPD == 64 ? 2 : 3;  // fragment sets in flight (edge strides above 32: register allocation of the kernel is at its limit)
-            Frag fq[QD];
+          f32x16 F = zero16;
 #pragma unroll
-            for (int st = 0; st < QD - 1; ++st) fq[st] = fr(st);
-#pragma unroll
-            for (int st = 0; st < 12; ++st) {
-              if (st + QD - 1 < 12) fq[(st + QD - 1) % QD] = fr(st + QD - 1);
-              MF_SCHED();
-              mm(F, fq[st % QD]);
-              MF_SCHED();
-            }
-            MSTAMP(2);
-            split(F, Ah, Al);
+          for (int st = 0; st < 12; ++st) {
+            if (st + QD - 1 < 12) fq[(st + QD - 1) % QD] = fr(st + QD - 1, cb);
+            MF_SCHED();
+            mm(F, fq[st % QD]);
+            MF_SCHED();
           }
+          MSTAMP(2);
+          LDS_BARRIER();
+#pragma unroll
+          for (int st = 0; st < QD - 1; ++st) fq[st] = fr(st, cbn);  // (first reads of the next step; unused after the last)
+          MF_SCHED();
+          split(F, Ah, Al);
           MSTAMP(3);
           contract(Ah, Al, cur, nxt);
           MSTAMP(4);
-          LDS_BARRIER();
           MSTAMP(5);
 #ifdef MF_TRACE
           ++trc;
@@ -614,27 +619,29 @@ __global__ __launch_bounds__(MF_THREADS) void k_conv_mf(MfArgs a) {
         for (int p = 0; p < R; ++p) RB[p] = wload(c0 + p * 1024);
       }
       LDS_BARRIER();  // x rows, C(k0), T(k0) complete
+      // steps 0..3 x1[m] C[1] | 4..7 x1[m+1] C[v_(m+2)] | 8..11 x1[m+2] C[v_(m+1)] ((x1 x v)[m] = x1[m+1] v[m+2] - x1[m+2] v[m+1]) |
+      // 12..15 the T term: out_m[i][w'] += sum_j C[v_m][i][j] T_k[j][w'] (A = coefficient rows, B = T^T rows; own accumulator: scale 2^(sC + sT))
+      auto fr = [&](int st, int cb, int tb) {
+        const int g = st >> 2, s4 = 32 * (st & 3);
+        if (g == 0) return ldf(x1a + m * 32 * MF_ROWB + s4, MF_X1L - MF_X1H, cb + s4);
+        if (g == 1) return ldf(x1a + m1 * 32 * MF_ROWB + s4, MF_X1L - MF_X1H, cb + (1 + m2) * 2 * MF_PL + s4);
+        if (g == 2) return ldf(x1a + m2 * 32 * MF_ROWB + s4, MF_X1L - MF_X1H, cb + (1 + m1) * 2 * MF_PL + s4);
+        return ldf(cb + (1 + m) * 2 * MF_PL + s4, MF_PL, tb + s4);
+      };
+      // (the step's barrier sits after the T term — this wave's last read of the step's tiles — and the contraction, registers only,
+      // runs past it with the first fragments of the next step already requested: see wave 4)
+      Frag fq[3];
+      fq[0] = fr(0, MF_C + fo, MF_TT + fo); fq[1] = fr(1, MF_C + fo, MF_TT + fo);
       for (int it = 0; it < nk; ++it) {
         const int cur = wstream(k_of(it)), nxt = wstream(k_of(it + 1));
-        const int cb = MF_C + (it & 1) * MF_CB + fo;
-        const int tb = MF_TT + (it & 1) * MF_TTB + fo;
+        const int cb = MF_C + (it & 1) * MF_CB + fo, cbn = MF_C + ((it + 1) & 1) * MF_CB + fo;
+        const int tb = MF_TT + (it & 1) * MF_TTB + fo, tbn = MF_TT + ((it + 1) & 1) * MF_TTB + fo;
         MSTAMP(0);
         MSTAMP(1);
-        // steps 0..3 x1[m] C[1] | 4..7 x1[m+1] C[v_(m+2)] | 8..11 x1[m+2] C[v_(m+1)] ((x1 x v)[m] = x1[m+1] v[m+2] - x1[m+2] v[m+1]) |
-        // 12..15 the T term: out_m[i][w'] += sum_j C[v_m][i][j] T_k[j][w'] (A = coefficient rows, B = T^T rows; own accumulator: scale 2^(sC + sT))
-        auto fr = [&](int st) {
-          const int g = st >> 2, s4 = 32 * (st & 3);
-          if (g == 0) return ldf(x1a + m * 32 * MF_ROWB + s4, MF_X1L - MF_X1H, cb + s4);
-          if (g == 1) return ldf(x1a + m1 * 32 * MF_ROWB + s4, MF_X1L - MF_X1H, cb + (1 + m2) * 2 * MF_PL + s4);
-          if (g == 2) return ldf(x1a + m2 * 32 * MF_ROWB + s4, MF_X1L - MF_X1H, cb + (1 + m1) * 2 * MF_PL + s4);
-          return ldf(cb + (1 + m) * 2 * MF_PL + s4, MF_PL, tb + s4);
-        };
         f32x16 FA = zero16, F1 = zero16, F2 = zero16;
-        Frag fq[3];
-        fq[0] = fr(0); fq[1] = fr(1);
 #pragma unroll
         for (int st = 0; st < 12; ++st) {
-          fq[(st + 2) % 3] = fr(st + 2);
+          fq[(st + 2) % 3] = fr(st + 2, cb, tb);
           MF_SCHED();
           mm(st < 4 ? FA : st < 8 ? F1 : F2, fq[st % 3]);
           MF_SCHED();
@@ -661,7 +668,7 @@ __global__ __launch_bounds__(MF_THREADS) void k_conv_mf(MfArgs a) {
         };
 #pragma unroll
         for (int st = 12; st < 16; ++st) {
-          if (st + 2 < 16) fq[(st + 2) % 3] = fr(st + 2);
+          if (st + 2 < 16) fq[(st + 2) % 3] = fr(st + 2, cb, tb);
           MF_SCHED();
           const Frag& f = fq[st % 3];
           const int e = 4 * (st - 12);  // pairs e .. e + 3 ride on this step's three MFMAs (1 + 1 + 2)
@@ -680,6 +687,9 @@ __global__ __launch_bounds__(MF_THREADS) void k_conv_mf(MfArgs a) {
           MF_SCHED();
         }
         MSTAMP(3);
+        LDS_BARRIER();
+        fq[0] = fr(0, cbn, tbn); fq[1] = fr(1, cbn, tbn);  // (unused after the last step)
+        MF_SCHED();
         auto f4 = [](const unsigned (&v)[4]) { return make_float4(__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3])); };
 #pragma unroll
         for (int g = 0; g < 4; ++g) {  // x1 inputs (blocks 0..3), then cross inputs (4..7): (hi, lo) per K-step
@@ -693,7 +703,6 @@ __global__ __launch_bounds__(MF_THREADS) void k_conv_mf(MfArgs a) {
           }
         }
         MSTAMP(4);
-        LDS_BARRIER();
         MSTAMP(5);
 #ifdef MF_TRACE
         ++trc;
