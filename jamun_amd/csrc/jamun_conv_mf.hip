@@ -67,8 +67,11 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 #ifdef MF_TRACE  // per-wave timeline of workgroup 7 (diagnostic builds): [wave][k-step][stamp]
 __device__ unsigned long long g_mftrace[8][40][8];
 #define MSTAMP(slot) do { if (blockIdx.x == 7 && trc < 40) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); g_mftrace[wave][trc][slot] = t_; } } while (0)
+__device__ unsigned long long g_mfseg[8][4][8];  // [wave][segment][stamp]: segment prologue / epilogue
+#define SSTAMP(slot) do { if (blockIdx.x == 7 && sgi < 4) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); g_mfseg[wave][sgi][slot] = t_; } } while (0)
 #else
 #define MSTAMP(slot) do { } while (0)
+#define SSTAMP(slot) do { } while (0)
 #endif
 
 namespace {
@@ -173,61 +176,12 @@ __global__ __launch_bounds__(MF_THREADS) void k_conv_mf(MfArgs a) {
     const int n0 = RFL(t_at.x), n_dst = RFL(t_at.y);
     const int s_lo = RFL(span.x), rows = RFL(span.y) - s_lo;
     const int s_base = s_lo & ~1, off = s_lo - s_base;  // window of 64 source rows from an even atom (8-byte T loads)
+    SSTAMP(0);
 
-    // ---- segment prologue (all threads): zero the coefficient tiles, stage the span's rows transposed and split
-    for (int idx = tid; idx < 2 * MF_CB / 16; idx += MF_THREADS) reinterpret_cast<float4*>(lds + MF_C)[idx] = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (tid < 144) {  // channel rows 120..127 of the scalar block (inputs of the last K-step that do not exist)
-      const int pl = tid / 72, q = tid - pl * 72;
-      *reinterpret_cast<float4*>(lds + (pl ? MF_X0L : MF_X0H) + 120 * MF_ROWB + 16 * q) = make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-    if (tid < 32) deg_lds[tid] = (tid < n_dst) ? a.deg[n0 + tid] : 0;
-    if (tid == 0) *xmax_lds = 0u;
-    float4 va[4], vb[4];
-    float mx = 0.f;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {  // item = (pair of source rows jp, float4 column c4): 32 x 54 items
-      const int it = tid + MF_THREADS * q, c4 = it >> 5, jp = it & 31;
-      const int j0 = 2 * jp - off, j1 = j0 + 1;  // rows relative to the span
-      va[q] = vb[q] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (c4 < 54) {
-        if (j0 >= 0 && j0 < rows) va[q] = *reinterpret_cast<const float4*>(a.x + (size_t)(s_lo + j0) * a.XS + 4 * c4);
-        if (j1 >= 0 && j1 < rows) vb[q] = *reinterpret_cast<const float4*>(a.x + (size_t)(s_lo + j1) * a.XS + 4 * c4);
-      }
-      mx = fmaxf(mx, fmaxf(fmaxf(fabsf(va[q].x), fabsf(va[q].y)), fmaxf(fabsf(va[q].z), fabsf(va[q].w))));
-      mx = fmaxf(mx, fmaxf(fmaxf(fabsf(vb[q].x), fabsf(vb[q].y)), fmaxf(fabsf(vb[q].z), fabsf(vb[q].w))));
-    }
-    LDS_BARRIER();  // xmax zeroed (and the previous segment's staging tile read)
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
-    if (lane == 0) atomicMax(xmax_lds, __float_as_uint(mx));
-    LDS_BARRIER();
-    const float xm = __uint_as_float(*xmax_lds);
-    const int sX = RFL(xm > 0.f ? clamp40(14 - exp_above(xm)) : 0);
-    {
-      const float scx = pow2f(sX);
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int it = tid + MF_THREADS * q, c4 = it >> 5, jp = it & 31;
-        if (c4 < 54) {
-          const float ea[4] = {va[q].x, va[q].y, va[q].z, va[q].w}, eb[4] = {vb[q].x, vb[q].y, vb[q].z, vb[q].w};
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const int f = 4 * c4 + e;
-            int rowb;  // byte offset of the channel's hi row
-            if (f < 120) rowb = MF_X0H + f * MF_ROWB;
-            else { const int e1 = f - 120, u = e1 / 3, m = e1 - 3 * u; rowb = MF_X1H + (m * 32 + u) * MF_ROWB; }
-            const int lo_off = f < 120 ? (MF_X0L - MF_X0H) : (MF_X1L - MF_X1H);
-            const float a0 = ea[e] * scx, b0 = eb[e] * scx;
-            const unsigned ph = cvt_pk_f16(a0, b0), pl = cvt_pk_f16(resid_lo(a0, ph), resid_hi(b0, ph));
-            *reinterpret_cast<unsigned*>(lds + rowb + 4 * jp) = ph;
-            *reinterpret_cast<unsigned*>(lds + rowb + lo_off + 4 * jp) = pl;
-          }
-        }
-      }
-    }
-
-    const int r = lane & 31, hh = lane >> 5;
-
+    // (in-degrees of the tile: the FIRST load of the segment, stored after the first barrier — waiting for it before that barrier
+    // would wait for every load issued in front of it, i.e. hold all eight waves for a global round trip)
+    int dgv = 0;
+    if (tid < 32 && tid < n_dst) dgv = a.deg[n0 + tid];
     // ---- builder lanes (waves 0..3, the lighter matrix role): their share of the coefficient-tile entries (edge slots) and of the T
     // tile.  Edge strides up to 32: four passes of 8 destinations x 32 slots; above: eight passes of 4 destinations x 64 slots (a
     // destination's slots stay within one wave: the pair bookkeeping uses ballots and shuffles)
@@ -258,19 +212,100 @@ __global__ __launch_bounds__(MF_THREADS) void k_conv_mf(MfArgs a) {
         tv[q] = *reinterpret_cast<const float2*>(tk + (size_t)wp * a.t_stride + 2 * jp);
       }
     };
-    load_k(k_of(0));  // (first of all: its round trip hides behind the edge records)
+    load_k(k_of(0));
     float evx[NP], evy[NP], evz[NP];
     int sjv[NP];
 #pragma unroll
-    for (int p = 0; p < NP; ++p) {  // (all passes' edge records requested before the first is looked at: one round trip, not NP)
+    for (int p = 0; p < NP; ++p) {  // (all passes' edge records requested at once, and before the rows are staged: their round trip hides behind that)
       const int g = (tid & (BT - 1)) + BT * p, i = g / SPD, t = g % SPD;
       const int slot = (n0 + i) * a.S + t;
-      const bool in = builder && t < deg_lds[i] && t < a.S;
+      const bool in = builder && i < n_dst && t < a.S;  // (the in-degree is applied below: slots past it hold stale records)
       sjv[p] = in ? a.esrc[slot] : 0;
       float4 ge = make_float4(0.f, 0.f, 0.f, 0.f);
       if (in) ge = a.egeo[slot];
       evx[p] = ge.x; evy[p] = ge.y; evz[p] = ge.z;
     }
+
+    // ---- segment prologue (all threads): zero the coefficient tiles, stage the span's rows transposed and split
+    for (int idx = tid; idx < 2 * MF_CB / 16; idx += MF_THREADS) reinterpret_cast<float4*>(lds + MF_C)[idx] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (tid < 144) {  // channel rows 120..127 of the scalar block (inputs of the last K-step that do not exist)
+      const int pl = tid / 72, q = tid - pl * 72;
+      *reinterpret_cast<float4*>(lds + (pl ? MF_X0L : MF_X0H) + 120 * MF_ROWB + 16 * q) = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    if (tid == 0) *xmax_lds = 0u;
+    // The span's rows are loaded, scaled, split and stored transposed by waves 4..7 alone (seven float4 columns of a row pair per lane)
+    // WHILE waves 0..3 — their SIMD partners — examine the edge records and build the first hidden unit's tiles: both are vector work
+    // of a few hundred instructions per lane that used to run one after the other on all eight waves.
+    constexpr int NXQ = 7;  // 32 row pairs x 54 float4 columns over 256 lanes
+    float4 va[NXQ], vb[NXQ];
+    float mx = 0.f;
+    const bool stager = wave >= 4;
+    const int xt = tid - 256;
+#pragma unroll
+    for (int q = 0; q < NXQ; ++q) va[q] = vb[q] = make_float4(0.f, 0.f, 0.f, 0.f);  // (defined on every path: no value carried around the segment loop)
+    // lane = (row pair jp, float4 column c40 + 8 q): the two row pointers and their predicates do not depend on q — one address pair, the
+    // columns by immediate offsets
+    const int xjp = xt & 31, xc40 = (xt >> 5) & 7;
+    {
+      const int j0 = 2 * xjp - off, j1 = j0 + 1;  // rows relative to the span
+      const bool in0 = stager && j0 >= 0 && j0 < rows, in1 = stager && j1 >= 0 && j1 < rows;
+      const float4* __restrict__ pa = reinterpret_cast<const float4*>(a.x + (size_t)(s_lo + j0) * a.XS) + xc40;
+      const float4* __restrict__ pb = reinterpret_cast<const float4*>(a.x + (size_t)(s_lo + j1) * a.XS) + xc40;
+      if (in0) {
+#pragma unroll
+        for (int q = 0; q < NXQ - 1; ++q) va[q] = pa[8 * q];
+        if (xc40 < 6) va[NXQ - 1] = pa[8 * (NXQ - 1)];  // (columns 48..53)
+      }
+      if (in1) {
+#pragma unroll
+        for (int q = 0; q < NXQ - 1; ++q) vb[q] = pb[8 * q];
+        if (xc40 < 6) vb[NXQ - 1] = pb[8 * (NXQ - 1)];
+      }
+    }
+    SSTAMP(1);
+    LDS_BARRIER();  // tiles zeroed, xmax = 0 (and the previous segment's staging tile read)
+    if (tid < 32) deg_lds[tid] = dgv;
+    if (stager) {
+#pragma unroll
+      for (int q = 0; q < NXQ; ++q) {
+        mx = fmaxf(mx, fmaxf(fmaxf(fabsf(va[q].x), fabsf(va[q].y)), fmaxf(fabsf(va[q].z), fabsf(va[q].w))));
+        mx = fmaxf(mx, fmaxf(fmaxf(fabsf(vb[q].x), fabsf(vb[q].y)), fmaxf(fabsf(vb[q].z), fabsf(vb[q].w))));
+      }
+#pragma unroll
+      for (int o = 32; o >= 1; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+      if (lane == 0) atomicMax(xmax_lds, __float_as_uint(mx));
+    }
+    LDS_BARRIER();
+    const float xm = __uint_as_float(*xmax_lds);
+    const int sX = RFL(xm > 0.f ? clamp40(14 - exp_above(xm)) : 0);
+    if (stager) {
+      const float scx = pow2f(sX);
+#pragma unroll
+      for (int q = 0; q < NXQ; ++q) {
+        const int c4 = xc40 + 8 * q, jp = xjp;
+        if (c4 < 54) {
+          const float ea[4] = {va[q].x, va[q].y, va[q].z, va[q].w}, eb[4] = {vb[q].x, vb[q].y, vb[q].z, vb[q].w};
+          // byte offsets of the four channels' hi rows: float4 columns below 30 are scalar channels (q < 3: always, q > 3: never,
+          // q = 3: per wave), the others vector elements 3 u + m -> row (m, u); the division is done once per column
+          const bool sc4 = q < 3 || (q == 3 && c4 < 30);
+          const int e1 = 4 * c4 - 120, u0 = e1 / 3, m0 = e1 - 3 * u0;
+          const int lo_off = sc4 ? (MF_X0L - MF_X0H) : (MF_X1L - MF_X1H);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int mm_ = m0 + e, wr = mm_ >= 3 ? 1 : 0;
+            const int rowb = sc4 ? MF_X0H + (4 * c4 + e) * MF_ROWB : MF_X1H + ((mm_ - 3 * wr) * 32 + u0 + wr) * MF_ROWB;
+            const float a0 = ea[e] * scx, b0 = eb[e] * scx;
+            const unsigned ph = cvt_pk_f16(a0, b0), pl = cvt_pk_f16(resid_lo(a0, ph), resid_hi(b0, ph));
+            *reinterpret_cast<unsigned*>(lds + rowb + 4 * jp) = ph;
+            *reinterpret_cast<unsigned*>(lds + rowb + lo_off + 4 * jp) = pl;
+          }
+        }
+      }
+    }
+
+    const int r = lane & 31, hh = lane >> 5;
+    SSTAMP(2);
+
 #pragma unroll
     for (int p = 0; p < NP; ++p) {
       const int g = (tid & (BT - 1)) + BT * p, i = g / SPD, t = g % SPD;
@@ -306,6 +341,7 @@ __global__ __launch_bounds__(MF_THREADS) void k_conv_mf(MfArgs a) {
       }
       ent[p] = active ? (i * MF_ROWB + 2 * jl) | (d0 << 13) | (d1 << 19) : 128;
     }
+    SSTAMP(3);
     const float scC = pow2f(a.sC), scT = pow2f(clamp100(sX + a.sTw));
     auto coef = [&](int p) {  // h~ of pass p's entry: this lane's edge + the pair's other edges
       const int d0 = (ent[p] >> 13) & 63, d1 = (ent[p] >> 19) & 63;
@@ -432,6 +468,7 @@ __global__ __launch_bounds__(MF_THREADS) void k_conv_mf(MfArgs a) {
           for (int p = 0; p < R; ++p) RB[p] = wload(c0 + p * 1024);
         }
         LDS_BARRIER();  // x rows, C(k0), T(k0) complete
+        SSTAMP(4);
         const int xa = MF_X0H + 32 * w * MF_ROWB + fo;
         for (int it = 0; it < nk; ++it) {
           const int cur = wstream(k_of(it)), nxt = wstream(k_of(it + 1));
@@ -559,6 +596,7 @@ __global__ __launch_bounds__(MF_THREADS) void k_conv_mf(MfArgs a) {
           for (int p = 0; p < RD; ++p) RB[p] = wload(c0 + p * 1024);
         }
         LDS_BARRIER();  // x rows, C(k0), T(k0) complete
+        SSTAMP(4);
         // The barrier of a step sits right after this wave's LAST read of the step's coefficient tile (end of forming), not at the end
         // of its work: split and contraction need registers only and run past it, next to the scalar waves' start of the next step
         // (whose first fragment reads would otherwise leave the matrix pipe idle).  The barrier still orders both hazards: the
@@ -597,13 +635,13 @@ __global__ __launch_bounds__(MF_THREADS) void k_conv_mf(MfArgs a) {
 #endif
         }
       }
+      SSTAMP(5);
       float* __restrict__ ST0 = reinterpret_cast<float*>(lds);  // [5 waves][32][160] partial scalar-output tiles (every tile of the segment is dead)
 #pragma unroll
-      for (int q = 0; q < 16; ++q) {
+      for (int q = 0; q < 16; ++q) {  // (raw accumulators: the power-of-two factors i1, i2 are applied to the SUM of the five partial tiles below)
         const int row = (q & 3) + 8 * (q >> 2) + 4 * hh;
-        const float i2 = i2_of(row);
 #pragma unroll
-        for (int n = 0; n < 5; ++n) ST0[(w * 32 + row) * 160 + 32 * n + r] = (accS[n][q] * i1) * i2;
+        for (int n = 0; n < 5; ++n) ST0[(w * 32 + row) * 160 + 32 * n + r] = accS[n][q];
       }
     } else {
       // ---- plane waves: 8 weight blocks per k (x1 inputs, cross inputs: (hi, lo) per K-step), ring of 4
@@ -619,6 +657,7 @@ __global__ __launch_bounds__(MF_THREADS) void k_conv_mf(MfArgs a) {
         for (int p = 0; p < R; ++p) RB[p] = wload(c0 + p * 1024);
       }
       LDS_BARRIER();  // x rows, C(k0), T(k0) complete
+        SSTAMP(4);
       // steps 0..3 x1[m] C[1] | 4..7 x1[m+1] C[v_(m+2)] | 8..11 x1[m+2] C[v_(m+1)] ((x1 x v)[m] = x1[m+1] v[m+2] - x1[m+2] v[m+1]) |
       // 12..15 the T term: out_m[i][w'] += sum_j C[v_m][i][j] T_k[j][w'] (A = coefficient rows, B = T^T rows; own accumulator: scale 2^(sC + sT))
       auto fr = [&](int st, int cb, int tb) {
@@ -708,17 +747,20 @@ __global__ __launch_bounds__(MF_THREADS) void k_conv_mf(MfArgs a) {
         ++trc;
 #endif
       }
-      float* __restrict__ ST1 = reinterpret_cast<float*>(lds + 5 * 32 * 160 * 4);  // [32][96] vector planes
+      SSTAMP(5);
+      float* __restrict__ ST1 = reinterpret_cast<float*>(lds + 5 * 32 * 160 * 4);  // [2][32][96] vector planes: contraction, T term (raw)
 #pragma unroll
       for (int q = 0; q < 16; ++q) {
         const int row = (q & 3) + 8 * (q >> 2) + 4 * hh;
-        ST1[row * 96 + m * 32 + r] = (accP[q] * i1) * i2_of(row) + (accT[q] * i1) * iT2;
+        ST1[row * 96 + m * 32 + r] = accP[q];
+        ST1[3072 + row * 96 + m * 32 + r] = accT[q];
       }
     }
     // ---- all threads: sum of the five K-partial tiles -> partial slab of this segment, coalesced 16-byte stores
     sg0 = nsg0; sg1 = nsg1;
     if (RFL(sg0.x) >= 0) { t_at = ld_const(a.tile_atoms + RFL(sg0.x)); span = ld_const(a.tile_span + RFL(sg0.x)); }
     LDS_BARRIER();
+    SSTAMP(6);
     {
       const float* __restrict__ ST0 = reinterpret_cast<const float*>(lds);
       const float* __restrict__ ST1 = reinterpret_cast<const float*>(lds + 5 * 32 * 160 * 4);
@@ -730,16 +772,22 @@ __global__ __launch_bounds__(MF_THREADS) void k_conv_mf(MfArgs a) {
         const float4 a0 = *reinterpret_cast<const float4*>(q0), a1 = *reinterpret_cast<const float4*>(q0 + 5120),
                      a2 = *reinterpret_cast<const float4*>(q0 + 10240), a3 = *reinterpret_cast<const float4*>(q0 + 15360),
                      a4 = *reinterpret_cast<const float4*>(q0 + 20480);
-        const float4 v = make_float4((((a0.x + a1.x) + a2.x) + a3.x) + a4.x, (((a0.y + a1.y) + a2.y) + a3.y) + a4.y,
-                                     (((a0.z + a1.z) + a2.z) + a3.z) + a4.z, (((a0.w + a1.w) + a2.w) + a3.w) + a4.w);
+        const float i2 = i2_of(row);
+        const float4 v = make_float4((((((a0.x + a1.x) + a2.x) + a3.x) + a4.x) * i1) * i2, (((((a0.y + a1.y) + a2.y) + a3.y) + a4.y) * i1) * i2,
+                                     (((((a0.z + a1.z) + a2.z) + a3.z) + a4.z) * i1) * i2, (((((a0.w + a1.w) + a2.w) + a3.w) + a4.w) * i1) * i2);
         if (row < n_dst) *reinterpret_cast<float4*>(p0 + row * 160 + 4 * c4) = v;
       }
       for (int idx = tid; idx < 32 * 24; idx += MF_THREADS) {
         const int row = idx / 24, c4 = idx - row * 24;
-        if (row < n_dst) *reinterpret_cast<float4*>(p1 + row * 96 + 4 * c4) = *reinterpret_cast<const float4*>(ST1 + row * 96 + 4 * c4);
+        const float i2 = i2_of(row);
+        const float4 c = *reinterpret_cast<const float4*>(ST1 + row * 96 + 4 * c4), t = *reinterpret_cast<const float4*>(ST1 + 3072 + row * 96 + 4 * c4);
+        const float4 v = make_float4((c.x * i1) * i2 + (t.x * i1) * iT2, (c.y * i1) * i2 + (t.y * i1) * iT2, (c.z * i1) * i2 + (t.z * i1) * iT2,
+                                     (c.w * i1) * i2 + (t.w * i1) * iT2);
+        if (row < n_dst) *reinterpret_cast<float4*>(p1 + row * 96 + 4 * c4) = v;
       }
     }
     LDS_BARRIER();  // the next segment rewrites the tiles
+    SSTAMP(7);
   }
 }
 
@@ -971,6 +1019,16 @@ void conv_mf_print_stamps() {
     for (int w = 0; w < 8; ++w) {
       fprintf(stderr, "  step %2d wave %d:", st, w);
       for (int i = 0; i < 6; ++i) fprintf(stderr, " %7lld", (long long)(tr[w][st][i] - t0));
+      fprintf(stderr, "\n");
+    }
+  static unsigned long long sg[8][4][8];
+  if (hipMemcpyFromSymbol(sg, HIP_SYMBOL(g_mfseg), sizeof(sg)) != hipSuccess) return;
+  fprintf(stderr, "segments: start / loads issued, tiles zeroed (before the first barrier) / rows staged (waves 4..7) / edges examined (waves 0..3) / loop entered / loop left / tiles staged / slab stored\n");
+  for (int q = 0; q < 4; ++q)
+    for (int w = 0; w < 8; ++w) {
+      if (sg[w][q][0] == 0) continue;
+      fprintf(stderr, "  seg %d wave %d:", q, w);
+      for (int i = 0; i < 8; ++i) fprintf(stderr, " %7lld", (long long)(sg[w][q][i] - t0));
       fprintf(stderr, "\n");
     }
 #endif
