@@ -19,6 +19,7 @@ typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 
 #define NH_T 512
 #define NH_S 3  // partial slabs fetched at once (more are summed in a loop)
+#define NH_W 8  // K-steps of weight blocks in flight per wave (the first NH_W are requested before phase 1)
 #define MFMA32H(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8, (a)), __builtin_bit_cast(h8, (b)), (c), 0, 0, 0)
 #define RFL(v) __builtin_amdgcn_readfirstlane(v)
 
@@ -89,6 +90,19 @@ __global__ __launch_bounds__(NH_T) void k_node_update_h(NodeArgs a) {
   const size_t slab0 = (size_t)a.n_pad * w0, slab1 = (size_t)a.n_pad * 96;
   const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
 
+  // this wave's job of phase 2: scalar-output tile `job` (32 columns, K0h / 16 steps) or vector plane job - nts (K1h / 16 steps)
+  const int nts = (a.mul0 + 31) >> 5, nst0 = a.K0h >> 4, nst1 = a.K1h >> 4;
+  const int job = wave;
+  const bool has_job = job < nts + 3, scalar_j = job < nts;
+  const int nst_j = scalar_j ? nst0 : nst1;
+  const float4* __restrict__ wp_j = (scalar_j ? a.wh0 + (size_t)job * nst0 * 128 : a.wh1) + lane;
+  const int r_j = lane & 31, hh_j = lane >> 5;
+  const int col_j = scalar_j ? job * 32 + r_j : r_j;                  // output channel within the irrep block
+  const bool col_ok_j = has_job && (scalar_j ? col_j < a.mul0 : col_j < a.mul1);
+  const int o_j = scalar_j ? col_j : a.mul0 + 3 * col_j + (job - nts);  // column of x_out
+  float4 wh[NH_W], wl[NH_W];
+  float xo[16];
+
   // ---- loads: scalar rows (<= 40 pieces of 16 bytes per atom and slab), vector rows (24), input features (<= 56); the first NH_S
   // slabs of everything are in flight together, summation order stays s = 0, 1, 2, ...
   float4 ms[3], mv[2], xv[4];
@@ -115,6 +129,19 @@ __global__ __launch_bounds__(NH_T) void k_node_update_h(NodeArgs a) {
       xv[q] = (ok && 4 * j < a.XSin) ? *reinterpret_cast<const float4*>(a.x_in + (size_t)i * a.XSin + 4 * j) : z4;
     }
     // (the loads above do not wait for this atom's slab count: slab indices are clamped to the batch's maximum, results masked here)
+    // phase 2's operands that do not depend on phase 1 — the first NH_W K-steps of this wave's weight blocks and the x_old values of its
+    // output tile — are requested now, behind the slab loads: their round trips run during phase 1 instead of after its barrier
+#pragma unroll
+    for (int t = 0; t < NH_W; ++t) {
+      const int sw = t < nst_j ? t : nst_j - 1;
+      wh[t] = has_job ? wp_j[(2 * sw) * 64] : z4;
+      wl[t] = has_job ? wp_j[(2 * sw + 1) * 64] : z4;
+    }
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int rl = (q & 3) + 8 * (q >> 2) + 4 * hh_j, ii = n0 + rl;
+      xo[q] = (a.mix && col_ok_j && ii < a.n_atoms) ? a.x_in[(size_t)ii * a.XSin + o_j] : 0.f;
+    }
 #pragma unroll
     for (int q = 0; q < 3; ++q) {
       ms[q] = 0 < ns ? ls[0][q] : z4;
@@ -231,37 +258,28 @@ __global__ __launch_bounds__(NH_T) void k_node_update_h(NodeArgs a) {
   __syncthreads();
 
   // ---- phase 2: one job per wave: scalar-output tile (32 columns, K0h / 16 steps) or vector plane (K1h / 16 steps); weight blocks of
-  // 64 lanes x 8 halves, (hi, lo) per step, four steps in flight
+  // 64 lanes x 8 halves, (hi, lo) per step, NH_W steps in flight (the first NH_W requested before phase 1)
 #if defined(NH_EXP) && (NH_EXP & 1)
   if (a.mix) return;
 #endif
   const int XSo = a.mul0 + 3 * a.mul1;
-  const int nts = (a.mul0 + 31) >> 5, nst0 = a.K0h >> 4, nst1 = a.K1h >> 4;
-  const int r = lane & 31, hh = lane >> 5;
-  for (int job = wave; job < nts + 3; job += NH_T / 64) {
-    const bool scalar = job < nts;
-    const int nst = scalar ? nst0 : nst1;
-    const float4* __restrict__ wp = (scalar ? a.wh0 + (size_t)job * nst0 * 128 : a.wh1) + lane;
+  if (has_job) {
+    const bool scalar = scalar_j;
+    const int nst = nst_j, r = r_j, hh = hh_j;
+    const float4* __restrict__ wp = wp_j;
     const char* __restrict__ ap = (scalar ? A0 + r * RB0 : A1 + ((job - nts) * 32 + r) * RB1) + 16 * hh;
     const int lo = scalar ? L0 : L1;
     f32x16 acc;
 #pragma unroll
     for (int q = 0; q < 16; ++q) acc[q] = 0.f;
-    float4 wh[4], wl[4];
+    for (int s0 = 0; s0 < nst; s0 += NH_W) {
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      const int s = t < nst ? t : nst - 1;
-      wh[t] = wp[(2 * s) * 64];
-      wl[t] = wp[(2 * s + 1) * 64];
-    }
-    for (int s0 = 0; s0 < nst; s0 += 4) {
-#pragma unroll
-      for (int t = 0; t < 4; ++t) {
+      for (int t = 0; t < NH_W; ++t) {
         if (s0 + t < nst) {  // wave-uniform
           const float4 bh = wh[t], bl = wl[t];
-          if (s0 + t + 4 < nst) {
-            wh[t] = wp[(2 * (s0 + t + 4)) * 64];
-            wl[t] = wp[(2 * (s0 + t + 4) + 1) * 64];
+          if (s0 + t + NH_W < nst) {
+            wh[t] = wp[(2 * (s0 + t + NH_W)) * 64];
+            wl[t] = wp[(2 * (s0 + t + NH_W) + 1) * 64];
           }
           const float4 ah = *reinterpret_cast<const float4*>(ap + 32 * (s0 + t)), al = *reinterpret_cast<const float4*>(ap + lo + 32 * (s0 + t));
           acc = MFMA32H(al, bh, acc);
@@ -270,18 +288,15 @@ __global__ __launch_bounds__(NH_T) void k_node_update_h(NodeArgs a) {
         }
       }
     }
-    const int col = scalar ? job * 32 + r : r;                    // output channel within the irrep block
-    const bool col_ok = scalar ? col < a.mul0 : col < a.mul1;
-    const int o = scalar ? col : a.mul0 + 3 * col + (job - nts);  // column of x_out
-    const float mw = (a.mix && col_ok) ? a.mix[scalar ? col : a.mul0 + col] : 0.f;
+    const float mw = (a.mix && col_ok_j) ? a.mix[scalar ? col_j : a.mul0 + col_j] : 0.f;
     const float* __restrict__ isc = scalar ? isc0 : isc1;
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
       const int rl = (q & 3) + 8 * (q >> 2) + 4 * hh, ii = n0 + rl;
-      if (col_ok && ii < a.n_atoms) {
+      if (col_ok_j && ii < a.n_atoms) {
         float v = acc[q] * isc[rl];
-        if (a.mix) v = mw * a.x_in[(size_t)ii * a.XSin + o] + (1.f - mw) * v;  // hidden layers: XSin == XSo, x_in is x_old
-        a.x_out[(size_t)ii * XSo + o] = v;
+        if (a.mix) v = mw * xo[q] + (1.f - mw) * v;  // hidden layers: XSin == XSo, x_in is x_old
+        a.x_out[(size_t)ii * XSo + o_j] = v;
       }
     }
   }
@@ -291,7 +306,7 @@ size_t node_update_h_lds_bytes(const NodeArgs& a) {
   return (size_t)2 * 32 * (a.K0h * 2 + 16) + (size_t)2 * 96 * (a.K1h * 2 + 16) + sizeof(float) * (32 * 32 + 64);
 }
 bool node_update_h_supported(const NodeArgs& a) {
-  return a.wh0 != nullptr && a.wh1 != nullptr && a.nt0 <= 5 && a.nt1 == 1 && a.mul1 <= 32 && (a.mul0 & 3) == 0 && (a.in0 & 3) == 0 && (a.XSin & 3) == 0 &&
+  return ((a.mul0 + 31) >> 5) + 3 <= NH_T / 64 && a.wh0 != nullptr && a.wh1 != nullptr && a.nt0 <= 5 && a.nt1 == 1 && a.mul1 <= 32 && (a.mul0 & 3) == 0 && (a.in0 & 3) == 0 && (a.XSin & 3) == 0 &&
          a.XSin <= 256 && (a.K0h & 15) == 0 && (a.K1h & 15) == 0 && a.K0h >= a.mul0 + a.in0 && a.K1h >= a.mul1 + a.in1 &&
          ((a.K0h - a.mul0 - a.in0) & 3) == 0 && ((a.K1h - a.mul1 - a.in1) & 3) == 0 && node_update_h_lds_bytes(a) <= 64 * 1024;
 }
