@@ -510,7 +510,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(args.config, cfg1_exact=not args.no_cfg1_cpu)
         print(json.dumps(out), flush=True)
     if world > 1:
-        torch.distributed.barrier()
+        dist.barrier()  # (names the device under nccl)
         torch.distributed.destroy_process_group()
 
 
