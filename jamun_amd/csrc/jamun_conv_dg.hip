@@ -1385,6 +1385,7 @@ void conv_dg_print_stamps() {
 // The launch is sized to ONE wave per SIMD (1024 waves: k-groups = 1024 / row tiles).  Measured on MI355X, 4352 atoms:
 // 4352 short waves of ~2 hidden units 36 us; 2040 waves (two per SIMD) 38 us; 952 waves 27 us (standalone: profiles/microbench/tprod_bench.hip).
 #define TP_WAVES 4
+#define TP_LD 36  // floats per row of a wave's output staging tile (144 bytes: 16-byte aligned, rows 4 banks apart)
 __global__ __launch_bounds__(64 * TP_WAVES) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_tprod(
     const float* __restrict__ x, int XS, int n_atoms, int n_k, int kg, const float4* __restrict__ wt, float* __restrict__ T) {
   const int lane = threadIdx.x & 63, wave = RFL(threadIdx.x >> 6);
@@ -1494,6 +1495,13 @@ __global__ __launch_bounds__(64 * TP_WAVES) __attribute__((amdgpu_waves_per_eu(2
     for (int q = 0; q < 16; ++q) wv[q] = wk[q * 64 + lane];
   };
   load_w(w0, k_lo);
+  __shared__ float tp_tile[TP_WAVES][32 * TP_LD];
+  float* __restrict__ tt = tp_tile[wave];
+  auto stage = [&](const f32x16& acc) {  // row r of the tile <- this lane's four quads (columns 8 g4 + 4 hh ..), scaled
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4)
+      *reinterpret_cast<float4*>(tt + r * TP_LD + 8 * g4 + 4 * hh) = make_float4(acc[4 * g4] * isc, acc[4 * g4 + 1] * isc, acc[4 * g4 + 2] * isc, acc[4 * g4 + 3] * isc);
+  };
   auto step = [&](const float4 (&wv)[16], int k) {
     f32x16 acc;
 #pragma unroll
@@ -1508,10 +1516,13 @@ __global__ __launch_bounds__(64 * TP_WAVES) __attribute__((amdgpu_waves_per_eu(2
         acc = MFMA32H(xl[q], wv[2 * q], acc);
         acc = MFMA32H(xh[q], wv[2 * q], acc);
       }
-      float* __restrict__ tk = T + ((size_t)k * 32 + r) * t_stride + a0 + 4 * hh;
+      // lane (r, hh) holds 16-byte pieces of 32 different rows: through the wave's LDS tile, so that a store instruction writes eight
+      // whole 128-byte row segments (eight lanes per row) instead of 64 half sectors — the 36 MB of T were bound by the L2 request rate
+      stage(acc);
+      const int R = lane >> 3, c = lane & 7;
 #pragma unroll
-      for (int g4 = 0; g4 < 4; ++g4)
-        *reinterpret_cast<float4*>(tk + 8 * g4) = make_float4(acc[4 * g4] * isc, acc[4 * g4 + 1] * isc, acc[4 * g4 + 2] * isc, acc[4 * g4 + 3] * isc);
+      for (int j = 0; j < 4; ++j)
+        *reinterpret_cast<float4*>(T + ((size_t)k * 32 + 8 * j + R) * t_stride + a0 + 4 * c) = *reinterpret_cast<const float4*>(tt + (8 * j + R) * TP_LD + 4 * c);
       return;
     }
 #pragma unroll
@@ -1521,12 +1532,11 @@ __global__ __launch_bounds__(64 * TP_WAVES) __attribute__((amdgpu_waves_per_eu(2
       acc = MFMA32H(wv[2 * q], xh[q], acc);
     }
     float* __restrict__ tk = T + ((size_t)k * n_atoms + a0) * 32;
-    if (a0 + r < n_atoms) {
+    stage(acc);  // (accumulator register 4 g4 + i  <->  output channel 8 g4 + 4 hh + i of atom r: whole 128-byte atom rows per eight lanes)
+    const int R = lane >> 3, c = lane & 7;
 #pragma unroll
-      for (int g4 = 0; g4 < 4; ++g4)  // accumulator register 4 g4 + i  <->  output channel 8 g4 + 4 hh + i
-        *reinterpret_cast<float4*>(tk + r * 32 + 8 * g4 + 4 * hh) =
-            make_float4(acc[4 * g4] * isc, acc[4 * g4 + 1] * isc, acc[4 * g4 + 2] * isc, acc[4 * g4 + 3] * isc);
-    }
+    for (int j = 0; j < 4; ++j)
+      if (a0 + 8 * j + R < n_atoms) *reinterpret_cast<float4*>(tk + (8 * j + R) * 32 + 4 * c) = *reinterpret_cast<const float4*>(tt + (8 * j + R) * TP_LD + 4 * c);
   };
   for (int k = k_lo; k < k_hi; k += 2) {
     load_w(w1, k + 1);
