@@ -829,6 +829,35 @@ __global__ __launch_bounds__(MF_THREADS) void k_conv_mfi(MfiArgs a) {
     const int s_lo = RFL(span.x), rows = RFL(span.y) - s_lo;
     const int s_base = s_lo;
 
+    // ---- everything the builder needs from global memory is requested first (in-degrees, h~ of the first hidden unit, the edge records
+    // of all passes without the degree predicate — slots past it hold stale records and are masked below), so that these round trips
+    // and the selector's overlap instead of following one another
+    int dgv = 0;
+    if (tid < 32 && tid < n_dst) dgv = a.deg[n0 + tid];
+    constexpr int BT = MF_THREADS, DPP = BT / SPD, NP = 32 / DPP;
+    const int gsh = (SPD == 32) ? 32 * (lane >> 5) : 0;
+    int ent[NP];
+    const int slot0 = (n0 + tid / SPD) * a.S + tid % SPD, pstride = DPP * a.S;
+    float hv[NP];
+    // (every lane loads the h~ of its OWN slot; the owner of a coefficient entry fetches the pair's other edges by lane shuffle, as in k_conv_mf)
+    auto load_k = [&](int k) {
+      const float* __restrict__ hk = a.h + (size_t)k * a.h_kstride;
+#pragma unroll
+      for (int p = 0; p < NP; ++p) hv[p] = hk[slot0 + p * pstride];
+    };
+    load_k(k_of(0));
+    float evx[NP], evy[NP], evz[NP];
+    int sjv[NP];
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+      const int g = tid + BT * p, i = g / SPD, t = g % SPD;
+      const bool in = i < n_dst && t < a.S;
+      sjv[p] = in ? a.esrc[slot0 + p * pstride] : 0;
+      float4 ge = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (in) ge = a.egeo[slot0 + p * pstride];
+      evx[p] = ge.x; evy[p] = ge.y; evz[p] = ge.z;
+    }
+
     // ---- segment prologue: zero the coefficient tiles, the selector
     for (int idx = tid; idx < 2 * MF_CB / 16; idx += MF_THREADS) reinterpret_cast<float4*>(lds + I_C)[idx] = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int idx = tid; idx < UT * 32 * 32; idx += MF_THREADS) {  // (uid, pair of source rows)
@@ -837,25 +866,16 @@ __global__ __launch_bounds__(MF_THREADS) void k_conv_mfi(MfiArgs a) {
       const int u0 = j0 < rows ? a.atom_uid[s_lo + j0] : -1, u1 = j1 < rows ? a.atom_uid[s_lo + j1] : -1;
       *reinterpret_cast<unsigned*>(lds + I_S + uid * MF_ROWB + 4 * jp) = (u0 == uid ? 0x3c00u : 0u) | (u1 == uid ? 0x3c000000u : 0u);
     }
-    if (tid < 32) deg_lds[tid] = (tid < n_dst) ? a.deg[n0 + tid] : 0;
+    if (tid < 32) deg_lds[tid] = dgv;
     LDS_BARRIER();
 
     // ---- builder state (all eight waves): as k_conv_mf
-    constexpr int BT = MF_THREADS, DPP = BT / SPD, NP = 32 / DPP;
-    const int gsh = (SPD == 32) ? 32 * (lane >> 5) : 0;
-    int ent[NP];
-    const int slot0 = (n0 + tid / SPD) * a.S + tid % SPD, pstride = DPP * a.S;
-    float evx[NP], evy[NP], evz[NP];
-    bool any_tw = false;
 #pragma unroll
     for (int p = 0; p < NP; ++p) {
       const int g = tid + BT * p, i = g / SPD, t = g % SPD;
       const int dg = deg_lds[i];
-      const int slot = (n0 + i) * a.S + t;
       const bool in = t < dg && t < a.S;
-      const int sj = in ? a.esrc[slot] : 0;
-      float4 ge = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (in) ge = a.egeo[slot];
+      const int sj = sjv[p];
       const bool bonded = in && sj < 0;
       const int jraw = sj & 0x7fffffff, jl = jraw - s_base;
       const bool valid = in && jl >= 0 && jl < 64;
@@ -880,32 +900,19 @@ __global__ __launch_bounds__(MF_THREADS) void k_conv_mfi(MfiArgs a) {
           }
         }
       }
-      any_tw = any_tw || d0 > 0;
       ent[p] = active ? (i * MF_ROWB + 2 * jl) | (d0 << 13) | (d1 << 19) : 128;
-      evx[p] = ge.x; evy[p] = ge.y; evz[p] = ge.z;
     }
-    const bool wave_tw = __ballot(any_tw) != 0ull;
     const float scC = pow2f(a.sC);
-    float hv[NP], ht0[NP], ht1[NP];
-#pragma unroll
-    for (int p = 0; p < NP; ++p) ht0[p] = ht1[p] = 0.f;
-    auto load_k = [&](int k) {
-      const float* __restrict__ hk = a.h + (size_t)k * a.h_kstride;
-#pragma unroll
-      for (int p = 0; p < NP; ++p) hv[p] = hk[slot0 + p * pstride];
-      if (wave_tw) {
-#pragma unroll
-        for (int p = 0; p < NP; ++p) {
-          ht0[p] = hk[slot0 + p * pstride + ((ent[p] >> 13) & 63)];
-          ht1[p] = hk[slot0 + p * pstride + ((ent[p] >> 19) & 63)];
-        }
-      }
+    auto coef = [&](int p) {  // h~ of pass p's entry: this lane's edge + the pair's other edges
+      const int d0 = (ent[p] >> 13) & 63, d1 = (ent[p] >> 19) & 63;
+      const float t0 = __shfl(hv[p], lane + d0, 64), t1 = __shfl(hv[p], lane + d1, 64);
+      return (hv[p] + (d0 ? t0 : 0.f)) + (d1 ? t1 : 0.f);
     };
     auto build = [&](int buf) {
       char* __restrict__ cbuf = lds + I_C + buf * MF_CB;
 #pragma unroll
       for (int p = 0; p < NP; ++p) {
-        const float c0 = ((hv[p] + ((ent[p] & (63 << 13)) ? ht0[p] : 0.f)) + ((ent[p] & (63 << 19)) ? ht1[p] : 0.f)) * scC, c1 = c0 * evx[p], c2 = c0 * evy[p], c3 = c0 * evz[p];
+        const float c0 = coef(p) * scC, c1 = c0 * evx[p], c2 = c0 * evy[p], c3 = c0 * evz[p];
         const unsigned h01 = cvt_pk_f16(c0, c1), h23 = cvt_pk_f16(c2, c3);
         const unsigned l01 = cvt_pk_f16(resid_lo(c0, h01), resid_hi(c1, h01)), l23 = cvt_pk_f16(resid_lo(c2, h23), resid_hi(c3, h23));
         char* __restrict__ d = cbuf + (ent[p] & 0x1fff);
@@ -935,7 +942,6 @@ __global__ __launch_bounds__(MF_THREADS) void k_conv_mfi(MfiArgs a) {
 #pragma unroll
     for (int q = 0; q < 16; ++q) acc[q] = 0.f;
     u32x4 RB[NBW];
-    load_k(k_of(0));
     build(0);
     load_k(k_of(1));
     __builtin_amdgcn_sched_barrier(0);
