@@ -1023,3 +1023,36 @@ def test_missing_tensor_and_bad_config_fail_loudly(dev, ckpt):
         model.score(batch, 0.04)
     with pytest.raises(RuntimeError):
         Denoiser.from_checkpoint_dict(ckpt).score(WalkerBatch.from_molecules(_mols("ag4")), 0.04)  # CPU tensors: no CPU path
+
+
+@pytest.mark.parametrize("shape", ["17x256", "33x128", "ragged"])
+def test_long_walks_are_bit_reproducible(dev, shape):
+    """Soak test against intermittent hazards of the hand-scheduled kernels (a spill store under a stale exec mask, packed FMAs beside
+    f16 MFMAs — both were met during development and showed up as ONE wrong row in about every second forward): the same walk of a
+    few hundred forwards, twice, from the same state and seed, must agree bit for bit in every saved frame."""
+    from jamun_amd import native, synth
+    from jamun_amd.data import WalkerBatch
+    from jamun_amd.model import Denoiser
+
+    if shape == "17x256":
+        mols, steps = [synth.random_chain(17, seed=0)] * 256, 300
+    elif shape == "33x128":
+        mols, steps = [synth.random_chain(33, seed=0)] * 128, 80
+    else:
+        mols, steps = [synth.random_chain(n, seed=n) for n in (17, 57, 23, 41, 30, 19, 52, 36)] * 16, 80
+    model = Denoiser.from_checkpoint_dict(synth.synthetic_checkpoint(output_gain=0.05)).to(dev)
+    batch = WalkerBatch.from_molecules(mols).to(dev)
+    smp = model.sampler_for(batch, 0.04)
+    assert smp.stats()["dg_mode"] == 4 and smp.stats()["init_path"] == (1 if shape == "ragged" else 3), smp.stats()  # (ragged: > 128 distinct embedding rows)
+    torch.manual_seed(0)
+    y0 = batch.pos + 0.04 * torch.randn_like(batch.pos)
+    params = native.make_mcmc_params(steps, delta=0.04, friction=1.0, M=1.0, inverse_temperature=1.0, score_fn_clip=100.0)
+    runs = []
+    for _ in range(2):
+        y, v = y0.clone(), torch.zeros_like(y0)
+        y_traj, score_traj, xhat_traj, _ = smp.walk("baoab", y, v, params, None, seed=77, save_trajectory=True)
+        torch.cuda.synchronize()
+        runs.append((xhat_traj.clone(), y_traj.clone(), score_traj.clone()))
+    assert torch.isfinite(runs[0][0]).all()
+    for a, b in zip(runs[0], runs[1]):
+        assert torch.equal(a, b)
