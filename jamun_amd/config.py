@@ -31,6 +31,7 @@ TARGET_ALIASES = {
     "jamun.sampling.mcmc.ABOBA": "jamun_amd.sampling.ABOBA",
     "jamun.data.create_dataset_from_pdbs": "jamun_amd.pdb.create_dataset_from_pdbs",
     "jamun.data.MDtrajDataset": "jamun_amd.pdb.MDtrajDataset",
+    "jamun.data.parse_datasets_from_directory": "jamun_amd.pdb.parse_datasets_from_directory",
     "jamun.callbacks.sampler.SaveTrajectoryCallback": "jamun_amd.callbacks.SaveTrajectoryCallback",
     "jamun.callbacks.sampler.MeasureSamplingTimeCallback": "jamun_amd.callbacks.MeasureSamplingTimeCallback",
     "jamun.callbacks.sampler.TrajectoryMetricCallback": "jamun_amd.callbacks.TrajectoryMetricCallback",

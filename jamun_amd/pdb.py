@@ -10,6 +10,7 @@ between selected atoms.  Coordinates are converted from Angstrom to nanometres (
 from __future__ import annotations
 
 import os
+import re
 from typing import Dict, List, Optional, Sequence, Tuple
 
 import torch
@@ -286,3 +287,60 @@ def create_dataset_from_pdbs(pdbfiles: Sequence[str], label_prefix: Optional[str
             label = f"{label_prefix}{label}"
         out.append(PDBDataset(os.path.dirname(p), os.path.basename(p), label))
     return out
+
+
+def parse_datasets_from_directory(root: str, traj_pattern: str, pdb_pattern: Optional[str] = None,
+                                  pdb_file: Optional[Sequence[str]] = None, max_datasets: Optional[int] = None,
+                                  max_datasets_offset: Optional[int] = None, filter_codes: Optional[Sequence[str]] = None,
+                                  as_iterable: bool = False, **dataset_kwargs) -> List[MDtrajDataset]:
+    """``jamun.data.parse_datasets_from_directory`` (``/root/reference/src/jamun/data/_utils.py:36-116``) — the
+    ``init_datasets._target_`` of the reference's ``sample_uncapped_2AA / 4AA / mdgen`` experiment files: one
+    ``MDtrajDataset`` per molecule code found under ``root``.
+
+    ``traj_pattern`` / ``pdb_pattern`` are ``<sub-directory>/<regular expression>``; the expression is matched (``re.match``:
+    anchored at the start) against the ENTRY NAMES of that directory and its group 1 is the code.  All trajectory files of a
+    code belong to its dataset; ``pdb_pattern`` picks the topology per code (entries whose code has no trajectory are
+    skipped), ``pdb_file`` is one topology shared by every code.  Then, in the reference's order: ``filter_codes``, sort,
+    ``max_datasets_offset``, ``max_datasets``.  ``dataset_kwargs`` (``subsample``, ``num_frames``, ``start_frame`` ...) go to
+    every dataset; label = code.  A code without a topology raises ``KeyError`` as the reference's dict lookup does.
+    ``as_iterable`` (the reference's streaming ``MDtrajIterableDataset``, a training feature) is out of scope: rejected."""
+    if pdb_file is not None and pdb_pattern is not None:
+        raise ValueError("Exactly one of pdb_file and pdb_pattern should be provided.")
+    if as_iterable:
+        raise NotImplementedError("as_iterable=True (MDtrajIterableDataset, a streaming training dataset) is out of scope")
+    traj_prefix, traj_name = os.path.split(traj_pattern)
+    if "*" in traj_prefix or "?" in traj_prefix:
+        raise ValueError("traj_prefix should not contain wildcards.")
+    traj_re = re.compile(traj_name)
+    traj_files: Dict[str, List[str]] = {}
+    for entry in os.scandir(os.path.join(root, traj_prefix)):
+        m = traj_re.match(entry.name)
+        if m:
+            traj_files.setdefault(m.group(1), []).append(os.path.join(traj_prefix, entry.name))
+    if not traj_files:
+        raise ValueError("No codes found in directory.")
+    pdb_files: Dict[str, object] = {}
+    if pdb_pattern is not None:
+        pdb_prefix, pdb_name = os.path.split(pdb_pattern)
+        if "*" in pdb_prefix or "?" in pdb_prefix:
+            raise ValueError("pdb_prefix should not contain wildcards.")
+        pdb_re = re.compile(pdb_name)
+        for entry in os.scandir(os.path.join(root, pdb_prefix)):
+            m = pdb_re.match(entry.name)
+            if m and m.group(1) in traj_files:
+                pdb_files[m.group(1)] = os.path.join(pdb_prefix, entry.name)
+    else:
+        pdb_files = {code: pdb_file for code in traj_files}
+    codes = list(traj_files)
+    if filter_codes is not None:
+        wanted = set(filter_codes)
+        codes = [c for c in codes if c in wanted]
+    codes = sorted(codes)
+    if max_datasets_offset is not None:
+        codes = codes[max_datasets_offset:]
+    if max_datasets is not None:
+        codes = codes[:max_datasets]
+    # os.scandir order is arbitrary; the reference keeps it (mdtraj concatenates the files in that order) — sorted here so that
+    # a code's frames do not depend on the file system
+    return [MDtrajDataset(root, trajfiles=sorted(traj_files[c]), pdbfile=pdb_files[c], label=c, **dataset_kwargs) for c in codes]
+

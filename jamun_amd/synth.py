@@ -115,6 +115,141 @@ def ag_dipeptide() -> dict:
     )
 
 
+AA_3CODES = {"A": "ALA", "R": "ARG", "N": "ASN", "D": "ASP", "C": "CYS", "E": "GLU", "Q": "GLN", "G": "GLY", "H": "HIS", "I": "ILE",
+             "L": "LEU", "K": "LYS", "M": "MET", "F": "PHE", "P": "PRO", "S": "SER", "T": "THR", "W": "TRP", "Y": "TYR", "V": "VAL"}  # residue_metadata.py:34-55
+
+
+def peptide(sequence: str, seed: int = 0, bond: float = 0.15, min_dist: float = 0.25) -> dict:
+    """Uncapped peptide of the one-letter ``sequence`` as a heavy-atom molecule dict with REAL topology — atom names, elements,
+    residue names, standard-residue bonds + peptide bonds + the C-terminal OXT, i.e. what ``pdb.read_pdb`` returns for a
+    Timewarp ``*-traj-state0.pdb`` after the hydrogens are dropped — and SYNTHETIC coordinates: atoms are grown along the bond
+    tree (self-avoiding, bond length 0.15 nm) and relaxed so that ring-closing bonds reach bond length and non-bonded pairs keep
+    ``min_dist``.  Dipeptides have 9 (GG) ... 29 (WW) atoms, the uncapped-2AA range of SURVEY.md section 8."""
+    from .data import encode_atom_code, encode_atom_type, encode_residue
+    from .pdb import _BACKBONE, _SIDECHAIN
+
+    names: List[str] = []
+    res: List[str] = []
+    res_idx: List[int] = []
+    pairs: List[tuple] = []
+    prev_c = None
+    for r, aa in enumerate(sequence):
+        rn = AA_3CODES[aa.upper()]
+        order = ["N", "CA", "C", "O"]
+        templ = _BACKBONE + _SIDECHAIN[rn]
+        for a, b in templ:
+            for x in (a, b):
+                if x not in order and not (x == "OXT" and r != len(sequence) - 1) and not (x == "CB" and rn == "GLY"):
+                    order.append(x)
+        if "OXT" in order:  # the terminal oxygen closes the residue, as tleap writes it
+            order.remove("OXT")
+            order.append("OXT")
+        base = len(names)
+        idx = {x: base + i for i, x in enumerate(order)}
+        names += order
+        res += [rn] * len(order)
+        res_idx += [r] * len(order)
+        if prev_c is not None:
+            pairs.append((prev_c, idx["N"]))
+        for a, b in templ:
+            if a in idx and b in idx:
+                pairs.append((min(idx[a], idx[b]), max(idx[a], idx[b])))
+        prev_c = idx["C"]
+    pairs = sorted(set(pairs))
+    n = len(names)
+    rng = np.random.RandomState(seed)
+    nbr = [[] for _ in range(n)]
+    for a, b in pairs:
+        nbr[a].append(b)
+        nbr[b].append(a)
+    pos = np.zeros((n, 3))
+    placed = [0]
+    seen = {0}
+    queue = [0]
+    while queue:  # breadth-first growth along the bond graph
+        p = queue.pop(0)
+        for c in nbr[p]:
+            if c in seen:
+                continue
+            thr = min_dist
+            for attempt in range(1, 20001):
+                d = rng.normal(size=3)
+                cand = pos[p] + bond * d / np.linalg.norm(d)
+                others = [j for j in placed if j != p]
+                if not others or np.min(np.linalg.norm(pos[others] - cand, axis=1)) >= thr:
+                    break
+                if attempt % 200 == 0:
+                    thr *= 0.95
+            pos[c] = cand
+            seen.add(c)
+            placed.append(c)
+            queue.append(c)
+    bonded = np.zeros((n, n), dtype=bool)
+    for a, b in pairs:
+        bonded[a, b] = bonded[b, a] = True
+    ia, ib = np.array([p[0] for p in pairs]), np.array([p[1] for p in pairs])
+    for _ in range(300):  # relaxation: bonds to their length (closes the rings), non-bonded pairs apart
+        d = pos[:, None] - pos[None]
+        r = np.linalg.norm(d, axis=-1) + np.eye(n)
+        push = np.where(~bonded & (r < min_dist) & ~np.eye(n, dtype=bool), (min_dist - r) / r, 0.0)
+        step = 0.25 * (push[..., None] * d).sum(1)
+        db = pos[ia] - pos[ib]
+        rb = np.linalg.norm(db, axis=-1, keepdims=True)
+        f = 0.25 * (bond - rb) / rb * db
+        np.add.at(step, ia, f)
+        np.add.at(step, ib, -f)
+        pos = pos + step
+    els = [x[0] for x in names]
+    return dict(
+        pos=torch.tensor(pos - pos.mean(0), dtype=torch.float32),
+        atom_type_index=torch.tensor([encode_atom_type(e) for e in els], dtype=torch.int32),
+        atom_code_index=torch.tensor([encode_atom_code(x) for x in names], dtype=torch.int32),
+        residue_code_index=torch.tensor([encode_residue(x) for x in res], dtype=torch.int32),
+        residue_sequence_index=torch.tensor(res_idx, dtype=torch.int32),
+        bonds=torch.tensor(pairs, dtype=torch.long).T.contiguous(),
+        atom_names=names, residues=res, elements=els, residue_ids=[i + 1 for i in res_idx], chain_index=[0] * n,
+    )
+
+
+def all_dipeptides() -> List[str]:
+    """The 400 two-letter codes in the alphabetical order of ``residue_metadata.py:34-55``'s one-letter keys."""
+    aa = sorted(AA_3CODES)
+    return [a + b for a in aa for b in aa]
+
+
+def write_timewarp_tree(root: str, codes: Sequence[str], n_frames: int = 3, seed: int = 0) -> Dict[str, dict]:
+    """A directory in the layout of Timewarp's ``2AA-1-large/test`` (what ``sample_uncapped_2AA.yaml:8-13`` points
+    ``parse_datasets_from_directory`` at): per code ``<code>-traj-state0.pdb`` — ALL atoms, one hydrogen after every backbone N
+    included, so the trajectory arrays carry more atoms than the model sees — and ``<code>-traj-arrays.npz`` with
+    ``positions [n_frames, all atoms, 3]`` in nm (frame t = the structure displaced by a seeded 0.01 nm jitter).  Returns
+    ``{code: heavy-atom molecule dict of frame 0}``."""
+    import os
+
+    os.makedirs(root, exist_ok=True)
+    out = {}
+    for ci, code in enumerate(codes):
+        mol = peptide(code, seed=seed + ci)
+        heavy = mol["pos"].double().numpy()
+        recs, xyz = [], []
+        for i, name in enumerate(mol["atom_names"]):
+            recs.append((name, mol["residues"][i], mol["residue_ids"][i], mol["elements"][i]))
+            xyz.append(heavy[i])
+            if name == "N":
+                recs.append(("H", mol["residues"][i], mol["residue_ids"][i], "H"))
+                xyz.append(heavy[i] + np.array([0.0, 0.0, 0.1]))
+        xyz = np.array(xyz)
+        rng = np.random.RandomState(1000 + seed + ci)
+        frames = np.stack([xyz + (0.01 * rng.normal(size=xyz.shape) if t else 0.0) for t in range(n_frames)]).astype(np.float32)
+        with open(os.path.join(root, f"{code}-traj-state0.pdb"), "w") as f:
+            for i, (name, rn, rid, el) in enumerate(recs):
+                x, y, z = (frames[0, i] * 10).tolist()
+                f.write(f"ATOM  {i + 1:5d} {name:<4s} {rn:>3s} A{rid:4d}    {x:8.3f}{y:8.3f}{z:8.3f}  1.00  0.00          {el:>2s}\n")
+            f.write("END\n")
+        np.savez(os.path.join(root, f"{code}-traj-arrays.npz"), positions=frames)
+        out[code] = mol
+    return out
+
+
 def _irreps_muls(s: str):
     m0 = m1 = 0
     for part in s.split("+"):

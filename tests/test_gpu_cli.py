@@ -43,6 +43,51 @@ def test_jamun_sample_cfg1_end_to_end(tmp_path, monkeypatch):
                       f"++checkpoint_dir={ck_dir}", "checkpoint_type=best_so_far", "num_sampling_steps_per_batch=3", "++trainer.accelerator=cpu"])
 
 
+def test_jamun_sample_uncapped_2aa_directory_end_to_end(tmp_path, monkeypatch):
+    """BASELINE.json configs[1] as the reference runs it (configs/experiment/sample_uncapped_2AA.yaml:8-19): init_datasets =
+    jamun.data.parse_datasets_from_directory over a Timewarp-style test directory, ONE walker per distinct dipeptide (ragged
+    9..29-atom batch), SaveTrajectory files per dataset label.  28 dipeptides covering all 20 residue types."""
+    from jamun_amd import cmdline, synth
+
+    codes = ["AG", "GG", "WW", "FY", "KR", "PH", "CM", "DE", "NQ", "ST", "IL", "VA", "RK", "HP", "MC", "ED", "QN", "TS", "LI", "YF",
+             "GW", "WA", "AV", "SG", "PP", "KE", "DR", "HH"]
+    root = tmp_path / "data" / "timewarp" / "2AA-1-large" / "test"
+    mols = synth.write_timewarp_tree(str(root), codes, n_frames=2)
+    assert len({a for c in codes for a in c}) == 20
+    ck_dir = tmp_path / "ckpt"
+    ck_dir.mkdir()
+    torch.save(synth.synthetic_checkpoint(output_gain=0.05), str(ck_dir / "epoch=3-step=10.ckpt"))
+    monkeypatch.chdir(tmp_path)
+    monkeypatch.setenv("JAMUN_ROOT_PATH", str(tmp_path))
+    monkeypatch.setenv("JAMUN_DATA_PATH", str(tmp_path / "data"))
+    args = ["--config-dir=" + os.path.join(ROOT, "configs"), "experiment=sample_timewarp_2AA", f"++checkpoint_dir={ck_dir}",
+            "num_sampling_steps_per_batch=12", "num_batches=2", "++sampler.rng=torch_cpu", "++init_datasets.num_frames=1"]
+    run_dir = cmdline.main(args)
+    sizes = {}
+    for c in codes:
+        d = os.path.join(run_dir, "sampler", c, "predicted_samples")
+        a = np.load(os.path.join(d, "npy", "0.npy"))
+        n = mols[c]["pos"].shape[0]
+        assert a.shape == (n, 12, 3) and np.isfinite(a).all(), (c, a.shape)
+        j = np.load(os.path.join(d, "npy", "joined.npy"))
+        assert j.shape == (n, 24, 3)
+        assert os.path.exists(os.path.join(d, "pdb", "joined.pdb")) and os.path.exists(os.path.join(d, "dcd", "joined.dcd"))
+        assert os.path.exists(os.path.join(run_dir, "sampler", c, "topology.pdb"))
+        sizes[c] = n
+        # the chain starts at the data frame + sigma * noise and stays near it on this contractive checkpoint
+        assert np.abs(a[:, 0] - mols[c]["pos"].numpy()).max() < 0.3
+    assert min(sizes.values()) == 9 and max(sizes.values()) == 29
+    t = json.load(open(os.path.join(run_dir, "sampler", "timing.json"))) if os.path.exists(os.path.join(run_dir, "sampler", "timing.json")) else None
+    assert t is None or t["batches"][0]["conformations"] == len(codes) * 12
+    # max_datasets (data/_utils.py:98-99) through the command line: the first three codes in sorted order, nothing else
+    run2 = cmdline.main(args + ["++init_datasets.max_datasets=3", "run_key=second"])
+    first = sorted(codes)[:3]
+    assert sorted(x for x in os.listdir(os.path.join(run2, "sampler")) if x != "timing.json") == first
+    for c in first:
+        b = np.load(os.path.join(run2, "sampler", c, "predicted_samples", "npy", "0.npy"))
+        assert b.shape == (sizes[c], 12, 3) and np.isfinite(b).all()
+
+
 _RCCL_WORKER = r'''
 import os, sys, json
 sys.path.insert(0, sys.argv[1])

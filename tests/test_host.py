@@ -738,3 +738,67 @@ def test_docs_cite_profile_files_that_exist():
                 if not glob.glob(os.path.join(ROOT, pat)):
                     missing.append(f"{doc}: {ref} ({pat})")
     assert not missing, missing
+
+
+def test_parse_datasets_from_directory(tmp_path):
+    """data/_utils.py:36-116 over a Timewarp-style tree (`<code>-traj-arrays.npz` + `<code>-traj-state0.pdb`): code = group 1 of
+    the anchored regular expression, datasets sorted by code, filter -> offset -> max in the reference's order, dataset kwargs
+    forwarded, topology per code (pdb_pattern) or shared (pdb_file), the reference's errors, and the Hydra target alias the
+    reference's own sample_uncapped_2AA / 4AA / mdgen experiment files use."""
+    import numpy as np
+
+    from jamun_amd import config as C
+    from jamun_amd import synth
+    from jamun_amd.pdb import parse_datasets_from_directory
+
+    root = tmp_path / "timewarp" / "2AA-1-large" / "test"
+    codes = ["WG", "AG", "KR", "GA", "FY"]
+    mols = synth.write_timewarp_tree(str(root), codes, n_frames=5)
+    (root / "notes.txt").write_text("not a trajectory")
+    (root / "ZZ-traj-state0.pdb").write_text((root / "AG-traj-state0.pdb").read_text())  # a topology without a trajectory: ignored
+    kw = dict(root=str(root), traj_pattern="^(.*)-traj-arrays.npz", pdb_pattern="^(.*)-traj-state0.pdb")
+    ds = parse_datasets_from_directory(**kw, subsample=2)
+    assert [d.label() for d in ds] == sorted(codes)
+    for d in ds:
+        m = mols[d.label()]
+        assert len(d) == 3  # frames 0, 2, 4
+        g = d[0]
+        assert g["dataset_label"] == d.label() and g["pos"].shape == m["pos"].shape  # hydrogens of the arrays dropped
+        assert torch.equal(g["atom_code_index"], m["atom_code_index"]) and torch.equal(g["residue_code_index"], m["residue_code_index"])
+        assert sorted(map(tuple, g["bonds"].T.tolist())) == sorted(map(tuple, m["bonds"].T.tolist()))  # template order vs sorted
+        assert torch.allclose(g["pos"], m["pos"], atol=1e-6)
+        arr = np.load(root / f"{d.label()}-traj-arrays.npz")["positions"]
+        assert arr.shape[1] == m["pos"].shape[0] + 2  # one H per residue
+    # filter, then sort, then offset, then max (data/_utils.py:91-99)
+    lab = lambda **k: [d.label() for d in parse_datasets_from_directory(**kw, **k)]
+    assert lab(filter_codes=["KR", "AG", "QQ"]) == ["AG", "KR"]
+    assert lab(max_datasets=2) == ["AG", "FY"]
+    assert lab(max_datasets_offset=3) == ["KR", "WG"]
+    assert lab(max_datasets_offset=1, max_datasets=2) == ["FY", "GA"]
+    assert lab(filter_codes=["WG", "GA", "AG"], max_datasets_offset=1, max_datasets=1) == ["GA"]
+    ds = parse_datasets_from_directory(**kw, num_frames=2, start_frame=1)
+    assert all(len(d) == 2 for d in ds)
+    # a shared topology (pdb_file) for every code; sub-directory prefixes in the patterns
+    sub = tmp_path / "tree"
+    (sub / "trajs").mkdir(parents=True)
+    (sub / "top").mkdir()
+    for c in ("AG", "AG2"):
+        np.savez(sub / "trajs" / f"{c}_sim.npz", positions=np.load(root / "AG-traj-arrays.npz")["positions"])
+    (sub / "top" / "shared.pdb").write_text((root / "AG-traj-state0.pdb").read_text())
+    ds = parse_datasets_from_directory(str(sub), "trajs/^(.*)_sim.npz", pdb_file="top/shared.pdb")
+    assert [d.label() for d in ds] == ["AG", "AG2"] and len(ds[1]) == 5
+    with pytest.raises(ValueError, match="Exactly one"):
+        parse_datasets_from_directory(str(sub), "trajs/^(.*)_sim.npz", pdb_pattern="top/^(.*).pdb", pdb_file="top/shared.pdb")
+    with pytest.raises(ValueError, match="wildcards"):
+        parse_datasets_from_directory(str(sub), "tr*/^(.*)_sim.npz", pdb_file="top/shared.pdb")
+    with pytest.raises(ValueError, match="No codes"):
+        parse_datasets_from_directory(str(sub), "top/^(.*)_sim.npz", pdb_file="top/shared.pdb")
+    with pytest.raises(KeyError):  # a code whose topology is missing (the reference's dict lookup)
+        parse_datasets_from_directory(str(sub), "trajs/^(.*)_sim.npz", pdb_pattern="top/^(AG2).pdb")
+    with pytest.raises(NotImplementedError):
+        parse_datasets_from_directory(**kw, as_iterable=True)
+    # the Hydra node of sample_uncapped_2AA.yaml:8-13 instantiates through the alias
+    node = {"_target_": "jamun.data.parse_datasets_from_directory", "root": str(root), "traj_pattern": "^(.*)-traj-arrays.npz",
+            "pdb_pattern": "^(.*)-traj-state0.pdb", "subsample": 1, "max_datasets": 3}
+    ds = C.instantiate(node)
+    assert [d.label() for d in ds] == ["AG", "FY", "GA"] and len(ds[0]) == 5
