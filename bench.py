@@ -21,9 +21,10 @@ the level of one fp32 rounding per product.  The reference's sam
 undefined, and the 1e-5 nm parity bar needs fp32-level accuracy.
 
 Timing: W untimed warm-up steps, then the K-step walk is timed R times back to back — each repeat bracketed by a barrier +
-torch.cuda.synchronize() on both sides and taken as the MAX over ranks — until >= ~2 s of timed work have accumulated
-(a 20-step walk lasts 50 ms, below what an external GPU-busy sampler resolves); ``ms_per_step`` and ``value`` are the
-MEDIAN repeat.  ``--repeats R`` fixes R.
+torch.cuda.synchronize() on both sides and taken as the MAX over ranks — until >= ~10 s of timed work have accumulated
+(a 20-step walk lasts 20 ms, below what an external GPU-busy sampler resolves); ``ms_per_step`` and ``value`` are the
+MEDIAN repeat.  ``--repeats R`` fixes R.  The CPU baseline (rank 0, N = 1) runs FIRST, so that the GPU legs are the tail of
+the run and an outside observer sampling GPU activity sees them.
 
 Multi-GPU: one process per GPU.  Either launch with ``python -m torch.distributed.run --nproc-per-node N bench.py --gpus N``
 or just ``python bench.py --gpus N``: without WORLD_SIZE in the environment the parent spawns the N ranks itself (before any
@@ -49,7 +50,7 @@ MCMC = dict(delta=0.04, friction=1.0, M=1.0, inverse_temperature=1.0, score_fn_c
 F32_MFMA_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
 F16_MFMA_PEAK_TFLOPS = 2500.0  # same guide, "Peak BF16/FP16 MFMA ~2.5 PF dense"
 HBM_PEAK_GBS = 8000.0         # same guide, "HBM3E peak BW" (spec; ~6.3 TB/s measured on a float4 copy)
-MIN_TIMED_S = 2.0
+MIN_TIMED_S = 10.0
 
 CONFIGS = {
     "cfg2": dict(baseline="configs[1]", desc="uncapped-2AA-like 17-atom molecule", atoms=17, walkers=256),
@@ -293,7 +294,7 @@ def main():
     ap.add_argument("--config", choices=sorted(CONFIGS), default="cfg2", help="workload (default: cfg2 = BASELINE configs[1], the metric's config)")
     ap.add_argument("--walkers", type=int, default=None, help="walkers per GPU (default: the config's)")
     ap.add_argument("--atoms", type=int, default=None, help="atoms per walker (default: the config's)")
-    ap.add_argument("--repeats", type=int, default=0, help="timed repeats of the K-step walk (default: until >= 2 s)")
+    ap.add_argument("--repeats", type=int, default=0, help="timed repeats of the K-step walk (default: until >= 10 s)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-cfg1-cpu", action="store_true", help="skip the exact configs[0] CPU run (~1 min) inside cpu_baseline")
     ap.add_argument("--no-secondary", action="store_true", help="skip the scatter-mean / Langevin-kernel bandwidth measurements")
@@ -337,6 +338,9 @@ def main():
     torch.cuda.set_device(dev)
 
     cfg = CONFIGS[args.config]
+    cpu_line = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu_line = cpu_baseline(args.config, cfg1_exact=not args.no_cfg1_cpu)  # before the GPU legs (see the module docstring)
     walkers = args.walkers if args.walkers is not None else cfg["walkers"]
     total_walkers = None
     if args.strong:  # north_star's "2048 parallel walkers" at every N: the total is fixed, each rank takes a contiguous share
@@ -359,7 +363,7 @@ def main():
         """profile: None (no events), "dominant" (events around the conv launches only), "all" (every kernel class)."""
         params = native.make_mcmc_params(steps, **MCMC)
         if profile == "dominant":
-            smp.profile_enable(True, classes=["conv0", "conv1"])
+            smp.profile_enable(True, classes=["conv0", "conv1", "tprod"])
         elif profile == "all":
             smp.profile_enable(True)
         return smp.walk("baoab", y, v, params, None, seed=1234 + rank, save_trajectory=True)
@@ -451,43 +455,56 @@ def main():
         if prof is not None:
             ms0, c0 = prof["conv0"]
             ms1, c1 = prof["conv1"]
-            avg0 = ms0 / max(c0, 1)
-            fused = c1 == 0  # fused kernel: scalar-row and vector-row contractions of a hidden layer in ONE launch
+            mst, ct = prof.get("tprod", (0.0, 0))
+            avg0 = ms0 / max(c0, 1)                 # the conv kernel alone (k_conv_mf / k_conv_dg): the launch rocprofv3 lists under that name
+            avg_pair = avg0 + mst / max(ct, 1)      # ... with the T pre-pass in front of it (k_tprod_h): one hidden layer's conv
+            fused = c1 == 0  # one launch covers the scalar-row and the vector-row contraction of a hidden layer
             flop = stats["conv0_flop_alg"] + (stats["conv1_flop_alg"] if fused else 0)
-            ach = flop / (avg0 * 1e-3) / 1e12 if avg0 > 0 else 0.0
-            out["roofline"] = {
-                "kernel": ("hidden-layer conv contraction, scalar + vector rows in one launch (destination-grouped; conv_path "
-                           f"{stats['conv_path']}, " + ("k_conv_mf: A operand formed on the matrix cores" if stats.get("dg_mode") == 4 else
-                                                         f"k_conv_dg mode {stats.get('dg_mode')}: A operand formed on the vector ALUs") + "; with its T pre-pass k_tprod)"
-                           if fused else "k_conv<RC=1,NT=5,NK=5> (scalar-output conv contraction, hidden layers)"),
-                "bound": "mfma",
-                "achieved": ach,
-                "peak": F32_MFMA_PEAK_TFLOPS,
-                "unit": "TFLOP/s",
-                "frac": ach / F32_MFMA_PEAK_TFLOPS,
-                "traffic": None,
-                "traffic_unit": "bytes per launch = 2 x FETCH_SIZE + WRITE_SIZE (gfx950 read correction of MI355X_MICROARCH.md)",
-                "avg_launch_ms": avg0,
-                "launches": c0,
-                "flop_per_launch": flop,
-                "mfma_flop_executed_per_forward": stats["flop_executed"],  # all conv launches of one forward, padding included
-            }
-            if stats.get("dg_emu", -1) == 1 and fused:
-                # f16x3: every fp32 product of the contraction is three v_mfma_f32_*_f16 (hi hi + hi lo + lo hi of operands split into
-                # two f16 terms, fp32 accumulate; error ~ one fp32 rounding per product).  `achieved` / `frac` stay the
-                # ALGORITHMIC fp32 FLOP rate against the fp32-MFMA peak (comparable with earlier rounds; it may exceed what
-                # v_mfma_f32_32x32x2_f32 could deliver); `frac_executed` prices the instructions actually issued against the f16 peak.
+            kname = ("k_conv_mf" if stats.get("dg_mode") == 4 else f"k_conv_dg<mode {stats.get('dg_mode')}>") if stats["conv_path"] == 2 else \
+                {1: "k_conv_fused"}.get(stats["conv_path"], "k_conv")
+            f16x3 = stats.get("dg_emu", -1) == 1 and fused and stats.get("conv_flop_exec_launch", 0) > 0
+            if f16x3 or (fused and stats.get("conv_flop_exec_launch", 0) > 0):
+                # The roof is the one of the instructions the kernel issues: dense f16 MFMA (2.5 PFLOP/s) for the f16x3 scheme — every
+                # fp32 product is three v_mfma_f32_32x32x16_f16 on operands split hi + lo, fp32 accumulate — or the
+                # fp32 MFMA roof for the v_mfma_f32_32x32x2_f32 variant.  achieved = FLOPs of the MFMA instructions ONE launch executes
+                # (jamun_stats.conv_flop_exec_launch = tiles x hidden units x MFMAs per (tile, unit) x 32768; reproducible as
+                # PMC SQ_INSTS_MFMA per dispatch x 32768) / the launch's mean duration from HIP events on the launch stream
+                peak = F16_MFMA_PEAK_TFLOPS if f16x3 else F32_MFMA_PEAK_TFLOPS
                 ex = stats["conv_flop_exec_launch"] / (avg0 * 1e-3) / 1e12 if avg0 > 0 else 0.0
-                out["roofline"].update({"mfma_scheme": "f16x3 (fp32 operands split hi+lo into f16, 3 MFMAs per product, fp32 accumulate)",
-                                        "executed": ex, "peak_executed": F16_MFMA_PEAK_TFLOPS, "frac_executed": ex / F16_MFMA_PEAK_TFLOPS,
-                                        "flop_executed_per_launch": stats["conv_flop_exec_launch"],
-                                        "note": "peak / frac: algorithmic fp32 FLOP against the fp32-MFMA roof (the roof of an fp32 implementation; a value above 1 "
-                                                "means the f16x3 path beats it); executed / frac_executed: the f16 MFMA instructions issued (forming on the "
-                                                "matrix cores included for k_conv_mf) against the dense f16 roof — the utilisation of the matrix pipe"})
-            elif fused and stats.get("conv_flop_exec_launch", 0) > 0:
-                ex = stats["conv_flop_exec_launch"] / (avg0 * 1e-3) / 1e12 if avg0 > 0 else 0.0
-                out["roofline"].update({"mfma_scheme": "v_mfma_f32_32x32x2_f32", "executed": ex, "peak_executed": F32_MFMA_PEAK_TFLOPS,
-                                        "frac_executed": ex / F32_MFMA_PEAK_TFLOPS, "flop_executed_per_launch": stats["conv_flop_exec_launch"]})
+                useful = stats.get("conv_flop_useful_launch", 0) / (avg0 * 1e-3) / 1e12 if avg0 > 0 else 0.0
+                out["roofline"] = {
+                    "kernel": f"{kname} (hidden-layer conv: destination-grouped tensor-product contraction, scalar + vector rows in one launch"
+                              + ("; A operand formed on the matrix cores" if stats.get("dg_mode") == 4 else "; A operand formed on the vector ALUs") + ")",
+                    "bound": "mfma",
+                    "mfma_dtype": "f16 (f16x3 emulation of fp32: operands split hi + lo, 3 MFMAs per product, fp32 accumulate)" if f16x3 else "f32",
+                    "achieved": ex,
+                    "peak": peak,
+                    "unit": "TFLOP/s",
+                    "frac": ex / peak,
+                    "traffic": None,
+                    "traffic_unit": "bytes per launch = 2 x FETCH_SIZE + WRITE_SIZE (gfx950 read correction of MI355X_MICROARCH.md)",
+                    "avg_launch_ms": avg0,
+                    "launches": c0,
+                    "flop_executed_per_launch": stats["conv_flop_exec_launch"],
+                    "flop_useful_per_launch": stats.get("conv_flop_useful_launch", 0),
+                    "frac_useful": useful / peak,
+                    "bytes_algorithmic_per_launch": stats.get("conv_bytes_alg_launch", 0),
+                    "frac_fp32_equiv": (flop / (avg_pair * 1e-3) / 1e12 / F32_MFMA_PEAK_TFLOPS) if avg_pair > 0 else 0.0,
+                    "flop_fp32_algorithmic_per_layer": flop,
+                    "avg_layer_ms_with_t_prepass": avg_pair,
+                    "note": "achieved / frac: MFMA FLOPs the launch EXECUTES (padding, structural zeros of the forming GEMMs, 3 products per fp32 product) "
+                            "against the dense peak of that MFMA dtype — at most 1 by construction; frac_useful: the part of them the "
+                            "destination-grouped association needs (no padding, no zero blocks), same time, same peak; frac_fp32_equiv: the "
+                            "layer's algorithmic fp32 FLOPs / (conv + T pre-pass time) against the 157.3 TFLOP/s fp32-MFMA roof (the figure "
+                            "earlier rounds reported as frac; can exceed 1)",
+                    "mfma_flop_executed_per_forward": stats["flop_executed"],
+                }
+            else:
+                ach = flop / (avg0 * 1e-3) / 1e12 if avg0 > 0 else 0.0
+                out["roofline"] = {"kernel": kname, "bound": "mfma", "mfma_dtype": "f32", "achieved": ach, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                   "frac": ach / F32_MFMA_PEAK_TFLOPS, "traffic": None, "avg_launch_ms": avg0, "launches": c0, "flop_per_launch": flop,
+                                   "traffic_unit": "bytes per launch = 2 x FETCH_SIZE + WRITE_SIZE (gfx950 read correction of MI355X_MICROARCH.md)",
+                                   "mfma_flop_executed_per_forward": stats["flop_executed"]}
             # HBM-side bytes per launch from the committed PMC passes of the cfg2 command (profiles/collect.sh); rocprofv3
             # cannot run inside the timed process, so the newest committed summary is quoted, with its file name
             if args.atoms is None and args.walkers is None and not args.strong:
@@ -496,6 +513,8 @@ def main():
                 if tr is not None:
                     out["roofline"]["traffic"] = tr[0]
                     out["roofline"]["traffic_source"] = tr[1]
+                    if out["roofline"].get("bytes_algorithmic_per_launch"):
+                        out["roofline"]["traffic_ratio"] = tr[0] / out["roofline"]["bytes_algorithmic_per_launch"]
             if prof_all is not None:  # separate untimed pass (see above)
                 tot = sum(ms for ms, _ in prof_all.values())
                 out["kernel_time_share"] = {k: round(ms / tot, 4) for k, (ms, _) in prof_all.items()} if tot > 0 else {}
@@ -506,8 +525,8 @@ def main():
         if not args.no_secondary and world == 1:
             del y_traj, score_traj, xhat_traj
             out["secondary_rooflines"] = secondary_rooflines(dev)
-        if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(args.config, cfg1_exact=not args.no_cfg1_cpu)
+        if cpu_line is not None:
+            out["cpu_baseline"] = cpu_line
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()  # (names the device under nccl)

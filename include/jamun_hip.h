@@ -176,16 +176,26 @@ int jamun_aboba_b(float* y_dev, float* v_dev, const float* score_dev, const floa
  * from positions ALREADY scaled by c_in (as E3Conv receives them, src/jamun/model/denoiser.py:198):
  *   sh_dev     [n_edges, 4]        o3.SphericalHarmonics("1x0e+1x1e", normalize=True, normalization="component") = [1, sqrt(3) v/|v|]
  *   radial_dev [n_edges, n_basis]  e3nn soft_one_hot_linspace(|v|, 0, radial_cutoff, n_basis, basis="gaussian", cutoff=True)
- * (the radial half of edge_attr; the bonded half is an embedding lookup).  src_dev / dst_dev: int64 device arrays (edge_index). */
-int jamun_edge_geometry(const float* pos_dev, const int64_t* src_dev, const int64_t* dst_dev, int32_t n_edges, float radial_cutoff,
-                        int32_t n_basis, float* sh_dev, float* radial_dev, void* stream);
+ * (the radial half of edge_attr; the bonded half is an embedding lookup).  src_dev / dst_dev: int64 device arrays (edge_index);
+ * pos_dev is [n_atoms, 3]: an edge with an index outside [0, n_atoms) reads nothing and gets NaN outputs. */
+int jamun_edge_geometry(const float* pos_dev, int32_t n_atoms, const int64_t* src_dev, const int64_t* dst_dev, int32_t n_edges,
+                        float radial_cutoff, int32_t n_basis, float* sh_dev, float* radial_dev, void* stream);
 
 /* e3nn o3.Linear on node features between irreps (in0 x0e + in1 x1e) and (out0 x0e + out1 x1e): the skip / self-interaction /
  * head Linears of the path (src/jamun/e3tools/nn/_interaction.py:23-24, _mlp.py:69,109).  w_dev: the flat e3nn weight
  * [in0 x out0 | in1 x out1] on the device (instruction order i_in outer, i_out inner; path normalisation 1/sqrt(fan_in) applied
  * here).  x_dev [n_atoms, in0 + 3 in1] -> out_dev [n_atoms, out0 + 3 out1], e3nn layout (channel-major, m fastest). */
 int jamun_node_linear(const float* x_dev, int32_t n_atoms, int32_t in0, int32_t in1, int32_t out0, int32_t out1, const float* w_dev,
-                      float* out_dev, void* stream);
+                      int64_t w_numel, float* out_dev, void* stream);
+
+/* The noise of the walks when noise_dev == NULL — the in-kernel replacement of the reference's per-step torch.randn_like
+ * (src/jamun/sampling/mcmc/functional/_splitting.py:161; iid N(0,1) per atom and component): out_dev [n, 3] = the draws R of
+ * integrator iteration `iteration` (1 .. steps-1) for atoms first_atom .. first_atom + n - 1 of a rank's batch under `seed`.
+ * Philox4x32-10 (Salmon et al., SC'11) with key = seed (low, high word), counter = (atom, iteration, 0x4a414d55, 0); the four
+ * output words w0..w3 give u_i = (float(w_i) + 0.5) * 2^-32, R = (sqrt(-2 ln u0) cos 2 pi u1, sqrt(-2 ln u0) sin 2 pi u1,
+ * sqrt(-2 ln u2) cos 2 pi u3) (Box-Muller).  jamun_walk_baoab / jamun_walk_aboba with noise_dev == NULL are bit-identical to the
+ * same walk fed these draws as noise_dev. */
+int jamun_philox_normal(float* out_dev, int32_t n, uint64_t seed, uint32_t iteration, uint32_t first_atom, void* stream);
 
 /* The graph half of a forward on its own: Denoiser.add_edges + the edge geometry + the radial MLPs' hidden layer
  * (src/jamun/model/denoiser.py:138-166, arch/e3conv.py:110-127, e3tools/nn/_conv.py:112) for positions y_dev [n_atoms,3]; the
@@ -219,15 +229,21 @@ typedef struct jamun_stats {
                              ~80 atoms), 2 single phase (spans up to ~52 atoms), 3 single phase with one Y tile (spans up to ~73 atoms);
                              -1: not in use */
   int32_t init_path;      /* initial projector: 3 k_conv_mfi (jamun_conv_mf.hip: coefficient sums per distinct embedding row formed on the
-                             matrix cores, contracted with the input-times-weight table; dg_mode 4 tiles, <= 32 distinct rows),
+                             matrix cores, contracted with the input-times-weight table; dg_mode 4 tiles, <= 128 distinct rows),
                              2 edge-by-edge VALU kernel on the tiles of jamun_conv_dg.hip (jamun_conv_initv.hip),
                              1 input-times-weight table applied with MFMAs (jamun_conv_init.hip), 0 the hidden layers' fused /
                              general kernel */
   int32_t dg_row_blocks;  /* jamun_conv_dg.hip: 1 when some molecule exceeds the span budget and its sources are cut into row blocks */
   int32_t dg_emu;         /* jamun_conv_dg.hip contraction: 1 f16x3 (three v_mfma_f32_*_f16 per fp32 product, operands split hi + lo),
                              0 v_mfma_f32_32x32x2_f32 (JAMUN_DG_FP32=1); -1: not in use */
-  int64_t conv_flop_exec_launch; /* matrix-core FLOPs EXECUTED by one hidden-layer conv launch (k_tprod + k_conv_dg, padding and the
-                             three products of the f16x3 scheme included); 0 when another conv path is in use */
+  int64_t conv_flop_exec_launch; /* matrix-core FLOPs EXECUTED by ONE launch of the hidden-layer conv kernel (k_conv_mf / k_conv_dg; padding,
+                             structural zeros of the forming GEMMs and the three products of the f16x3 scheme included; the T pre-pass is
+                             a separate launch and not counted); 0 when another conv path is in use */
+  int64_t conv_flop_useful_launch; /* of those, what the destination-grouped association needs at the edge count of the last forward:
+                             3 (f16x3) x [2 x 65 x n_atoms x (G0 K0 + 3 G1 K1) contraction + 2 x 65 x n_edges x (in0 + 15 in1) forming
+                             (x0, dot, x1, cross and T term per edge)], no padding, no zero blocks */
+  int64_t conv_bytes_alg_launch;  /* algorithmic HBM bytes of that launch: h~ of the layer, T, the weight stream once, the feature
+                             rows once, the partial slabs written */
 } jamun_stats;
 /* Synchronises `stream`. */
 int jamun_sampler_stats(jamun_sampler* s, jamun_stats* out, void* stream);
@@ -243,7 +259,8 @@ int jamun_sampler_stats(jamun_sampler* s, jamun_stats* out, void* stream);
 #define JAMUN_PROF_CONV1 5       /* conv contraction, vector-output rows, hidden layers              */
 #define JAMUN_PROF_NODE 6        /* partial-slab reduce + gate + self/skip Linear + noise skip mix   */
 #define JAMUN_PROF_HEAD 7        /* output head + xhat/score finalize                                */
-#define JAMUN_PROF_NCLASS 8
+#define JAMUN_PROF_TPROD 8       /* T pre-pass of a hidden layer (k_tprod / k_tprod_h), in front of the conv kernel */
+#define JAMUN_PROF_NCLASS 9
 /* on = 0: off; 1: every class; otherwise a mask with bit (c + 1) set for each class c to time (event records are not free:
  * timing all 16 launches of a forward costs ~4 % of a step, the dominant class alone ~1 %). */
 int jamun_profile_enable(jamun_sampler* s, int32_t on);

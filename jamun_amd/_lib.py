@@ -83,6 +83,8 @@ class jamun_stats(C.Structure):
         ("dg_row_blocks", C.c_int32),
         ("dg_emu", C.c_int32),
         ("conv_flop_exec_launch", C.c_int64),
+        ("conv_flop_useful_launch", C.c_int64),
+        ("conv_bytes_alg_launch", C.c_int64),
     ]
 
 
@@ -107,8 +109,9 @@ SYMBOLS = {
     "jamun_baoab_post": (C.c_int, [_P, _P, _P, C.c_int32, C.POINTER(jamun_mcmc_params), _P]),
     "jamun_aboba_a": (C.c_int, [_P, _P, C.c_int32, C.POINTER(jamun_mcmc_params), _P]),
     "jamun_aboba_b": (C.c_int, [_P, _P, _P, _P, C.c_int32, C.POINTER(jamun_mcmc_params), _P]),
-    "jamun_edge_geometry": (C.c_int, [_P, _P, _P, C.c_int32, C.c_float, C.c_int32, _P, _P, _P]),
-    "jamun_node_linear": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P]),
+    "jamun_edge_geometry": (C.c_int, [_P, C.c_int32, _P, _P, C.c_int32, C.c_float, C.c_int32, _P, _P, _P]),
+    "jamun_node_linear": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, C.c_int64, _P, _P]),
+    "jamun_philox_normal": (C.c_int, [_P, C.c_int32, C.c_uint64, C.c_uint32, C.c_uint32, _P]),
     "jamun_build_edges": (C.c_int, [_P, _P, _P]),
     "jamun_conv_block": (C.c_int, [_P, C.c_int32, _P, _P, _P]),
     "jamun_sampler_stats": (C.c_int, [_P, C.POINTER(jamun_stats), _P]),
@@ -118,7 +121,9 @@ SYMBOLS = {
     "jamun_debug_read": (C.c_int, [_P, C.c_int32, C.c_int32, _P, _P]),
 }
 
-PROF_CLASSES = ["geom", "edge_h", "conv0_init", "conv1_init", "conv0", "conv1", "node_update", "head_finalize"]
+PROF_CLASSES = ["geom", "edge_h", "conv0_init", "conv1_init", "conv0", "conv1", "node_update", "head_finalize", "tprod"]
+
+ABI_VERSION = 3  # jamun_version() of the library this binding was written for (struct layouts and signatures above)
 
 _lib: Optional[C.CDLL] = None
 
@@ -159,6 +164,10 @@ def load() -> C.CDLL:
         fn = getattr(lib, name)  # AttributeError if the library does not export a declared symbol
         fn.restype = res
         fn.argtypes = args
+    ver = int(lib.jamun_version())
+    if ver != ABI_VERSION:
+        raise RuntimeError(f"{LIB_PATH} reports ABI version {ver}, this binding is written for version {ABI_VERSION} "
+                           "(struct layouts differ): rebuild with `python jamun_amd/csrc/build.py --force`")
     _lib = lib
     return lib
 

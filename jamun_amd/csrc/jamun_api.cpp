@@ -357,7 +357,7 @@ struct jamun_sampler {
   int dg_tstride = 0;     // mode 4 (jamun_conv_mf.hip): dg_T is [n_k][32][dg_tstride], transposed
   bool mfi_on = false;    // initial projector on k_conv_mfi (mode 4 tiles, at most 32 distinct embedding rows)
   int* mf_err = nullptr;  // device flag of k_conv_mf
-  int* mf_err_host = nullptr;  // pinned copy, refreshed after every forward
+  int* mf_err_host = nullptr;  // pinned copy, refreshed behind every entry point that ran a forward (mf_err_fetch / mf_err_check)
   float *x_emb = nullptr, *mu = nullptr;
   std::vector<LayerDev> layers;
   float *w_gate = nullptr, *w_vec = nullptr, *w_out = nullptr;
@@ -1274,8 +1274,11 @@ void run_layer(jamun_sampler* s, size_t l, const float* x_in, int XSin, float* x
         f.sC = std::max(-40, std::min(40, 14 - e3));
       }
       f.partial0 = s->partial0; f.partial1 = s->partial1; f.err = s->mf_err;
-      ProfScope ps(s, JAMUN_PROF_CONV0, st);  // (the T pre-pass is part of the hidden-layer conv: timed with it)
-      launch_tprod(x_in, XSin, s->n_atoms, s->hp.edge_attr_dim + 1, L.dg.wt, L.dg.wth, L.dg.sBt, s->dg_T, s->dg_tstride, st);
+      {
+        ProfScope pt(s, JAMUN_PROF_TPROD, st);
+        launch_tprod(x_in, XSin, s->n_atoms, s->hp.edge_attr_dim + 1, L.dg.wt, L.dg.wth, L.dg.sBt, s->dg_T, s->dg_tstride, st);
+      }
+      ProfScope ps(s, JAMUN_PROF_CONV0, st);
       if (launch_conv_mf(f, s->dg_grid, st) != 0) throw Err(JAMUN_ERR_INVALID, "matrix-formed conv launch failed (configuration not supported)");
     } else if (l > 0 && s->dg_on) {
       DgArgs f{};
@@ -1294,8 +1297,11 @@ void run_layer(jamun_sampler* s, size_t l, const float* x_in, int XSin, float* x
         f.dbg = atoi(getenv("JAMUN_DG_DUMP"));
         f.dump = s->dg_dump;
       }
-      ProfScope ps(s, JAMUN_PROF_CONV0, st);  // (the T pre-pass is part of the hidden-layer conv: timed with it)
-      launch_tprod(x_in, XSin, s->n_atoms, s->hp.edge_attr_dim + 1, L.dg.wt, s->dg_emu ? L.dg.wth : nullptr, L.dg.sBt, s->dg_T, 0, st);
+      {
+        ProfScope pt(s, JAMUN_PROF_TPROD, st);
+        launch_tprod(x_in, XSin, s->n_atoms, s->hp.edge_attr_dim + 1, L.dg.wt, s->dg_emu ? L.dg.wth : nullptr, L.dg.sBt, s->dg_T, 0, st);
+      }
+      ProfScope ps(s, JAMUN_PROF_CONV0, st);
       const int rcode = launch_conv_dg(f, s->dg_grid, st);
       if (rcode != 0) throw Err(JAMUN_ERR_INVALID, "destination-grouped conv launch failed (configuration not supported)");
     } else if (L.fu.wpack) {
@@ -1341,6 +1347,19 @@ void run_layer(jamun_sampler* s, size_t l, const float* x_in, int XSin, float* x
       if (!nu_fp32 && node_update_h_supported(n)) launch_node_update_h(n, st);
       else launch_node_update(n, st);
     }
+}
+
+// k_conv_mf / k_conv_mfi set a device flag when an ordered (source, destination) pair carries more edges than one coefficient
+// entry can hold (the host plan excludes such topologies at create time; the kernels still report what they see).  Every entry
+// point that ran a forward copies the flag into a pinned word behind its work (no synchronisation); every entry point first looks
+// at that word, so a disagreement between plan and kernel surfaces as JAMUN_ERR_INVALID at the next call after the copy landed —
+// at the latest in jamun_sampler_stats, which synchronises — instead of as silently wrong coordinates.
+void mf_err_check(jamun_sampler* s) {
+  if (s->mf_err_host && *(volatile int*)s->mf_err_host != 0)
+    throw Err(JAMUN_ERR_INVALID, "k_conv_mf: more than three edges of one (source, destination) pair — results of this sampler are invalid");
+}
+void mf_err_fetch(jamun_sampler* s, hipStream_t st) {
+  if (s->mf_err && s->mf_err_host) HIPCHECK(hipMemcpyAsync(s->mf_err_host, s->mf_err, sizeof(int), hipMemcpyDeviceToHost, st));
 }
 
 // One denoiser forward.  `pre` / `post`: the two halves of a BAOAB iteration fused into the first and the last kernel of the
@@ -1506,7 +1525,7 @@ SegPlan plan_segments(int cus, int ng, int n_k, int N, const std::vector<int2>& 
 extern "C" {
 
 const char* jamun_last_error(void) { return g_err.c_str(); }
-int jamun_version(void) { return 2; }
+int jamun_version(void) { return 3; }
 
 int jamun_model_create(const jamun_hparams* hp, const jamun_tensor* tensors, int32_t n_tensors, jamun_model** out) {
   return guarded([&] {
@@ -1711,6 +1730,9 @@ int jamun_sampler_create(const jamun_model* m, float sigma, const jamun_topology
       L.mix = dev_upload(mix);
       s->layers.push_back(L);
     }
+    for (auto& L : s->layers)
+      if (L.sep.w2p)
+        if (const char* why = sep_conv_unsupported(L.sep.n0, L.sep.n1, L.sep.NWp, s->S)) throw Err(JAMUN_ERR_INVALID, why);
     // ---- head (EquivariantMLP, _mlp.py:84-114) and output gain (e3conv.py:134-135)
     {
       const int mul0 = hp.mul0, mul1 = hp.mul1, G0 = mul0 + mul1;
@@ -1983,8 +2005,8 @@ int jamun_sampler_create(const jamun_model* m, float sigma, const jamun_topology
         // in the T pre-pass
         // (mode 4, jamun_conv_mf.hip: 414 v_mfma_f32_32x32x16_f16 per (tile, k): 228 forming + 186 contraction)
         const int64_t per_tile_k = s->dg_mode == 4 ? 414LL * 32768 : s->dg_emu ? (150LL * 32768 + 72LL * 16384) : 476LL * 4096;
-        s->conv_flop_exec_launch = ((int64_t)s->dg_n_tiles * per_tile_k + (int64_t)((s->n_atoms + 31) / 32) * 60 * 4096) * (hp.edge_attr_dim + 1);
-        s->flop_exec += s->conv_flop_exec_launch;
+        s->conv_flop_exec_launch = (int64_t)s->dg_n_tiles * per_tile_k * (hp.edge_attr_dim + 1);
+        s->flop_exec += s->conv_flop_exec_launch + (int64_t)((s->n_atoms + 31) / 32) * (s->dg_emu ? 24LL * 32768 : 60LL * 4096) * (hp.edge_attr_dim + 1);
       }
       else if (L.sep.w2p) s->flop_exec += 2LL * (int64_t)NS * 66 * L.sep.NWp;  // the per-edge weight GEMM (the rest is VALU work per edge)
       else if (L.fu.wpack) s->flop_exec += (int64_t)s->n_ftiles * (hp.edge_attr_dim + 1) * L.fu.mfma_per_k * 4096;  // 32x32x2 MFMA = 4096 FLOP
@@ -1999,13 +2021,17 @@ void jamun_sampler_destroy(jamun_sampler* s) { delete s; }
 int jamun_xhat(jamun_sampler* s, const float* y_dev, float* xhat_dev, void* stream) {
   return guarded([&] {
     if (!s || !y_dev || !xhat_dev) throw Err(JAMUN_ERR_INVALID, "null argument");
+    mf_err_check(s);
     forward(s, const_cast<float*>(y_dev), xhat_dev, nullptr, (hipStream_t)stream);  // (y is written only with a fused pre-update)
+    mf_err_fetch(s, (hipStream_t)stream);
   });
 }
 int jamun_score(jamun_sampler* s, const float* y_dev, float* score_dev, void* stream) {
   return guarded([&] {
     if (!s || !y_dev || !score_dev) throw Err(JAMUN_ERR_INVALID, "null argument");
+    mf_err_check(s);
     forward(s, const_cast<float*>(y_dev), nullptr, score_dev, (hipStream_t)stream);
+    mf_err_fetch(s, (hipStream_t)stream);
   });
 }
 
@@ -2025,6 +2051,7 @@ int jamun_walk_baoab(jamun_sampler* s, float* y, float* v, const jamun_mcmc_para
   return guarded([&] {
     if (!s || !y || !v) throw Err(JAMUN_ERR_INVALID, "null argument");
     check_mcmc(p);
+    mf_err_check(s);
     hipStream_t st = (hipStream_t)stream;
     const LangevinConsts k = make_consts(p);
     const int n = s->n_atoms;
@@ -2058,6 +2085,7 @@ int jamun_walk_baoab(jamun_sampler* s, float* y, float* v, const jamun_mcmc_para
       if (sv) { ++fy; ++fs; }
     }
     if (xhat_out) launch_copy(s->xhat_buf, xhat_out, n * 3, st);  // last forward was evaluated at the final y
+    mf_err_fetch(s, st);
     HIPCHECK(hipGetLastError());
   });
 }
@@ -2067,6 +2095,7 @@ int jamun_walk_aboba(jamun_sampler* s, float* y, float* v, const jamun_mcmc_para
   return guarded([&] {
     if (!s || !y || !v) throw Err(JAMUN_ERR_INVALID, "null argument");
     check_mcmc(p);
+    mf_err_check(s);
     hipStream_t st = (hipStream_t)stream;
     const LangevinConsts k = make_consts(p);
     const int n = s->n_atoms;
@@ -2090,6 +2119,7 @@ int jamun_walk_aboba(jamun_sampler* s, float* y, float* v, const jamun_mcmc_para
       }
     }
     if (xhat_out) forward(s, y, xhat_out, nullptr, st);
+    mf_err_fetch(s, st);
     HIPCHECK(hipGetLastError());
   });
 }
@@ -2159,25 +2189,37 @@ int jamun_aboba_b(float* y, float* v, const float* score, const float* noise, in
   });
 }
 
-int jamun_edge_geometry(const float* pos, const int64_t* src, const int64_t* dst, int32_t n_edges, float radial_cutoff, int32_t n_basis,
-                        float* sh, float* radial, void* stream) {
+int jamun_edge_geometry(const float* pos, int32_t n_atoms, const int64_t* src, const int64_t* dst, int32_t n_edges, float radial_cutoff,
+                        int32_t n_basis, float* sh, float* radial, void* stream) {
   return guarded([&] {
-    if (!pos || !src || !dst || !sh || !radial || n_edges < 0) throw Err(JAMUN_ERR_INVALID, "bad argument");
+    if (!pos || !src || !dst || !sh || !radial || n_edges < 0 || n_atoms < 0) throw Err(JAMUN_ERR_INVALID, "bad argument");
     if (n_basis < 1 || !(radial_cutoff > 0)) throw Err(JAMUN_ERR_INVALID, "n_basis must be >= 1 and radial_cutoff positive");
     if (n_edges == 0) return;
-    launch_edge_geometry(pos, (const long long*)src, (const long long*)dst, n_edges, radial_cutoff, n_basis, sh, radial, (hipStream_t)stream);
+    launch_edge_geometry(pos, (const long long*)src, (const long long*)dst, n_edges, n_atoms, radial_cutoff, n_basis, sh, radial, (hipStream_t)stream);
     HIPCHECK(hipGetLastError());
   });
 }
 
-int jamun_node_linear(const float* x, int32_t n_atoms, int32_t in0, int32_t in1, int32_t out0, int32_t out1, const float* w, float* out,
-                      void* stream) {
+int jamun_node_linear(const float* x, int32_t n_atoms, int32_t in0, int32_t in1, int32_t out0, int32_t out1, const float* w, int64_t w_numel,
+                      float* out, void* stream) {
   return guarded([&] {
     if (!x || !w || !out || n_atoms < 0 || in0 < 0 || in1 < 0 || out0 < 0 || out1 < 0 || in0 + in1 < 1 || out0 + out1 < 1)
       throw Err(JAMUN_ERR_INVALID, "bad argument");
+    if (w_numel != (int64_t)in0 * out0 + (int64_t)in1 * out1)
+      throw Err(JAMUN_ERR_INVALID, "weight has " + std::to_string(w_numel) + " elements, the irreps need in0*out0 + in1*out1 = " +
+                                       std::to_string((int64_t)in0 * out0 + (int64_t)in1 * out1));
     if (n_atoms == 0) return;
     if (launch_node_linear(x, n_atoms, in0, in1, out0, out1, w, out, (hipStream_t)stream) != 0)
       throw Err(JAMUN_ERR_INVALID, "input irreps too wide (8 feature rows must fit 60 KiB of LDS)");
+    HIPCHECK(hipGetLastError());
+  });
+}
+
+int jamun_philox_normal(float* out_dev, int32_t n, uint64_t seed, uint32_t iteration, uint32_t first_atom, void* stream) {
+  return guarded([&] {
+    if (!out_dev || n < 0) throw Err(JAMUN_ERR_INVALID, "bad argument");
+    if (n == 0) return;
+    launch_philox_normal(out_dev, n, seed, iteration, first_atom, (hipStream_t)stream);
     HIPCHECK(hipGetLastError());
   });
 }
@@ -2195,6 +2237,7 @@ int jamun_conv_block(jamun_sampler* s, int32_t layer, const float* x_in_dev, flo
     if (!s || !x_out_dev) throw Err(JAMUN_ERR_INVALID, "null argument");
     if (layer < 0 || layer >= (int)s->layers.size()) throw Err(JAMUN_ERR_INVALID, "layer out of range");
     if (!s->edges_built) throw Err(JAMUN_ERR_INVALID, "no edge table yet: call jamun_build_edges (or a forward) first");
+    mf_err_check(s);
     if (layer == 0) {
       if (x_in_dev) throw Err(JAMUN_ERR_INVALID, "block 0 (initial projector) takes the sampler's own noise-scaled atom embedding: pass x_in = NULL");
       run_layer(s, 0, s->x_emb, s->n_emb, x_out_dev, (hipStream_t)stream);
@@ -2203,6 +2246,7 @@ int jamun_conv_block(jamun_sampler* s, int32_t layer, const float* x_in_dev, flo
       if (x_in_dev == x_out_dev) throw Err(JAMUN_ERR_INVALID, "x_in and x_out must not alias (the skip path reads x_in after the conv)");
       run_layer(s, (size_t)layer, x_in_dev, s->XS, x_out_dev, (hipStream_t)stream);
     }
+    mf_err_fetch(s, (hipStream_t)stream);
     HIPCHECK(hipGetLastError());
   });
 }
@@ -2220,7 +2264,10 @@ int jamun_sampler_stats(jamun_sampler* s, jamun_stats* out, void* stream) {
     HIPCHECK(hipStreamSynchronize(st));
     // (k_conv_mf / k_conv_mfi: an ordered pair with more than three edges cannot share one coefficient entry; the host excludes such
     // topologies at create time, the kernels still flag what they see)
-    if (mf_flag != 0) throw Err(JAMUN_ERR_INVALID, "k_conv_mf: more than three edges of one (source, destination) pair");
+    if (mf_flag != 0) {
+      if (s->mf_err_host) *s->mf_err_host = mf_flag;
+      mf_err_check(s);
+    }
     out->n_edges = (int64_t)e;
     out->flop_ref_assoc = (int64_t)e * s->flop_ref_per_edge;
     out->flop_executed = s->flop_exec;
@@ -2239,6 +2286,20 @@ int jamun_sampler_stats(jamun_sampler* s, jamun_stats* out, void* stream) {
     out->dg_row_blocks = s->dg_on && s->dg_row_blocks ? 1 : 0;
     out->dg_emu = s->dg_on ? s->dg_emu : -1;
     out->conv_flop_exec_launch = s->conv_flop_exec_launch;
+    out->conv_flop_useful_launch = 0;
+    out->conv_bytes_alg_launch = 0;
+    if (s->dg_on && s->layers.size() > 1) {
+      const int64_t m0 = s->hp.mul0, m1 = s->hp.mul1, H1 = s->hp.edge_attr_dim + 1, N = s->n_atoms;
+      const int64_t contraction = 2 * H1 * N * ((m0 + m1) * (m0 + m1) + 3 * m1 * (2 * m1));
+      const int64_t forming = 2 * H1 * (int64_t)e * (m0 + 15 * m1);  // per edge and k: x0 (m0), dot 3 m1, x1 3 m1, cross 6 m1, T term 3 m1
+      out->conv_flop_useful_launch = (s->dg_emu ? 3 : 1) * (contraction + forming);
+      const int64_t slots = (int64_t)s->h_kstride;
+      out->conv_bytes_alg_launch = 4 * (H1 * slots          // h~ of the layer
+                                        + H1 * 32 * N         // T
+                                        + N * s->XS           // feature rows
+                                        + (int64_t)s->dg_n_slabs * s->n_pad * 32 * (s->layers[1].p0.nt + 3 * s->layers[1].p1.nt)) +  // slabs
+                                   (s->dg_mode == 4 ? H1 * 124 * 64 * 16 : s->dg_emu ? H1 * 4 * 34 * 64 * 16 : H1 * (5 * 16 + 5 * 4 + 2 * 4) * 64 * 16);  // weights
+    }
   });
 }
 

@@ -224,6 +224,7 @@ struct SepArgs {
   float* partial0;  // [n_pad][nt0 * 32]  (one slab)
   float* partial1;  // [n_pad][3][nt1 * 32]
 };
+const char* sep_conv_unsupported(int n0, int n1, int NWp, int S);
 int launch_sep_conv(const SepArgs& a, hipStream_t st);
 
 struct NodeArgs {
@@ -341,6 +342,7 @@ void launch_copy(const float* src, float* dst, int n, hipStream_t st);
 void launch_deg_to_float(const int* deg, float* out, int n, hipStream_t st);
 void launch_count_edges(const int* deg, int n, unsigned long long* out, hipStream_t st);
 void launch_scatter_mean(const float* src, const int* seg_ptr, int n_out, int width, float* out, hipStream_t st);
-void launch_edge_geometry(const float* pos, const long long* src, const long long* dst, int n_edges, float cutoff, int n_basis, float* sh,
-                          float* radial, hipStream_t st);
+void launch_edge_geometry(const float* pos, const long long* src, const long long* dst, int n_edges, int n_atoms, float cutoff, int n_basis,
+                          float* sh, float* radial, hipStream_t st);
+void launch_philox_normal(float* out, int n, uint64_t seed, uint32_t iter, uint32_t atom0, hipStream_t st);
 int launch_node_linear(const float* x, int n_atoms, int in0, int in1, int out0, int out1, const float* w, float* out, hipStream_t st);

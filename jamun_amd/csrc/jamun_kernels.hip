@@ -919,10 +919,16 @@ void launch_scatter_mean(const float* src, const int* seg_ptr, int n_out, int wi
 //   radial[k] = exp(-((|v| - mu_k) / step)^2) / 1.12,  mu = linspace(0, cutoff, n_basis + 2)[1:-1]   (soft_one_hot_linspace, gaussian)
 // One thread per edge; the basis row is written by the same thread (n_basis floats: 128 B for the default 32).
 __global__ __launch_bounds__(256) void k_edge_geometry(const float* __restrict__ pos, const long long* __restrict__ src, const long long* __restrict__ dst,
-                                                       int n_edges, float cutoff, int n_basis, float* __restrict__ sh, float* __restrict__ radial) {
+                                                       int n_edges, int n_atoms, float cutoff, int n_basis, float* __restrict__ sh, float* __restrict__ radial) {
   const int e = blockIdx.x * 256 + threadIdx.x;
   if (e >= n_edges) return;
   const long long j = src[e], i = dst[e];
+  if (j < 0 || j >= n_atoms || i < 0 || i >= n_atoms) {  // an index outside the position array: nothing is read, the edge's outputs are NaN
+    const float q = __int_as_float(0x7fc00000);
+    reinterpret_cast<float4*>(sh)[e] = make_float4(q, q, q, q);
+    for (int k = 0; k < n_basis; ++k) radial[(size_t)e * n_basis + k] = q;
+    return;
+  }
   const float vx = pos[3 * j] - pos[3 * i], vy = pos[3 * j + 1] - pos[3 * i + 1], vz = pos[3 * j + 2] - pos[3 * i + 2];
   const float d = sqrtf(__fadd_rn(__fadd_rn(__fmul_rn(vx, vx), __fmul_rn(vy, vy)), __fmul_rn(vz, vz)));
   const float inv = 1.f / fmaxf(d, 1e-12f), s3 = 1.7320508075688772f;
@@ -936,9 +942,22 @@ __global__ __launch_bounds__(256) void k_edge_geometry(const float* __restrict__
     radial[(size_t)e * n_basis + k] = expf(-(t * t)) / 1.12f;
   }
 }
-void launch_edge_geometry(const float* pos, const long long* src, const long long* dst, int n_edges, float cutoff, int n_basis, float* sh,
+void launch_edge_geometry(const float* pos, const long long* src, const long long* dst, int n_edges, int n_atoms, float cutoff, int n_basis, float* sh,
                           float* radial, hipStream_t st) {
-  hipLaunchKernelGGL(k_edge_geometry, dim3((n_edges + 255) / 256), dim3(256), 0, st, pos, src, dst, n_edges, cutoff, n_basis, sh, radial);
+  hipLaunchKernelGGL(k_edge_geometry, dim3((n_edges + 255) / 256), dim3(256), 0, st, pos, src, dst, n_edges, n_atoms, cutoff, n_basis, sh, radial);
+}
+
+// jamun_philox_normal: the standard-normal draws the walks use when no noise tensor is supplied (R of iteration `iter` for atoms
+// atom0 .. atom0 + n - 1), written out as [n, 3] — the counterpart of the reference's torch.randn_like (functional/_splitting.py:161)
+__global__ __launch_bounds__(256) void k_philox_normal(float* __restrict__ out, int n, uint64_t seed, uint32_t iter, uint32_t atom0) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  float R[3];
+  philox_normal3(seed, iter, atom0 + (uint32_t)i, R);
+  out[(size_t)i * 3] = R[0]; out[(size_t)i * 3 + 1] = R[1]; out[(size_t)i * 3 + 2] = R[2];
+}
+void launch_philox_normal(float* out, int n, uint64_t seed, uint32_t iter, uint32_t atom0, hipStream_t st) {
+  hipLaunchKernelGGL(k_philox_normal, dim3((n + 255) / 256), dim3(256), 0, st, out, n, seed, iter, atom0);
 }
 
 // jamun_node_linear: e3nn o3.Linear between irreps (in0 x0e + in1 x1e) and (out0 x0e + out1 x1e) with the flat e3nn weight

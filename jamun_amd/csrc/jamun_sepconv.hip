@@ -176,10 +176,19 @@ __global__ __launch_bounds__(256) void k_sep_apply(SepArgs a) {
   }
 }
 
+// What the SeparableConv kernels can run: checked once in jamun_sampler_create (a model / topology outside these limits is rejected
+// there with this message, not at the first forward) and again at launch.
+const char* sep_conv_unsupported(int n0, int n1, int NWp, int S) {
+  if (n0 > 128 || n1 > 32) return "SeparableConv: input irreps wider than 128x0e + 32x1e";
+  if (NWp % 32 != 0 || NWp < 2 * n0 + 3 * n1) return "SeparableConv: internal weight padding";
+  if (S > 64) return "SeparableConv: more than 64 edge slots per destination (32 radial neighbours + bonded in-edges; repeated bond listings count)";  // edge slot t lives in lane t
+  if ((size_t)16 * (n0 + n1 + 3 * (n0 + 2 * n1)) * sizeof(float) > 64 * 1024) return "SeparableConv: per-destination sums exceed 64 KiB of LDS";
+  return nullptr;
+}
+
 int launch_sep_conv(const SepArgs& a, hipStream_t st) {
-  if (a.n0 > 128 || a.n1 > 32 || a.NWp % 32 != 0 || a.NWp < 2 * a.n0 + 3 * a.n1 || a.S > 64) return -1;  // (edge slot t of a destination lives in lane t)
+  if (sep_conv_unsupported(a.n0, a.n1, a.NWp, a.S)) return -1;
   const size_t smem = (size_t)16 * (a.n0 + a.n1 + 3 * (a.n0 + 2 * a.n1)) * sizeof(float);
-  if (smem > 64 * 1024) return -1;
   const int64_t tiles = (a.n_slots + 31) / 32;
   hipLaunchKernelGGL(k_sep_weights, dim3((unsigned)((tiles + 3) / 4)), dim3(256), 0, st, a);
   hipLaunchKernelGGL(k_sep_apply, dim3((a.n_atoms + 15) / 16), dim3(256), smem, st, a);

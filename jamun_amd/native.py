@@ -303,8 +303,8 @@ def edge_geometry(pos_scaled: torch.Tensor, edge_index: torch.Tensor, radial_cut
     sh = torch.empty((E, 4), dtype=torch.float32, device=pos.device)
     radial = torch.empty((E, n_basis), dtype=torch.float32, device=pos.device)
     with torch.cuda.device(pos.device):
-        _lib.check(lib.jamun_edge_geometry(_ptr(pos), _ptr(ei[0].contiguous()), _ptr(ei[1].contiguous()), E, C.c_float(radial_cutoff), n_basis,
-                                           _ptr(sh), _ptr(radial), _stream()))
+        _lib.check(lib.jamun_edge_geometry(_ptr(pos), int(pos.shape[0]), _ptr(ei[0].contiguous()), _ptr(ei[1].contiguous()), E,
+                                           C.c_float(radial_cutoff), n_basis, _ptr(sh), _ptr(radial), _stream()))
     return sh, radial
 
 
@@ -313,10 +313,21 @@ def node_linear(x: torch.Tensor, weight: torch.Tensor, in0: int, in1: int, out0:
     lib = _lib.load()
     x = _dev_f32(x, "x")
     w = _dev_f32(weight, "weight")
-    assert x.shape[1] == in0 + 3 * in1 and w.numel() == in0 * out0 + in1 * out1, (x.shape, w.numel())
+    assert x.shape[1] == in0 + 3 * in1, x.shape
     out = torch.empty((x.shape[0], out0 + 3 * out1), dtype=torch.float32, device=x.device)
     with torch.cuda.device(x.device):
-        _lib.check(lib.jamun_node_linear(_ptr(x), x.shape[0], in0, in1, out0, out1, _ptr(w), _ptr(out), _stream()))
+        _lib.check(lib.jamun_node_linear(_ptr(x), x.shape[0], in0, in1, out0, out1, _ptr(w), int(w.numel()), _ptr(out), _stream()))
+    return out
+
+
+def philox_normal(n: int, seed: int, iteration: int, device, first_atom: int = 0) -> torch.Tensor:
+    """``[n, 3]`` standard-normal draws of integrator iteration ``iteration`` under ``seed``: exactly what the walks use in place of
+    the reference's ``torch.randn_like`` (``functional/_splitting.py:161``) when no noise tensor is passed; see ``jamun_philox_normal``."""
+    lib = _lib.load()
+    device = torch.device(device)
+    out = torch.empty((n, 3), dtype=torch.float32, device=device)
+    with torch.cuda.device(device):
+        _lib.check(lib.jamun_philox_normal(_ptr(out), int(n), C.c_uint64(seed & (2**64 - 1)), C.c_uint32(iteration), C.c_uint32(first_atom), _stream()))
     return out
 
 

@@ -1,7 +1,10 @@
 # per-wave timeline of workgroup 7: k_conv_dg from the -DJAMUN_STAMP build (default), k_conv_mf with XF=-DMF_TRACE:  XF=-DMF_TRACE CFG=cfg2 bash profiles/wave_timeline.sh
-cd $GRAFT_REPO_ROOT
+set -euo pipefail
+cd "${GRAFT_REPO_ROOT:?run on the GPU box (gpurun exports GRAFT_REPO_ROOT)}"
+# the diagnostic build replaces the in-tree library: put the production build back on every exit path
+trap 'env -u JAMUN_EXTRA_CFLAGS python3 jamun_amd/csrc/build.py > /dev/null' EXIT
 export JAMUN_EXTRA_CFLAGS="${XF:--DJAMUN_STAMP}"
-python3 jamun_amd/csrc/build.py > /dev/null 2>&1
+python3 jamun_amd/csrc/build.py > /dev/null
 python3 - <<'PY'
 import ctypes as C, torch, sys, os
 sys.path.insert(0,'.')
