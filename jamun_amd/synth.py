@@ -348,6 +348,71 @@ def synthetic_state_dict(arch: Optional[dict] = None, seed: int = 0, output_gain
     return sd
 
 
+def trained_like(sd: Dict[str, torch.Tensor], arch: Optional[dict] = None, seed: int = 1, log2_spread: float = 10.0,
+                 outlier_fraction: float = 0.01, outlier_factor: float = 100.0) -> Dict[str, torch.Tensor]:
+    """Re-shape the weight DISTRIBUTION of a synthetic state dict towards what training produces, keeping the function's overall
+    size: (a) a per-channel gauge of the hidden features — channel u of ``irreps_hidden`` carries 2^t_u times its former values in
+    every layer, t_u ~ U(-log2_spread, log2_spread) rounded to integers (exact powers of two), with the producers of the channel
+    (skip / self-interaction output columns) multiplied by 2^t_u and its consumers (tensor-product weights, skip inputs, head
+    inputs of the channel, and the per-channel noise scalings stay as they are) by 2^-t_u; (b) heavy tails — a fraction
+    ``outlier_fraction`` of the entries of every large weight tensor times ``outlier_factor``, the tensor then rescaled to its former
+    Frobenius norm.  The default checkpoints have N(0,1) / uniform weights of one scale per tensor, which is the easy case for
+    the f16x3 kernels (one power-of-two scale per layer and operand); this preset is the hard one."""
+    arch = arch or default_arch()
+    g = torch.Generator().manual_seed(seed)
+    m0, m1 = _irreps_muls(arch["irreps_hidden"])
+    G0, G1 = m0 + m1, m1
+    t0 = torch.randint(-int(log2_spread), int(log2_spread) + 1, (m0,), generator=g).double()
+    t1 = torch.randint(-int(log2_spread), int(log2_spread) + 1, (m1,), generator=g).double()
+    s0, s1 = torch.pow(2.0, t0), torch.pow(2.0, t1)
+    out = {k: v.clone().double() for k, v in sd.items()}
+    emb = [arch["atom_type_embedding_dim"], arch["atom_type_embedding_dim"], arch["residue_code_embedding_dim"], arch["residue_index_embedding_dim"]]
+    n_emb = sum(emb)
+    separable = any(k.endswith("tp.lin.weight") for k in sd)
+
+    def gauge_linear_out(name, in0, in1):  # o3.Linear flat weight [in0 x m0 | in1 x m1]: output channel gauge
+        w = out[name]
+        a = w[: in0 * m0].reshape(in0, m0) * s0[None, :]
+        b = w[in0 * m0 :].reshape(in1, m1) * s1[None, :] if in1 else w[in0 * m0 :]
+        out[name] = torch.cat([a.reshape(-1), b.reshape(-1)])
+
+    def gauge_linear_in(name, out0_, out1_):  # input channels are hidden features: rows times 2^-t
+        w = out[name]
+        a = w[: m0 * out0_].reshape(m0, out0_) / s0[:, None]
+        b = w[m0 * out0_ :].reshape(m1, out1_) / s1[:, None]
+        out[name] = torch.cat([a.reshape(-1), b.reshape(-1)])
+
+    def gauge_tp_in(prefix):  # rows of radial_nn.3 (weight, bias) = tensor-product weights; input channel u of a hidden layer
+        W, b = out[prefix + ".radial_nn.3.weight"], out[prefix + ".radial_nn.3.bias"]
+        if separable:  # "uvu" weights: [A m0 | B m0 | C m1 | D m1 | E m1], one per input channel
+            f = torch.cat([1 / s0, 1 / s0, 1 / s1, 1 / s1, 1 / s1])
+        else:  # FCTP blocks in instruction order: (0e 0e->0e) m0 x G0, (0e 1e->1e) m0 x G1, (1e 0e->1e) m1 x G1, (1e 1e->0e) m1 x G0, (1e 1e->1e) m1 x G1
+            f = torch.cat([(1 / s0)[:, None].expand(m0, G0).reshape(-1), (1 / s0)[:, None].expand(m0, G1).reshape(-1),
+                           (1 / s1)[:, None].expand(m1, G1).reshape(-1), (1 / s1)[:, None].expand(m1, G0).reshape(-1),
+                           (1 / s1)[:, None].expand(m1, G1).reshape(-1)])
+        assert f.numel() == b.numel(), (f.numel(), b.numel())
+        out[prefix + ".radial_nn.3.weight"], out[prefix + ".radial_nn.3.bias"] = W * f[:, None], b * f
+        if separable:  # the point-wise Linear sees the depth-wise outputs, already in the un-gauged size: nothing to do
+            pass
+
+    gauge_linear_out("initial_projector.gated_conv.skip_connection.weight", n_emb, 0)
+    gauge_linear_out("initial_projector.gated_conv.self_interaction.weight", m0, m1)
+    for i in range(arch["n_layers"]):
+        pre = f"layers.{i}.gated_conv"
+        gauge_linear_in(pre + ".skip_connection.weight", m0, m1)
+        gauge_linear_out(pre + ".skip_connection.weight", m0, m1)
+        gauge_linear_out(pre + ".self_interaction.weight", m0, m1)
+        gauge_tp_in(pre + ".f.f")
+    gauge_linear_in("output_head.0.lin.weight", G0, m1)
+    for k, v in out.items():  # heavy tails
+        if v.numel() >= 1024 and "embedding" not in k and "embed_" not in k:
+            nrm = v.norm()
+            mask = torch.rand(v.shape, generator=g) < outlier_fraction
+            v = torch.where(mask, v * outlier_factor, v)
+            out[k] = v * (nrm / v.norm())
+    return {k: v.to(torch.float32) for k, v in out.items()}
+
+
 def synthetic_checkpoint(
     arch: Optional[dict] = None,
     seed: int = 0,
@@ -356,10 +421,16 @@ def synthetic_checkpoint(
     output_gain: float = 0.5,
     prefix: str = "g.",
     separable: bool = False,
+    weights: str = "gaussian",
 ) -> dict:
-    """A Lightning-shaped checkpoint dict: ``{"state_dict": {"g.<name>": ...}, "hyper_parameters": {...}}``."""
+    """A Lightning-shaped checkpoint dict: ``{"state_dict": {"g.<name>": ...}, "hyper_parameters": {...}}``.  ``weights``:
+    "gaussian" (one scale per tensor) or "trained_like" (``trained_like``: per-channel scale spread 2^+-10, 1 % outliers x 100)."""
     arch = arch or default_arch()
     sd = synthetic_state_dict(arch, seed=seed, output_gain=output_gain, separable=separable)
+    if weights == "trained_like":
+        sd = trained_like(sd, arch, seed=seed + 1)
+    elif weights != "gaussian":
+        raise ValueError(weights)
     if separable:  # as e3conv_separable.yaml:14-19 reaches the checkpoint's hyper-parameters (a partial of ConvBlock with conv = SeparableConv)
         arch = dict(arch, hidden_layer_factory={"_target_": "jamun.e3tools.nn.ConvBlock", "_partial_": True,
                                                 "conv": {"_target_": "jamun.e3tools.nn.SeparableConv", "_partial_": True}})

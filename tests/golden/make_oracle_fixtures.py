@@ -59,20 +59,57 @@ def molecules(kind):
     raise KeyError(kind)
 
 
-def setup(kind, preset, dtype=torch.float32, separable=False):
+# Hyper-parameter points / architectures / weight distributions beyond the default one, each with the reference file that ships it
+# ("A, sigma and max_radius are per-checkpoint values, never hard-code").  `ckpt`: keyword arguments of
+# jamun_amd.synth.synthetic_checkpoint; `sigma`: the noise level of the forward.
+VARIANTS = {
+    "default": dict(ckpt={}, sigma=SIGMA),
+    # configs/experiment/train_test.yaml:7-8 (n_layers: 2)
+    "nl2": dict(ckpt=dict(arch=synth.default_arch(n_layers=2)), sigma=SIGMA),
+    # hydra_config/model/arch/e3conv_separable.yaml:6 (SeparableConv, n_layers: 4)
+    "sep_nl4": dict(ckpt=dict(arch=synth.default_arch(n_layers=4), separable=True), sigma=SIGMA),
+    # configs/experiment/train_idrome_cg.yaml:13-17 (sigma 0.25, max_radius 6.0, average_squared_distance 9.5): on nm-scale
+    # molecules every atom of a molecule above 33 atoms sits at the 32-neighbour cap and the radial basis is far below its first centre
+    "idrome": dict(ckpt=dict(max_radius=6.0, average_squared_distance=9.5), sigma=0.25),
+    # configs/experiment/train_test_single_shape.yaml:9 (max_radius: 1000)
+    "r1000": dict(ckpt=dict(max_radius=1000.0), sigma=SIGMA),
+    # a narrower hidden representation than e3conv.yaml's 120x0e + 32x1e
+    "h64x16": dict(ckpt=dict(arch=synth.default_arch(irreps_hidden="64x0e + 16x1e")), sigma=SIGMA),
+    # "trained-like" weights (synth.trained_like: per-channel scale spread 2^+-10, 1 % outliers x 100), a second seed
+    "trained": dict(ckpt=dict(weights="trained_like", seed=1), sigma=SIGMA),
+    "sep_trained": dict(ckpt=dict(weights="trained_like", seed=1, separable=True), sigma=SIGMA),
+}
+
+
+def variant_checkpoint(variant, output_gain=GAINS["strong"]):
+    return synth.synthetic_checkpoint(output_gain=output_gain, **VARIANTS[variant]["ckpt"])
+
+
+def variant_hparams(ckpt):
+    hp = ckpt["hyper_parameters"]
+    arch = {k: v for k, v in hp["arch"].items() if k != "hidden_layer_factory"}
+    return od.default_hparams(max_radius=hp["max_radius"], average_squared_distance=hp["average_squared_distance"],
+                              conv="separable" if "hidden_layer_factory" in hp["arch"] else "conv", **arch)
+
+
+def setup(kind, preset, dtype=torch.float32, separable=False, variant=None):
     mols = molecules(kind)
     topo = og.collate([{k: v for k, v in m.items() if torch.is_tensor(v)} for m in mols])
+    if variant is not None:
+        ck = variant_checkpoint(variant, GAINS[preset])
+        return mols, topo, {k[2:]: v.to(dtype) for k, v in ck["state_dict"].items()}, variant_hparams(ck)
     sd = synth.synthetic_state_dict(output_gain=GAINS[preset], separable=separable)
     p = {k: v.to(dtype) for k, v in sd.items()}
     return mols, topo, p, od.default_hparams(conv="separable" if separable else "conv")
 
 
-def forward_case(kind, with_layers, separable=False):
-    mols, topo, p, hp = setup(kind, "strong", separable=separable)
+def forward_case(kind, with_layers, separable=False, variant=None):
+    mols, topo, p, hp = setup(kind, "strong", separable=separable, variant=variant)
+    sigma = VARIANTS[variant]["sigma"] if variant else SIGMA
     torch.manual_seed(2)
-    y = topo["pos"] + SIGMA * torch.randn_like(topo["pos"])
-    x, inter = od.xhat(y, topo, SIGMA, p, hp, return_intermediates=True)
-    s = od.score(y, topo, SIGMA, p, hp)
+    y = topo["pos"] + sigma * torch.randn_like(topo["pos"])
+    x, inter = od.xhat(y, topo, sigma, p, hp, return_intermediates=True)
+    s = od.score(y, topo, sigma, p, hp)
     out = dict(y=y, xhat=x, score=s, g=inter["g"], deg=torch.bincount(inter["edge_index"][1], minlength=y.shape[0]),
                n_edges=torch.tensor(inter["edge_index"].shape[1]))
     if with_layers:
@@ -81,8 +118,8 @@ def forward_case(kind, with_layers, separable=False):
     return out
 
 
-def walk_case(kind, integrator, steps, preset, max_steps=None):
-    mols, topo, p, hp = setup(kind, preset)
+def walk_case(kind, integrator, steps, preset, max_steps=None, variant=None):
+    mols, topo, p, hp = setup(kind, preset, variant=variant)
     g = torch.Generator().manual_seed(42)
     noise = torch.randn(steps + 1, topo["pos"].shape[0], 3, generator=g)
     run_steps = steps if max_steps is None else min(steps, max_steps)
@@ -116,6 +153,17 @@ CASES = {
     "oracle_forward_sep_ragged": lambda **kw: forward_case("ragged", False, separable=True),
     "oracle_forward_sep_chig93x2": lambda **kw: forward_case("chig93x2", False, separable=True),
     "oracle_forward_cfg4kinds": lambda **kw: forward_case("cfg4kinds", False),
+    # beyond the default hyper-parameter point / architecture / weight distribution (VARIANTS above)
+    "oracle_forward_nl2_ragged": lambda **kw: forward_case("ragged", True, variant="nl2"),
+    "oracle_forward_sep_nl4_ragged": lambda **kw: forward_case("ragged", True, variant="sep_nl4"),
+    "oracle_forward_idrome_ragged": lambda **kw: forward_case("ragged", True, variant="idrome"),
+    "oracle_forward_idrome_dense70": lambda **kw: forward_case("dense70", False, variant="idrome"),
+    "oracle_forward_r1000_ragged": lambda **kw: forward_case("ragged", True, variant="r1000"),
+    "oracle_forward_h64x16_ragged": lambda **kw: forward_case("ragged", True, variant="h64x16"),
+    "oracle_forward_trained_chain17x6": lambda **kw: forward_case("chain17x6", True, variant="trained"),
+    "oracle_forward_trained_ragged": lambda **kw: forward_case("ragged", True, variant="trained"),
+    "oracle_forward_sep_trained_ragged": lambda **kw: forward_case("ragged", True, variant="sep_trained"),
+    "oracle_walk_baoab_trained_ag4_12": lambda max_steps=None, **kw: walk_case("ag4", "baoab", 12, "stable", max_steps, variant="trained"),
     "oracle_walk_baoab_chig93_6": lambda max_steps=None, **kw: walk_case("chig93x2", "baoab", 6, "stable", max_steps),
     "oracle_walk_baoab_chig166_4": lambda max_steps=None, **kw: walk_case("chig166x2", "baoab", 4, "stable", max_steps),
     "oracle_walk_baoab_ag4_50_mid": lambda max_steps=None, **kw: walk_case("ag4", "baoab", 50, "mid", max_steps),

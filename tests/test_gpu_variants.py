@@ -1,0 +1,140 @@
+"""GPU parity beyond the default hyper-parameter point (``-m gpu``): other depths, the separable architecture at its shipped depth,
+the noise level / cutoff / normalisation of the reference's other experiment files, a narrower hidden representation, and a
+"trained-like" weight distribution — each against cached CPU-oracle outputs (``tests/golden/make_oracle_fixtures.py: VARIANTS``,
+which cites the reference file of every point).  Tolerances as ``test_gpu_parity.py``: x-hat <= 1e-5 nm RMSD, per-layer features
+<= 2e-5 of the layer maximum, edge structure exact.
+"""
+import importlib.util
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+RMSD_TOL_NM = 1e-5
+HERE = os.path.dirname(os.path.abspath(__file__))
+GOLDEN = os.path.join(HERE, "golden")
+
+
+def _mk():
+    spec = importlib.util.spec_from_file_location("make_oracle_fixtures", os.path.join(GOLDEN, "make_oracle_fixtures.py"))
+    mk = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mk)
+    return mk
+
+
+def _golden(name):
+    return {k: torch.tensor(v) for k, v in np.load(os.path.join(GOLDEN, name + ".npz")).items()}
+
+
+def rmsd(a, b):
+    return ((a.double().cpu() - b.double().cpu()) ** 2).sum(-1).mean().sqrt().item()
+
+
+# (variant, molecules, what jamun_sampler_stats must report — the kernels the case is meant to exercise)
+CASES = [
+    ("nl2", "ragged", dict(dg_mode=4, dg_emu=1)),
+    ("sep_nl4", "ragged", dict()),
+    ("idrome", "ragged", dict(dg_emu=1)),
+    ("idrome", "dense70", dict(dg_emu=1)),
+    ("r1000", "ragged", dict(dg_emu=1)),
+    ("h64x16", "ragged", dict()),
+    ("trained", "chain17x6", dict(dg_mode=4, init_path=3, dg_emu=1)),
+    ("trained", "ragged", dict(dg_mode=4, init_path=3, dg_emu=1)),
+    ("sep_trained", "ragged", dict()),
+]
+
+
+@pytest.mark.parametrize("variant,kind,want", CASES, ids=[f"{v}-{k}" for v, k, _ in CASES])
+def test_forward_matches_oracle_at_other_hyperparameters(variant, kind, want):
+    from jamun_amd.data import WalkerBatch
+    from jamun_amd.model import Denoiser
+
+    mk = _mk()
+    dev = torch.device("cuda", 0)
+    ref = _golden(f"oracle_forward_{variant}_{kind}")
+    sigma = mk.VARIANTS[variant]["sigma"]
+    ck = mk.variant_checkpoint(variant)
+    model = Denoiser.from_checkpoint_dict(ck).to(dev)
+    batch = WalkerBatch.from_molecules(mk.molecules(kind)).to(dev)
+    smp = model.sampler_for(batch, sigma)
+    y = ref["y"].to(dev)
+    x = smp.xhat(y)
+    st = smp.stats()
+    for k, v in want.items():
+        assert st[k] == v, (k, st)
+    assert torch.equal(smp.debug_read(1).cpu().flatten().long(), ref["deg"])
+    assert st["n_edges"] == int(ref["n_edges"])
+    if variant == "idrome":  # everything inside the cutoff: molecules above 33 atoms sit at torch_cluster's 32-neighbour cap
+        deg = ref["deg"]
+        assert int(deg.max()) >= 32 and (deg >= 32).float().mean() > 0.3
+    n_layers = ck["hyper_parameters"]["arch"]["n_layers"]
+    assert f"x{n_layers}" in ref and f"x{n_layers + 1}" not in ref
+    for l in range(n_layers + 1):
+        xl, r = smp.debug_read(0, l).cpu(), ref[f"x{l}"]
+        err = (xl - r).abs().max().item() / max(r.abs().max().item(), 1e-6)
+        assert err < 2e-5, (l, err)
+        if variant.endswith("trained"):
+            # per CHANNEL: the features of this preset spread over 2^+-10 between channels, so an error measured against the
+            # layer maximum would say nothing about the small channels (which the next layer multiplies by large weights)
+            cmax = r.abs().amax(0)
+            cerr = ((xl - r).abs().amax(0) / cmax.clamp_min(1e-30)).max().item()
+            assert cerr < 1e-4, (l, cerr)
+    g = smp.debug_read(2).cpu()
+    assert (g - ref["g"]).abs().max().item() < 2e-5 * max(ref["g"].abs().max().item(), 1.0)
+    assert rmsd(x, ref["xhat"]) <= RMSD_TOL_NM, rmsd(x, ref["xhat"])
+    s = smp.score(y)
+    assert rmsd(s, ref["score"]) <= RMSD_TOL_NM / sigma**2
+
+
+def test_trained_like_weights_through_every_f16x3_kernel_against_the_fp32_kernels(monkeypatch):
+    """Kernel against kernel on the trained-like preset: the f16x3 paths (k_conv_mf, k_conv_mfi, k_node_update_h, k_edge_h16) against
+    the general fp32 kernels (k_conv, k_node_update, k_edge_h) on the same input, block by block — per channel."""
+    from jamun_amd.data import WalkerBatch
+    from jamun_amd.model import Denoiser
+    from jamun_amd.native import NativeSampler
+
+    mk = _mk()
+    dev = torch.device("cuda", 0)
+    ref = _golden("oracle_forward_trained_chain17x6")
+    model = Denoiser.from_checkpoint_dict(mk.variant_checkpoint("trained")).to(dev)
+    batch = WalkerBatch.from_molecules(mk.molecules("chain17x6")).to(dev)
+    fast = NativeSampler(model._native, 0.04, batch, dev)
+    st = fast.stats()
+    assert st["dg_mode"] == 4 and st["init_path"] == 3 and st["dg_emu"] == 1
+    for e in ("JAMUN_NO_DG", "JAMUN_NO_FUSED", "JAMUN_NODE_FP32", "JAMUN_EDGE_H_FP32", "JAMUN_NO_INIT_TABLE"):
+        monkeypatch.setenv(e, "1")
+    general = NativeSampler(model._native, 0.04, batch, dev)
+    assert general.stats()["conv_path"] == 0
+    y = ref["y"].to(dev)
+    fast.build_edges(y)
+    general.build_edges(y)
+    a0, b0 = fast.conv_block(0).cpu(), general.conv_block(0).cpu()
+    worst = ((a0 - b0).abs().amax(0) / b0.abs().amax(0).clamp_min(1e-30)).max().item()
+    for l in range(1, 6):
+        x_in = ref[f"x{l - 1}"].to(dev)
+        a, b = fast.conv_block(l, x_in).cpu(), general.conv_block(l, x_in).cpu()
+        worst = max(worst, ((a - b).abs().amax(0) / b.abs().amax(0).clamp_min(1e-30)).max().item())
+    assert worst < 5e-5, worst
+
+
+def test_walk_with_trained_like_weights_matches_oracle():
+    from jamun_amd import native
+    from jamun_amd.data import WalkerBatch
+    from jamun_amd.model import Denoiser
+
+    mk = _mk()
+    dev = torch.device("cuda", 0)
+    ref = _golden("oracle_walk_baoab_trained_ag4_12")
+    model = Denoiser.from_checkpoint_dict(mk.variant_checkpoint("trained", mk.GAINS["stable"])).to(dev)
+    batch = WalkerBatch.from_molecules(mk.molecules("ag4")).to(dev)
+    smp = model.sampler_for(batch, 0.04)
+    steps = 12
+    noise = ref["noise"]
+    y, v = ref["y0"].to(dev).clone(), noise[1].to(dev).clone()
+    params = native.make_mcmc_params(steps, 0.04, 1.0, 1.0, 1.0, 100.0)
+    y_traj, score_traj, xhat_traj, xhat = smp.walk("baoab", y, v, params, noise[2 : steps + 1].to(dev).contiguous(), 0, True)
+    worst = max(rmsd(xhat_traj[t], ref["xhat_traj"][t]) for t in range(steps))
+    assert worst <= RMSD_TOL_NM, worst
