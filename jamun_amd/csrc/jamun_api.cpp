@@ -110,6 +110,9 @@ struct DgDev {
   float4* wm = nullptr;   // jamun_conv_mf.hip: [k][4 matrix waves][40 blocks], K index permuted to the forming MFMA's accumulator layout
   int sB = 0, sBt = 0, sTw = 0;
   float hmax2 = 2.f;
+  // f16x3 balancing (build_layer): gx [216] 2^e_u per feature element (layout of a feature row), gT [128] the T pre-pass's input factors,
+  // cf0 [160] / cf1 [32] / cfT [32] the inverse column scales of the scalar / vector outputs / T
+  float *gx = nullptr, *gT = nullptr, *cf0 = nullptr, *cf1 = nullptr, *cfT = nullptr;
 };
 struct SepDev {
   float *w2p = nullptr, *wl0 = nullptr, *wl1 = nullptr;  // null: not a SeparableConv layer
@@ -128,8 +131,9 @@ struct LayerDev {
   int tab_sB = 0, tab_ut = 0;
   float4 *wcat0 = nullptr, *wcat1 = nullptr;  // node update: [W_self ; W_skip] as MFMA fragments
   int K0p = 0, K1p = 0;
-  float4 *wh0 = nullptr, *wh1 = nullptr;      // ... and scaled, split hi + lo for the f16x3 kernel (jamun_node.hip)
-  int K0h = 0, K1h = 0, sW0 = 0, sW1 = 0;
+  float4 *wh0 = nullptr, *wh1 = nullptr;      // ... and balanced per row / column, split hi + lo for the f16x3 kernel (jamun_node.hip)
+  int K0h = 0, K1h = 0;
+  float *kga0 = nullptr, *kga1 = nullptr, *kgx = nullptr, *cg0 = nullptr, *cg1 = nullptr;  // its row (input) / column (output) powers of two
   float* mix = nullptr;
   int in0 = 0, in1 = 0, XSin = 0;
   int64_t tp_numel = 0;
@@ -142,6 +146,7 @@ void free_fused(FusedDev& f) {
 
 void free_dg(DgDev& d) {
   hipFree(d.wx); hipFree(d.wd); hipFree(d.wv); hipFree(d.wt); hipFree(d.wxh); hipFree(d.wth); hipFree(d.wm);
+  hipFree(d.gx); hipFree(d.gT); hipFree(d.cf0); hipFree(d.cf1); hipFree(d.cfT);
   d = DgDev{};
 }
 
@@ -388,7 +393,7 @@ struct jamun_sampler {
     for (auto& L : layers) {
       free_problem(L.p0); free_problem(L.p1); free_fused(L.fu); free_dg(L.dg);
       hipFree(L.sep.w2p); hipFree(L.sep.wl0); hipFree(L.sep.wl1);
-      hipFree(L.wcat0); hipFree(L.wcat1); hipFree(L.wh0); hipFree(L.wh1); hipFree(L.mix); hipFree(L.tt); hipFree(L.tt2); hipFree(L.tabw);
+      hipFree(L.wcat0); hipFree(L.wcat1); hipFree(L.wh0); hipFree(L.wh1); hipFree(L.kga0); hipFree(L.kga1); hipFree(L.kgx); hipFree(L.cg0); hipFree(L.cg1); hipFree(L.mix); hipFree(L.tt); hipFree(L.tt2); hipFree(L.tabw);
     }
     hipFree(w_gate); hipFree(w_vec); hipFree(w_out);
     hipFree(yc); hipFree(h); hipFree(partial0); hipFree(partial1); hipFree(g); hipFree(tmp);
@@ -482,17 +487,38 @@ void build_layer_common(const jamun_model& m, const std::string& prefix, const s
   };
   L.wcat0 = dev_upload(pack_cat(wf0, mul0, ws0, in0, mul0, L.K0p));
   L.wcat1 = dev_upload(pack_cat(wf1, mul1, ws1, in1, std::max(mul1, 1), L.K1p));
-  // f16x3 node update: the same matrices scaled to the top of the f16 range and split; K padded to 16
-  auto pack_cat_h = [](const std::vector<float>& wself, int ks, const std::vector<float>& wskip, int kk, int ncol, int& Kh, int& sW) {
+  // f16x3 node update: the same matrices balanced by exact powers of two — row K (an input channel) times 2^-e_K so that its largest
+  // magnitude sits in [0.5, 1), then column w times 2^sW_w so that its largest sits in [2^13, 2^14) — and split hi + lo; K padded to 16.
+  // rowf[K] = 2^e_K multiplies the input when the kernel stages it, colf[w] = 2^-sW_w the output column.
+  auto pow2_above = [](double v) { int ex = 0; if (v > 0 && std::isfinite(v)) std::frexp(v, &ex); return std::max(-40, std::min(40, ex)); };  // v < 2^ex
+  auto pack_cat_h = [&](const std::vector<float>& wself, int ks, const std::vector<float>& wskip, int kk, int ncol, int& Kh,
+                        std::vector<float>& rowf, std::vector<float>& colf) {
     Kh = (ks + kk + 15) & ~15;
-    double wmax = 0;
-    for (int r = 0; r < ks; ++r) for (int c = 0; c < ncol; ++c) wmax = std::max(wmax, std::fabs((double)wself[(size_t)r * ncol + c]));
-    for (int r = 0; r < kk; ++r) for (int c = 0; c < ncol; ++c) wmax = std::max(wmax, std::fabs((double)wskip[(size_t)r * ncol + c]));
-    int ex = 0;
-    if (wmax > 0 && std::isfinite(wmax)) std::frexp(wmax, &ex);
-    sW = std::max(-40, std::min(40, 14 - ex));
-    const double sc = std::ldexp(1.0, sW);
+    auto W = [&](int row, int c) -> double {
+      if (c >= ncol) return 0.0;
+      if (row < ks) return wself[(size_t)row * ncol + c];
+      if (row < ks + kk) return wskip[(size_t)(row - ks) * ncol + c];
+      return 0.0;
+    };
+    rowf.assign(Kh, 1.f);
+    std::vector<double> rinv(Kh, 1.0);
+    for (int r = 0; r < ks + kk; ++r) {
+      double m = 0;
+      for (int c = 0; c < ncol; ++c) m = std::max(m, std::fabs(W(r, c)));
+      const int ex = pow2_above(m);
+      rowf[r] = (float)std::ldexp(1.0, ex);
+      rinv[r] = std::ldexp(1.0, -ex);
+    }
     const int nt = (ncol + 31) / 32, nst = Kh / 16;
+    colf.assign((size_t)nt * 32, 0.f);
+    std::vector<double> csc((size_t)nt * 32, 1.0);
+    for (int c = 0; c < ncol; ++c) {
+      double m = 0;
+      for (int r = 0; r < ks + kk; ++r) m = std::max(m, std::fabs(W(r, c) * rinv[r]));
+      const int sW = 14 - pow2_above(m);
+      csc[c] = std::ldexp(1.0, sW);
+      colf[c] = (float)std::ldexp(1.0, -sW);
+    }
     std::vector<float4> out((size_t)nt * nst * 2 * 64, make_float4(0.f, 0.f, 0.f, 0.f));
     for (int t = 0; t < nt; ++t)
       for (int st = 0; st < nst; ++st)
@@ -503,12 +529,7 @@ void build_layer_common(const jamun_model& m, const std::string& prefix, const s
             uint16_t hp[2], lp[2];
             for (int e = 0; e < 2; ++e) {
               const int row = 16 * st + 8 * hh + 2 * i + e;
-              double v = 0.0;
-              if (c < ncol) {
-                if (row < ks) v = wself[(size_t)row * ncol + c];
-                else if (row < ks + kk) v = wskip[(size_t)(row - ks) * ncol + c];
-              }
-              split_f16(v * sc, hp[e], lp[e]);
+              split_f16(W(row, c) * rinv[row] * csc[c], hp[e], lp[e]);
             }
             h[i] = (uint32_t)hp[0] | ((uint32_t)hp[1] << 16);
             l[i] = (uint32_t)lp[0] | ((uint32_t)lp[1] << 16);
@@ -519,8 +540,20 @@ void build_layer_common(const jamun_model& m, const std::string& prefix, const s
         }
     return out;
   };
-  L.wh0 = dev_upload(pack_cat_h(wf0, mul0, ws0, in0, mul0, L.K0h, L.sW0));
-  L.wh1 = dev_upload(pack_cat_h(wf1, mul1, ws1, in1, std::max(mul1, 1), L.K1h, L.sW1));
+  {
+    std::vector<float> r0, c0, r1, c1;
+    L.wh0 = dev_upload(pack_cat_h(wf0, mul0, ws0, in0, mul0, L.K0h, r0, c0));
+    L.wh1 = dev_upload(pack_cat_h(wf1, mul1, ws1, in1, std::max(mul1, 1), L.K1h, r1, c1));
+    // row factors in the layouts the kernel reads them: activated scalars [mul0], gated vectors [mul1], and the channels of x_in in
+    // x_in's own layout (in0 scalars, then in1 vectors x 3 components)
+    std::vector<float> ka0(r0.begin(), r0.begin() + mul0), ka1(std::max(mul1, 1), 1.f), kx((size_t)((in0 + 3 * in1 + 3) & ~3), 1.f);
+    for (int u = 0; u < mul1; ++u) ka1[u] = r1[u];
+    for (int u = 0; u < in0; ++u) kx[u] = r0[mul0 + u];
+    for (int u = 0; u < in1; ++u)
+      for (int mm = 0; mm < 3; ++mm) kx[in0 + 3 * u + mm] = r1[mul1 + u];
+    ka0.resize((size_t)((mul0 + 3) & ~3) + 4, 1.f);
+    L.kga0 = dev_upload(ka0); L.kga1 = dev_upload(ka1); L.kgx = dev_upload(kx); L.cg0 = dev_upload(c0); L.cg1 = dev_upload(c1);
+  }
 }
 
 // SeparableConv block (src/jamun/e3tools/nn/_tensor_product.py:27-47): depth-wise "uvu" instructions in e3nn order — for every
@@ -909,28 +942,63 @@ LayerDev build_layer(const jamun_model& m, const std::string& prefix, const std:
     L.dg.wd = dev_upload(wd);
     L.dg.wv = dev_upload(wv);
     L.dg.wt = dev_upload(wt);
-    // f16x3 contraction: the same weights scaled by 2^sB (largest magnitude just below 2^14) and split into hi + lo halves;
+    // f16x3 contraction: the same weights BALANCED by exact powers of two and split into hi + lo halves.  An f16 pair carries 22 bits
+    // only while its lo half is a normal number, i.e. within 2^-14 .. 2^-17 of the largest value sharing its scale, and trained
+    // checkpoints spread their channels over many octaves (a feature channel that is small has large weights, and the other way
+    // round), so one scale per tensor is not enough:
+    //   * input channel u: its weight rows (k, u) times 2^-e_u (largest magnitude over k and columns -> [0.5, 1)); the kernels multiply
+    //     the feature rows by 2^e_u when they stage them (DgDev::gx, in the layout of a feature row), BEFORE they measure the maxima their
+    //     dynamic scales come from — every input then enters with the weight of its contribution.  The vector channel u shares one
+    //     exponent over its three blocks (dot, x1, cross); the T pre-pass has its own (gT);
+    //   * output column w: times 2^sB_w (largest -> [2^13, 2^14)); undone per column in the kernels' epilogues (cf0 / cf1 / cfT).
     // one block = 64 lanes x 8 halves = the B fragment of one v_mfma_f32_32x32x16_f16 (lane (c, hh): inputs 16 g + 8 hh + j,
     // column 32 t + c) or v_mfma_f32_16x16x32_f16 (lane (c16, kq): kappa = 32 G + 8 kq + j, column 16 ch + c16)
     {
-      double wmax = 0;
-      for (int k = 0; k < n_k; ++k) {
-        for (const UEntry& e : x0e) for (int col = 0; col < G0; ++col) wmax = std::max(wmax, std::fabs(Wk(k, e.wbase + col) * e.scale));
-        for (const UEntry& e : dote) for (int col = 0; col < G0; ++col) wmax = std::max(wmax, std::fabs(Wk(k, e.wbase + col) * e.scale));
-        for (const UEntry& e : x1e) for (int col = 0; col < G1; ++col) wmax = std::max(wmax, std::fabs(Wk(k, e.wbase + col) * e.scale));
-        for (const UEntry& e : crosse) for (int col = 0; col < G1; ++col) wmax = std::max(wmax, std::fabs(Wk(k, e.wbase + col) * e.scale));
+      auto pow2_above = [](double v) { int ex = 0; if (v > 0 && std::isfinite(v)) std::frexp(v, &ex); return std::max(-40, std::min(40, ex)); };  // v < 2^ex
+      auto row_exp = [&](const UEntry& e, int ncols) {
+        double m = 0;
+        for (int k = 0; k < n_k; ++k) for (int col = 0; col < ncols; ++col) m = std::max(m, std::fabs(Wk(k, e.wbase + col) * e.scale));
+        return m;
+      };
+      std::vector<int> e0(120), e1(32), eT(120);
+      for (int u = 0; u < 120; ++u) { e0[u] = pow2_above(row_exp(x0e[u], G0)); eT[u] = pow2_above(row_exp(x0ve[u], G1)); }
+      for (int u = 0; u < 32; ++u) e1[u] = pow2_above(std::max(row_exp(dote[u], G0), std::max(row_exp(x1e[u], G1), row_exp(crosse[u], G1))));
+      auto Wg = [&](const UEntry& e, int ex, int k, int col) { return std::ldexp(Wk(k, e.wbase + col) * e.scale, -ex); };
+      std::vector<double> sc0(160, 1.0), sc1(32, 1.0), scT(32, 1.0);  // column scales 2^sB_w
+      std::vector<float> cf0(160, 0.f), cf1(32, 0.f), cfT(32, 0.f);   // ... and their inverses for the epilogues
+      for (int col = 0; col < G0; ++col) {
+        double m = 0;
+        for (int k = 0; k < n_k; ++k) {
+          for (int u = 0; u < 120; ++u) m = std::max(m, std::fabs(Wg(x0e[u], e0[u], k, col)));
+          for (int u = 0; u < 32; ++u) m = std::max(m, std::fabs(Wg(dote[u], e1[u], k, col)));
+        }
+        const int sB = 14 - pow2_above(m);
+        sc0[col] = std::ldexp(1.0, sB); cf0[col] = (float)std::ldexp(1.0, -sB);
       }
-      int ex = 0;
-      if (wmax > 0 && std::isfinite(wmax)) std::frexp(wmax, &ex);  // wmax < 2^ex
-      const int sB = std::max(-60, std::min(60, 14 - ex));
-      L.dg.sB = sB;
-      const double sc = std::ldexp(1.0, sB);
+      for (int col = 0; col < G1; ++col) {
+        double m = 0, mt = 0;
+        for (int k = 0; k < n_k; ++k) {
+          for (int u = 0; u < 32; ++u) m = std::max(m, std::max(std::fabs(Wg(x1e[u], e1[u], k, col)), std::fabs(Wg(crosse[u], e1[u], k, col))));
+          for (int u = 0; u < 120; ++u) mt = std::max(mt, std::fabs(Wg(x0ve[u], eT[u], k, col)));
+        }
+        const int sB = 14 - pow2_above(m), sT = 14 - pow2_above(mt);
+        sc1[col] = std::ldexp(1.0, sB); cf1[col] = (float)std::ldexp(1.0, -sB);
+        scT[col] = std::ldexp(1.0, sT); cfT[col] = (float)std::ldexp(1.0, -sT);
+      }
+      {
+        std::vector<float> gx(216), gT(128, 1.f);
+        for (int u = 0; u < 120; ++u) { gx[u] = (float)std::ldexp(1.0, e0[u]); gT[u] = (float)std::ldexp(1.0, eT[u]); }
+        for (int u = 0; u < 32; ++u) for (int mm = 0; mm < 3; ++mm) gx[120 + 3 * u + mm] = (float)std::ldexp(1.0, e1[u]);
+        L.dg.gx = dev_upload(gx); L.dg.gT = dev_upload(gT);
+        L.dg.cf0 = dev_upload(cf0); L.dg.cf1 = dev_upload(cf1); L.dg.cfT = dev_upload(cfT);
+      }
+      L.dg.sB = 0;  // (the column factors carry the weight scales)
       auto pack8 = [&](const double (&v)[8], float4& hi, float4& lo) {
         uint32_t h[4], l[4];
         for (int i = 0; i < 4; ++i) {
           uint16_t h0, l0, h1, l1;
-          split_f16(v[2 * i] * sc, h0, l0);
-          split_f16(v[2 * i + 1] * sc, h1, l1);
+          split_f16(v[2 * i], h0, l0);
+          split_f16(v[2 * i + 1], h1, l1);
           h[i] = (uint32_t)h0 | ((uint32_t)h1 << 16);
           l[i] = (uint32_t)l0 | ((uint32_t)l1 << 16);
         }
@@ -946,7 +1014,7 @@ LayerDev build_layer(const jamun_model& m, const std::string& prefix, const std:
               double v[8];
               for (int j = 0; j < 8; ++j) {
                 const int u = 16 * g + 8 * hh + j;
-                v[j] = (u < 120 && col < G0) ? Wk(k, x0e[u].wbase + col) * x0e[u].scale : 0.0;
+                v[j] = (u < 120 && col < G0) ? Wg(x0e[u], e0[u], k, col) * sc0[col] : 0.0;
               }
               const size_t b = ((((size_t)k * 5 + t) * 8 + g) * 2) * 64 + lane;
               pack8(v, wxh[b], wxh[b + 64]);
@@ -955,7 +1023,7 @@ LayerDev build_layer(const jamun_model& m, const std::string& prefix, const std:
               double v[8];
               for (int j = 0; j < 8; ++j) {
                 const int u = 16 * g + 8 * hh + j;
-                v[j] = col < G0 ? Wk(k, dote[u].wbase + col) * dote[u].scale : 0.0;
+                v[j] = col < G0 ? Wg(dote[u], e1[u], k, col) * sc0[col] : 0.0;
               }
               const size_t b = ((((size_t)k * 5 + t) * 2 + g) * 2) * 64 + lane;
               pack8(v, wdh[b], wdh[b + 64]);
@@ -969,7 +1037,7 @@ LayerDev build_layer(const jamun_model& m, const std::string& prefix, const std:
               for (int j = 0; j < 8; ++j) {
                 const int kap = 32 * G + 8 * kq + j;  // input order of the vector planes' A tiles: 2 u + {x1, cross}
                 const UEntry& e = (kap & 1) ? crosse[kap >> 1] : x1e[kap >> 1];
-                v[j] = Wk(k, e.wbase + col) * e.scale;
+                v[j] = Wg(e, e1[kap >> 1], k, col) * sc1[col];
               }
               const size_t b = ((((size_t)k * 2 + ch) * 2 + G) * 2) * 64 + lane;
               pack8(v, wvh[b], wvh[b + 64]);
@@ -997,14 +1065,7 @@ LayerDev build_layer(const jamun_model& m, const std::string& prefix, const std:
       L.dg.wxh = dev_upload(wh);
       // T pre-pass (k_tprod_h): scalar inputs -> vector rows, weights as the A operand of v_mfma_f32_32x32x16_f16
       {
-        double tmax = 0;
-        for (int k = 0; k < n_k; ++k)
-          for (const UEntry& e : x0ve)
-            for (int c = 0; c < G1; ++c) tmax = std::max(tmax, std::fabs(Wk(k, e.wbase + c) * e.scale));
-        int ext = 0;
-        if (tmax > 0 && std::isfinite(tmax)) std::frexp(tmax, &ext);
-        L.dg.sBt = std::max(-60, std::min(60, 14 - ext));
-        const double sct = std::ldexp(1.0, L.dg.sBt);
+        L.dg.sBt = 0;  // (balanced per input channel (gT) and per column (cfT), as the contraction's weights)
         std::vector<float4> wth((size_t)n_k * 16 * 64);
         for (int k = 0; k < n_k; ++k)
           for (int g = 0; g < 8; ++g)
@@ -1013,7 +1074,7 @@ LayerDev build_layer(const jamun_model& m, const std::string& prefix, const std:
               double v[8];
               for (int j = 0; j < 8; ++j) {
                 const int u = 16 * g + 8 * hh + j;
-                v[j] = (u < 120 && c < G1) ? Wk(k, x0ve[u].wbase + c) * x0ve[u].scale * sct / sc : 0.0;
+                v[j] = (u < 120 && c < G1) ? Wg(x0ve[u], eT[u], k, c) * scT[c] : 0.0;
               }
               const size_t b = ((size_t)k * 16 + 2 * g) * 64 + lane;
               pack8(v, wth[b], wth[b + 64]);
@@ -1029,7 +1090,7 @@ LayerDev build_layer(const jamun_model& m, const std::string& prefix, const std:
         for (int k = 0; k < n_k; ++k)
           for (int c = 0; c < G1; ++c) {
             double cs = 0;
-            for (const UEntry& e : x0ve) cs += std::fabs(Wk(k, e.wbase + c) * e.scale);
+            for (int u = 0; u < 120; ++u) cs += std::fabs(Wg(x0ve[u], e0[u], k, c));  // (the gauge of the conv kernel's scalar channels: |T| <= max|x'| x this)
             wcs = std::max(wcs, cs);
           }
         int exs = 0;
@@ -1051,8 +1112,8 @@ LayerDev build_layer(const jamun_model& m, const std::string& prefix, const std:
                   double v[8];
                   for (int p = 0; p < 8; ++p) {
                     const int u = 32 * w + u_of(s2, hh, p);
-                    if (w < 4) v[p] = (u < 120 && col < G0) ? Wk(k, x0e[u].wbase + col) * x0e[u].scale : 0.0;
-                    else v[p] = col < G0 ? Wk(k, dote[u - 128].wbase + col) * dote[u - 128].scale : 0.0;
+                    if (w < 4) v[p] = (u < 120 && col < G0) ? Wg(x0e[u], e0[u], k, col) * sc0[col] : 0.0;
+                    else v[p] = col < G0 ? Wg(dote[u - 128], e1[u - 128], k, col) * sc0[col] : 0.0;
                   }
                   const size_t b = kb + (size_t)(20 * w + 2 * (2 * n + s2)) * 64 + lane;
                   pack8m(v, wm[b], wm[b + 64]);
@@ -1063,7 +1124,7 @@ LayerDev build_layer(const jamun_model& m, const std::string& prefix, const std:
                   double v[8];
                   for (int p = 0; p < 8; ++p) {
                     const UEntry& e = part == 0 ? x1e[u_of(s2, hh, p)] : crosse[u_of(s2, hh, p)];
-                    v[p] = c < G1 ? Wk(k, e.wbase + c) * e.scale : 0.0;
+                    v[p] = c < G1 ? Wg(e, e1[u_of(s2, hh, p)], k, c) * sc1[c] : 0.0;
                   }
                   const size_t b = kb + (size_t)(100 + 8 * m + 4 * part + 2 * s2) * 64 + lane;
                   pack8m(v, wm[b], wm[b + 64]);
@@ -1268,6 +1329,7 @@ void run_layer(jamun_sampler* s, size_t l, const float* x_in, int XSin, float* x
       f.n_pad = s->n_pad; f.S = s->S; f.XS = XSin; f.n_atoms = s->n_atoms;
       f.tile_span = s->dg_tile_span; f.tile_atoms = s->dg_tile_atoms; f.segs = s->dg_segs; f.max_segs = s->dg_max_segs; f.nt0 = L.p0.nt;
       f.wm = L.dg.wm; f.Tt = s->dg_T; f.t_stride = s->dg_tstride; f.sB = L.dg.sB; f.sTw = L.dg.sTw;
+      f.gx = L.dg.gx; f.cf0 = L.dg.cf0; f.cf1 = L.dg.cf1;
       {
         int e3 = 0;
         std::frexp(1.5 * (double)L.dg.hmax2, &e3);  // 3 max|h~| < 2^e3
@@ -1276,7 +1338,7 @@ void run_layer(jamun_sampler* s, size_t l, const float* x_in, int XSin, float* x
       f.partial0 = s->partial0; f.partial1 = s->partial1; f.err = s->mf_err;
       {
         ProfScope pt(s, JAMUN_PROF_TPROD, st);
-        launch_tprod(x_in, XSin, s->n_atoms, s->hp.edge_attr_dim + 1, L.dg.wt, L.dg.wth, L.dg.sBt, s->dg_T, s->dg_tstride, st);
+        launch_tprod(x_in, XSin, s->n_atoms, s->hp.edge_attr_dim + 1, L.dg.wt, L.dg.wth, L.dg.gT, L.dg.cfT, s->dg_T, s->dg_tstride, st);
       }
       ProfScope ps(s, JAMUN_PROF_CONV0, st);
       if (launch_conv_mf(f, s->dg_grid, st) != 0) throw Err(JAMUN_ERR_INVALID, "matrix-formed conv launch failed (configuration not supported)");
@@ -1288,6 +1350,7 @@ void run_layer(jamun_sampler* s, size_t l, const float* x_in, int XSin, float* x
       f.row_blocks = s->dg_row_blocks ? 1 : 0; f.nt0 = L.p0.nt; f.alt = s->dg_mode;
       f.wx = L.dg.wx; f.wd = L.dg.wd; f.wv = L.dg.wv; f.T = s->dg_T; f.n_atoms = s->n_atoms;
       f.emu = s->dg_emu; f.wh = L.dg.wxh; f.sB = L.dg.sB; f.hmax2 = L.dg.hmax2;
+      f.gx = L.dg.gx; f.cf0 = L.dg.cf0; f.cf1 = L.dg.cf1;
       f.partial0 = s->partial0; f.partial1 = s->partial1;
       static const int dg_dbg = getenv("JAMUN_DG_DBG") ? atoi(getenv("JAMUN_DG_DBG")) : 0;
       f.dbg = dg_dbg;
@@ -1299,7 +1362,7 @@ void run_layer(jamun_sampler* s, size_t l, const float* x_in, int XSin, float* x
       }
       {
         ProfScope pt(s, JAMUN_PROF_TPROD, st);
-        launch_tprod(x_in, XSin, s->n_atoms, s->hp.edge_attr_dim + 1, L.dg.wt, s->dg_emu ? L.dg.wth : nullptr, L.dg.sBt, s->dg_T, 0, st);
+        launch_tprod(x_in, XSin, s->n_atoms, s->hp.edge_attr_dim + 1, L.dg.wt, s->dg_emu ? L.dg.wth : nullptr, L.dg.gT, L.dg.cfT, s->dg_T, 0, st);
       }
       ProfScope ps(s, JAMUN_PROF_CONV0, st);
       const int rcode = launch_conv_dg(f, s->dg_grid, st);
@@ -1340,10 +1403,11 @@ void run_layer(jamun_sampler* s, size_t l, const float* x_in, int XSin, float* x
     n.atom_nslab = dg_layer ? s->dg_atom_nslab : (L.fu.wpack ? s->atom_nslab : nullptr);
     n.max_slabs = dg_layer ? s->dg_n_slabs : (L.fu.wpack ? s->n_slabs : s->n_slices);
     if (L.sep.w2p) { n.n_slices = 1; n.atom_nslab = nullptr; n.max_slabs = 1; }  // SeparableConv writes the summed messages as ONE slab
-    n.wh0 = L.wh0; n.wh1 = L.wh1; n.K0h = L.K0h; n.K1h = L.K1h; n.sW0 = L.sW0; n.sW1 = L.sW1;
+    n.wh0 = L.wh0; n.wh1 = L.wh1; n.K0h = L.K0h; n.K1h = L.K1h;
+    n.kga0 = L.kga0; n.kga1 = L.kga1; n.kgx = L.kgx; n.cg0 = L.cg0; n.cg1 = L.cg1;
     {
       ProfScope ps(s, JAMUN_PROF_NODE, st);
-      static const bool nu_fp32 = getenv("JAMUN_NODE_FP32") != nullptr;  // (A/B aid: the v_mfma_f32_32x32x2_f32 kernel)
+      const bool nu_fp32 = getenv("JAMUN_NODE_FP32") != nullptr;  // (A/B aid: the v_mfma_f32_32x32x2_f32 kernel)
       if (!nu_fp32 && node_update_h_supported(n)) launch_node_update_h(n, st);
       else launch_node_update(n, st);
     }

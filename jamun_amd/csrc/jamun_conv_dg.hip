@@ -256,7 +256,10 @@ __global__ __launch_bounds__(DG_THREADS) void k_conv_dg(DgArgs a) {
           const int idx = base + q8 * DG_THREADS;
           const int j = idx / (DG_XST_ALT / 4), q = idx - j * (DG_XST_ALT / 4);
           v[q8] = make_float4(0.f, 0.f, 0.f, 0.f);
-          if (idx < total && j < rows && q < 30) v[q8] = *reinterpret_cast<const float4*>(a.x + (size_t)(s_lo + j) * a.XS + 4 * q);
+          if (idx < total && j < rows && q < 30) {
+            v[q8] = *reinterpret_cast<const float4*>(a.x + (size_t)(s_lo + j) * a.XS + 4 * q);
+            if constexpr (H) { const float4 g4 = reinterpret_cast<const float4*>(a.gx)[q]; v[q8] = make_float4(v[q8].x * g4.x, v[q8].y * g4.y, v[q8].z * g4.z, v[q8].w * g4.w); }
+          }
         }
 #pragma unroll
         for (int q8 = 0; q8 < DG_SBA; ++q8) {
@@ -277,7 +280,8 @@ __global__ __launch_bounds__(DG_THREADS) void k_conv_dg(DgArgs a) {
         for (int q8 = 0; q8 < DG_SBA; ++q8) {
           const int idx = min(base + q8 * DG_THREADS, total - 1);
           const float* __restrict__ p1 = a.x + (size_t)(s_lo + (idx >> 5)) * a.XS + 120 + 3 * (idx & 31);
-          v[q8] = make_float4(p1[0], tk[idx], p1[1], p1[2]);
+          const float g1 = H ? a.gx[120 + 3 * (idx & 31)] : 1.f;  // (f16x3: the channel's power of two, DgArgs::gx; T stays in true units)
+          v[q8] = make_float4(p1[0] * g1, tk[idx], p1[1] * g1, p1[2] * g1);
         }
 #pragma unroll
         for (int q8 = 0; q8 < DG_SBA; ++q8) {
@@ -306,7 +310,8 @@ __global__ __launch_bounds__(DG_THREADS) void k_conv_dg(DgArgs a) {
         const int total = rows * 54;  // 216 floats = 54 x 16 bytes per row
         for (int idx = tid; idx < total; idx += DG_THREADS) {
           const int j = idx / 54, q = idx - j * 54;
-          atomicMax(&rowmax[j], absmax4(*reinterpret_cast<const float4*>(a.x + (size_t)(s_lo + j) * a.XS + 4 * q)));
+          const float4 xv_ = *reinterpret_cast<const float4*>(a.x + (size_t)(s_lo + j) * a.XS + 4 * q), g4 = reinterpret_cast<const float4*>(a.gx)[q];
+          atomicMax(&rowmax[j], absmax4(make_float4(xv_.x * g4.x, xv_.y * g4.y, xv_.z * g4.z, xv_.w * g4.w)));
         }
       }
       stage_x1(k_of(0));
@@ -321,8 +326,14 @@ __global__ __launch_bounds__(DG_THREADS) void k_conv_dg(DgArgs a) {
           v[q8] = make_float4(0.f, 0.f, 0.f, 0.f);
           if (idx < total && j < rows) {
             const float* __restrict__ xr = a.x + (size_t)(s_lo + j) * a.XS;
-            if (q < 30) v[q8] = *reinterpret_cast<const float4*>(xr + 4 * q);             // x0 (120 = 30 x 4)
-            else if (q < 62) { const float* p = xr + 120 + 3 * (q - 30); v[q8] = make_float4(p[0], 0.f, p[1], p[2]); }  // x1[u] -> (x, T = 0, y, z)
+            if (q < 30) {  // x0 (120 = 30 x 4)
+              v[q8] = *reinterpret_cast<const float4*>(xr + 4 * q);
+              if constexpr (H) { const float4 g4 = reinterpret_cast<const float4*>(a.gx)[q]; v[q8] = make_float4(v[q8].x * g4.x, v[q8].y * g4.y, v[q8].z * g4.z, v[q8].w * g4.w); }
+            } else if (q < 62) {  // x1[u] -> (x, T = 0, y, z)
+              const float* p = xr + 120 + 3 * (q - 30);
+              const float g1 = H ? a.gx[120 + 3 * (q - 30)] : 1.f;
+              v[q8] = make_float4(p[0] * g1, 0.f, p[1] * g1, p[2] * g1);
+            }
           }
         }
 #pragma unroll
@@ -1329,11 +1340,20 @@ __global__ __launch_bounds__(DG_THREADS) void k_conv_dg(DgArgs a) {
           v = make_float4(((a0.x + a1.x) + a2.x) + a3.x, ((a0.y + a1.y) + a2.y) + a3.y, ((a0.z + a1.z) + a2.z) + a3.z,
                           ((a0.w + a1.w) + a2.w) + a3.w);
         }
+        if constexpr (H) {  // the column scales of the balanced weights (exact powers of two)
+          const float4 cf = reinterpret_cast<const float4*>(a.cf0)[c4];
+          v = make_float4(v.x * cf.x, v.y * cf.y, v.z * cf.z, v.w * cf.w);
+        }
         if (row < n_dst) *reinterpret_cast<float4*>(p0 + row * 160 + 4 * c4) = v;
       }
       for (int idx = tid; idx < 32 * 24; idx += DG_THREADS) {
         const int row = idx / 24, c4 = idx - row * 24;
-        const float4 pv = *reinterpret_cast<const float4*>(OP + row * 96 + 4 * c4), ov = *reinterpret_cast<const float4*>(OL + row * 96 + 4 * c4);
+        float4 pv = *reinterpret_cast<const float4*>(OP + row * 96 + 4 * c4);
+        const float4 ov = *reinterpret_cast<const float4*>(OL + row * 96 + 4 * c4);
+        if constexpr (H) {
+          const float4 cf = reinterpret_cast<const float4*>(a.cf1)[c4 & 7];
+          pv = make_float4(pv.x * cf.x, pv.y * cf.y, pv.z * cf.z, pv.w * cf.w);
+        }
         if (row < n_dst) *reinterpret_cast<float4*>(p1 + row * 96 + 4 * c4) = make_float4(pv.x + ov.x, pv.y + ov.y, pv.z + ov.z, pv.w + ov.w);
       }
     }
@@ -1440,7 +1460,8 @@ __global__ __launch_bounds__(64 * TP_WAVES) __attribute__((amdgpu_waves_per_eu(2
 // on the host after scaling by 2^sBt) stream through a double buffer and 24 MFMAs of 32 cycles replace 60 of 64.  The kernel turns
 // from MFMA-bound to bound by its weight stream (16 KB per wave and hidden unit from L2).
 __global__ __launch_bounds__(64 * TP_WAVES) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_tprod_h(
-    const float* __restrict__ x, int XS, int n_atoms, int n_k, int kg, const float4* __restrict__ wth, int sBt, float* __restrict__ T, int t_stride) {
+    const float* __restrict__ x, int XS, int n_atoms, int n_k, int kg, const float4* __restrict__ wth, const float* __restrict__ gT, const float* __restrict__ cfT,
+    float* __restrict__ T, int t_stride) {
   const int lane = threadIdx.x & 63, wave = RFL(threadIdx.x >> 6);
   const int r = lane & 31, hh = lane >> 5;
   const int gid = blockIdx.x * TP_WAVES + wave;
@@ -1462,6 +1483,8 @@ __global__ __launch_bounds__(64 * TP_WAVES) __attribute__((amdgpu_waves_per_eu(2
         const int u = 16 * q + 8 * hh + 4 * p2;  // inputs u .. u + 3 (120..127: beyond the scalar block -> zeros)
         float4 v = *reinterpret_cast<const float4*>(x + (size_t)row * XS + u);
         if (u >= 120) v = make_float4(0.f, 0.f, 0.f, 0.f);
+        const float4 gv = *reinterpret_cast<const float4*>(gT + u);  // 2^e_u of the input channels (the host took it out of their weight rows)
+        v = make_float4(v.x * gv.x, v.y * gv.y, v.z * gv.z, v.w * gv.w);
         xf[q][p2] = v;
         mx = fmaxf(mx, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
       }
@@ -1474,7 +1497,7 @@ __global__ __launch_bounds__(64 * TP_WAVES) __attribute__((amdgpu_waves_per_eu(2
     if (mx > 0.f) sA = 14 - ((int)((__float_as_uint(mx) >> 23) & 0xffu) - 126);
     sA = max(-60, min(60, sA));
     const float sc = pow2f(sA);
-    isc = pow2f(-sA - sBt);
+    isc = pow2f(-sA);
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
       const float4 a4 = xf[q][0], b4 = xf[q][1];
@@ -1497,10 +1520,18 @@ __global__ __launch_bounds__(64 * TP_WAVES) __attribute__((amdgpu_waves_per_eu(2
   load_w(w0, k_lo);
   __shared__ float tp_tile[TP_WAVES][32 * TP_LD];
   float* __restrict__ tt = tp_tile[wave];
+  // (inverse column scales of the weights: transposed output — lane = output channel r: one factor; else register 4 g4 + i = channel 8 g4 + 4 hh + i)
+  const float cfr = cfT[r];
+  float4 cfq[4];
+#pragma unroll
+  for (int g4 = 0; g4 < 4; ++g4) cfq[g4] = *reinterpret_cast<const float4*>(cfT + 8 * g4 + 4 * hh);
   auto stage = [&](const f32x16& acc) {  // row r of the tile <- this lane's four quads (columns 8 g4 + 4 hh ..), scaled
 #pragma unroll
-    for (int g4 = 0; g4 < 4; ++g4)
-      *reinterpret_cast<float4*>(tt + r * TP_LD + 8 * g4 + 4 * hh) = make_float4(acc[4 * g4] * isc, acc[4 * g4 + 1] * isc, acc[4 * g4 + 2] * isc, acc[4 * g4 + 3] * isc);
+    for (int g4 = 0; g4 < 4; ++g4) {
+      const float4 c = t_stride > 0 ? make_float4(cfr, cfr, cfr, cfr) : cfq[g4];
+      *reinterpret_cast<float4*>(tt + r * TP_LD + 8 * g4 + 4 * hh) =
+          make_float4((acc[4 * g4] * isc) * c.x, (acc[4 * g4 + 1] * isc) * c.y, (acc[4 * g4 + 2] * isc) * c.z, (acc[4 * g4 + 3] * isc) * c.w);
+    }
   };
   auto step = [&](const float4 (&wv)[16], int k) {
     f32x16 acc;
@@ -1548,11 +1579,12 @@ __global__ __launch_bounds__(64 * TP_WAVES) __attribute__((amdgpu_waves_per_eu(2
   }
 }
 
-void launch_tprod(const float* x, int XS, int n_atoms, int n_k, const float4* wt, const float4* wth, int sBt, float* T, int t_stride, hipStream_t st) {
+void launch_tprod(const float* x, int XS, int n_atoms, int n_k, const float4* wt, const float4* wth, const float* gT, const float* cfT, float* T, int t_stride,
+                  hipStream_t st) {
   const int tiles = (n_atoms + 31) / 32;
   const int kg = std::min(n_k, std::max(1, 1024 / tiles));
   if (wth)
-    hipLaunchKernelGGL(k_tprod_h, dim3((tiles * kg + TP_WAVES - 1) / TP_WAVES), dim3(64 * TP_WAVES), 0, st, x, XS, n_atoms, n_k, kg, wth, sBt, T, t_stride);
+    hipLaunchKernelGGL(k_tprod_h, dim3((tiles * kg + TP_WAVES - 1) / TP_WAVES), dim3(64 * TP_WAVES), 0, st, x, XS, n_atoms, n_k, kg, wth, gT, cfT, T, t_stride);
   else
     hipLaunchKernelGGL(k_tprod, dim3((tiles * kg + TP_WAVES - 1) / TP_WAVES), dim3(64 * TP_WAVES), 0, st, x, XS, n_atoms, n_k, kg, wt, T);
 }

@@ -246,6 +246,11 @@ __global__ __launch_bounds__(MF_THREADS) void k_conv_mf(MfArgs a) {
     // lane = (row pair jp, float4 column c40 + 8 q): the two row pointers and their predicates do not depend on q — one address pair, the
     // columns by immediate offsets
     const int xjp = xt & 31, xc40 = (xt >> 5) & 7;
+    // (per-channel powers of two 2^e_u, MfArgs::gx: the inverse of what the host took out of the channel's weight rows — applied BEFORE the
+    // span's maximum is measured, so that every channel enters the f16 split with the weight of its contribution)
+    float4 gq[NXQ];
+#pragma unroll
+    for (int q = 0; q < NXQ; ++q) gq[q] = (stager && xc40 + 8 * q < 54) ? reinterpret_cast<const float4*>(a.gx)[xc40 + 8 * q] : make_float4(1.f, 1.f, 1.f, 1.f);
     {
       const int j0 = 2 * xjp - off, j1 = j0 + 1;  // rows relative to the span
       const bool in0 = stager && j0 >= 0 && j0 < rows, in1 = stager && j1 >= 0 && j1 < rows;
@@ -268,6 +273,8 @@ __global__ __launch_bounds__(MF_THREADS) void k_conv_mf(MfArgs a) {
     if (stager) {
 #pragma unroll
       for (int q = 0; q < NXQ; ++q) {
+        va[q] = make_float4(va[q].x * gq[q].x, va[q].y * gq[q].y, va[q].z * gq[q].z, va[q].w * gq[q].w);
+        vb[q] = make_float4(vb[q].x * gq[q].x, vb[q].y * gq[q].y, vb[q].z * gq[q].z, vb[q].w * gq[q].w);
         mx = fmaxf(mx, fmaxf(fmaxf(fabsf(va[q].x), fabsf(va[q].y)), fmaxf(fabsf(va[q].z), fabsf(va[q].w))));
         mx = fmaxf(mx, fmaxf(fmaxf(fabsf(vb[q].x), fabsf(vb[q].y)), fmaxf(fabsf(vb[q].z), fabsf(vb[q].w))));
       }
@@ -422,8 +429,9 @@ __global__ __launch_bounds__(MF_THREADS) void k_conv_mf(MfArgs a) {
       }
     };
     const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    // segment end: row i of the contraction carries 2^(sX + sC + sB - 14 - e(in-degree_i)), the T term 2^(sX + sC + sTw); two
-    // factors each, so that no intermediate power of two leaves the fp32 range
+    // segment end: row i of the contraction carries 2^(sX + sC - 14 - e(in-degree_i)) and column w 2^sB_w (the host's column scale of the
+    // weights, undone by cf0 / cf1), the T term 2^(sX + sC + sTw); several factors each, so that no intermediate power of two leaves
+    // the fp32 range
     const float i1 = pow2f(clamp100(-(sX + a.sC))), iT2 = pow2f(clamp100(-a.sTw));
     auto i2_of = [&](int row) {
       const int edeg = deg_lds[row] > 0 ? exp_above((float)deg_lds[row]) : 1;
@@ -773,16 +781,18 @@ __global__ __launch_bounds__(MF_THREADS) void k_conv_mf(MfArgs a) {
                      a2 = *reinterpret_cast<const float4*>(q0 + 10240), a3 = *reinterpret_cast<const float4*>(q0 + 15360),
                      a4 = *reinterpret_cast<const float4*>(q0 + 20480);
         const float i2 = i2_of(row);
-        const float4 v = make_float4((((((a0.x + a1.x) + a2.x) + a3.x) + a4.x) * i1) * i2, (((((a0.y + a1.y) + a2.y) + a3.y) + a4.y) * i1) * i2,
-                                     (((((a0.z + a1.z) + a2.z) + a3.z) + a4.z) * i1) * i2, (((((a0.w + a1.w) + a2.w) + a3.w) + a4.w) * i1) * i2);
+        const float4 cf = reinterpret_cast<const float4*>(a.cf0)[c4];
+        const float4 v = make_float4(((((((a0.x + a1.x) + a2.x) + a3.x) + a4.x) * i1) * i2) * cf.x, ((((((a0.y + a1.y) + a2.y) + a3.y) + a4.y) * i1) * i2) * cf.y,
+                                     ((((((a0.z + a1.z) + a2.z) + a3.z) + a4.z) * i1) * i2) * cf.z, ((((((a0.w + a1.w) + a2.w) + a3.w) + a4.w) * i1) * i2) * cf.w);
         if (row < n_dst) *reinterpret_cast<float4*>(p0 + row * 160 + 4 * c4) = v;
       }
       for (int idx = tid; idx < 32 * 24; idx += MF_THREADS) {
         const int row = idx / 24, c4 = idx - row * 24;
         const float i2 = i2_of(row);
         const float4 c = *reinterpret_cast<const float4*>(ST1 + row * 96 + 4 * c4), t = *reinterpret_cast<const float4*>(ST1 + 3072 + row * 96 + 4 * c4);
-        const float4 v = make_float4((c.x * i1) * i2 + (t.x * i1) * iT2, (c.y * i1) * i2 + (t.y * i1) * iT2, (c.z * i1) * i2 + (t.z * i1) * iT2,
-                                     (c.w * i1) * i2 + (t.w * i1) * iT2);
+        const float4 cf = reinterpret_cast<const float4*>(a.cf1)[c4 & 7];  // (column 4 (c4 % 8) .. of plane c4 / 8)
+        const float4 v = make_float4(((c.x * i1) * i2) * cf.x + (t.x * i1) * iT2, ((c.y * i1) * i2) * cf.y + (t.y * i1) * iT2, ((c.z * i1) * i2) * cf.z + (t.z * i1) * iT2,
+                                     ((c.w * i1) * i2) * cf.w + (t.w * i1) * iT2);
         if (row < n_dst) *reinterpret_cast<float4*>(p1 + row * 96 + 4 * c4) = v;
       }
     }

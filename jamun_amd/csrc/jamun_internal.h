@@ -101,7 +101,10 @@ struct DgArgs {
   //   24..27 dot(x1, v) inputs, own tile, groups 0, 1;  28, 29 output tile 4, group w (w < 2)
   //   30..33 x1 | cross inputs of the vector planes (16x16x32: kappa = 32 G + 8 kq + j), column half w >> 1, groups 0, 1
   const float4* wh;
-  int sB;             // weights were scaled by 2^sB before the split
+  int sB;             // (0: the weights are balanced per input channel and per output column, see gx / cf0 / cf1)
+  // f16x3 balancing (jamun_api.cpp: build_layer): the feature rows are multiplied by gx [216] (2^e_u per element, layout of a row) when
+  // they are staged; the weights carry 2^-e_u per input and 2^sB_w per output column; cf0 [160] / cf1 [32] = 2^-sB_w undo the latter
+  const float *gx, *cf0, *cf1;
   float hmax2;        // 2 * upper bound of |h~| over the layer (static, from the radial MLP's first layer): bounds the A tiles
   float* partial0;   // [slab][n_pad][nt0*32]
   float* partial1;   // [slab][n_pad][3][32]
@@ -129,7 +132,8 @@ struct MfArgs {
   const float4* wm;
   const float* Tt;   // [k][32 w'][t_stride] TRANSPOSED pre-pass product (k_tprod_h): T_k[j][w'] at Tt[(k * 32 + w') * t_stride + j]
   int t_stride;      // even, >= n_atoms + 64
-  int sB;            // weights were scaled by 2^sB before the split (largest below 2^14)
+  int sB;            // (0: balanced weights, as DgArgs)
+  const float *gx, *cf0, *cf1;  // as DgArgs
   int sC;            // coefficients are scaled by 2^sC: 3 max|h~| (an entry may sum three edges of one pair) below 2^14
   int sTw;           // 2^sTw x (largest column sum of |T weights|) < 1: T_k = x0 W is scaled by 2^(sX + sTw)
   float* partial0;   // [slab][n_pad][nt0*32]
@@ -242,7 +246,13 @@ struct NodeArgs {
   // v_mfma_f32_32x32x16_f16: wh0 [nt][K0h/16][hi, lo][64 lanes] (lane (c, hh): rows 16 s + 8 hh + p, column 32 nt + c), wh1 [K1h/16][hi, lo][64]
   const float4* wh0;
   const float4* wh1;
-  int K0h, K1h, sW0, sW1;
+  int K0h, K1h;
+  // ... balanced by exact powers of two on the host: row K of [W_self ; W_skip] times 2^-e_K (its largest magnitude -> [0.5, 1)), then
+  // column w times 2^sW_w (largest -> [2^13, 2^14)).  The kernel multiplies the inputs by 2^e_K when it stages them — kga0 [mul0]
+  // (activated scalars), kga1 [mul1] (gated vectors), kgx [XSin] (the x_in channels, in x_in's layout) — and the output columns by
+  // cg0 [mul0] / cg1 [mul1] = 2^-sW_w.  A per-tensor scale would leave rows / columns 2^-14 below the largest weight with denormal
+  // lo halves (trained checkpoints spread their channels over many octaves).
+  const float *kga0, *kga1, *kgx, *cg0, *cg1;
   const float* mix;      // [mul0+mul1] or nullptr (initial projector)
   float cL, cS;
   int n_atoms, n_pad, n_slices, nt0, nt1;
@@ -310,7 +320,8 @@ void conv_dg_print_stamps();
 void conv_initv_print_stamps();
 void conv_mf_print_stamps();
 size_t conv_dg_lds_bytes(int rs, int pmax, int mode, int emu);
-void launch_tprod(const float* x, int XS, int n_atoms, int n_k, const float4* wt, const float4* wth, int sBt, float* T, int t_stride, hipStream_t st);
+void launch_tprod(const float* x, int XS, int n_atoms, int n_k, const float4* wt, const float4* wth, const float* gT, const float* cfT, float* T, int t_stride,
+                  hipStream_t st);
 int launch_conv_mf(const MfArgs& a, int grid, hipStream_t st);
 int launch_conv_mfi(const MfiArgs& a, int grid, hipStream_t st);
 int conv_mf_set_max_lds();

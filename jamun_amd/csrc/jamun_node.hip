@@ -7,7 +7,11 @@
 //     ([atom][K] halves, hi and lo planes: the A fragments of v_mfma_f32_32x32x16_f16 are 16-byte reads of a row), scaled per atom
 //     by a power of two so that its largest input sits below 2^14 (one scale for the scalar K range, one for the vector planes);
 //   * phase 2 runs 15 (scalar tile, K = 240) or 4 (vector plane, K = 64) K-steps of three f16 MFMAs — 1.4 k matrix cycles for a scalar
-//     tile against 7.7 k with v_mfma_f32_32x32x2_f32 — against weights split hi + lo on the host (scaled by 2^sW).
+//     tile against 7.7 k with v_mfma_f32_32x32x2_f32 — against weights split hi + lo on the host;
+//   * the weights are balanced by exact powers of two per ROW (K index: the input is multiplied by the inverse when it is staged, before
+//     the per-atom scale is chosen) and per COLUMN (undone in the epilogue): with one scale per tensor, weights 2^-14 below the largest
+//     have denormal lo halves, and an input channel that is small because its weights are large would lose its low bits to the
+//     atom's largest input (NodeArgs::kga0 ...; round 4: a checkpoint with a per-channel spread of 2^+-10 came out 0.9 off per channel).
 // Measured on MI355X (cfg2, 4352 atoms, 3 slabs): k_node_update 24.4 us = 13.8 phase 1 + 10.6 phase 2; see DESIGN.md 3.4 for this kernel.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -182,7 +186,7 @@ __global__ __launch_bounds__(NH_T) void k_node_update_h(NodeArgs a) {
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
       const int w = c + t;
-      if (w < a.mul0) { e[t] = a.cL * (e[t] > 0.f ? e[t] : 0.01f * e[t]); mxS = fmaxf(mxS, fabsf(e[t])); }
+      if (w < a.mul0) { e[t] = (a.cL * (e[t] > 0.f ? e[t] : 0.01f * e[t])) * a.kga0[w]; mxS = fmaxf(mxS, fabsf(e[t])); }
       else if (w < G0) s_gate[il * 32 + (w - a.mul0)] = a.cS / (1.f + expf(-e[t]));
     }
     ms[q] = make_float4(e[0], e[1], e[2], e[3]);
@@ -191,6 +195,10 @@ __global__ __launch_bounds__(NH_T) void k_node_update_h(NodeArgs a) {
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     const int c = 4 * (c16 + 16 * q);
+    if (c < a.XSin) {  // x_in channels times the row factors of the skip weights (exact powers of two)
+      const float4 kg = *reinterpret_cast<const float4*>(a.kgx + c);
+      xv[q] = make_float4(xv[q].x * kg.x, xv[q].y * kg.y, xv[q].z * kg.z, xv[q].w * kg.w);
+    }
     if (c < a.in0) mxS = fmaxf(mxS, max4(xv[q]));          // (in0 is a multiple of 4: a piece is all scalar or all vector)
     else if (c < a.XSin) mxV = fmaxf(mxV, max4(xv[q]));
   }
@@ -211,7 +219,7 @@ __global__ __launch_bounds__(NH_T) void k_node_update_h(NodeArgs a) {
       if (c < a.in0) put4(row, L0, a.mul0 + c, xv[q], sc);
     }
     for (int k = a.mul0 + a.in0 + 4 * c16; k < a.K0h; k += 64) put4(row, L0, k, z4, 1.f);  // pad rows of the K range
-    if (c16 == 0) isc0[il] = pow2f(-sS - a.sW0);
+    if (c16 == 0) isc0[il] = pow2f(-sS);
   }
   __syncthreads();  // gates
 
@@ -223,7 +231,7 @@ __global__ __launch_bounds__(NH_T) void k_node_update_h(NodeArgs a) {
     const float e[4] = {mv[q].x / degf, mv[q].y / degf, mv[q].z / degf, mv[q].w / degf};
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
-      gv[q][t] = (j < 24 && c + t < a.mul1) ? e[t] * s_gate[il * 32 + c + t] : 0.f;
+      gv[q][t] = (j < 24 && c + t < a.mul1) ? (e[t] * s_gate[il * 32 + c + t]) * a.kga1[c + t] : 0.f;
       mxV = fmaxf(mxV, fabsf(gv[q][t]));
     }
   }
@@ -253,7 +261,7 @@ __global__ __launch_bounds__(NH_T) void k_node_update_h(NodeArgs a) {
       const int per = (a.K1h - a.mul1 - a.in1) >> 2, m = idx / per, k = a.mul1 + a.in1 + 4 * (idx - m * per);
       put4(A1 + (m * 32 + il) * RB1, L1, k, z4, 1.f);
     }
-    if (c16 == 0) isc1[il] = pow2f(-sV - a.sW1);
+    if (c16 == 0) isc1[il] = pow2f(-sV);
   }
   __syncthreads();
 
@@ -289,12 +297,13 @@ __global__ __launch_bounds__(NH_T) void k_node_update_h(NodeArgs a) {
       }
     }
     const float mw = (a.mix && col_ok_j) ? a.mix[scalar ? col_j : a.mul0 + col_j] : 0.f;
+    const float cinv = col_ok_j ? (scalar ? a.cg0[col_j] : a.cg1[col_j]) : 0.f;  // 2^-sW of this lane's output column
     const float* __restrict__ isc = scalar ? isc0 : isc1;
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
       const int rl = (q & 3) + 8 * (q >> 2) + 4 * hh, ii = n0 + rl;
       if (col_ok_j && ii < a.n_atoms) {
-        float v = acc[q] * isc[rl];
+        float v = (acc[q] * isc[rl]) * cinv;
         if (a.mix) v = mw * xo[q] + (1.f - mw) * v;  // hidden layers: XSin == XSo, x_in is x_old
         a.x_out[(size_t)ii * XSo + o_j] = v;
       }
@@ -306,7 +315,7 @@ size_t node_update_h_lds_bytes(const NodeArgs& a) {
   return (size_t)2 * 32 * (a.K0h * 2 + 16) + (size_t)2 * 96 * (a.K1h * 2 + 16) + sizeof(float) * (32 * 32 + 64);
 }
 bool node_update_h_supported(const NodeArgs& a) {
-  return ((a.mul0 + 31) >> 5) + 3 <= NH_T / 64 && a.wh0 != nullptr && a.wh1 != nullptr && a.nt0 <= 5 && a.nt1 == 1 && a.mul1 <= 32 && (a.mul0 & 3) == 0 && (a.in0 & 3) == 0 && (a.XSin & 3) == 0 &&
+  return ((a.mul0 + 31) >> 5) + 3 <= NH_T / 64 && a.wh0 != nullptr && a.wh1 != nullptr && a.kgx != nullptr && a.nt0 <= 5 && a.nt1 == 1 && a.mul1 <= 32 && (a.mul0 & 3) == 0 && (a.in0 & 3) == 0 && (a.XSin & 3) == 0 &&
          a.XSin <= 256 && (a.K0h & 15) == 0 && (a.K1h & 15) == 0 && a.K0h >= a.mul0 + a.in0 && a.K1h >= a.mul1 + a.in1 &&
          ((a.K0h - a.mul0 - a.in0) & 3) == 0 && ((a.K1h - a.mul1 - a.in1) & 3) == 0 && node_update_h_lds_bytes(a) <= 64 * 1024;
 }

@@ -71,8 +71,8 @@ def test_forward_matches_oracle_at_other_hyperparameters(variant, kind, want):
         deg = ref["deg"]
         assert int(deg.max()) >= 32 and (deg >= 32).float().mean() > 0.3
     n_layers = ck["hyper_parameters"]["arch"]["n_layers"]
-    assert f"x{n_layers}" in ref and f"x{n_layers + 1}" not in ref
-    for l in range(n_layers + 1):
+    assert f"x{n_layers + 1}" not in ref
+    for l in range(n_layers + 1 if "x0" in ref else 0):  # (the big cases cache no per-layer features)
         xl, r = smp.debug_read(0, l).cpu(), ref[f"x{l}"]
         err = (xl - r).abs().max().item() / max(r.abs().max().item(), 1e-6)
         assert err < 2e-5, (l, err)
