@@ -12,6 +12,7 @@ Workloads (per GPU; weak scaling: the walker count grows with the number of GPUs
 sigma = delta = 0.04, friction 1, M 1, clip 100, synthetic molecules + seeded synthetic checkpoint (no datasets / published
 checkpoints are reachable offline):
     cfg2  BASELINE.json configs[1]  uncapped-2AA shape: 17 heavy atoms x 256 walkers              (the default, the metric's config)
+    cfg2r the same config as the reference runs it: one walker per DISTINCT dipeptide (9..29 atoms, real topology, 143 embedding rows)
     cfg3  configs[2]                uncapped-4AA shape: 33 atoms x 256 walkers per GPU (2048 on 8)
     cfg4  configs[3]                MDGen-4AA-like ragged batch: 256 walkers of 17..57 atoms
     cfg5  configs[4]                chignolin size with hydrogens: 166 atoms x 64 walkers per GPU (512 on 8)
@@ -54,6 +55,8 @@ MIN_TIMED_S = 10.0
 
 CONFIGS = {
     "cfg2": dict(baseline="configs[1]", desc="uncapped-2AA-like 17-atom molecule", atoms=17, walkers=256),
+    "cfg2r": dict(baseline="configs[1] as the reference runs it (sample_uncapped_2AA.yaml:18-19: ONE walker per distinct test peptide)",
+                  desc="256 DISTINCT dipeptides with real topology (9..29 heavy atoms, all 20 residue types, 143 distinct embedding rows)", atoms=None, walkers=256),
     "cfg3": dict(baseline="configs[2]", desc="uncapped-4AA-like 33-atom molecule (2048 walkers over 8 GPUs)", atoms=33, walkers=256),
     "cfg4": dict(baseline="configs[3]", desc="MDGen-4AA-like ragged batch, 17..57 atoms per walker", atoms=None, walkers=256),
     "cfg5": dict(baseline="configs[4]", desc="chignolin-size 166-atom molecule with hydrogens (512 walkers over 8 GPUs)", atoms=166, walkers=64),
@@ -66,6 +69,9 @@ def workload_molecules(cfg: str, walkers: int, atoms=None, rank: int = 0):
 
     c = CONFIGS[cfg]
     n = atoms if atoms is not None else c["atoms"]
+    if cfg == "cfg2r":  # every walker its own dipeptide: codes spread evenly over the 400, a different stretch per rank
+        codes = synth.all_dipeptides()
+        return [synth.peptide(codes[(i * len(codes) // max(walkers, 1) + 7 * rank) % len(codes)], seed=i + 1000 * rank) for i in range(walkers)]
     if n is not None:
         return [synth.random_chain(n, seed=0)] * walkers
     import random

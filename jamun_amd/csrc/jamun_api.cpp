@@ -129,6 +129,11 @@ struct LayerDev {
   float* tt2 = nullptr;  // the same table re-laid for k_conv_init_v: [k][U][192]
   float4* tabw = nullptr;  // ... and scaled by 2^tab_sB, split hi + lo, as MFMA B fragments for k_conv_mfi (U <= 32): [k][24 blocks][64 lanes]
   int tab_sB = 0, tab_ut = 0;
+  // k_conv_mfx (initial projector formed from the feature rows; batches with more than 32 distinct embedding rows)
+  float4* wx = nullptr;                  // [k][48 blocks] balanced, split weights (MfxArgs::wx)
+  unsigned *xph = nullptr, *xpl = nullptr;  // the embedding rows times channel factors and 2^x_sX, split, two atoms per word
+  int x_sX = 0;
+  float *xcf0 = nullptr, *xcf1 = nullptr;
   float4 *wcat0 = nullptr, *wcat1 = nullptr;  // node update: [W_self ; W_skip] as MFMA fragments
   int K0p = 0, K1p = 0;
   float4 *wh0 = nullptr, *wh1 = nullptr;      // ... and balanced per row / column, split hi + lo for the f16x3 kernel (jamun_node.hip)
@@ -361,6 +366,8 @@ struct jamun_sampler {
   float* dg_T = nullptr;  // [n_k][n_atoms][32] pre-pass product of a hidden layer (k_tprod), reused by every layer
   int dg_tstride = 0;     // mode 4 (jamun_conv_mf.hip): dg_T is [n_k][32][dg_tstride], transposed
   bool mfi_on = false;    // initial projector on k_conv_mfi (mode 4 tiles, at most 32 distinct embedding rows)
+  bool mfx_on = false;    // ... or on k_conv_mfx (mode 4 tiles, any number of distinct rows: formed from the feature rows)
+  int n_uniq = 0;         // distinct (noise-scaled) embedding rows of the batch
   int* mf_err = nullptr;  // device flag of k_conv_mf
   int* mf_err_host = nullptr;  // pinned copy, refreshed behind every entry point that ran a forward (mf_err_fetch / mf_err_check)
   float *x_emb = nullptr, *mu = nullptr;
@@ -394,6 +401,7 @@ struct jamun_sampler {
       free_problem(L.p0); free_problem(L.p1); free_fused(L.fu); free_dg(L.dg);
       hipFree(L.sep.w2p); hipFree(L.sep.wl0); hipFree(L.sep.wl1);
       hipFree(L.wcat0); hipFree(L.wcat1); hipFree(L.wh0); hipFree(L.wh1); hipFree(L.kga0); hipFree(L.kga1); hipFree(L.kgx); hipFree(L.cg0); hipFree(L.cg1); hipFree(L.mix); hipFree(L.tt); hipFree(L.tt2); hipFree(L.tabw);
+      hipFree(L.wx); hipFree(L.xph); hipFree(L.xpl); hipFree(L.xcf0); hipFree(L.xcf1);
     }
     hipFree(w_gate); hipFree(w_vec); hipFree(w_out);
     hipFree(yc); hipFree(h); hipFree(partial0); hipFree(partial1); hipFree(g); hipFree(tmp);
@@ -637,7 +645,8 @@ LayerDev build_layer_separable(const jamun_model& m, const std::string& prefix, 
 
 LayerDev build_layer(const jamun_model& m, const std::string& prefix, const std::vector<InBlock>& in_blocks,
                      const std::vector<double>& s_in, int n_slices, int fused_JR, int fused_span,
-                     const std::vector<float>* uniq_rows = nullptr, int row_len = 0, bool pack_dg = false) {
+                     const std::vector<float>* uniq_rows = nullptr, int row_len = 0, bool pack_dg = false,
+                     const std::vector<float>* all_rows = nullptr) {
   const jamun_hparams& hp = m.hp;
   const int mul0 = hp.mul0, mul1 = hp.mul1, G0 = mul0 + mul1, G1 = mul1, H = hp.edge_attr_dim;
   LayerDev L;
@@ -1226,6 +1235,99 @@ LayerDev build_layer(const jamun_model& m, const std::string& prefix, const std:
     }
   }
 
+  // ---- k_conv_mfx: the initial projector formed from the feature rows themselves (scalar inputs only, at most 64 channels): weights
+  // balanced per input channel (2^-e_u; the factor goes into the stored rows) and per output column (2^sB_w, undone by xcf0 / xcf1), the
+  // rows x 2^e_u x 2^x_sX (ONE static scale: the rows are constants of (topology, sigma)) split hi + lo on the host, two atoms per word
+  if (all_rows && row_len > 0 && row_len <= 64 && in1 == 0 && NT0 == 5 && G1 <= 32 && G1 > 0 && (int)x0e.size() == row_len && (int)x0ve.size() == row_len) {
+    const int n_k = H + 1, C = row_len;
+    auto Wk = [&](int k, int64_t p) -> double { return (k < H) ? (double)W3[(size_t)p * H + k] : (double)b3[p]; };
+    auto pow2_above = [](double v) { int ex = 0; if (v > 0 && std::isfinite(v)) std::frexp(v, &ex); return std::max(-40, std::min(40, ex)); };
+    std::vector<const UEntry*> es(64, nullptr), ev(64, nullptr);  // by feature column (xoff)
+    for (const UEntry& e : x0e) es[e.xoff] = &e;
+    for (const UEntry& e : x0ve) ev[e.xoff] = &e;
+    std::vector<int> eu(64, 0);
+    for (int u = 0; u < C; ++u) {
+      double mx = 0;
+      for (int k = 0; k < n_k; ++k) {
+        for (int col = 0; col < G0; ++col) mx = std::max(mx, std::fabs(Wk(k, es[u]->wbase + col) * es[u]->scale));
+        for (int col = 0; col < G1; ++col) mx = std::max(mx, std::fabs(Wk(k, ev[u]->wbase + col) * ev[u]->scale));
+      }
+      eu[u] = pow2_above(mx);
+    }
+    auto Wg = [&](const UEntry* e, int u, int k, int col) { return e ? std::ldexp(Wk(k, e->wbase + col) * e->scale, -eu[u]) : 0.0; };
+    std::vector<double> sc0(160, 1.0), sc1(32, 1.0);
+    std::vector<float> cf0(160, 0.f), cf1(32, 0.f);
+    for (int col = 0; col < G0; ++col) {
+      double mx = 0;
+      for (int k = 0; k < n_k; ++k) for (int u = 0; u < C; ++u) mx = std::max(mx, std::fabs(Wg(es[u], u, k, col)));
+      const int sB = 14 - pow2_above(mx);
+      sc0[col] = std::ldexp(1.0, sB); cf0[col] = (float)std::ldexp(1.0, -sB);
+    }
+    for (int col = 0; col < G1; ++col) {
+      double mx = 0;
+      for (int k = 0; k < n_k; ++k) for (int u = 0; u < C; ++u) mx = std::max(mx, std::fabs(Wg(ev[u], u, k, col)));
+      const int sB = 14 - pow2_above(mx);
+      sc1[col] = std::ldexp(1.0, sB); cf1[col] = (float)std::ldexp(1.0, -sB);
+    }
+    auto pack8 = [&](const double (&v)[8], float4& hi, float4& lo) {
+      uint32_t h[4], l[4];
+      for (int i = 0; i < 4; ++i) {
+        uint16_t h0, l0, h1, l1;
+        split_f16(v[2 * i], h0, l0);
+        split_f16(v[2 * i + 1], h1, l1);
+        h[i] = (uint32_t)h0 | ((uint32_t)h1 << 16);
+        l[i] = (uint32_t)l0 | ((uint32_t)l1 << 16);
+      }
+      std::memcpy(&hi, h, 16);
+      std::memcpy(&lo, l, 16);
+    };
+    auto u_of = [](int t, int s2, int hh, int p) { return 32 * t + 16 * s2 + (p & 3) + 8 * (p >> 2) + 4 * hh; };
+    std::vector<float4> wx((size_t)n_k * 48 * 64, make_float4(0.f, 0.f, 0.f, 0.f));
+    for (int k = 0; k < n_k; ++k)
+      for (int lane = 0; lane < 64; ++lane) {
+        const int hh = lane >> 5, c = lane & 31;
+        for (int t = 0; t < 2; ++t)
+          for (int s2 = 0; s2 < 2; ++s2) {
+            for (int n = 0; n < 5; ++n) {
+              const int col = 32 * n + c;
+              double v[8];
+              for (int pp = 0; pp < 8; ++pp) {
+                const int u = u_of(t, s2, hh, pp);
+                v[pp] = (u < C && col < G0) ? Wg(es[u], u, k, col) * sc0[col] : 0.0;
+              }
+              const size_t b = ((size_t)k * 48 + 20 * t + 2 * (2 * n + s2)) * 64 + lane;
+              pack8(v, wx[b], wx[b + 64]);
+            }
+            double v[8];
+            for (int pp = 0; pp < 8; ++pp) {
+              const int u = u_of(t, s2, hh, pp);
+              v[pp] = (u < C && c < G1) ? Wg(ev[u], u, k, c) * sc1[c] : 0.0;
+            }
+            const size_t b = ((size_t)k * 48 + 40 + 4 * t + 2 * s2) * 64 + lane;
+            pack8(v, wx[b], wx[b + 64]);
+          }
+      }
+    const size_t N = all_rows->size() / (size_t)row_len;
+    double xm = 0;
+    for (size_t i = 0; i < N; ++i)
+      for (int u = 0; u < C; ++u) xm = std::max(xm, std::fabs(std::ldexp((double)(*all_rows)[i * row_len + u], eu[u])));
+    L.x_sX = 14 - pow2_above(xm);
+    const size_t n_pairs = (N + 1) / 2 + 40;  // a window reads 32 pairs from the pair of its first atom: zero rows behind the batch
+    std::vector<unsigned> xph(n_pairs * 64, 0u), xpl(n_pairs * 64, 0u);
+    for (size_t i = 0; i < N; ++i)
+      for (int u = 0; u < C; ++u) {
+        uint16_t hi, lo;
+        split_f16(std::ldexp((double)(*all_rows)[i * row_len + u], eu[u] + L.x_sX), hi, lo);
+        const size_t w = (i >> 1) * 64 + u;
+        const int sh = (i & 1) ? 16 : 0;
+        xph[w] |= (unsigned)hi << sh;
+        xpl[w] |= (unsigned)lo << sh;
+      }
+    L.wx = dev_upload(wx);
+    L.xph = dev_upload(xph); L.xpl = dev_upload(xpl);
+    L.xcf0 = dev_upload(cf0); L.xcf1 = dev_upload(cf1);
+  }
+
   build_layer_common(m, prefix, in_blocks, s_in, L, in0, in1);
   return L;
 }
@@ -1302,6 +1404,20 @@ void run_layer(jamun_sampler* s, size_t l, const float* x_in, int XSin, float* x
       f.partial0 = s->partial0; f.partial1 = s->partial1; f.err = s->mf_err;
       ProfScope ps(s, JAMUN_PROF_CONV0_INIT, st);
       if (launch_conv_mfi(f, s->dg_grid, st) != 0) throw Err(JAMUN_ERR_INVALID, "initial-projector conv launch failed (configuration not supported)");
+    } else if (l == 0 && s->mfx_on) {
+      MfxArgs f{};
+      f.deg = s->deg; f.esrc = s->esrc; f.egeo = s->egeo; f.h = h_l; f.h_kstride = s->h_kstride;
+      f.n_pad = s->n_pad; f.S = s->S; f.nt0 = L.p0.nt;
+      f.tile_span = s->dg_tile_span; f.tile_atoms = s->dg_tile_atoms; f.segs = s->dg_segs; f.max_segs = s->dg_max_segs;
+      f.xph = L.xph; f.xpl = L.xpl; f.wx = L.wx; f.sX = L.x_sX; f.cf0 = L.xcf0; f.cf1 = L.xcf1;
+      {
+        int e3 = 0;
+        std::frexp(1.5 * (double)L.dg.hmax2, &e3);
+        f.sC = std::max(-40, std::min(40, 14 - e3));
+      }
+      f.partial0 = s->partial0; f.partial1 = s->partial1; f.err = s->mf_err;
+      ProfScope ps(s, JAMUN_PROF_CONV0_INIT, st);
+      if (launch_conv_mfx(f, s->dg_grid, st) != 0) throw Err(JAMUN_ERR_INVALID, "initial-projector conv launch failed (configuration not supported)");
     } else if (l == 0 && s->initv_on) {
       InitVArgs f{};
       f.deg = s->deg; f.esrc = s->esrc; f.egeo = s->egeo; f.h = h_l; f.h_kstride = s->h_kstride;
@@ -1399,7 +1515,7 @@ void run_layer(jamun_sampler* s, size_t l, const float* x_in, int XSin, float* x
     n.cL = s->hp.act_scalar_const; n.cS = s->hp.act_gate_const;
     n.n_atoms = s->n_atoms; n.n_pad = s->n_pad; n.n_slices = s->n_slices; n.nt0 = L.p0.nt; n.nt1 = L.p1.nt;
     n.mul0 = s->hp.mul0; n.mul1 = s->hp.mul1; n.in0 = L.in0; n.in1 = L.in1; n.XSin = XSin;
-    const bool dg_layer = (l > 0 && s->dg_on) || (l == 0 && (s->initv_on || s->mfi_on));  // (slabs of the dg tile plan)
+    const bool dg_layer = (l > 0 && s->dg_on) || (l == 0 && (s->initv_on || s->mfi_on || s->mfx_on));  // (slabs of the dg tile plan)
     n.atom_nslab = dg_layer ? s->dg_atom_nslab : (L.fu.wpack ? s->atom_nslab : nullptr);
     n.max_slabs = dg_layer ? s->dg_n_slabs : (L.fu.wpack ? s->n_slabs : s->n_slices);
     if (L.sep.w2p) { n.n_slices = 1; n.atom_nslab = nullptr; n.max_slabs = 1; }  // SeparableConv writes the summed messages as ONE slab
@@ -1779,7 +1895,8 @@ int jamun_sampler_create(const jamun_model* m, float sigma, const jamun_topology
       }
       const bool no_init = getenv("JAMUN_NO_INIT_TABLE") != nullptr;  // debugging / A-B aid
       s->layers.push_back(build_layer(*m, "initial_projector", ib, ones, s->n_slices, s->fused_JR, s->span_max,
-                                      !no_init ? &uniq : nullptr, s->n_emb));
+                                      !no_init ? &uniq : nullptr, s->n_emb, false, &xe_host));
+      s->n_uniq = (int)(uniq.size() / (size_t)std::max(s->n_emb, 1));
       if (s->layers.back().tt || s->layers.back().tabw) s->atom_uid = dev_upload(uid);
     }
     for (int l = 0; l < hp.n_layers; ++l) {
@@ -1977,8 +2094,12 @@ int jamun_sampler_create(const jamun_model* m, float sigma, const jamun_topology
         }
         // ... or, on the tiles of k_conv_mf (spans within one K = 64 window) and with at most 32 distinct embedding rows, the same
         // scheme with a one-hot selector in place of the feature rows (k_conv_mfi)
-        if (s->dg_mode == 4 && s->layers[0].tabw != nullptr && s->atom_uid != nullptr && s->layers[0].p0.nt == 5 && getenv("JAMUN_NO_MFI") == nullptr)
-          s->mfi_on = true;
+        if (s->dg_mode == 4 && s->layers[0].p0.nt == 5 && getenv("JAMUN_NO_MFI") == nullptr) {
+          // up to 32 distinct rows: one selector tile (112 MFMAs per (tile, k), eight equal waves); more: from the feature rows (192)
+          if (s->n_uniq <= 32 && s->layers[0].tabw != nullptr && s->atom_uid != nullptr && s->layers[0].tab_ut == 1) s->mfi_on = true;
+          else if (s->layers[0].wx != nullptr) s->mfx_on = true;
+        }
+        if (s->mfi_on || s->mfx_on) s->initv_on = false;
       }
       if (!s->dg_on)
         for (auto& L : s->layers) free_dg(L.dg);
@@ -2346,7 +2467,7 @@ int jamun_sampler_stats(jamun_sampler* s, jamun_stats* out, void* stream) {
     out->n_slices = s->dg_on ? s->dg_n_slabs : (s->fused_JR > 0 ? s->n_slabs : s->n_slices);
     out->conv_path = s->dg_on ? 2 : (s->fused_JR > 0 ? 1 : 0);
     out->dg_mode = s->dg_on ? s->dg_mode : -1;
-    out->init_path = s->mfi_on ? 3 : s->initv_on ? 2 : (s->layers[0].tt ? 1 : 0);
+    out->init_path = s->mfx_on ? 4 : s->mfi_on ? 3 : s->initv_on ? 2 : (s->layers[0].tt ? 1 : 0);
     out->dg_row_blocks = s->dg_on && s->dg_row_blocks ? 1 : 0;
     out->dg_emu = s->dg_on ? s->dg_emu : -1;
     out->conv_flop_exec_launch = s->conv_flop_exec_launch;

@@ -1025,6 +1025,292 @@ __global__ __launch_bounds__(MF_THREADS) void k_conv_mfi(MfiArgs a) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------
+// k_conv_mfx — the initial projector for batches with MANY distinct embedding rows (k_conv_mfi's one-hot selector costs 8 + 6 MFMAs per
+// wave, hidden unit and 32 distinct rows: 143 rows — every realistic peptide batch: 20 residue types x their heavy-atom names — would be
+// 5 selector tiles).  Here the layer runs like a hidden layer with 64 scalar input channels (the 56 noise-scaled embedding channels,
+// padded): the aggregated operand is FORMED from the feature rows,
+//   A_k[(i,c)][u] = sum_j C_k[c][i][j] x_j[u]     (c = 0: scalar outputs;  c = 1 + m: x0 (x) v_m -> vector plane m),
+// 4 components x 2 channel tiles of 32 = 8 formed tiles per (tile, k), one per wave (wave = 2 c + t), 12 MFMAs each, split in
+// registers and contracted with weight blocks streamed from L2: waves 0, 1 into the five scalar-output tiles (K-split over the two
+// channel tiles: 30 MFMAs each), waves 2 + 2 m + t into vector plane m (6 MFMAs); 192 MFMAs per (tile, k) whatever the number of
+// distinct rows.  The feature rows are constant per (topology, sigma): the host balances the weights per channel and column as for
+// the hidden layers, folds the channel factors and ONE static scale 2^sX into the rows and stores them split (hi / lo halves, two atoms
+// per word): staging is a copy.  All eight waves build the coefficient tiles of the next hidden unit (as k_conv_mfi).
+template <int SPD>
+__global__ __launch_bounds__(MF_THREADS) void k_conv_mfx(MfxArgs a) {
+  extern __shared__ float4 lds4[];
+  char* __restrict__ lds = reinterpret_cast<char*>(lds4);
+  const int L0 = lds_addr(lds);
+  constexpr int X_H = 0, X_L = 64 * MF_ROWB, X_C = 2 * 64 * MF_ROWB, X_MISC = X_C + 2 * MF_CB;  // x^T hi | lo ([64 ch][64 j]) | coefficient tiles | deg
+  int* __restrict__ deg_lds = reinterpret_cast<int*>(lds + X_MISC);
+  const int tid0 = threadIdx.x, lane0 = tid0 & 63;
+  const int wave = RFL(tid0 >> 6);
+  for (int sgi = 0; sgi < a.max_segs; ++sgi) {
+    const int4 sg0 = a.segs[((size_t)blockIdx.x * a.max_segs + sgi) * 2];
+    const int4 sg1 = a.segs[((size_t)blockIdx.x * a.max_segs + sgi) * 2 + 1];
+    const int tile = RFL(sg0.x);
+    if (tile < 0) break;
+    int lane = lane0;
+    asm volatile("" : "+v"(lane));
+    const int tid = wave * 64 + lane;
+    const int slab = RFL(sg0.y), k_begin = RFL(sg0.z), k_run = RFL(sg0.w) - k_begin, k_extra = RFL(sg1.x);
+    const int nk = k_run + (k_extra >= 0 ? 1 : 0);
+    auto k_of = [&](int kk) { kk = kk < 0 ? 0 : (kk < nk ? kk : nk - 1); return kk < k_run ? k_begin + kk : k_extra; };
+    const int2 t_at = a.tile_atoms[tile];
+    const int n0 = RFL(t_at.x), n_dst = RFL(t_at.y);
+    const int2 span = a.tile_span[tile];
+    const int s_base = RFL(span.x) & ~1;  // window of 64 source rows from an even atom (the rows are stored in pairs)
+
+    // ---- loads first: in-degrees, h~ of the first hidden unit, the edge records of all passes (as k_conv_mfi)
+    int dgv = 0;
+    if (tid < 32 && tid < n_dst) dgv = a.deg[n0 + tid];
+    constexpr int BT = MF_THREADS, DPP = BT / SPD, NP = 32 / DPP;
+    const int gsh = (SPD == 32) ? 32 * (lane >> 5) : 0;
+    int ent[NP];
+    const int slot0 = (n0 + tid / SPD) * a.S + tid % SPD, pstride = DPP * a.S;
+    float hv[NP];
+    auto load_k = [&](int k) {
+      const float* __restrict__ hk = a.h + (size_t)k * a.h_kstride;
+#pragma unroll
+      for (int p = 0; p < NP; ++p) hv[p] = hk[slot0 + p * pstride];
+    };
+    load_k(k_of(0));
+    float evx[NP], evy[NP], evz[NP];
+    int sjv[NP];
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+      const int g = tid + BT * p, i = g / SPD, t = g % SPD;
+      const bool in = i < n_dst && t < a.S;
+      sjv[p] = in ? a.esrc[slot0 + p * pstride] : 0;
+      float4 ge = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (in) ge = a.egeo[slot0 + p * pstride];
+      evx[p] = ge.x; evy[p] = ge.y; evz[p] = ge.z;
+    }
+    // ---- segment prologue: zero the coefficient tiles; the window's rows (already split, two atoms per word): a copy, transposed
+    for (int idx = tid; idx < 2 * MF_CB / 16; idx += MF_THREADS) reinterpret_cast<float4*>(lds + X_C)[idx] = make_float4(0.f, 0.f, 0.f, 0.f);
+    {
+      const unsigned* __restrict__ ph = a.xph + (size_t)(s_base >> 1) * 64;
+      const unsigned* __restrict__ pl = a.xpl + (size_t)(s_base >> 1) * 64;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {  // 32 pairs x 64 channels over 512 threads
+        const int idx = tid + MF_THREADS * q, ch = idx & 63, jp = idx >> 6;
+        *reinterpret_cast<unsigned*>(lds + X_H + ch * MF_ROWB + 4 * jp) = ph[idx];
+        *reinterpret_cast<unsigned*>(lds + X_L + ch * MF_ROWB + 4 * jp) = pl[idx];
+      }
+    }
+    if (tid < 32) deg_lds[tid] = dgv;
+    LDS_BARRIER();
+
+    // ---- builder state (all eight waves): as k_conv_mfi
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+      const int g = tid + BT * p, i = g / SPD, t = g % SPD;
+      const int dg = deg_lds[i];
+      const bool in = t < dg && t < a.S;
+      const int sj = sjv[p];
+      const bool bonded = in && sj < 0;
+      const int jraw = sj & 0x7fffffff, jl = jraw - s_base;
+      const bool valid = in && jl >= 0 && jl < 64;
+      bool active = valid;
+      int d0 = 0, d1 = 0;
+      const unsigned long long balb = __ballot(bonded);
+      const unsigned long long gmask = (SPD == 32) ? 0xffffffffull : ~0ull;
+      const int nb = __popcll((balb >> gsh) & gmask);
+      const int nb_max = RFL(SPD == 32 ? max(__popcll(balb & 0xffffffffull), __popcll(balb >> 32)) : __popcll(balb));
+      for (int b = 0; b < nb_max; ++b) {
+        const int lb = dg - nb + b;
+        const int jb = __shfl(jraw, (lb & (SPD - 1)) + gsh, 64);
+        const bool match = b < nb && valid && t < lb && jraw == jb;
+        const unsigned long long mb = (__ballot(match) >> gsh) & gmask;
+        if (b < nb && mb != 0ull) {
+          const int first = __ffsll((long long)mb) - 1;
+          if (t == lb) active = false;
+          if (t == first) {
+            if (d0 == 0) d0 = lb - t;
+            else if (d1 == 0) d1 = lb - t;
+            else atomicOr(a.err, 1);
+          }
+        }
+      }
+      ent[p] = active ? (i * MF_ROWB + 2 * jl) | (d0 << 13) | (d1 << 19) : 128;
+    }
+    const float scC = pow2f(a.sC);
+    auto coef = [&](int p) {
+      const int d0 = (ent[p] >> 13) & 63, d1 = (ent[p] >> 19) & 63;
+      const float t0 = __shfl(hv[p], lane + d0, 64), t1 = __shfl(hv[p], lane + d1, 64);
+      return (hv[p] + (d0 ? t0 : 0.f)) + (d1 ? t1 : 0.f);
+    };
+    auto build = [&](int buf) {
+      char* __restrict__ cbuf = lds + X_C + buf * MF_CB;
+#pragma unroll
+      for (int p = 0; p < NP; ++p) {
+        const float c0 = coef(p) * scC, c1 = c0 * evx[p], c2 = c0 * evy[p], c3 = c0 * evz[p];
+        const unsigned h01 = cvt_pk_f16(c0, c1), h23 = cvt_pk_f16(c2, c3);
+        const unsigned l01 = cvt_pk_f16(resid_lo(c0, h01), resid_hi(c1, h01)), l23 = cvt_pk_f16(resid_lo(c2, h23), resid_hi(c3, h23));
+        char* __restrict__ d = cbuf + (ent[p] & 0x1fff);
+        *reinterpret_cast<unsigned short*>(d) = (unsigned short)(h01 & 0xffffu);
+        *reinterpret_cast<unsigned short*>(d + MF_PL) = (unsigned short)(l01 & 0xffffu);
+        *reinterpret_cast<unsigned short*>(d + 2 * MF_PL) = (unsigned short)(h01 >> 16);
+        *reinterpret_cast<unsigned short*>(d + 3 * MF_PL) = (unsigned short)(l01 >> 16);
+        *reinterpret_cast<unsigned short*>(d + 4 * MF_PL) = (unsigned short)(h23 & 0xffffu);
+        *reinterpret_cast<unsigned short*>(d + 5 * MF_PL) = (unsigned short)(l23 & 0xffffu);
+        *reinterpret_cast<unsigned short*>(d + 6 * MF_PL) = (unsigned short)(h23 >> 16);
+        *reinterpret_cast<unsigned short*>(d + 7 * MF_PL) = (unsigned short)(l23 >> 16);
+      }
+    };
+
+    // ---- matrix work: wave = 2 c + t: coefficient component c, channel tile t
+    const int r = lane & 31, hh = lane >> 5;
+    const int comp = wave >> 1, ct = wave & 1;
+    const int edeg_r = deg_lds[r] > 0 ? exp_above((float)deg_lds[r]) : 1;
+    const float rs = pow2f(-14 - edeg_r);  // formed values are below in-degree x 2^28 -> below 2^14
+    const int fo = r * MF_ROWB + 16 * hh + L0;
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float4*>(a.wx), 0, 0x7fffffff, 0x00020000);
+    const int wvo = lane * 16;
+    auto wload = [&](int so) { return __builtin_amdgcn_raw_buffer_load_b128(wrs, wvo, so, 0); };
+    // the wave's x^T fragments do not depend on the hidden unit: read once per segment (A operand: channels 32 t + r, K-steps of 16 rows)
+    float4 xh[4], xl[4];
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) { xh[s4] = lds_f4(X_H + 32 * ct * MF_ROWB + fo + 32 * s4); xl[s4] = lds_f4(X_L + 32 * ct * MF_ROWB + fo + 32 * s4); }
+    auto form_split = [&](int cb, float4 (&Ah)[2], float4 (&Al)[2]) {
+      f32x16 F;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) F[q] = 0.f;
+#pragma unroll
+      for (int s4 = 0; s4 < 4; ++s4) {
+        const float4 bh = lds_f4(cb + 32 * s4), bl = lds_f4(cb + MF_PL + 32 * s4);
+        M3(F, xh[s4], xl[s4], bh, bl);
+      }
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        unsigned ph[4], pl[4];
+#pragma unroll
+        for (int p2 = 0; p2 < 4; ++p2) {
+          const float v0 = F[8 * s2 + 2 * p2] * rs, v1 = F[8 * s2 + 2 * p2 + 1] * rs;
+          ph[p2] = cvt_pk_f16(v0, v1);
+          pl[p2] = cvt_pk_f16(resid_lo(v0, ph[p2]), resid_hi(v1, ph[p2]));
+        }
+        Ah[s2] = make_float4(__uint_as_float(ph[0]), __uint_as_float(ph[1]), __uint_as_float(ph[2]), __uint_as_float(ph[3]));
+        Al[s2] = make_float4(__uint_as_float(pl[0]), __uint_as_float(pl[1]), __uint_as_float(pl[2]), __uint_as_float(pl[3]));
+      }
+    };
+    build(0);
+    load_k(k_of(1));
+    __builtin_amdgcn_sched_barrier(0);
+    float* __restrict__ ST0 = reinterpret_cast<float*>(lds);                   // [2 channel tiles][32][160] partial scalar-output tiles
+    float* __restrict__ ST1 = reinterpret_cast<float*>(lds + 2 * 32 * 160 * 4);  // [2][32][96] partial vector planes
+    if (comp == 0) {
+      // scalar outputs: 20 weight blocks per hidden unit ((hi, lo) per (output tile n, K-step s2)), ring of 10
+      constexpr int NB = 20, R = 10;
+      f32x16 accS[5];
+#pragma unroll
+      for (int n = 0; n < 5; ++n)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) accS[n][q] = 0.f;
+      auto wstream = [&](int k) { return (k * 48 + 20 * ct) * 1024; };
+      u32x4 RB[R];
+      {
+        const int c0 = wstream(k_of(0));
+#pragma unroll
+        for (int p = 0; p < R; ++p) RB[p] = wload(c0 + p * 1024);
+      }
+      LDS_BARRIER();  // C(k0) complete
+      for (int it = 0; it < nk; ++it) {
+        const int cur = wstream(k_of(it)), nxt = wstream(k_of(it + 1));
+        float4 Ah[2], Al[2];
+        form_split(X_C + (it & 1) * MF_CB + fo, Ah, Al);
+#pragma unroll
+        for (int n = 0; n < 5; ++n)
+#pragma unroll
+          for (int s2 = 0; s2 < 2; ++s2) {
+            const int p = 2 * (2 * n + s2);
+            M3(accS[n], Ah[s2], Al[s2], RB[p % R], RB[(p + 1) % R]);
+#pragma unroll
+            for (int e = 0; e < 2; ++e) RB[(p + e) % R] = (p + e + R < NB) ? wload(cur + (p + e + R) * 1024) : wload(nxt + (p + e + R - NB) * 1024);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        build((it + 1) & 1);
+        load_k(k_of(it + 2));
+        __builtin_amdgcn_sched_barrier(0);
+        LDS_BARRIER();
+      }
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int row = (q & 3) + 8 * (q >> 2) + 4 * hh;
+#pragma unroll
+        for (int n = 0; n < 5; ++n) ST0[(ct * 32 + row) * 160 + 32 * n + r] = accS[n][q];
+      }
+    } else {
+      // vector plane m = comp - 1: 4 weight blocks per hidden unit ((hi, lo) per K-step), the next unit's requested as they are used
+      f32x16 accP;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) accP[q] = 0.f;
+      auto wstream = [&](int k) { return (k * 48 + 40 + 4 * ct) * 1024; };
+      u32x4 RB[4];
+      {
+        const int c0 = wstream(k_of(0));
+#pragma unroll
+        for (int p = 0; p < 4; ++p) RB[p] = wload(c0 + p * 1024);
+      }
+      LDS_BARRIER();
+      for (int it = 0; it < nk; ++it) {
+        const int nxt = wstream(k_of(it + 1));
+        float4 Ah[2], Al[2];
+        form_split(X_C + (it & 1) * MF_CB + comp * 2 * MF_PL + fo, Ah, Al);
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+          M3(accP, Ah[s2], Al[s2], RB[2 * s2], RB[2 * s2 + 1]);
+          RB[2 * s2] = wload(nxt + (2 * s2) * 1024);
+          RB[2 * s2 + 1] = wload(nxt + (2 * s2 + 1) * 1024);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        build((it + 1) & 1);
+        load_k(k_of(it + 2));
+        __builtin_amdgcn_sched_barrier(0);
+        LDS_BARRIER();
+      }
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int row = (q & 3) + 8 * (q >> 2) + 4 * hh;
+        ST1[(ct * 32 + row) * 96 + (comp - 1) * 32 + r] = accP[q];
+      }
+    }
+    // (the staging tiles alias the x^T rows and the first coefficient buffer: every wave left the loop through its last barrier, after
+    // which nothing reads those; the stores above of a fast wave may precede a slow wave's last barrier only by program order of ITS
+    // OWN reads, all finished — the k loop ends with a barrier on every path)
+    LDS_BARRIER();
+    {
+      const float i1 = pow2f(clamp100(-(a.sX + a.sC)));
+      auto i2_of = [&](int row) {
+        const int edeg = deg_lds[row] > 0 ? exp_above((float)deg_lds[row]) : 1;
+        return pow2f(14 + edeg);
+      };
+      float* __restrict__ p0 = a.partial0 + ((size_t)slab * a.n_pad + n0) * (size_t)(a.nt0 * 32);
+      float* __restrict__ p1 = a.partial1 + ((size_t)slab * a.n_pad + n0) * 96;
+      for (int idx = tid; idx < 32 * 40; idx += MF_THREADS) {
+        const int row = idx / 40, c4 = idx - row * 40;
+        const float4 a0 = *reinterpret_cast<const float4*>(ST0 + row * 160 + 4 * c4), a1 = *reinterpret_cast<const float4*>(ST0 + 5120 + row * 160 + 4 * c4);
+        const float4 cf = reinterpret_cast<const float4*>(a.cf0)[c4];
+        const float i2 = i2_of(row);
+        if (row < n_dst)
+          *reinterpret_cast<float4*>(p0 + row * 160 + 4 * c4) = make_float4((((a0.x + a1.x) * i1) * i2) * cf.x, (((a0.y + a1.y) * i1) * i2) * cf.y,
+                                                                             (((a0.z + a1.z) * i1) * i2) * cf.z, (((a0.w + a1.w) * i1) * i2) * cf.w);
+      }
+      for (int idx = tid; idx < 32 * 24; idx += MF_THREADS) {
+        const int row = idx / 24, c4 = idx - row * 24;
+        const float4 a0 = *reinterpret_cast<const float4*>(ST1 + row * 96 + 4 * c4), a1 = *reinterpret_cast<const float4*>(ST1 + 3072 + row * 96 + 4 * c4);
+        const float4 cf = reinterpret_cast<const float4*>(a.cf1)[c4 & 7];
+        const float i2 = i2_of(row);
+        if (row < n_dst)
+          *reinterpret_cast<float4*>(p1 + row * 96 + 4 * c4) = make_float4((((a0.x + a1.x) * i1) * i2) * cf.x, (((a0.y + a1.y) * i1) * i2) * cf.y,
+                                                                            (((a0.z + a1.z) * i1) * i2) * cf.z, (((a0.w + a1.w) * i1) * i2) * cf.w);
+      }
+    }
+    LDS_BARRIER();  // the next segment rewrites the tiles
+  }
+}
+
 void conv_mf_print_stamps() {
 #ifdef MF_TRACE
   static unsigned long long tr[8][40][8];
@@ -1074,7 +1360,18 @@ int launch_conv_mfi(const MfiArgs& a, int grid, hipStream_t st) {
   return 0;
 }
 
+int launch_conv_mfx(const MfxArgs& a, int grid, hipStream_t st) {
+  if (a.nt0 != 5 || a.S > 64) return -1;
+  const size_t smem = 2 * 64 * MF_ROWB + 2 * MF_CB + 144;
+  if (a.S <= 32) hipLaunchKernelGGL((k_conv_mfx<32>), dim3(grid), dim3(MF_THREADS), smem, st, a);
+  else hipLaunchKernelGGL((k_conv_mfx<64>), dim3(grid), dim3(MF_THREADS), smem, st, a);
+  return 0;
+}
+
 int conv_mf_set_max_lds() {
+  const void* fx[2] = {(const void*)k_conv_mfx<32>, (const void*)k_conv_mfx<64>};
+  for (const void* f : fx)
+    if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, JAMUN_MAX_DYN_LDS) != hipSuccess) return -1;
   const void* fi[6] = {(const void*)k_conv_mfi<32, 1>, (const void*)k_conv_mfi<64, 1>, (const void*)k_conv_mfi<32, 2>, (const void*)k_conv_mfi<64, 2>,
                        (const void*)k_conv_mfi<32, 4>, (const void*)k_conv_mfi<64, 4>};
   for (const void* f : fi)

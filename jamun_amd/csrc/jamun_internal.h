@@ -166,6 +166,33 @@ struct MfiArgs {
   int* err;
 };
 
+// initial projector formed from the feature rows (k_conv_mfx in jamun_conv_mf.hip): batches with many distinct embedding rows
+struct MfxArgs {
+  const int* deg;
+  const int* esrc;
+  const float4* egeo;
+  const float* h;  // [hidden unit k (65 rows)][h_kstride]
+  size_t h_kstride;
+  int n_pad, S;
+  const int2* tile_span;
+  const int2* tile_atoms;
+  const int4* segs;
+  int max_segs, nt0;
+  // the noise-scaled atom embedding, padded to 64 channels, times the channel factors 2^e_u and 2^sX, split: word [atom pair p][channel]
+  // = halves of atoms 2 p (low) and 2 p + 1 (high); hi plane and lo plane; zero rows behind the last atom (a window reads 32 pairs)
+  const unsigned* xph;
+  const unsigned* xpl;
+  // wx [k][48 blocks of 64 lanes x 8 halves], (hi, lo) pairs, K index permuted as MfArgs::wm (half p of lane (column c, hh), K-step s2
+  // <-> channel 32 t + 16 s2 + (p & 3) + 8 (p >> 2) + 4 hh):  20 t + 2 (2 n + s2) + {0, 1}: channel tile t -> scalar-output tile n;
+  // 40 + 4 t + 2 s2 + {0, 1}: channel tile t -> the vector rows (the same block for the three planes)
+  const float4* wx;
+  int sX, sC;
+  const float *cf0, *cf1;  // inverse column scales of the balanced weights, as MfArgs
+  float* partial0;
+  float* partial1;
+  int* err;
+};
+
 // initial-projector conv (jamun_conv_init.hip): apply-only contraction against the precomputed input-times-weight table
 struct InitArgs {
   const int* deg;
@@ -324,6 +351,7 @@ void launch_tprod(const float* x, int XS, int n_atoms, int n_k, const float4* wt
                   hipStream_t st);
 int launch_conv_mf(const MfArgs& a, int grid, hipStream_t st);
 int launch_conv_mfi(const MfiArgs& a, int grid, hipStream_t st);
+int launch_conv_mfx(const MfxArgs& a, int grid, hipStream_t st);
 int conv_mf_set_max_lds();
 size_t conv_mf_lds_bytes();
 int launch_conv_init(const InitArgs& a, int grid, hipStream_t st);

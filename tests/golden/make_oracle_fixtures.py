@@ -51,6 +51,11 @@ def molecules(kind):
     # tests/test_gpu_parity.py::test_full_size_batches_of_the_multi_gpu_configs_match_the_oracle
     if kind == "chain33x4":
         return [synth.random_chain(33, seed=0)] * 4
+    # BASELINE configs[1] as the reference runs it (sample_uncapped_2AA.yaml:18-19): one walker per distinct dipeptide — 48 of the 400,
+    # real topology (9..29 heavy atoms), every residue type: 100+ distinct embedding rows in one batch
+    if kind == "dipep48":
+        codes = synth.all_dipeptides()
+        return [synth.peptide(codes[(i * 400) // 48 + (i % 7)], seed=i) for i in range(48)]
     if kind == "cfg4kinds":
         import random
 
@@ -154,6 +159,7 @@ CASES = {
     "oracle_forward_sep_chig93x2": lambda **kw: forward_case("chig93x2", False, separable=True),
     "oracle_forward_cfg4kinds": lambda **kw: forward_case("cfg4kinds", False),
     # beyond the default hyper-parameter point / architecture / weight distribution (VARIANTS above)
+    "oracle_forward_dipep48": lambda **kw: forward_case("dipep48", True),
     "oracle_forward_nl2_ragged": lambda **kw: forward_case("ragged", True, variant="nl2"),
     "oracle_forward_sep_nl4_ragged": lambda **kw: forward_case("ragged", True, variant="sep_nl4"),
     "oracle_forward_idrome_ragged": lambda **kw: forward_case("ragged", True, variant="idrome"),

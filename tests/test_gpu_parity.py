@@ -60,6 +60,15 @@ def _mols(kind):
     raise KeyError(kind)
 
 
+def _init_path_of(mols):
+    """The initial projector jamun_sampler_create picks on the tiles of k_conv_mf: up to 32 distinct embedding rows (atom type, atom
+    name, residue — the sequence index is not used) k_conv_mfi (3), more k_conv_mfx (4)."""
+    rows = set()
+    for m in mols:
+        rows |= set(zip(m["atom_type_index"].tolist(), m["atom_code_index"].tolist(), m["residue_code_index"].tolist()))
+    return 3 if len(rows) <= 32 else 4
+
+
 def _oracle_setup(mols, ckpt, dtype=torch.float32):
     from oracle import denoiser as od
     from oracle import graph as og
@@ -354,10 +363,10 @@ def test_fused_and_fallback_conv_agree(dev, golden_dir, kind, monkeypatch):
     # embedding rows, k_conv_mfi (selector-formed coefficient sums on the matrix cores, init_path 3); else edge by edge on the tiles of
     # the dg kernel when the spans fit two LDS row buffers (jamun_conv_initv.hip, 2: molecules up to 40 atoms, one buffer for
     # chignolin-size spans); mid-size molecules keep the MFMA table kernel (1).  Each is switched off in turn: same features.
-    expect_init = {"ag4": 3, "chain17x6": 3, "ragged_small": 3, "ragged": 3, "dense70": 1, "chig93x2": 2, "chig166x2": 2}[kind]
+    expect_init = {"ag4": 3, "chain17x6": 3, "ragged_small": 4, "ragged": 4, "dense70": 1, "chig93x2": 2, "chig166x2": 2}[kind]
     assert dg.stats()["init_path"] == expect_init, (kind, dg.stats()["init_path"])
     a1 = dg.debug_read(0, 0).cpu()
-    if expect_init == 3:
+    if expect_init >= 3:
         monkeypatch.setenv("JAMUN_NO_MFI", "1")
         no_mfi = NativeSampler(model._native, 0.04, batch, dev)
         assert no_mfi.stats()["init_path"] == (1 if kind == "ragged" else 2), no_mfi.stats()["init_path"]
@@ -466,8 +475,10 @@ def test_matrix_formed_conv_edge_cases(dev, case, monkeypatch):
     y = batch.pos + 0.04 * torch.randn(batch.pos.shape).to(dev)
     mf = NativeSampler(model._native, 0.04, batch, dev)
     st = mf.stats()
-    # (more than 128 distinct embedding rows: the initial projector stays on the table kernel of the fused tile plan)
-    assert (st["conv_path"], st["dg_mode"], st["init_path"]) == (2, 4, 1 if case == "many_rows" else 3), st
+    # (more than 32 distinct embedding rows: the initial projector is formed from the feature rows, k_conv_mfx)
+    assert (st["conv_path"], st["dg_mode"], st["init_path"]) == (2, 4, _init_path_of(mols)), st
+    if case in ("many_rows", "rows100"):
+        assert st["init_path"] == 4
     monkeypatch.setenv("JAMUN_NO_DG", "1")
     monkeypatch.setenv("JAMUN_NO_FUSED", "1")
     general = NativeSampler(model._native, 0.04, batch, dev)
@@ -485,7 +496,7 @@ def test_matrix_formed_conv_edge_cases(dev, case, monkeypatch):
         assert NativeSampler(model._native, 0.04, big, dev).stats()["dg_mode"] != 4
 
 
-@pytest.mark.parametrize("atoms,walkers,dg_mode,init_path", [(17, 64, 4, 3), (33, 64, 4, 3), (57, 32, 4, 3), (70, 16, 3, 1), (166, 4, 1, 2)])
+@pytest.mark.parametrize("atoms,walkers,dg_mode,init_path", [(17, 64, 4, 3), (33, 64, 4, 3), (57, 32, 4, 4), (70, 16, 3, 1), (166, 4, 1, 2)])
 def test_kernel_variants_chosen_for_the_baseline_shapes(dev, atoms, walkers, dg_mode, init_path):
     """BASELINE configs[1..4] shapes (fewer walkers): which variant of the hidden-layer conv kernel (jamun_stats.dg_mode) and of
     the initial projector (init_path) the sampler picks, and that the forward through them is finite and rotation-equivariant."""
@@ -1043,7 +1054,8 @@ def test_long_walks_are_bit_reproducible(dev, shape):
     model = Denoiser.from_checkpoint_dict(synth.synthetic_checkpoint(output_gain=0.05)).to(dev)
     batch = WalkerBatch.from_molecules(mols).to(dev)
     smp = model.sampler_for(batch, 0.04)
-    assert smp.stats()["dg_mode"] == 4 and smp.stats()["init_path"] == (1 if shape == "ragged" else 3), smp.stats()  # (ragged: > 128 distinct embedding rows)
+    assert smp.stats()["dg_mode"] == 4 and smp.stats()["init_path"] == _init_path_of(mols), smp.stats()
+    assert (shape == "ragged") == (smp.stats()["init_path"] == 4)  # (the ragged batch has more than 32 distinct embedding rows)
     torch.manual_seed(0)
     y0 = batch.pos + 0.04 * torch.randn_like(batch.pos)
     params = native.make_mcmc_params(steps, delta=0.04, friction=1.0, M=1.0, inverse_temperature=1.0, score_fn_clip=100.0)

@@ -42,8 +42,10 @@ CASES = [
     ("r1000", "ragged", dict(dg_emu=1)),
     ("h64x16", "ragged", dict()),
     ("trained", "chain17x6", dict(dg_mode=4, init_path=3, dg_emu=1)),
-    ("trained", "ragged", dict(dg_mode=4, init_path=3, dg_emu=1)),
+    ("trained", "ragged", dict(dg_mode=4, init_path=4, dg_emu=1)),
     ("sep_trained", "ragged", dict()),
+    # the default point on BASELINE configs[1] as the reference runs it: 48 DISTINCT dipeptides (real topology, 143 distinct embedding rows)
+    ("default", "dipep48", dict(dg_mode=4, dg_emu=1, init_path=4)),
 ]
 
 
@@ -54,7 +56,7 @@ def test_forward_matches_oracle_at_other_hyperparameters(variant, kind, want):
 
     mk = _mk()
     dev = torch.device("cuda", 0)
-    ref = _golden(f"oracle_forward_{variant}_{kind}")
+    ref = _golden(f"oracle_forward_{variant}_{kind}" if variant != "default" else f"oracle_forward_{kind}")
     sigma = mk.VARIANTS[variant]["sigma"]
     ck = mk.variant_checkpoint(variant)
     model = Denoiser.from_checkpoint_dict(ck).to(dev)
