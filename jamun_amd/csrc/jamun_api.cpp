@@ -115,8 +115,9 @@ struct DgDev {
   float *gx = nullptr, *gT = nullptr, *cf0 = nullptr, *cf1 = nullptr, *cfT = nullptr;
 };
 struct SepDev {
-  float *w2p = nullptr, *wl0 = nullptr, *wl1 = nullptr;  // null: not a SeparableConv layer
-  int n0 = 0, n1 = 0, NWp = 0;
+  float4* w2b = nullptr;  // null: not a SeparableConv layer
+  float *cfw = nullptr, *bias = nullptr, *wl0 = nullptr, *wl1 = nullptr;
+  int n0 = 0, n1 = 0, sH = 0;
 };
 struct LayerDev {
   ConvProblemDev p0, p1;
@@ -361,7 +362,8 @@ struct jamun_sampler {
   int2 *dg_tile_atoms = nullptr, *dg_tile_span = nullptr;
   int4* dg_segs = nullptr;
   int* dg_atom_nslab = nullptr;
-  float* sep_w = nullptr;  // SeparableConv: [n_atoms * S][NWp] per-edge depth-wise weights of the layer at hand
+  float* sep_D = nullptr;  // SeparableConv: [n_atoms][K0 + 3 K1] per-destination sums of the layer at hand
+  int cus = 1;
   float* dg_dump = nullptr;  // diagnostic A-tile dump (JAMUN_DG_DUMP, -DJAMUN_DUMP builds)
   float* dg_T = nullptr;  // [n_k][n_atoms][32] pre-pass product of a hidden layer (k_tprod), reused by every layer
   int dg_tstride = 0;     // mode 4 (jamun_conv_mf.hip): dg_T is [n_k][32][dg_tstride], transposed
@@ -399,7 +401,7 @@ struct jamun_sampler {
     if (mf_err_host) hipHostFree(mf_err_host);
     for (auto& L : layers) {
       free_problem(L.p0); free_problem(L.p1); free_fused(L.fu); free_dg(L.dg);
-      hipFree(L.sep.w2p); hipFree(L.sep.wl0); hipFree(L.sep.wl1);
+      hipFree(L.sep.w2b); hipFree(L.sep.cfw); hipFree(L.sep.bias); hipFree(L.sep.wl0); hipFree(L.sep.wl1);
       hipFree(L.wcat0); hipFree(L.wcat1); hipFree(L.wh0); hipFree(L.wh1); hipFree(L.kga0); hipFree(L.kga1); hipFree(L.kgx); hipFree(L.cg0); hipFree(L.cg1); hipFree(L.mix); hipFree(L.tt); hipFree(L.tt2); hipFree(L.tabw);
       hipFree(L.wx); hipFree(L.xph); hipFree(L.xpl); hipFree(L.xcf0); hipFree(L.xcf1);
     }
@@ -407,7 +409,7 @@ struct jamun_sampler {
     hipFree(yc); hipFree(h); hipFree(partial0); hipFree(partial1); hipFree(g); hipFree(tmp);
     hipFree(xhat_buf); hipFree(score_buf); hipFree(psi); hipFree(deg); hipFree(esrc); hipFree(egeo);
     for (float* p : x) hipFree(p);
-    hipFree(counter); hipFree(sep_w);
+    hipFree(counter); hipFree(sep_D);
     for (hipEvent_t e : ev_pool) hipEventDestroy(e);
   }
 };
@@ -613,13 +615,52 @@ LayerDev build_layer_separable(const jamun_model& m, const std::string& prefix, 
       for (int k = 0; k <= H; ++k)
         w2c[(size_t)k * NWp + col] = sc * (k < H ? (double)W3[(size_t)(t.woff + u) * H + k] : (double)b3[t.woff + u]);
     }
-  std::vector<float> w2p((size_t)33 * n_ct * 64, 0.f);
-  for (int s = 0; s < 33; ++s)
-    for (int ct = 0; ct < n_ct; ++ct)
-      for (int lane = 0; lane < 64; ++lane) {
-        const int k = 2 * s + (lane >> 5), col = 32 * ct + (lane & 31);
-        if (k <= H) w2p[((size_t)s * n_ct + ct) * 64 + lane] = (float)w2c[(size_t)k * NWp + col];
-      }
+  // B fragments of the f16x3 weight GEMM of k_sep_fused: column tiles A 0..3 (x0 -> 0e, channel u at column 32 ct + c), B 4..7, C 8, D 9,
+  // E 10; every column balanced by its own power of two (the depth-wise weights inherit the spread of the channels they multiply),
+  // split hi + lo; the bias row (hidden unit H: the radial MLP's output bias) is added in fp32 after the product
+  if (H != 64 || n0 > 128 || n1 > 32) throw Err(JAMUN_ERR_INVALID, "SeparableConv: unsupported irreps / radial MLP width");
+  (void)n_ct;
+  std::vector<float> cfw(352, 0.f), bias(352, 0.f);
+  std::vector<float4> w2b((size_t)4 * 11 * 2 * 64, make_float4(0.f, 0.f, 0.f, 0.f));
+  {
+    auto old_col = [&](int nc) -> int {  // new column -> canonical column of w2c (-1: padding)
+      if (nc < 128) return nc < n0 ? base[0] + nc : -1;
+      if (nc < 256) return nc - 128 < n0 ? base[1] + (nc - 128) : -1;
+      const int kind = 2 + (nc - 256) / 32, u = (nc - 256) % 32;
+      return u < n1 ? base[kind] + u : -1;
+    };
+    std::vector<double> csc(352, 1.0);
+    for (int nc = 0; nc < 352; ++nc) {
+      const int oc = old_col(nc);
+      if (oc < 0) continue;
+      double mx = 0;
+      for (int k = 0; k < H; ++k) mx = std::max(mx, std::fabs(w2c[(size_t)k * NWp + oc]));
+      int ex = 0;
+      if (mx > 0 && std::isfinite(mx)) std::frexp(mx, &ex);
+      const int sW = 14 - std::max(-40, std::min(40, ex));
+      csc[nc] = std::ldexp(1.0, sW);
+      cfw[nc] = (float)std::ldexp(1.0, -sW);
+      bias[nc] = (float)w2c[(size_t)H * NWp + oc];
+    }
+    for (int s4 = 0; s4 < 4; ++s4)
+      for (int ct = 0; ct < 11; ++ct)
+        for (int lane = 0; lane < 64; ++lane) {
+          const int hh = lane >> 5, nc = 32 * ct + (lane & 31), oc = old_col(nc);
+          uint32_t hw[4], lw[4];
+          for (int i = 0; i < 4; ++i) {
+            uint16_t hp[2], lp[2];
+            for (int e = 0; e < 2; ++e) {
+              const int k = 16 * s4 + 8 * hh + 2 * i + e;
+              split_f16(oc >= 0 ? w2c[(size_t)k * NWp + oc] * csc[nc] : 0.0, hp[e], lp[e]);
+            }
+            hw[i] = (uint32_t)hp[0] | ((uint32_t)hp[1] << 16);
+            lw[i] = (uint32_t)lp[0] | ((uint32_t)lp[1] << 16);
+          }
+          const size_t bidx = (((size_t)s4 * 11 + ct) * 2) * 64 + lane;
+          std::memcpy(&w2b[bidx], hw, 16);
+          std::memcpy(&w2b[bidx + 64], lw, 16);
+        }
+  }
   const int K0 = n0 + n1, K1 = n0 + 2 * n1;
   std::vector<float> wl0((size_t)K0 * G0, 0.f), wl1((size_t)std::max(K1 * G1, 1), 0.f);
   for (const Tri& t : tri)
@@ -630,16 +671,23 @@ LayerDev build_layer_separable(const jamun_model& m, const std::string& prefix, 
       const double nrm = 1.0 / std::sqrt((double)(scalar_out ? K0 : K1));
       for (int w = 0; w < G; ++w) (scalar_out ? wl0 : wl1)[(size_t)row * G + w] = (float)((double)WL[t.loff + (int64_t)u * G + w] * nrm);
     }
-  L.sep.w2p = dev_upload(w2p);
+  L.sep.w2b = dev_upload(w2b);
+  L.sep.cfw = dev_upload(cfw);
+  L.sep.bias = dev_upload(bias);
   L.sep.wl0 = dev_upload(wl0);
   L.sep.wl1 = dev_upload(wl1);
-  L.sep.n0 = n0; L.sep.n1 = n1; L.sep.NWp = NWp;
+  L.sep.n0 = n0; L.sep.n1 = n1;
   L.p0.nt = (G0 + 31) / 32;  // (the node update reads the slab widths from here)
   L.p1.nt = (G1 + 31) / 32;
   L.p0.planes = 1; L.p1.planes = 3;
   L.in0 = n0; L.in1 = n1; L.XSin = n0 + 3 * n1;
   L.tp_numel = woff;
   build_layer_common(m, prefix, in_blocks, s_in, L, n0, n1);
+  {  // static scale of h~ (bounded by the radial MLP's first layer: build_layer_common)
+    int ex = 0;
+    std::frexp(0.5 * (double)L.dg.hmax2, &ex);
+    L.sep.sH = std::max(-40, std::min(40, 14 - ex));
+  }
   return L;
 }
 
@@ -1381,15 +1429,16 @@ void run_layer(jamun_sampler* s, size_t l, const float* x_in, int XSin, float* x
     launch_edge_h(s->deg, s->esrc, s->egeo, s->n_atoms, s->S, s->w1r_all + l * 64 * 32, s->cmask_all + l * 128, 1, s->mu, s->rb_step, s->h,
                   s->h_stride, s->h_kstride, st, s->w1h_all ? s->w1h_all + l * 8 * 64 : nullptr, s->w1isc_all ? s->w1isc_all + l : nullptr);
   }
-    if (L.sep.w2p) {
+    if (L.sep.w2b) {
       SepArgs f{};
       f.deg = s->deg; f.esrc = s->esrc; f.egeo = s->egeo; f.h = h_l; f.h_kstride = s->h_kstride; f.x = x_in;
-      f.n_atoms = s->n_atoms; f.S = s->S; f.XS = XSin; f.n_slots = (int64_t)s->n_atoms * s->S;
-      f.n0 = L.sep.n0; f.n1 = L.sep.n1; f.NWp = L.sep.NWp; f.w2p = L.sep.w2p; f.w = s->sep_w; f.wl0 = L.sep.wl0; f.wl1 = L.sep.wl1;
+      f.n_atoms = s->n_atoms; f.S = s->S; f.XS = XSin;
+      f.n0 = L.sep.n0; f.n1 = L.sep.n1; f.w2b = L.sep.w2b; f.cfw = L.sep.cfw; f.bias = L.sep.bias; f.sH = L.sep.sH; f.D = s->sep_D;
+      f.wl0 = L.sep.wl0; f.wl1 = L.sep.wl1;
       f.G0 = s->hp.mul0 + s->hp.mul1; f.G1 = s->hp.mul1; f.nt0 = L.p0.nt; f.nt1 = L.p1.nt;
       f.partial0 = s->partial0; f.partial1 = s->partial1;
       ProfScope ps(s, l == 0 ? JAMUN_PROF_CONV0_INIT : JAMUN_PROF_CONV0, st);
-      if (launch_sep_conv(f, st) != 0) throw Err(JAMUN_ERR_INVALID, "separable conv launch failed (irreps not supported)");
+      if (launch_sep_conv(f, s->cus, st) != 0) throw Err(JAMUN_ERR_INVALID, "separable conv launch failed (irreps not supported)");
     } else if (l == 0 && s->mfi_on) {
       MfiArgs f{};
       f.deg = s->deg; f.esrc = s->esrc; f.egeo = s->egeo; f.h = h_l; f.h_kstride = s->h_kstride;
@@ -1518,7 +1567,7 @@ void run_layer(jamun_sampler* s, size_t l, const float* x_in, int XSin, float* x
     const bool dg_layer = (l > 0 && s->dg_on) || (l == 0 && (s->initv_on || s->mfi_on || s->mfx_on));  // (slabs of the dg tile plan)
     n.atom_nslab = dg_layer ? s->dg_atom_nslab : (L.fu.wpack ? s->atom_nslab : nullptr);
     n.max_slabs = dg_layer ? s->dg_n_slabs : (L.fu.wpack ? s->n_slabs : s->n_slices);
-    if (L.sep.w2p) { n.n_slices = 1; n.atom_nslab = nullptr; n.max_slabs = 1; }  // SeparableConv writes the summed messages as ONE slab
+    if (L.sep.w2b) { n.n_slices = 1; n.atom_nslab = nullptr; n.max_slabs = 1; }  // SeparableConv writes the summed messages as ONE slab
     n.wh0 = L.wh0; n.wh1 = L.wh1; n.K0h = L.K0h; n.K1h = L.K1h;
     n.kga0 = L.kga0; n.kga1 = L.kga1; n.kgx = L.kgx; n.cg0 = L.cg0; n.cg1 = L.cg1;
     {
@@ -1787,7 +1836,7 @@ int jamun_sampler_create(const jamun_model* m, float sigma, const jamun_topology
     if (s->S < 1) s->S = 1;
     s->n_tiles = s->n_pad / 32;
     if (conv_set_max_lds() != 0 || conv_fused_set_max_lds() != 0 || node_update_set_max_lds() != 0 || conv_init_set_max_lds() != 0 || conv_initv_set_max_lds() != 0 ||
-        conv_dg_set_max_lds() != 0 || conv_mf_set_max_lds() != 0)
+        conv_dg_set_max_lds() != 0 || conv_mf_set_max_lds() != 0 || sep_conv_set_max_lds() != 0)
       throw Err(JAMUN_ERR_HIP, "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed");
     {
       // ---- fused conv kernel: eligibility and tiling.  A tile = up to 32 consecutive destination atoms whose source
@@ -1912,8 +1961,8 @@ int jamun_sampler_create(const jamun_model* m, float sigma, const jamun_topology
       s->layers.push_back(L);
     }
     for (auto& L : s->layers)
-      if (L.sep.w2p)
-        if (const char* why = sep_conv_unsupported(L.sep.n0, L.sep.n1, L.sep.NWp, s->S)) throw Err(JAMUN_ERR_INVALID, why);
+      if (L.sep.w2b)
+        if (const char* why = sep_conv_unsupported(L.sep.n0, L.sep.n1, L.p0.nt, L.p1.nt, s->S, hp.edge_attr_dim)) throw Err(JAMUN_ERR_INVALID, why);
     // ---- head (EquivariantMLP, _mlp.py:84-114) and output gain (e3conv.py:134-135)
     {
       const int mul0 = hp.mul0, mul1 = hp.mul1, G0 = mul0 + mul1;
@@ -1945,6 +1994,7 @@ int jamun_sampler_create(const jamun_model* m, float sigma, const jamun_topology
       HIPCHECK(hipGetDeviceProperties(&prop, dev));
     }
     const int cus = std::max(prop.multiProcessorCount, 1);
+    s->cus = cus;
     const int n_k = hp.edge_attr_dim + 1;
     auto k_groups = [&](const char* env, int dflt) {  // k-slices over XCD groups: 1, 2, 4 or 8 (XCDs x, x + ng, ... share one)
       int ng = (cus % 8 == 0 && n_k >= 8) ? dflt : 1;
@@ -2168,9 +2218,10 @@ int jamun_sampler_create(const jamun_model* m, float sigma, const jamun_topology
     s->partial0 = dev_alloc<float>(n_part * s->n_pad * nt0 * 32);
     s->partial1 = dev_alloc<float>(n_part * s->n_pad * 3 * nt1 * 32);
     {
-      int nwp = 0;
-      for (auto& L : s->layers) nwp = std::max(nwp, L.sep.NWp);
-      if (nwp > 0) s->sep_w = dev_alloc<float>(NS * (size_t)nwp);
+      int dw = 0;
+      for (auto& L : s->layers)
+        if (L.sep.w2b) dw = std::max(dw, L.sep.n0 + L.sep.n1 + 3 * (L.sep.n0 + 2 * L.sep.n1));
+      if (dw > 0) s->sep_D = dev_alloc<float>((size_t)N * dw);
     }
     s->g = dev_alloc<float>((size_t)N * 3);
     s->tmp = dev_alloc<float>((size_t)N * 3);
@@ -2193,7 +2244,7 @@ int jamun_sampler_create(const jamun_model* m, float sigma, const jamun_topology
         s->conv_flop_exec_launch = (int64_t)s->dg_n_tiles * per_tile_k * (hp.edge_attr_dim + 1);
         s->flop_exec += s->conv_flop_exec_launch + (int64_t)((s->n_atoms + 31) / 32) * (s->dg_emu ? 24LL * 32768 : 60LL * 4096) * (hp.edge_attr_dim + 1);
       }
-      else if (L.sep.w2p) s->flop_exec += 2LL * (int64_t)NS * 66 * L.sep.NWp;  // the per-edge weight GEMM (the rest is VALU work per edge)
+      else if (L.sep.w2b) s->flop_exec += 3LL * 2 * (int64_t)N * 32 * ((s->S + 31) / 32) * 64 * 352;  // the per-edge weight GEMM as f16x3 (the rest is VALU work per edge)
       else if (L.fu.wpack) s->flop_exec += (int64_t)s->n_ftiles * (hp.edge_attr_dim + 1) * L.fu.mfma_per_k * 4096;  // 32x32x2 MFMA = 4096 FLOP
       else s->flop_exec += 2LL * s->n_pad * (1LL * L.p0.K * L.p0.nt * 32 + 3LL * L.p1.K * L.p1.nt * 32);
     }

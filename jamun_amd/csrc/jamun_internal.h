@@ -235,7 +235,7 @@ struct InitVArgs {
   float* partial1;      // [slab][n_pad][3][32]
 };
 
-// SeparableConv (jamun_sepconv.hip): per-edge depth-wise weights from one GEMM, per-destination sums, point-wise Linear
+// SeparableConv (jamun_sepconv.hip): per-edge depth-wise weights formed and consumed in registers, per-destination sums, point-wise Linear
 struct SepArgs {
   const int* deg;
   const int* esrc;
@@ -244,19 +244,24 @@ struct SepArgs {
   size_t h_kstride;
   const float* x;  // [n_atoms][XS] input features (scalars first, then vectors [u][3])
   int n_atoms, S, XS;
-  int64_t n_slots;  // n_atoms * S
   int n0, n1;       // scalar / vector input channels
-  int NWp;          // depth-wise weights per edge (2 n0 + 3 n1) padded to a multiple of 32
-  const float* w2p;  // [33 pairs of hidden units][NWp / 32 column tiles][64 lanes]: lane (c, hh) -> W2~[k = 2 s + hh][32 ct + c]
-  float* w;          // [n_slots][NWp] per-edge weights (work buffer)
+  // W2~ (radial MLP's second layer with every constant folded in) as B fragments of v_mfma_f32_32x32x16_f16: [4 K-steps of 16 hidden
+  // units][11 column tiles][hi, lo][64 lanes x 8 halves] (lane (c, hh): hidden units 16 s + 8 hh + j, column 32 ct + c); column tiles
+  // A 0..3, B 4..7, C 8, D 9, E 10 (jamun_sepconv.hip); columns balanced by 2^sW_col: cfw [352] = 2^-sW_col, bias [352] = the bias row
+  const float4* w2b;
+  const float* cfw;
+  const float* bias;
+  int sH;            // h~ is scaled by 2^sH (static bound of the radial MLP's hidden activations -> [2^13, 2^14))
+  float* D;          // [n_atoms][K0 + 3 K1] per-destination sums (work buffer): scalars [D0 | D3], per component m [D1 | D2 | D4]
   const float* wl0;  // [n0 + n1][G0]      point-wise Linear, scalar outputs (1 / sqrt(fan_in) folded)
   const float* wl1;  // [n0 + 2 n1][G1]    vector outputs
   int G0, G1, nt0, nt1;
   float* partial0;  // [n_pad][nt0 * 32]  (one slab)
   float* partial1;  // [n_pad][3][nt1 * 32]
 };
-const char* sep_conv_unsupported(int n0, int n1, int NWp, int S);
-int launch_sep_conv(const SepArgs& a, hipStream_t st);
+const char* sep_conv_unsupported(int n0, int n1, int nt0, int nt1, int S, int edge_attr_dim);
+int sep_conv_set_max_lds();
+int launch_sep_conv(const SepArgs& a, int cus, hipStream_t st);
 
 struct NodeArgs {
   const float* partial0;  // [n_slices][n_pad][nt0*32]

@@ -2,195 +2,333 @@
 // with the tensor product factored into a depth-wise part ("uvu": one weight per input channel and (input x sh -> output) triple,
 // 2 n0 + 3 n1 = 336 weights per edge for 120x0e + 32x1e) and a point-wise o3.Linear shared by all edges.
 //
-// Unlike the fully connected product (28 992 weights per edge, re-associated by destination in jamun_conv_dg.hip) the per-edge
-// weights are cheap here, so the REFERENCE association is the right one:
-//   k_sep_weights   w[slot][336] = h~[slot][0..64] . W2~  (+ bias row)                one fp32-MFMA GEMM, M = edge slots, K = 65
-//   k_sep_apply     per destination: D = sum_e dtp(x_src, v_e; w_e)  (704 values), then m = Linear(D)  (the Linear commutes with
-//                   the sum over edges); m goes to the partial-slab buffers of k_node_update (one slab), which divides by the
-//                   in-degree (the mean), gates, and applies self-interaction + skip as for every other conv path.
+// Unlike the fully connected product (28 992 weights per edge, re-associated by destination in jamun_conv_mf.hip) the per-edge
+// weights are cheap here, so the REFERENCE association is the right one — but the [edge slots, 336] weight tensor never reaches
+// memory (round 3 wrote and re-read 116 MB of it per layer):
+//   k_sep_fused   one wave per destination: the weights of its <= 32 edge slots, w[slot][col] = h~[slot] . W2~[:, col] + b~[col], as ONE
+//                 f16x3 MFMA tile per column tile (M = edge slots, K = 64 hidden units, N = 32 columns; h~ scaled by a static bound,
+//                 W2~ balanced per column, both split hi + lo; 12 MFMAs), consumed straight from the accumulator: lane = channel,
+//                 registers = edge slots, times the gathered source features and the edge's unit vector, summed over the slots:
+//                     D0[u]   += wA x0[u]           D1[u][m] += wB x0[u] v[m]        D2[u'][m] += wC x1[u'][m]
+//                     D3[u']  += wD (x1[u'] . v)    D4[u'][m] += wE (x1[u'] x v)[m]
+//                 -> D [atom][K0 + 3 K1] (704 floats per atom).  W2~ sits in LDS (88 KB) for the whole launch.
+//   k_sep_linear  m = Linear(D) (it commutes with the sum over edges): fp32 MFMAs, 32 atoms per workgroup, one output tile per wave;
+//                 m goes to the partial-slab buffers of the node update (one slab), which divides by the in-degree (the mean), gates,
+//                 and applies self-interaction + skip as for every other conv path.
 // Constants folded into W2~ on the host: input noise scaling, path weights sqrt(2 l + 1), Clebsch-Gordan factors and the sqrt(3)
-// of the l = 1 spherical harmonic, so that with the unit vector v of an edge
-//   D0[u]   += wA x0[u]           D1[u][m] += wB x0[u] v[m]        D2[u'][m] += wC x1[u'][m]
-//   D3[u']  += wD (x1[u'] . v)    D4[u'][m] += wE (x1[u'] x v)[m]
-// Both kernels stream: HBM / L2-bound (the weights table is written once and read once per layer).
+// of the l = 1 spherical harmonic.  Column order of W2~ (host: build_layer_separable): tiles of 32 columns — A (x0 -> 0e) in tiles
+// 0..3, B (x0 x v -> 1e) in 4..7, C (x1 -> 1e) 8, D (x1 . v -> 0e) 9, E (x1 x v -> 1e) 10.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+
+#include <algorithm>
 
 #include "jamun_internal.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 #define RFL(v) __builtin_amdgcn_readfirstlane(v)
+#define MFMA32H(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8, (a)), __builtin_bit_cast(h8, (b)), (c), 0, 0, 0)
+#define M3(ACC, AH_, AL_, BH_, BL_)   \
+  ACC = MFMA32H(AL_, BH_, ACC);       \
+  ACC = MFMA32H(AH_, BL_, ACC);       \
+  ACC = MFMA32H(AH_, BH_, ACC)
 
-// One wave = 32 consecutive edge slots x all weight columns.  A operand: h~ (k-major table: a K step is one coalesced 128-byte read
-// per half-wave), held in 33 registers for the whole wave; B operand: W2~ packed [33 K pairs][column tile][64 lanes].
-__global__ __launch_bounds__(256) void k_sep_weights(SepArgs a) {
-  const int lane = threadIdx.x & 63, wave = RFL(threadIdx.x >> 6);
-  const int r = lane & 31, hh = lane >> 5;
-  const int64_t tile = (int64_t)blockIdx.x * 4 + wave;
-  const int64_t slot0 = tile * 32;
-  if (slot0 >= a.n_slots) return;
-  const int64_t slot = slot0 + r < a.n_slots ? slot0 + r : a.n_slots - 1;
-  float av[33];
-#pragma unroll
-  for (int s = 0; s < 33; ++s) {
-    const int k = 2 * s + hh;
-    av[s] = k < JAMUN_HROWS ? a.h[(size_t)k * a.h_kstride + slot] : 0.f;
+#define SF_THREADS 512
+#define SF_NCT 11                                  // column tiles of W2~
+#define SF_W2_BYTES (4 * SF_NCT * 2 * 1024)        // [4 K-steps][11 column tiles][hi, lo][64 lanes x 16 B]
+#define SF_LDS_BYTES (SF_W2_BYTES + 8 * 64 * 16 + 2 * 352 * 4)  // + slot records [8 waves][64] float4 + column factors and biases [2][352]
+
+namespace {
+__device__ __forceinline__ unsigned cvt_pk_f16(float a, float b) {
+  unsigned r;
+  asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ float resid_lo(float a, unsigned pk) {
+  float r;
+  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r) : "v"(pk), "v"(a));
+  return r;
+}
+__device__ __forceinline__ float resid_hi(float a, unsigned pk) {
+  float r;
+  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(pk), "v"(a));
+  return r;
+}
+__device__ __forceinline__ float pow2f(int e) { return __uint_as_float((unsigned)(e + 127) << 23); }
+}  // namespace
+
+__global__ __launch_bounds__(SF_THREADS) void k_sep_fused(SepArgs a) {
+  extern __shared__ float4 sf_lds[];
+  const int tid = threadIdx.x, lane0 = tid & 63, wave = RFL(tid >> 6);
+  for (int idx = tid; idx < SF_W2_BYTES / 16; idx += SF_THREADS) sf_lds[idx] = a.w2b[idx];
+  float4* __restrict__ rec = sf_lds + SF_W2_BYTES / 16 + wave * 64;  // this wave's edge slots: (vx, vy, vz, source atom)
+  // per column: inverse column scale (times the inverse of the static scale of h~) and the bias row of W2~ (read from LDS at the point
+  // of use: 22 loop-invariant registers otherwise)
+  float* __restrict__ colc = reinterpret_cast<float*>(sf_lds + SF_W2_BYTES / 16 + 8 * 64);
+  {
+    const float ish0 = pow2f(-a.sH);
+    for (int idx = tid; idx < 352; idx += SF_THREADS) { colc[idx] = a.cfw[idx] * ish0; colc[352 + idx] = a.bias[idx]; }
   }
-  const int n_ct = a.NWp / 32;
-  for (int ct = 0; ct < n_ct; ++ct) {
-    f32x16 acc;
+  __syncthreads();
+  const int n0 = a.n0, n1 = a.n1, K0 = n0 + n1, K1 = n0 + 2 * n1, DW = K0 + 3 * K1;
+  const int nA = RFL((n0 + 31) >> 5);
+  const bool hasV = n1 > 0;
+  const float sch = pow2f(a.sH);
+
+  for (int d = blockIdx.x * 8 + wave; d < a.n_atoms; d += gridDim.x * 8) {
+    int lane = lane0;
+    asm volatile("" : "+v"(lane));  // (keeps ~40 lane-derived 64-bit addresses from being hoisted out of this loop and spilled)
+    const int c = lane & 31, hh = lane >> 5;
+    const bool vok = c < n1;
+    auto bfrag = [&](int s, int ct, int p) { return sf_lds[((s * SF_NCT + ct) * 2 + p) * 64 + lane]; };
+    const int dg = RFL(min(a.deg[d], a.S));
+    {
+      float4 r4 = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (lane < dg) {
+        const size_t slot = (size_t)d * a.S + lane;
+        const float4 ge = a.egeo[slot];
+        r4 = make_float4(ge.x, ge.y, ge.z, __int_as_float(a.esrc[slot] & 0x7fffffff));
+      }
+      rec[lane] = r4;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+    }
+    float D0[4] = {0.f, 0.f, 0.f, 0.f}, D1[4][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
+    float D2[3] = {0.f, 0.f, 0.f}, D3 = 0.f, D4[3] = {0.f, 0.f, 0.f};
+    const int n_mt = (dg + 31) >> 5;
+    for (int mt = 0; mt < n_mt; ++mt) {
+      // A fragments: h~ of slot 32 mt + c (the tile's row c), hidden units 16 s + 8 hh + j; scaled by the static 2^sH, split hi + lo
+      float4 Ah[4], Al[4];
+      {
+        const int trow = 32 * mt + c;
+        const bool rowok = trow < dg;
+        // (one lane-dependent base, then wave-uniform strides: scalar offsets)
+        const float* __restrict__ hp = a.h + (size_t)d * a.S + (rowok ? trow : 0) + (size_t)(8 * hh) * a.h_kstride;
+        float hv[4][8];
 #pragma unroll
-    for (int q = 0; q < 16; ++q) acc[q] = 0.f;
-    const float* __restrict__ bp = a.w2p + ((size_t)ct * 64 + lane);
+        for (int s = 0; s < 4; ++s)
 #pragma unroll
-    for (int s = 0; s < 33; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], bp[(size_t)s * n_ct * 64], acc, 0, 0, 0);
+          for (int j = 0; j < 8; ++j) hv[s][j] = hp[(size_t)(16 * s + j) * a.h_kstride];
 #pragma unroll
-    for (int q = 0; q < 16; ++q) {
-      const int64_t row = slot0 + (q & 3) + 8 * (q >> 2) + 4 * hh;
-      if (row < a.n_slots) a.w[(size_t)row * a.NWp + ct * 32 + r] = acc[q];
+        for (int s = 0; s < 4; ++s) {
+          unsigned ph[4], pl[4];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const float e0 = rowok ? hv[s][2 * i] * sch : 0.f, e1 = rowok ? hv[s][2 * i + 1] * sch : 0.f;
+            ph[i] = cvt_pk_f16(e0, e1);
+            pl[i] = cvt_pk_f16(resid_lo(e0, ph[i]), resid_hi(e1, ph[i]));
+          }
+          Ah[s] = make_float4(__uint_as_float(ph[0]), __uint_as_float(ph[1]), __uint_as_float(ph[2]), __uint_as_float(ph[3]));
+          Al[s] = make_float4(__uint_as_float(pl[0]), __uint_as_float(pl[1]), __uint_as_float(pl[2]), __uint_as_float(pl[3]));
+        }
+      }
+      // the 16 accumulator rows of this lane: edge slots 32 mt + (q & 3) + 8 (q >> 2) + 4 hh
+      int roff[16];
+      unsigned rmask = 0u;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int t = 32 * mt + (q & 3) + 8 * (q >> 2) + 4 * hh;
+        const bool ok = t < dg;
+        roff[q] = ok ? __float_as_int(rec[t & 63].w) * a.XS : 0;
+        rmask |= ok ? (1u << q) : 0u;
+      }
+#pragma unroll
+      for (int ct = 0; ct < 4; ++ct) {  // (compile-time ct: the per-tile sums stay in registers)
+        __builtin_amdgcn_sched_barrier(0);  // (one tile pair's gathers and accumulators at a time: hoisting the next pair's loads spills)
+        if (ct < nA) {
+          const int u = 32 * ct + c;
+          const bool uok = u < n0;
+          float xv[16];
+#pragma unroll
+          for (int q = 0; q < 16; ++q) xv[q] = uok ? a.x[(size_t)roff[q] + u] : 0.f;
+          f32x16 accA, accB;
+#pragma unroll
+          for (int q = 0; q < 16; ++q) { accA[q] = 0.f; accB[q] = 0.f; }
+#pragma unroll
+          for (int s = 0; s < 4; ++s) {
+            const float4 ah = bfrag(s, ct, 0), al = bfrag(s, ct, 1), bh = bfrag(s, 4 + ct, 0), bl = bfrag(s, 4 + ct, 1);
+            M3(accA, Ah[s], Al[s], ah, al);
+            M3(accB, Ah[s], Al[s], bh, bl);
+          }
+          int z0 = 0;
+          asm volatile("" : "+v"(z0));  // (opaque zero: the slot records are re-read per phase instead of living in 64 registers)
+          const float cA = colc[32 * ct + c], oA = colc[352 + 32 * ct + c], cB = colc[128 + 32 * ct + c], oB = colc[352 + 128 + 32 * ct + c];
+#pragma unroll
+          for (int q = 0; q < 16; ++q) {
+            const bool ok = (rmask >> q) & 1u;
+            const float4 r4 = rec[((32 * mt + (q & 3) + 8 * (q >> 2) + 4 * hh) & 63) + z0];
+            const float wa = ok ? accA[q] * cA + oA : 0.f, wb = ok ? accB[q] * cB + oB : 0.f;
+            D0[ct] = fmaf(wa, xv[q], D0[ct]);
+            const float bx = wb * xv[q];
+            D1[ct][0] = fmaf(bx, r4.x, D1[ct][0]);
+            D1[ct][1] = fmaf(bx, r4.y, D1[ct][1]);
+            D1[ct][2] = fmaf(bx, r4.z, D1[ct][2]);
+          }
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if (hasV) {
+        float x1[16][3];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+          const float* __restrict__ p1 = a.x + (size_t)roff[q] + n0 + 3 * (vok ? c : 0);
+          x1[q][0] = vok ? p1[0] : 0.f; x1[q][1] = vok ? p1[1] : 0.f; x1[q][2] = vok ? p1[2] : 0.f;
+        }
+        // C, D, E one after the other (one accumulator tile live at a time)
+        __builtin_amdgcn_sched_barrier(0);
+        {
+          f32x16 acc;
+#pragma unroll
+          for (int q = 0; q < 16; ++q) acc[q] = 0.f;
+#pragma unroll
+          for (int s = 0; s < 4; ++s) { const float4 bh = bfrag(s, 8, 0), bl = bfrag(s, 8, 1); M3(acc, Ah[s], Al[s], bh, bl); }
+          const float cf = colc[256 + c], bb = colc[352 + 256 + c];
+#pragma unroll
+          for (int q = 0; q < 16; ++q) {
+            const float wc = ((rmask >> q) & 1u) ? acc[q] * cf + bb : 0.f;
+            D2[0] = fmaf(wc, x1[q][0], D2[0]);
+            D2[1] = fmaf(wc, x1[q][1], D2[1]);
+            D2[2] = fmaf(wc, x1[q][2], D2[2]);
+          }
+        }
+        {
+          f32x16 acc;
+#pragma unroll
+          for (int q = 0; q < 16; ++q) acc[q] = 0.f;
+#pragma unroll
+          for (int s = 0; s < 4; ++s) { const float4 bh = bfrag(s, 9, 0), bl = bfrag(s, 9, 1); M3(acc, Ah[s], Al[s], bh, bl); }
+          const float cf = colc[288 + c], bb = colc[352 + 288 + c];
+          int z0 = 0;
+          asm volatile("" : "+v"(z0));
+#pragma unroll
+          for (int q = 0; q < 16; ++q) {
+            const float4 r4 = rec[((32 * mt + (q & 3) + 8 * (q >> 2) + 4 * hh) & 63) + z0];
+            const float wd = ((rmask >> q) & 1u) ? acc[q] * cf + bb : 0.f;
+            D3 = fmaf(wd, fmaf(x1[q][2], r4.z, fmaf(x1[q][1], r4.y, x1[q][0] * r4.x)), D3);
+          }
+        }
+        {
+          f32x16 acc;
+#pragma unroll
+          for (int q = 0; q < 16; ++q) acc[q] = 0.f;
+#pragma unroll
+          for (int s = 0; s < 4; ++s) { const float4 bh = bfrag(s, 10, 0), bl = bfrag(s, 10, 1); M3(acc, Ah[s], Al[s], bh, bl); }
+          const float cf = colc[320 + c], bb = colc[352 + 320 + c];
+          int z0 = 0;
+          asm volatile("" : "+v"(z0));
+#pragma unroll
+          for (int q = 0; q < 16; ++q) {
+            const float4 r4 = rec[((32 * mt + (q & 3) + 8 * (q >> 2) + 4 * hh) & 63) + z0];
+            const float we = ((rmask >> q) & 1u) ? acc[q] * cf + bb : 0.f;
+            const float vx = x1[q][0], vy = x1[q][1], vz = x1[q][2];
+            // (x1 x v)[m] = x1[m+1] v[m+2] - x1[m+2] v[m+1]
+            D4[0] = fmaf(we, vy * r4.z - vz * r4.y, D4[0]);
+            D4[1] = fmaf(we, vz * r4.x - vx * r4.z, D4[1]);
+            D4[2] = fmaf(we, vx * r4.y - vy * r4.x, D4[2]);
+          }
+        }
+      }
+    }
+    __builtin_amdgcn_wave_barrier();  // (the records are rewritten for the next destination)
+    // the two half-waves hold the even / odd groups of four slots: one sum per channel, stored by the lower half.
+    // Rows of the Linear's input: scalars [D0 (n0) | D3 (n1)], vectors per component m: [D1 (n0) | D2 (n1) | D4 (n1)]
+    float* __restrict__ dr = a.D + (size_t)d * DW;
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) {
+      const int u = 32 * ct + c;
+      const float s0 = D0[ct] + __shfl_xor(D0[ct], 32, 64);
+      const float s1 = D1[ct][0] + __shfl_xor(D1[ct][0], 32, 64), s2 = D1[ct][1] + __shfl_xor(D1[ct][1], 32, 64), s3 = D1[ct][2] + __shfl_xor(D1[ct][2], 32, 64);
+      if (ct < nA && hh == 0 && u < n0) {
+        dr[u] = s0;
+        dr[K0 + u] = s1; dr[K0 + K1 + u] = s2; dr[K0 + 2 * K1 + u] = s3;
+      }
+    }
+    if (hasV) {
+      const float s3 = D3 + __shfl_xor(D3, 32, 64);
+      float s2[3], s4[3];
+#pragma unroll
+      for (int m = 0; m < 3; ++m) { s2[m] = D2[m] + __shfl_xor(D2[m], 32, 64); s4[m] = D4[m] + __shfl_xor(D4[m], 32, 64); }
+      if (hh == 0 && vok) {
+        dr[n0 + c] = s3;
+#pragma unroll
+        for (int m = 0; m < 3; ++m) { dr[K0 + m * K1 + n0 + c] = s2[m]; dr[K0 + m * K1 + n0 + n1 + c] = s4[m]; }
+      }
     }
   }
 }
 
-// One workgroup = 16 destination atoms, 4 waves x 4 atoms.  Edge phase: one wave per destination, lanes = input channels
-// (scalar channels lane and lane + 64, vector channel lane < n1): coalesced reads of the edge's weight row and of the source's
-// feature row, sums in registers in edge order (fixed order: bit-reproducible).  Then the 704 sums of the wave's four atoms go to
-// LDS and the point-wise Linear runs with lanes = output columns, every weight read shared by the four atoms.
-#define SEP_APW 4  // atoms per wave
-__global__ __launch_bounds__(256) void k_sep_apply(SepArgs a) {
-  extern __shared__ float sep_lds[];  // [16 atoms][K0 + 3 K1]
-  const int lane = threadIdx.x & 63, wave = RFL(threadIdx.x >> 6);
-  const int n0 = a.n0, n1 = a.n1, K0 = n0 + n1, K1 = n0 + 2 * n1, DW = K0 + 3 * K1;
-  const int atom0 = (blockIdx.x * 4 + wave) * SEP_APW;
-  float* __restrict__ dl = sep_lds + (size_t)wave * SEP_APW * DW;
-  for (int ai = 0; ai < SEP_APW; ++ai) {
-    const int i = atom0 + ai;
-    float d0[2] = {0.f, 0.f}, d1[2][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}}, d2[3] = {0.f, 0.f, 0.f}, d3 = 0.f, d4[3] = {0.f, 0.f, 0.f};
-    if (i < a.n_atoms) {
-      const int dg = a.deg[i];
-      // edge slot t of this destination lives in lane t (source index, unit vector): one coalesced read each, then broadcasts — and
-      // the operands of edge t + 1 are requested before the FMAs of edge t (the loop is a chain of dependent global reads otherwise)
-      const size_t slot_l = (size_t)i * a.S + (lane < dg ? lane : 0);
-      const int j_l = a.esrc[slot_l] & 0x7fffffff;
-      const float4 ge_l = a.egeo[slot_l];
-      struct Ops { float x0[2], wa[2], wb[2], x1[3], wc, wd, we, gx, gy, gz; };
-      auto fetch = [&](int t) {
-        Ops o;
-        const int tt = t < dg ? t : 0;
-        const int j = __shfl(j_l, tt, 64);
-        o.gx = __shfl(ge_l.x, tt, 64); o.gy = __shfl(ge_l.y, tt, 64); o.gz = __shfl(ge_l.z, tt, 64);
-        const float* __restrict__ wr = a.w + ((size_t)i * a.S + tt) * a.NWp;
-        const float* __restrict__ xr = a.x + (size_t)j * a.XS;
-#pragma unroll
-        for (int c = 0; c < 2; ++c) {
-          const int u = lane + 64 * c;
-          const bool ok = u < n0;
-          o.x0[c] = ok ? xr[u] : 0.f; o.wa[c] = ok ? wr[u] : 0.f; o.wb[c] = ok ? wr[n0 + u] : 0.f;
-        }
-        const bool ok1 = lane < n1;
-        const float* __restrict__ x1 = xr + n0 + 3 * (ok1 ? lane : 0);
-        o.x1[0] = ok1 ? x1[0] : 0.f; o.x1[1] = ok1 ? x1[1] : 0.f; o.x1[2] = ok1 ? x1[2] : 0.f;
-        o.wc = ok1 ? wr[2 * n0 + lane] : 0.f; o.wd = ok1 ? wr[2 * n0 + n1 + lane] : 0.f; o.we = ok1 ? wr[2 * n0 + 2 * n1 + lane] : 0.f;
-        return o;
-      };
-      Ops cur{};
-      if (dg > 0) cur = fetch(0);  // (the slots of an atom without in-edges hold no valid source index)
-      for (int t = 0; t < dg; ++t) {
-        const Ops nxt = fetch(t + 1);
-#pragma unroll
-        for (int c = 0; c < 2; ++c) {
-          d0[c] = fmaf(cur.wa[c], cur.x0[c], d0[c]);
-          const float bx = cur.wb[c] * cur.x0[c];
-          d1[c][0] = fmaf(bx, cur.gx, d1[c][0]);
-          d1[c][1] = fmaf(bx, cur.gy, d1[c][1]);
-          d1[c][2] = fmaf(bx, cur.gz, d1[c][2]);
-        }
-        {
-          const float vx = cur.x1[0], vy = cur.x1[1], vz = cur.x1[2];
-          d2[0] = fmaf(cur.wc, vx, d2[0]);
-          d2[1] = fmaf(cur.wc, vy, d2[1]);
-          d2[2] = fmaf(cur.wc, vz, d2[2]);
-          d3 = fmaf(cur.wd, fmaf(vz, cur.gz, fmaf(vy, cur.gy, vx * cur.gx)), d3);
-          // (x1 x v)[m] = x1[m+1] v[m+2] - x1[m+2] v[m+1]
-          d4[0] = fmaf(cur.we, vy * cur.gz - vz * cur.gy, d4[0]);
-          d4[1] = fmaf(cur.we, vz * cur.gx - vx * cur.gz, d4[1]);
-          d4[2] = fmaf(cur.we, vx * cur.gy - vy * cur.gx, d4[2]);
-        }
-        cur = nxt;
-      }
-    }
-    // rows of the Linear's inputs: scalars [D0 (n0) | D3 (n1)], vectors per component m: [D1 (n0) | D2 (n1) | D4 (n1)]
-    float* __restrict__ d = dl + (size_t)ai * DW;
-#pragma unroll
-    for (int c = 0; c < 2; ++c) {
-      const int u = lane + 64 * c;
-      if (u < n0) {
-        d[u] = d0[c];
-#pragma unroll
-        for (int m = 0; m < 3; ++m) d[K0 + m * K1 + u] = d1[c][m];
-      }
-    }
-    if (lane < n1) {
-      d[n0 + lane] = d3;
-#pragma unroll
-      for (int m = 0; m < 3; ++m) {
-        d[K0 + m * K1 + n0 + lane] = d2[m];
-        d[K0 + m * K1 + n0 + n1 + lane] = d4[m];
-      }
-    }
+// m = Linear(D): one workgroup = 32 atoms, its D tile in LDS (row stride DW + 1 floats: the A operand of v_mfma_f32_32x32x2_f32 is
+// one float per lane, row = atom), wave j < nt0: scalar-output tile j (K0 rows of wl0), wave nt0 + m: vector plane m (K1 rows of wl1).
+__global__ __launch_bounds__(512) void k_sep_linear(SepArgs a) {
+  extern __shared__ float sl_lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = RFL(tid >> 6);
+  const int r = lane & 31, hh = lane >> 5;
+  const int n0 = a.n0, n1 = a.n1, K0 = n0 + n1, K1 = n0 + 2 * n1, DW = K0 + 3 * K1, LD = DW + 1;
+  const int a0 = blockIdx.x * 32;
+  for (int idx = tid; idx < 32 * DW; idx += 512) {
+    const int row = idx / DW, col = idx - row * DW;
+    sl_lds[row * LD + col] = (a0 + row < a.n_atoms) ? a.D[(size_t)(a0 + row) * DW + col] : 0.f;
   }
   __syncthreads();
-  // point-wise Linear (normalisation folded into the weights): lanes = output columns, four atoms per weight read
   const int G0 = a.G0, G1 = a.G1;
-  for (int c0 = 0; c0 < a.nt0 * 32; c0 += 64) {
-    const int col = c0 + lane;
-    float acc[SEP_APW] = {0.f, 0.f, 0.f, 0.f};
-    if (col < G0) {
-      for (int rr = 0; rr < K0; ++rr) {
-        const float wv = a.wl0[(size_t)rr * G0 + col];
+  if (wave < a.nt0) {
+    const int col = 32 * wave + r;
+    f32x16 acc;
 #pragma unroll
-        for (int ai = 0; ai < SEP_APW; ++ai) acc[ai] = fmaf(wv, dl[(size_t)ai * DW + rr], acc[ai]);
-      }
-    }
-    if (col < a.nt0 * 32) {
-#pragma unroll
-      for (int ai = 0; ai < SEP_APW; ++ai)
-        if (atom0 + ai < a.n_atoms) a.partial0[(size_t)(atom0 + ai) * (a.nt0 * 32) + col] = acc[ai];
-    }
-  }
-  for (int o0 = 0; o0 < 3 * a.nt1 * 32; o0 += 64) {
-    const int o = o0 + lane;  // (m, column) of the vector outputs
-    if (o >= 3 * a.nt1 * 32) break;
-    const int m = o / (a.nt1 * 32), col = o - m * (a.nt1 * 32);
-    float acc[SEP_APW] = {0.f, 0.f, 0.f, 0.f};
-    if (col < G1) {
-      for (int rr = 0; rr < K1; ++rr) {
-        const float wv = a.wl1[(size_t)rr * G1 + col];
-#pragma unroll
-        for (int ai = 0; ai < SEP_APW; ++ai) acc[ai] = fmaf(wv, dl[(size_t)ai * DW + K0 + m * K1 + rr], acc[ai]);
-      }
+    for (int q = 0; q < 16; ++q) acc[q] = 0.f;
+    for (int s = 0; 2 * s < K0; ++s) {
+      const int k = 2 * s + hh;
+      const float av = k < K0 ? sl_lds[r * LD + k] : 0.f;
+      const float bv = (k < K0 && col < G0) ? a.wl0[(size_t)k * G0 + col] : 0.f;
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
     }
 #pragma unroll
-    for (int ai = 0; ai < SEP_APW; ++ai)
-      if (atom0 + ai < a.n_atoms) a.partial1[((size_t)(atom0 + ai) * 3 + m) * (a.nt1 * 32) + col] = acc[ai];
+    for (int q = 0; q < 16; ++q) {
+      const int row = (q & 3) + 8 * (q >> 2) + 4 * hh;
+      if (a0 + row < a.n_atoms) a.partial0[(size_t)(a0 + row) * (a.nt0 * 32) + col] = acc[q];
+    }
+  } else if (wave < a.nt0 + 3 && a.nt1 == 1) {
+    const int m = wave - a.nt0;
+    f32x16 acc;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc[q] = 0.f;
+    for (int s = 0; 2 * s < K1; ++s) {
+      const int k = 2 * s + hh;
+      const float av = k < K1 ? sl_lds[r * LD + K0 + m * K1 + k] : 0.f;
+      const float bv = (k < K1 && r < G1) ? a.wl1[(size_t)k * G1 + r] : 0.f;
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int row = (q & 3) + 8 * (q >> 2) + 4 * hh;
+      if (a0 + row < a.n_atoms) a.partial1[((size_t)(a0 + row) * 3 + m) * 32 + r] = acc[q];
+    }
   }
 }
 
 // What the SeparableConv kernels can run: checked once in jamun_sampler_create (a model / topology outside these limits is rejected
 // there with this message, not at the first forward) and again at launch.
-const char* sep_conv_unsupported(int n0, int n1, int NWp, int S) {
+const char* sep_conv_unsupported(int n0, int n1, int nt0, int nt1, int S, int edge_attr_dim) {
   if (n0 > 128 || n1 > 32) return "SeparableConv: input irreps wider than 128x0e + 32x1e";
-  if (NWp % 32 != 0 || NWp < 2 * n0 + 3 * n1) return "SeparableConv: internal weight padding";
-  if (S > 64) return "SeparableConv: more than 64 edge slots per destination (32 radial neighbours + bonded in-edges; repeated bond listings count)";  // edge slot t lives in lane t
-  if ((size_t)16 * (n0 + n1 + 3 * (n0 + 2 * n1)) * sizeof(float) > 64 * 1024) return "SeparableConv: per-destination sums exceed 64 KiB of LDS";
+  if (nt0 + 3 > 8 || nt1 != 1) return "SeparableConv: output irreps wider than five scalar tiles / 32 vector channels";
+  if (edge_attr_dim != 64) return "SeparableConv: radial MLP with other than 64 hidden units";
+  if (S > 64) return "SeparableConv: more than 64 edge slots per destination (32 radial neighbours + bonded in-edges; repeated bond listings count)";
+  if ((size_t)32 * (n0 + n1 + 3 * (n0 + 2 * n1) + 1) * sizeof(float) > 150 * 1024) return "SeparableConv: a 32-atom tile of per-destination sums exceeds the LDS";
   return nullptr;
 }
 
-int launch_sep_conv(const SepArgs& a, hipStream_t st) {
-  if (sep_conv_unsupported(a.n0, a.n1, a.NWp, a.S)) return -1;
-  const size_t smem = (size_t)16 * (a.n0 + a.n1 + 3 * (a.n0 + 2 * a.n1)) * sizeof(float);
-  const int64_t tiles = (a.n_slots + 31) / 32;
-  hipLaunchKernelGGL(k_sep_weights, dim3((unsigned)((tiles + 3) / 4)), dim3(256), 0, st, a);
-  hipLaunchKernelGGL(k_sep_apply, dim3((a.n_atoms + 15) / 16), dim3(256), smem, st, a);
+int sep_conv_set_max_lds() {
+  if (hipFuncSetAttribute((const void*)k_sep_fused, hipFuncAttributeMaxDynamicSharedMemorySize, JAMUN_MAX_DYN_LDS) != hipSuccess) return -1;
+  if (hipFuncSetAttribute((const void*)k_sep_linear, hipFuncAttributeMaxDynamicSharedMemorySize, JAMUN_MAX_DYN_LDS) != hipSuccess) return -1;
+  return 0;
+}
+
+int launch_sep_conv(const SepArgs& a, int cus, hipStream_t st) {
+  if (sep_conv_unsupported(a.n0, a.n1, a.nt0, a.nt1, a.S, 64)) return -1;
+  const int grid = std::max(1, std::min(cus, (a.n_atoms + 7) / 8));
+  hipLaunchKernelGGL(k_sep_fused, dim3(grid), dim3(SF_THREADS), SF_LDS_BYTES, st, a);
+  const int DW = a.n0 + a.n1 + 3 * (a.n0 + 2 * a.n1);
+  hipLaunchKernelGGL(k_sep_linear, dim3((a.n_atoms + 31) / 32), dim3(512), (size_t)32 * (DW + 1) * sizeof(float), st, a);
   return 0;
 }
