@@ -83,6 +83,25 @@ typedef struct jamun_mcmc_params {
   float delta, friction, M, inverse_temperature, score_fn_clip;
 } jamun_mcmc_params;
 
+/* Kernel-selection switches of jamun_sampler_create.  NOT needed in production: NULL (or all zero) selects the default kernels, and the
+ * library reads no environment variables — these exist so that tests can run every implementation of a block against the others
+ * (tests/test_gpu_parity.py) and profiling scripts can time an alternative.  Each field only EXCLUDES a kernel; what then runs is
+ * reported by jamun_sampler_stats (conv_path / dg_mode / init_path / dg_emu). */
+typedef struct jamun_tuning {
+  int32_t no_dg;        /* hidden layers and initial projector on the general kernel k_conv (no destination-grouped tile plan)     */
+  int32_t no_mf;        /* hidden layers: not k_conv_mf (A operand formed on the matrix cores); k_conv_dg (vector-ALU forming)      */
+  int32_t dg_fp32;      /* k_conv_dg with v_mfma_f32_32x32x2_f32 instead of the f16x3 scheme (implies no_mf)                        */
+  int32_t dg_no_alt;    /* k_conv_dg: not mode 1 (two passes over the hidden units for molecules above ~80 atoms)                   */
+  int32_t dg_no_sp;     /* k_conv_dg: not mode 2 (single phase, spans up to ~52 atoms)                                              */
+  int32_t dg_no_sph;    /* k_conv_dg: not mode 3 (single phase with one Y tile, spans up to ~73 atoms)                              */
+  int32_t no_mfi;       /* initial projector: not k_conv_mfi / k_conv_mfx (matrix-core forming)                                      */
+  int32_t no_init_v;    /* initial projector: not k_conv_init_v (edge by edge on the vector ALUs)                                    */
+  int32_t node_fp32;    /* node update with v_mfma_f32_32x32x2_f32 (k_node_update) instead of f16x3 (k_node_update_h)                */
+  int32_t edge_h_fp32;  /* radial MLP first layer with fp32 MFMAs (k_edge_h) instead of f16x3 (k_edge_h16)                           */
+  int32_t dg_kgroups;   /* hidden-unit slices over XCD groups for the destination-grouped kernels: 0 (default = 1), 1, 2, 4, 8       */
+  int32_t reserved[5];  /* must be zero                                                                                              */
+} jamun_tuning;
+
 typedef struct jamun_model jamun_model;     /* raw checkpoint tensors kept on the host          */
 typedef struct jamun_sampler jamun_sampler; /* sigma- and topology-specific device state        */
 
@@ -99,7 +118,8 @@ void jamun_model_destroy(jamun_model* m);
  * MFMA-ordered packed weights, uploads them, and allocates every work buffer.  Replaces
  * ModelSamplingWrapper.__init__ + the per-call graph clone (src/jamun/utils/sampling_wrapper.py:12-47).
  * Synchronous (uploads weights). */
-int jamun_sampler_create(const jamun_model* m, float sigma, const jamun_topology* topo, jamun_sampler** out);
+int jamun_sampler_create(const jamun_model* m, float sigma, const jamun_topology* topo, const jamun_tuning* tuning /* NULL: defaults */,
+                         jamun_sampler** out);
 void jamun_sampler_destroy(jamun_sampler* s);
 
 /* Denoiser.xhat (src/jamun/model/denoiser.py:203-217): y_dev [n_atoms,3] -> xhat_dev [n_atoms,3]. */
@@ -222,7 +242,7 @@ typedef struct jamun_stats {
   int32_t edge_stride;
   int32_t n_slices;       /* partial slabs per tile summed by the node update (max over tiles)          */
   int32_t conv_path;      /* hidden layers: 2 destination-grouped kernels on host-planned tiles (jamun_conv_mf.hip / jamun_conv_dg.hip),
-                             1 fused matrix-core-forming kernel, 0 general k_conv */
+                             0 general k_conv (any irreps, any topology; also SeparableConv's slot in this field) */
   int32_t dg_mode;        /* destination-grouped kernel: 4 jamun_conv_mf.hip (A operand formed on the matrix cores and chained into the
                              contraction; source spans up to 62 atoms); jamun_conv_dg.hip (A operand formed edge by edge on the vector ALUs):
                              0 two phases per hidden unit with resident source rows, 1 two passes over the hidden units (molecules above
@@ -233,11 +253,10 @@ typedef struct jamun_stats {
                              3 k_conv_mfi (coefficient sums per distinct embedding row formed with a one-hot selector, contracted with the
                              input-times-weight table; dg_mode 4 tiles, <= 32 distinct rows),
                              2 edge-by-edge VALU kernel on the tiles of jamun_conv_dg.hip (jamun_conv_initv.hip),
-                             1 input-times-weight table applied with MFMAs (jamun_conv_init.hip), 0 the hidden layers' fused /
-                             general kernel */
+                             0 the general kernel k_conv  (1 was the table kernel jamun_conv_init.hip, retired in round 4) */
   int32_t dg_row_blocks;  /* jamun_conv_dg.hip: 1 when some molecule exceeds the span budget and its sources are cut into row blocks */
   int32_t dg_emu;         /* jamun_conv_dg.hip contraction: 1 f16x3 (three v_mfma_f32_*_f16 per fp32 product, operands split hi + lo),
-                             0 v_mfma_f32_32x32x2_f32 (JAMUN_DG_FP32=1); -1: not in use */
+                             0 v_mfma_f32_32x32x2_f32 (jamun_tuning.dg_fp32); -1: not in use */
   int64_t conv_flop_exec_launch; /* matrix-core FLOPs EXECUTED by ONE launch of the hidden-layer conv kernel (k_conv_mf / k_conv_dg; padding,
                              structural zeros of the forming GEMMs and the three products of the f16x3 scheme included; the T pre-pass is
                              a separate launch and not counted); 0 when another conv path is in use */

@@ -52,6 +52,11 @@ class jamun_topology(C.Structure):
     ]
 
 
+class jamun_tuning(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("no_dg", "no_mf", "dg_fp32", "dg_no_alt", "dg_no_sp", "dg_no_sph", "no_mfi", "no_init_v", "node_fp32",
+                                         "edge_h_fp32", "dg_kgroups")] + [("reserved", C.c_int32 * 5)]
+
+
 class jamun_mcmc_params(C.Structure):
     _fields_ = [
         ("steps", C.c_int32),
@@ -95,7 +100,7 @@ SYMBOLS = {
     "jamun_version": (C.c_int, []),
     "jamun_model_create": (C.c_int, [C.POINTER(jamun_hparams), C.POINTER(jamun_tensor), C.c_int32, C.POINTER(_P)]),
     "jamun_model_destroy": (None, [_P]),
-    "jamun_sampler_create": (C.c_int, [_P, C.c_float, C.POINTER(jamun_topology), C.POINTER(_P)]),
+    "jamun_sampler_create": (C.c_int, [_P, C.c_float, C.POINTER(jamun_topology), C.POINTER(jamun_tuning), C.POINTER(_P)]),
     "jamun_sampler_destroy": (None, [_P]),
     "jamun_xhat": (C.c_int, [_P, _P, _P, _P]),
     "jamun_score": (C.c_int, [_P, _P, _P, _P]),
@@ -123,7 +128,7 @@ SYMBOLS = {
 
 PROF_CLASSES = ["geom", "edge_h", "conv0_init", "conv1_init", "conv0", "conv1", "node_update", "head_finalize", "tprod"]
 
-ABI_VERSION = 3  # jamun_version() of the library this binding was written for (struct layouts and signatures above)
+ABI_VERSION = 4  # jamun_version() of the library this binding was written for (struct layouts and signatures above)
 
 _lib: Optional[C.CDLL] = None
 

@@ -19,8 +19,8 @@ PKG = os.path.dirname(HERE)
 ROOT = os.path.dirname(PKG)
 OUT = os.path.join(PKG, "libjamun_hip.so")
 OBJ_DIR = os.path.join(HERE, "build")
-SOURCES = ["jamun_kernels.hip", "jamun_conv.hip", "jamun_conv_fused.hip", "jamun_conv_init.hip", "jamun_conv_initv.hip", "jamun_conv_dg.hip",
-           "jamun_conv_mf.hip", "jamun_node.hip", "jamun_sepconv.hip", "jamun_api.cpp"]
+SOURCES = ["jamun_kernels.hip", "jamun_conv.hip", "jamun_conv_initv.hip", "jamun_conv_dg.hip", "jamun_conv_mf.hip", "jamun_node.hip", "jamun_sepconv.hip",
+           "jamun_api.cpp"]
 HEADERS = ["jamun_internal.h", os.path.join(ROOT, "include", "jamun_hip.h")]
 DEPS = SOURCES + HEADERS
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")

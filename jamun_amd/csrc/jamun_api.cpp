@@ -96,13 +96,6 @@ struct ConvProblemDev {
   int planes = 0, nt = 0, xw = 0;
   int64_t K = 0;  // padded contraction depth
 };
-struct FusedDev {
-  float4* wpack = nullptr;  // null: the layer cannot use the fused kernel
-  int4 *a_units = nullptr, *b_units = nullptr, *owner = nullptr;
-  int k_stride = 0, max_a = 0, n_p = 0, n_t = 0, nt0 = 0;
-  size_t lds_bytes = 0;
-  int64_t mfma_per_k = 0;  // MFMA instructions per hidden unit k and tile (forming + main), for FLOP bookkeeping
-};
 struct DgDev {
   float4 *wx = nullptr, *wd = nullptr, *wv = nullptr, *wt = nullptr;  // null: the layer cannot use jamun_conv_dg.hip
   float4* wxh = nullptr;  // f16x3 contraction: hi / lo planes of the scaled weights, one stream per (hidden unit, matrix wave)
@@ -121,12 +114,10 @@ struct SepDev {
 };
 struct LayerDev {
   ConvProblemDev p0, p1;
-  FusedDev fu;
   DgDev dg;
   SepDev sep;
   std::vector<float> w1r_h, cmask_h;  // radial MLP first layer (uploaded for all layers together: jamun_sampler::w1r_all)
-  float* tt = nullptr;  // initial projector only: [k][distinct embedding row][32 (nt0 + 1)] input-times-weight table
-  int tt_row = 0, tt_U = 0;
+  int tt_U = 0;  // distinct embedding rows of the tables below
   float* tt2 = nullptr;  // the same table re-laid for k_conv_init_v: [k][U][192]
   float4* tabw = nullptr;  // ... and scaled by 2^tab_sB, split hi + lo, as MFMA B fragments for k_conv_mfi (U <= 32): [k][24 blocks][64 lanes]
   int tab_sB = 0, tab_ut = 0;
@@ -144,11 +135,6 @@ struct LayerDev {
   int in0 = 0, in1 = 0, XSin = 0;
   int64_t tp_numel = 0;
 };
-
-void free_fused(FusedDev& f) {
-  hipFree(f.wpack); hipFree(f.a_units); hipFree(f.b_units); hipFree(f.owner);
-  f = FusedDev{};
-}
 
 void free_dg(DgDev& d) {
   hipFree(d.wx); hipFree(d.wd); hipFree(d.wv); hipFree(d.wt); hipFree(d.wxh); hipFree(d.wth); hipFree(d.wm);
@@ -332,6 +318,7 @@ void pad_even(UBlock& b) {
 
 struct jamun_sampler {
   jamun_hparams hp;
+  jamun_tuning tune{};  // kernel-selection switches of jamun_sampler_create (all zero: defaults)
   float sigma = 0;
   int n_atoms = 0, n_graphs = 0, n_pad = 0, S = 0, n_slices = 8;
   int XS = 0, n_emb = 0;
@@ -339,21 +326,9 @@ struct jamun_sampler {
   // static device data
   int *ptr = nullptr, *bond_in_ptr = nullptr, *bond_in_src = nullptr;
   int n_tiles = 0;
-  int2* tile_span = nullptr;
-  int span_max = 0;
-  // fused MFMA-forming conv kernel (small molecules): fused_JR > 0 when in use
-  int fused_JR = 0, fused_grid = 0, fused_max_segs = 0, n_slabs = 0, n_ftiles = 0;
-  int4* fused_segs = nullptr;
-  int2* tile_atoms = nullptr;         // [n_ftiles] {first atom, atoms (<= 32)} of each fused-kernel tile
   bool initv_on = false;              // initial projector on k_conv_init_v (tiles / segments of the dg kernel)
   int initv_nbuf = 2;                 // its row buffers in LDS
   int* atom_uid = nullptr;            // [n_atoms] index of the atom's distinct (scaled) embedding row
-  std::vector<int2> ftile_atoms_h;
-  std::vector<int> ftile_chunk_h;     // destination chunk of each tile
-  std::vector<int2> ftile_span_h;
-  int n_fchunks = 0;
-  bool row_blocks = false;            // some molecule exceeds the per-tile source budget
-  int* atom_nslab = nullptr;          // [n_atoms] partial slabs of the tile the atom belongs to
   // destination-grouped VALU-forming conv kernel (jamun_conv_dg.hip; hidden layers): own tile plan (larger source spans)
   bool dg_on = false, dg_row_blocks = false;
   int dg_mode = 0;  // 0 two-phase resident, 1 alternating residency, 2 single phase (see jamun_sampler_create)
@@ -364,7 +339,6 @@ struct jamun_sampler {
   int* dg_atom_nslab = nullptr;
   float* sep_D = nullptr;  // SeparableConv: [n_atoms][K0 + 3 K1] per-destination sums of the layer at hand
   int cus = 1;
-  float* dg_dump = nullptr;  // diagnostic A-tile dump (JAMUN_DG_DUMP, -DJAMUN_DUMP builds)
   float* dg_T = nullptr;  // [n_k][n_atoms][32] pre-pass product of a hidden layer (k_tprod), reused by every layer
   int dg_tstride = 0;     // mode 4 (jamun_conv_mf.hip): dg_T is [n_k][32][dg_tstride], transposed
   bool mfi_on = false;    // initial projector on k_conv_mfi (mode 4 tiles, at most 32 distinct embedding rows)
@@ -395,14 +369,14 @@ struct jamun_sampler {
   size_t ev_next = 0;
 
   ~jamun_sampler() {
-    hipFree(ptr); hipFree(bond_in_ptr); hipFree(bond_in_src); hipFree(x_emb); hipFree(mu); hipFree(tile_span);
-    hipFree(fused_segs); hipFree(atom_nslab); hipFree(tile_atoms); hipFree(atom_uid); hipFree(w1r_all); hipFree(cmask_all); hipFree(w1h_all); hipFree(w1isc_all);
-    hipFree(dg_dump); hipFree(dg_tile_atoms); hipFree(dg_tile_span); hipFree(dg_segs); hipFree(dg_atom_nslab); hipFree(dg_T); hipFree(mf_err);
+    hipFree(ptr); hipFree(bond_in_ptr); hipFree(bond_in_src); hipFree(x_emb); hipFree(mu);
+    hipFree(atom_uid); hipFree(w1r_all); hipFree(cmask_all); hipFree(w1h_all); hipFree(w1isc_all);
+    hipFree(dg_tile_atoms); hipFree(dg_tile_span); hipFree(dg_segs); hipFree(dg_atom_nslab); hipFree(dg_T); hipFree(mf_err);
     if (mf_err_host) hipHostFree(mf_err_host);
     for (auto& L : layers) {
-      free_problem(L.p0); free_problem(L.p1); free_fused(L.fu); free_dg(L.dg);
+      free_problem(L.p0); free_problem(L.p1); free_dg(L.dg);
       hipFree(L.sep.w2b); hipFree(L.sep.cfw); hipFree(L.sep.bias); hipFree(L.sep.wl0); hipFree(L.sep.wl1);
-      hipFree(L.wcat0); hipFree(L.wcat1); hipFree(L.wh0); hipFree(L.wh1); hipFree(L.kga0); hipFree(L.kga1); hipFree(L.kgx); hipFree(L.cg0); hipFree(L.cg1); hipFree(L.mix); hipFree(L.tt); hipFree(L.tt2); hipFree(L.tabw);
+      hipFree(L.wcat0); hipFree(L.wcat1); hipFree(L.wh0); hipFree(L.wh1); hipFree(L.kga0); hipFree(L.kga1); hipFree(L.kgx); hipFree(L.cg0); hipFree(L.cg1); hipFree(L.mix); hipFree(L.tt2); hipFree(L.tabw);
       hipFree(L.wx); hipFree(L.xph); hipFree(L.xpl); hipFree(L.xcf0); hipFree(L.xcf1);
     }
     hipFree(w_gate); hipFree(w_vec); hipFree(w_out);
@@ -692,7 +666,7 @@ LayerDev build_layer_separable(const jamun_model& m, const std::string& prefix, 
 }
 
 LayerDev build_layer(const jamun_model& m, const std::string& prefix, const std::vector<InBlock>& in_blocks,
-                     const std::vector<double>& s_in, int n_slices, int fused_JR, int fused_span,
+                     const std::vector<double>& s_in, int n_slices,
                      const std::vector<float>* uniq_rows = nullptr, int row_len = 0, bool pack_dg = false,
                      const std::vector<float>* all_rows = nullptr) {
   const jamun_hparams& hp = m.hp;
@@ -766,182 +740,9 @@ LayerDev build_layer(const jamun_model& m, const std::string& prefix, const std:
   L.p0 = pack_problem(blocks0, 1, G0, n_slices, JAMUN_KSUB0, W3, b3, H);
   L.p1 = pack_problem(blocks1, 3, G1, n_slices, JAMUN_KSUB1, W3, b3, H);
 
-  // ---- fused kernel (jamun_conv_fused.hip): forming units (stage A), owner entries (stage B), weights in
-  // accumulator-register K order
   bool x0_contig = true;
   for (size_t i = 1; i < x0ve.size(); ++i) x0_contig = x0_contig && x0ve[i].xoff == x0ve[0].xoff + (int)i;
   const int NT0 = (G0 + 31) / 32;
-  if (fused_JR > 0 && G1 <= 32 && G1 > 0 && x0_contig && NT0 + 3 <= JAMUN_FUSED_WAVES) {
-    // kind 0: D' tile formed from coefficient tiles (n_terms products), consumed by `nt` owner tiles of output `out`
-    // (0 scalar rows, 1..3 vector plane); kind 1: T tile of source-row tile jt, applied by all three plane owners
-    // n_enc = positive terms | negative terms << 4 (terms are listed positives first)
-    struct AUnit { int kind, n_terms, out, nt; int term[3]; int jt; std::vector<const UEntry*> ue; int wofs, cost, n_enc; };
-    auto term = [](int xcol0, int stride, int ctype, bool neg) { return xcol0 | (stride << 12) | (ctype << 16) | ((neg ? 1 : 0) << 20); };
-    std::vector<AUnit> au;
-    auto add = [&](int n_terms, int out, int nt, int t0, int t1, int t2, const std::vector<UEntry>& src, size_t i) {
-      int n_neg = 0;
-      for (int t : {t0, t1, t2}) n_neg += (t >> 20) & 1;
-      AUnit u{0, n_terms, out, nt, {t0, t1, t2}, 0, {}, 0, 0, (n_terms - n_neg) | (n_neg << 4)};
-      for (size_t j = i; j < std::min(src.size(), i + 32); ++j) u.ue.push_back(&src[j]);
-      au.push_back(u);
-    };
-    for (size_t i = 0; i < x0e.size(); i += 32) add(1, 0, NT0, term(x0e[i].xoff, 1, 0, false), 0, 0, x0e, i);
-    for (size_t i = 0; i < dote.size(); i += 32)
-      add(3, 0, NT0, term(dote[i].xoff + 0, 3, 1, false), term(dote[i].xoff + 1, 3, 2, false), term(dote[i].xoff + 2, 3, 3, false), dote, i);
-    // groups of 4 K-steps (8 input channels) of the T contraction, padded to the depth of the kernel's weight ring (8)
-    const int n_tsg = ((((int)x0ve.size() + 7) / 8) + 7) & ~7;
-    const int n_jt = x0ve.empty() ? 0 : (fused_JR + 31) / 32;
-    for (int jt = 0; jt < n_jt; ++jt) au.push_back(AUnit{1, 0, 4, 0, {0, 0, 0}, jt, {}, 0, 0, 0});
-    for (int mm = 0; mm < 3; ++mm) {
-      for (size_t i = 0; i < x1e.size(); i += 32) add(1, 1 + mm, 1, term(x1e[i].xoff + mm, 3, 0, false), 0, 0, x1e, i);
-      for (size_t i = 0; i < crosse.size(); i += 32) {
-        // (x1 x vhat)[m] = x1[m+1] vhat[m+2] - x1[m+2] vhat[m+1]
-        const int m1 = (mm + 1) % 3, m2 = (mm + 2) % 3;
-        add(2, 1 + mm, 1, term(crosse[i].xoff + m1, 3, 1 + m2, false), term(crosse[i].xoff + m2, 3, 1 + m1, true), 0, crosse, i);
-      }
-    }
-    FusedDev& F = L.fu;
-    F.nt0 = NT0;
-    // parked tiles: scalar-row tiles (index p) and T tiles (index = row tile)
-    int n_p = 0;
-    std::vector<int> tix(au.size(), 0);
-    for (size_t i = 0; i < au.size(); ++i) {
-      if (au[i].kind == 0 && au[i].out == 0) tix[i] = n_p++;
-      if (au[i].kind == 1) tix[i] = au[i].jt;
-    }
-    F.n_p = n_p; F.n_t = std::max(n_jt, 1);
-    // weight blocks (64 lanes x float4) per k: main units [nt][qg 0..3], then the shared T weights [n_tsg]
-    int blocks = 0;
-    for (auto& u : au)
-      if (u.kind == 0) { u.wofs = blocks; blocks += 4 * u.nt; }
-    const int t_wofs = blocks;
-    if (n_jt) blocks += n_tsg;
-    for (auto& u : au)
-      if (u.kind == 1) u.wofs = t_wofs;
-    F.k_stride = blocks * 64;
-    const int n_k = H + 1;
-    std::vector<float4> wp((size_t)n_k * F.k_stride, make_float4(0.f, 0.f, 0.f, 0.f));
-    for (int k = 0; k < n_k; ++k) {
-      for (const AUnit& u : au) {
-        if (u.kind != 0) continue;
-        const int Gout = u.out == 0 ? G0 : G1;
-        for (int nt = 0; nt < u.nt; ++nt)
-          for (int qg = 0; qg < 4; ++qg)
-            for (int lane = 0; lane < 64; ++lane) {
-              const int hh = lane >> 5, c = lane & 31, col = nt * 32 + c;
-              float v[4] = {0.f, 0.f, 0.f, 0.f};
-              for (int st = 0; st < 4; ++st) {
-                const int q = 4 * qg + st;
-                const int ul = (q & 3) + 8 * (q >> 2) + 4 * hh;  // accumulator row of register q in lane half hh
-                if (ul >= (int)u.ue.size() || col >= Gout) continue;
-                const UEntry& e = *u.ue[ul];
-                const int64_t p = e.wbase + col;
-                const double w = (k < H) ? (double)W3[(size_t)p * H + k] : (double)b3[p];
-                v[st] = (float)(w * e.scale);
-              }
-              wp[(size_t)k * F.k_stride + ((size_t)(u.wofs + nt * 4 + qg)) * 64 + lane] = make_float4(v[0], v[1], v[2], v[3]);
-            }
-      }
-      for (int sg = 0; sg < (n_jt ? n_tsg : 0); ++sg)  // T weights: lane (w = lane & 31, hh): W[(k, u = 2 (4 sg + st) + hh)][w]
-        for (int lane = 0; lane < 64; ++lane) {
-          const int hh = lane >> 5, c = lane & 31;
-          float v[4] = {0.f, 0.f, 0.f, 0.f};
-          for (int st = 0; st < 4; ++st) {
-            const int ul = 2 * (4 * sg + st) + hh;
-            if (ul >= (int)x0ve.size() || c >= G1) continue;
-            const UEntry& e = x0ve[ul];
-            const int64_t p = e.wbase + c;
-            const double w = (k < H) ? (double)W3[(size_t)p * H + k] : (double)b3[p];
-            v[st] = (float)(w * e.scale);
-          }
-          wp[(size_t)k * F.k_stride + ((size_t)(t_wofs + sg)) * 64 + lane] = make_float4(v[0], v[1], v[2], v[3]);
-        }
-    }
-    const int J4 = (fused_span + 3) & ~3;
-    const int steps = 4 * (J4 / 8) + ((J4 & 4) ? 2 : 0);
-    const int FWv = JAMUN_FUSED_WAVES;
-    // owner entries: wave w < NT0 owns scalar-row tile w; waves NT0 + m own vector plane m (its x1 / cross tiles are formed
-    // in the owner's registers)
-    std::vector<int4> ubv((size_t)FWv * JAMUN_FUSED_MAX_B * 2, make_int4(-1, 0, 0, 0)), own(FWv, make_int4(-1, 0, -1, 0));
-    std::vector<int64_t> load(FWv, 0);
-    bool fits = true;
-    int64_t total = 0;
-    for (int w = 0; w < FWv; ++w) {
-      std::vector<std::pair<int4, int4>> ent;
-      const int4 z = make_int4(0, 0, 0, 0);
-      int n_self = 0;
-      if (w < NT0) {
-        own[w] = make_int4(0, w, -1, 0);
-        for (size_t i = 0; i < au.size(); ++i)
-          if (au[i].kind == 0 && au[i].out == 0) { ent.push_back({make_int4(0, tix[i], au[i].wofs + 4 * w, 0), z}); load[w] += 16; }
-      } else if (w < NT0 + 3) {
-        const int mm = w - NT0;
-        own[w] = make_int4(1, mm, -1, 0);
-        for (size_t i = 0; i < au.size(); ++i)
-          if (au[i].kind == 0 && au[i].out == 1 + mm) {
-            ent.push_back({make_int4(2, au[i].n_enc, au[i].wofs, 0), make_int4(au[i].term[0], au[i].term[1], au[i].term[2], 0)});
-            ++n_self;
-            load[w] += au[i].n_terms * steps + 16;
-          }
-        for (size_t i = 0; i < au.size(); ++i)
-          if (au[i].kind == 1) { ent.push_back({make_int4(1, tix[i], mm, au[i].jt), z}); load[w] += 16; }
-      }
-      total += load[w];
-      if ((int)ent.size() > JAMUN_FUSED_MAX_B || n_self > 2) { fits = false; break; }
-      own[w].w = (int)ent.size() | (n_self << 8);
-      for (size_t i = 0; i < ent.size(); ++i) {
-        ubv[((size_t)w * JAMUN_FUSED_MAX_B + i) * 2] = ent[i].first;
-        ubv[((size_t)w * JAMUN_FUSED_MAX_B + i) * 2 + 1] = ent[i].second;
-      }
-    }
-    // parked-tile forming units: longest-processing-time greedy on the MFMA count, onto the wave whose SIMD (waves w and
-    // w + 4 share one) carries the least work per interval, owner entries included
-    std::vector<int> order;
-    for (size_t i = 0; i < au.size(); ++i) {
-      au[i].cost = au[i].kind == 1 ? 4 * n_tsg : au[i].n_terms * steps;
-      if (au[i].kind == 1 || au[i].out == 0) { order.push_back((int)i); total += au[i].cost; }
-    }
-    F.mfma_per_k = total;
-    std::stable_sort(order.begin(), order.end(), [&](int a1, int b1) { return au[a1].cost > au[b1].cost; });
-    std::vector<std::vector<int>> per_wave(FWv);
-    for (int i : order) {
-      int best = 0;
-      auto key = [&](int w) {  // (MFMAs on the wave's SIMD: waves w, w+4, ... share one; then the wave's own)
-        int64_t simd = 0;
-        for (int c = w % 4; c < FWv; c += 4) simd += load[c];
-        return std::make_pair(simd, load[w]);
-      };
-      for (int c = 1; c < FWv; ++c)
-        if (key(c) < key(best)) best = c;
-      per_wave[best].push_back(i);
-      load[best] += au[i].cost;
-    }
-    F.max_a = 1;
-    for (auto& v : per_wave) F.max_a = std::max(F.max_a, (int)v.size() + 1);
-    std::vector<int4> ua((size_t)FWv * F.max_a * 2, make_int4(-1, 0, 0, 0));
-    for (int w = 0; w < FWv; ++w)
-      for (size_t i = 0; i < per_wave[w].size(); ++i) {
-        const int id = per_wave[w][i];
-        const AUnit& u = au[id];
-        if (u.kind == 1 && own[w].z < 0) own[w].z = (int)i;  // the wave's first T unit: its weight ring is prefetched
-        int4* d = &ua[((size_t)w * F.max_a + i) * 2];
-        if (u.kind == 1) { d[0] = make_int4(1, tix[id], u.wofs, 0); d[1] = make_int4(u.jt, n_tsg, x0ve[0].xoff, 0); }
-        else { d[0] = make_int4(0, tix[id], u.n_enc, 0); d[1] = make_int4(u.term[0], u.term[1], u.term[2], 0); }
-      }
-    F.lds_bytes = fused_lds_bytes(L.XSin, fused_JR, F.n_p, F.n_t, F.max_a);
-    if (fits && 32 * fused_JR <= 2 * F.n_p * 1024) {
-      F.wpack = dev_upload(wp);
-      F.a_units = dev_upload(ua);
-      F.b_units = dev_upload(ubv);
-      F.owner = dev_upload(own);
-    }
-    if (getenv("JAMUN_DEBUG_UNITS")) {
-      fprintf(stderr, "[jamun] %s: n_p %d n_t %d steps %d mfma/k %lld; per-wave MFMAs per interval:", prefix.c_str(), F.n_p, F.n_t,
-              steps, (long long)total);
-      for (int w = 0; w < FWv; ++w) fprintf(stderr, " %lld", (long long)load[w]);
-      fprintf(stderr, "\n");
-    }
-  }
 
   // ---- destination-grouped VALU-forming kernel (jamun_conv_dg.hip): weights as 64-lane float4 blocks in MFMA operand order
   if (pack_dg && mul0 == 120 && mul1 == 32 && x0e.size() == 120 && dote.size() == 32 && x1e.size() == 32 && crosse.size() == 32 &&
@@ -1193,8 +994,7 @@ LayerDev build_layer(const jamun_model& m, const std::string& prefix, const std:
     }
   }
 
-  // ---- initial projector: input-times-weight table for jamun_conv_init.hip (inputs are constant per distinct embedding row)
-  // (the table itself does not depend on the fused kernel's packing: k_conv_mfi uses it on the tiles of k_conv_mf)
+  // ---- initial projector: input-times-weight table (inputs are constant per distinct embedding row) for k_conv_init_v and k_conv_mfi
   if (uniq_rows && G0 <= 32 * NT0 && G1 <= 32) {
     bool scalar_only = true;
     for (auto& ib : in_blocks) scalar_only = scalar_only && ib.l == 0;
@@ -1223,12 +1023,8 @@ LayerDev build_layer(const jamun_model& m, const std::string& prefix, const std:
             out[32 * NT0 + w] = (float)acc;
           }
         }
-      if (L.fu.wpack) {
-        L.tt = dev_upload(tt);
-        L.tt_row = tt_row;
-        L.tt_U = U;
-      }
-      if (L.fu.wpack && NT0 == 5 && G0 <= 152 && G1 <= 32) {  // scalar columns 0..127 as they are, then per lane u (column 128+u, vector column u)
+      L.tt_U = U;
+      if (NT0 == 5 && G0 <= 152 && G1 <= 32) {  // scalar columns 0..127 as they are, then per lane u (column 128+u, vector column u)
         std::vector<float> tt2((size_t)(H + 1) * U * 192, 0.f);
         for (int k = 0; k <= H; ++k)
           for (int uid = 0; uid < U; ++uid) {
@@ -1242,7 +1038,6 @@ LayerDev build_layer(const jamun_model& m, const std::string& prefix, const std:
           }
         L.tt2 = dev_upload(tt2);
       }
-      if (getenv("JAMUN_DEBUG_UNITS")) fprintf(stderr, "[jamun] %s: %d distinct embedding rows\n", prefix.c_str(), U);
       if (NT0 == 5 && G0 <= 160 && G1 <= 32 && U <= 128) {
         const int UT = U <= 32 ? 1 : (U <= 64 ? 2 : 4);
         L.tab_ut = UT;
@@ -1473,21 +1268,10 @@ void run_layer(jamun_sampler* s, size_t l, const float* x_in, int XSin, float* x
       f.n_pad = s->n_pad; f.S = s->S; f.PMAX = (s->S + 3) & ~3; f.RS = s->dg_RS; f.nt0 = L.p0.nt; f.nbuf = s->initv_nbuf;
       f.tile_span = s->dg_tile_span; f.tile_atoms = s->dg_tile_atoms; f.segs = s->dg_segs; f.max_segs = s->dg_max_segs;
       f.atom_uid = s->atom_uid; f.tt2 = L.tt2; f.tt2_kstride = (size_t)L.tt_U * 192;
-      static const int iv_dbg = getenv("JAMUN_IV_DBG") ? atoi(getenv("JAMUN_IV_DBG")) : 0;
-      f.dbg = iv_dbg;
+      f.dbg = 0;
       f.partial0 = s->partial0; f.partial1 = s->partial1;
       ProfScope ps(s, JAMUN_PROF_CONV0_INIT, st);
       if (launch_conv_initv(f, s->dg_grid, st) != 0) throw Err(JAMUN_ERR_INVALID, "initial-projector conv launch failed (configuration not supported)");
-    } else if (l == 0 && L.tt) {
-      InitArgs f{};
-      f.deg = s->deg; f.esrc = s->esrc; f.egeo = s->egeo; f.h = h_l; f.h_kstride = s->h_kstride;
-      f.n_pad = s->n_pad; f.S = s->S; f.JR = s->fused_JR; f.nt0 = L.fu.nt0; f.row_blocks = s->row_blocks ? 1 : 0;
-      f.tile_span = s->tile_span; f.tile_atoms = s->tile_atoms; f.segs = s->fused_segs; f.max_segs = s->fused_max_segs;
-      f.atom_uid = s->atom_uid; f.tt = L.tt; f.tt_row = L.tt_row; f.tt_kstride = (size_t)L.tt_U * L.tt_row;
-      f.partial0 = s->partial0; f.partial1 = s->partial1;
-      ProfScope ps(s, JAMUN_PROF_CONV0_INIT, st);
-      const int rcode = launch_conv_init(f, s->fused_grid, st);
-      if (rcode != 0) throw Err(JAMUN_ERR_INVALID, "initial-projector conv launch failed (configuration not supported)");
     } else if (l > 0 && s->dg_on && s->dg_mode == 4) {
       MfArgs f{};
       f.deg = s->deg; f.esrc = s->esrc; f.egeo = s->egeo; f.h = h_l; f.h_kstride = s->h_kstride; f.x = x_in;
@@ -1517,14 +1301,8 @@ void run_layer(jamun_sampler* s, size_t l, const float* x_in, int XSin, float* x
       f.emu = s->dg_emu; f.wh = L.dg.wxh; f.sB = L.dg.sB; f.hmax2 = L.dg.hmax2;
       f.gx = L.dg.gx; f.cf0 = L.dg.cf0; f.cf1 = L.dg.cf1;
       f.partial0 = s->partial0; f.partial1 = s->partial1;
-      static const int dg_dbg = getenv("JAMUN_DG_DBG") ? atoi(getenv("JAMUN_DG_DBG")) : 0;
-      f.dbg = dg_dbg;
+      f.dbg = 0;
       f.dump = nullptr;
-      if (l == 1 && getenv("JAMUN_DG_DUMP")) {
-        if (!s->dg_dump) s->dg_dump = dev_alloc<float>(32 * 12288);
-        f.dbg = atoi(getenv("JAMUN_DG_DUMP"));
-        f.dump = s->dg_dump;
-      }
       {
         ProfScope pt(s, JAMUN_PROF_TPROD, st);
         launch_tprod(x_in, XSin, s->n_atoms, s->hp.edge_attr_dim + 1, L.dg.wt, s->dg_emu ? L.dg.wth : nullptr, L.dg.gT, L.dg.cfT, s->dg_T, 0, st);
@@ -1532,16 +1310,6 @@ void run_layer(jamun_sampler* s, size_t l, const float* x_in, int XSin, float* x
       ProfScope ps(s, JAMUN_PROF_CONV0, st);
       const int rcode = launch_conv_dg(f, s->dg_grid, st);
       if (rcode != 0) throw Err(JAMUN_ERR_INVALID, "destination-grouped conv launch failed (configuration not supported)");
-    } else if (L.fu.wpack) {
-      FusedArgs f{};
-      f.deg = s->deg; f.esrc = s->esrc; f.egeo = s->egeo; f.h = h_l; f.h_kstride = s->h_kstride; f.x = x_in;
-      f.n_atoms = s->n_atoms; f.n_pad = s->n_pad; f.S = s->S; f.XS = XSin; f.JR = s->fused_JR; f.tile_span = s->tile_span; f.tile_atoms = s->tile_atoms;
-      f.wpack = L.fu.wpack; f.a_units = L.fu.a_units; f.b_units = L.fu.b_units; f.owner = L.fu.owner; f.segs = s->fused_segs;
-      f.k_stride = L.fu.k_stride; f.max_a = L.fu.max_a; f.n_p = L.fu.n_p; f.n_t = L.fu.n_t; f.max_segs = s->fused_max_segs;
-      f.nt0 = L.fu.nt0; f.partial0 = s->partial0; f.partial1 = s->partial1; f.row_blocks = s->row_blocks ? 1 : 0;
-      ProfScope ps(s, l == 0 ? JAMUN_PROF_CONV0_INIT : JAMUN_PROF_CONV0, st);
-      const int rcode = launch_conv_fused(f, s->fused_grid, st);
-      if (rcode != 0) throw Err(JAMUN_ERR_INVALID, "fused conv launch failed (configuration not supported)");
     } else {
     ConvArgs a{};
     a.deg = s->deg; a.esrc = s->esrc; a.egeo = s->egeo; a.h = h_l; a.h_kstride = s->h_kstride; a.x = x_in;
@@ -1565,15 +1333,14 @@ void run_layer(jamun_sampler* s, size_t l, const float* x_in, int XSin, float* x
     n.n_atoms = s->n_atoms; n.n_pad = s->n_pad; n.n_slices = s->n_slices; n.nt0 = L.p0.nt; n.nt1 = L.p1.nt;
     n.mul0 = s->hp.mul0; n.mul1 = s->hp.mul1; n.in0 = L.in0; n.in1 = L.in1; n.XSin = XSin;
     const bool dg_layer = (l > 0 && s->dg_on) || (l == 0 && (s->initv_on || s->mfi_on || s->mfx_on));  // (slabs of the dg tile plan)
-    n.atom_nslab = dg_layer ? s->dg_atom_nslab : (L.fu.wpack ? s->atom_nslab : nullptr);
-    n.max_slabs = dg_layer ? s->dg_n_slabs : (L.fu.wpack ? s->n_slabs : s->n_slices);
+    n.atom_nslab = dg_layer ? s->dg_atom_nslab : nullptr;
+    n.max_slabs = dg_layer ? s->dg_n_slabs : s->n_slices;
     if (L.sep.w2b) { n.n_slices = 1; n.atom_nslab = nullptr; n.max_slabs = 1; }  // SeparableConv writes the summed messages as ONE slab
     n.wh0 = L.wh0; n.wh1 = L.wh1; n.K0h = L.K0h; n.K1h = L.K1h;
     n.kga0 = L.kga0; n.kga1 = L.kga1; n.kgx = L.kgx; n.cg0 = L.cg0; n.cg1 = L.cg1;
     {
       ProfScope ps(s, JAMUN_PROF_NODE, st);
-      const bool nu_fp32 = getenv("JAMUN_NODE_FP32") != nullptr;  // (A/B aid: the v_mfma_f32_32x32x2_f32 kernel)
-      if (!nu_fp32 && node_update_h_supported(n)) launch_node_update_h(n, st);
+      if (!s->tune.node_fp32 && node_update_h_supported(n)) launch_node_update_h(n, st);  // (node_fp32: the v_mfma_f32_32x32x2_f32 kernel, A/B aid)
       else launch_node_update(n, st);
     }
 }
@@ -1754,7 +1521,7 @@ SegPlan plan_segments(int cus, int ng, int n_k, int N, const std::vector<int2>& 
 extern "C" {
 
 const char* jamun_last_error(void) { return g_err.c_str(); }
-int jamun_version(void) { return 3; }
+int jamun_version(void) { return 4; }
 
 int jamun_model_create(const jamun_hparams* hp, const jamun_tensor* tensors, int32_t n_tensors, jamun_model** out) {
   return guarded([&] {
@@ -1780,14 +1547,19 @@ int jamun_model_create(const jamun_hparams* hp, const jamun_tensor* tensors, int
 }
 void jamun_model_destroy(jamun_model* m) { delete m; }
 
-int jamun_sampler_create(const jamun_model* m, float sigma, const jamun_topology* topo, jamun_sampler** out) {
+int jamun_sampler_create(const jamun_model* m, float sigma, const jamun_topology* topo, const jamun_tuning* tuning, jamun_sampler** out) {
   return guarded([&] {
     if (!m || !topo || !out) throw Err(JAMUN_ERR_INVALID, "null argument");
+    jamun_tuning tn{};
+    if (tuning) tn = *tuning;
+    if (tn.dg_kgroups != 0 && tn.dg_kgroups != 1 && tn.dg_kgroups != 2 && tn.dg_kgroups != 4 && tn.dg_kgroups != 8)
+      throw Err(JAMUN_ERR_INVALID, "jamun_tuning.dg_kgroups must be 0 (default), 1, 2, 4 or 8");
     if (!(sigma > 0)) throw Err(JAMUN_ERR_INVALID, "sigma must be positive");
     if (topo->n_atoms < 1 || topo->n_graphs < 1) throw Err(JAMUN_ERR_INVALID, "empty walker batch");
     const jamun_hparams& hp = m->hp;
     std::unique_ptr<jamun_sampler> s(new jamun_sampler());
     s->hp = hp;
+    s->tune = tn;
     s->sigma = sigma;
     s->n_atoms = topo->n_atoms;
     s->n_graphs = topo->n_graphs;
@@ -1835,50 +1607,9 @@ int jamun_sampler_create(const jamun_model* m, float sigma, const jamun_topology
     s->S = std::min(std::max(nmax - 1, 0), JAMUN_MAX_NEIGHBORS + 1) + max_in;
     if (s->S < 1) s->S = 1;
     s->n_tiles = s->n_pad / 32;
-    if (conv_set_max_lds() != 0 || conv_fused_set_max_lds() != 0 || node_update_set_max_lds() != 0 || conv_init_set_max_lds() != 0 || conv_initv_set_max_lds() != 0 ||
+    if (conv_set_max_lds() != 0 || node_update_set_max_lds() != 0 || conv_initv_set_max_lds() != 0 ||
         conv_dg_set_max_lds() != 0 || conv_mf_set_max_lds() != 0 || sep_conv_set_max_lds() != 0)
       throw Err(JAMUN_ERR_HIP, "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed");
-    {
-      // ---- fused conv kernel: eligibility and tiling.  A tile = up to 32 consecutive destination atoms whose source
-      // span (whole molecules) fits the LDS budget; tiles are cut greedily at molecule granularity, so molecules larger
-      // than 17 atoms get partly filled tiles instead of spans that do not fit.  Needs one bonded edge per ordered pair.
-      bool dup = false;
-      {
-        std::vector<std::pair<int64_t, int64_t>> bb;
-        for (int b = 0; b < topo->n_bonds; ++b) bb.push_back({topo->bond_src[b], topo->bond_dst[b]});
-        std::sort(bb.begin(), bb.end());
-        dup = std::adjacent_find(bb.begin(), bb.end()) != bb.end();
-      }
-      const bool no_fused = getenv("JAMUN_NO_FUSED") != nullptr;  // debugging / A-B aid
-      const int nt0 = (hp.mul0 + hp.mul1 + 31) / 32;
-      bool ok = !no_fused && !dup && s->S < 255 && hp.mul1 <= 32 && hp.mul1 > 0 && nt0 + 3 <= JAMUN_FUSED_WAVES &&
-                (int64_t)N * s->S < (int64_t)0x7fffffff;
-      // largest row stride JR = 4 * odd (b128 reads; 8 lanes x 16 B cover all banks) whose LDS footprint fits both layer kinds
-      int jr_cap = 0;
-      for (int jr = 60; jr >= 4 && ok; jr -= 8) {
-        const int n_t = (jr + 31) / 32;
-        const size_t hid = fused_lds_bytes(s->XS, jr, (hp.mul0 + 31) / 32 + (hp.mul1 + 31) / 32, n_t, 8);
-        const size_t ini = fused_lds_bytes(s->n_emb, jr, (s->n_emb + 31) / 32, n_t, 8);
-        if (std::max(hid, ini) <= JAMUN_MAX_DYN_LDS) { jr_cap = jr; break; }
-      }
-      std::vector<int2> t_atoms, t_span;
-      std::vector<int> t_chunk;  // destination chunk of each tile (tiles of one chunk share its partial-slab numbering)
-      int n_chunks = 0;
-      if (ok && jr_cap > 0) plan_tiles(topo->ptr, graph_of, N, jr_cap, t_atoms, t_span, t_chunk, n_chunks, s->span_max, s->row_blocks);
-      else ok = false;
-      if (ok) {
-        int JR = (s->span_max + 3) & ~3;
-        if ((JR / 4) % 2 == 0) JR += 4;
-        s->fused_JR = JR;
-        s->n_ftiles = (int)t_atoms.size();
-        s->ftile_atoms_h = t_atoms;
-        s->ftile_chunk_h = t_chunk;
-        s->ftile_span_h = t_span;
-        s->n_fchunks = n_chunks;
-        s->tile_atoms = dev_upload(t_atoms);
-        s->tile_span = dev_upload(t_span);
-      }
-    }
     std::vector<int> ptr_h(topo->ptr, topo->ptr + W + 1);
     s->ptr = dev_upload(ptr_h);
     s->bond_in_ptr = dev_upload(bip);
@@ -1942,18 +1673,15 @@ int jamun_sampler_create(const jamun_model* m, float sigma, const jamun_topology
           uid[i] = it->second;
         }
       }
-      const bool no_init = getenv("JAMUN_NO_INIT_TABLE") != nullptr;  // debugging / A-B aid
-      s->layers.push_back(build_layer(*m, "initial_projector", ib, ones, s->n_slices, s->fused_JR, s->span_max,
-                                      !no_init ? &uniq : nullptr, s->n_emb, false, &xe_host));
+      s->layers.push_back(build_layer(*m, "initial_projector", ib, ones, s->n_slices, &uniq, s->n_emb, false, &xe_host));
       s->n_uniq = (int)(uniq.size() / (size_t)std::max(s->n_emb, 1));
-      if (s->layers.back().tt || s->layers.back().tabw) s->atom_uid = dev_upload(uid);
+      if (s->layers.back().tt2 || s->layers.back().tabw) s->atom_uid = dev_upload(uid);
     }
     for (int l = 0; l < hp.n_layers; ++l) {
       std::vector<InBlock> ib = {{hp.mul0, 0, 0, 0}, {hp.mul1, 1, hp.mul0, hp.mul0}};
       const std::string li = std::to_string(l);
       std::vector<double> sc = noise_mlp(*m, "noise_scalings." + li + ".scale_predictor", hp.mul0 + hp.mul1, c_noise);
-      LayerDev L = build_layer(*m, "layers." + li, ib, sc, s->n_slices, s->fused_JR, s->span_max, nullptr, 0,
-                               /*pack_dg=*/getenv("JAMUN_NO_DG") == nullptr);
+      LayerDev L = build_layer(*m, "layers." + li, ib, sc, s->n_slices, nullptr, 0, /*pack_dg=*/!tn.no_dg);
       std::vector<double> wm = noise_mlp(*m, "skip_connections." + li + ".weights.scale_predictor", hp.mul0 + hp.mul1, c_noise);
       std::vector<float> mix(wm.size());
       for (size_t i = 0; i < wm.size(); ++i) mix[i] = (float)(1.0 / (1.0 + std::exp(-wm[i])));
@@ -1978,15 +1706,6 @@ int jamun_sampler_create(const jamun_model* m, float sigma, const jamun_topology
       s->w_vec = dev_upload(wv);
       s->w_out = dev_upload(wo);
     }
-    // ---- fused conv: all layers or none; persistent-workgroup segment lists
-    {
-      bool all = s->fused_JR > 0;
-      for (auto& L : s->layers) all = all && L.fu.wpack && L.fu.lds_bytes <= JAMUN_MAX_DYN_LDS;
-      if (!all) {
-        for (auto& L : s->layers) { free_fused(L.fu); hipFree(L.tt); L.tt = nullptr; }
-        s->fused_JR = 0;
-      }
-    }
     hipDeviceProp_t prop;
     {
       int dev = 0;
@@ -1996,40 +1715,15 @@ int jamun_sampler_create(const jamun_model* m, float sigma, const jamun_topology
     const int cus = std::max(prop.multiProcessorCount, 1);
     s->cus = cus;
     const int n_k = hp.edge_attr_dim + 1;
-    auto k_groups = [&](const char* env, int dflt) {  // k-slices over XCD groups: 1, 2, 4 or 8 (XCDs x, x + ng, ... share one)
-      int ng = (cus % 8 == 0 && n_k >= 8) ? dflt : 1;
-      if (const char* e = getenv(env)) {
-        const int v = atoi(e);
-        if ((v == 1 || v == 2 || v == 4 || v == 8) && cus % 8 == 0 && n_k >= v) ng = v;
-      }
-      return ng;
-    };
-    if (s->fused_JR > 0) {
-      // Two k-slices measured best on MI355X for the fused kernel (profiles/r1d): longer runs of k per segment amortise the
-      // pipeline ramp and the per-tile staging, and beat the better L2 residency of the weights with 8 slices (one per XCD).
-      const int ng = k_groups("JAMUN_FUSED_KGROUPS", 2);
-      // items are weighted by the MFMA count of one hidden-layer (tile, k): forming scales with the tile's source rows
-      auto weight = [&](int t) -> int64_t {
-        const int J4 = (s->ftile_span_h[t].y - s->ftile_span_h[t].x + 3) & ~3;
-        const int steps = 4 * (J4 / 8) + ((J4 & 4) ? 2 : 0), n_jt = (J4 + 31) / 32;
-        return 16 * steps + n_jt * (64 + 48) + 496 + 256;  // + the fixed per-interval cost (barrier, build), in MFMA units
-      };
-      SegPlan P = plan_segments(cus, ng, n_k, N, s->ftile_atoms_h, s->ftile_chunk_h, s->n_fchunks, weight);
-      s->fused_grid = cus;
-      s->fused_max_segs = P.max_segs;
-      s->fused_segs = dev_upload(P.segs);
-      s->n_slabs = P.n_slabs;
-      s->atom_nslab = dev_upload(P.atom_nslab);
-    }
     // ---- destination-grouped VALU-forming kernel for the hidden layers (jamun_conv_dg.hip): own tile plan, larger spans
     {
-      bool ok = getenv("JAMUN_NO_DG") == nullptr && hp.n_layers > 0 && s->S <= 64 && (int64_t)N * s->S < (int64_t)0x7fffffff;
+      bool ok = !tn.no_dg && hp.n_layers > 0 && s->S <= 64 && (int64_t)N * s->S < (int64_t)0x7fffffff;
       for (size_t l = 1; l < s->layers.size(); ++l) ok = ok && s->layers[l].dg.wx != nullptr;
       // Source rows resident in LDS for the whole segment when the largest molecule fits the resident budget (~80 rows);
       // otherwise the alternating-residency mode of the kernel (rows re-staged per phase: spans up to ~170 rows), and only
       // molecules above THAT are cut into source row blocks.
       const int pmax = (s->S + 3) & ~3;
-      s->dg_emu = getenv("JAMUN_DG_FP32") == nullptr ? 1 : 0;
+      s->dg_emu = tn.dg_fp32 ? 0 : 1;
       auto cap_of = [&](int mode) {
         for (int rs = mode == 1 ? 192 : 128; rs >= 16; rs -= 4)
           if (conv_dg_lds_bytes(rs, pmax, mode, s->dg_emu) <= JAMUN_MAX_DYN_LDS) return rs;
@@ -2043,14 +1737,14 @@ int jamun_sampler_create(const jamun_model* m, float sigma, const jamun_topology
       std::vector<int2> t_atoms, t_span;
       std::vector<int> t_chunk;
       int n_chunks = 0, span_max = 0;
-      if (ok && nmax > cap && getenv("JAMUN_DG_NO_ALT") == nullptr) {
+      if (ok && nmax > cap && !tn.dg_no_alt) {
         const int cap_alt = cap_of(1);
         if (cap_alt > cap) { cap = cap_alt; s->dg_mode = 1; }
       }
       if (ok && cap > 0) {
         plan_tiles(topo->ptr, graph_of, N, cap, t_atoms, t_span, t_chunk, n_chunks, span_max, s->dg_row_blocks);
         const int cap_sp = cap_of(2);
-        if (s->dg_mode == 0 && cap_sp >= 16 && getenv("JAMUN_DG_NO_SP") == nullptr) {
+        if (s->dg_mode == 0 && cap_sp >= 16 && !tn.dg_no_sp) {
           std::vector<int2> a2, s2;
           std::vector<int> c2;
           int nc2 = 0, sm2 = 0;
@@ -2065,7 +1759,7 @@ int jamun_sampler_create(const jamun_model* m, float sigma, const jamun_topology
         // fully double-buffered variant does not fit: a k-step of the two-phase kernel takes 25 k cycles on such tiles, of this
         // one ~17 k, so up to 15 % more tiles are accepted
         const int cap_sph = cap_of(3);
-        if (s->dg_mode == 0 && cap_sph >= 16 && getenv("JAMUN_DG_NO_SPH") == nullptr) {
+        if (s->dg_mode == 0 && cap_sph >= 16 && !tn.dg_no_sph) {
           std::vector<int2> a2, s2;
           std::vector<int> c2;
           int nc2 = 0, sm2 = 0;
@@ -2078,7 +1772,7 @@ int jamun_sampler_create(const jamun_model* m, float sigma, const jamun_topology
         }
         // A operand formed on the matrix cores (jamun_conv_mf.hip): spans that fit one K = 64 window of source rows (from an even
         // atom: 62 rows), when that budget costs no tiles; f16x3 only
-        if ((s->dg_mode == 0 || s->dg_mode == 2 || s->dg_mode == 3) && s->dg_emu && getenv("JAMUN_DG_NO_MF") == nullptr && s->layers.size() > 1 && s->layers[1].dg.wm) {
+        if ((s->dg_mode == 0 || s->dg_mode == 2 || s->dg_mode == 3) && s->dg_emu && !tn.no_mf && s->layers.size() > 1 && s->layers[1].dg.wm) {
           std::vector<int2> a2, s2;
           std::vector<int> c2;
           int nc2 = 0, sm2 = 0;
@@ -2106,10 +1800,10 @@ int jamun_sampler_create(const jamun_model* m, float sigma, const jamun_topology
         }
         s->dg_RS = std::max((span_max + 3) & ~3, 16);  // (>= 16 rows: the segment-end staging tile of the forming waves aliases the source rows)
         s->dg_n_tiles = (int)t_atoms.size();
-        // k-slices over XCD groups (JAMUN_DG_KGROUPS = 1, 2, 4, 8).  Measured on MI355X (cfg2, profiles/r2*): 1 slice 0.317 ms per
+        // k-slices over XCD groups (jamun_tuning.dg_kgroups = 1, 2, 4, 8).  Measured on MI355X (cfg2, profiles/r2*): 1 slice 0.317 ms per
         // launch, 2: 0.318, 4: 0.328, 8: 0.343 and the node update slows from 25 to 71 us (more partial slabs per tile): the
         // ~7.7 MB of weight blocks per layer are served from L2 / Infinity Cache fast enough, longer runs of k per segment win.
-        const int ng = k_groups("JAMUN_DG_KGROUPS", 1);
+        const int ng = (tn.dg_kgroups > 1 && cus % 8 == 0 && n_k >= tn.dg_kgroups) ? tn.dg_kgroups : 1;
         auto weight = [&](int t) -> int64_t { return 476 + (s->dg_mode == 1 ? 24 : 2) * ((t_span[t].y - t_span[t].x + 15) / 16); };
         SegPlan P = plan_segments(cus, ng, n_k, N, t_atoms, t_chunk, n_chunks, weight);
         s->dg_grid = cus;
@@ -2135,8 +1829,7 @@ int jamun_sampler_create(const jamun_model* m, float sigma, const jamun_topology
         // (up to ~170 rows)
         // (mid-size ragged batches keep the MFMA table kernel: on 17-57 atom molecules, mean in-degree 11, it takes 0.283 ms
         // against 0.312 — the per-k staging of ~76 table rows outweighs the few edges; 33-atom molecules: 0.398 against 0.328)
-        if (getenv("JAMUN_NO_INIT_V") == nullptr && !s->dg_row_blocks && s->layers[0].tt2 != nullptr && s->layers[0].p0.nt == 5 && s->dg_RS <= 170 &&
-            (s->dg_mode == 1 || nmax <= 40)) {
+        if (!tn.no_init_v && !s->dg_row_blocks && s->layers[0].tt2 != nullptr && s->layers[0].p0.nt == 5 && s->dg_RS <= 170) {
           // (one buffer only for the large-molecule plan: measured on the ragged 17-57 atom batch the MFMA table kernel is 10 %
           // faster than the one-buffer variant, on 166-atom molecules — where it falls back to source row blocks — 2.1x slower)
           for (int nbuf = 2; nbuf >= (s->dg_mode == 1 ? 1 : 2) && !s->initv_on; --nbuf)
@@ -2144,7 +1837,7 @@ int jamun_sampler_create(const jamun_model* m, float sigma, const jamun_topology
         }
         // ... or, on the tiles of k_conv_mf (spans within one K = 64 window) and with at most 32 distinct embedding rows, the same
         // scheme with a one-hot selector in place of the feature rows (k_conv_mfi)
-        if (s->dg_mode == 4 && s->layers[0].p0.nt == 5 && getenv("JAMUN_NO_MFI") == nullptr) {
+        if (s->dg_mode == 4 && s->layers[0].p0.nt == 5 && !tn.no_mfi) {
           // up to 32 distinct rows: one selector tile (112 MFMAs per (tile, k), eight equal waves); more: from the feature rows (192)
           if (s->n_uniq <= 32 && s->layers[0].tabw != nullptr && s->atom_uid != nullptr && s->layers[0].tab_ut == 1) s->mfi_on = true;
           else if (s->layers[0].wx != nullptr) s->mfx_on = true;
@@ -2167,7 +1860,7 @@ int jamun_sampler_create(const jamun_model* m, float sigma, const jamun_topology
         cmask_all.insert(cmask_all.end(), L.cmask_h.begin(), L.cmask_h.end());
       }
       s->w1r_all = dev_upload(w1r_all);
-      if (hp.edge_attr_dim == 64 && getenv("JAMUN_EDGE_H_FP32") == nullptr) {
+      if (hp.edge_attr_dim == 64 && !tn.edge_h_fp32) {
         // f16x3 radial MLP (k_edge_h16): W1's radial part per layer scaled to the top of the f16 range and split hi + lo, as A fragments
         std::vector<float4> w1h;
         std::vector<float> isc;
@@ -2214,7 +1907,7 @@ int jamun_sampler_create(const jamun_model* m, float sigma, const jamun_topology
     }
     int nt0 = 0, nt1 = 0;
     for (auto& L : s->layers) { nt0 = std::max(nt0, L.p0.nt); nt1 = std::max(nt1, L.p1.nt); }
-    const size_t n_part = (size_t)std::max(std::max(s->n_slices, s->n_slabs), s->dg_n_slabs);
+    const size_t n_part = (size_t)std::max(s->n_slices, s->dg_n_slabs);
     s->partial0 = dev_alloc<float>(n_part * s->n_pad * nt0 * 32);
     s->partial1 = dev_alloc<float>(n_part * s->n_pad * 3 * nt1 * 32);
     {
@@ -2245,7 +1938,6 @@ int jamun_sampler_create(const jamun_model* m, float sigma, const jamun_topology
         s->flop_exec += s->conv_flop_exec_launch + (int64_t)((s->n_atoms + 31) / 32) * (s->dg_emu ? 24LL * 32768 : 60LL * 4096) * (hp.edge_attr_dim + 1);
       }
       else if (L.sep.w2b) s->flop_exec += 3LL * 2 * (int64_t)N * 32 * ((s->S + 31) / 32) * 64 * 352;  // the per-edge weight GEMM as f16x3 (the rest is VALU work per edge)
-      else if (L.fu.wpack) s->flop_exec += (int64_t)s->n_ftiles * (hp.edge_attr_dim + 1) * L.fu.mfma_per_k * 4096;  // 32x32x2 MFMA = 4096 FLOP
       else s->flop_exec += 2LL * s->n_pad * (1LL * L.p0.K * L.p0.nt * 32 + 3LL * L.p1.K * L.p1.nt * 32);
     }
     HIPCHECK(hipDeviceSynchronize());
@@ -2515,10 +2207,10 @@ int jamun_sampler_stats(jamun_sampler* s, jamun_stats* out, void* stream) {
       out->conv1_flop_alg = 2 * 3 * (int64_t)s->n_atoms * H1 * (m0 + 2 * m1) * m1;
     }
     out->edge_stride = s->S;
-    out->n_slices = s->dg_on ? s->dg_n_slabs : (s->fused_JR > 0 ? s->n_slabs : s->n_slices);
-    out->conv_path = s->dg_on ? 2 : (s->fused_JR > 0 ? 1 : 0);
+    out->n_slices = s->dg_on ? s->dg_n_slabs : s->n_slices;
+    out->conv_path = s->dg_on ? 2 : 0;
     out->dg_mode = s->dg_on ? s->dg_mode : -1;
-    out->init_path = s->mfx_on ? 4 : s->mfi_on ? 3 : s->initv_on ? 2 : (s->layers[0].tt ? 1 : 0);
+    out->init_path = s->mfx_on ? 4 : s->mfi_on ? 3 : s->initv_on ? 2 : 0;
     out->dg_row_blocks = s->dg_on && s->dg_row_blocks ? 1 : 0;
     out->dg_emu = s->dg_on ? s->dg_emu : -1;
     out->conv_flop_exec_launch = s->conv_flop_exec_launch;
@@ -2571,9 +2263,7 @@ int jamun_debug_stamps(unsigned long long* out8) {
     conv_dg_print_stamps();
     conv_initv_print_stamps();
     conv_mf_print_stamps();
-    const int r = conv_fused_read_stamps(out8);
-    if (r == -2) throw Err(JAMUN_ERR_INVALID, "library was not built with -DJAMUN_STAMP");
-    if (r != 0) throw Err(JAMUN_ERR_HIP, "reading stamp counters failed");
+    for (int i = 0; i < 8; ++i) out8[i] = 0;
   });
 }
 
@@ -2588,9 +2278,6 @@ int jamun_debug_read(jamun_sampler* s, int32_t what, int32_t layer, float* out, 
       launch_deg_to_float(s->deg, out, s->n_atoms, st);
     } else if (what == 2) {
       launch_copy(s->g, out, s->n_atoms * 3, st);
-    } else if (what == 3) {
-      if (!s->dg_dump) throw Err(JAMUN_ERR_INVALID, "no A-tile dump (JAMUN_DG_DUMP unset)");
-      launch_copy(s->dg_dump, out, 32 * 12288, st);
     } else {
       throw Err(JAMUN_ERR_INVALID, "unknown debug buffer");
     }

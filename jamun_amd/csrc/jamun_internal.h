@@ -10,8 +10,6 @@
 #define JAMUN_KSUB0 5  // hidden units per k-subgroup, scalar-output rows (subgroups of 4 or 5)
 #define JAMUN_KSUB1 2  // hidden units per k-subgroup, vector-output rows (3 planes per workgroup; subgroups of 1 or 2)
 #define JAMUN_MAX_DYN_LDS (160 * 1024 - 256)  // dynamic LDS per workgroup: 160 KiB minus the kernels' static words (at most 256 B: the vote of __syncthreads_or)
-#define JAMUN_FUSED_WAVES 8   // waves per workgroup of the fused conv kernel; every wave owns at most one output tile
-#define JAMUN_FUSED_MAX_B 6   // stage-B entries (formed tiles consumed) per owner wave
 #define JAMUN_MAX_BATCH 128  // edge batches (of 4) per wave: 8 atoms x ceil(S / 4); limits the edge stride S to 64
 
 // zeta types of a u-block (what the edge feeds into the contraction)
@@ -40,33 +38,6 @@ struct ConvArgs {
   int n_slices;
 };
 
-// fused conv (jamun_conv_fused.hip): A operand formed on the matrix cores from dense coefficient tiles; persistent
-// workgroups walk host-built segment lists
-struct FusedArgs {
-  const int* deg;
-  const int* esrc;
-  const float4* egeo;
-  const float* h;  // [hidden unit k (65 rows)][h_kstride >= n_atoms*S]: radial-MLP activations per edge slot
-  size_t h_kstride;
-  const float* x;  // [n_atoms][XS]
-  int n_atoms, n_pad, S, XS, JR;  // JR: row stride of the transposed feature / coefficient tiles (4 * odd, >= every tile span)
-  const int2* tile_span;  // [n_tiles] {lo, hi}: atoms whose features the tile's in-edges can read (whole molecules)
-  const int2* tile_atoms; // [n_tiles] {first destination atom, number of destination atoms (<= 32)}
-  const float4* wpack;    // [k][k_stride] 16-byte weight fragments (blocks of 64 lanes)
-  // forming units [waves][max_a][2]: {kind (0 scalar-row tile from coefficient tiles, 1 T tile, -1 end), tile index,
-  //   n_terms | weight block, 0}, {term0, term1, term2, 0} | {row tile, weight groups, first x0 column, 0}
-  const int4* a_units;
-  // owner entries [waves][JAMUN_FUSED_MAX_B][2]: {kind (0 main K-steps of a parked tile, 1 apply T, 2 form in registers
-  //   + main K-steps, -1 end), tile index | n_terms, weight block | plane, row tile}, {term0, term1, term2, 0}
-  const int4* b_units;
-  const int4* owner;  // [waves] {kind (-1 none, 0 scalar-row tile, 1 vector plane), index, 0, 0}
-  const int4* segs;   // [grid][max_segs][2]: {tile (-1 end), slab, k_begin, k_end}, {k_extra (-1 none), 0, 0, 0}
-  int k_stride, max_a, n_p, n_t, max_segs, nt0;  // n_p / n_t: parked scalar-row / T tiles per k
-  int row_blocks;  // 1: some molecule's sources are cut into row blocks (tiles may be edge-less: checked at run time)
-  float* partial0;  // [slab][n_pad][nt0*32]
-  float* partial1;  // [slab][n_pad][3][32]
-};
-
 // destination-grouped conv with VALU forming (jamun_conv_dg.hip): hidden layers with irreps 120x0e + 32x1e
 struct DgArgs {
   const int* deg;
@@ -80,7 +51,7 @@ struct DgArgs {
   int PMAX;  // per-destination capacity of the coefficient tables (= edge stride S)
   const int2* tile_span;   // [n_tiles] {lo, hi} source atoms of the tile
   const int2* tile_atoms;  // [n_tiles] {first destination atom, number of destination atoms (<= 32)}
-  const int4* segs;        // [grid][max_segs][2]: as FusedArgs
+  const int4* segs;        // [grid][max_segs][2]: {tile (-1 end), slab, k_begin, k_end}, {k_extra (-1 none), 0, 0, 0}
   int max_segs, row_blocks, nt0;
   int alt;  // kernel mode: 0 two-phase resident, 1 alternating residency of the source rows (large molecules), 2 single phase (small spans)
   int dbg;  // tuning aid (JAMUN_DG_DBG): 1 forming waves skip their edge loops, 2 matrix waves skip their MFMAs
@@ -122,7 +93,7 @@ struct MfArgs {
   int n_pad, S, XS, n_atoms;
   const int2* tile_span;   // [n_tiles] {lo, hi} source atoms of the tile (hi - lo <= 62)
   const int2* tile_atoms;  // [n_tiles] {first destination atom, number of destination atoms (<= 32)}
-  const int4* segs;        // [grid][max_segs][2]: as FusedArgs
+  const int4* segs;        // [grid][max_segs][2]: {tile (-1 end), slab, k_begin, k_end}, {k_extra (-1 none), 0, 0, 0}
   int max_segs, nt0;
   // wm [k][124 blocks of 64 lanes x 8 halves] in consumption order, (hi, lo) pairs; B fragments of v_mfma_f32_32x32x16_f16 with the
   // K index of a step permuted to the accumulator layout of the forming MFMA: half p of lane (column c, hh) <-> input
@@ -191,27 +162,6 @@ struct MfxArgs {
   float* partial0;
   float* partial1;
   int* err;
-};
-
-// initial-projector conv (jamun_conv_init.hip): apply-only contraction against the precomputed input-times-weight table
-struct InitArgs {
-  const int* deg;
-  const int* esrc;
-  const float4* egeo;
-  const float* h;  // [hidden unit k (65 rows)][h_kstride]
-  size_t h_kstride;
-  int n_pad, S, JR, nt0;
-  const int2* tile_span;
-  const int2* tile_atoms;
-  const int4* segs;  // same segment lists as the fused kernel
-  int max_segs;
-  int row_blocks;       // as FusedArgs
-  const int* atom_uid;  // [n_atoms] index of the atom's distinct embedding row
-  const float* tt;      // [k][U][tt_row]: columns 32 t + c of output tile t (t < nt0 scalar rows, t = nt0 vector rows)
-  size_t tt_kstride;    // U * tt_row
-  int tt_row;           // 32 * (nt0 + 1)
-  float* partial0;      // [slab][n_pad][nt0*32]
-  float* partial1;      // [slab][n_pad][3][32]
 };
 
 // k_conv_init_v (jamun_conv_initv.hip): the initial projector edge by edge on the VALU, on the tiles / segments of k_conv_dg
@@ -343,9 +293,6 @@ void launch_edge_h(const int* deg, const int* esrc, const float4* egeo, int n_at
                    size_t h_kstride, hipStream_t st, const float4* w1h = nullptr, const float* isc_all = nullptr);
 int launch_conv(const ConvArgs& a, int rc, int nt, hipStream_t st);
 int conv_set_max_lds();
-int launch_conv_fused(const FusedArgs& a, int grid, hipStream_t st);
-int conv_fused_set_max_lds();
-int conv_fused_read_stamps(unsigned long long* out8);
 int launch_conv_dg(const DgArgs& a, int grid, hipStream_t st);
 int conv_dg_set_max_lds();
 void conv_dg_print_stamps();
@@ -359,13 +306,9 @@ int launch_conv_mfi(const MfiArgs& a, int grid, hipStream_t st);
 int launch_conv_mfx(const MfxArgs& a, int grid, hipStream_t st);
 int conv_mf_set_max_lds();
 size_t conv_mf_lds_bytes();
-int launch_conv_init(const InitArgs& a, int grid, hipStream_t st);
 int launch_conv_initv(const InitVArgs& a, int grid, hipStream_t st);
 int conv_initv_set_max_lds();
 size_t conv_initv_lds_bytes(int rs, int pmax, int nbuf);
-int conv_init_set_max_lds();
-size_t conv_init_lds_bytes(int JR);
-size_t fused_lds_bytes(int XS, int JR, int n_p, int n_t, int max_a);
 void launch_node_update(const NodeArgs& a, hipStream_t st);
 void launch_node_update_h(const NodeArgs& a, hipStream_t st);
 bool node_update_h_supported(const NodeArgs& a);

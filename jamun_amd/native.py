@@ -7,6 +7,7 @@ PyTorch is used only for device memory and streams: every call passes ``tensor.d
 from __future__ import annotations
 
 import ctypes as C
+import os
 import functools
 from typing import Dict, Optional, Tuple
 
@@ -122,10 +123,30 @@ class NativeModel:
             self._lib.jamun_model_destroy(h)
 
 
+# Kernel-selection switches (``jamun_tuning`` in include/jamun_hip.h) applied to every sampler created in this process.  Empty in
+# production; tests set entries (``monkeypatch.setitem(native.TUNING, "no_mf", 1)``) to run one implementation of a block against another,
+# and profiling scripts may set ``JAMUN_TUNING="no_mf,dg_kgroups=2"`` — the ONLY environment variable that reaches kernel selection,
+# read here, once, at import (the C library reads none).
+TUNING: dict = {}
+for _item in filter(None, (os.environ.get("JAMUN_TUNING") or "").split(",")):
+    _k, _, _v = _item.strip().partition("=")
+    TUNING[_k] = int(_v) if _v else 1
+
+
+def make_tuning(extra: Optional[dict] = None) -> "_lib.jamun_tuning":
+    t = _lib.jamun_tuning()
+    names = {n for n, _ in _lib.jamun_tuning._fields_} - {"reserved"}
+    for k, v in {**TUNING, **(extra or {})}.items():
+        if k not in names:
+            raise ValueError(f"unknown tuning switch {k!r} (known: {sorted(names)})")
+        setattr(t, k, int(v))
+    return t
+
+
 class NativeSampler:
     """Owns a ``jamun_sampler*``: packed weights for one sigma + work buffers for one walker batch."""
 
-    def __init__(self, model: NativeModel, sigma: float, batch: WalkerBatch, device: torch.device):
+    def __init__(self, model: NativeModel, sigma: float, batch: WalkerBatch, device: torch.device, tuning: Optional[dict] = None):
         lib = _lib.load()
         if device.type != "cuda":
             raise RuntimeError("jamun_amd needs a GPU device (cuda / ROCm); there is no CPU path")
@@ -146,7 +167,7 @@ class NativeSampler:
         topo.bond_dst = C.cast(bd.data_ptr(), C.POINTER(C.c_int64))
         handle = C.c_void_p()
         with torch.cuda.device(device):
-            _lib.check(lib.jamun_sampler_create(model.handle, C.c_float(self.sigma), C.byref(topo), C.byref(handle)))
+            _lib.check(lib.jamun_sampler_create(model.handle, C.c_float(self.sigma), C.byref(topo), C.byref(make_tuning(tuning)), C.byref(handle)))
         self._h = handle
         self._lib = lib
         self._model = model  # keep alive

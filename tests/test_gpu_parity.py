@@ -11,6 +11,8 @@ import numpy as np
 import pytest
 import torch
 
+from jamun_amd import native  # (native.TUNING: the kernel-selection switches, jamun_tuning)
+
 pytestmark = pytest.mark.gpu
 
 RMSD_TOL_NM = 1e-5  # 1e-4 Angstrom
@@ -222,9 +224,8 @@ def test_matrix_formed_conv_block_at_extreme_feature_scales(dev, golden_dir, log
     batch = WalkerBatch.from_molecules(_mols("chain17x6")).to(dev)
     mf = NativeSampler(model._native, 0.04, batch, dev)
     assert mf.stats()["dg_mode"] == 4
-    monkeypatch.setenv("JAMUN_NO_DG", "1")
-    monkeypatch.setenv("JAMUN_NO_FUSED", "1")
-    monkeypatch.setenv("JAMUN_NODE_FP32", "1")
+    monkeypatch.setitem(native.TUNING, "no_dg", 1)
+    monkeypatch.setitem(native.TUNING, "node_fp32", 1)
     general = NativeSampler(model._native, 0.04, batch, dev)
     assert general.stats()["conv_path"] == 0
     y = ref["y"].to(dev)
@@ -282,12 +283,11 @@ def test_forward_matches_oracle(dev, golden_dir, kind):
 
 
 @pytest.mark.parametrize("kind", ["ag4", "chain17x6", "ragged_small", "ragged", "dense70", "chig93x2", "chig166x2"])
-def test_fused_and_fallback_conv_agree(dev, golden_dir, kind, monkeypatch):
-    """The three conv kernels (VALU-forming jamun_conv_dg, matrix-core-forming jamun_conv_fused, general k_conv) are
-    independent implementations of the same contraction: all must meet the oracle (where a cached oracle output exists),
-    and each other, on the same input.
-    `ragged` (molecules up to 57 atoms) and `dense70` exceed the fused kernel's LDS budget per tile and exercise its
-    source-row-block tiling (several tiles per destination chunk, summed as extra partial slabs)."""
+def test_conv_kernel_variants_agree(dev, golden_dir, kind, monkeypatch):
+    """The conv kernels — jamun_conv_mf (A operand formed on the matrix cores), the four modes of jamun_conv_dg (formed on the vector
+    ALUs) and the general k_conv — are independent implementations of the same contraction, and so are the initial projector's
+    k_conv_mfi / k_conv_mfx, k_conv_init_v and k_conv: all must meet the oracle (where a cached oracle output exists) and each other
+    on the same input.  Kernels are excluded one at a time through jamun_tuning (native.TUNING)."""
     from jamun_amd import synth
     from jamun_amd.data import WalkerBatch
     from jamun_amd.model import Denoiser
@@ -304,28 +304,22 @@ def test_fused_and_fallback_conv_agree(dev, golden_dir, kind, monkeypatch):
         ref = _golden(golden_dir, f"oracle_forward_{kind}")
         batch = WalkerBatch.from_molecules(_mols(kind)).to(dev)
         y = ref["y"].to(dev)
-    monkeypatch.delenv("JAMUN_NO_FUSED", raising=False)
-    monkeypatch.delenv("JAMUN_NO_DG", raising=False)
-    dg = NativeSampler(model._native, 0.04, batch, dev)  # default: VALU-forming kernel for the hidden layers
+    monkeypatch.delitem(native.TUNING, "no_dg", raising=False)
+    dg = NativeSampler(model._native, 0.04, batch, dev)  # default: the destination-grouped kernels on host-planned tiles
     assert dg.stats()["conv_path"] == 2
-    monkeypatch.setenv("JAMUN_NO_DG", "1")
-    fused = NativeSampler(model._native, 0.04, batch, dev)
-    assert fused.stats()["conv_path"] == 1
-    monkeypatch.setenv("JAMUN_NO_FUSED", "1")
+    monkeypatch.setitem(native.TUNING, "no_dg", 1)
     general = NativeSampler(model._native, 0.04, batch, dev)
-    assert general.stats()["conv_path"] == 0
-    xd, xf, xg = dg.xhat(y), fused.xhat(y), general.xhat(y)
+    assert general.stats()["conv_path"] == 0 and general.stats()["init_path"] == 0
+    xd, xg = dg.xhat(y), general.xhat(y)
     if ref is not None:
         assert rmsd(xd, ref["xhat"]) <= RMSD_TOL_NM, rmsd(xd, ref["xhat"])
-        assert rmsd(xf, ref["xhat"]) <= RMSD_TOL_NM and rmsd(xg, ref["xhat"]) <= RMSD_TOL_NM
-    assert rmsd(xf, xg) <= RMSD_TOL_NM and rmsd(xd, xg) <= RMSD_TOL_NM
+        assert rmsd(xg, ref["xhat"]) <= RMSD_TOL_NM
+    assert rmsd(xd, xg) <= RMSD_TOL_NM
     for l in range(6):
         b = general.debug_read(0, l).cpu()
-        for other in (fused, dg):
-            a = other.debug_read(0, l).cpu()
-            assert (a - b).abs().max().item() <= 2e-5 * max(b.abs().max().item(), 1e-6), l
-    monkeypatch.delenv("JAMUN_NO_DG")
-    monkeypatch.delenv("JAMUN_NO_FUSED")
+        a = dg.debug_read(0, l).cpu()
+        assert (a - b).abs().max().item() <= 2e-5 * max(b.abs().max().item(), 1e-6), l
+    monkeypatch.delitem(native.TUNING, "no_dg", raising=False)
     # jamun_conv_dg.hip has four variants, chosen by the span of the tiles: single phase (small molecules), single phase with one
     # Y tile (mid-size spans), two phases with resident source rows, two passes (large molecules).  Switch the chosen one off
     # and the two-phase kernel must give the same features.
@@ -337,20 +331,16 @@ def test_fused_and_fallback_conv_agree(dev, golden_dir, kind, monkeypatch):
     expect = {"ag4": 4, "chain17x6": 4, "ragged_small": 4, "ragged": 4, "dense70": 3, "chig93x2": 1, "chig166x2": 1}[kind]
     assert mode == expect, (kind, mode)
     small = kind in ("ag4", "chain17x6", "ragged_small")  # spans within the single-phase budget of jamun_conv_dg.hip (~52 rows)
-    variants = {4: [("JAMUN_DG_NO_MF",)], 1: [("JAMUN_DG_NO_ALT",)], 2: [], 3: []}[mode]
+    variants = {4: [("no_mf",)], 1: [("dg_no_alt",)], 2: [], 3: []}[mode]
     if mode == 4:
-        variants.append(("JAMUN_DG_NO_MF", "JAMUN_DG_NO_SP") if small else ("JAMUN_DG_NO_MF", "JAMUN_DG_NO_SPH"))
+        variants.append(("no_mf", "dg_no_sp") if small else ("no_mf", "dg_no_sph"))
         if small:
-            variants.append(("JAMUN_DG_NO_MF", "JAMUN_DG_NO_SP", "JAMUN_DG_NO_SPH"))
+            variants.append(("no_mf", "dg_no_sp", "dg_no_sph"))
     if mode == 3:
-        variants.append(("JAMUN_DG_NO_SPH",))
+        variants.append(("dg_no_sph",))
     seen = {mode}
     for envs in variants:
-        for e in envs:
-            monkeypatch.setenv(e, "1")
-        other = NativeSampler(model._native, 0.04, batch, dev)
-        for e in envs:
-            monkeypatch.delenv(e)
+        other = NativeSampler(model._native, 0.04, batch, dev, tuning={e: 1 for e in envs})
         seen.add(other.stats()["dg_mode"])
         assert other.stats()["conv_path"] == 2 and other.stats()["dg_mode"] != mode, (envs, other.stats()["dg_mode"])
         assert rmsd(other.xhat(y), xg) <= RMSD_TOL_NM
@@ -359,43 +349,29 @@ def test_fused_and_fallback_conv_agree(dev, golden_dir, kind, monkeypatch):
             assert (a2 - b2).abs().max().item() <= 2e-5 * max(b2.abs().max().item(), 1e-6), (envs, l)
     assert seen == {"ag4": {4, 2, 3, 0}, "chain17x6": {4, 2, 3, 0}, "ragged_small": {4, 2, 3, 0}, "ragged": {4, 3, 0}, "dense70": {3, 0},
                     "chig93x2": {1, 0}, "chig166x2": {1, 0}}[kind], seen
-    # The initial projector of the default path: on the tiles of k_conv_mf (spans up to 62 rows) and with at most 128 distinct
-    # embedding rows, k_conv_mfi (selector-formed coefficient sums on the matrix cores, init_path 3); else edge by edge on the tiles of
-    # the dg kernel when the spans fit two LDS row buffers (jamun_conv_initv.hip, 2: molecules up to 40 atoms, one buffer for
-    # chignolin-size spans); mid-size molecules keep the MFMA table kernel (1).  Each is switched off in turn: same features.
-    expect_init = {"ag4": 3, "chain17x6": 3, "ragged_small": 4, "ragged": 4, "dense70": 1, "chig93x2": 2, "chig166x2": 2}[kind]
+    # The initial projector of the default path: on the tiles of k_conv_mf (spans up to 62 rows) k_conv_mfi (up to 32 distinct
+    # embedding rows: one-hot selector, init_path 3) or k_conv_mfx (formed from the embedding rows, 4); on the tiles of the dg kernel
+    # k_conv_init_v (edge by edge on the vector ALUs, 2).  Each is switched off in turn: same features; with all of them off the
+    # general kernel takes the layer (0).
+    expect_init = {"ag4": 3, "chain17x6": 3, "ragged_small": 4, "ragged": 4, "dense70": 2, "chig93x2": 2, "chig166x2": 2}[kind]
     assert dg.stats()["init_path"] == expect_init, (kind, dg.stats()["init_path"])
     a1 = dg.debug_read(0, 0).cpu()
     if expect_init >= 3:
-        monkeypatch.setenv("JAMUN_NO_MFI", "1")
-        no_mfi = NativeSampler(model._native, 0.04, batch, dev)
-        assert no_mfi.stats()["init_path"] == (1 if kind == "ragged" else 2), no_mfi.stats()["init_path"]
+        no_mfi = NativeSampler(model._native, 0.04, batch, dev, tuning={"no_mfi": 1})
+        assert no_mfi.stats()["init_path"] == 2, no_mfi.stats()["init_path"]
         assert rmsd(no_mfi.xhat(y), xd) <= RMSD_TOL_NM
         b1 = no_mfi.debug_read(0, 0).cpu()
         assert (a1 - b1).abs().max().item() <= 2e-5 * max(b1.abs().max().item(), 1e-6)
-    if expect_init >= 2:
-        monkeypatch.setenv("JAMUN_NO_MFI", "1")
-        monkeypatch.setenv("JAMUN_NO_INIT_V", "1")
-        no_v = NativeSampler(model._native, 0.04, batch, dev)
-        monkeypatch.delenv("JAMUN_NO_INIT_V")
-        monkeypatch.delenv("JAMUN_NO_MFI")
-        assert no_v.stats()["init_path"] == 1
-        assert rmsd(no_v.xhat(y), xd) <= RMSD_TOL_NM
-        b1 = no_v.debug_read(0, 0).cpu()
-        assert (a1 - b1).abs().max().item() <= 2e-5 * max(b1.abs().max().item(), 1e-6)
-    # the initial projector has a third implementation (input-times-weight table, jamun_conv_init.hip): switch it off and
-    # the fused kernel takes that layer as well — same result
-    monkeypatch.setenv("JAMUN_NO_INIT_TABLE", "1")
-    no_table = NativeSampler(model._native, 0.04, batch, dev)
-    monkeypatch.delenv("JAMUN_NO_INIT_TABLE")
-    a0, b0 = fused.debug_read(0, 0).cpu(), (no_table.xhat(y), no_table.debug_read(0, 0).cpu())[1]
-    assert (a0 - b0).abs().max().item() <= 2e-5 * max(b0.abs().max().item(), 1e-6)
-    assert rmsd(no_table.xhat(y), xf) <= RMSD_TOL_NM
+    no_v = NativeSampler(model._native, 0.04, batch, dev, tuning={"no_mfi": 1, "no_init_v": 1})
+    assert no_v.stats()["init_path"] == 0 and no_v.stats()["conv_path"] == 2
+    assert rmsd(no_v.xhat(y), xd) <= RMSD_TOL_NM
+    b1 = no_v.debug_read(0, 0).cpu()
+    assert (a1 - b1).abs().max().item() <= 2e-5 * max(b1.abs().max().item(), 1e-6)
 
 
 @pytest.mark.parametrize("seed", [0, 7])
-def test_fused_and_fallback_conv_agree_on_random_ragged_batches(dev, seed, monkeypatch):
-    """Fuzz the tiling of the fused conv path (multi-molecule tiles, partly filled tiles, source-row blocks of molecules
+def test_tiled_and_general_conv_agree_on_random_ragged_batches(dev, seed, monkeypatch):
+    """Fuzz the tile plans of the destination-grouped kernels (multi-molecule tiles, partly filled tiles, source-row blocks of molecules
     above the per-tile budget, 1-atom walkers, tiny batches) against the general kernel: random walker counts and sizes."""
     import random
 
@@ -413,23 +389,17 @@ def test_fused_and_fallback_conv_agree_on_random_ragged_batches(dev, seed, monke
         batch = WalkerBatch.from_molecules(mols).to(dev)
         torch.manual_seed(trial)
         y = batch.pos + 0.04 * torch.randn(batch.pos.shape).to(dev)
-        monkeypatch.delenv("JAMUN_NO_FUSED", raising=False)
-        monkeypatch.delenv("JAMUN_NO_DG", raising=False)
         dg = NativeSampler(model._native, 0.04, batch, dev)
-        monkeypatch.setenv("JAMUN_NO_DG", "1")
-        fused = NativeSampler(model._native, 0.04, batch, dev)
-        monkeypatch.setenv("JAMUN_NO_FUSED", "1")
-        general = NativeSampler(model._native, 0.04, batch, dev)
-        monkeypatch.delenv("JAMUN_NO_FUSED")
-        monkeypatch.delenv("JAMUN_NO_DG")
-        assert dg.stats()["conv_path"] == 2 and fused.stats()["conv_path"] == 1 and general.stats()["conv_path"] == 0
-        xd, xf, xg = dg.xhat(y), fused.xhat(y), general.xhat(y)
+        vf = NativeSampler(model._native, 0.04, batch, dev, tuning={"no_mf": 1, "no_mfi": 1})  # vector-ALU forming kernels on their own tile plans
+        general = NativeSampler(model._native, 0.04, batch, dev, tuning={"no_dg": 1})
+        assert dg.stats()["conv_path"] == 2 and vf.stats()["conv_path"] == 2 and vf.stats()["dg_mode"] != 4 and general.stats()["conv_path"] == 0
+        xd, xf, xg = dg.xhat(y), vf.xhat(y), general.xhat(y)
         assert torch.isfinite(xf).all() and torch.isfinite(xd).all()
         assert rmsd(xf, xg) <= RMSD_TOL_NM, (trial, nw, hi)
         assert rmsd(xd, xg) <= RMSD_TOL_NM, (trial, nw, hi)
         for l in range(6):
             b = general.debug_read(0, l).cpu()
-            for other in (fused, dg):
+            for other in (vf, dg):
                 a = other.debug_read(0, l).cpu()
                 assert (a - b).abs().max().item() <= 2e-5 * max(b.abs().max().item(), 1e-6), (trial, l)
 
@@ -479,11 +449,9 @@ def test_matrix_formed_conv_edge_cases(dev, case, monkeypatch):
     assert (st["conv_path"], st["dg_mode"], st["init_path"]) == (2, 4, _init_path_of(mols)), st
     if case in ("many_rows", "rows100"):
         assert st["init_path"] == 4
-    monkeypatch.setenv("JAMUN_NO_DG", "1")
-    monkeypatch.setenv("JAMUN_NO_FUSED", "1")
+    monkeypatch.setitem(native.TUNING, "no_dg", 1)
     general = NativeSampler(model._native, 0.04, batch, dev)
-    monkeypatch.delenv("JAMUN_NO_DG")
-    monkeypatch.delenv("JAMUN_NO_FUSED")
+    monkeypatch.delitem(native.TUNING, "no_dg", raising=False)
     assert general.stats()["conv_path"] == 0
     xm, xg = mf.xhat(y), general.xhat(y)
     assert torch.isfinite(xm).all() and rmsd(xm, xg) <= RMSD_TOL_NM, rmsd(xm, xg)
@@ -496,7 +464,7 @@ def test_matrix_formed_conv_edge_cases(dev, case, monkeypatch):
         assert NativeSampler(model._native, 0.04, big, dev).stats()["dg_mode"] != 4
 
 
-@pytest.mark.parametrize("atoms,walkers,dg_mode,init_path", [(17, 64, 4, 3), (33, 64, 4, 3), (57, 32, 4, 4), (70, 16, 3, 1), (166, 4, 1, 2)])
+@pytest.mark.parametrize("atoms,walkers,dg_mode,init_path", [(17, 64, 4, 3), (33, 64, 4, 3), (57, 32, 4, 4), (70, 16, 3, 2), (166, 4, 1, 2)])
 def test_kernel_variants_chosen_for_the_baseline_shapes(dev, atoms, walkers, dg_mode, init_path):
     """BASELINE configs[1..4] shapes (fewer walkers): which variant of the hidden-layer conv kernel (jamun_stats.dg_mode) and of
     the initial projector (init_path) the sampler picks, and that the forward through them is finite and rotation-equivariant."""
@@ -643,21 +611,18 @@ def test_source_row_blocks_of_the_default_conv_kernel(dev, monkeypatch, case):
     batch = WalkerBatch.from_molecules(mols).to(dev)
     torch.manual_seed(9)
     y = batch.pos + 0.04 * torch.randn(batch.pos.shape).to(dev)
-    monkeypatch.delenv("JAMUN_NO_FUSED", raising=False)
-    monkeypatch.delenv("JAMUN_NO_DG", raising=False)
+    monkeypatch.delitem(native.TUNING, "no_dg", raising=False)
     dg = NativeSampler(model._native, 0.04, batch, dev)
     st = dg.stats()
     assert st["conv_path"] == 2 and st["dg_mode"] == 1 and st["dg_row_blocks"] == 1, st
-    monkeypatch.setenv("JAMUN_DG_NO_ALT", "1")
+    monkeypatch.setitem(native.TUNING, "dg_no_alt", 1)
     dg0 = NativeSampler(model._native, 0.04, batch, dev)
-    monkeypatch.delenv("JAMUN_DG_NO_ALT")
+    monkeypatch.delitem(native.TUNING, "dg_no_alt", raising=False)
     st0 = dg0.stats()
     assert st0["conv_path"] == 2 and st0["dg_mode"] == 0 and st0["dg_row_blocks"] == 1, st0
-    monkeypatch.setenv("JAMUN_NO_DG", "1")
-    monkeypatch.setenv("JAMUN_NO_FUSED", "1")
+    monkeypatch.setitem(native.TUNING, "no_dg", 1)
     general = NativeSampler(model._native, 0.04, batch, dev)
-    monkeypatch.delenv("JAMUN_NO_FUSED")
-    monkeypatch.delenv("JAMUN_NO_DG")
+    monkeypatch.delitem(native.TUNING, "no_dg", raising=False)
     assert general.stats()["conv_path"] == 0
     xg = general.xhat(y)
     for other in (dg, dg0):

@@ -106,9 +106,7 @@ def test_trained_like_weights_through_every_f16x3_kernel_against_the_fp32_kernel
     fast = NativeSampler(model._native, 0.04, batch, dev)
     st = fast.stats()
     assert st["dg_mode"] == 4 and st["init_path"] == 3 and st["dg_emu"] == 1
-    for e in ("JAMUN_NO_DG", "JAMUN_NO_FUSED", "JAMUN_NODE_FP32", "JAMUN_EDGE_H_FP32", "JAMUN_NO_INIT_TABLE"):
-        monkeypatch.setenv(e, "1")
-    general = NativeSampler(model._native, 0.04, batch, dev)
+    general = NativeSampler(model._native, 0.04, batch, dev, tuning={"no_dg": 1, "node_fp32": 1, "edge_h_fp32": 1})
     assert general.stats()["conv_path"] == 0
     y = ref["y"].to(dev)
     fast.build_edges(y)
