@@ -464,7 +464,7 @@ def main():
             mst, ct = prof_all.get("tprod", (0.0, 0)) if prof_all is not None else (0.0, 0)  # (T pre-pass: from the separate untimed pass)
             avg0 = ms0 / max(c0, 1)                 # the conv kernel alone (k_conv_mf / k_conv_dg): the launch rocprofv3 lists under that name
             avg_pair = avg0 + mst / max(ct, 1)      # ... with the T pre-pass in front of it (k_tprod_h): one hidden layer's conv
-            fused = c1 == 0  # one launch covers the scalar-row and the vector-row contraction of a hidden layer
+            fused = stats["conv_path"] == 2  # one launch covers the scalar-row and the vector-row contraction of a hidden layer (conv1: tail tiles)
             flop = stats["conv0_flop_alg"] + (stats["conv1_flop_alg"] if fused else 0)
             kname = ("k_conv_mf" if stats.get("dg_mode") == 4 else f"k_conv_dg<mode {stats.get('dg_mode')}>") if stats["conv_path"] == 2 else \
                 {1: "k_conv_fused"}.get(stats["conv_path"], "k_conv")

@@ -99,7 +99,8 @@ typedef struct jamun_tuning {
   int32_t node_fp32;    /* node update with v_mfma_f32_32x32x2_f32 (k_node_update) instead of f16x3 (k_node_update_h)                */
   int32_t edge_h_fp32;  /* radial MLP first layer with fp32 MFMAs (k_edge_h) instead of f16x3 (k_edge_h16)                           */
   int32_t dg_kgroups;   /* hidden-unit slices over XCD groups for the destination-grouped kernels: 0 (default = 1), 1, 2, 4, 8       */
-  int32_t reserved[5];  /* must be zero                                                                                              */
+  int32_t no_tail;      /* k_conv_mf: tiles with few destinations stay whole tiles (no k_tail_form / k_tail_contract)                 */
+  int32_t reserved[4];  /* must be zero                                                                                              */
 } jamun_tuning;
 
 typedef struct jamun_model jamun_model;     /* raw checkpoint tensors kept on the host          */
@@ -263,6 +264,8 @@ typedef struct jamun_stats {
   int64_t conv_flop_useful_launch; /* of those, what the destination-grouped association needs at the edge count of the last forward:
                              3 (f16x3) x [2 x 65 x n_atoms x (G0 K0 + 3 G1 K1) contraction + 2 x 65 x n_edges x (in0 + 15 in1) forming
                              (x0, dot, x1, cross and T term per edge)], no padding, no zero blocks */
+  int32_t n_tail_tiles;   /* tiles of the dg_mode-4 plan that go through k_tail_form / k_tail_contract instead of k_conv_mf (0: none)            */
+  int32_t n_tail;         /* ... and their destinations                                                                                   */
   int64_t conv_bytes_alg_launch;  /* algorithmic HBM bytes of that launch: h~ of the layer, T, the weight stream once, the feature
                              rows once, the partial slabs written */
 } jamun_stats;
@@ -277,7 +280,7 @@ int jamun_sampler_stats(jamun_sampler* s, jamun_stats* out, void* stream);
 #define JAMUN_PROF_CONV0_INIT 2  /* conv contraction, initial projector (fused path: all rows)        */
 #define JAMUN_PROF_CONV1_INIT 3  /* conv contraction, vector-output rows, initial projector          */
 #define JAMUN_PROF_CONV0 4       /* conv contraction, hidden layers (dominant; fused path: all rows)  */
-#define JAMUN_PROF_CONV1 5       /* conv contraction, vector-output rows, hidden layers              */
+#define JAMUN_PROF_CONV1 5       /* hidden layers: tail tiles (k_tail_form + k_tail_contract); general kernel: vector-output rows */
 #define JAMUN_PROF_NODE 6        /* partial-slab reduce + gate + self/skip Linear + noise skip mix   */
 #define JAMUN_PROF_HEAD 7        /* output head + xhat/score finalize                                */
 #define JAMUN_PROF_TPROD 8       /* T pre-pass of a hidden layer (k_tprod / k_tprod_h), in front of the conv kernel */

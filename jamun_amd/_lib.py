@@ -54,7 +54,7 @@ class jamun_topology(C.Structure):
 
 class jamun_tuning(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("no_dg", "no_mf", "dg_fp32", "dg_no_alt", "dg_no_sp", "dg_no_sph", "no_mfi", "no_init_v", "node_fp32",
-                                         "edge_h_fp32", "dg_kgroups")] + [("reserved", C.c_int32 * 5)]
+                                         "edge_h_fp32", "dg_kgroups", "no_tail")] + [("reserved", C.c_int32 * 4)]
 
 
 class jamun_mcmc_params(C.Structure):
@@ -89,6 +89,8 @@ class jamun_stats(C.Structure):
         ("dg_emu", C.c_int32),
         ("conv_flop_exec_launch", C.c_int64),
         ("conv_flop_useful_launch", C.c_int64),
+        ("n_tail_tiles", C.c_int32),
+        ("n_tail", C.c_int32),
         ("conv_bytes_alg_launch", C.c_int64),
     ]
 

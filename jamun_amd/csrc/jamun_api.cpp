@@ -106,6 +106,8 @@ struct DgDev {
   // f16x3 balancing (build_layer): gx [216] 2^e_u per feature element (layout of a feature row), gT [128] the T pre-pass's input factors,
   // cf0 [160] / cf1 [32] / cfT [32] the inverse column scales of the scalar / vector outputs / T
   float *gx = nullptr, *gT = nullptr, *cf0 = nullptr, *cf1 = nullptr, *cfT = nullptr;
+  float4* wmt = nullptr;   // tail tiles (k_tail_contract): vector-output weights [k][24 blocks] under one column scale
+  float* cf1t = nullptr;   // ... its inverse [32]
 };
 struct SepDev {
   float4* w2b = nullptr;  // null: not a SeparableConv layer
@@ -138,7 +140,7 @@ struct LayerDev {
 
 void free_dg(DgDev& d) {
   hipFree(d.wx); hipFree(d.wd); hipFree(d.wv); hipFree(d.wt); hipFree(d.wxh); hipFree(d.wth); hipFree(d.wm);
-  hipFree(d.gx); hipFree(d.gT); hipFree(d.cf0); hipFree(d.cf1); hipFree(d.cfT);
+  hipFree(d.gx); hipFree(d.gT); hipFree(d.cf0); hipFree(d.cf1); hipFree(d.cfT); hipFree(d.wmt); hipFree(d.cf1t);
   d = DgDev{};
 }
 
@@ -341,6 +343,17 @@ struct jamun_sampler {
   int cus = 1;
   float* dg_T = nullptr;  // [n_k][n_atoms][32] pre-pass product of a hidden layer (k_tprod), reused by every layer
   int dg_tstride = 0;     // mode 4 (jamun_conv_mf.hip): dg_T is [n_k][32][dg_tstride], transposed
+  // tail tiles of the mode-4 plan (tiles with few destinations): formed with the hidden unit in the column index and contracted 32 gathered
+  // destinations at a time (k_tail_form / k_tail_contract) instead of as whole tiles of k_conv_mf; the initial projector keeps them as tiles
+  int n_tail_tiles = 0, n_tail = 0, tail_runs = 0;
+  int4* tail_tiles = nullptr;
+  int* tail_atom = nullptr;
+  float* tail_scale = nullptr;
+  float4* tail_P = nullptr;
+  int4* init_segs = nullptr;   // segment lists of the initial projector (ALL tiles) when the hidden layers' lists leave the tail tiles out
+  int* init_atom_nslab = nullptr;
+  int init_max_segs = 0, init_n_slabs = 0;
+  bool init_tail = false;      // the initial projector sends the tail tiles through k_tail_form_init / k_tail_contract as well
   bool mfi_on = false;    // initial projector on k_conv_mfi (mode 4 tiles, at most 32 distinct embedding rows)
   bool mfx_on = false;    // ... or on k_conv_mfx (mode 4 tiles, any number of distinct rows: formed from the feature rows)
   int n_uniq = 0;         // distinct (noise-scaled) embedding rows of the batch
@@ -372,6 +385,7 @@ struct jamun_sampler {
     hipFree(ptr); hipFree(bond_in_ptr); hipFree(bond_in_src); hipFree(x_emb); hipFree(mu);
     hipFree(atom_uid); hipFree(w1r_all); hipFree(cmask_all); hipFree(w1h_all); hipFree(w1isc_all);
     hipFree(dg_tile_atoms); hipFree(dg_tile_span); hipFree(dg_segs); hipFree(dg_atom_nslab); hipFree(dg_T); hipFree(mf_err);
+    hipFree(tail_tiles); hipFree(tail_atom); hipFree(tail_scale); hipFree(tail_P); hipFree(init_segs); hipFree(init_atom_nslab);
     if (mf_err_host) hipHostFree(mf_err_host);
     for (auto& L : layers) {
       free_problem(L.p0); free_problem(L.p1); free_dg(L.dg);
@@ -990,6 +1004,42 @@ LayerDev build_layer(const jamun_model& m, const std::string& prefix, const std:
           }
         }
         L.dg.wm = dev_upload(wm);
+        // tail tiles (k_tail_contract): the vector outputs take x1, cross AND the scalar channels times v_m (no T pre-pass there) in one
+        // accumulator, so the three weight blocks share one column scale; 24 blocks per hidden unit: x1 (2 K-steps x hi, lo), cross,
+        // then the scalar channel tiles w = 0..3 (input gauge e0: the rows are staged once, with the conv kernel's channel factors)
+        {
+          std::vector<double> sct(32, 1.0);
+          std::vector<float> cf1t(32, 0.f);
+          for (int col = 0; col < G1; ++col) {
+            double mx = 0;
+            for (int k = 0; k < n_k; ++k) {
+              for (int u = 0; u < 32; ++u) mx = std::max(mx, std::max(std::fabs(Wg(x1e[u], e1[u], k, col)), std::fabs(Wg(crosse[u], e1[u], k, col))));
+              for (int u = 0; u < 120; ++u) mx = std::max(mx, std::fabs(Wg(x0ve[u], e0[u], k, col)));
+            }
+            const int sB = 14 - pow2_above(mx);
+            sct[col] = std::ldexp(1.0, sB); cf1t[col] = (float)std::ldexp(1.0, -sB);
+          }
+          std::vector<float4> wmt((size_t)n_k * 24 * 64, make_float4(0.f, 0.f, 0.f, 0.f));
+          for (int k = 0; k < n_k; ++k)
+            for (int lane = 0; lane < 64; ++lane) {
+              const int hh = lane >> 5, c = lane & 31;
+              for (int g = 0; g < 6; ++g)
+                for (int s2 = 0; s2 < 2; ++s2) {
+                  double v[8];
+                  for (int pp = 0; pp < 8; ++pp) {
+                    const int ul = u_of(s2, hh, pp);
+                    if (c >= G1) v[pp] = 0.0;
+                    else if (g == 0) v[pp] = Wg(x1e[ul], e1[ul], k, c) * sct[c];
+                    else if (g == 1) v[pp] = Wg(crosse[ul], e1[ul], k, c) * sct[c];
+                    else { const int u = 32 * (g - 2) + ul; v[pp] = u < 120 ? Wg(x0ve[u], e0[u], k, c) * sct[c] : 0.0; }
+                  }
+                  const size_t b = ((size_t)k * 24 + 4 * g + 2 * s2) * 64 + lane;
+                  pack8m(v, wmt[b], wmt[b + 64]);
+                }
+            }
+          L.dg.wmt = dev_upload(wmt);
+          L.dg.cf1t = dev_upload(cf1t);
+        }
       }
     }
   }
@@ -1238,7 +1288,7 @@ void run_layer(jamun_sampler* s, size_t l, const float* x_in, int XSin, float* x
       MfiArgs f{};
       f.deg = s->deg; f.esrc = s->esrc; f.egeo = s->egeo; f.h = h_l; f.h_kstride = s->h_kstride;
       f.n_pad = s->n_pad; f.S = s->S; f.nt0 = L.p0.nt;
-      f.tile_span = s->dg_tile_span; f.tile_atoms = s->dg_tile_atoms; f.segs = s->dg_segs; f.max_segs = s->dg_max_segs;
+      f.tile_span = s->dg_tile_span; f.tile_atoms = s->dg_tile_atoms; f.segs = s->init_segs ? s->init_segs : s->dg_segs; f.max_segs = s->init_segs ? s->init_max_segs : s->dg_max_segs;
       f.atom_uid = s->atom_uid; f.tabw = L.tabw; f.sB = L.tab_sB; f.ut = L.tab_ut;
       {
         int e3 = 0;
@@ -1246,13 +1296,26 @@ void run_layer(jamun_sampler* s, size_t l, const float* x_in, int XSin, float* x
         f.sC = std::max(-40, std::min(40, 14 - e3));
       }
       f.partial0 = s->partial0; f.partial1 = s->partial1; f.err = s->mf_err;
-      ProfScope ps(s, JAMUN_PROF_CONV0_INIT, st);
-      if (launch_conv_mfi(f, s->dg_grid, st) != 0) throw Err(JAMUN_ERR_INVALID, "initial-projector conv launch failed (configuration not supported)");
+      {
+        ProfScope ps(s, JAMUN_PROF_CONV0_INIT, st);
+        if (launch_conv_mfi(f, s->dg_grid, st) != 0) throw Err(JAMUN_ERR_INVALID, "initial-projector conv launch failed (configuration not supported)");
+      }
+      if (s->init_tail) {
+        TailArgs t{};
+        t.deg = s->deg; t.esrc = s->esrc; t.egeo = s->egeo; t.h = h_l; t.h_kstride = s->h_kstride;
+        t.n_pad = s->n_pad; t.S = s->S; t.n_k = s->hp.edge_attr_dim + 1; t.nt0 = L.p0.nt;
+        t.tile_span = s->dg_tile_span; t.tile_atoms = s->dg_tile_atoms; t.tail_tiles = s->tail_tiles;
+        t.n_tail_tiles = s->n_tail_tiles; t.n_tail = s->n_tail; t.n_runs = s->tail_runs; t.tail_atom = s->tail_atom; t.tail_scale = s->tail_scale;
+        t.P = s->tail_P; t.sC = f.sC; t.xph = L.xph; t.xpl = L.xpl; t.wx = L.wx; t.sX = L.x_sX; t.cf0 = L.xcf0; t.cf1t = L.xcf1;
+        t.partial0 = s->partial0; t.partial1 = s->partial1; t.err = s->mf_err;
+        ProfScope pt(s, JAMUN_PROF_CONV1_INIT, st);
+        if (launch_conv_tail_init(t, st) != 0) throw Err(JAMUN_ERR_INVALID, "tail-tile conv launch failed (configuration not supported)");
+      }
     } else if (l == 0 && s->mfx_on) {
       MfxArgs f{};
       f.deg = s->deg; f.esrc = s->esrc; f.egeo = s->egeo; f.h = h_l; f.h_kstride = s->h_kstride;
       f.n_pad = s->n_pad; f.S = s->S; f.nt0 = L.p0.nt;
-      f.tile_span = s->dg_tile_span; f.tile_atoms = s->dg_tile_atoms; f.segs = s->dg_segs; f.max_segs = s->dg_max_segs;
+      f.tile_span = s->dg_tile_span; f.tile_atoms = s->dg_tile_atoms; f.segs = s->init_segs ? s->init_segs : s->dg_segs; f.max_segs = s->init_segs ? s->init_max_segs : s->dg_max_segs;
       f.xph = L.xph; f.xpl = L.xpl; f.wx = L.wx; f.sX = L.x_sX; f.cf0 = L.xcf0; f.cf1 = L.xcf1;
       {
         int e3 = 0;
@@ -1260,13 +1323,26 @@ void run_layer(jamun_sampler* s, size_t l, const float* x_in, int XSin, float* x
         f.sC = std::max(-40, std::min(40, 14 - e3));
       }
       f.partial0 = s->partial0; f.partial1 = s->partial1; f.err = s->mf_err;
-      ProfScope ps(s, JAMUN_PROF_CONV0_INIT, st);
-      if (launch_conv_mfx(f, s->dg_grid, st) != 0) throw Err(JAMUN_ERR_INVALID, "initial-projector conv launch failed (configuration not supported)");
+      {
+        ProfScope ps(s, JAMUN_PROF_CONV0_INIT, st);
+        if (launch_conv_mfx(f, s->dg_grid, st) != 0) throw Err(JAMUN_ERR_INVALID, "initial-projector conv launch failed (configuration not supported)");
+      }
+      if (s->init_tail) {
+        TailArgs t{};
+        t.deg = s->deg; t.esrc = s->esrc; t.egeo = s->egeo; t.h = h_l; t.h_kstride = s->h_kstride;
+        t.n_pad = s->n_pad; t.S = s->S; t.n_k = s->hp.edge_attr_dim + 1; t.nt0 = L.p0.nt;
+        t.tile_span = s->dg_tile_span; t.tile_atoms = s->dg_tile_atoms; t.tail_tiles = s->tail_tiles;
+        t.n_tail_tiles = s->n_tail_tiles; t.n_tail = s->n_tail; t.n_runs = s->tail_runs; t.tail_atom = s->tail_atom; t.tail_scale = s->tail_scale;
+        t.P = s->tail_P; t.sC = f.sC; t.xph = L.xph; t.xpl = L.xpl; t.wx = L.wx; t.sX = L.x_sX; t.cf0 = L.xcf0; t.cf1t = L.xcf1;
+        t.partial0 = s->partial0; t.partial1 = s->partial1; t.err = s->mf_err;
+        ProfScope pt(s, JAMUN_PROF_CONV1_INIT, st);
+        if (launch_conv_tail_init(t, st) != 0) throw Err(JAMUN_ERR_INVALID, "tail-tile conv launch failed (configuration not supported)");
+      }
     } else if (l == 0 && s->initv_on) {
       InitVArgs f{};
       f.deg = s->deg; f.esrc = s->esrc; f.egeo = s->egeo; f.h = h_l; f.h_kstride = s->h_kstride;
       f.n_pad = s->n_pad; f.S = s->S; f.PMAX = (s->S + 3) & ~3; f.RS = s->dg_RS; f.nt0 = L.p0.nt; f.nbuf = s->initv_nbuf;
-      f.tile_span = s->dg_tile_span; f.tile_atoms = s->dg_tile_atoms; f.segs = s->dg_segs; f.max_segs = s->dg_max_segs;
+      f.tile_span = s->dg_tile_span; f.tile_atoms = s->dg_tile_atoms; f.segs = s->init_segs ? s->init_segs : s->dg_segs; f.max_segs = s->init_segs ? s->init_max_segs : s->dg_max_segs;
       f.atom_uid = s->atom_uid; f.tt2 = L.tt2; f.tt2_kstride = (size_t)L.tt_U * 192;
       f.dbg = 0;
       f.partial0 = s->partial0; f.partial1 = s->partial1;
@@ -1289,8 +1365,21 @@ void run_layer(jamun_sampler* s, size_t l, const float* x_in, int XSin, float* x
         ProfScope pt(s, JAMUN_PROF_TPROD, st);
         launch_tprod(x_in, XSin, s->n_atoms, s->hp.edge_attr_dim + 1, L.dg.wt, L.dg.wth, L.dg.gT, L.dg.cfT, s->dg_T, s->dg_tstride, st);
       }
-      ProfScope ps(s, JAMUN_PROF_CONV0, st);
-      if (launch_conv_mf(f, s->dg_grid, st) != 0) throw Err(JAMUN_ERR_INVALID, "matrix-formed conv launch failed (configuration not supported)");
+      {
+        ProfScope ps(s, JAMUN_PROF_CONV0, st);
+        if (launch_conv_mf(f, s->dg_grid, st) != 0) throw Err(JAMUN_ERR_INVALID, "matrix-formed conv launch failed (configuration not supported)");
+      }
+      if (s->n_tail_tiles) {
+        TailArgs t{};
+        t.deg = s->deg; t.esrc = s->esrc; t.egeo = s->egeo; t.h = h_l; t.h_kstride = s->h_kstride; t.x = x_in;
+        t.n_pad = s->n_pad; t.S = s->S; t.XS = XSin; t.n_k = s->hp.edge_attr_dim + 1; t.nt0 = L.p0.nt;
+        t.tile_span = s->dg_tile_span; t.tile_atoms = s->dg_tile_atoms; t.tail_tiles = s->tail_tiles;
+        t.n_tail_tiles = s->n_tail_tiles; t.n_tail = s->n_tail; t.n_runs = s->tail_runs; t.tail_atom = s->tail_atom; t.tail_scale = s->tail_scale;
+        t.P = s->tail_P; t.gx = L.dg.gx; t.sC = f.sC; t.wm = L.dg.wm; t.wmt = L.dg.wmt; t.cf0 = L.dg.cf0; t.cf1t = L.dg.cf1t;
+        t.partial0 = s->partial0; t.partial1 = s->partial1; t.err = s->mf_err;
+        ProfScope pt(s, JAMUN_PROF_CONV1, st);
+        if (launch_conv_tail(t, st) != 0) throw Err(JAMUN_ERR_INVALID, "tail-tile conv launch failed (configuration not supported)");
+      }
     } else if (l > 0 && s->dg_on) {
       DgArgs f{};
       f.deg = s->deg; f.esrc = s->esrc; f.egeo = s->egeo; f.h = h_l; f.h_kstride = s->h_kstride; f.x = x_in;
@@ -1333,8 +1422,9 @@ void run_layer(jamun_sampler* s, size_t l, const float* x_in, int XSin, float* x
     n.n_atoms = s->n_atoms; n.n_pad = s->n_pad; n.n_slices = s->n_slices; n.nt0 = L.p0.nt; n.nt1 = L.p1.nt;
     n.mul0 = s->hp.mul0; n.mul1 = s->hp.mul1; n.in0 = L.in0; n.in1 = L.in1; n.XSin = XSin;
     const bool dg_layer = (l > 0 && s->dg_on) || (l == 0 && (s->initv_on || s->mfi_on || s->mfx_on));  // (slabs of the dg tile plan)
-    n.atom_nslab = dg_layer ? s->dg_atom_nslab : nullptr;
-    n.max_slabs = dg_layer ? s->dg_n_slabs : s->n_slices;
+    const bool init_plan = l == 0 && dg_layer && s->init_segs != nullptr;  // (the initial projector keeps the tail tiles on its own segment lists)
+    n.atom_nslab = dg_layer ? (init_plan ? s->init_atom_nslab : s->dg_atom_nslab) : nullptr;
+    n.max_slabs = dg_layer ? (init_plan ? s->init_n_slabs : s->dg_n_slabs) : s->n_slices;
     if (L.sep.w2b) { n.n_slices = 1; n.atom_nslab = nullptr; n.max_slabs = 1; }  // SeparableConv writes the summed messages as ONE slab
     n.wh0 = L.wh0; n.wh1 = L.wh1; n.K0h = L.K0h; n.K1h = L.K1h;
     n.kga0 = L.kga0; n.kga1 = L.kga1; n.kgx = L.kgx; n.cg0 = L.cg0; n.cg1 = L.cg1;
@@ -1459,7 +1549,7 @@ struct SegPlan {
 };
 template <typename WeightFn>
 SegPlan plan_segments(int cus, int ng, int n_k, int N, const std::vector<int2>& t_atoms, const std::vector<int>& t_chunk, int n_chunks,
-                      WeightFn weight) {
+                      WeightFn weight, const std::vector<char>* skip = nullptr) {  // skip[t]: tile t is not on this plan (its atoms get 0 slabs)
   SegPlan P;
   const int ncx_all = cus / ng;
   std::vector<std::vector<int>> wg_of(ng);  // workgroups of k-slice x, in launch order
@@ -1472,12 +1562,19 @@ SegPlan plan_segments(int cus, int ng, int n_k, int N, const std::vector<int2>& 
     auto extra_of = [&](int t) { const int e = ((x - t) % ng + ng) % ng; return e < rem ? ng * base + e : -1; };
     // (near-uniform batches are cut by item count: measured 1 % better on cfg2 than the modelled weights, whose error
     // then exceeds the spread they describe)
-    int64_t w_min = weight(0), w_max = w_min;
-    for (int t = 1; t < n_tiles; ++t) { w_min = std::min<int64_t>(w_min, weight(t)); w_max = std::max<int64_t>(w_max, weight(t)); }
+    auto skipped = [&](int t) { return skip && (*skip)[t]; };
+    int64_t w_min = -1, w_max = -1;
+    for (int t = 0; t < n_tiles; ++t) {
+      if (skipped(t)) continue;
+      w_min = w_min < 0 ? weight(t) : std::min<int64_t>(w_min, weight(t));
+      w_max = std::max<int64_t>(w_max, weight(t));
+    }
+    if (w_max < 0) continue;  // (no tile on this plan)
     const bool uniform = 4 * (w_max - w_min) < w_max;
     auto weight_of = [&](int t) -> int64_t { return uniform ? 1 : weight(t); };
     int64_t Lx = 0, Wx = 0;
     for (int t = 0; t < n_tiles; ++t) {
+      if (skipped(t)) continue;
       const int cnt = base + (extra_of(t) >= 0 ? 1 : 0);
       Lx += cnt;
       Wx += cnt * weight_of(t);
@@ -1487,6 +1584,7 @@ SegPlan plan_segments(int cus, int ng, int n_k, int N, const std::vector<int2>& 
     const int ncx = (int)std::max<int64_t>(1, std::min<int64_t>(ncx_all, Lx / 8));
     int64_t off_w = 0;
     for (int t = 0; t < n_tiles; ++t) {
+      if (skipped(t)) continue;
       const int ex = extra_of(t), cnt = base + (ex >= 0 ? 1 : 0);
       const int64_t w = weight_of(t);
       auto wg_of_item = [&](int i) { return (int)std::min<int64_t>(ncx - 1, ((off_w + i * w + w / 2) * ncx) / Wx); };
@@ -1805,7 +1903,48 @@ int jamun_sampler_create(const jamun_model* m, float sigma, const jamun_topology
         // ~7.7 MB of weight blocks per layer are served from L2 / Infinity Cache fast enough, longer runs of k per segment win.
         const int ng = (tn.dg_kgroups > 1 && cus % 8 == 0 && n_k >= tn.dg_kgroups) ? tn.dg_kgroups : 1;
         auto weight = [&](int t) -> int64_t { return 476 + (s->dg_mode == 1 ? 24 : 2) * ((t_span[t].y - t_span[t].x + 15) / 16); };
-        SegPlan P = plan_segments(cus, ng, n_k, N, t_atoms, t_chunk, n_chunks, weight);
+        // Tail tiles (mode 4): a tile with at most 8 destinations costs k_conv_mf a whole tile per hidden unit (a 33-atom molecule cuts into
+        // 32 + 1: twice the work of a 32-atom one).  They leave the hidden layers' segment lists and go through k_tail_form /
+        // k_tail_contract (jamun_conv_mf.hip); worth two more launches per layer when they are at least 4 and 3 % of the tiles.
+        std::vector<char> is_tail(t_atoms.size(), 0);
+        if (s->dg_mode == 4 && !tn.no_tail && s->layers.size() > 1 && s->layers[1].dg.wmt) {
+          std::vector<int4> tt;
+          std::vector<int> tatom;
+          for (size_t t = 0; t < t_atoms.size(); ++t)
+            if (t_atoms[t].y <= 8) {
+              tt.push_back(make_int4((int)t, (int)tatom.size(), 0, 0));
+              for (int i = 0; i < t_atoms[t].y; ++i) tatom.push_back(t_atoms[t].x + i);
+            }
+          const size_t p_bytes = (size_t)((tatom.size() + 31) / 32) * 32 * (size_t)n_k * TAIL_NFT * 8 * 16;
+          if (tt.size() >= 4 && 100 * tt.size() >= 3 * t_atoms.size() && tt.size() < t_atoms.size() && p_bytes <= ((size_t)2 << 30)) {
+            for (auto& e : tt) is_tail[e.x] = 1;
+            s->n_tail_tiles = (int)tt.size();
+            s->n_tail = (int)tatom.size();
+            const int n_ct = (s->n_tail + 31) / 32;
+            // runs of hidden units of the contraction = partial slabs of the tail atoms: one workgroup per (32 destinations, run, output
+            // tile); the node update fetches three slabs at once, so at most three
+            s->tail_runs = std::max(1, std::min(3, (32 + n_ct - 1) / n_ct));
+            s->tail_tiles = dev_upload(tt);
+            s->tail_atom = dev_upload(tatom);
+            s->tail_scale = dev_alloc<float>(tatom.size());
+            s->tail_P = dev_alloc<float4>(p_bytes / 16);
+          }
+        }
+        SegPlan P = plan_segments(cus, ng, n_k, N, t_atoms, t_chunk, n_chunks, weight, s->n_tail_tiles ? &is_tail : nullptr);
+        if (s->n_tail_tiles) {
+          for (size_t t = 0; t < t_atoms.size(); ++t)
+            if (is_tail[t])
+              for (int i = 0; i < t_atoms[t].y; ++i) P.atom_nslab[t_atoms[t].x + i] = s->tail_runs;
+          P.n_slabs = std::max(P.n_slabs, s->tail_runs);
+          s->init_tail = s->layers[0].wx != nullptr && s->layers[0].p0.nt == 5 && !tn.no_mfi;
+          if (!s->init_tail) {  // the initial projector keeps every tile on segment lists of its own
+            SegPlan PI = plan_segments(cus, ng, n_k, N, t_atoms, t_chunk, n_chunks, weight);
+            s->init_segs = dev_upload(PI.segs);
+            s->init_atom_nslab = dev_upload(PI.atom_nslab);
+            s->init_max_segs = PI.max_segs;
+            s->init_n_slabs = PI.n_slabs;
+          }
+        }
         s->dg_grid = cus;
         s->dg_max_segs = P.max_segs;
         s->dg_segs = dev_upload(P.segs);
@@ -1907,7 +2046,7 @@ int jamun_sampler_create(const jamun_model* m, float sigma, const jamun_topology
     }
     int nt0 = 0, nt1 = 0;
     for (auto& L : s->layers) { nt0 = std::max(nt0, L.p0.nt); nt1 = std::max(nt1, L.p1.nt); }
-    const size_t n_part = (size_t)std::max(s->n_slices, s->dg_n_slabs);
+    const size_t n_part = (size_t)std::max(std::max(s->n_slices, s->dg_n_slabs), s->init_n_slabs);
     s->partial0 = dev_alloc<float>(n_part * s->n_pad * nt0 * 32);
     s->partial1 = dev_alloc<float>(n_part * s->n_pad * 3 * nt1 * 32);
     {
@@ -1934,7 +2073,7 @@ int jamun_sampler_create(const jamun_model* m, float sigma, const jamun_topology
         // in the T pre-pass
         // (mode 4, jamun_conv_mf.hip: 414 v_mfma_f32_32x32x16_f16 per (tile, k): 228 forming + 186 contraction)
         const int64_t per_tile_k = s->dg_mode == 4 ? 414LL * 32768 : s->dg_emu ? (150LL * 32768 + 72LL * 16384) : 476LL * 4096;
-        s->conv_flop_exec_launch = (int64_t)s->dg_n_tiles * per_tile_k * (hp.edge_attr_dim + 1);
+        s->conv_flop_exec_launch = (int64_t)(s->dg_n_tiles - s->n_tail_tiles) * per_tile_k * (hp.edge_attr_dim + 1);  // (tail tiles run in their own kernels)
         s->flop_exec += s->conv_flop_exec_launch + (int64_t)((s->n_atoms + 31) / 32) * (s->dg_emu ? 24LL * 32768 : 60LL * 4096) * (hp.edge_attr_dim + 1);
       }
       else if (L.sep.w2b) s->flop_exec += 3LL * 2 * (int64_t)N * 32 * ((s->S + 31) / 32) * 64 * 352;  // the per-edge weight GEMM as f16x3 (the rest is VALU work per edge)
@@ -2214,6 +2353,8 @@ int jamun_sampler_stats(jamun_sampler* s, jamun_stats* out, void* stream) {
     out->dg_row_blocks = s->dg_on && s->dg_row_blocks ? 1 : 0;
     out->dg_emu = s->dg_on ? s->dg_emu : -1;
     out->conv_flop_exec_launch = s->conv_flop_exec_launch;
+    out->n_tail_tiles = s->n_tail_tiles;
+    out->n_tail = s->n_tail;
     out->conv_flop_useful_launch = 0;
     out->conv_bytes_alg_launch = 0;
     if (s->dg_on && s->layers.size() > 1) {

@@ -1311,6 +1311,499 @@ __global__ __launch_bounds__(MF_THREADS) void k_conv_mfx(MfxArgs a) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------
+// Tail tiles.  A tile with FEW destinations (a 33-atom molecule cuts into 32 + 1) costs k_conv_mf a whole tile: 414 MFMAs per hidden unit
+// for one useful column of the forming GEMMs and one useful row of the contraction.  For such tiles the two halves separate:
+//   k_tail_form      one workgroup per tail tile: the forming GEMMs with the HIDDEN UNIT in the column index — column (d, kk) of a step
+//                    = destination d of the tile, hidden unit k0 + kk; 32 / ndp hidden units per step (ndp = destinations rounded up to a
+//                    power of two) — against the same resident x^T window: ceil(65 / KB) steps instead of 65.  All 23 formed tiles of a
+//                    column (scalar channels, dot, x1, cross — and x0 (x) v_m in place of the T pre-pass) are scaled, split and PARKED in
+//                    global memory in the A-fragment layout of the contraction (the accumulator layout of the forming MFMA).
+//   k_tail_contract  tail destinations of MANY molecules gathered 32 to a tile: the contraction alone, A fragments from the parked buffer,
+//                    weights from the same stream as k_conv_mf (scalar outputs) / a small stream of their own (vector outputs: x1, cross
+//                    and the x0 (x) v weights under one column scale); one output tile per wave, the hidden units cut into R runs = R
+//                    partial slabs for the node update.
+// Cost per tail destination: ~3 forming steps + 1/32 of a contraction tile, instead of 65 full steps: 33-atom molecules 2 tiles -> 1.03.
+template <int SPD>
+__global__ __launch_bounds__(MF_THREADS) void k_tail_form(TailArgs a) {
+  extern __shared__ float4 lds4[];
+  char* __restrict__ lds = reinterpret_cast<char*>(lds4);
+  const int L0 = lds_addr(lds);
+  int* __restrict__ deg_lds = reinterpret_cast<int*>(lds + MF_MISC);
+  unsigned* __restrict__ xmax_lds = reinterpret_cast<unsigned*>(lds + MF_MISC + 128);
+  const int tid = threadIdx.x, lane = tid & 63, wave = RFL(tid >> 6);
+  const int4 tt = a.tail_tiles[blockIdx.x];  // {tile index, first tail-destination index, 0, 0}
+  const int tile = RFL(tt.x), td0 = RFL(tt.y);
+  const int2 t_at = a.tile_atoms[tile], span = a.tile_span[tile];
+  const int n0 = RFL(t_at.x), n_dst = RFL(t_at.y);
+  const int s_lo = RFL(span.x), rows = RFL(span.y) - s_lo;
+  const int s_base = s_lo & ~1, off = s_lo - s_base;
+  const int ndp = n_dst <= 1 ? 1 : (n_dst <= 2 ? 2 : (n_dst <= 4 ? 4 : 8));
+  const int KB = 32 / ndp, kb_sh = ndp == 1 ? 5 : (ndp == 2 ? 4 : (ndp == 4 ? 3 : 2));  // hidden units per step = 1 << kb_sh
+  const int n_k = a.n_k, nsteps = (n_k + KB - 1) / KB;
+
+  // ---- prologue: zero the coefficient tiles, stage the span's rows transposed, scaled (channel factors, then the span's power of two)
+  // and split — as k_conv_mf, without its role split (this kernel's time does not matter)
+  for (int idx = tid; idx < 2 * MF_CB / 16; idx += MF_THREADS) reinterpret_cast<float4*>(lds + MF_C)[idx] = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (tid < 144) {
+    const int pl = tid / 72, q = tid - pl * 72;
+    *reinterpret_cast<float4*>(lds + (pl ? MF_X0L : MF_X0H) + 120 * MF_ROWB + 16 * q) = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  if (tid == 0) *xmax_lds = 0u;
+  if (tid < 32) deg_lds[tid] = tid < n_dst ? a.deg[n0 + tid] : 0;
+  float4 va[4], vb[4];
+  float mx = 0.f;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int item = tid + MF_THREADS * q, jp = item & 31, c4 = item >> 5;
+    va[q] = vb[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (c4 < 54) {
+      const int j0 = 2 * jp - off, j1 = j0 + 1;
+      const float4 g4 = reinterpret_cast<const float4*>(a.gx)[c4];
+      if (j0 >= 0 && j0 < rows) { const float4 v = reinterpret_cast<const float4*>(a.x + (size_t)(s_lo + j0) * a.XS)[c4]; va[q] = make_float4(v.x * g4.x, v.y * g4.y, v.z * g4.z, v.w * g4.w); }
+      if (j1 >= 0 && j1 < rows) { const float4 v = reinterpret_cast<const float4*>(a.x + (size_t)(s_lo + j1) * a.XS)[c4]; vb[q] = make_float4(v.x * g4.x, v.y * g4.y, v.z * g4.z, v.w * g4.w); }
+      mx = fmaxf(mx, fmaxf(fmaxf(fabsf(va[q].x), fabsf(va[q].y)), fmaxf(fabsf(va[q].z), fabsf(va[q].w))));
+      mx = fmaxf(mx, fmaxf(fmaxf(fabsf(vb[q].x), fabsf(vb[q].y)), fmaxf(fabsf(vb[q].z), fabsf(vb[q].w))));
+    }
+  }
+  LDS_BARRIER();
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+  if (lane == 0) atomicMax(xmax_lds, __float_as_uint(mx));
+  LDS_BARRIER();
+  const float xm = __uint_as_float(*xmax_lds);
+  const int sX = RFL(xm > 0.f ? clamp40(14 - exp_above(xm)) : 0);
+  {
+    const float scx = pow2f(sX);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int item = tid + MF_THREADS * q, jp = item & 31, c4 = item >> 5;
+      if (c4 < 54) {
+        const float ea[4] = {va[q].x, va[q].y, va[q].z, va[q].w}, eb[4] = {vb[q].x, vb[q].y, vb[q].z, vb[q].w};
+        const bool sc4 = c4 < 30;  // scalar channels 4 c4 .. (120 = 30 x 4), else vector elements 3 u + m -> row (m, u)
+        const int e1 = 4 * c4 - 120, u0 = e1 / 3, m0 = e1 - 3 * u0;
+        const int lo_off = sc4 ? (MF_X0L - MF_X0H) : (MF_X1L - MF_X1H);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int mm_ = m0 + e, wr = mm_ >= 3 ? 1 : 0;
+          const int rowb = sc4 ? MF_X0H + (4 * c4 + e) * MF_ROWB : MF_X1H + ((mm_ - 3 * wr) * 32 + u0 + wr) * MF_ROWB;
+          const float a0 = ea[e] * scx, b0 = eb[e] * scx;
+          const unsigned ph = cvt_pk_f16(a0, b0), pl = cvt_pk_f16(resid_lo(a0, ph), resid_hi(b0, ph));
+          *reinterpret_cast<unsigned*>(lds + rowb + 4 * jp) = ph;
+          *reinterpret_cast<unsigned*>(lds + rowb + lo_off + 4 * jp) = pl;
+        }
+      }
+    }
+  }
+  // ---- builder state (all eight waves): entry (column i, edge slot t); column i = (destination d = i >> kb_sh, hidden unit k0 + (i & (KB - 1)))
+  constexpr int BT = MF_THREADS, DPP = BT / SPD, NP = 32 / DPP;
+  const int gsh = (SPD == 32) ? 32 * (lane >> 5) : 0;
+  int ent[NP], slotv[NP];
+  float hv[NP], evx[NP], evy[NP], evz[NP];
+#pragma unroll
+  for (int p = 0; p < NP; ++p) {
+    const int g = tid + BT * p, i = g / SPD, t = g % SPD;
+    const int d = i >> kb_sh;
+    const int dg = d < n_dst ? deg_lds[d] : 0;
+    const bool in = d < n_dst && t < dg && t < a.S;
+    const int slot = (n0 + (d < n_dst ? d : 0)) * a.S + (t < a.S ? t : 0);
+    slotv[p] = slot;
+    const int sj = in ? a.esrc[slot] : 0;
+    float4 ge = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (in) ge = a.egeo[slot];
+    evx[p] = ge.x; evy[p] = ge.y; evz[p] = ge.z;
+    const bool bonded = in && sj < 0;
+    const int jraw = sj & 0x7fffffff, jl = jraw - s_base;
+    const bool valid = in && jl >= 0 && jl < 64;
+    bool active = valid;
+    int d0 = 0, d1 = 0;
+    const unsigned long long balb = __ballot(bonded);
+    const unsigned long long gmask = (SPD == 32) ? 0xffffffffull : ~0ull;
+    const int nb = __popcll((balb >> gsh) & gmask);
+    const int nb_max = RFL(SPD == 32 ? max(__popcll(balb & 0xffffffffull), __popcll(balb >> 32)) : __popcll(balb));
+    for (int b = 0; b < nb_max; ++b) {
+      const int lb = dg - nb + b;
+      const int jb = __shfl(jraw, (lb & (SPD - 1)) + gsh, 64);
+      const bool match = b < nb && valid && t < lb && jraw == jb;
+      const unsigned long long mb = (__ballot(match) >> gsh) & gmask;
+      if (b < nb && mb != 0ull) {
+        const int first = __ffsll((long long)mb) - 1;
+        if (t == lb) active = false;
+        if (t == first) {
+          if (d0 == 0) d0 = lb - t;
+          else if (d1 == 0) d1 = lb - t;
+          else atomicOr(a.err, 1);
+        }
+      }
+    }
+    ent[p] = active ? (i * MF_ROWB + 2 * jl) | (d0 << 13) | (d1 << 19) : 128;
+  }
+  auto load_k = [&](int st) {
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+      const int g = tid + BT * p, i = g / SPD;
+      const int k = (st << kb_sh) + (i & (KB - 1));
+      hv[p] = (st < nsteps && k < n_k) ? a.h[(size_t)k * a.h_kstride + slotv[p]] : 0.f;
+    }
+  };
+  const float scC = pow2f(a.sC);
+  auto coef = [&](int p) {
+    const int d0 = (ent[p] >> 13) & 63, d1 = (ent[p] >> 19) & 63;
+    const float t0 = __shfl(hv[p], lane + d0, 64), t1 = __shfl(hv[p], lane + d1, 64);
+    return (hv[p] + (d0 ? t0 : 0.f)) + (d1 ? t1 : 0.f);
+  };
+  auto build = [&](int buf) {
+    char* __restrict__ cbuf = lds + MF_C + buf * MF_CB;
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+      const float c0 = coef(p) * scC, c1 = c0 * evx[p], c2 = c0 * evy[p], c3 = c0 * evz[p];
+      const unsigned h01 = cvt_pk_f16(c0, c1), h23 = cvt_pk_f16(c2, c3);
+      const unsigned l01 = cvt_pk_f16(resid_lo(c0, h01), resid_hi(c1, h01)), l23 = cvt_pk_f16(resid_lo(c2, h23), resid_hi(c3, h23));
+      char* __restrict__ d = cbuf + (ent[p] & 0x1fff);
+      *reinterpret_cast<unsigned short*>(d) = (unsigned short)(h01 & 0xffffu);
+      *reinterpret_cast<unsigned short*>(d + MF_PL) = (unsigned short)(l01 & 0xffffu);
+      *reinterpret_cast<unsigned short*>(d + 2 * MF_PL) = (unsigned short)(h01 >> 16);
+      *reinterpret_cast<unsigned short*>(d + 3 * MF_PL) = (unsigned short)(l01 >> 16);
+      *reinterpret_cast<unsigned short*>(d + 4 * MF_PL) = (unsigned short)(h23 & 0xffffu);
+      *reinterpret_cast<unsigned short*>(d + 5 * MF_PL) = (unsigned short)(l23 & 0xffffu);
+      *reinterpret_cast<unsigned short*>(d + 6 * MF_PL) = (unsigned short)(h23 >> 16);
+      *reinterpret_cast<unsigned short*>(d + 7 * MF_PL) = (unsigned short)(l23 >> 16);
+    }
+  };
+  load_k(0);
+  build(0);
+  load_k(1);
+  LDS_BARRIER();  // x rows, C(step 0)
+
+  // ---- forming, one step = 32 columns; this lane: column c = lane & 31 = (destination dc, hidden-unit offset kkc)
+  const int r = lane & 31, hh = lane >> 5;
+  const int dc = r >> kb_sh, kkc = r & (KB - 1);
+  const int edeg_c = (dc < n_dst && deg_lds[dc] > 0) ? exp_above((float)deg_lds[dc]) : 1;
+  const float rs = pow2f(-14 - edeg_c);
+  const int fo = r * MF_ROWB + 16 * hh + L0;
+  if (kkc == 0 && hh == 0 && dc < n_dst) a.tail_scale[td0 + dc] = pow2f(clamp100(-(sX + a.sC)));
+  const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  // F (+ optional second tile to subtract) -> scaled, split, parked as formed tile `ft` of (tail destination td0 + dc, hidden unit k)
+  auto park = [&](const f32x16& F, int ft, int k) {
+    if (dc >= n_dst || k >= n_k) return;
+    // parked layout [hidden unit][tile of 32 tail destinations][formed tile][K-step][row][lane half][hi, lo] x 16 B: what a wave of the
+    // contraction reads for one (k, formed tile, K-step) is 2 KB contiguous
+    const int tdc = td0 + dc, n_ct = (a.n_tail + 31) >> 5;
+    float4* __restrict__ dst = a.P + (((((size_t)k * n_ct + (tdc >> 5)) * TAIL_NFT + ft) * 2) * 32 + (tdc & 31)) * 4 + 2 * hh;
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+      unsigned ph[4], pl[4];
+#pragma unroll
+      for (int p2 = 0; p2 < 4; ++p2) {
+        const float v0 = F[8 * s2 + 2 * p2] * rs, v1 = F[8 * s2 + 2 * p2 + 1] * rs;
+        ph[p2] = cvt_pk_f16(v0, v1);
+        pl[p2] = cvt_pk_f16(resid_lo(v0, ph[p2]), resid_hi(v1, ph[p2]));
+      }
+      dst[128 * s2] = make_float4(__uint_as_float(ph[0]), __uint_as_float(ph[1]), __uint_as_float(ph[2]), __uint_as_float(ph[3]));
+      dst[128 * s2 + 1] = make_float4(__uint_as_float(pl[0]), __uint_as_float(pl[1]), __uint_as_float(pl[2]), __uint_as_float(pl[3]));
+    }
+  };
+  auto form = [&](int xa, int xlo, int ca) {  // one 32 x 32 tile: 4 K-steps of 16 source rows
+    f32x16 F = zero16;
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) {
+      const float4 ah = lds_f4(xa + 32 * s4), al = lds_f4(xa + xlo + 32 * s4), bh = lds_f4(ca + 32 * s4), bl = lds_f4(ca + MF_PL + 32 * s4);
+      M3(F, ah, al, bh, bl);
+    }
+    return F;
+  };
+  for (int st = 0; st < nsteps; ++st) {
+    const int k = (st << kb_sh) + kkc;
+    const int cb = MF_C + (st & 1) * MF_CB + fo;
+    if (wave < 4) {  // scalar channels 32 w ..: with the plain coefficients (formed tile w) and with each component of v (x0 (x) v_m: 11 + 3 w + m)
+      const int xa = MF_X0H + 32 * wave * MF_ROWB + fo;
+      park(form(xa, MF_X0L - MF_X0H, cb), wave, k);
+#pragma unroll
+      for (int m = 0; m < 3; ++m) park(form(xa, MF_X0L - MF_X0H, cb + (1 + m) * 2 * MF_PL), 11 + 3 * wave + m, k);
+    } else if (wave == 4) {  // dot(x1, v)
+      f32x16 F = zero16;
+#pragma unroll
+      for (int m = 0; m < 3; ++m)
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) {
+          const int xa = MF_X1H + m * 32 * MF_ROWB + fo + 32 * s4, ca = cb + (1 + m) * 2 * MF_PL + 32 * s4;
+          const float4 ah = lds_f4(xa), al = lds_f4(xa + (MF_X1L - MF_X1H)), bh = lds_f4(ca), bl = lds_f4(ca + MF_PL);
+          M3(F, ah, al, bh, bl);
+        }
+      park(F, 4, k);
+    } else {  // plane m: x1[m]; (x1 x v)[m] = x1[m+1] v[m+2] - x1[m+2] v[m+1]
+      const int m = wave - 5, m1 = (m + 1) % 3, m2 = (m + 2) % 3;
+      const int x1a = MF_X1H + fo;
+      park(form(x1a + m * 32 * MF_ROWB, MF_X1L - MF_X1H, cb), 5 + 2 * m, k);
+      const f32x16 F1 = form(x1a + m1 * 32 * MF_ROWB, MF_X1L - MF_X1H, cb + (1 + m2) * 2 * MF_PL);
+      const f32x16 F2 = form(x1a + m2 * 32 * MF_ROWB, MF_X1L - MF_X1H, cb + (1 + m1) * 2 * MF_PL);
+      f32x16 Fc;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) Fc[q] = F1[q] - F2[q];
+      park(Fc, 6 + 2 * m, k);
+    }
+    build((st + 1) & 1);  // (after the last step: the unused buffer, from zeros)
+    load_k(st + 2);
+    LDS_BARRIER();
+  }
+}
+
+// The same for the INITIAL projector (the scheme of k_conv_mfx: 64 scalar channels of the noise-scaled embedding, stored split): formed
+// tile 2 c + t = coefficient component c (0: scalar outputs, 1 + m: vector plane m) x channel tile t; wave = formed tile.
+template <int SPD>
+__global__ __launch_bounds__(MF_THREADS) void k_tail_form_init(TailArgs a) {
+  extern __shared__ float4 lds4[];
+  char* __restrict__ lds = reinterpret_cast<char*>(lds4);
+  const int L0 = lds_addr(lds);
+  constexpr int X_H = 0, X_L = 64 * MF_ROWB, X_C = 2 * 64 * MF_ROWB, X_MISC = X_C + 2 * MF_CB;
+  int* __restrict__ deg_lds = reinterpret_cast<int*>(lds + X_MISC);
+  const int tid = threadIdx.x, lane = tid & 63, wave = RFL(tid >> 6);
+  const int4 tt = a.tail_tiles[blockIdx.x];
+  const int tile = RFL(tt.x), td0 = RFL(tt.y);
+  const int2 t_at = a.tile_atoms[tile], span = a.tile_span[tile];
+  const int n0 = RFL(t_at.x), n_dst = RFL(t_at.y);
+  const int s_base = RFL(span.x) & ~1;
+  const int ndp = n_dst <= 1 ? 1 : (n_dst <= 2 ? 2 : (n_dst <= 4 ? 4 : 8));
+  const int KB = 32 / ndp, kb_sh = ndp == 1 ? 5 : (ndp == 2 ? 4 : (ndp == 4 ? 3 : 2));
+  const int n_k = a.n_k, nsteps = (n_k + KB - 1) / KB;
+  for (int idx = tid; idx < 2 * MF_CB / 16; idx += MF_THREADS) reinterpret_cast<float4*>(lds + X_C)[idx] = make_float4(0.f, 0.f, 0.f, 0.f);
+  {
+    const unsigned* __restrict__ ph = a.xph + (size_t)(s_base >> 1) * 64;
+    const unsigned* __restrict__ pl = a.xpl + (size_t)(s_base >> 1) * 64;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int idx = tid + MF_THREADS * q, ch = idx & 63, jp = idx >> 6;
+      *reinterpret_cast<unsigned*>(lds + X_H + ch * MF_ROWB + 4 * jp) = ph[idx];
+      *reinterpret_cast<unsigned*>(lds + X_L + ch * MF_ROWB + 4 * jp) = pl[idx];
+    }
+  }
+  if (tid < 32) deg_lds[tid] = tid < n_dst ? a.deg[n0 + tid] : 0;
+  LDS_BARRIER();
+  constexpr int BT = MF_THREADS, DPP = BT / SPD, NP = 32 / DPP;
+  const int gsh = (SPD == 32) ? 32 * (lane >> 5) : 0;
+  int ent[NP], slotv[NP];
+  float hv[NP], evx[NP], evy[NP], evz[NP];
+#pragma unroll
+  for (int p = 0; p < NP; ++p) {
+    const int g = tid + BT * p, i = g / SPD, t = g % SPD;
+    const int d = i >> kb_sh;
+    const int dg = d < n_dst ? deg_lds[d] : 0;
+    const bool in = d < n_dst && t < dg && t < a.S;
+    const int slot = (n0 + (d < n_dst ? d : 0)) * a.S + (t < a.S ? t : 0);
+    slotv[p] = slot;
+    const int sj = in ? a.esrc[slot] : 0;
+    float4 ge = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (in) ge = a.egeo[slot];
+    evx[p] = ge.x; evy[p] = ge.y; evz[p] = ge.z;
+    const bool bonded = in && sj < 0;
+    const int jraw = sj & 0x7fffffff, jl = jraw - s_base;
+    const bool valid = in && jl >= 0 && jl < 64;
+    bool active = valid;
+    int d0 = 0, d1 = 0;
+    const unsigned long long balb = __ballot(bonded);
+    const unsigned long long gmask = (SPD == 32) ? 0xffffffffull : ~0ull;
+    const int nb = __popcll((balb >> gsh) & gmask);
+    const int nb_max = RFL(SPD == 32 ? max(__popcll(balb & 0xffffffffull), __popcll(balb >> 32)) : __popcll(balb));
+    for (int b = 0; b < nb_max; ++b) {
+      const int lb = dg - nb + b;
+      const int jb = __shfl(jraw, (lb & (SPD - 1)) + gsh, 64);
+      const bool match = b < nb && valid && t < lb && jraw == jb;
+      const unsigned long long mb = (__ballot(match) >> gsh) & gmask;
+      if (b < nb && mb != 0ull) {
+        const int first = __ffsll((long long)mb) - 1;
+        if (t == lb) active = false;
+        if (t == first) {
+          if (d0 == 0) d0 = lb - t;
+          else if (d1 == 0) d1 = lb - t;
+          else atomicOr(a.err, 1);
+        }
+      }
+    }
+    ent[p] = active ? (i * MF_ROWB + 2 * jl) | (d0 << 13) | (d1 << 19) : 128;
+  }
+  auto load_k = [&](int st) {
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+      const int g = tid + BT * p, i = g / SPD;
+      const int k = (st << kb_sh) + (i & (KB - 1));
+      hv[p] = (st < nsteps && k < n_k) ? a.h[(size_t)k * a.h_kstride + slotv[p]] : 0.f;
+    }
+  };
+  const float scC = pow2f(a.sC);
+  auto coef = [&](int p) {
+    const int d0 = (ent[p] >> 13) & 63, d1 = (ent[p] >> 19) & 63;
+    const float t0 = __shfl(hv[p], lane + d0, 64), t1 = __shfl(hv[p], lane + d1, 64);
+    return (hv[p] + (d0 ? t0 : 0.f)) + (d1 ? t1 : 0.f);
+  };
+  auto build = [&](int buf) {
+    char* __restrict__ cbuf = lds + X_C + buf * MF_CB;
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+      const float c0 = coef(p) * scC, c1 = c0 * evx[p], c2 = c0 * evy[p], c3 = c0 * evz[p];
+      const unsigned h01 = cvt_pk_f16(c0, c1), h23 = cvt_pk_f16(c2, c3);
+      const unsigned l01 = cvt_pk_f16(resid_lo(c0, h01), resid_hi(c1, h01)), l23 = cvt_pk_f16(resid_lo(c2, h23), resid_hi(c3, h23));
+      char* __restrict__ d = cbuf + (ent[p] & 0x1fff);
+      *reinterpret_cast<unsigned short*>(d) = (unsigned short)(h01 & 0xffffu);
+      *reinterpret_cast<unsigned short*>(d + MF_PL) = (unsigned short)(l01 & 0xffffu);
+      *reinterpret_cast<unsigned short*>(d + 2 * MF_PL) = (unsigned short)(h01 >> 16);
+      *reinterpret_cast<unsigned short*>(d + 3 * MF_PL) = (unsigned short)(l01 >> 16);
+      *reinterpret_cast<unsigned short*>(d + 4 * MF_PL) = (unsigned short)(h23 & 0xffffu);
+      *reinterpret_cast<unsigned short*>(d + 5 * MF_PL) = (unsigned short)(l23 & 0xffffu);
+      *reinterpret_cast<unsigned short*>(d + 6 * MF_PL) = (unsigned short)(h23 >> 16);
+      *reinterpret_cast<unsigned short*>(d + 7 * MF_PL) = (unsigned short)(l23 >> 16);
+    }
+  };
+  load_k(0);
+  build(0);
+  load_k(1);
+  LDS_BARRIER();
+  const int r = lane & 31, hh = lane >> 5;
+  const int dc = r >> kb_sh, kkc = r & (KB - 1);
+  const int edeg_c = (dc < n_dst && deg_lds[dc] > 0) ? exp_above((float)deg_lds[dc]) : 1;
+  const float rs = pow2f(-14 - edeg_c);
+  const int fo = r * MF_ROWB + 16 * hh + L0;
+  if (kkc == 0 && hh == 0 && dc < n_dst) a.tail_scale[td0 + dc] = pow2f(clamp100(-(a.sX + a.sC)));
+  const int comp = wave >> 1, ct = wave & 1;
+  float4 xh[4], xl[4];
+#pragma unroll
+  for (int s4 = 0; s4 < 4; ++s4) { xh[s4] = lds_f4(X_H + 32 * ct * MF_ROWB + fo + 32 * s4); xl[s4] = lds_f4(X_L + 32 * ct * MF_ROWB + fo + 32 * s4); }
+  const int n_ct = (a.n_tail + 31) >> 5;
+  for (int st = 0; st < nsteps; ++st) {
+    const int k = (st << kb_sh) + kkc;
+    const int cb = X_C + (st & 1) * MF_CB + comp * 2 * MF_PL + fo;
+    f32x16 F;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) F[q] = 0.f;
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) {
+      const float4 bh = lds_f4(cb + 32 * s4), bl = lds_f4(cb + MF_PL + 32 * s4);
+      M3(F, xh[s4], xl[s4], bh, bl);
+    }
+    if (dc < n_dst && k < n_k) {
+      const int tdc = td0 + dc;
+      float4* __restrict__ dst = a.P + (((((size_t)k * n_ct + (tdc >> 5)) * TAIL_NFT_INIT + wave) * 2) * 32 + (tdc & 31)) * 4 + 2 * hh;
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        unsigned ph[4], pl[4];
+#pragma unroll
+        for (int p2 = 0; p2 < 4; ++p2) {
+          const float v0 = F[8 * s2 + 2 * p2] * rs, v1 = F[8 * s2 + 2 * p2 + 1] * rs;
+          ph[p2] = cvt_pk_f16(v0, v1);
+          pl[p2] = cvt_pk_f16(resid_lo(v0, ph[p2]), resid_hi(v1, ph[p2]));
+        }
+        dst[128 * s2] = make_float4(__uint_as_float(ph[0]), __uint_as_float(ph[1]), __uint_as_float(ph[2]), __uint_as_float(ph[3]));
+        dst[128 * s2 + 1] = make_float4(__uint_as_float(pl[0]), __uint_as_float(pl[1]), __uint_as_float(pl[2]), __uint_as_float(pl[3]));
+      }
+    }
+    build((st + 1) & 1);
+    load_k(st + 2);
+    LDS_BARRIER();
+  }
+}
+
+// The contraction of 32 gathered tail destinations: one workgroup per (tile of 32 tail destinations, run of hidden units, output job) —
+// job n < 5: scalar-output tile n (K = the five scalar formed tiles), job 5 + m: vector plane m (x1[m], cross[m], x0 (x) v_m: six formed
+// tiles).  The run's hidden units are dealt to the EIGHT WAVES (wave w: k_lo + w, + 8, ...), every wave accumulating its own 32 x 32 tile
+// with all loads of a hidden unit in flight at once; the eight partial tiles are summed through LDS in wave order: one partial slab per
+// run for the node update.
+template <bool INIT>  // INIT: the initial projector (formed tiles 2 c + t of k_tail_form_init, weight stream of k_conv_mfx)
+__global__ __launch_bounds__(MF_THREADS) void k_tail_contract(TailArgs a) {
+  __shared__ float red[8][32][33];
+  constexpr int NFT = INIT ? TAIL_NFT_INIT : TAIL_NFT;
+  const int tid = threadIdx.x, lane = tid & 63, wave = RFL(tid >> 6);
+  const int r = lane & 31, hh = lane >> 5;
+  const int job = blockIdx.x & 7, cr = blockIdx.x >> 3;
+  const int ctile = cr / a.n_runs, run = cr - ctile * a.n_runs;
+  const int k_lo = (run * a.n_k) / a.n_runs, k_hi = ((run + 1) * a.n_k) / a.n_runs;
+  const int n_ct = (a.n_tail + 31) >> 5;
+  f32x16 acc;
+#pragma unroll
+  for (int q = 0; q < 16; ++q) acc[q] = 0.f;
+  // A fragments of (hidden unit k, formed tile ft, K-step s2): row = this lane's tail destination
+  auto aptr = [&](int k, int ft, int s2) { return a.P + ((((((size_t)k * n_ct + ctile) * NFT + ft) * 2 + s2) * 32 + r) * 4 + 2 * hh); };
+  if constexpr (INIT) {
+    // scalar outputs: formed tiles t = 0, 1 (component 0), blocks 20 t + 2 (2 n + s2); plane m: formed tiles 2 (1 + m) + t, blocks 40 + 4 t + 2 s2
+    for (int k = k_lo + wave; k < k_hi; k += 8) {
+      const float4* __restrict__ wk = a.wx + (size_t)k * 48 * 64 + lane;
+      float4 ah[4], al[4], bh[4], bl[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {  // (t, s2) = (i >> 1, i & 1)
+        const int t = i >> 1, s2 = i & 1;
+        const float4* __restrict__ p = aptr(k, job < 5 ? t : 2 * (job - 4) + t, s2);
+        ah[i] = p[0]; al[i] = p[1];
+        const int blk = job < 5 ? 20 * t + 2 * (2 * job + s2) : 40 + 4 * t + 2 * s2;
+        bh[i] = wk[blk * 64]; bl[i] = wk[(blk + 1) * 64];
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { M3(acc, ah[i], al[i], bh[i], bl[i]); }
+    }
+  } else if (job < 5) {
+    const int n = job;
+    for (int k = k_lo + wave; k < k_hi; k += 8) {
+      const float4* __restrict__ wk = a.wm + (size_t)k * 124 * 64 + lane;
+      float4 ah[10], al[10], bh[10], bl[10];
+#pragma unroll
+      for (int i = 0; i < 10; ++i) {  // (w, s2) = (i >> 1, i & 1)
+        const float4* __restrict__ p = aptr(k, i >> 1, i & 1);
+        ah[i] = p[0]; al[i] = p[1];
+        bh[i] = wk[(20 * (i >> 1) + 2 * (2 * n + (i & 1))) * 64]; bl[i] = wk[(20 * (i >> 1) + 2 * (2 * n + (i & 1)) + 1) * 64];
+      }
+#pragma unroll
+      for (int i = 0; i < 10; ++i) { M3(acc, ah[i], al[i], bh[i], bl[i]); }
+    }
+  } else {
+    const int m = job - 5;
+    for (int k = k_lo + wave; k < k_hi; k += 8) {
+      const float4* __restrict__ wk = a.wmt + (size_t)k * 24 * 64 + lane;
+      float4 ah[12], al[12], bh[12], bl[12];
+#pragma unroll
+      for (int i = 0; i < 12; ++i) {  // (g, s2) = (i >> 1, i & 1): x1[m], cross[m], then x0 (x) v_m of the four scalar channel tiles
+        const int g = i >> 1, ft = g == 0 ? 5 + 2 * m : (g == 1 ? 6 + 2 * m : 11 + 3 * (g - 2) + m);
+        const float4* __restrict__ p = aptr(k, ft, i & 1);
+        ah[i] = p[0]; al[i] = p[1];
+        bh[i] = wk[(4 * g + 2 * (i & 1)) * 64]; bl[i] = wk[(4 * g + 2 * (i & 1) + 1) * 64];
+      }
+#pragma unroll
+      for (int i = 0; i < 12; ++i) { M3(acc, ah[i], al[i], bh[i], bl[i]); }
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < 16; ++q) red[wave][(q & 3) + 8 * (q >> 2) + 4 * hh][r] = acc[q];
+  __syncthreads();
+  // rows carry 2^(sX + sC - 14 - e(in-degree)) (tail_scale holds 2^-(sX + sC)), columns the weights' 2^sB_w
+  for (int idx = tid; idx < 32 * 32; idx += MF_THREADS) {
+    const int row = idx >> 5, col = idx & 31, t2 = 32 * ctile + row;
+    if (t2 >= a.n_tail) continue;
+    float v = red[0][row][col];
+#pragma unroll
+    for (int w = 1; w < 8; ++w) v += red[w][row][col];
+    const int atom = a.tail_atom[t2];
+    const int dg = a.deg[atom];
+    const int edeg = dg > 0 ? exp_above((float)dg) : 1;
+    const float cf = job < 5 ? a.cf0[32 * job + col] : a.cf1t[col];  // (INIT: the column factors of k_conv_mfx's weights)
+    v = ((v * a.tail_scale[t2]) * pow2f(14 + edeg)) * cf;
+    if (job < 5) a.partial0[((size_t)run * a.n_pad + atom) * (size_t)(a.nt0 * 32) + 32 * job + col] = v;
+    else a.partial1[((size_t)run * a.n_pad + atom) * 96 + (job - 5) * 32 + col] = v;
+  }
+}
+
+int launch_conv_tail(const TailArgs& a, hipStream_t st) {
+  if (a.XS != 216 || a.nt0 != 5 || a.S > 64 || a.n_tail_tiles < 1) return -1;
+  if (a.S <= 32) hipLaunchKernelGGL((k_tail_form<32>), dim3(a.n_tail_tiles), dim3(MF_THREADS), MF_LDS_BYTES, st, a);
+  else hipLaunchKernelGGL((k_tail_form<64>), dim3(a.n_tail_tiles), dim3(MF_THREADS), MF_LDS_BYTES, st, a);
+  hipLaunchKernelGGL(k_tail_contract<false>, dim3(((a.n_tail + 31) / 32) * a.n_runs * 8), dim3(MF_THREADS), 0, st, a);
+  return 0;
+}
+
+int launch_conv_tail_init(const TailArgs& a, hipStream_t st) {
+  if (a.nt0 != 5 || a.S > 64 || a.n_tail_tiles < 1) return -1;
+  const size_t smem = 2 * 64 * MF_ROWB + 2 * MF_CB + 144;
+  if (a.S <= 32) hipLaunchKernelGGL((k_tail_form_init<32>), dim3(a.n_tail_tiles), dim3(MF_THREADS), smem, st, a);
+  else hipLaunchKernelGGL((k_tail_form_init<64>), dim3(a.n_tail_tiles), dim3(MF_THREADS), smem, st, a);
+  hipLaunchKernelGGL(k_tail_contract<true>, dim3(((a.n_tail + 31) / 32) * a.n_runs * 8), dim3(MF_THREADS), 0, st, a);
+  return 0;
+}
+
 void conv_mf_print_stamps() {
 #ifdef MF_TRACE
   static unsigned long long tr[8][40][8];
@@ -1369,6 +1862,9 @@ int launch_conv_mfx(const MfxArgs& a, int grid, hipStream_t st) {
 }
 
 int conv_mf_set_max_lds() {
+  const void* ft[4] = {(const void*)k_tail_form<32>, (const void*)k_tail_form<64>, (const void*)k_tail_form_init<32>, (const void*)k_tail_form_init<64>};
+  for (const void* f : ft)
+    if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, JAMUN_MAX_DYN_LDS) != hipSuccess) return -1;
   const void* fx[2] = {(const void*)k_conv_mfx<32>, (const void*)k_conv_mfx<64>};
   for (const void* f : fx)
     if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, JAMUN_MAX_DYN_LDS) != hipSuccess) return -1;

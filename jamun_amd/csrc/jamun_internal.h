@@ -137,6 +137,45 @@ struct MfiArgs {
   int* err;
 };
 
+// tail tiles of k_conv_mf (k_tail_form + k_tail_contract in jamun_conv_mf.hip): tiles with few destinations, formed with the hidden unit in
+// the column index, parked, and contracted 32 gathered destinations at a time
+#define TAIL_NFT 23  // formed tiles of 32 channels per (destination, hidden unit): 0..3 scalar channels, 4 dot, 5 + 2 m x1[m], 6 + 2 m cross[m],
+                     // 11 + 3 w + m scalar channels 32 w .. times v_m (in place of the T pre-pass)
+#define TAIL_NFT_INIT 8  // initial projector: formed tile 2 c + t (coefficient component c, channel tile t of the 64 embedding channels)
+struct TailArgs {
+  const int* deg;
+  const int* esrc;
+  const float4* egeo;
+  const float* h;  // [hidden unit k][h_kstride]
+  size_t h_kstride;
+  const float* x;  // [n_atoms][XS = 216]
+  int n_pad, S, XS, n_k, nt0;
+  const int2* tile_span;   // the tile arrays of k_conv_mf
+  const int2* tile_atoms;
+  const int4* tail_tiles;  // [n_tail_tiles] {tile, index of its first tail destination, 0, 0}
+  int n_tail_tiles, n_tail, n_runs;  // tail tiles, tail destinations, runs of hidden units (= partial slabs) of the contraction
+  const int* tail_atom;    // [n_tail] atom of each tail destination
+  float* tail_scale;       // [n_tail] 2^-(sX + sC) of the destination's forming (work buffer)
+  float4* P;               // parked operands [n_k][tiles of 32 tail destinations][TAIL_NFT][2 K-steps][32 rows][2 lane halves][hi, lo] x 16 B (work buffer)
+  const float* gx;         // channel factors of the staged rows (MfArgs::gx)
+  int sC;
+  const float4* wm;        // the weight stream of k_conv_mf (scalar outputs: blocks 20 w + 2 (2 n + s2) + {hi, lo})
+  const float4* wmt;       // [k][24 blocks] vector outputs under one column scale: x1 (4 blocks: 2 s2 + {hi, lo}), cross (4), x0 (x) v of the
+                           // four scalar channel tiles (8 + 4 w + 2 s2 + {hi, lo}); the same for the three planes
+  const float *cf0, *cf1t; // inverse column scales: scalar outputs (as MfArgs::cf0), vector outputs of wmt
+  // initial projector (k_tail_form_init, k_tail_contract<true>): the split embedding rows and weight stream of k_conv_mfx (MfxArgs), its
+  // static row scale; cf0 / cf1t then hold MfxArgs::cf0 / cf1
+  const unsigned* xph;
+  const unsigned* xpl;
+  const float4* wx;
+  int sX;
+  float* partial0;
+  float* partial1;
+  int* err;
+};
+int launch_conv_tail(const TailArgs& a, hipStream_t st);
+int launch_conv_tail_init(const TailArgs& a, hipStream_t st);
+
 // initial projector formed from the feature rows (k_conv_mfx in jamun_conv_mf.hip): batches with many distinct embedding rows
 struct MfxArgs {
   const int* deg;

@@ -404,6 +404,55 @@ def test_tiled_and_general_conv_agree_on_random_ragged_batches(dev, seed, monkey
                 assert (a - b).abs().max().item() <= 2e-5 * max(b.abs().max().item(), 1e-6), (trial, l)
 
 
+@pytest.mark.parametrize("case", ["chain33x4", "tails_1_to_8", "doubled_bonds"])
+def test_tail_tiles_of_the_matrix_formed_conv(dev, golden_dir, case, monkeypatch):
+    """Tiles of k_conv_mf with few destinations (a 33-atom molecule cuts into 32 + 1) go through k_tail_form / k_tail_contract: formed with
+    the hidden unit in the column index, parked, contracted 32 gathered destinations at a time.  Against the oracle (33-atom fixture),
+    against the same tiles run as whole tiles (jamun_tuning.no_tail) and against the general kernel; tail sizes 1..8 (every
+    columns-per-step variant), edge strides above 32, bonds listed twice in both directions (three edges per pair)."""
+    from jamun_amd import synth
+    from jamun_amd.data import WalkerBatch
+    from jamun_amd.model import Denoiser
+    from jamun_amd.native import NativeSampler
+
+    model = Denoiser.from_checkpoint_dict(_ckpt("strong")).to(dev)
+    ref = None
+    if case == "chain33x4":
+        mols = _mols("chain33x4")
+        ref = _golden(golden_dir, "oracle_forward_chain33x4")
+    elif case == "tails_1_to_8":
+        mols = [synth.random_chain(n, seed=50 + i) for i, n in enumerate([33, 34, 35, 36, 37, 38, 39, 40, 17, 33, 9, 40, 36])]
+    else:
+        mols = []
+        for i, n in enumerate([33, 35, 34, 33, 40]):
+            m = synth.random_chain(n, seed=70 + i)
+            b = m["bonds"]
+            m["bonds"] = torch.cat([b, b, b.flip(0), b.flip(0)], dim=1)
+            mols.append(m)
+    batch = WalkerBatch.from_molecules(mols).to(dev)
+    if ref is not None:
+        y = ref["y"].to(dev)
+    else:
+        torch.manual_seed(11)
+        y = batch.pos + 0.04 * torch.randn(batch.pos.shape).to(dev)
+    tails = NativeSampler(model._native, 0.04, batch, dev)
+    whole = NativeSampler(model._native, 0.04, batch, dev, tuning={"no_tail": 1})
+    general = NativeSampler(model._native, 0.04, batch, dev, tuning={"no_dg": 1})
+    assert tails.stats()["dg_mode"] == 4 and whole.stats()["dg_mode"] == 4 and general.stats()["conv_path"] == 0
+    assert tails.stats()["n_tail_tiles"] >= 4 and whole.stats()["n_tail_tiles"] == 0
+    xt, xw, xg = tails.xhat(y), whole.xhat(y), general.xhat(y)
+    assert torch.isfinite(xt).all()
+    assert rmsd(xt, xg) <= RMSD_TOL_NM and rmsd(xw, xg) <= RMSD_TOL_NM, (rmsd(xt, xg), rmsd(xw, xg))
+    assert torch.equal(tails.xhat(y), xt)  # bit-reproducible
+    if ref is not None:
+        assert rmsd(xt, ref["xhat"]) <= RMSD_TOL_NM
+    for l in range(6):
+        b = general.debug_read(0, l).cpu()
+        for other in (tails, whole):
+            a = other.debug_read(0, l).cpu()
+            assert (a - b).abs().max().item() <= 2e-5 * max(b.abs().max().item(), 1e-6), (case, l)
+
+
 @pytest.mark.parametrize("case", ["span62", "single62", "odd_start", "double_bonds", "rows100", "many_rows"])
 def test_matrix_formed_conv_edge_cases(dev, case, monkeypatch):
     """k_conv_mf / k_conv_mfi (jamun_conv_mf.hip) against the general kernel on the shapes that stress their bookkeeping: a tile span of
