@@ -458,7 +458,18 @@ def main():
                 **({"arch": "SeparableConv (e3conv_separable.yaml) — NOT the metric's architecture"} if args.separable else {}),
             },
         }
-        if prof is not None:
+        if prof is not None and args.separable:
+            # SeparableConv: per-edge weights, per-destination sums and the point-wise Linear in two launches (k_sep_fused + k_sep_linear);
+            # no big contraction: the layer is bound by memory traffic / latency, priced against the HBM roof
+            ms0, c0 = prof["conv0"]
+            avg0 = ms0 / max(c0, 1)
+            nbytes = stats.get("conv_bytes_alg_launch", 0)
+            out["roofline"] = {"kernel": "k_sep_fused + k_sep_linear (SeparableConv hidden layer: depth-wise weights formed and consumed in registers, per-destination sums, point-wise Linear)",
+                               "bound": "hbm", "achieved": nbytes / (avg0 * 1e-3) / 1e9 if avg0 > 0 else 0.0, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                               "frac": nbytes / (avg0 * 1e-3) / 1e9 / HBM_PEAK_GBS if avg0 > 0 else 0.0, "traffic": None, "avg_launch_ms": avg0, "launches": c0,
+                               "bytes_algorithmic_per_launch": nbytes,
+                               "note": "both launches of a hidden layer timed together; algorithmic bytes = h~ of the layer + one feature row per edge + the per-destination sums written and read + slab + weights"}
+        elif prof is not None:
             ms0, c0 = prof["conv0"]
             ms1, c1 = prof["conv1"]
             mst, ct = prof_all.get("tprod", (0.0, 0)) if prof_all is not None else (0.0, 0)  # (T pre-pass: from the separate untimed pass)
@@ -514,13 +525,13 @@ def main():
             # HBM-side bytes per launch from the committed PMC passes of the cfg2 command (profiles/collect.sh); rocprofv3
             # cannot run inside the timed process, so the newest committed summary is quoted, with its file name
             if args.atoms is None and args.walkers is None and not args.strong:
-                tr = _pmc_traffic(("k_conv_mf<" if stats.get("dg_mode") == 4 else "k_conv_dg<") if stats["conv_path"] == 2 else
-                                  {1: "k_conv_fused"}.get(stats["conv_path"], "k_conv<"), args.config)
+                tr = _pmc_traffic(("k_conv_mf<" if stats.get("dg_mode") == 4 else "k_conv_dg<") if stats["conv_path"] == 2 else "k_conv<", args.config)
                 if tr is not None:
                     out["roofline"]["traffic"] = tr[0]
                     out["roofline"]["traffic_source"] = tr[1]
                     if out["roofline"].get("bytes_algorithmic_per_launch"):
                         out["roofline"]["traffic_ratio"] = tr[0] / out["roofline"]["bytes_algorithmic_per_launch"]
+        if prof is not None:
             if prof_all is not None:  # separate untimed pass (see above)
                 tot = sum(ms for ms, _ in prof_all.values())
                 out["kernel_time_share"] = {k: round(ms / tot, 4) for k, (ms, _) in prof_all.items()} if tot > 0 else {}
@@ -528,6 +539,8 @@ def main():
                 out["kernel_breakdown_source"] = f"separate untimed pass of {min(args.steps, 5)} steps with every launch bracketed by HIP events"
             # the reference-association FLOP rate, for comparison with SURVEY.md section 8(d) (not a roofline fraction)
             out["config"]["ref_association_tflops_equiv"] = stats["flop_ref_assoc"] * args.steps / dt_med / 1e12
+            if stats.get("n_tail_tiles"):
+                out["config"]["tail_tiles"] = f"{stats['n_tail_tiles']} tiles / {stats['n_tail']} destinations through k_tail_form + k_tail_contract (kernel class conv1)"
         if not args.no_secondary and world == 1:
             del y_traj, score_traj, xhat_traj
             out["secondary_rooflines"] = secondary_rooflines(dev)

@@ -2360,7 +2360,8 @@ int jamun_sampler_stats(jamun_sampler* s, jamun_stats* out, void* stream) {
     if (s->dg_on && s->layers.size() > 1) {
       const int64_t m0 = s->hp.mul0, m1 = s->hp.mul1, H1 = s->hp.edge_attr_dim + 1, N = s->n_atoms;
       const int64_t contraction = 2 * H1 * N * ((m0 + m1) * (m0 + m1) + 3 * m1 * (2 * m1));
-      const int64_t forming = 2 * H1 * (int64_t)e * (m0 + 15 * m1);  // per edge and k: x0 (m0), dot 3 m1, x1 3 m1, cross 6 m1, T term 3 m1
+      // per edge and k: x0 (m0), dot 3 m1, x1 3 m1, cross 6 m1, T term 3 m1 — on the matrix cores only in k_conv_mf (k_conv_dg forms on the vector ALUs)
+      const int64_t forming = s->dg_mode == 4 ? 2 * H1 * (int64_t)e * (m0 + 15 * m1) : 0;
       out->conv_flop_useful_launch = (s->dg_emu ? 3 : 1) * (contraction + forming);
       const int64_t slots = (int64_t)s->h_kstride;
       out->conv_bytes_alg_launch = 4 * (H1 * slots          // h~ of the layer
@@ -2368,6 +2369,12 @@ int jamun_sampler_stats(jamun_sampler* s, jamun_stats* out, void* stream) {
                                         + N * s->XS           // feature rows
                                         + (int64_t)s->dg_n_slabs * s->n_pad * 32 * (s->layers[1].p0.nt + 3 * s->layers[1].p1.nt)) +  // slabs
                                    (s->dg_mode == 4 ? H1 * 124 * 64 * 16 : s->dg_emu ? H1 * 4 * 34 * 64 * 16 : H1 * (5 * 16 + 5 * 4 + 2 * 4) * 64 * 16);  // weights
+    } else if (s->layers.size() > 1 && s->layers[1].sep.w2b) {
+      // SeparableConv hidden layer (k_sep_fused + k_sep_linear): h~ of the layer, one feature row per edge, the per-destination sums written
+      // and read once, the slab, W2~ and the Linear's weights once
+      const int64_t n0 = s->layers[1].sep.n0, n1 = s->layers[1].sep.n1, DW = n0 + n1 + 3 * (n0 + 2 * n1), N = s->n_atoms;
+      out->conv_bytes_alg_launch = 4 * ((int64_t)(s->hp.edge_attr_dim + 1) * (int64_t)s->h_kstride + (int64_t)e * s->XS + 2 * N * DW + N * (160 + 96) +
+                                        (n0 + n1) * (int64_t)(s->hp.mul0 + s->hp.mul1) + (n0 + 2 * n1) * (int64_t)s->hp.mul1) + 4 * 11 * 2 * 1024;
     }
   });
 }
