@@ -163,6 +163,11 @@ def load() -> C.CDLL:
             f"{LIB_PATH} not found: the HIP extension is not built. Run `python jamun_amd/csrc/build.py` "
             "(hipcc --offload-arch=gfx950). jamun_amd has no CPU fallback."
         )
+    # PyTorch first: its wheel carries its own HIP runtime, and the library's HIP calls must land in THAT copy (the one that owns the
+    # tensors' memory and streams).  Loaded the other way round — the library before torch, as `build()` followed by `smoke()` in one
+    # process did — the library binds /opt/rocm's runtime and its first call fails with "no ROCm-capable device is detected".
+    import torch  # noqa: F401
+
     try:
         lib = C.CDLL(LIB_PATH)
     except OSError as e:  # pragma: no cover

@@ -1705,9 +1705,14 @@ int jamun_sampler_create(const jamun_model* m, float sigma, const jamun_topology
     s->S = std::min(std::max(nmax - 1, 0), JAMUN_MAX_NEIGHBORS + 1) + max_in;
     if (s->S < 1) s->S = 1;
     s->n_tiles = s->n_pad / 32;
-    if (conv_set_max_lds() != 0 || node_update_set_max_lds() != 0 || conv_initv_set_max_lds() != 0 ||
-        conv_dg_set_max_lds() != 0 || conv_mf_set_max_lds() != 0 || sep_conv_set_max_lds() != 0)
-      throw Err(JAMUN_ERR_HIP, "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed");
+    {
+      const std::pair<const char*, int (*)()> lds_attr[] = {{"k_conv", conv_set_max_lds}, {"k_node_update", node_update_set_max_lds},
+                                                            {"k_conv_init_v", conv_initv_set_max_lds}, {"k_conv_dg", conv_dg_set_max_lds},
+                                                            {"jamun_conv_mf.hip", conv_mf_set_max_lds}, {"jamun_sepconv.hip", sep_conv_set_max_lds}};
+      for (auto& f : lds_attr)
+        if (f.second() != 0)
+          throw Err(JAMUN_ERR_HIP, std::string("hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed for ") + f.first + ": " + hipGetErrorString(hipGetLastError()));
+    }
     std::vector<int> ptr_h(topo->ptr, topo->ptr + W + 1);
     s->ptr = dev_upload(ptr_h);
     s->bond_in_ptr = dev_upload(bip);
