@@ -71,3 +71,22 @@ def test_product_does_not_import_oracle():
             if f.endswith(".py"):
                 txt = open(os.path.join(dp, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", txt, flags=re.M), f
+
+
+def test_library_reads_no_environment_and_tuning_is_validated():
+    """Kernel selection goes through jamun_tuning only (include/jamun_hip.h): no getenv in the native sources; the Python side rejects
+    switches the struct does not have."""
+    csrc = os.path.join(ROOT, "jamun_amd", "csrc")
+    for f in os.listdir(csrc):
+        if f.endswith((".hip", ".cpp", ".h")):
+            assert "getenv" not in open(os.path.join(csrc, f)).read(), f
+    from jamun_amd import _lib, native
+
+    t = native.make_tuning({"no_mf": 1, "dg_kgroups": 4})
+    assert t.no_mf == 1 and t.dg_kgroups == 4 and t.no_dg == 0
+    with pytest.raises(ValueError, match="unknown tuning switch"):
+        native.make_tuning({"no_such_kernel": 1})
+    hdr = open(os.path.join(ROOT, "include", "jamun_hip.h")).read()
+    body = hdr[hdr.index("typedef struct jamun_tuning {") : hdr.index("} jamun_tuning;")]
+    fields = re.findall(r"int32_t\s+(\w+)", body)
+    assert fields == [n for n, _ in _lib.jamun_tuning._fields_]  # the binding mirrors the header field for field

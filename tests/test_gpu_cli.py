@@ -154,3 +154,28 @@ def test_sharded_sampler_inside_an_rccl_group(tmp_path):
     r = subprocess.run([sys.executable, str(script), ROOT, str(tmp_path), str(port)], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-3000:]
     assert json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])["ok"], r.stdout[-1000:]
+
+
+def test_bench_line_contract_and_roofline_invariants():
+    """`python bench.py` (short run, no CPU baseline): ONE JSON line with the driver's keys; the roofline block prices the dominant kernel's
+    EXECUTED f16 MFMA FLOPs against the dense f16 peak (at most 1 by construction), the useful part is a part of them, and the counted
+    bytes stand beside the algorithmic ones."""
+    import subprocess
+    import sys
+
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "4", "--warmup", "1", "--repeats", "3", "--no-cpu-baseline", "--no-secondary"],
+                       capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert k in d, k
+    assert d["steps"] == 4 and d["warmup"] == 1 and d["n_gpus"] == 1 and d["vs_baseline"] is None and d["dtype"] == "f32" and "workload" in d["config"]
+    assert abs(d["value"] - 256 * 4 / (d["ms_per_step"] * 4e-3)) < 1e-6 * d["value"]
+    rf = d["roofline"]
+    assert rf["bound"] == "mfma" and rf["peak"] == 2500.0 and rf["unit"] == "TFLOP/s"
+    assert 0.05 < rf["frac"] <= 1.0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9
+    assert 0.0 < rf["frac_useful"] < rf["frac"] and rf["flop_useful_per_launch"] < rf["flop_executed_per_launch"]
+    assert rf["flop_executed_per_launch"] == 136 * 65 * 414 * 32768  # tiles x hidden units x MFMAs per (tile, unit) x FLOP per v_mfma_f32_32x32x16_f16
+    assert rf["bytes_algorithmic_per_launch"] > 5e7 and (rf["traffic"] is None or rf["traffic_ratio"] > 1.0)
