@@ -446,9 +446,14 @@ def test_tail_tiles_of_the_matrix_formed_conv(dev, golden_dir, case, monkeypatch
     assert torch.equal(tails.xhat(y), xt)  # bit-reproducible
     if ref is not None:
         assert rmsd(xt, ref["xhat"]) <= RMSD_TOL_NM
+    # (the initial projector without its matrix-formed kernels keeps the tail tiles on segment lists of its own: k_conv_init_v on all tiles,
+    # the hidden layers' tails still through the tail kernels)
+    mixed = NativeSampler(model._native, 0.04, batch, dev, tuning={"no_mfi": 1})
+    assert mixed.stats()["init_path"] == 2 and mixed.stats()["n_tail_tiles"] >= 4
+    assert rmsd(mixed.xhat(y), xg) <= RMSD_TOL_NM
     for l in range(6):
         b = general.debug_read(0, l).cpu()
-        for other in (tails, whole):
+        for other in (tails, whole, mixed):
             a = other.debug_read(0, l).cpu()
             assert (a - b).abs().max().item() <= 2e-5 * max(b.abs().max().item(), 1e-6), (case, l)
 
