@@ -75,6 +75,7 @@ __global__ __launch_bounds__(SF_THREADS) void k_sep_fused(SepArgs a) {
   const int nA = RFL((n0 + 31) >> 5);
   const bool hasV = n1 > 0;
   const float sch = pow2f(a.sH);
+  const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, 0x7fffffff, 0x00020000);
 
   for (int d = blockIdx.x * 8 + wave; d < a.n_atoms; d += gridDim.x * 8) {
     int lane = lane0;
@@ -133,15 +134,31 @@ __global__ __launch_bounds__(SF_THREADS) void k_sep_fused(SepArgs a) {
         roff[q] = ok ? __float_as_int(rec[t & 63].w) * a.XS : 0;
         rmask |= ok ? (1u << q) : 0u;
       }
+      // (software pipeline over the tile pairs: the gathers of pair ct + 1 are requested before the products of pair ct are applied;
+      // requesting the vector channels' 48 values behind the last pair as well spilled 240 bytes per lane)
+      float x2[2][16], x1[16][3];  // (x2: ping-pong buffers of the scalar channels' gathers, indexed by the compile-time tile counter)
+      // (buffer loads: one 32-bit byte offset per gather instead of a 64-bit address pair — sixteen gathers in flight twice over would
+      // otherwise hold 64 registers of addresses)
+      auto gather0 = [&](int ct, float (&dst)[16]) {
+        const int u = 32 * ct + c;
+        const bool uok = ct < nA && u < n0;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) dst[q] = uok ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, 4 * (roff[q] + u), 0, 0)) : 0.f;
+      };
+      auto gather1 = [&]() {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+          const int o = 4 * (roff[q] + n0 + 3 * (vok ? c : 0));
+          x1[q][0] = vok ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, o, 0, 0)) : 0.f;
+          x1[q][1] = vok ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, o + 4, 0, 0)) : 0.f;
+          x1[q][2] = vok ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, o + 8, 0, 0)) : 0.f;
+        }
+      };
+      gather0(0, x2[0]);
 #pragma unroll
       for (int ct = 0; ct < 4; ++ct) {  // (compile-time ct: the per-tile sums stay in registers)
-        __builtin_amdgcn_sched_barrier(0);  // (one tile pair's gathers and accumulators at a time: hoisting the next pair's loads spills)
+        __builtin_amdgcn_sched_barrier(0);
         if (ct < nA) {
-          const int u = 32 * ct + c;
-          const bool uok = u < n0;
-          float xv[16];
-#pragma unroll
-          for (int q = 0; q < 16; ++q) xv[q] = uok ? a.x[(size_t)roff[q] + u] : 0.f;
           f32x16 accA, accB;
 #pragma unroll
           for (int q = 0; q < 16; ++q) { accA[q] = 0.f; accB[q] = 0.f; }
@@ -151,6 +168,8 @@ __global__ __launch_bounds__(SF_THREADS) void k_sep_fused(SepArgs a) {
             M3(accA, Ah[s], Al[s], ah, al);
             M3(accB, Ah[s], Al[s], bh, bl);
           }
+          if (ct + 1 < 4 && ct + 1 < nA) gather0(ct + 1, x2[(ct + 1) & 1]);
+          __builtin_amdgcn_sched_barrier(0);
           int z0 = 0;
           asm volatile("" : "+v"(z0));  // (opaque zero: the slot records are re-read per phase instead of living in 64 registers)
           const float cA = colc[32 * ct + c], oA = colc[352 + 32 * ct + c], cB = colc[128 + 32 * ct + c], oB = colc[352 + 128 + 32 * ct + c];
@@ -159,8 +178,8 @@ __global__ __launch_bounds__(SF_THREADS) void k_sep_fused(SepArgs a) {
             const bool ok = (rmask >> q) & 1u;
             const float4 r4 = rec[((32 * mt + (q & 3) + 8 * (q >> 2) + 4 * hh) & 63) + z0];
             const float wa = ok ? accA[q] * cA + oA : 0.f, wb = ok ? accB[q] * cB + oB : 0.f;
-            D0[ct] = fmaf(wa, xv[q], D0[ct]);
-            const float bx = wb * xv[q];
+            D0[ct] = fmaf(wa, x2[ct & 1][q], D0[ct]);
+            const float bx = wb * x2[ct & 1][q];
             D1[ct][0] = fmaf(bx, r4.x, D1[ct][0]);
             D1[ct][1] = fmaf(bx, r4.y, D1[ct][1]);
             D1[ct][2] = fmaf(bx, r4.z, D1[ct][2]);
@@ -169,12 +188,7 @@ __global__ __launch_bounds__(SF_THREADS) void k_sep_fused(SepArgs a) {
       }
       __builtin_amdgcn_sched_barrier(0);
       if (hasV) {
-        float x1[16][3];
-#pragma unroll
-        for (int q = 0; q < 16; ++q) {
-          const float* __restrict__ p1 = a.x + (size_t)roff[q] + n0 + 3 * (vok ? c : 0);
-          x1[q][0] = vok ? p1[0] : 0.f; x1[q][1] = vok ? p1[1] : 0.f; x1[q][2] = vok ? p1[2] : 0.f;
-        }
+        gather1();
         // C, D, E one after the other (one accumulator tile live at a time)
         __builtin_amdgcn_sched_barrier(0);
         {
@@ -266,23 +280,55 @@ __global__ __launch_bounds__(512) void k_sep_linear(SepArgs a) {
   const int r = lane & 31, hh = lane >> 5;
   const int n0 = a.n0, n1 = a.n1, K0 = n0 + n1, K1 = n0 + 2 * n1, DW = K0 + 3 * K1, LD = DW + 1;
   const int a0 = blockIdx.x * 32;
-  for (int idx = tid; idx < 32 * DW; idx += 512) {
-    const int row = idx / DW, col = idx - row * DW;
-    sl_lds[row * LD + col] = (a0 + row < a.n_atoms) ? a.D[(size_t)(a0 + row) * DW + col] : 0.f;
+  // (the tile's 32 rows are contiguous in D: 16-byte loads, sixteen in flight per thread before the first LDS store — one load per loop
+  // iteration with its store behind it was a chain of 64 round trips)
+  {
+    const int total4 = 32 * DW / 4;  // DW = 4 (n0 + 2 n1 + ...) is a multiple of 4 for the supported irreps (checked at launch)
+    const float4* __restrict__ src = reinterpret_cast<const float4*>(a.D + (size_t)a0 * DW);
+    const int lim4 = (int)(((size_t)min(32, a.n_atoms - a0) * DW) / 4);
+    for (int base = tid; base < total4; base += 512 * 8) {
+      float4 v[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int idx = base + 512 * i;
+        v[i] = idx < lim4 ? src[idx] : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int idx = base + 512 * i;
+        if (idx < total4) {
+          const int e = 4 * idx, row = e / DW, col = e - row * DW;
+          float* __restrict__ d = sl_lds + row * LD + col;
+          d[0] = v[i].x; d[1] = v[i].y; d[2] = v[i].z; d[3] = v[i].w;
+        }
+      }
+    }
   }
   __syncthreads();
   const int G0 = a.G0, G1 = a.G1;
-  if (wave < a.nt0) {
-    const int col = 32 * wave + r;
+  // K loop in groups of eight MFMAs with their sixteen operand loads issued first: one weight load per MFMA in program order is a chain of
+  // ~90 dependent L2 round trips (first version: 43 us, as long as k_sep_fused)
+  auto gemm = [&](const float* __restrict__ arow, const float* __restrict__ wcol, int K, int wstride, bool col_ok) {
     f32x16 acc;
 #pragma unroll
     for (int q = 0; q < 16; ++q) acc[q] = 0.f;
-    for (int s = 0; 2 * s < K0; ++s) {
-      const int k = 2 * s + hh;
-      const float av = k < K0 ? sl_lds[r * LD + k] : 0.f;
-      const float bv = (k < K0 && col < G0) ? a.wl0[(size_t)k * G0 + col] : 0.f;
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+    for (int s0 = 0; 2 * s0 < K; s0 += 8) {
+      float av[8], bv[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int k = 2 * (s0 + i) + hh;
+        const bool ok = k < K;
+        av[i] = ok ? arow[k] : 0.f;
+        bv[i] = (ok && col_ok) ? wcol[(size_t)k * wstride] : 0.f;
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[i], acc, 0, 0, 0);
     }
+    return acc;
+  };
+  if (wave < a.nt0) {
+    const int col = 32 * wave + r;
+    const f32x16 acc = gemm(sl_lds + r * LD, a.wl0 + col, K0, G0, col < G0);
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
       const int row = (q & 3) + 8 * (q >> 2) + 4 * hh;
@@ -290,15 +336,7 @@ __global__ __launch_bounds__(512) void k_sep_linear(SepArgs a) {
     }
   } else if (wave < a.nt0 + 3 && a.nt1 == 1) {
     const int m = wave - a.nt0;
-    f32x16 acc;
-#pragma unroll
-    for (int q = 0; q < 16; ++q) acc[q] = 0.f;
-    for (int s = 0; 2 * s < K1; ++s) {
-      const int k = 2 * s + hh;
-      const float av = k < K1 ? sl_lds[r * LD + K0 + m * K1 + k] : 0.f;
-      const float bv = (k < K1 && r < G1) ? a.wl1[(size_t)k * G1 + r] : 0.f;
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
-    }
+    const f32x16 acc = gemm(sl_lds + r * LD + K0 + m * K1, a.wl1 + r, K1, G1, r < G1);
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
       const int row = (q & 3) + 8 * (q >> 2) + 4 * hh;
@@ -315,6 +353,7 @@ const char* sep_conv_unsupported(int n0, int n1, int nt0, int nt1, int S, int ed
   if (edge_attr_dim != 64) return "SeparableConv: radial MLP with other than 64 hidden units";
   if (S > 64) return "SeparableConv: more than 64 edge slots per destination (32 radial neighbours + bonded in-edges; repeated bond listings count)";
   if ((size_t)32 * (n0 + n1 + 3 * (n0 + 2 * n1) + 1) * sizeof(float) > 150 * 1024) return "SeparableConv: a 32-atom tile of per-destination sums exceeds the LDS";
+  if ((n0 + n1 + 3 * (n0 + 2 * n1)) % 4 != 0) return "SeparableConv: input irreps whose per-destination sums are not a multiple of four floats";
   return nullptr;
 }
 

@@ -1,14 +1,16 @@
 # Collects the rocprofv3 evidence bench.py and DESIGN.md cite.  Run on the GPU box from the repo root:
-#   bash profiles/collect.sh <tag> [cfg2|cfg3|cfg4|cfg5]   -> gpurun_out/prof_<tag>/{kernel_stats_summary.csv, pmc_summary.txt, pmc_traffic.json}
+#   bash profiles/collect.sh <tag> [cfg2|cfg2r|cfg3|cfg4|cfg5] [extra bench flag, e.g. --separable]
+#                                                          -> gpurun_out/prof_<tag>/{kernel_stats_summary.csv, pmc_summary.txt, pmc_traffic.json}
 # then copy the summaries to profiles/<tag>_*.  Kernel trace and every PMC set run in separate passes (no --sys-trace).
 set -euo pipefail
 cd "${GRAFT_REPO_ROOT:?run on the GPU box (gpurun exports GRAFT_REPO_ROOT)}"
 export TMPDIR=/tmp
 tag=${1:?usage: collect.sh <tag> [config]}
 cfg=${2:-cfg2}
+extra=${3:-}
 out=gpurun_out/prof_$tag
 mkdir -p "$out"
-BENCH="python3 bench.py --config $cfg --no-cpu-baseline --no-secondary --repeats 1"
+BENCH="python3 bench.py --config $cfg $extra --no-cpu-baseline --no-secondary --repeats 1"
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- $BENCH --steps 10 --warmup 2 > $out/bench_under_rocprof.log 2>&1
 f=$(find $out/trace -name "*kernel_stats.csv" | head -1)
 [ -n "$f" ] || { echo "no kernel_stats.csv produced; see $out/bench_under_rocprof.log" >&2; exit 1; }
