@@ -100,7 +100,8 @@ typedef struct jamun_tuning {
   int32_t edge_h_fp32;  /* radial MLP first layer with fp32 MFMAs (k_edge_h) instead of f16x3 (k_edge_h16)                           */
   int32_t dg_kgroups;   /* hidden-unit slices over XCD groups for the destination-grouped kernels: 0 (default = 1), 1, 2, 4, 8       */
   int32_t no_tail;      /* k_conv_mf: tiles with few destinations stay whole tiles (no k_tail_form / k_tail_contract)                 */
-  int32_t reserved[4];  /* must be zero                                                                                              */
+  int32_t no_short_k;   /* k_conv_mf: always four forming K-steps (64 source rows), also when every tile's sources fit the first 48      */
+  int32_t reserved[3];  /* must be zero                                                                                              */
 } jamun_tuning;
 
 typedef struct jamun_model jamun_model;     /* raw checkpoint tensors kept on the host          */
@@ -268,6 +269,8 @@ typedef struct jamun_stats {
   int32_t n_tail;         /* ... and their destinations                                                                                   */
   int64_t conv_bytes_alg_launch;  /* algorithmic HBM bytes of that launch: h~ of the layer, T, the weight stream once, the feature
                              rows once, the partial slabs written */
+  int32_t mf_nks;         /* k_conv_mf: forming K-steps of 16 source rows per product (4; 3 when every tile's sources fit 48 rows; 0: other kernel) */
+  int32_t reserved0;
 } jamun_stats;
 /* Synchronises `stream`. */
 int jamun_sampler_stats(jamun_sampler* s, jamun_stats* out, void* stream);

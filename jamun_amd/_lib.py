@@ -54,7 +54,7 @@ class jamun_topology(C.Structure):
 
 class jamun_tuning(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("no_dg", "no_mf", "dg_fp32", "dg_no_alt", "dg_no_sp", "dg_no_sph", "no_mfi", "no_init_v", "node_fp32",
-                                         "edge_h_fp32", "dg_kgroups", "no_tail")] + [("reserved", C.c_int32 * 4)]
+                                         "edge_h_fp32", "dg_kgroups", "no_tail", "no_short_k")] + [("reserved", C.c_int32 * 3)]
 
 
 class jamun_mcmc_params(C.Structure):
@@ -92,6 +92,8 @@ class jamun_stats(C.Structure):
         ("n_tail_tiles", C.c_int32),
         ("n_tail", C.c_int32),
         ("conv_bytes_alg_launch", C.c_int64),
+        ("mf_nks", C.c_int32),
+        ("reserved0", C.c_int32),
     ]
 
 

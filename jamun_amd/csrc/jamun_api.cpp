@@ -346,6 +346,7 @@ struct jamun_sampler {
   // tail tiles of the mode-4 plan (tiles with few destinations): formed with the hidden unit in the column index and contracted 32 gathered
   // destinations at a time (k_tail_form / k_tail_contract) instead of as whole tiles of k_conv_mf; the initial projector keeps them as tiles
   int n_tail_tiles = 0, n_tail = 0, tail_runs = 0;
+  int mf_nks = 4;  // forming K-steps of k_conv_mf (3: every whole tile's sources lie in the first 48 rows of its window)
   int4* tail_tiles = nullptr;
   int* tail_atom = nullptr;
   float* tail_scale = nullptr;
@@ -1353,7 +1354,7 @@ void run_layer(jamun_sampler* s, size_t l, const float* x_in, int XSin, float* x
       f.deg = s->deg; f.esrc = s->esrc; f.egeo = s->egeo; f.h = h_l; f.h_kstride = s->h_kstride; f.x = x_in;
       f.n_pad = s->n_pad; f.S = s->S; f.XS = XSin; f.n_atoms = s->n_atoms;
       f.tile_span = s->dg_tile_span; f.tile_atoms = s->dg_tile_atoms; f.segs = s->dg_segs; f.max_segs = s->dg_max_segs; f.nt0 = L.p0.nt;
-      f.wm = L.dg.wm; f.Tt = s->dg_T; f.t_stride = s->dg_tstride; f.sB = L.dg.sB; f.sTw = L.dg.sTw;
+      f.wm = L.dg.wm; f.Tt = s->dg_T; f.t_stride = s->dg_tstride; f.sB = L.dg.sB; f.sTw = L.dg.sTw; f.nks = s->mf_nks;
       f.gx = L.dg.gx; f.cf0 = L.dg.cf0; f.cf1 = L.dg.cf1;
       {
         int e3 = 0;
@@ -1430,7 +1431,7 @@ void run_layer(jamun_sampler* s, size_t l, const float* x_in, int XSin, float* x
     n.kga0 = L.kga0; n.kga1 = L.kga1; n.kgx = L.kgx; n.cg0 = L.cg0; n.cg1 = L.cg1;
     {
       ProfScope ps(s, JAMUN_PROF_NODE, st);
-      if (!s->tune.node_fp32 && node_update_h_supported(n)) launch_node_update_h(n, st);  // (node_fp32: the v_mfma_f32_32x32x2_f32 kernel, A/B aid)
+      if (!s->tune.node_fp32 && node_update_h_supported(n)) launch_node_update_h(n, s->cus, st);  // (node_fp32: the v_mfma_f32_32x32x2_f32 kernel, A/B aid)
       else launch_node_update(n, st);
     }
 }
@@ -1442,7 +1443,9 @@ void run_layer(jamun_sampler* s, size_t l, const float* x_in, int XSin, float* x
 // at the latest in jamun_sampler_stats, which synchronises — instead of as silently wrong coordinates.
 void mf_err_check(jamun_sampler* s) {
   if (s->mf_err_host && *(volatile int*)s->mf_err_host != 0)
-    throw Err(JAMUN_ERR_INVALID, "k_conv_mf: more than three edges of one (source, destination) pair — results of this sampler are invalid");
+    throw Err(JAMUN_ERR_INVALID, (*(volatile int*)s->mf_err_host & 2)
+                                     ? "k_conv_mf: an edge's source lies outside the rows the selected instantiation multiplies (host plan and kernel disagree) — results of this sampler are invalid"
+                                     : "k_conv_mf: more than three edges of one (source, destination) pair — results of this sampler are invalid");
 }
 void mf_err_fetch(jamun_sampler* s, hipStream_t st) {
   if (s->mf_err && s->mf_err_host) HIPCHECK(hipMemcpyAsync(s->mf_err_host, s->mf_err, sizeof(int), hipMemcpyDeviceToHost, st));
@@ -1958,6 +1961,10 @@ int jamun_sampler_create(const jamun_model* m, float sigma, const jamun_topology
         s->dg_tile_atoms = dev_upload(t_atoms);
         s->dg_tile_span = dev_upload(t_span);
         if (s->dg_mode == 4) {
+          int need = 0;  // rows of the window a tile's sources reach (the window starts at an even atom)
+          for (size_t t = 0; t < t_span.size(); ++t)
+            if (!is_tail[t]) need = std::max(need, t_span[t].y - (t_span[t].x & ~1));
+          s->mf_nks = (need <= 48 && !tn.no_short_k) ? 3 : 4;
           s->dg_tstride = ((N + 31) & ~31) + 64;
           s->dg_T = dev_alloc<float>((size_t)n_k * 32 * s->dg_tstride);
           HIPCHECK(hipMemset(s->dg_T, 0, sizeof(float) * (size_t)n_k * 32 * s->dg_tstride));
@@ -2077,7 +2084,7 @@ int jamun_sampler_create(const jamun_model* m, float sigma, const jamun_topology
         // (32768 FLOP: 50 groups of 16 inputs x 3 products) + 72 v_mfma_f32_16x16x32_f16 (16384 FLOP); + 60 fp32 units per (32 atoms, k)
         // in the T pre-pass
         // (mode 4, jamun_conv_mf.hip: 414 v_mfma_f32_32x32x16_f16 per (tile, k): 228 forming + 186 contraction)
-        const int64_t per_tile_k = s->dg_mode == 4 ? 414LL * 32768 : s->dg_emu ? (150LL * 32768 + 72LL * 16384) : 476LL * 4096;
+        const int64_t per_tile_k = s->dg_mode == 4 ? (s->mf_nks == 3 ? 357LL : 414LL) * 32768 : s->dg_emu ? (150LL * 32768 + 72LL * 16384) : 476LL * 4096;
         s->conv_flop_exec_launch = (int64_t)(s->dg_n_tiles - s->n_tail_tiles) * per_tile_k * (hp.edge_attr_dim + 1);  // (tail tiles run in their own kernels)
         s->flop_exec += s->conv_flop_exec_launch + (int64_t)((s->n_atoms + 31) / 32) * (s->dg_emu ? 24LL * 32768 : 60LL * 4096) * (hp.edge_attr_dim + 1);
       }
@@ -2360,6 +2367,8 @@ int jamun_sampler_stats(jamun_sampler* s, jamun_stats* out, void* stream) {
     out->conv_flop_exec_launch = s->conv_flop_exec_launch;
     out->n_tail_tiles = s->n_tail_tiles;
     out->n_tail = s->n_tail;
+    out->mf_nks = (s->dg_on && s->dg_mode == 4) ? s->mf_nks : 0;
+    out->reserved0 = 0;
     out->conv_flop_useful_launch = 0;
     out->conv_bytes_alg_launch = 0;
     if (s->dg_on && s->layers.size() > 1) {

@@ -136,7 +136,10 @@ __device__ __forceinline__ int clamp100(int s) { return max(-100, min(100, s)); 
 }  // namespace
 
 // SPD: edge slots per destination handled by one lane group of the helper waves (32 for edge strides up to 32, else 64)
-template <int SPD>
+// NKS: K-steps of 16 source rows per forming product (4 = the whole 64-row window; 3 when EVERY tile of the launch has its sources
+// in the window's first 48 rows — one 33-atom molecule per tile: 57 instead of 76 forming products per hidden unit; chosen by the host,
+// MfArgs::nks: a per-step branch on the span breaks the pinned schedule, a compile-time count does not)
+template <int SPD, int NKS>
 __global__ __launch_bounds__(MF_THREADS) void k_conv_mf(MfArgs a) {
   extern __shared__ float4 lds4[];
   char* __restrict__ lds = reinterpret_cast<char*>(lds4);
@@ -321,7 +324,8 @@ __global__ __launch_bounds__(MF_THREADS) void k_conv_mf(MfArgs a) {
       const int sj = sjv[p];
       const bool bonded = in && sj < 0;  // bit 31
       const int jraw = sj & 0x7fffffff, jl = jraw - s_base;
-      const bool valid = in && jl >= 0 && jl < 64;
+      const bool valid = in && jl >= 0 && jl < 16 * NKS;
+      if (in && jl >= 16 * NKS) atomicOr(a.err, 2);  // a source outside the rows this instantiation multiplies: the host's plan is wrong
       bool active = valid;
       int d0 = 0, d1 = 0;
       // Several edges of one (source, destination) pair (a bonded pair inside the cutoff has a radial and a bonded edge:
@@ -494,17 +498,19 @@ __global__ __launch_bounds__(MF_THREADS) void k_conv_mf(MfArgs a) {
             MF_SCHED();
             mm(F, f1);
             MF_SCHED();
-            f1 = ldf(xa + 96, MF_X0L - MF_X0H, cb + 96);
-            MF_SCHED();
+            if constexpr (NKS == 4) {
+              f1 = ldf(xa + 96, MF_X0L - MF_X0H, cb + 96);
+              MF_SCHED();
+            }
             mm(F, f0);
-            mm(F, f1);
+            if constexpr (NKS == 4) mm(F, f1);
             MSTAMP(2);
             split(F, Ah, Al);
           } else {  // (one fragment set: the eight builder passes need the registers; this wave is not the longest stream of its SIMD)
             MSTAMP(1);
             f32x16 F = zero16;
 #pragma unroll
-            for (int st = 0; st < 4; ++st) {
+            for (int st = 0; st < NKS; ++st) {
               const Frag f0 = ldf(xa + 32 * st, MF_X0L - MF_X0H, cb + 32 * st);
               mm(F, f0);
               MF_SCHED();
@@ -610,7 +616,7 @@ __global__ __launch_bounds__(MF_THREADS) void k_conv_mf(MfArgs a) {
         // (whose first fragment reads would otherwise leave the matrix pipe idle).  The barrier still orders both hazards: the
         // builders arrive with C(k + 1) complete, every reader arrives after its last read of C(k).
         constexpr int QD = SPD == 64 ? 2 : 3;  // fragment sets in flight (edge strides above 32: register allocation of the kernel is at its limit)
-        auto fr = [&](int st, int cb) { const int m = st >> 2, s4 = st & 3; return ldf(MF_X1H + (m * 32) * MF_ROWB + fo + 32 * s4, MF_X1L - MF_X1H, cb + (1 + m) * 2 * MF_PL + 32 * s4); };
+        auto fr = [&](int st, int cb) { const int m = st / NKS, s4 = st % NKS; return ldf(MF_X1H + (m * 32) * MF_ROWB + fo + 32 * s4, MF_X1L - MF_X1H, cb + (1 + m) * 2 * MF_PL + 32 * s4); };
         Frag fq[QD];
 #pragma unroll
         for (int st = 0; st < QD - 1; ++st) fq[st] = fr(st, MF_C + fo);
@@ -622,8 +628,8 @@ __global__ __launch_bounds__(MF_THREADS) void k_conv_mf(MfArgs a) {
           float4 Ah[2], Al[2];
           f32x16 F = zero16;
 #pragma unroll
-          for (int st = 0; st < 12; ++st) {
-            if (st + QD - 1 < 12) fq[(st + QD - 1) % QD] = fr(st + QD - 1, cb);
+          for (int st = 0; st < 3 * NKS; ++st) {
+            if (st + QD - 1 < 3 * NKS) fq[(st + QD - 1) % QD] = fr(st + QD - 1, cb);
             MF_SCHED();
             mm(F, fq[st % QD]);
             MF_SCHED();
@@ -669,7 +675,7 @@ __global__ __launch_bounds__(MF_THREADS) void k_conv_mf(MfArgs a) {
       // steps 0..3 x1[m] C[1] | 4..7 x1[m+1] C[v_(m+2)] | 8..11 x1[m+2] C[v_(m+1)] ((x1 x v)[m] = x1[m+1] v[m+2] - x1[m+2] v[m+1]) |
       // 12..15 the T term: out_m[i][w'] += sum_j C[v_m][i][j] T_k[j][w'] (A = coefficient rows, B = T^T rows; own accumulator: scale 2^(sC + sT))
       auto fr = [&](int st, int cb, int tb) {
-        const int g = st >> 2, s4 = 32 * (st & 3);
+        const int g = st / NKS, s4 = 32 * (st % NKS);
         if (g == 0) return ldf(x1a + m * 32 * MF_ROWB + s4, MF_X1L - MF_X1H, cb + s4);
         if (g == 1) return ldf(x1a + m1 * 32 * MF_ROWB + s4, MF_X1L - MF_X1H, cb + (1 + m2) * 2 * MF_PL + s4);
         if (g == 2) return ldf(x1a + m2 * 32 * MF_ROWB + s4, MF_X1L - MF_X1H, cb + (1 + m1) * 2 * MF_PL + s4);
@@ -687,12 +693,12 @@ __global__ __launch_bounds__(MF_THREADS) void k_conv_mf(MfArgs a) {
         MSTAMP(1);
         f32x16 FA = zero16, F1 = zero16, F2 = zero16;
 #pragma unroll
-        for (int st = 0; st < 12; ++st) {
+        for (int st = 0; st < 3 * NKS; ++st) {
           fq[(st + 2) % 3] = fr(st + 2, cb, tb);
           MF_SCHED();
-          mm(st < 4 ? FA : st < 8 ? F1 : F2, fq[st % 3]);
+          mm(st < NKS ? FA : st < 2 * NKS ? F1 : F2, fq[st % 3]);
           MF_SCHED();
-          if (st == 3) MSTAMP(2);
+          if (st == NKS - 1) MSTAMP(2);
         }
         // The 12 MFMAs of the T term (steps 12..15; their own accumulator) carry the vector work of BOTH splits between them — 16 pairs
         // of values (x1[m] tile, then the cross-product tile F1 - F2), one or two pairs behind each MFMA, pinned with scheduling
@@ -713,24 +719,28 @@ __global__ __launch_bounds__(MF_THREADS) void k_conv_mf(MfArgs a) {
             alC[s2][p2] = cvt_pk_f16(resid_lo(v0, ph), resid_hi(v1, ph));
           }
         };
+        // (MFMA slot i of the 3 NKS carries pairs [16 i / (3 NKS), 16 (i + 1) / (3 NKS)): 1 + 1 + 2 per step for four steps)
+        auto ride = [&](int slot) {
 #pragma unroll
-        for (int st = 12; st < 16; ++st) {
-          if (st + 2 < 16) fq[(st + 2) % 3] = fr(st + 2, cb, tb);
+          for (int i = 16 * slot / (3 * NKS); i < 16 * (slot + 1) / (3 * NKS); ++i) split_pair(i);
+        };
+#pragma unroll
+        for (int st = 3 * NKS; st < 4 * NKS; ++st) {
+          if (st + 2 < 4 * NKS) fq[(st + 2) % 3] = fr(st + 2, cb, tb);
           MF_SCHED();
           const Frag& f = fq[st % 3];
-          const int e = 4 * (st - 12);  // pairs e .. e + 3 ride on this step's three MFMAs (1 + 1 + 2)
+          const int e = 3 * (st - 3 * NKS);
           if constexpr (!(dbg & 2)) accT = MFMA32H(f.al, f.bh, accT);
           MF_SCHED();
-          split_pair(e);
+          ride(e);
           MF_SCHED();
           if constexpr (!(dbg & 2)) accT = MFMA32H(f.ah, f.bl, accT);
           MF_SCHED();
-          split_pair(e + 1);
+          ride(e + 1);
           MF_SCHED();
           if constexpr (!(dbg & 2)) accT = MFMA32H(f.ah, f.bh, accT);
           MF_SCHED();
-          split_pair(e + 2);
-          split_pair(e + 3);
+          ride(e + 2);
           MF_SCHED();
         }
         MSTAMP(3);
@@ -1833,8 +1843,14 @@ size_t conv_mf_lds_bytes() { return MF_LDS_BYTES; }
 
 int launch_conv_mf(const MfArgs& a, int grid, hipStream_t st) {
   if (a.XS != 216 || a.nt0 != 5 || a.S > 64 || (a.t_stride & 1)) return -1;
-  if (a.S <= 32) hipLaunchKernelGGL((k_conv_mf<32>), dim3(grid), dim3(MF_THREADS), MF_LDS_BYTES, st, a);
-  else hipLaunchKernelGGL((k_conv_mf<64>), dim3(grid), dim3(MF_THREADS), MF_LDS_BYTES, st, a);
+  if (a.nks != 3 && a.nks != 4) return -1;
+  if (a.S <= 32) {
+    if (a.nks == 3) hipLaunchKernelGGL((k_conv_mf<32, 3>), dim3(grid), dim3(MF_THREADS), MF_LDS_BYTES, st, a);
+    else hipLaunchKernelGGL((k_conv_mf<32, 4>), dim3(grid), dim3(MF_THREADS), MF_LDS_BYTES, st, a);
+  } else {
+    if (a.nks == 3) hipLaunchKernelGGL((k_conv_mf<64, 3>), dim3(grid), dim3(MF_THREADS), MF_LDS_BYTES, st, a);
+    else hipLaunchKernelGGL((k_conv_mf<64, 4>), dim3(grid), dim3(MF_THREADS), MF_LDS_BYTES, st, a);
+  }
   return 0;
 }
 
@@ -1872,7 +1888,7 @@ int conv_mf_set_max_lds() {
                        (const void*)k_conv_mfi<32, 4>, (const void*)k_conv_mfi<64, 4>};
   for (const void* f : fi)
     if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, JAMUN_MAX_DYN_LDS) != hipSuccess) return -1;
-  const void* fns[2] = {(const void*)k_conv_mf<32>, (const void*)k_conv_mf<64>};
+  const void* fns[4] = {(const void*)k_conv_mf<32, 4>, (const void*)k_conv_mf<64, 4>, (const void*)k_conv_mf<32, 3>, (const void*)k_conv_mf<64, 3>};
   for (const void* f : fns)
     if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, JAMUN_MAX_DYN_LDS) != hipSuccess) return -1;
   return 0;

@@ -95,6 +95,7 @@ struct MfArgs {
   const int2* tile_atoms;  // [n_tiles] {first destination atom, number of destination atoms (<= 32)}
   const int4* segs;        // [grid][max_segs][2]: {tile (-1 end), slab, k_begin, k_end}, {k_extra (-1 none), 0, 0, 0}
   int max_segs, nt0;
+  int nks;                 // forming K-steps of 16 source rows: 4, or 3 when every tile's sources lie in the first 48 rows of its window
   // wm [k][124 blocks of 64 lanes x 8 halves] in consumption order, (hi, lo) pairs; B fragments of v_mfma_f32_32x32x16_f16 with the
   // K index of a step permuted to the accumulator layout of the forming MFMA: half p of lane (column c, hh) <-> input
   // 16 s2 + (p & 3) + 8 (p >> 2) + 4 hh of the wave's 32 channels:
@@ -349,7 +350,7 @@ int launch_conv_initv(const InitVArgs& a, int grid, hipStream_t st);
 int conv_initv_set_max_lds();
 size_t conv_initv_lds_bytes(int rs, int pmax, int nbuf);
 void launch_node_update(const NodeArgs& a, hipStream_t st);
-void launch_node_update_h(const NodeArgs& a, hipStream_t st);
+void launch_node_update_h(const NodeArgs& a, int cus, hipStream_t st);
 bool node_update_h_supported(const NodeArgs& a);
 size_t node_update_lds_bytes(const NodeArgs& a);
 int node_update_set_max_lds();

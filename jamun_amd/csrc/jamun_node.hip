@@ -71,7 +71,12 @@ __device__ __forceinline__ void put1(char* hi_row, int lo_off, int k, float v, f
 
 // One workgroup = 32 atoms, 8 waves; 16 threads per atom in phase 1.  Requires nt0 <= 5 (partial0 rows of <= 160 floats), nt1 == 1,
 // XSin a multiple of 4 and <= 224, in0 a multiple of 4, mul0 a multiple of 4, K0h / K1h multiples of 16.
-__global__ __launch_bounds__(NH_T) void k_node_update_h(NodeArgs a) {
+// LR = the low-register variant (<= 128 registers: two workgroups per CU; chosen by the launcher when the grid exceeds the CUs, where a
+// second round of a few workgroups would double the launch: 33 x 256 atoms = 264 workgroups took 36 us against 21 for 256): nothing of
+// phase 2 is requested before phase 1 — the other workgroup of the CU covers those round trips — and the weight ring is 4 steps deep.
+template <bool LR>
+__global__ __launch_bounds__(NH_T, LR ? 4 : 2) void k_node_update_h(NodeArgs a) {
+  constexpr int NW = LR ? 4 : NH_W;
   extern __shared__ float4 nh_lds[];
   char* __restrict__ sm = reinterpret_cast<char*>(nh_lds);
   const int RB0 = RFL(a.K0h * 2 + 16), RB1 = RFL(a.K1h * 2 + 16);  // row bytes: K halves + 16 (rows 16 B apart mod 32: conflict-free b128 reads)
@@ -104,8 +109,8 @@ __global__ __launch_bounds__(NH_T) void k_node_update_h(NodeArgs a) {
   const int col_j = scalar_j ? job * 32 + r_j : r_j;                  // output channel within the irrep block
   const bool col_ok_j = has_job && (scalar_j ? col_j < a.mul0 : col_j < a.mul1);
   const int o_j = scalar_j ? col_j : a.mul0 + 3 * col_j + (job - nts);  // column of x_out
-  float4 wh[NH_W], wl[NH_W];
-  float xo[16];
+  float4 wh[NW], wl[NW];
+  float xo[LR ? 1 : 16];
 
   // ---- loads: scalar rows (<= 40 pieces of 16 bytes per atom and slab), vector rows (24), input features (<= 56); the first NH_S
   // slabs of everything are in flight together, summation order stays s = 0, 1, 2, ...
@@ -119,45 +124,53 @@ __global__ __launch_bounds__(NH_T) void k_node_update_h(NodeArgs a) {
 #pragma unroll
       for (int q = 0; q < 3; ++q) {
         const int j = c16 + 16 * q;
-        ls[s][q] = 4 * j < w0 ? *reinterpret_cast<const float4*>(p0 + (s < ns_max ? s : 0) * slab0 + 4 * j) : z4;
+        ls[s][q] = *reinterpret_cast<const float4*>(p0 + (s < ns_max ? s : 0) * slab0 + min(4 * j, w0 - 4));  // (clamped, masked below:
+        // a conditional load of this form compiles to a FLAT load through a pointer select with the zero constant in scratch)
       }
 #pragma unroll
       for (int q = 0; q < 2; ++q) {
         const int j = c16 + 16 * q;
-        lv[s][q] = j < 24 ? *reinterpret_cast<const float4*>(p1 + (s < ns_max ? s : 0) * slab1 + 4 * j) : z4;
+        lv[s][q] = *reinterpret_cast<const float4*>(p1 + (s < ns_max ? s : 0) * slab1 + 4 * min(j, 23));
       }
     }
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int j = c16 + 16 * q;
-      xv[q] = (ok && 4 * j < a.XSin) ? *reinterpret_cast<const float4*>(a.x_in + (size_t)i * a.XSin + 4 * j) : z4;
+      xv[q] = *reinterpret_cast<const float4*>(a.x_in + (size_t)min(i, a.n_atoms - 1) * a.XSin + min(4 * j, a.XSin - 4));
     }
     // (the loads above do not wait for this atom's slab count: slab indices are clamped to the batch's maximum, results masked here)
     // phase 2's operands that do not depend on phase 1 — the first NH_W K-steps of this wave's weight blocks and the x_old values of its
     // output tile — are requested now, behind the slab loads: their round trips run during phase 1 instead of after its barrier
+    if constexpr (!LR) {
 #pragma unroll
-    for (int t = 0; t < NH_W; ++t) {
-      const int sw = t < nst_j ? t : nst_j - 1;
-      wh[t] = has_job ? wp_j[(2 * sw) * 64] : z4;
-      wl[t] = has_job ? wp_j[(2 * sw + 1) * 64] : z4;
-    }
+      for (int t = 0; t < NW; ++t) {
+        const int sw = t < nst_j ? t : nst_j - 1;
+        wh[t] = wp_j[(2 * sw) * 64];  // (a wave without a job reads the blocks of plane 0: valid addresses, results unused)
+        wl[t] = wp_j[(2 * sw + 1) * 64];
+      }
 #pragma unroll
-    for (int q = 0; q < 16; ++q) {
-      const int rl = (q & 3) + 8 * (q >> 2) + 4 * hh_j, ii = n0 + rl;
-      xo[q] = (a.mix && col_ok_j && ii < a.n_atoms) ? a.x_in[(size_t)ii * a.XSin + o_j] : 0.f;
+      for (int q = 0; q < 16; ++q) {
+        const int rl = (q & 3) + 8 * (q >> 2) + 4 * hh_j, ii = n0 + rl;
+        xo[q] = (a.mix && col_ok_j && ii < a.n_atoms) ? a.x_in[(size_t)ii * a.XSin + o_j] : 0.f;
+      }
     }
 #pragma unroll
     for (int q = 0; q < 3; ++q) {
-      ms[q] = 0 < ns ? ls[0][q] : z4;
+      const bool in = 4 * (c16 + 16 * q) < w0;
+      ms[q] = (in && 0 < ns) ? ls[0][q] : z4;
 #pragma unroll
-      for (int s = 1; s < NH_S; ++s) ms[q] = f4add(ms[q], s < ns ? ls[s][q] : z4);
+      for (int s = 1; s < NH_S; ++s) ms[q] = f4add(ms[q], (in && s < ns) ? ls[s][q] : z4);
     }
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
-      mv[q] = 0 < ns ? lv[0][q] : z4;
+      const bool in = c16 + 16 * q < 24;
+      mv[q] = (in && 0 < ns) ? lv[0][q] : z4;
 #pragma unroll
-      for (int s = 1; s < NH_S; ++s) mv[q] = f4add(mv[q], s < ns ? lv[s][q] : z4);
+      for (int s = 1; s < NH_S; ++s) mv[q] = f4add(mv[q], (in && s < ns) ? lv[s][q] : z4);
     }
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      if (!(ok && 4 * (c16 + 16 * q) < a.XSin)) xv[q] = z4;
     for (int s = NH_S; s < ns_max; ++s) {
       if (s < ns) {
 #pragma unroll
@@ -280,14 +293,22 @@ __global__ __launch_bounds__(NH_T) void k_node_update_h(NodeArgs a) {
     f32x16 acc;
 #pragma unroll
     for (int q = 0; q < 16; ++q) acc[q] = 0.f;
-    for (int s0 = 0; s0 < nst; s0 += NH_W) {
+    if constexpr (LR) {
 #pragma unroll
-      for (int t = 0; t < NH_W; ++t) {
+      for (int t = 0; t < NW; ++t) {
+        const int sw = t < nst ? t : nst - 1;
+        wh[t] = wp[(2 * sw) * 64];
+        wl[t] = wp[(2 * sw + 1) * 64];
+      }
+    }
+    for (int s0 = 0; s0 < nst; s0 += NW) {
+#pragma unroll
+      for (int t = 0; t < NW; ++t) {
         if (s0 + t < nst) {  // wave-uniform
           const float4 bh = wh[t], bl = wl[t];
-          if (s0 + t + NH_W < nst) {
-            wh[t] = wp[(2 * (s0 + t + NH_W)) * 64];
-            wl[t] = wp[(2 * (s0 + t + NH_W) + 1) * 64];
+          if (s0 + t + NW < nst) {
+            wh[t] = wp[(2 * (s0 + t + NW)) * 64];
+            wl[t] = wp[(2 * (s0 + t + NW) + 1) * 64];
           }
           const float4 ah = *reinterpret_cast<const float4*>(ap + 32 * (s0 + t)), al = *reinterpret_cast<const float4*>(ap + lo + 32 * (s0 + t));
           acc = MFMA32H(al, bh, acc);
@@ -304,7 +325,7 @@ __global__ __launch_bounds__(NH_T) void k_node_update_h(NodeArgs a) {
       const int rl = (q & 3) + 8 * (q >> 2) + 4 * hh, ii = n0 + rl;
       if (col_ok_j && ii < a.n_atoms) {
         float v = (acc[q] * isc[rl]) * cinv;
-        if (a.mix) v = mw * xo[q] + (1.f - mw) * v;  // hidden layers: XSin == XSo, x_in is x_old
+        if (a.mix) v = mw * (LR ? a.x_in[(size_t)ii * a.XSin + o_j] : xo[LR ? 0 : q]) + (1.f - mw) * v;  // hidden layers: XSin == XSo, x_in is x_old
         a.x_out[(size_t)ii * XSo + o_j] = v;
       }
     }
@@ -319,6 +340,10 @@ bool node_update_h_supported(const NodeArgs& a) {
          a.XSin <= 256 && (a.K0h & 15) == 0 && (a.K1h & 15) == 0 && a.K0h >= a.mul0 + a.in0 && a.K1h >= a.mul1 + a.in1 &&
          ((a.K0h - a.mul0 - a.in0) & 3) == 0 && ((a.K1h - a.mul1 - a.in1) & 3) == 0 && node_update_h_lds_bytes(a) <= 64 * 1024;
 }
-void launch_node_update_h(const NodeArgs& a, hipStream_t st) {
-  hipLaunchKernelGGL(k_node_update_h, dim3(a.n_pad / 32), dim3(NH_T), node_update_h_lds_bytes(a), st, a);
+void launch_node_update_h(const NodeArgs& a, int cus, hipStream_t st) {
+  const int grid = a.n_pad / 32;
+  if (grid > cus && 2 * node_update_h_lds_bytes(a) <= 150 * 1024)
+    hipLaunchKernelGGL(k_node_update_h<true>, dim3(grid), dim3(NH_T), node_update_h_lds_bytes(a), st, a);
+  else
+    hipLaunchKernelGGL(k_node_update_h<false>, dim3(grid), dim3(NH_T), node_update_h_lds_bytes(a), st, a);
 }

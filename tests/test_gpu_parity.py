@@ -458,6 +458,48 @@ def test_tail_tiles_of_the_matrix_formed_conv(dev, golden_dir, case, monkeypatch
             assert (a - b).abs().max().item() <= 2e-5 * max(b.abs().max().item(), 1e-6), (case, l)
 
 
+@pytest.mark.parametrize("case", ["chain33x4", "odd_starts_47", "mixed_40_46", "one_too_many"])
+def test_short_forming_window_of_the_matrix_formed_conv(dev, golden_dir, case):
+    """k_conv_mf<SPD, 3>: when every whole tile's sources lie in the first 48 rows of its 64-row window (one 33-atom molecule per tile — the
+    4AA shape) the forming products run three K-steps instead of four (jamun_stats.mf_nks).  The dropped step multiplied zeros, so the result
+    must be BIT-identical to the four-step instantiation (jamun_tuning.no_short_k); against the general kernel and the 33-atom oracle fixture
+    besides.  47-atom molecules starting at odd atoms need exactly 48 rows; one 48-atom molecule at an odd atom needs 49 and must keep four."""
+    from jamun_amd import synth
+    from jamun_amd.data import WalkerBatch
+    from jamun_amd.model import Denoiser
+    from jamun_amd.native import NativeSampler
+
+    model = Denoiser.from_checkpoint_dict(_ckpt("strong")).to(dev)
+    ref = None
+    if case == "chain33x4":
+        mols, ref, want = _mols("chain33x4"), _golden(golden_dir, "oracle_forward_chain33x4"), 3
+    elif case == "odd_starts_47":
+        mols, want = [synth.random_chain(n, seed=90 + i) for i, n in enumerate([47, 47, 47, 45, 47, 46])], 3
+    elif case == "mixed_40_46":
+        mols, want = [synth.random_chain(n, seed=120 + i) for i, n in enumerate([40, 46, 33, 44, 41, 35, 46, 43])], 3
+    else:
+        mols, want = [synth.random_chain(n, seed=150 + i) for i, n in enumerate([33, 48, 33, 40])], 4  # 48 atoms from atom 33: rows 32..80
+    batch = WalkerBatch.from_molecules(mols).to(dev)
+    if ref is not None:
+        y = ref["y"].to(dev)
+    else:
+        torch.manual_seed(13)
+        y = batch.pos + 0.04 * torch.randn(batch.pos.shape).to(dev)
+    short = NativeSampler(model._native, 0.04, batch, dev)
+    full = NativeSampler(model._native, 0.04, batch, dev, tuning={"no_short_k": 1})
+    general = NativeSampler(model._native, 0.04, batch, dev, tuning={"no_dg": 1})
+    assert short.stats()["dg_mode"] == 4 and short.stats()["mf_nks"] == want, short.stats()
+    assert full.stats()["mf_nks"] == 4 and general.stats()["mf_nks"] == 0
+    xs, xf, xg = short.xhat(y), full.xhat(y), general.xhat(y)
+    assert torch.equal(xs, xf)
+    assert rmsd(xs, xg) <= RMSD_TOL_NM, rmsd(xs, xg)
+    if ref is not None:
+        assert rmsd(xs, ref["xhat"]) <= RMSD_TOL_NM
+    for l in range(6):
+        assert torch.equal(short.debug_read(0, l), full.debug_read(0, l)), (case, l)
+    short.stats()  # (synchronises; a source outside the multiplied rows would have raised JAMUN_ERR_INVALID here)
+
+
 @pytest.mark.parametrize("case", ["span62", "single62", "odd_start", "double_bonds", "rows100", "many_rows"])
 def test_matrix_formed_conv_edge_cases(dev, case, monkeypatch):
     """k_conv_mf / k_conv_mfi (jamun_conv_mf.hip) against the general kernel on the shapes that stress their bookkeeping: a tile span of
