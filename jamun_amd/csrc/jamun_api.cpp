@@ -372,6 +372,7 @@ struct jamun_sampler {
   float *yc = nullptr, *h = nullptr, *partial0 = nullptr, *partial1 = nullptr, *g = nullptr, *tmp = nullptr;
   float *xhat_buf = nullptr, *score_buf = nullptr, *psi = nullptr;
   int *deg = nullptr, *esrc = nullptr;
+  int* epair = nullptr;  // k_geom's pair table (jamun_internal.h: JAMUN_EP_*), [N * S]; allocated when k_conv_mf runs the hidden layers
   float4* egeo = nullptr;
   std::vector<float*> x;  // per block output [n_atoms][XS]
   unsigned long long* counter = nullptr;
@@ -385,7 +386,7 @@ struct jamun_sampler {
   ~jamun_sampler() {
     hipFree(ptr); hipFree(bond_in_ptr); hipFree(bond_in_src); hipFree(x_emb); hipFree(mu);
     hipFree(atom_uid); hipFree(w1r_all); hipFree(cmask_all); hipFree(w1h_all); hipFree(w1isc_all);
-    hipFree(dg_tile_atoms); hipFree(dg_tile_span); hipFree(dg_segs); hipFree(dg_atom_nslab); hipFree(dg_T); hipFree(mf_err);
+    hipFree(epair); hipFree(dg_tile_atoms); hipFree(dg_tile_span); hipFree(dg_segs); hipFree(dg_atom_nslab); hipFree(dg_T); hipFree(mf_err);
     hipFree(tail_tiles); hipFree(tail_atom); hipFree(tail_scale); hipFree(tail_P); hipFree(init_segs); hipFree(init_atom_nslab);
     if (mf_err_host) hipHostFree(mf_err_host);
     for (auto& L : layers) {
@@ -1255,7 +1256,7 @@ void build_edges(jamun_sampler* s, float* y, hipStream_t st, const LangevinPre& 
   {
     ProfScope ps(s, JAMUN_PROF_GEOM, st);
     launch_geom(y, s->ptr, s->n_graphs, s->c_in, s->r2, s->S, s->bond_in_ptr, s->bond_in_src, s->hp.mean_center, s->yc,
-                s->deg, s->esrc, s->egeo, pre, st);
+                s->deg, s->esrc, s->egeo, s->epair, pre, st);
   }
   if (s->h_batched) {
     ProfScope ps(s, JAMUN_PROF_EDGE_H, st);
@@ -1354,7 +1355,7 @@ void run_layer(jamun_sampler* s, size_t l, const float* x_in, int XSin, float* x
       f.deg = s->deg; f.esrc = s->esrc; f.egeo = s->egeo; f.h = h_l; f.h_kstride = s->h_kstride; f.x = x_in;
       f.n_pad = s->n_pad; f.S = s->S; f.XS = XSin; f.n_atoms = s->n_atoms;
       f.tile_span = s->dg_tile_span; f.tile_atoms = s->dg_tile_atoms; f.segs = s->dg_segs; f.max_segs = s->dg_max_segs; f.nt0 = L.p0.nt;
-      f.wm = L.dg.wm; f.Tt = s->dg_T; f.t_stride = s->dg_tstride; f.sB = L.dg.sB; f.sTw = L.dg.sTw; f.nks = s->mf_nks;
+      f.wm = L.dg.wm; f.Tt = s->dg_T; f.t_stride = s->dg_tstride; f.sB = L.dg.sB; f.sTw = L.dg.sTw; f.nks = s->mf_nks; f.epair = s->epair;
       f.gx = L.dg.gx; f.cf0 = L.dg.cf0; f.cf1 = L.dg.cf1;
       {
         int e3 = 0;
@@ -1968,6 +1969,8 @@ int jamun_sampler_create(const jamun_model* m, float sigma, const jamun_topology
           s->dg_tstride = ((N + 31) & ~31) + 64;
           s->dg_T = dev_alloc<float>((size_t)n_k * 32 * s->dg_tstride);
           HIPCHECK(hipMemset(s->dg_T, 0, sizeof(float) * (size_t)n_k * 32 * s->dg_tstride));
+          s->epair = dev_alloc<int>((size_t)N * s->S + 64);
+          HIPCHECK(hipMemset(s->epair, 0, sizeof(int) * ((size_t)N * s->S + 64)));
           s->mf_err = dev_alloc<int>(1);
           HIPCHECK(hipMemset(s->mf_err, 0, sizeof(int)));
           HIPCHECK(hipHostMalloc((void**)&s->mf_err_host, sizeof(int), hipHostMallocDefault));

@@ -135,7 +135,10 @@ __device__ __forceinline__ int clamp100(int s) { return max(-100, min(100, s)); 
 
 }  // namespace
 
-// SPD: edge slots per destination handled by one lane group of the helper waves (32 for edge strides up to 32, else 64)
+// SPD: the builder's lane layout.  32: edge strides up to 32 — four passes of 8 destinations x 32 slots over the 256 builder lanes;
+// 64: eight passes of 4 destinations x 64 slots; 40: edge strides 33..40 — the four passes of layout 32 plus ONE pass for slots 32..39 of
+// all 32 destinations (lane = (destination of this wave, slot - 32): k_geom caps the radial neighbours at 32, so those slots hold bonded
+// edges only): five passes instead of eight for a 33-atom molecule with every atom at the neighbour cap.
 // NKS: K-steps of 16 source rows per forming product (4 = the whole 64-row window; 3 when EVERY tile of the launch has its sources
 // in the window's first 48 rows — one 33-atom molecule per tile: 57 instead of 76 forming products per hidden unit; chosen by the host,
 // MfArgs::nks: a per-step branch on the span breaks the pinned schedule, a compile-time count does not)
@@ -189,15 +192,22 @@ __global__ __launch_bounds__(MF_THREADS) void k_conv_mf(MfArgs a) {
     // tile.  Edge strides up to 32: four passes of 8 destinations x 32 slots; above: eight passes of 4 destinations x 64 slots (a
     // destination's slots stay within one wave: the pair bookkeeping uses ballots and shuffles)
     constexpr int BT = 256;                          // builder threads
-    constexpr int DPP = BT / SPD, NP = 32 / DPP;     // destinations per pass, passes
+    constexpr int SPL = SPD == 40 ? 32 : SPD;        // slots per destination of the main passes
+    constexpr int DPP = BT / SPL, NPM = 32 / DPP;    // destinations per main pass, main passes
+    constexpr int NP = NPM + (SPD == 40 ? 1 : 0);    // + the pass of slots 32..39 (layout 40)
     constexpr int NTV = 1024 / BT;                   // T elements (pairs of source rows) per builder lane
     const bool builder = tid < BT;
-    const int gsh = (SPD == 32) ? 32 * (lane >> 5) : 0;  // this lane group's bit offset inside the wave's ballot
-    // per pass ONE packed word: bits 0..12 byte offset of the entry inside a coefficient plane (i * 144 + 2 jl), 13..18 / 19..24 the
-    // slot distance to a second / third edge of the same pair (0: none).  Lanes without an entry point at the pad bytes of row 0 (offset
-    // 128 of every plane; never read), so that build() is straight-line code.  The slot of pass p is slot0 + p * DPP * S.
+    // (destination, slot) of this lane in pass p; layout 40, last pass: wave w owns the destinations of its main passes —
+    // 8 (q >> 1) + 2 w + (q & 1), q = lane >> 3 — so that every edge of a destination stays inside one wave (lane shuffles below)
+    auto dst_of = [&](int p) { return (SPD == 40 && p == NPM) ? 8 * (lane >> 4) + 2 * wave + ((lane >> 3) & 1) : ((tid & (BT - 1)) + BT * p) / SPL; };
+    auto slt_of = [&](int p) { return (SPD == 40 && p == NPM) ? 32 + (lane & 7) : ((tid & (BT - 1)) + BT * p) % SPL; };
+    // per pass ONE packed word: bits 0..12 byte offset of the entry inside a coefficient plane (i * 144 + 2 jl), 13..18 / 19..24 where a
+    // second / third edge of the same pair sits (0: none): the LANE DISTANCE inside this pass, or — bits 25 / 26 set, layout 40 — the lane
+    // of the last pass.  Lanes without an entry point at the pad bytes of row 0 (offset 128 of every plane; never read), so that build()
+    // is straight-line code.
     int ent[NP];
-    const int slot0 = (n0 + (tid & (BT - 1)) / SPD) * a.S + (tid & (BT - 1)) % SPD, pstride = DPP * a.S;
+    const int slot0 = (n0 + dst_of(0)) * a.S + slt_of(0), pstride = DPP * a.S, slot_x = (n0 + dst_of(NP - 1)) * a.S + slt_of(NP - 1);
+    auto slot_of = [&](int p) { return (SPD == 40 && p == NPM) ? slot_x : slot0 + p * pstride; };
     float hv[NP];
     float2 tv[NTV];
     // (loads only, nothing consumed here: a use would wait for EVERY vector load in flight, the weight ring included)
@@ -207,7 +217,7 @@ __global__ __launch_bounds__(MF_THREADS) void k_conv_mf(MfArgs a) {
       if (!builder) return;
       const float* __restrict__ hk = a.h + (size_t)k * a.h_kstride;
 #pragma unroll
-      for (int p = 0; p < NP; ++p) hv[p] = hk[slot0 + p * pstride];  // (lanes past the in-degree read a neighbouring slot or the table's slack: never used)
+      for (int p = 0; p < NP; ++p) hv[p] = hk[slot_of(p)];  // (lanes past the in-degree read a neighbouring slot or the table's slack: never used)
       const float* __restrict__ tk = a.Tt + (size_t)k * 32 * a.t_stride + s_base;
 #pragma unroll
       for (int q = 0; q < NTV; ++q) {
@@ -217,13 +227,14 @@ __global__ __launch_bounds__(MF_THREADS) void k_conv_mf(MfArgs a) {
     };
     load_k(k_of(0));
     float evx[NP], evy[NP], evz[NP];
-    int sjv[NP];
+    int sjv[NP], epv[NP];
 #pragma unroll
     for (int p = 0; p < NP; ++p) {  // (all passes' edge records requested at once, and before the rows are staged: their round trip hides behind that)
-      const int g = (tid & (BT - 1)) + BT * p, i = g / SPD, t = g % SPD;
-      const int slot = (n0 + i) * a.S + t;
+      const int i = dst_of(p), t = slt_of(p);
+      const int slot = slot_of(p);
       const bool in = builder && i < n_dst && t < a.S;  // (the in-degree is applied below: slots past it hold stale records)
       sjv[p] = in ? a.esrc[slot] : 0;
+      epv[p] = in ? a.epair[slot] : 0;
       float4 ge = make_float4(0.f, 0.f, 0.f, 0.f);
       if (in) ge = a.egeo[slot];
       evx[p] = ge.x; evy[p] = ge.y; evz[p] = ge.z;
@@ -318,46 +329,41 @@ __global__ __launch_bounds__(MF_THREADS) void k_conv_mf(MfArgs a) {
 
 #pragma unroll
     for (int p = 0; p < NP; ++p) {
-      const int g = (tid & (BT - 1)) + BT * p, i = g / SPD, t = g % SPD;
+      const int i = dst_of(p), t = slt_of(p);
       const int dg = deg_lds[i];
       const bool in = builder && t < dg && t < a.S;
-      const int sj = sjv[p];
-      const bool bonded = in && sj < 0;  // bit 31
-      const int jraw = sj & 0x7fffffff, jl = jraw - s_base;
+      const int jl = (sjv[p] & 0x7fffffff) - s_base;  // (bit 31: bonded)
       const bool valid = in && jl >= 0 && jl < 16 * NKS;
       if (in && jl >= 16 * NKS) atomicOr(a.err, 2);  // a source outside the rows this instantiation multiplies: the host's plan is wrong
-      bool active = valid;
-      int d0 = 0, d1 = 0;
       // Several edges of one (source, destination) pair (a bonded pair inside the cutoff has a radial and a bonded edge:
-      // src/jamun/model/denoiser.py:152) share ONE entry of the coefficient tile: the first slot of the pair owns it and adds
-      // the h~ of the others (bonded edges are the last slots of a destination: k_geom).
-      const unsigned long long balb = __ballot(bonded);
-      const unsigned long long gmask = (SPD == 32) ? 0xffffffffull : ~0ull;
-      const int nb = __popcll((balb >> gsh) & gmask);
-      const int nb_max = RFL(SPD == 32 ? max(__popcll(balb & 0xffffffffull), __popcll(balb >> 32)) : __popcll(balb));
-      for (int b = 0; b < nb_max; ++b) {
-        const int lb = dg - nb + b;  // slot of this group's b-th bonded edge
-        const int jb = __shfl(jraw, (lb & (SPD - 1)) + gsh, 64);
-        const bool match = b < nb && valid && t < lb && jraw == jb;
-        const unsigned long long mb = (__ballot(match) >> gsh) & gmask;
-        if (b < nb && mb != 0ull) {
-          const int first = __ffsll((long long)mb) - 1;
-          if (t == lb) active = false;
-          if (t == first) {
-            if (d0 == 0) d0 = lb - t;
-            else if (d1 == 0) d1 = lb - t;
-            else atomicOr(a.err, 1);  // more than three edges of one pair: not representable here (excluded by the host)
-          }
-        }
-      }
-      ent[p] = active ? (i * MF_ROWB + 2 * jl) | (d0 << 13) | (d1 << 19) : 128;
+      // src/jamun/model/denoiser.py:152) share ONE entry of the coefficient tile: the first slot of the pair owns it and adds the
+      // h~ of the others.  k_geom has matched them (JAMUN_EP_*: an owned slot carries bit 31, an owner the slots of up to two others).
+      const int ep = in ? epv[p] : 0;
+      if (ep & JAMUN_EP_OVERFLOW) atomicOr(a.err, 1);  // more than three edges of one pair: not representable here (excluded by the host)
+      const int pa = (ep & 127) - 1, pb = ((ep >> 7) & 127) - 1;  // slots of the pair's other edges (-1: none); always behind this one
+      auto ref = [&](int ps) {  // where this lane finds the h~ of slot ps of its destination
+        if (ps < 0) return 0;
+        if (SPD == 40 && p < NPM && ps >= 32) return (((2 * p + (lane >> 5)) << 3) + (ps - 32)) | 64;
+        return ps - t;
+      };
+      const int r0 = ref(pa), r1 = ref(pb);
+      const bool active = valid && !((unsigned)ep & JAMUN_EP_OWNED);
+      ent[p] = active ? (i * MF_ROWB + 2 * jl) | ((r0 & 63) << 13) | ((r1 & 63) << 19) | ((r0 >> 6) << 25) | ((r1 >> 6) << 26) : 128;
     }
     SSTAMP(3);
     const float scC = pow2f(a.sC), scT = pow2f(clamp100(sX + a.sTw));
     auto coef = [&](int p) {  // h~ of pass p's entry: this lane's edge + the pair's other edges
       const int d0 = (ent[p] >> 13) & 63, d1 = (ent[p] >> 19) & 63;
-      const float t0 = __shfl(hv[p], lane + d0, 64), t1 = __shfl(hv[p], lane + d1, 64);
-      return (hv[p] + (d0 ? t0 : 0.f)) + (d1 ? t1 : 0.f);
+      float t0 = __shfl(hv[p], lane + d0, 64), t1 = __shfl(hv[p], lane + d1, 64);
+      bool u0 = d0 != 0, u1 = d1 != 0;
+      if constexpr (SPD == 40) {
+        if (p < NPM) {  // (the other edge in the pass of slots 32..39: absolute lane)
+          const float q0 = __shfl(hv[NP - 1], d0, 64), q1 = __shfl(hv[NP - 1], d1, 64);
+          if ((ent[p] >> 25) & 1) { t0 = q0; u0 = true; }
+          if ((ent[p] >> 26) & 1) { t1 = q1; u1 = true; }
+        }
+      }
+      return (hv[p] + (u0 ? t0 : 0.f)) + (u1 ? t1 : 0.f);
     };
     auto build = [&](int buf) {  // the loaded hidden unit -> coefficient tiles and T tile of buffer `buf`
       if constexpr ((dbg & 8) != 0) return;
@@ -447,7 +453,7 @@ __global__ __launch_bounds__(MF_THREADS) void k_conv_mf(MfArgs a) {
       // ---- scalar-output waves: 20 weight blocks per k ((hi, lo) per (output tile n, K-step s2)); ring: half a hidden unit ahead
       // (edge strides above 32: eight builder passes per lane instead of four — their registers come out of the ring of waves 0..3,
       // whose contraction is bound by the vector work riding on it, not by the weight latency)
-      constexpr int NB = 20, R = SPD == 64 ? 5 : 10, RD = 10;
+      constexpr int NB = 20, R = SPD == 64 ? 5 : SPD == 40 ? 10 : 10, RD = 10;  // (R divides NB: block b of every hidden unit lives in RB[b % R])
       const int w = wave;
       f32x16 accS[5];
 #pragma unroll
@@ -1844,9 +1850,13 @@ size_t conv_mf_lds_bytes() { return MF_LDS_BYTES; }
 int launch_conv_mf(const MfArgs& a, int grid, hipStream_t st) {
   if (a.XS != 216 || a.nt0 != 5 || a.S > 64 || (a.t_stride & 1)) return -1;
   if (a.nks != 3 && a.nks != 4) return -1;
+  if (!a.epair) return -1;
   if (a.S <= 32) {
     if (a.nks == 3) hipLaunchKernelGGL((k_conv_mf<32, 3>), dim3(grid), dim3(MF_THREADS), MF_LDS_BYTES, st, a);
     else hipLaunchKernelGGL((k_conv_mf<32, 4>), dim3(grid), dim3(MF_THREADS), MF_LDS_BYTES, st, a);
+  } else if (a.S <= 40) {
+    if (a.nks == 3) hipLaunchKernelGGL((k_conv_mf<40, 3>), dim3(grid), dim3(MF_THREADS), MF_LDS_BYTES, st, a);
+    else hipLaunchKernelGGL((k_conv_mf<40, 4>), dim3(grid), dim3(MF_THREADS), MF_LDS_BYTES, st, a);
   } else {
     if (a.nks == 3) hipLaunchKernelGGL((k_conv_mf<64, 3>), dim3(grid), dim3(MF_THREADS), MF_LDS_BYTES, st, a);
     else hipLaunchKernelGGL((k_conv_mf<64, 4>), dim3(grid), dim3(MF_THREADS), MF_LDS_BYTES, st, a);
@@ -1888,7 +1898,8 @@ int conv_mf_set_max_lds() {
                        (const void*)k_conv_mfi<32, 4>, (const void*)k_conv_mfi<64, 4>};
   for (const void* f : fi)
     if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, JAMUN_MAX_DYN_LDS) != hipSuccess) return -1;
-  const void* fns[4] = {(const void*)k_conv_mf<32, 4>, (const void*)k_conv_mf<64, 4>, (const void*)k_conv_mf<32, 3>, (const void*)k_conv_mf<64, 3>};
+  const void* fns[6] = {(const void*)k_conv_mf<32, 4>, (const void*)k_conv_mf<64, 4>, (const void*)k_conv_mf<32, 3>, (const void*)k_conv_mf<64, 3>,
+                        (const void*)k_conv_mf<40, 4>, (const void*)k_conv_mf<40, 3>};
   for (const void* f : fns)
     if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, JAMUN_MAX_DYN_LDS) != hipSuccess) return -1;
   return 0;

@@ -83,8 +83,15 @@ struct DgArgs {
 
 // conv with the A operand formed on the matrix cores and chained into the contraction (jamun_conv_mf.hip): hidden layers with
 // irreps 120x0e + 32x1e, tiles whose source span fits a K = 64 window
+// k_geom's pair table (one word per edge slot; several edges of one ordered (source, destination) pair — a radial edge and the bonded
+// edge(s) of the same atoms — share one entry of the matrix-formed kernels' coefficient tiles): the FIRST slot of the pair owns the
+// entry and lists the slots of up to two others (bits 0..6 and 7..13: slot + 1, 0 = none); the others carry JAMUN_EP_OWNED.
+#define JAMUN_EP_OWNED 0x80000000u
+#define JAMUN_EP_OVERFLOW 0x40000000  // more than three edges of one pair
+
 struct MfArgs {
   const int* deg;
+  const int* epair;  // [n_atoms * S] pair table (above)
   const int* esrc;
   const float4* egeo;
   const float* h;  // [hidden unit k (65 rows)][h_kstride]
@@ -325,7 +332,7 @@ void launch_mean_center(const float* pos, const int* ptr, int n_graphs, float* o
 void launch_radius_graph(const float* pos, const int* ptr, int n_graphs, float r2, int stride, int* nbr, int* deg,
                          hipStream_t st);
 void launch_geom(float* y, const int* ptr, int n_graphs, float c_in, float r2, int S, const int* bip,
-                 const int* bis, int mean_center, float* yc, int* deg, int* esrc, float4* egeo, const LangevinPre& pre,
+                 const int* bis, int mean_center, float* yc, int* deg, int* esrc, float4* egeo, int* epair, const LangevinPre& pre,
                  hipStream_t st);
 // (w1h / isc_all non-null: the f16x3 kernel k_edge_h16 — W1's radial part as scaled hi + lo A fragments [layer][2][2][2][64], 2^-(14 + sW) per layer)
 void launch_edge_h(const int* deg, const int* esrc, const float4* egeo, int n_atoms, int S, const float* w1r_all,

@@ -75,7 +75,7 @@ __device__ __forceinline__ void philox_normal3(uint64_t seed, uint32_t iter, uin
 __global__ void k_geom(float* __restrict__ y, const int* __restrict__ ptr, float c_in, float r2, int S,
                        const int* __restrict__ bond_in_ptr, const int* __restrict__ bond_in_src, int mean_center,
                        float* __restrict__ yc, int* __restrict__ deg, int* __restrict__ esrc,
-                       float4* __restrict__ egeo, LangevinPre pre) {
+                       float4* __restrict__ egeo, int* __restrict__ epair, LangevinPre pre) {
   __shared__ float cen[3];
   const int g = blockIdx.x;
   const int lo = ptr[g], hi = ptr[g + 1];
@@ -113,6 +113,13 @@ __global__ void k_geom(float* __restrict__ y, const int* __restrict__ ptr, float
     const float sx = FMUL(px, c_in), sy = FMUL(py, c_in), sz = FMUL(pz, c_in);
     int count = 0, nr = 0;
     const size_t base = (size_t)i * S;
+    // pair table (jamun_internal.h: JAMUN_EP_*): the radial slot of each bonded neighbour is noted while the radial edges are written
+    // (atoms with up to four bonds; more: a scan over the slots below)
+    const int bnd0 = bond_in_ptr[i], n_bnd = bond_in_ptr[i + 1] - bnd0;
+    const bool ep_fast = epair != nullptr && n_bnd <= 4;
+    int bsrc[4], twin[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { bsrc[q] = (ep_fast && q < n_bnd) ? bond_in_src[bnd0 + q] : -1; twin[q] = -1; }
     for (int j = lo; j < hi; ++j) {
       const float qx = yc[j * 3], qy = yc[j * 3 + 1], qz = yc[j * 3 + 2];
       float dx = FSUB(qx, px), dy = FSUB(qy, py), dz = FSUB(qz, pz);
@@ -125,11 +132,16 @@ __global__ void k_geom(float* __restrict__ y, const int* __restrict__ ptr, float
           float dn = d < 1e-12f ? 1e-12f : d;
           esrc[base + nr] = j;
           egeo[base + nr] = make_float4(ex / dn, ey / dn, ez / dn, d);
+          if (epair) epair[base + nr] = 0;  // (owners of a pair are rewritten below)
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            if (j == bsrc[q]) twin[q] = nr;
           ++nr;
         }
         if (++count >= JAMUN_MAX_NEIGHBORS + 1) break;
       }
     }
+    const int nr_rad = nr;
     for (int b = bond_in_ptr[i]; b < bond_in_ptr[i + 1]; ++b) {
       const int j = bond_in_src[b];
       const float qx = yc[j * 3], qy = yc[j * 3 + 1], qz = yc[j * 3 + 2];
@@ -141,6 +153,47 @@ __global__ void k_geom(float* __restrict__ y, const int* __restrict__ ptr, float
       ++nr;
     }
     deg[i] = nr;
+    // a bonded edge whose source already has a slot — its radial twin inside the cutoff, or an earlier copy of the same bond — is owned by
+    // the FIRST such slot, which lists it (up to two; more: JAMUN_EP_OVERFLOW)
+    if (epair) {
+      int wrd[4] = {0, 0, 0, 0};  // words of the twins' slots (fast path: written once, below)
+      for (int t = nr_rad; t < nr; ++t) {
+        const int j = esrc[base + t] & 0x7fffffff;
+        int owner = -1;
+        if (ep_fast) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            if (q == t - nr_rad) owner = twin[q];
+          // (several bonds from one source share its twin: twin[] holds the same slot for each; no radial twin: an earlier bonded slot)
+          for (int o = nr_rad; owner < 0 && o < t; ++o)
+            if ((esrc[base + o] & 0x7fffffff) == j) owner = o;
+        } else {
+          for (int o = 0; owner < 0 && o < t; ++o)
+            if ((esrc[base + o] & 0x7fffffff) == j) owner = o;
+        }
+        epair[base + t] = owner >= 0 ? (int)JAMUN_EP_OWNED : 0;
+        if (owner >= 0) {
+          auto add = [&](int w) { return (w & 127) == 0 ? (w | (t + 1)) : ((w >> 7) & 127) == 0 ? (w | ((t + 1) << 7)) : (w | JAMUN_EP_OVERFLOW); };
+          bool kept = false;
+          if (ep_fast && owner < nr_rad) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+              if (!kept && twin[q] == owner) { wrd[q] = add(wrd[q]); kept = true; }  // (the first bond of this source keeps the word)
+          }
+          if (!kept) epair[base + owner] = add(epair[base + owner]);  // (bonded owners, and the scan path: written above, same thread)
+        }
+      }
+      if (ep_fast) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          bool first = twin[q] >= 0;
+#pragma unroll
+          for (int q2 = 0; q2 < q; ++q2)
+            if (twin[q2] == twin[q]) first = false;
+          if (first && wrd[q] != 0) epair[base + twin[q]] = wrd[q];
+        }
+      }
+    }
   }
 }
 
@@ -834,10 +887,10 @@ void launch_radius_graph(const float* pos, const int* ptr, int n_graphs, float r
   hipLaunchKernelGGL(k_radius_graph, dim3(n_graphs), dim3(128), 0, st, pos, ptr, r2, stride, nbr, deg);
 }
 void launch_geom(float* y, const int* ptr, int n_graphs, float c_in, float r2, int S, const int* bip,
-                 const int* bis, int mean_center, float* yc, int* deg, int* esrc, float4* egeo, const LangevinPre& pre,
+                 const int* bis, int mean_center, float* yc, int* deg, int* esrc, float4* egeo, int* epair, const LangevinPre& pre,
                  hipStream_t st) {
   hipLaunchKernelGGL(k_geom, dim3(n_graphs), dim3(128), 0, st, y, ptr, c_in, r2, S, bip, bis, mean_center, yc, deg,
-                     esrc, egeo, pre);
+                     esrc, egeo, epair, pre);
 }
 void launch_edge_h(const int* deg, const int* esrc, const float4* egeo, int n_atoms, int S, const float* w1r_all,
                    const float* cmask_all, int n_layers, const float* mu, float step, float* h_all, size_t h_layer_stride,
