@@ -192,22 +192,28 @@ __global__ __launch_bounds__(MF_THREADS) void k_conv_mf(MfArgs a) {
     // tile.  Edge strides up to 32: four passes of 8 destinations x 32 slots; above: eight passes of 4 destinations x 64 slots (a
     // destination's slots stay within one wave: the pair bookkeeping uses ballots and shuffles)
     constexpr int BT = 256;                          // builder threads
-    constexpr int SPL = SPD == 40 ? 32 : SPD;        // slots per destination of the main passes
+    constexpr bool XP = SPD == 40;                   // layout with an extra pass of eight slots per destination behind the main passes
+    // (a 16 + 8 layout for strides up to 24 — three passes instead of four on 17-atom molecules — was measured and dropped: cfg2 0.1132 ->
+    // 0.1133 ms per launch; there the builder waves wait at the barrier anyway, the plane waves' streams set the step)
+    constexpr int SPL = XP ? SPD - 8 : SPD;          // slots per destination of the main passes
+    constexpr int LG = SPL == 16 ? 4 : 5;            // log2 of a main pass' lane group
     constexpr int DPP = BT / SPL, NPM = 32 / DPP;    // destinations per main pass, main passes
-    constexpr int NP = NPM + (SPD == 40 ? 1 : 0);    // + the pass of slots 32..39 (layout 40)
+    constexpr int NP = NPM + (XP ? 1 : 0);           // + the pass of slots SPL .. SPL + 7
     constexpr int NTV = 1024 / BT;                   // T elements (pairs of source rows) per builder lane
     const bool builder = tid < BT;
     // (destination, slot) of this lane in pass p; layout 40, last pass: wave w owns the destinations of its main passes —
     // 8 (q >> 1) + 2 w + (q & 1), q = lane >> 3 — so that every edge of a destination stays inside one wave (lane shuffles below)
-    auto dst_of = [&](int p) { return (SPD == 40 && p == NPM) ? 8 * (lane >> 4) + 2 * wave + ((lane >> 3) & 1) : ((tid & (BT - 1)) + BT * p) / SPL; };
-    auto slt_of = [&](int p) { return (SPD == 40 && p == NPM) ? 32 + (lane & 7) : ((tid & (BT - 1)) + BT * p) % SPL; };
+    // (extra pass: lane = (q, slot - SPL), q = lane >> 3 = the wave's q-th destination: main pass q / GPW, lane group q % GPW)
+    constexpr int GPW = 64 / SPL;  // lane groups (destinations) of a wave per main pass
+    auto dst_of = [&](int p) { return (XP && p == NPM) ? DPP * ((lane >> 3) / GPW) + GPW * wave + ((lane >> 3) % GPW) : ((tid & (BT - 1)) + BT * p) / SPL; };
+    auto slt_of = [&](int p) { return (XP && p == NPM) ? SPL + (lane & 7) : ((tid & (BT - 1)) + BT * p) % SPL; };
     // per pass ONE packed word: bits 0..12 byte offset of the entry inside a coefficient plane (i * 144 + 2 jl), 13..18 / 19..24 where a
     // second / third edge of the same pair sits (0: none): the LANE DISTANCE inside this pass, or — bits 25 / 26 set, layout 40 — the lane
     // of the last pass.  Lanes without an entry point at the pad bytes of row 0 (offset 128 of every plane; never read), so that build()
     // is straight-line code.
     int ent[NP];
     const int slot0 = (n0 + dst_of(0)) * a.S + slt_of(0), pstride = DPP * a.S, slot_x = (n0 + dst_of(NP - 1)) * a.S + slt_of(NP - 1);
-    auto slot_of = [&](int p) { return (SPD == 40 && p == NPM) ? slot_x : slot0 + p * pstride; };
+    auto slot_of = [&](int p) { return (XP && p == NPM) ? slot_x : slot0 + p * pstride; };
     float hv[NP];
     float2 tv[NTV];
     // (loads only, nothing consumed here: a use would wait for EVERY vector load in flight, the weight ring included)
@@ -343,7 +349,7 @@ __global__ __launch_bounds__(MF_THREADS) void k_conv_mf(MfArgs a) {
       const int pa = (ep & 127) - 1, pb = ((ep >> 7) & 127) - 1;  // slots of the pair's other edges (-1: none); always behind this one
       auto ref = [&](int ps) {  // where this lane finds the h~ of slot ps of its destination
         if (ps < 0) return 0;
-        if (SPD == 40 && p < NPM && ps >= 32) return (((2 * p + (lane >> 5)) << 3) + (ps - 32)) | 64;
+        if (XP && p < NPM && ps >= SPL) return (((GPW * p + (lane >> LG)) << 3) + (ps - SPL)) | 64;
         return ps - t;
       };
       const int r0 = ref(pa), r1 = ref(pb);
@@ -356,8 +362,8 @@ __global__ __launch_bounds__(MF_THREADS) void k_conv_mf(MfArgs a) {
       const int d0 = (ent[p] >> 13) & 63, d1 = (ent[p] >> 19) & 63;
       float t0 = __shfl(hv[p], lane + d0, 64), t1 = __shfl(hv[p], lane + d1, 64);
       bool u0 = d0 != 0, u1 = d1 != 0;
-      if constexpr (SPD == 40) {
-        if (p < NPM) {  // (the other edge in the pass of slots 32..39: absolute lane)
+      if constexpr (XP) {
+        if (p < NPM) {  // (the other edge in the extra pass: absolute lane)
           const float q0 = __shfl(hv[NP - 1], d0, 64), q1 = __shfl(hv[NP - 1], d1, 64);
           if ((ent[p] >> 25) & 1) { t0 = q0; u0 = true; }
           if ((ent[p] >> 26) & 1) { t1 = q1; u1 = true; }
