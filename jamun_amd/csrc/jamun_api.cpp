@@ -372,7 +372,7 @@ struct jamun_sampler {
   float *yc = nullptr, *h = nullptr, *partial0 = nullptr, *partial1 = nullptr, *g = nullptr, *tmp = nullptr;
   float *xhat_buf = nullptr, *score_buf = nullptr, *psi = nullptr;
   int *deg = nullptr, *esrc = nullptr;
-  int* epair = nullptr;  // k_geom's pair table (jamun_internal.h: JAMUN_EP_*), [N * S]; allocated when k_conv_mf runs the hidden layers
+  int* epair = nullptr;  // k_geom's pair table (jamun_internal.h: JAMUN_EP_*), one word per edge slot
   float4* egeo = nullptr;
   std::vector<float*> x;  // per block output [n_atoms][XS]
   unsigned long long* counter = nullptr;
@@ -1288,7 +1288,7 @@ void run_layer(jamun_sampler* s, size_t l, const float* x_in, int XSin, float* x
       if (launch_sep_conv(f, s->cus, st) != 0) throw Err(JAMUN_ERR_INVALID, "separable conv launch failed (irreps not supported)");
     } else if (l == 0 && s->mfi_on) {
       MfiArgs f{};
-      f.deg = s->deg; f.esrc = s->esrc; f.egeo = s->egeo; f.h = h_l; f.h_kstride = s->h_kstride;
+      f.deg = s->deg; f.epair = s->epair; f.esrc = s->esrc; f.egeo = s->egeo; f.h = h_l; f.h_kstride = s->h_kstride;
       f.n_pad = s->n_pad; f.S = s->S; f.nt0 = L.p0.nt;
       f.tile_span = s->dg_tile_span; f.tile_atoms = s->dg_tile_atoms; f.segs = s->init_segs ? s->init_segs : s->dg_segs; f.max_segs = s->init_segs ? s->init_max_segs : s->dg_max_segs;
       f.atom_uid = s->atom_uid; f.tabw = L.tabw; f.sB = L.tab_sB; f.ut = L.tab_ut;
@@ -1304,7 +1304,7 @@ void run_layer(jamun_sampler* s, size_t l, const float* x_in, int XSin, float* x
       }
       if (s->init_tail) {
         TailArgs t{};
-        t.deg = s->deg; t.esrc = s->esrc; t.egeo = s->egeo; t.h = h_l; t.h_kstride = s->h_kstride;
+        t.deg = s->deg; t.epair = s->epair; t.esrc = s->esrc; t.egeo = s->egeo; t.h = h_l; t.h_kstride = s->h_kstride;
         t.n_pad = s->n_pad; t.S = s->S; t.n_k = s->hp.edge_attr_dim + 1; t.nt0 = L.p0.nt;
         t.tile_span = s->dg_tile_span; t.tile_atoms = s->dg_tile_atoms; t.tail_tiles = s->tail_tiles;
         t.n_tail_tiles = s->n_tail_tiles; t.n_tail = s->n_tail; t.n_runs = s->tail_runs; t.tail_atom = s->tail_atom; t.tail_scale = s->tail_scale;
@@ -1315,7 +1315,7 @@ void run_layer(jamun_sampler* s, size_t l, const float* x_in, int XSin, float* x
       }
     } else if (l == 0 && s->mfx_on) {
       MfxArgs f{};
-      f.deg = s->deg; f.esrc = s->esrc; f.egeo = s->egeo; f.h = h_l; f.h_kstride = s->h_kstride;
+      f.deg = s->deg; f.epair = s->epair; f.esrc = s->esrc; f.egeo = s->egeo; f.h = h_l; f.h_kstride = s->h_kstride;
       f.n_pad = s->n_pad; f.S = s->S; f.nt0 = L.p0.nt;
       f.tile_span = s->dg_tile_span; f.tile_atoms = s->dg_tile_atoms; f.segs = s->init_segs ? s->init_segs : s->dg_segs; f.max_segs = s->init_segs ? s->init_max_segs : s->dg_max_segs;
       f.xph = L.xph; f.xpl = L.xpl; f.wx = L.wx; f.sX = L.x_sX; f.cf0 = L.xcf0; f.cf1 = L.xcf1;
@@ -1331,7 +1331,7 @@ void run_layer(jamun_sampler* s, size_t l, const float* x_in, int XSin, float* x
       }
       if (s->init_tail) {
         TailArgs t{};
-        t.deg = s->deg; t.esrc = s->esrc; t.egeo = s->egeo; t.h = h_l; t.h_kstride = s->h_kstride;
+        t.deg = s->deg; t.epair = s->epair; t.esrc = s->esrc; t.egeo = s->egeo; t.h = h_l; t.h_kstride = s->h_kstride;
         t.n_pad = s->n_pad; t.S = s->S; t.n_k = s->hp.edge_attr_dim + 1; t.nt0 = L.p0.nt;
         t.tile_span = s->dg_tile_span; t.tile_atoms = s->dg_tile_atoms; t.tail_tiles = s->tail_tiles;
         t.n_tail_tiles = s->n_tail_tiles; t.n_tail = s->n_tail; t.n_runs = s->tail_runs; t.tail_atom = s->tail_atom; t.tail_scale = s->tail_scale;
@@ -1373,7 +1373,7 @@ void run_layer(jamun_sampler* s, size_t l, const float* x_in, int XSin, float* x
       }
       if (s->n_tail_tiles) {
         TailArgs t{};
-        t.deg = s->deg; t.esrc = s->esrc; t.egeo = s->egeo; t.h = h_l; t.h_kstride = s->h_kstride; t.x = x_in;
+        t.deg = s->deg; t.epair = s->epair; t.esrc = s->esrc; t.egeo = s->egeo; t.h = h_l; t.h_kstride = s->h_kstride; t.x = x_in;
         t.n_pad = s->n_pad; t.S = s->S; t.XS = XSin; t.n_k = s->hp.edge_attr_dim + 1; t.nt0 = L.p0.nt;
         t.tile_span = s->dg_tile_span; t.tile_atoms = s->dg_tile_atoms; t.tail_tiles = s->tail_tiles;
         t.n_tail_tiles = s->n_tail_tiles; t.n_tail = s->n_tail; t.n_runs = s->tail_runs; t.tail_atom = s->tail_atom; t.tail_scale = s->tail_scale;
@@ -1969,8 +1969,6 @@ int jamun_sampler_create(const jamun_model* m, float sigma, const jamun_topology
           s->dg_tstride = ((N + 31) & ~31) + 64;
           s->dg_T = dev_alloc<float>((size_t)n_k * 32 * s->dg_tstride);
           HIPCHECK(hipMemset(s->dg_T, 0, sizeof(float) * (size_t)n_k * 32 * s->dg_tstride));
-          s->epair = dev_alloc<int>((size_t)N * s->S + 64);
-          HIPCHECK(hipMemset(s->epair, 0, sizeof(int) * ((size_t)N * s->S + 64)));
           s->mf_err = dev_alloc<int>(1);
           HIPCHECK(hipMemset(s->mf_err, 0, sizeof(int)));
           HIPCHECK(hipHostMalloc((void**)&s->mf_err_host, sizeof(int), hipHostMallocDefault));
@@ -2006,6 +2004,8 @@ int jamun_sampler_create(const jamun_model* m, float sigma, const jamun_topology
     s->yc = dev_alloc<float>((size_t)N * 3);
     s->deg = dev_alloc<int>(N);
     s->esrc = dev_alloc<int>(NS);
+    s->epair = dev_alloc<int>(NS);  // (pair table of the matrix-formed kernels, written by k_geom with the edges)
+    HIPCHECK(hipMemset(s->epair, 0, sizeof(int) * NS));
     s->egeo = dev_alloc<float4>(NS);
     {
       std::vector<float> w1r_all, cmask_all;

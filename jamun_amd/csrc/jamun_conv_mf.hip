@@ -867,7 +867,6 @@ __global__ __launch_bounds__(MF_THREADS) void k_conv_mfi(MfiArgs a) {
     int dgv = 0;
     if (tid < 32 && tid < n_dst) dgv = a.deg[n0 + tid];
     constexpr int BT = MF_THREADS, DPP = BT / SPD, NP = 32 / DPP;
-    const int gsh = (SPD == 32) ? 32 * (lane >> 5) : 0;
     int ent[NP];
     const int slot0 = (n0 + tid / SPD) * a.S + tid % SPD, pstride = DPP * a.S;
     float hv[NP];
@@ -879,12 +878,13 @@ __global__ __launch_bounds__(MF_THREADS) void k_conv_mfi(MfiArgs a) {
     };
     load_k(k_of(0));
     float evx[NP], evy[NP], evz[NP];
-    int sjv[NP];
+    int sjv[NP], epv[NP];
 #pragma unroll
     for (int p = 0; p < NP; ++p) {
       const int g = tid + BT * p, i = g / SPD, t = g % SPD;
       const bool in = i < n_dst && t < a.S;
       sjv[p] = in ? a.esrc[slot0 + p * pstride] : 0;
+      epv[p] = in ? a.epair[slot0 + p * pstride] : 0;
       float4 ge = make_float4(0.f, 0.f, 0.f, 0.f);
       if (in) ge = a.egeo[slot0 + p * pstride];
       evx[p] = ge.x; evy[p] = ge.y; evz[p] = ge.z;
@@ -907,31 +907,14 @@ __global__ __launch_bounds__(MF_THREADS) void k_conv_mfi(MfiArgs a) {
       const int g = tid + BT * p, i = g / SPD, t = g % SPD;
       const int dg = deg_lds[i];
       const bool in = t < dg && t < a.S;
-      const int sj = sjv[p];
-      const bool bonded = in && sj < 0;
-      const int jraw = sj & 0x7fffffff, jl = jraw - s_base;
+      const int sj = sjv[p], ep = in ? epv[p] : 0;
+      const int jl = (sj & 0x7fffffff) - s_base;  // (bit 31: bonded)
       const bool valid = in && jl >= 0 && jl < 64;
-      bool active = valid;
-      int d0 = 0, d1 = 0;
-      const unsigned long long balb = __ballot(bonded);
-      const unsigned long long gmask = (SPD == 32) ? 0xffffffffull : ~0ull;
-      const int nb = __popcll((balb >> gsh) & gmask);
-      const int nb_max = RFL(SPD == 32 ? max(__popcll(balb & 0xffffffffull), __popcll(balb >> 32)) : __popcll(balb));
-      for (int b = 0; b < nb_max; ++b) {
-        const int lb = dg - nb + b;
-        const int jb = __shfl(jraw, (lb & (SPD - 1)) + gsh, 64);
-        const bool match = b < nb && valid && t < lb && jraw == jb;
-        const unsigned long long mb = (__ballot(match) >> gsh) & gmask;
-        if (b < nb && mb != 0ull) {
-          const int first = __ffsll((long long)mb) - 1;
-          if (t == lb) active = false;
-          if (t == first) {
-            if (d0 == 0) d0 = lb - t;
-            else if (d1 == 0) d1 = lb - t;
-            else atomicOr(a.err, 1);
-          }
-        }
-      }
+      // (edges of one ordered pair share one entry: matched by k_geom — MfArgs::epair, JAMUN_EP_* — as in k_conv_mf)
+      if (ep & JAMUN_EP_OVERFLOW) atomicOr(a.err, 1);
+      const int pa = (ep & 127) - 1, pb = ((ep >> 7) & 127) - 1;
+      const int d0 = pa >= 0 ? pa - t : 0, d1 = pb >= 0 ? pb - t : 0;  // lane distance to the pair's other edges (same lane group)
+      const bool active = valid && !((unsigned)ep & JAMUN_EP_OWNED);
       ent[p] = active ? (i * MF_ROWB + 2 * jl) | (d0 << 13) | (d1 << 19) : 128;
     }
     const float scC = pow2f(a.sC);
@@ -1088,7 +1071,6 @@ __global__ __launch_bounds__(MF_THREADS) void k_conv_mfx(MfxArgs a) {
     int dgv = 0;
     if (tid < 32 && tid < n_dst) dgv = a.deg[n0 + tid];
     constexpr int BT = MF_THREADS, DPP = BT / SPD, NP = 32 / DPP;
-    const int gsh = (SPD == 32) ? 32 * (lane >> 5) : 0;
     int ent[NP];
     const int slot0 = (n0 + tid / SPD) * a.S + tid % SPD, pstride = DPP * a.S;
     float hv[NP];
@@ -1099,12 +1081,13 @@ __global__ __launch_bounds__(MF_THREADS) void k_conv_mfx(MfxArgs a) {
     };
     load_k(k_of(0));
     float evx[NP], evy[NP], evz[NP];
-    int sjv[NP];
+    int sjv[NP], epv[NP];
 #pragma unroll
     for (int p = 0; p < NP; ++p) {
       const int g = tid + BT * p, i = g / SPD, t = g % SPD;
       const bool in = i < n_dst && t < a.S;
       sjv[p] = in ? a.esrc[slot0 + p * pstride] : 0;
+      epv[p] = in ? a.epair[slot0 + p * pstride] : 0;
       float4 ge = make_float4(0.f, 0.f, 0.f, 0.f);
       if (in) ge = a.egeo[slot0 + p * pstride];
       evx[p] = ge.x; evy[p] = ge.y; evz[p] = ge.z;
@@ -1130,31 +1113,14 @@ __global__ __launch_bounds__(MF_THREADS) void k_conv_mfx(MfxArgs a) {
       const int g = tid + BT * p, i = g / SPD, t = g % SPD;
       const int dg = deg_lds[i];
       const bool in = t < dg && t < a.S;
-      const int sj = sjv[p];
-      const bool bonded = in && sj < 0;
-      const int jraw = sj & 0x7fffffff, jl = jraw - s_base;
+      const int sj = sjv[p], ep = in ? epv[p] : 0;
+      const int jl = (sj & 0x7fffffff) - s_base;  // (bit 31: bonded)
       const bool valid = in && jl >= 0 && jl < 64;
-      bool active = valid;
-      int d0 = 0, d1 = 0;
-      const unsigned long long balb = __ballot(bonded);
-      const unsigned long long gmask = (SPD == 32) ? 0xffffffffull : ~0ull;
-      const int nb = __popcll((balb >> gsh) & gmask);
-      const int nb_max = RFL(SPD == 32 ? max(__popcll(balb & 0xffffffffull), __popcll(balb >> 32)) : __popcll(balb));
-      for (int b = 0; b < nb_max; ++b) {
-        const int lb = dg - nb + b;
-        const int jb = __shfl(jraw, (lb & (SPD - 1)) + gsh, 64);
-        const bool match = b < nb && valid && t < lb && jraw == jb;
-        const unsigned long long mb = (__ballot(match) >> gsh) & gmask;
-        if (b < nb && mb != 0ull) {
-          const int first = __ffsll((long long)mb) - 1;
-          if (t == lb) active = false;
-          if (t == first) {
-            if (d0 == 0) d0 = lb - t;
-            else if (d1 == 0) d1 = lb - t;
-            else atomicOr(a.err, 1);
-          }
-        }
-      }
+      // (edges of one ordered pair share one entry: matched by k_geom — MfArgs::epair, JAMUN_EP_* — as in k_conv_mf)
+      if (ep & JAMUN_EP_OVERFLOW) atomicOr(a.err, 1);
+      const int pa = (ep & 127) - 1, pb = ((ep >> 7) & 127) - 1;
+      const int d0 = pa >= 0 ? pa - t : 0, d1 = pb >= 0 ? pb - t : 0;  // lane distance to the pair's other edges (same lane group)
+      const bool active = valid && !((unsigned)ep & JAMUN_EP_OWNED);
       ent[p] = active ? (i * MF_ROWB + 2 * jl) | (d0 << 13) | (d1 << 19) : 128;
     }
     const float scC = pow2f(a.sC);
@@ -1419,7 +1385,6 @@ __global__ __launch_bounds__(MF_THREADS) void k_tail_form(TailArgs a) {
   }
   // ---- builder state (all eight waves): entry (column i, edge slot t); column i = (destination d = i >> kb_sh, hidden unit k0 + (i & (KB - 1)))
   constexpr int BT = MF_THREADS, DPP = BT / SPD, NP = 32 / DPP;
-  const int gsh = (SPD == 32) ? 32 * (lane >> 5) : 0;
   int ent[NP], slotv[NP];
   float hv[NP], evx[NP], evy[NP], evz[NP];
 #pragma unroll
@@ -1430,34 +1395,17 @@ __global__ __launch_bounds__(MF_THREADS) void k_tail_form(TailArgs a) {
     const bool in = d < n_dst && t < dg && t < a.S;
     const int slot = (n0 + (d < n_dst ? d : 0)) * a.S + (t < a.S ? t : 0);
     slotv[p] = slot;
-    const int sj = in ? a.esrc[slot] : 0;
+    const int sj = in ? a.esrc[slot] : 0, ep = in ? a.epair[slot] : 0;
     float4 ge = make_float4(0.f, 0.f, 0.f, 0.f);
     if (in) ge = a.egeo[slot];
     evx[p] = ge.x; evy[p] = ge.y; evz[p] = ge.z;
-    const bool bonded = in && sj < 0;
-    const int jraw = sj & 0x7fffffff, jl = jraw - s_base;
+    const int jl = (sj & 0x7fffffff) - s_base;  // (bit 31: bonded)
     const bool valid = in && jl >= 0 && jl < 64;
-    bool active = valid;
-    int d0 = 0, d1 = 0;
-    const unsigned long long balb = __ballot(bonded);
-    const unsigned long long gmask = (SPD == 32) ? 0xffffffffull : ~0ull;
-    const int nb = __popcll((balb >> gsh) & gmask);
-    const int nb_max = RFL(SPD == 32 ? max(__popcll(balb & 0xffffffffull), __popcll(balb >> 32)) : __popcll(balb));
-    for (int b = 0; b < nb_max; ++b) {
-      const int lb = dg - nb + b;
-      const int jb = __shfl(jraw, (lb & (SPD - 1)) + gsh, 64);
-      const bool match = b < nb && valid && t < lb && jraw == jb;
-      const unsigned long long mb = (__ballot(match) >> gsh) & gmask;
-      if (b < nb && mb != 0ull) {
-        const int first = __ffsll((long long)mb) - 1;
-        if (t == lb) active = false;
-        if (t == first) {
-          if (d0 == 0) d0 = lb - t;
-          else if (d1 == 0) d1 = lb - t;
-          else atomicOr(a.err, 1);
-        }
-      }
-    }
+    // (edges of one ordered pair share one entry: matched by k_geom — MfArgs::epair, JAMUN_EP_* — as in k_conv_mf)
+    if (ep & JAMUN_EP_OVERFLOW) atomicOr(a.err, 1);
+    const int pa = (ep & 127) - 1, pb = ((ep >> 7) & 127) - 1;
+    const int d0 = pa >= 0 ? pa - t : 0, d1 = pb >= 0 ? pb - t : 0;  // lane distance to the pair's other edges (same lane group)
+    const bool active = valid && !((unsigned)ep & JAMUN_EP_OWNED);
     ent[p] = active ? (i * MF_ROWB + 2 * jl) | (d0 << 13) | (d1 << 19) : 128;
   }
   auto load_k = [&](int st) {
@@ -1602,7 +1550,6 @@ __global__ __launch_bounds__(MF_THREADS) void k_tail_form_init(TailArgs a) {
   if (tid < 32) deg_lds[tid] = tid < n_dst ? a.deg[n0 + tid] : 0;
   LDS_BARRIER();
   constexpr int BT = MF_THREADS, DPP = BT / SPD, NP = 32 / DPP;
-  const int gsh = (SPD == 32) ? 32 * (lane >> 5) : 0;
   int ent[NP], slotv[NP];
   float hv[NP], evx[NP], evy[NP], evz[NP];
 #pragma unroll
@@ -1613,34 +1560,17 @@ __global__ __launch_bounds__(MF_THREADS) void k_tail_form_init(TailArgs a) {
     const bool in = d < n_dst && t < dg && t < a.S;
     const int slot = (n0 + (d < n_dst ? d : 0)) * a.S + (t < a.S ? t : 0);
     slotv[p] = slot;
-    const int sj = in ? a.esrc[slot] : 0;
+    const int sj = in ? a.esrc[slot] : 0, ep = in ? a.epair[slot] : 0;
     float4 ge = make_float4(0.f, 0.f, 0.f, 0.f);
     if (in) ge = a.egeo[slot];
     evx[p] = ge.x; evy[p] = ge.y; evz[p] = ge.z;
-    const bool bonded = in && sj < 0;
-    const int jraw = sj & 0x7fffffff, jl = jraw - s_base;
+    const int jl = (sj & 0x7fffffff) - s_base;  // (bit 31: bonded)
     const bool valid = in && jl >= 0 && jl < 64;
-    bool active = valid;
-    int d0 = 0, d1 = 0;
-    const unsigned long long balb = __ballot(bonded);
-    const unsigned long long gmask = (SPD == 32) ? 0xffffffffull : ~0ull;
-    const int nb = __popcll((balb >> gsh) & gmask);
-    const int nb_max = RFL(SPD == 32 ? max(__popcll(balb & 0xffffffffull), __popcll(balb >> 32)) : __popcll(balb));
-    for (int b = 0; b < nb_max; ++b) {
-      const int lb = dg - nb + b;
-      const int jb = __shfl(jraw, (lb & (SPD - 1)) + gsh, 64);
-      const bool match = b < nb && valid && t < lb && jraw == jb;
-      const unsigned long long mb = (__ballot(match) >> gsh) & gmask;
-      if (b < nb && mb != 0ull) {
-        const int first = __ffsll((long long)mb) - 1;
-        if (t == lb) active = false;
-        if (t == first) {
-          if (d0 == 0) d0 = lb - t;
-          else if (d1 == 0) d1 = lb - t;
-          else atomicOr(a.err, 1);
-        }
-      }
-    }
+    // (edges of one ordered pair share one entry: matched by k_geom — MfArgs::epair, JAMUN_EP_* — as in k_conv_mf)
+    if (ep & JAMUN_EP_OVERFLOW) atomicOr(a.err, 1);
+    const int pa = (ep & 127) - 1, pb = ((ep >> 7) & 127) - 1;
+    const int d0 = pa >= 0 ? pa - t : 0, d1 = pb >= 0 ? pb - t : 0;  // lane distance to the pair's other edges (same lane group)
+    const bool active = valid && !((unsigned)ep & JAMUN_EP_OWNED);
     ent[p] = active ? (i * MF_ROWB + 2 * jl) | (d0 << 13) | (d1 << 19) : 128;
   }
   auto load_k = [&](int st) {
@@ -1810,7 +1740,7 @@ __global__ __launch_bounds__(MF_THREADS) void k_tail_contract(TailArgs a) {
 }
 
 int launch_conv_tail(const TailArgs& a, hipStream_t st) {
-  if (a.XS != 216 || a.nt0 != 5 || a.S > 64 || a.n_tail_tiles < 1) return -1;
+  if (a.XS != 216 || a.nt0 != 5 || a.S > 64 || a.n_tail_tiles < 1 || !a.epair) return -1;
   if (a.S <= 32) hipLaunchKernelGGL((k_tail_form<32>), dim3(a.n_tail_tiles), dim3(MF_THREADS), MF_LDS_BYTES, st, a);
   else hipLaunchKernelGGL((k_tail_form<64>), dim3(a.n_tail_tiles), dim3(MF_THREADS), MF_LDS_BYTES, st, a);
   hipLaunchKernelGGL(k_tail_contract<false>, dim3(((a.n_tail + 31) / 32) * a.n_runs * 8), dim3(MF_THREADS), 0, st, a);
@@ -1818,7 +1748,7 @@ int launch_conv_tail(const TailArgs& a, hipStream_t st) {
 }
 
 int launch_conv_tail_init(const TailArgs& a, hipStream_t st) {
-  if (a.nt0 != 5 || a.S > 64 || a.n_tail_tiles < 1) return -1;
+  if (a.nt0 != 5 || a.S > 64 || a.n_tail_tiles < 1 || !a.epair) return -1;
   const size_t smem = 2 * 64 * MF_ROWB + 2 * MF_CB + 144;
   if (a.S <= 32) hipLaunchKernelGGL((k_tail_form_init<32>), dim3(a.n_tail_tiles), dim3(MF_THREADS), smem, st, a);
   else hipLaunchKernelGGL((k_tail_form_init<64>), dim3(a.n_tail_tiles), dim3(MF_THREADS), smem, st, a);
@@ -1871,7 +1801,7 @@ int launch_conv_mf(const MfArgs& a, int grid, hipStream_t st) {
 }
 
 int launch_conv_mfi(const MfiArgs& a, int grid, hipStream_t st) {
-  if (a.nt0 != 5 || a.S > 64 || (a.ut != 1 && a.ut != 2 && a.ut != 4)) return -1;
+  if (a.nt0 != 5 || a.S > 64 || (a.ut != 1 && a.ut != 2 && a.ut != 4) || !a.epair) return -1;
   const size_t smem = a.ut * 32 * MF_ROWB + 2 * MF_CB + 144;
   if (a.S <= 32) {
     if (a.ut == 1) hipLaunchKernelGGL((k_conv_mfi<32, 1>), dim3(grid), dim3(MF_THREADS), smem, st, a);
@@ -1886,7 +1816,7 @@ int launch_conv_mfi(const MfiArgs& a, int grid, hipStream_t st) {
 }
 
 int launch_conv_mfx(const MfxArgs& a, int grid, hipStream_t st) {
-  if (a.nt0 != 5 || a.S > 64) return -1;
+  if (a.nt0 != 5 || a.S > 64 || !a.epair) return -1;
   const size_t smem = 2 * 64 * MF_ROWB + 2 * MF_CB + 144;
   if (a.S <= 32) hipLaunchKernelGGL((k_conv_mfx<32>), dim3(grid), dim3(MF_THREADS), smem, st, a);
   else hipLaunchKernelGGL((k_conv_mfx<64>), dim3(grid), dim3(MF_THREADS), smem, st, a);

@@ -124,6 +124,7 @@ struct MfArgs {
 // embedding row, contracted with the input-times-weight table
 struct MfiArgs {
   const int* deg;
+  const int* epair;  // k_geom's pair table (MfArgs::epair)
   const int* esrc;
   const float4* egeo;
   const float* h;  // [hidden unit k (65 rows)][h_kstride]
@@ -152,6 +153,7 @@ struct MfiArgs {
 #define TAIL_NFT_INIT 8  // initial projector: formed tile 2 c + t (coefficient component c, channel tile t of the 64 embedding channels)
 struct TailArgs {
   const int* deg;
+  const int* epair;  // k_geom's pair table (MfArgs::epair)
   const int* esrc;
   const float4* egeo;
   const float* h;  // [hidden unit k][h_kstride]
@@ -187,6 +189,7 @@ int launch_conv_tail_init(const TailArgs& a, hipStream_t st);
 // initial projector formed from the feature rows (k_conv_mfx in jamun_conv_mf.hip): batches with many distinct embedding rows
 struct MfxArgs {
   const int* deg;
+  const int* epair;  // k_geom's pair table (MfArgs::epair)
   const int* esrc;
   const float4* egeo;
   const float* h;  // [hidden unit k (65 rows)][h_kstride]
