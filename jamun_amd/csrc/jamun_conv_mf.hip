@@ -1659,8 +1659,9 @@ __global__ __launch_bounds__(MF_THREADS) void k_tail_form_init(TailArgs a) {
 // with all loads of a hidden unit in flight at once; the eight partial tiles are summed through LDS in wave order: one partial slab per
 // run for the node update.
 template <bool INIT>  // INIT: the initial projector (formed tiles 2 c + t of k_tail_form_init, weight stream of k_conv_mfx)
-__global__ __launch_bounds__(MF_THREADS) void k_tail_contract(TailArgs a) {
-  __shared__ float red[8][32][33];
+#define TC_WAVES 16  // hidden units of a run in flight at once (one per wave; a wave's units run one after the other: 48 loads each)
+__global__ __launch_bounds__(64 * TC_WAVES) void k_tail_contract(TailArgs a) {
+  __shared__ float red[TC_WAVES][32][33];
   constexpr int NFT = INIT ? TAIL_NFT_INIT : TAIL_NFT;
   const int tid = threadIdx.x, lane = tid & 63, wave = RFL(tid >> 6);
   const int r = lane & 31, hh = lane >> 5;
@@ -1675,7 +1676,7 @@ __global__ __launch_bounds__(MF_THREADS) void k_tail_contract(TailArgs a) {
   auto aptr = [&](int k, int ft, int s2) { return a.P + ((((((size_t)k * n_ct + ctile) * NFT + ft) * 2 + s2) * 32 + r) * 4 + 2 * hh); };
   if constexpr (INIT) {
     // scalar outputs: formed tiles t = 0, 1 (component 0), blocks 20 t + 2 (2 n + s2); plane m: formed tiles 2 (1 + m) + t, blocks 40 + 4 t + 2 s2
-    for (int k = k_lo + wave; k < k_hi; k += 8) {
+    for (int k = k_lo + wave; k < k_hi; k += TC_WAVES) {
       const float4* __restrict__ wk = a.wx + (size_t)k * 48 * 64 + lane;
       float4 ah[4], al[4], bh[4], bl[4];
 #pragma unroll
@@ -1691,7 +1692,7 @@ __global__ __launch_bounds__(MF_THREADS) void k_tail_contract(TailArgs a) {
     }
   } else if (job < 5) {
     const int n = job;
-    for (int k = k_lo + wave; k < k_hi; k += 8) {
+    for (int k = k_lo + wave; k < k_hi; k += TC_WAVES) {
       const float4* __restrict__ wk = a.wm + (size_t)k * 124 * 64 + lane;
       float4 ah[10], al[10], bh[10], bl[10];
 #pragma unroll
@@ -1705,7 +1706,7 @@ __global__ __launch_bounds__(MF_THREADS) void k_tail_contract(TailArgs a) {
     }
   } else {
     const int m = job - 5;
-    for (int k = k_lo + wave; k < k_hi; k += 8) {
+    for (int k = k_lo + wave; k < k_hi; k += TC_WAVES) {
       const float4* __restrict__ wk = a.wmt + (size_t)k * 24 * 64 + lane;
       float4 ah[12], al[12], bh[12], bl[12];
 #pragma unroll
@@ -1723,12 +1724,12 @@ __global__ __launch_bounds__(MF_THREADS) void k_tail_contract(TailArgs a) {
   for (int q = 0; q < 16; ++q) red[wave][(q & 3) + 8 * (q >> 2) + 4 * hh][r] = acc[q];
   __syncthreads();
   // rows carry 2^(sX + sC - 14 - e(in-degree)) (tail_scale holds 2^-(sX + sC)), columns the weights' 2^sB_w
-  for (int idx = tid; idx < 32 * 32; idx += MF_THREADS) {
+  for (int idx = tid; idx < 32 * 32; idx += 64 * TC_WAVES) {
     const int row = idx >> 5, col = idx & 31, t2 = 32 * ctile + row;
     if (t2 >= a.n_tail) continue;
     float v = red[0][row][col];
 #pragma unroll
-    for (int w = 1; w < 8; ++w) v += red[w][row][col];
+    for (int w = 1; w < TC_WAVES; ++w) v += red[w][row][col];
     const int atom = a.tail_atom[t2];
     const int dg = a.deg[atom];
     const int edeg = dg > 0 ? exp_above((float)dg) : 1;
@@ -1743,7 +1744,7 @@ int launch_conv_tail(const TailArgs& a, hipStream_t st) {
   if (a.XS != 216 || a.nt0 != 5 || a.S > 64 || a.n_tail_tiles < 1 || !a.epair) return -1;
   if (a.S <= 32) hipLaunchKernelGGL((k_tail_form<32>), dim3(a.n_tail_tiles), dim3(MF_THREADS), MF_LDS_BYTES, st, a);
   else hipLaunchKernelGGL((k_tail_form<64>), dim3(a.n_tail_tiles), dim3(MF_THREADS), MF_LDS_BYTES, st, a);
-  hipLaunchKernelGGL(k_tail_contract<false>, dim3(((a.n_tail + 31) / 32) * a.n_runs * 8), dim3(MF_THREADS), 0, st, a);
+  hipLaunchKernelGGL(k_tail_contract<false>, dim3(((a.n_tail + 31) / 32) * a.n_runs * 8), dim3(64 * TC_WAVES), 0, st, a);
   return 0;
 }
 
@@ -1752,7 +1753,7 @@ int launch_conv_tail_init(const TailArgs& a, hipStream_t st) {
   const size_t smem = 2 * 64 * MF_ROWB + 2 * MF_CB + 144;
   if (a.S <= 32) hipLaunchKernelGGL((k_tail_form_init<32>), dim3(a.n_tail_tiles), dim3(MF_THREADS), smem, st, a);
   else hipLaunchKernelGGL((k_tail_form_init<64>), dim3(a.n_tail_tiles), dim3(MF_THREADS), smem, st, a);
-  hipLaunchKernelGGL(k_tail_contract<true>, dim3(((a.n_tail + 31) / 32) * a.n_runs * 8), dim3(MF_THREADS), 0, st, a);
+  hipLaunchKernelGGL(k_tail_contract<true>, dim3(((a.n_tail + 31) / 32) * a.n_runs * 8), dim3(64 * TC_WAVES), 0, st, a);
   return 0;
 }
 
