@@ -1582,7 +1582,11 @@ __global__ __launch_bounds__(64 * TP_WAVES) __attribute__((amdgpu_waves_per_eu(2
 void launch_tprod(const float* x, int XS, int n_atoms, int n_k, const float4* wt, const float4* wth, const float* gT, const float* cfT, float* T, int t_stride,
                   hipStream_t st) {
   const int tiles = (n_atoms + 31) / 32;
-  const int kg = std::min(n_k, std::max(1, 1024 / tiles));
+  // waves = tiles x kg runs of hidden units.  One wave per SIMD (1024 waves) is best while a wave's run stays below ~10 hidden units
+  // (136 tiles: 18.0 us against 20.0 with 2048 waves); a wave walks its units one after the other behind a one-unit weight prefetch, so
+  // with more tiles the runs are cut to ~9 units again, up to two waves per SIMD — the register budget of the kernel (33 x 256 atoms,
+  // 264 tiles: 36.7 -> 29.7 us; 296 tiles: 29.8 -> 27.4)
+  const int kg = std::min(n_k, std::max(1, std::min(std::max(1024 / tiles, 7), 2048 / tiles)));
   if (wth)
     hipLaunchKernelGGL(k_tprod_h, dim3((tiles * kg + TP_WAVES - 1) / TP_WAVES), dim3(64 * TP_WAVES), 0, st, x, XS, n_atoms, n_k, kg, wth, gT, cfT, T, t_stride);
   else
