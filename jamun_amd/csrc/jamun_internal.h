@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#define GEOM_LDS_ATOMS 1024  // k_geom / k_finalize keep a walker's coordinates in LDS up to this many atoms (12 KB)
 #define JAMUN_MAX_NEIGHBORS 32  // torch_geometric.nn.radius_graph default (src/jamun/model/denoiser.py:149)
 #define JAMUN_HROWS 65          // rows of the per-layer radial-MLP activation table: 64 hidden units + the bias row
 

@@ -77,8 +77,13 @@ __global__ void k_geom(float* __restrict__ y, const int* __restrict__ ptr, float
                        float* __restrict__ yc, int* __restrict__ deg, int* __restrict__ esrc,
                        float4* __restrict__ egeo, int* __restrict__ epair, LangevinPre pre) {
   __shared__ float cen[3];
+  // The walker's coordinates through LDS (molecules up to GEOM_LDS_ATOMS): the centre is a sum in atom order by three threads and the
+  // neighbour search reads every atom of the molecule per thread — as global loads both are chains of dependent round trips (a
+  // 166-atom molecule: 50 us of a launch that computes almost nothing).  Same values, same operations, same order: bit-identical.
+  __shared__ float s_pos[3 * GEOM_LDS_ATOMS];
   const int g = blockIdx.x;
   const int lo = ptr[g], hi = ptr[g + 1];
+  const bool in_lds = hi - lo <= GEOM_LDS_ATOMS;
   if (pre.v) {
     for (int i = lo + threadIdx.x; i < hi; i += blockDim.x) {
       float R[3];
@@ -92,24 +97,39 @@ __global__ void k_geom(float* __restrict__ y, const int* __restrict__ ptr, float
         yy = FADD(yy, FMUL(pre.k.half_delta, vh));
         pre.v[i * 3 + c] = vh;
         y[i * 3 + c] = yy;
+        if (in_lds) s_pos[(i - lo) * 3 + c] = yy;
       }
     }
     __syncthreads();  // (this walker's y is read below by this workgroup only)
+  } else if (in_lds) {
+    for (int a = lo * 3 + threadIdx.x; a < hi * 3; a += blockDim.x) s_pos[a - lo * 3] = y[a];
+    __syncthreads();
   }
   if (threadIdx.x < 3) {
     float s = 0.f;
     if (mean_center) {
-      for (int a = lo; a < hi; ++a) s = FADD(s, y[a * 3 + threadIdx.x]);
+      if (in_lds) for (int a = 0; a < hi - lo; ++a) s = FADD(s, s_pos[a * 3 + threadIdx.x]);
+      else for (int a = lo; a < hi; ++a) s = FADD(s, y[a * 3 + threadIdx.x]);
       float cnt = (float)(hi - lo);
       s = s / (cnt < 1.f ? 1.f : cnt);
     }
     cen[threadIdx.x] = s;
   }
   __syncthreads();
-  for (int a = lo * 3 + threadIdx.x; a < hi * 3; a += blockDim.x) yc[a] = FSUB(y[a], cen[a % 3]);
-  __syncthreads();  // yc of this graph is only read by this workgroup (global memory, same CU)
+  if (in_lds) {
+    for (int a = lo * 3 + threadIdx.x; a < hi * 3; a += blockDim.x) {
+      const float v = FSUB(s_pos[a - lo * 3], cen[a % 3]);
+      yc[a] = v;
+      s_pos[a - lo * 3] = v;  // (from here on: the centred coordinates)
+    }
+  } else {
+    for (int a = lo * 3 + threadIdx.x; a < hi * 3; a += blockDim.x) yc[a] = FSUB(y[a], cen[a % 3]);
+  }
+  __syncthreads();  // yc of this graph is only read by this workgroup (LDS, or global memory on the same CU)
+  // (the per-atom body once per address space: a pointer chosen at run time between LDS and global memory would compile to flat loads)
+  auto atoms = [&](auto rd) {  // rd(k): element k of the centred coordinates [atom][3]
   for (int i = lo + threadIdx.x; i < hi; i += blockDim.x) {
-    const float px = yc[i * 3], py = yc[i * 3 + 1], pz = yc[i * 3 + 2];
+    const float px = rd(i * 3), py = rd(i * 3 + 1), pz = rd(i * 3 + 2);
     const float sx = FMUL(px, c_in), sy = FMUL(py, c_in), sz = FMUL(pz, c_in);
     int count = 0, nr = 0;
     const size_t base = (size_t)i * S;
@@ -121,7 +141,7 @@ __global__ void k_geom(float* __restrict__ y, const int* __restrict__ ptr, float
 #pragma unroll
     for (int q = 0; q < 4; ++q) { bsrc[q] = (ep_fast && q < n_bnd) ? bond_in_src[bnd0 + q] : -1; twin[q] = -1; }
     for (int j = lo; j < hi; ++j) {
-      const float qx = yc[j * 3], qy = yc[j * 3 + 1], qz = yc[j * 3 + 2];
+      const float qx = rd(j * 3), qy = rd(j * 3 + 1), qz = rd(j * 3 + 2);
       float dx = FSUB(qx, px), dy = FSUB(qy, py), dz = FSUB(qz, pz);
       float d2 = FADD(FADD(FMUL(dx, dx), FMUL(dy, dy)), FMUL(dz, dz));
       if (d2 < r2) {
@@ -144,7 +164,7 @@ __global__ void k_geom(float* __restrict__ y, const int* __restrict__ ptr, float
     const int nr_rad = nr;
     for (int b = bond_in_ptr[i]; b < bond_in_ptr[i + 1]; ++b) {
       const int j = bond_in_src[b];
-      const float qx = yc[j * 3], qy = yc[j * 3 + 1], qz = yc[j * 3 + 2];
+      const float qx = rd(j * 3), qy = rd(j * 3 + 1), qz = rd(j * 3 + 2);  // (bonds stay inside the walker's molecule)
       float ex = FSUB(FMUL(qx, c_in), sx), ey = FSUB(FMUL(qy, c_in), sy), ez = FSUB(FMUL(qz, c_in), sz);
       float d = sqrtf(fmaf(ez, ez, fmaf(ey, ey, FMUL(ex, ex))));
       float dn = d < 1e-12f ? 1e-12f : d;
@@ -195,6 +215,9 @@ __global__ void k_geom(float* __restrict__ y, const int* __restrict__ ptr, float
       }
     }
   }
+  };
+  if (in_lds) atoms([&](int k) { return s_pos[k - lo * 3]; });
+  else atoms([&](int k) { return yc[k]; });
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -623,25 +646,33 @@ __global__ void k_finalize(const float* __restrict__ y, const float* __restrict_
                            const int* __restrict__ ptr, float c_skip, float c_out, float sigma2, int mean_center,
                            float* __restrict__ tmp, float* __restrict__ xhat, float* __restrict__ score, LangevinPost post) {
   __shared__ float cen[3];
+  __shared__ float s_tmp[3 * GEOM_LDS_ATOMS];  // (as k_geom: the centre is a sum in atom order by three threads)
   const int gi = blockIdx.x;
   const int lo = ptr[gi], hi = ptr[gi + 1];
-  for (int a = lo * 3 + threadIdx.x; a < hi * 3; a += blockDim.x) tmp[a] = FADD(FMUL(c_skip, yc[a]), FMUL(c_out, g[a]));
+  const bool in_lds = hi - lo <= GEOM_LDS_ATOMS;
+  for (int a = lo * 3 + threadIdx.x; a < hi * 3; a += blockDim.x) {
+    const float v = FADD(FMUL(c_skip, yc[a]), FMUL(c_out, g[a]));
+    if (in_lds) s_tmp[a - lo * 3] = v;
+    else tmp[a] = v;
+  }
   __syncthreads();
   if (threadIdx.x < 3) {
     float s = 0.f;
     if (mean_center) {
-      for (int a = lo; a < hi; ++a) s = FADD(s, tmp[a * 3 + threadIdx.x]);
+      if (in_lds) for (int a = 0; a < hi - lo; ++a) s = FADD(s, s_tmp[a * 3 + threadIdx.x]);
+      else for (int a = lo; a < hi; ++a) s = FADD(s, tmp[a * 3 + threadIdx.x]);
       float cnt = (float)(hi - lo);
       s = s / (cnt < 1.f ? 1.f : cnt);
     }
     cen[threadIdx.x] = s;
   }
   __syncthreads();
+  auto atoms = [&](auto rd) {  // (once per address space, as k_geom)
   for (int i = lo + threadIdx.x; i < hi; i += blockDim.x) {
     float xh[3], sc[3];
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-      xh[c] = FSUB(tmp[i * 3 + c], cen[c]);
+      xh[c] = FSUB(rd(i * 3 + c), cen[c]);
       sc[c] = FSUB(xh[c], y[i * 3 + c]) / sigma2;
       if (xhat) xhat[i * 3 + c] = xh[c];
       if (score) score[i * 3 + c] = sc[c];
@@ -659,6 +690,9 @@ __global__ void k_finalize(const float* __restrict__ y, const float* __restrict_
       }
     }
   }
+  };
+  if (in_lds) atoms([&](int k) { return s_tmp[k - lo * 3]; });
+  else atoms([&](int k) { return tmp[k]; });
 }
 
 // ------------------------------------------------------------------------------------------------
