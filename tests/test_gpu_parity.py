@@ -458,6 +458,73 @@ def test_tail_tiles_of_the_matrix_formed_conv(dev, golden_dir, case, monkeypatch
             assert (a - b).abs().max().item() <= 2e-5 * max(b.abs().max().item(), 1e-6), (case, l)
 
 
+def test_pair_table_with_more_than_four_bonds_into_one_atom(dev):
+    """k_geom matches the edges of one ordered (source, destination) pair once per forward (the pair table the matrix-formed kernels read).
+    For atoms with up to four bonds it notes the radial twin of each bond while it writes the radial edges; atoms with MORE bonds take a scan
+    over their slots.  A hub with six bonded in-edges (all inside the cutoff: six pairs of two edges) and a second hub whose bonds are
+    listed twice (three edges per pair) — against the general kernel, which treats every slot as an edge of its own."""
+    from jamun_amd import synth
+    from jamun_amd.data import WalkerBatch
+    from jamun_amd.model import Denoiser
+    from jamun_amd.native import NativeSampler
+
+    mols = []
+    for i, n in enumerate([17, 21, 33]):
+        m = synth.random_chain(n, seed=300 + i)
+        hub = torch.tensor([[3, 5, 7, 9, 11, 13], [0] * 6])  # six more bonds INTO atom 0
+        extra = torch.tensor([[2, 4, 6], [15] * 3])           # three bonds into atom 15, listed twice below
+        m["bonds"] = torch.cat([m["bonds"], hub, extra, extra], dim=1)
+        mols.append(m)
+    model = Denoiser.from_checkpoint_dict(_ckpt("strong")).to(dev)
+    batch = WalkerBatch.from_molecules(mols * 3).to(dev)
+    torch.manual_seed(23)
+    y = batch.pos + 0.04 * torch.randn(batch.pos.shape).to(dev)
+    fast = NativeSampler(model._native, 0.04, batch, dev)
+    general = NativeSampler(model._native, 0.04, batch, dev, tuning={"no_dg": 1})
+    assert fast.stats()["dg_mode"] == 4 and general.stats()["conv_path"] == 0
+    xf, xg = fast.xhat(y), general.xhat(y)
+    assert torch.isfinite(xf).all() and rmsd(xf, xg) <= RMSD_TOL_NM, rmsd(xf, xg)
+    for l in range(6):
+        a, b = fast.debug_read(0, l).cpu(), general.debug_read(0, l).cpu()
+        assert (a - b).abs().max().item() <= 2e-5 * max(b.abs().max().item(), 1e-6), l
+    fast.stats()  # (synchronises: a kernel that saw more edges of a pair than an entry holds would raise here)
+
+
+def test_geometry_of_a_molecule_above_the_lds_budget_of_k_geom(dev):
+    """k_geom / k_finalize keep a walker's coordinates in LDS up to 1024 atoms and read global memory above that: a 1100-atom chain beside a
+    small molecule — in-degrees against the stand-alone jamun_radius_graph (another kernel) plus the bonds, centred output, and the small
+    molecule's x-hat independent of its big neighbour."""
+    from jamun_amd import native, synth
+    from jamun_amd.data import WalkerBatch
+    from jamun_amd.model import Denoiser
+
+    big, small = synth.random_chain(1100, seed=7, min_dist=0.2), synth.random_chain(17, seed=8)
+    model = Denoiser.from_checkpoint_dict(_ckpt("strong")).to(dev)
+    batch = WalkerBatch.from_molecules([small, big, small]).to(dev)
+    torch.manual_seed(29)
+    y = batch.pos + 0.04 * torch.randn(batch.pos.shape).to(dev)
+    smp = model.sampler_for(batch, 0.04)
+    x = smp.xhat(y)
+    assert torch.isfinite(x).all()
+    ptr = torch.tensor([0, 17, 1117, 1134], dtype=torch.int32)
+    for lo, hi in ((0, 17), (17, 1117), (1117, 1134)):  # x-hat is centred per walker
+        assert x[lo:hi].double().mean(0).abs().max().item() < 1e-5
+    yc = native.mean_center(y, ptr.to(dev))
+    # the sampler's cutoff on unscaled coordinates, fp32 op for op (jamun_sampler_create; denoiser.py:116-136,149): sqrt(r^2 + 6 s^2) / c_in
+    f = np.float32
+    s2 = f(0.04) * f(0.04)
+    c_in = f(1.0) / np.sqrt(f(0.332) + f(6.0) * s2)
+    r_cut = float(np.sqrt(f(1.0) + f(6.0) * s2) / c_in)
+    _, deg_r = native.radius_graph(yc, r_cut, ptr.to(dev))
+    bonded_in = torch.zeros(1134, dtype=torch.int32)
+    for off, m in ((0, small), (17, big), (1117, small)):
+        bonded_in += torch.bincount(m["bonds"][1] + off, minlength=1134).int()
+    assert torch.equal(smp.debug_read(1).cpu().flatten().int(), deg_r.cpu() + bonded_in)
+    alone = WalkerBatch.from_molecules([small]).to(dev)
+    x_alone = model.xhat(alone.with_pos(y[:17]), 0.04).pos
+    assert rmsd(x[:17], x_alone) <= RMSD_TOL_NM / 10
+
+
 @pytest.mark.parametrize("case", ["chain33x4", "odd_starts_47", "mixed_40_46", "one_too_many"])
 def test_short_forming_window_of_the_matrix_formed_conv(dev, golden_dir, case):
     """k_conv_mf<SPD, 3>: when every whole tile's sources lie in the first 48 rows of its 64-row window (one 33-atom molecule per tile — the
