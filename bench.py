@@ -51,6 +51,8 @@ MCMC = dict(delta=0.04, friction=1.0, M=1.0, inverse_temperature=1.0, score_fn_c
 F32_MFMA_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
 F16_MFMA_PEAK_TFLOPS = 2500.0  # same guide, "Peak BF16/FP16 MFMA ~2.5 PF dense"
 HBM_PEAK_GBS = 8000.0         # same guide, "HBM3E peak BW" (spec; ~6.3 TB/s measured on a float4 copy)
+PROF_EVERY = 7  # HIP events around every 7th launch of the dominant kernel inside the timed region (jamun_profile_sample)
+PROF_READ = 1  # ... and read back after every repeat (deferring the reads was slower: the event pool keeps growing inside the timed region)
 MIN_TIMED_S = 10.0
 
 CONFIGS = {
@@ -369,7 +371,7 @@ def main():
         """profile: None (no events), "dominant" (events around the conv launches only), "all" (every kernel class)."""
         params = native.make_mcmc_params(steps, **MCMC)
         if profile == "dominant":
-            smp.profile_enable(True, classes=["conv0", "conv1"])  # (every bracketed launch costs two event records: only the dominant kernel)
+            pass  # (armed once, in front of the timed region: below)
         elif profile == "all":
             smp.profile_enable(True)
         return smp.walk("baoab", y, v, params, None, seed=1234 + rank, save_trajectory=True)
@@ -388,6 +390,11 @@ def main():
         walk(args.warmup)
     # HIP events only around the dominant kernel inside the timed region (timing all 16 launches of a step costs ~4 %)
     prof_mode = None if args.no_profile else "dominant"
+    if prof_mode:
+        # Every bracketed launch costs two event records (~3 % of the step with all five conv launches of a step timed): only the dominant
+        # kernel, and every PROF_EVERY-th of its launches — coprime to the launches per step, so every layer is visited (same box: 277–285 k
+        # with every launch timed, 287–290 k with every 7th, 293 k without events).  Armed ONCE, outside the timed region.
+        smp.profile_enable(True, classes=["conv0", "conv1"], every=PROF_EVERY)
     dts = []
     dt, (y_traj, score_traj, xhat_traj, xhat) = timed(args.steps, prof_mode)
     assert xhat_traj.shape[0] == args.steps and torch.isfinite(xhat_traj).all()
@@ -399,10 +406,10 @@ def main():
         torch.distributed.all_reduce(t_first, op=torch.distributed.ReduceOp.MAX)
     if reps is None:  # the same count on every rank: derived from the max-over-ranks time of the first repeat
         reps = int(min(5000, max(1, math.ceil(MIN_TIMED_S / max(float(t_first.item()), 1e-6)))))
-    for _ in range(reps - 1):
+    for it in range(reps - 1):
         dt, _o = timed(args.steps, prof_mode)
         dts.append(dt)
-        if prof_mode:
+        if prof_mode and ((it + 1) % PROF_READ == 0 or it == reps - 2):
             p2 = smp.profile_read()
             prof = {k: (prof[k][0] + p2[k][0], prof[k][1] + p2[k][1]) for k in prof}
     smp.profile_enable(False)

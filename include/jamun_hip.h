@@ -291,6 +291,11 @@ int jamun_sampler_stats(jamun_sampler* s, jamun_stats* out, void* stream);
 /* on = 0: off; 1: every class; otherwise a mask with bit (c + 1) set for each class c to time (event records are not free:
  * timing all 16 launches of a forward costs ~4 % of a step, the dominant class alone ~1 %). */
 int jamun_profile_enable(jamun_sampler* s, int32_t on);
+/* Sample instead of timing every launch: only every `every`-th launch of each enabled class gets its two event records (every >= 1;
+ * 1 = all, the default after jamun_sampler_create).  An event record sits between two launches of the stream and costs ~1.3 us of a
+ * 0.87 ms step each: the five hidden-layer conv launches of every step timed = 3 % of the step (bench.py: 295 k against 304 k
+ * conformations/s); a stride that is coprime to the launches of the class per forward still visits every layer. */
+int jamun_profile_sample(jamun_sampler* s, int32_t every);
 int jamun_profile_read(jamun_sampler* s, double* ms_total, int64_t* launches, void* stream);
 
 /* Diagnostic builds only (-DJAMUN_STAMP): summed s_memtime cycles per phase of the fused conv kernel

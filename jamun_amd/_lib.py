@@ -125,6 +125,7 @@ SYMBOLS = {
     "jamun_conv_block": (C.c_int, [_P, C.c_int32, _P, _P, _P]),
     "jamun_sampler_stats": (C.c_int, [_P, C.POINTER(jamun_stats), _P]),
     "jamun_profile_enable": (C.c_int, [_P, C.c_int32]),
+    "jamun_profile_sample": (C.c_int, [_P, C.c_int32]),
     "jamun_profile_read": (C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(C.c_int64), _P]),
     "jamun_debug_stamps": (C.c_int, [C.POINTER(C.c_uint64)]),
     "jamun_debug_read": (C.c_int, [_P, C.c_int32, C.c_int32, _P, _P]),

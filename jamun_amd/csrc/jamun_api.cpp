@@ -379,6 +379,8 @@ struct jamun_sampler {
   int64_t flop_ref_per_edge = 0, flop_exec = 0, conv_flop_exec_launch = 0;
   // optional per-kernel-class timing with HIP events on the launch stream (jamun_profile_*)
   unsigned prof_mask = 0;  // bit c: record HIP events around launches of profile class c
+  int prof_every = 1;      // ... around every prof_every-th launch of the class (jamun_profile_sample)
+  int prof_seen[JAMUN_PROF_NCLASS] = {0};
   std::vector<hipEvent_t> ev_pool;
   std::vector<std::pair<int, std::pair<int, int>>> ev_used;  // (class, (begin, end))
   size_t ev_next = 0;
@@ -1231,6 +1233,7 @@ struct ProfScope {
   jamun_sampler* s; int cls; hipStream_t st; int b = -1;
   ProfScope(jamun_sampler* s_, int cls_, hipStream_t st_) : s(s_), cls(cls_), st(st_) {
     if (!(s->prof_mask >> cls & 1u)) return;
+    if (s->prof_seen[cls]++ % s->prof_every != 0) return;
     while (s->ev_pool.size() < s->ev_next + 2) {
       hipEvent_t e;
       HIPCHECK(hipEventCreate(&e));
@@ -2402,6 +2405,14 @@ int jamun_profile_enable(jamun_sampler* s, int32_t on) {
     s->prof_mask = on == 1 ? 0xffffffffu : (unsigned)on >> 1;  // 1: every class; otherwise bit (c + 1) selects class c
     s->ev_used.clear();
     s->ev_next = 0;
+    for (int& n : s->prof_seen) n = 0;
+  });
+}
+
+int jamun_profile_sample(jamun_sampler* s, int32_t every) {
+  return guarded([&] {
+    if (!s || every < 1) throw Err(JAMUN_ERR_INVALID, "every must be >= 1");
+    s->prof_every = every;
   });
 }
 

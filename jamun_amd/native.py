@@ -227,13 +227,15 @@ class NativeSampler:
             _lib.check(self._lib.jamun_sampler_stats(self._h, C.byref(st), _stream()))
         return {k: getattr(st, k) for k, _ in st._fields_}
 
-    def profile_enable(self, on: bool = True, classes=None) -> None:
-        """Record HIP events around the forward's launches: all classes, or only the named ones (``_lib.PROF_CLASSES``)."""
+    def profile_enable(self, on: bool = True, classes=None, every: int = 1) -> None:
+        """Record HIP events around the forward's launches: all classes, or only the named ones (``_lib.PROF_CLASSES``); ``every`` > 1
+        samples every ``every``-th launch of a class instead of all of them (``jamun_profile_sample``)."""
         code = int(bool(on))
         if on and classes is not None:
             code = 0
             for c in classes:
                 code |= 1 << (_lib.PROF_CLASSES.index(c) + 1)
+        _lib.check(self._lib.jamun_profile_sample(self._h, int(every)))
         _lib.check(self._lib.jamun_profile_enable(self._h, code))
 
     def profile_read(self) -> dict:
