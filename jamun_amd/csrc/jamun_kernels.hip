@@ -594,11 +594,39 @@ __global__ __launch_bounds__(256) void k_head(HeadArgs a) {
   const int i = blockIdx.x * 8 + (threadIdx.x >> 5);
   // weights and the 8 feature rows go through LDS once: the contraction loops below then run at LDS latency instead of
   // one dependent global load per iteration
-  for (int idx = threadIdx.x; idx < a.mul0 * a.mul1; idx += 256) s_wg[idx] = a.w_gate[idx];
-  for (int idx = threadIdx.x; idx < a.mul1 * a.mul1; idx += 256) s_wv[idx] = a.w_vec[idx];
-  for (int idx = threadIdx.x; idx < 8 * XS; idx += 256) {
-    const size_t gidx = (size_t)blockIdx.x * 8 * XS + idx;
-    s_x[idx] = gidx < (size_t)a.n_atoms * XS ? a.x[gidx] : 0.f;
+  // (16-byte pieces, all of a thread's loads in flight before its first LDS store: as 4-byte loads in three loops the staging was a chain of
+  // ~26 round trips per thread — most of this kernel's 12.7 us; mul1 and XS are multiples of 4 for every supported irreps string)
+  if ((a.mul0 | a.mul1) & 3) {  // (odd channel counts: 4-byte pieces)
+    for (int idx = threadIdx.x; idx < a.mul0 * a.mul1; idx += 256) s_wg[idx] = a.w_gate[idx];
+    for (int idx = threadIdx.x; idx < a.mul1 * a.mul1; idx += 256) s_wv[idx] = a.w_vec[idx];
+    for (int idx = threadIdx.x; idx < 8 * XS; idx += 256) {
+      const size_t gidx = (size_t)blockIdx.x * 8 * XS + idx;
+      s_x[idx] = gidx < (size_t)a.n_atoms * XS ? a.x[gidx] : 0.f;
+    }
+  } else {
+    const int n_wg4 = (a.mul0 * a.mul1) >> 2, n_wv4 = (a.mul1 * a.mul1) >> 2, n_x4 = (8 * XS) >> 2;
+    const size_t x4_total = ((size_t)a.n_atoms * XS) >> 2;
+    const float4* __restrict__ g4 = reinterpret_cast<const float4*>(a.w_gate);
+    const float4* __restrict__ v4 = reinterpret_cast<const float4*>(a.w_vec);
+    const float4* __restrict__ x4 = reinterpret_cast<const float4*>(a.x) + (size_t)blockIdx.x * n_x4;
+    constexpr int HQ = 8;  // pieces per thread and round (256 threads x 8 x 16 B = 32 KB per round)
+    const int n_all = n_wg4 + n_wv4 + n_x4;
+    for (int base = 0; base < n_all; base += 256 * HQ) {
+      float4 v[HQ];
+#pragma unroll
+      for (int q = 0; q < HQ; ++q) {
+        const int idx = base + threadIdx.x + 256 * q;
+        v[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (idx < n_wg4) v[q] = g4[idx];
+        else if (idx < n_wg4 + n_wv4) v[q] = v4[idx - n_wg4];
+        else if (idx < n_all && (size_t)blockIdx.x * n_x4 + (idx - n_wg4 - n_wv4) < x4_total) v[q] = x4[idx - n_wg4 - n_wv4];
+      }
+#pragma unroll
+      for (int q = 0; q < HQ; ++q) {
+        const int idx = base + threadIdx.x + 256 * q;
+        if (idx < n_all) reinterpret_cast<float4*>(hs)[idx] = v[q];  // (s_wg | s_wv | s_x are contiguous)
+      }
+    }
   }
   __syncthreads();
   float gx = 0.f, gy = 0.f, gz = 0.f;
