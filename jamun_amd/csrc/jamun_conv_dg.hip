@@ -1473,6 +1473,12 @@ __global__ __launch_bounds__(64 * TP_WAVES) __attribute__((amdgpu_waves_per_eu(2
   const int row = min(a0 + r, n_atoms - 1);
   float4 xh[8], xl[8], w0[16], w1[16];
   float isc;
+  auto load_w = [&](float4 (&wv)[16], int k) {
+    const float4* __restrict__ wk = wth + (size_t)min(k, n_k - 1) * 16 * 64;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) wv[q] = wk[q * 64 + lane];
+  };
+  load_w(w0, k_lo);  // (requested with the feature rows, not behind their split: one round trip less per wave)
   {
     float4 xf[8][2];
     float mx = 0.f;
@@ -1512,12 +1518,6 @@ __global__ __launch_bounds__(64 * TP_WAVES) __attribute__((amdgpu_waves_per_eu(2
       xl[q] = make_float4(__uint_as_float(pl[0]), __uint_as_float(pl[1]), __uint_as_float(pl[2]), __uint_as_float(pl[3]));
     }
   }
-  auto load_w = [&](float4 (&wv)[16], int k) {
-    const float4* __restrict__ wk = wth + (size_t)min(k, n_k - 1) * 16 * 64;
-#pragma unroll
-    for (int q = 0; q < 16; ++q) wv[q] = wk[q * 64 + lane];
-  };
-  load_w(w0, k_lo);
   __shared__ float tp_tile[TP_WAVES][32 * TP_LD];
   float* __restrict__ tt = tp_tile[wave];
   // (inverse column scales of the weights: transposed output — lane = output channel r: one factor; else register 4 g4 + i = channel 8 g4 + 4 hh + i)

@@ -178,16 +178,16 @@ __global__ void k_geom(float* __restrict__ y, const int* __restrict__ ptr, float
     if (epair) {
       int wrd[4] = {0, 0, 0, 0};  // words of the twins' slots (fast path: written once, below)
       for (int t = nr_rad; t < nr; ++t) {
-        const int j = esrc[base + t] & 0x7fffffff;
-        int owner = -1;
+        int j = -1, owner = -1;
         if (ep_fast) {
 #pragma unroll
           for (int q = 0; q < 4; ++q)
-            if (q == t - nr_rad) owner = twin[q];
+            if (q == t - nr_rad) { owner = twin[q]; j = bsrc[q]; }  // (the bond's source from the register, not read back from the slot)
           // (several bonds from one source share its twin: twin[] holds the same slot for each; no radial twin: an earlier bonded slot)
           for (int o = nr_rad; owner < 0 && o < t; ++o)
             if ((esrc[base + o] & 0x7fffffff) == j) owner = o;
         } else {
+          j = esrc[base + t] & 0x7fffffff;
           for (int o = 0; owner < 0 && o < t; ++o)
             if ((esrc[base + o] & 0x7fffffff) == j) owner = o;
         }
