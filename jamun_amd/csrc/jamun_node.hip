@@ -115,6 +115,26 @@ __global__ __launch_bounds__(NH_T, LR ? 4 : 2) void k_node_update_h(NodeArgs a) 
   // ---- loads: scalar rows (<= 40 pieces of 16 bytes per atom and slab), vector rows (24), input features (<= 56); the first NH_S
   // slabs of everything are in flight together, summation order stays s = 0, 1, 2, ...
   float4 ms[3], mv[2], xv[4];
+  // (row / column factors of the balanced weights and the skip-mix weight of this lane's output column: requested here, with the slabs —
+  // as loads at their points of use they were round trips of their own in front of phase 1a, phase 1b and the epilogue)
+  // (the low-register variant keeps them at their points of use: it has no registers to hold them, and a second workgroup on its CU to wait behind)
+  auto ld_kg0 = [&](int q) { return *reinterpret_cast<const float4*>(a.kga0 + min(4 * (c16 + 16 * q), a.mul0 - 4)); };
+  auto ld_kg1 = [&](int q) { return *reinterpret_cast<const float4*>(a.kga1 + min(4 * ((c16 + 16 * q) & 7), a.mul1 - 4)); };
+  auto ld_kgx = [&](int q) { return *reinterpret_cast<const float4*>(a.kgx + min(4 * (c16 + 16 * q), a.XSin - 4)); };
+  auto ld_mw = [&]() { return (a.mix && col_ok_j) ? a.mix[scalar_j ? col_j : a.mul0 + col_j] : 0.f; };
+  auto ld_cinv = [&]() { return col_ok_j ? (scalar_j ? a.cg0[col_j] : a.cg1[col_j]) : 0.f; };  // 2^-sW of this lane's output column
+  float4 kg0[LR ? 1 : 3], kg1[LR ? 1 : 2], kgxv[LR ? 1 : 4];
+  float mw_j = 0.f, cinv_j = 0.f;
+  if constexpr (!LR) {
+#pragma unroll
+    for (int q = 0; q < 3; ++q) kg0[q] = ld_kg0(q);
+#pragma unroll
+    for (int q = 0; q < 2; ++q) kg1[q] = ld_kg1(q);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) kgxv[q] = ld_kgx(q);
+    mw_j = ld_mw();
+    cinv_j = ld_cinv();
+  }
   {
     float4 ls[NH_S][3], lv[NH_S][2];
     const float* __restrict__ p0 = a.partial0 + (size_t)(n0 + il) * w0;
@@ -196,10 +216,12 @@ __global__ __launch_bounds__(NH_T, LR ? 4 : 2) void k_node_update_h(NodeArgs a) 
   for (int q = 0; q < 3; ++q) {
     const int c = 4 * (c16 + 16 * q);
     float e[4] = {ms[q].x / degf, ms[q].y / degf, ms[q].z / degf, ms[q].w / degf};
+    const float4 k4 = LR ? ld_kg0(q) : kg0[LR ? 0 : q];
+    const float kg[4] = {k4.x, k4.y, k4.z, k4.w};  // (a piece is all activated scalars or all gate pre-activations: mul0 % 4 == 0)
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
       const int w = c + t;
-      if (w < a.mul0) { e[t] = (a.cL * (e[t] > 0.f ? e[t] : 0.01f * e[t])) * a.kga0[w]; mxS = fmaxf(mxS, fabsf(e[t])); }
+      if (w < a.mul0) { e[t] = (a.cL * (e[t] > 0.f ? e[t] : 0.01f * e[t])) * kg[t]; mxS = fmaxf(mxS, fabsf(e[t])); }
       else if (w < G0) s_gate[il * 32 + (w - a.mul0)] = a.cS / (1.f + expf(-e[t]));
     }
     ms[q] = make_float4(e[0], e[1], e[2], e[3]);
@@ -209,7 +231,7 @@ __global__ __launch_bounds__(NH_T, LR ? 4 : 2) void k_node_update_h(NodeArgs a) 
   for (int q = 0; q < 4; ++q) {
     const int c = 4 * (c16 + 16 * q);
     if (c < a.XSin) {  // x_in channels times the row factors of the skip weights (exact powers of two)
-      const float4 kg = *reinterpret_cast<const float4*>(a.kgx + c);
+      const float4 kg = LR ? ld_kgx(q) : kgxv[LR ? 0 : q];
       xv[q] = make_float4(xv[q].x * kg.x, xv[q].y * kg.y, xv[q].z * kg.z, xv[q].w * kg.w);
     }
     if (c < a.in0) mxS = fmaxf(mxS, max4(xv[q]));          // (in0 is a multiple of 4: a piece is all scalar or all vector)
@@ -242,9 +264,11 @@ __global__ __launch_bounds__(NH_T, LR ? 4 : 2) void k_node_update_h(NodeArgs a) 
   for (int q = 0; q < 2; ++q) {
     const int j = c16 + 16 * q, c = 4 * (j & 7);  // piece j: plane j / 8, channels c .. c + 3
     const float e[4] = {mv[q].x / degf, mv[q].y / degf, mv[q].z / degf, mv[q].w / degf};
+    const float4 k4 = LR ? ld_kg1(q) : kg1[LR ? 0 : q];
+    const float kg[4] = {k4.x, k4.y, k4.z, k4.w};
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
-      gv[q][t] = (j < 24 && c + t < a.mul1) ? (e[t] * s_gate[il * 32 + c + t]) * a.kga1[c + t] : 0.f;
+      gv[q][t] = (j < 24 && c + t < a.mul1) ? (e[t] * s_gate[il * 32 + c + t]) * kg[t] : 0.f;
       mxV = fmaxf(mxV, fabsf(gv[q][t]));
     }
   }
@@ -317,8 +341,7 @@ __global__ __launch_bounds__(NH_T, LR ? 4 : 2) void k_node_update_h(NodeArgs a) 
         }
       }
     }
-    const float mw = (a.mix && col_ok_j) ? a.mix[scalar ? col_j : a.mul0 + col_j] : 0.f;
-    const float cinv = col_ok_j ? (scalar ? a.cg0[col_j] : a.cg1[col_j]) : 0.f;  // 2^-sW of this lane's output column
+    const float mw = LR ? ld_mw() : mw_j, cinv = LR ? ld_cinv() : cinv_j;
     const float* __restrict__ isc = scalar ? isc0 : isc1;
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
@@ -336,7 +359,7 @@ size_t node_update_h_lds_bytes(const NodeArgs& a) {
   return (size_t)2 * 32 * (a.K0h * 2 + 16) + (size_t)2 * 96 * (a.K1h * 2 + 16) + sizeof(float) * (32 * 32 + 64);
 }
 bool node_update_h_supported(const NodeArgs& a) {
-  return ((a.mul0 + 31) >> 5) + 3 <= NH_T / 64 && a.wh0 != nullptr && a.wh1 != nullptr && a.kgx != nullptr && a.nt0 <= 5 && a.nt1 == 1 && a.mul1 <= 32 && (a.mul0 & 3) == 0 && (a.in0 & 3) == 0 && (a.XSin & 3) == 0 &&
+  return ((a.mul0 + 31) >> 5) + 3 <= NH_T / 64 && a.wh0 != nullptr && a.wh1 != nullptr && a.kgx != nullptr && a.nt0 <= 5 && a.nt1 == 1 && a.mul1 <= 32 && (a.mul1 & 3) == 0 && a.mul1 >= 4 && (a.mul0 & 3) == 0 && a.mul0 >= 4 && (a.in0 & 3) == 0 && (a.XSin & 3) == 0 &&
          a.XSin <= 256 && (a.K0h & 15) == 0 && (a.K1h & 15) == 0 && a.K0h >= a.mul0 + a.in0 && a.K1h >= a.mul1 + a.in1 &&
          ((a.K0h - a.mul0 - a.in0) & 3) == 0 && ((a.K1h - a.mul1 - a.in1) & 3) == 0 && node_update_h_lds_bytes(a) <= 64 * 1024;
 }
