@@ -966,6 +966,12 @@ __global__ __launch_bounds__(MF_THREADS) void k_conv_mfi(MfiArgs a) {
       for (int p = 0; p < NBW; ++p) RB[p] = wload(c0 + p * 1024);
     }
     LDS_BARRIER();  // selector, C(k0) complete
+    // (the selector does not depend on the hidden unit: its fragments are read once per segment, not once per step)
+    float4 sa[UT][4];
+#pragma unroll
+    for (int ut = 0; ut < UT; ++ut)
+#pragma unroll
+      for (int s = 0; s < 4; ++s) sa[ut][s] = lds_f4(I_S + ut * 32 * MF_ROWB + fo + 32 * s);
     for (int it = 0; it < nk; ++it) {
       const int nxt = wstream(k_of(it + 1));
       const int cb = I_C + (it & 1) * MF_CB + comp * 2 * MF_PL + fo;
@@ -978,11 +984,8 @@ __global__ __launch_bounds__(MF_THREADS) void k_conv_mfi(MfiArgs a) {
         f32x16 G;
 #pragma unroll
         for (int q = 0; q < 16; ++q) G[q] = 0.f;
-        float4 sa[4];
 #pragma unroll
-        for (int s = 0; s < 4; ++s) sa[s] = lds_f4(I_S + ut * 32 * MF_ROWB + fo + 32 * s);
-#pragma unroll
-        for (int s = 0; s < 4; ++s) { G = MFMA32H(sa[s], bl[s], G); G = MFMA32H(sa[s], bh[s], G); }
+        for (int s = 0; s < 4; ++s) { G = MFMA32H(sa[ut][s], bl[s], G); G = MFMA32H(sa[ut][s], bh[s], G); }
         float4 Ah[2], Al[2];
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {
