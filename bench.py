@@ -16,7 +16,8 @@ checkpoints are reachable offline):
     cfg3  configs[2]                uncapped-4AA shape: 33 atoms x 256 walkers per GPU (2048 on 8)
     cfg4  configs[3]                MDGen-4AA-like ragged batch: 256 walkers of 17..57 atoms
     cfg5  configs[4]                chignolin size with hydrogens: 166 atoms x 64 walkers per GPU (512 on 8)
-Arithmetic is fp32 end to end — VALU work in fp32, the dominant contraction either on v_mfma_f32_32x32x2_f32 (JAMUN_DG_FP32=1) or, by
+    cfg5h configs[4] as the reference feeds it (heavy atoms only, data/_mdtraj.py:60,218): 93 atoms x 128 walkers per GPU
+Arithmetic is fp32 end to end — VALU work in fp32, the dominant contraction either on v_mfma_f32_32x32x2_f32 (jamun_tuning.dg_fp32) or, by
 default, as "f16x3": each fp32 operand split exactly into two f16 terms, three f16 MFMAs per product with fp32 accumulation, error at
 the level of one fp32 rounding per product.  The reference's sampling precision is "32-true" and its bf16 mode is
 undefined, and the 1e-5 nm parity bar needs fp32-level accuracy.
@@ -62,6 +63,7 @@ CONFIGS = {
     "cfg3": dict(baseline="configs[2]", desc="uncapped-4AA-like 33-atom molecule (2048 walkers over 8 GPUs)", atoms=33, walkers=256),
     "cfg4": dict(baseline="configs[3]", desc="MDGen-4AA-like ragged batch, 17..57 atoms per walker", atoms=None, walkers=256),
     "cfg5": dict(baseline="configs[4]", desc="chignolin-size 166-atom molecule with hydrogens (512 walkers over 8 GPUs)", atoms=166, walkers=64),
+    "cfg5h": dict(baseline="configs[4] as the reference feeds it (data/_mdtraj.py:60,218: hydrogens stripped)", desc="chignolin-size 93-heavy-atom molecule", atoms=93, walkers=128),
 }
 
 
@@ -117,7 +119,7 @@ def _cpu_walk(mols, steps):
     return time.perf_counter() - t0
 
 
-def cpu_baseline(cfg: str, sample_walkers=8, frames=20, cfg1_exact=True):
+def cpu_baseline(cfg: str, sample_walkers=8, frames=8, cfg1_exact=True):
     """The CPU oracle (op-for-op PyTorch restatement of the reference path, kind="port") timed on this box's host cores:
     a BOUNDED SAMPLE of the benchmarked workload — `sample_walkers` walkers (not the 256 of the GPU line: at ~2.5
     conformations/s the full batch would take half an hour) x `frames` walk-jump frames after a warm-up forward; each frame
@@ -203,33 +205,150 @@ def secondary_rooflines(dev):
                     "bound": "hbm", "bytes": nbytes, "avg_launch_ms": dt * 1e3, "achieved": nbytes / dt / 1e9, "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": nbytes / dt / 1e9 / HBM_PEAK_GBS})
         del srcs
-        y, v, psi, R, sc = (torch.randn(n, 3, device=dev) for _ in range(5))
-        dt = _time_launches(lambda: native.baoab_pre(y, v, psi, R, params), 200)
-        b = n * 3 * 4 * 6  # read y, v, psi, noise (parity mode); write y, v
-        out.append({"kernel": "k_baoab_pre", "shape": f"{walkers} walkers x 17 atoms (launch-latency-bound at this size; host-supplied noise: +12 B/atom read)", "bound": "hbm",
-                    "bytes": b, "avg_launch_ms": dt * 1e3, "achieved": b / dt / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": b / dt / 1e9 / HBM_PEAK_GBS})
-        dt = _time_launches(lambda: native.baoab_post(v, psi, sc, params), 200)
-        b = n * 3 * 4 * 4  # read v, score; write v, psi
-        out.append({"kernel": "k_baoab_post", "shape": f"{walkers} walkers x 17 atoms (launch-latency-bound at this size; no frame save)", "bound": "hbm",
-                    "bytes": b, "avg_launch_ms": dt * 1e3, "achieved": b / dt / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": b / dt / 1e9 / HBM_PEAK_GBS})
     return out
 
 
-def _pmc_traffic(kernel: str, cfg: str = "cfg2"):
+def build_signature(stats=None):
+    """What a committed counter summary must share with the running build to be quoted: the digest of the library's sources and flags
+    (jamun_amd/csrc/build.py) and the kernel selection of the config (jamun_stats)."""
+    from jamun_amd.csrc import build as b
+
+    sig = {"source_digest": b._digest()}
+    if stats is not None:
+        sig.update({k: int(stats.get(k, 0)) for k in ("conv_path", "dg_mode", "init_path", "mf_nks", "ml_window", "dg_emu", "n_tail_tiles")})
+    return sig
+
+
+def _pmc_traffic(kernel: str, cfg: str = "cfg2", tag: str = "", stats=None):
+    """HBM-side bytes per launch of `kernel` from the newest committed PMC summary of this config (profiles/<round>_<cfg><tag>_pmc_traffic.json,
+    written by profiles/collect.sh) — only if that summary was collected from THIS build: its `_build` record must equal
+    build_signature().  Returns (bytes, file) or (None, stale file) or None."""
     import glob
 
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")))
-    # summaries of a config carry its name (r3b_cfg3_pmc_traffic.json); older cfg2 summaries carry none
-    files = [f for f in files if f"_{cfg}_" in os.path.basename(f)] or ([f for f in files if "_cfg" not in os.path.basename(f)] if cfg == "cfg2" else [])
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")), key=lambda f: (os.path.getmtime(f), f))
+    files = [f for f in files if f"_{cfg}{tag}_" in os.path.basename(f)]
+    want = build_signature(stats)
+    stale = None
     for f in reversed(files):
         try:
             d = json.load(open(f))
         except Exception:
             continue
+        if d.get("_build") != want:
+            stale = stale or os.path.basename(f)
+            continue
         for k, v in d.items():
             if isinstance(v, dict) and kernel in k and "FETCH_SIZE_KB_per_dispatch" in v:
                 return (2.0 * v["FETCH_SIZE_KB_per_dispatch"] + v.get("WRITE_SIZE_KB_per_dispatch", 0.0)) * 1024.0, os.path.basename(f)
-    return None
+    return (None, stale) if stale else None
+
+
+# ---- the metric as SURVEY.md section 8(d) defines it: wall time of Sampler.sample -----------------------------------------
+
+
+class _BenchDataset:
+    """What SaveTrajectoryCallback needs of a dataset: a label and the molecule (synthetic chains carry no atom names: .npy + .dcd)."""
+
+    def __init__(self, mol, label):
+        self.molecule, self._label = dict(mol, dataset_label=label), label
+
+    def label(self):
+        return self._label
+
+
+def e2e_legs(model, mols, dev, steps_list=(1000, 20000), writer_steps=(1000, 20000), num_batches=2):
+    """`Sampler.sample(num_batches=2, continue_chain=True)` through SingleMeasurementSampler / BAOAB — the call the reference's
+    MeasureSamplingTimeCallback brackets (callbacks/sampler/_measure_sampling_time.py:57-71, sampling/_sampler.py:53-98) — at
+    num_sampling_steps_per_batch = 1000 and 20000 (the shipped value, configs/experiment/sample_uncapped_2AA.yaml:16-17): wall time
+    around sample() including the initial-noise draw, both batches, unbatch_samples and every callback; with and without
+    SaveTrajectoryCallback (.npy + .dcd per chain and joined, written to a temporary directory that is removed afterwards)."""
+    import shutil
+    import tempfile
+
+    import torch
+
+    from jamun_amd.callbacks import SaveTrajectoryCallback
+    from jamun_amd.data import WalkerBatch
+    from jamun_amd.sampling import BAOAB, Sampler, SingleMeasurementSampler
+
+    label = "bench"
+    batch = WalkerBatch.from_molecules([dict(m, dataset_label=label) for m in mols])
+    out = {"num_batches": num_batches, "continue_chain": True, "legs": []}
+    t0 = time.perf_counter()
+    model.sampler_for(batch.to(dev), SIGMA)  # (cached per (topology, sigma): the walks below reuse it)
+    torch.cuda.synchronize()
+    out["sampler_create_s"] = time.perf_counter() - t0
+    for steps in sorted(set(steps_list) | set(writer_steps)):
+        for with_writer in (False, True):
+            if (with_writer and steps not in writer_steps) or (not with_writer and steps not in steps_list):
+                continue
+            tmp = None
+            cbs = []
+            if with_writer:
+                n_bytes = 12 * batch.num_nodes * steps * num_batches * 6  # per-chain + joined files, .npy and .dcd, with slack
+                tmp = tempfile.mkdtemp(prefix="jamun_bench_")
+                if shutil.disk_usage(tmp).free < 2 * n_bytes:
+                    out["legs"].append({"steps_per_batch": steps, "writer": True, "skipped": f"less than {2 * n_bytes >> 20} MiB free in {tmp}"})
+                    shutil.rmtree(tmp, ignore_errors=True)
+                    continue
+                cbs = [SaveTrajectoryCallback([_BenchDataset(mols[0], label)], output_dir=tmp)]
+            mcmc = BAOAB(steps=steps, save_trajectory=True, save_every_n_steps=1, v_init="gaussian", **MCMC)
+            bs = SingleMeasurementSampler(mcmc=mcmc, sigma=SIGMA)
+            sampler = Sampler(callbacks=cbs)
+            torch.manual_seed(7)
+            torch.cuda.reset_peak_memory_stats(dev)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            sampler.sample(model, bs, num_batches=num_batches, init_graphs=batch, continue_chain=True)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            leg = {"steps_per_batch": steps, "writer": bool(with_writer), "wall_s": dt,
+                   "conformations_per_s": batch.num_graphs * steps * num_batches / dt, "ms_per_sample": 1e3 * dt / (batch.num_graphs * steps * num_batches),
+                   "peak_device_mem_GB": torch.cuda.max_memory_allocated(dev) / 1e9}
+            if with_writer:
+                leg["writer_files"] = ".npy + .dcd per chain and joined (synthetic chains carry no atom names: no .pdb text)"
+                leg["writer_wait_s"] = getattr(cbs[0], "wait_s", None)
+                shutil.rmtree(tmp, ignore_errors=True)
+            out["legs"].append(leg)
+    return out
+
+
+def batch_sweep(model, cfg, atoms, dev, rank, walker_counts=(256, 512, 1024, 2048), steps=20, target_s=2.0):
+    """conformations/s of the fused walk on ONE GPU at growing walker counts (north_star's strong-scaling curve has 2048 walkers in total:
+    256 per GPU at N = 8, all 2048 on one at N = 1): rate(256) / rate(2048) is the strong-scaling efficiency a perfect 8-GPU run would show."""
+    import torch
+
+    from jamun_amd import native
+    from jamun_amd.data import WalkerBatch
+
+    rows = []
+    for w in walker_counts:
+        mols = workload_molecules(cfg, w, atoms, rank)
+        batch = WalkerBatch.from_molecules(mols).to(dev)
+        smp = model.sampler_for(batch, SIGMA)
+        torch.manual_seed(42)
+        y = batch.pos + SIGMA * torch.randn_like(batch.pos)
+        v = torch.randn_like(y)
+        params = native.make_mcmc_params(steps, **MCMC)
+        run = lambda: smp.walk("baoab", y, v, params, None, seed=99, save_trajectory=True)
+        run()
+        torch.cuda.synchronize()
+        dts = []
+        t_all = time.perf_counter()
+        while time.perf_counter() - t_all < target_s or len(dts) < 3:
+            t0 = time.perf_counter()
+            run()
+            torch.cuda.synchronize()
+            dts.append(time.perf_counter() - t0)
+        dt = statistics.median(dts)
+        rows.append({"walkers": w, "atoms_total": batch.num_nodes, "conformations_per_s": w * steps / dt, "ms_per_step": 1e3 * dt / steps, "repeats": len(dts)})
+        del smp, batch, y, v
+    out = {"rows": rows}
+    r = {x["walkers"]: x["conformations_per_s"] for x in rows}
+    if 256 in r and 2048 in r:
+        out["predicted_strong_scaling_efficiency_1_to_8"] = r[256] / r[2048]
+        out["note"] = "rate(256 walkers) / rate(2048 walkers) on one GPU: what 8 GPUs x 256 walkers would reach of 8 x the one-GPU rate on 2048 walkers; predicted, not measured on 8 GPUs"
+    return out
 
 
 # ---- self-launch ---------------------------------------------------------------------------------------------------------
@@ -310,6 +429,9 @@ def main():
     ap.add_argument("--separable", action="store_true", help="SeparableConv architecture (e3conv_separable.yaml) instead of the default e3conv; not the metric's config")
     ap.add_argument("--dry-run", action="store_true", help="rank plumbing only (gloo, no kernels): used by the CPU test of the self-launch")
     ap.add_argument("--dry-run-fail-rank", type=int, default=-1, help="with --dry-run: this rank exits with an error before the rendezvous (tests the supervision of the self-launch)")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the Sampler.sample wall-time legs (1000 / 20000 steps per batch, with and without the trajectory writer)")
+    ap.add_argument("--no-sweep", action="store_true", help="skip the one-GPU walker-count sweep (256 / 512 / 1024 / 2048 walkers)")
+    ap.add_argument("--signature", action="store_true", help="print the build signature of this config (source digest + kernel selection) as JSON and exit (profiles/collect.sh)")
     ap.add_argument("--strong", action="store_true", help="strong scaling: the config's walker count x 8 (2048 for cfg2/3/4) is the TOTAL, split over the ranks")
     args = ap.parse_args()
 
@@ -362,6 +484,9 @@ def main():
     model = Denoiser.from_checkpoint_dict(synth.synthetic_checkpoint(separable=args.separable)).to(dev)
     smp = model.sampler_for(batch, SIGMA)
     n = batch.num_nodes
+    if args.signature:
+        print(json.dumps(build_signature(smp.stats())), flush=True)
+        return
 
     torch.manual_seed(42 + rank)  # seed + rank, as cmdline/sample.py:86-88
     y = batch.pos + SIGMA * torch.randn_like(batch.pos)
@@ -484,7 +609,7 @@ def main():
             avg_pair = avg0 + mst / max(ct, 1)      # ... with the T pre-pass in front of it (k_tprod_h): one hidden layer's conv
             fused = stats["conv_path"] == 2  # one launch covers the scalar-row and the vector-row contraction of a hidden layer (conv1: tail tiles)
             flop = stats["conv0_flop_alg"] + (stats["conv1_flop_alg"] if fused else 0)
-            kname = ("k_conv_mf" if stats.get("dg_mode") == 4 else f"k_conv_dg<mode {stats.get('dg_mode')}>") if stats["conv_path"] == 2 else \
+            kname = ("k_conv_mf" if stats.get("dg_mode") == 4 else "k_conv_ml" if stats.get("dg_mode") == 5 else f"k_conv_dg<mode {stats.get('dg_mode')}>") if stats["conv_path"] == 2 else \
                 {1: "k_conv_fused"}.get(stats["conv_path"], "k_conv")
             f16x3 = stats.get("dg_emu", -1) == 1 and fused and stats.get("conv_flop_exec_launch", 0) > 0
             if f16x3 or (fused and stats.get("conv_flop_exec_launch", 0) > 0):
@@ -498,7 +623,8 @@ def main():
                 useful = stats.get("conv_flop_useful_launch", 0) / (avg0 * 1e-3) / 1e12 if avg0 > 0 else 0.0
                 out["roofline"] = {
                     "kernel": f"{kname} (hidden-layer conv: destination-grouped tensor-product contraction, scalar + vector rows in one launch"
-                              + ("; A operand formed on the matrix cores" if stats.get("dg_mode") == 4 else "; A operand formed on the vector ALUs") + ")",
+                              + ("; A operand formed on the matrix cores" if stats.get("dg_mode") in (4, 5) else "; A operand formed on the vector ALUs")
+                              + ("; two passes over the hidden units, block-sparse forming over the occupied 16-row source blocks" if stats.get("dg_mode") == 5 else "") + ")",
                     "bound": "mfma",
                     "mfma_dtype": "f16 (f16x3 emulation of fp32: operands split hi + lo, 3 MFMAs per product, fp32 accumulate)" if f16x3 else "f32",
                     "achieved": ex,
@@ -532,12 +658,15 @@ def main():
             # HBM-side bytes per launch from the committed PMC passes of the cfg2 command (profiles/collect.sh); rocprofv3
             # cannot run inside the timed process, so the newest committed summary is quoted, with its file name
             if args.atoms is None and args.walkers is None and not args.strong:
-                tr = _pmc_traffic(("k_conv_mf<" if stats.get("dg_mode") == 4 else "k_conv_dg<") if stats["conv_path"] == 2 else "k_conv<", args.config)
-                if tr is not None:
+                tr = _pmc_traffic(("k_conv_mf<" if stats.get("dg_mode") == 4 else "k_conv_ml<" if stats.get("dg_mode") == 5 else "k_conv_dg<") if stats["conv_path"] == 2 else "k_conv<",
+                                  args.config, "", stats)
+                if tr is not None and tr[0] is not None:
                     out["roofline"]["traffic"] = tr[0]
                     out["roofline"]["traffic_source"] = tr[1]
                     if out["roofline"].get("bytes_algorithmic_per_launch"):
                         out["roofline"]["traffic_ratio"] = tr[0] / out["roofline"]["bytes_algorithmic_per_launch"]
+                elif tr is not None:  # a summary exists, but from another build (other sources / another kernel selection): not quoted
+                    out["roofline"]["traffic_stale"] = tr[1]
         if prof is not None:
             if prof_all is not None:  # separate untimed pass (see above)
                 tot = sum(ms for ms, _ in prof_all.values())
@@ -548,8 +677,17 @@ def main():
             out["config"]["ref_association_tflops_equiv"] = stats["flop_ref_assoc"] * args.steps / dt_med / 1e12
             if stats.get("n_tail_tiles"):
                 out["config"]["tail_tiles"] = f"{stats['n_tail_tiles']} tiles / {stats['n_tail']} destinations through k_tail_form + k_tail_contract (kernel class conv1)"
-        if not args.no_secondary and world == 1:
+        if world == 1:
             del y_traj, score_traj, xhat_traj
+        if not args.no_e2e and world == 1 and args.config in ("cfg2", "cfg2r") and args.walkers is None and args.atoms is None and not args.strong:
+            # (the metric's config only: two 20 000-step batches of cfg2 are 35 s of GPU time per leg; other shapes take minutes)
+            out["e2e"] = e2e_legs(model, mols, dev)
+            ref = [l for l in out["e2e"]["legs"] if l.get("steps_per_batch") == 20000 and not l.get("writer") and "wall_s" in l]
+            if ref:
+                out["e2e"]["ratio_to_value_at_20000_steps_without_writer"] = ref[0]["conformations_per_s"] / out["value"]
+        if not args.no_sweep and world == 1 and args.config in ("cfg2", "cfg2r") and args.walkers is None and not args.strong:
+            out["batch_sweep"] = batch_sweep(model, args.config, args.atoms, dev, rank)
+        if not args.no_secondary and world == 1:
             out["secondary_rooflines"] = secondary_rooflines(dev)
         if cpu_line is not None:
             out["cpu_baseline"] = cpu_line

@@ -101,7 +101,8 @@ typedef struct jamun_tuning {
   int32_t dg_kgroups;   /* hidden-unit slices over XCD groups for the destination-grouped kernels: 0 (default = 1), 1, 2, 4, 8       */
   int32_t no_tail;      /* k_conv_mf: tiles with few destinations stay whole tiles (no k_tail_form / k_tail_contract)                 */
   int32_t no_short_k;   /* k_conv_mf: always four forming K-steps (64 source rows), also when every tile's sources fit the first 48      */
-  int32_t reserved[3];  /* must be zero                                                                                              */
+  int32_t no_ml;        /* hidden layers: not k_conv_ml (matrix-core forming for source spans of 63..167 atoms); k_conv_dg there              */
+  int32_t reserved[2];  /* must be zero                                                                                              */
 } jamun_tuning;
 
 typedef struct jamun_model jamun_model;     /* raw checkpoint tensors kept on the host          */
@@ -245,7 +246,9 @@ typedef struct jamun_stats {
   int32_t n_slices;       /* partial slabs per tile summed by the node update (max over tiles)          */
   int32_t conv_path;      /* hidden layers: 2 destination-grouped kernels on host-planned tiles (jamun_conv_mf.hip / jamun_conv_dg.hip),
                              0 general k_conv (any irreps, any topology; also SeparableConv's slot in this field) */
-  int32_t dg_mode;        /* destination-grouped kernel: 4 jamun_conv_mf.hip (A operand formed on the matrix cores and chained into the
+  int32_t dg_mode;        /* destination-grouped kernel: 5 jamun_conv_ml.hip (as 4, for source spans of 63..167 atoms: two passes over the hidden
+                             units with the vector / scalar channels resident, block-sparse forming over the occupied 16-row source blocks);
+                             4 jamun_conv_mf.hip (A operand formed on the matrix cores and chained into the
                              contraction; source spans up to 62 atoms); jamun_conv_dg.hip (A operand formed edge by edge on the vector ALUs):
                              0 two phases per hidden unit with resident source rows, 1 two passes over the hidden units (molecules above
                              ~80 atoms), 2 single phase (spans up to ~52 atoms), 3 single phase with one Y tile (spans up to ~73 atoms);
@@ -270,7 +273,7 @@ typedef struct jamun_stats {
   int64_t conv_bytes_alg_launch;  /* algorithmic HBM bytes of that launch: h~ of the layer, T, the weight stream once, the feature
                              rows once, the partial slabs written */
   int32_t mf_nks;         /* k_conv_mf: forming K-steps of 16 source rows per product (4; 3 when every tile's sources fit 48 rows; 0: other kernel) */
-  int32_t reserved0;
+  int32_t ml_window;      /* k_conv_ml (dg_mode 5): source rows of the instantiation in use (96, 128 or 168); 0: other kernel */
 } jamun_stats;
 /* Synchronises `stream`. */
 int jamun_sampler_stats(jamun_sampler* s, jamun_stats* out, void* stream);

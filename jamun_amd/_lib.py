@@ -54,7 +54,7 @@ class jamun_topology(C.Structure):
 
 class jamun_tuning(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("no_dg", "no_mf", "dg_fp32", "dg_no_alt", "dg_no_sp", "dg_no_sph", "no_mfi", "no_init_v", "node_fp32",
-                                         "edge_h_fp32", "dg_kgroups", "no_tail", "no_short_k")] + [("reserved", C.c_int32 * 3)]
+                                         "edge_h_fp32", "dg_kgroups", "no_tail", "no_short_k", "no_ml")] + [("reserved", C.c_int32 * 2)]
 
 
 class jamun_mcmc_params(C.Structure):
@@ -93,7 +93,7 @@ class jamun_stats(C.Structure):
         ("n_tail", C.c_int32),
         ("conv_bytes_alg_launch", C.c_int64),
         ("mf_nks", C.c_int32),
-        ("reserved0", C.c_int32),
+        ("ml_window", C.c_int32),
     ]
 
 
@@ -133,7 +133,7 @@ SYMBOLS = {
 
 PROF_CLASSES = ["geom", "edge_h", "conv0_init", "conv1_init", "conv0", "conv1", "node_update", "head_finalize", "tprod"]
 
-ABI_VERSION = 4  # jamun_version() of the library this binding was written for (struct layouts and signatures above)
+ABI_VERSION = 5  # jamun_version() of the library this binding was written for (struct layouts and signatures above)
 
 _lib: Optional[C.CDLL] = None
 
@@ -175,14 +175,17 @@ def load() -> C.CDLL:
         lib = C.CDLL(LIB_PATH)
     except OSError as e:  # pragma: no cover
         raise RuntimeError(f"could not load {LIB_PATH}: {e}") from e
-    for name, (res, args) in SYMBOLS.items():
-        fn = getattr(lib, name)  # AttributeError if the library does not export a declared symbol
-        fn.restype = res
-        fn.argtypes = args
+    # (the version first: an older library may lack a symbol declared below, and "rebuild" is the helpful message, not AttributeError)
+    lib.jamun_version.restype = C.c_int
+    lib.jamun_version.argtypes = []
     ver = int(lib.jamun_version())
     if ver != ABI_VERSION:
         raise RuntimeError(f"{LIB_PATH} reports ABI version {ver}, this binding is written for version {ABI_VERSION} "
                            "(struct layouts differ): rebuild with `python jamun_amd/csrc/build.py --force`")
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)  # AttributeError if the library does not export a declared symbol
+        fn.restype = res
+        fn.argtypes = args
     _lib = lib
     return lib
 

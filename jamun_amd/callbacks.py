@@ -55,7 +55,8 @@ class SaveTrajectoryCallback:
     three use the running index; ``npy_index_restarts_per_batch=True`` reproduces the reference's files exactly."""
 
     def __init__(self, datasets: Sequence, sample_key: str = "xhat_traj", output_dir: str = "sampler", write_pdb: bool = True,
-                 write_dcd: bool = True, save_true_trajectory: bool = False, npy_index_restarts_per_batch: bool = False, **_):
+                 write_dcd: bool = True, save_true_trajectory: bool = False, npy_index_restarts_per_batch: bool = False,
+                 async_write: bool = True, **_):
         labels = []
         self.datasets = {}
         for d in datasets:
@@ -71,6 +72,13 @@ class SaveTrajectoryCallback:
         self.npy_index_restarts_per_batch = npy_index_restarts_per_batch
         self.chains: Dict[str, List[np.ndarray]] = {l: [] for l in self.labels}  # per label: list of [n, T, 3]
         self.num_chains_seen = {l: 0 for l in self.labels}
+        # Files are written on ONE side thread, in submission order, while the next batch walks on the GPU (the walk is a single native call
+        # that releases the GIL; numpy's file writes release it too): a 20 000-step batch of 256 dipeptides is 1 GB per key, and its files
+        # take as long to write as the GPU needs for the walk.  on_sample_end (and flush) wait for the writer; wait_s is that time.
+        self.async_write = bool(async_write)
+        self._pool = None
+        self._pending: list = []
+        self.wait_s = 0.0
 
     def _dir(self, label: str, ext: str) -> str:
         d = os.path.join(self.output_dir, label, "predicted_samples", ext)
@@ -137,17 +145,52 @@ class SaveTrajectoryCallback:
             gathered = dist.gather_ragged(block, dst=0, device=sampler.device)
             if gathered is None:
                 continue
-            new = [c for g in gathered for c in g.detach().cpu().numpy()]
-            start = len(self.chains[label])
-            self.chains[label].extend(new)
-            for i, arr in enumerate(new, start=start):
-                self._write_chain(label, i, arr, npy_index=(i - start) if self.npy_index_restarts_per_batch else None)
-            if self.chains[label]:
-                self._write_chain(label, "joined", np.concatenate(self.chains[label], axis=1))  # "b n t c -> n (b t) c"
-            self.num_chains_seen[label] = len(self.chains[label])
+            blocks = [self._to_host(g) for g in gathered]  # (pinned staging: one contiguous D2H copy per block)
+            start = self.num_chains_seen[label]
+            self.num_chains_seen[label] = start + sum(int(b.shape[0]) for b in blocks)
+            self._submit(self._write_batch, label, blocks, start)
+
+    @staticmethod
+    def _to_host(t: torch.Tensor) -> np.ndarray:
+        t = t.detach()
+        if t.is_cuda:
+            buf = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+            buf.copy_(t, non_blocking=True)
+            torch.cuda.current_stream(t.device).synchronize()
+            return buf.numpy()
+        return t.contiguous().numpy()
+
+    def _write_batch(self, label: str, blocks: List[np.ndarray], start: int) -> None:
+        new = [c for b in blocks for c in b]
+        self.chains[label].extend(new)
+        for i, arr in enumerate(new, start=start):
+            self._write_chain(label, i, arr, npy_index=(i - start) if self.npy_index_restarts_per_batch else None)
+        if self.chains[label]:
+            self._write_chain(label, "joined", np.concatenate(self.chains[label], axis=1))  # "b n t c -> n (b t) c"
+
+    def _submit(self, fn, *args) -> None:
+        if not self.async_write:
+            fn(*args)
+            return
+        if self._pool is None:
+            from concurrent.futures import ThreadPoolExecutor
+
+            self._pool = ThreadPoolExecutor(max_workers=1, thread_name_prefix="jamun-writer")
+        self._pending.append(self._pool.submit(fn, *args))
+
+    def flush(self) -> None:
+        """Wait for the files of every batch handed over so far (errors of the writer thread surface here)."""
+        t0 = time.perf_counter()
+        pending, self._pending = self._pending, []
+        for fut in pending:
+            fut.result()
+        self.wait_s += time.perf_counter() - t0
 
     def on_sample_end(self, sampler):
-        pass  # the reference only uploads the joined files to wandb here (_save_trajectory.py:64-76): out of scope
+        self.flush()  # (the reference only uploads the joined files to wandb here, _save_trajectory.py:64-76: out of scope)
+        if self._pool is not None:
+            self._pool.shutdown(wait=True)
+            self._pool = None
 
 
 class TrajectoryMetricCallback:

@@ -347,6 +347,9 @@ struct jamun_sampler {
   // destinations at a time (k_tail_form / k_tail_contract) instead of as whole tiles of k_conv_mf; the initial projector keeps them as tiles
   int n_tail_tiles = 0, n_tail = 0, tail_runs = 0;
   int mf_nks = 4;  // forming K-steps of k_conv_mf (3: every whole tile's sources lie in the first 48 rows of its window)
+  int ml_window = 0;  // mode 5 (jamun_conv_ml.hip): source rows of the instantiation (96, 128, 168)
+  unsigned long long* ml_count = nullptr;  // device: v_mfma_f32_32x32x16_f16 executed by k_conv_ml since create (depends on the occupied source blocks)
+  int64_t ml_launches = 0;                 // ... over this many launches
   int4* tail_tiles = nullptr;
   int* tail_atom = nullptr;
   float* tail_scale = nullptr;
@@ -388,7 +391,7 @@ struct jamun_sampler {
   ~jamun_sampler() {
     hipFree(ptr); hipFree(bond_in_ptr); hipFree(bond_in_src); hipFree(x_emb); hipFree(mu);
     hipFree(atom_uid); hipFree(w1r_all); hipFree(cmask_all); hipFree(w1h_all); hipFree(w1isc_all);
-    hipFree(epair); hipFree(dg_tile_atoms); hipFree(dg_tile_span); hipFree(dg_segs); hipFree(dg_atom_nslab); hipFree(dg_T); hipFree(mf_err);
+    hipFree(epair); hipFree(dg_tile_atoms); hipFree(dg_tile_span); hipFree(dg_segs); hipFree(dg_atom_nslab); hipFree(dg_T); hipFree(mf_err); hipFree(ml_count);
     hipFree(tail_tiles); hipFree(tail_atom); hipFree(tail_scale); hipFree(tail_P); hipFree(init_segs); hipFree(init_atom_nslab);
     if (mf_err_host) hipHostFree(mf_err_host);
     for (auto& L : layers) {
@@ -1385,6 +1388,29 @@ void run_layer(jamun_sampler* s, size_t l, const float* x_in, int XSin, float* x
         ProfScope pt(s, JAMUN_PROF_CONV1, st);
         if (launch_conv_tail(t, st) != 0) throw Err(JAMUN_ERR_INVALID, "tail-tile conv launch failed (configuration not supported)");
       }
+    } else if (l > 0 && s->dg_on && s->dg_mode == 5) {
+      MlArgs f{};
+      f.deg = s->deg; f.epair = s->epair; f.esrc = s->esrc; f.egeo = s->egeo; f.h = h_l; f.h_kstride = s->h_kstride; f.x = x_in;
+      f.n_pad = s->n_pad; f.S = s->S; f.XS = XSin; f.n_atoms = s->n_atoms;
+      f.tile_span = s->dg_tile_span; f.tile_atoms = s->dg_tile_atoms; f.segs = s->dg_segs; f.max_segs = s->dg_max_segs; f.nt0 = L.p0.nt;
+      f.window = s->ml_window;
+      f.wm = L.dg.wm; f.Tt = s->dg_T; f.t_stride = s->dg_tstride; f.sB = L.dg.sB; f.sTw = L.dg.sTw;
+      f.gx = L.dg.gx; f.cf0 = L.dg.cf0; f.cf1 = L.dg.cf1;
+      {
+        int e3 = 0;
+        std::frexp(1.5 * (double)L.dg.hmax2, &e3);  // 3 max|h~| < 2^e3
+        f.sC = std::max(-40, std::min(40, 14 - e3));
+      }
+      f.partial0 = s->partial0; f.partial1 = s->partial1; f.err = s->mf_err; f.mfma_count = s->ml_count;
+      {
+        ProfScope pt(s, JAMUN_PROF_TPROD, st);
+        launch_tprod(x_in, XSin, s->n_atoms, s->hp.edge_attr_dim + 1, L.dg.wt, L.dg.wth, L.dg.gT, L.dg.cfT, s->dg_T, s->dg_tstride, st);
+      }
+      {
+        ProfScope ps(s, JAMUN_PROF_CONV0, st);
+        if (launch_conv_ml(f, s->dg_grid, st) != 0) throw Err(JAMUN_ERR_INVALID, "large-span matrix-formed conv launch failed (configuration not supported)");
+        ++s->ml_launches;
+      }
     } else if (l > 0 && s->dg_on) {
       DgArgs f{};
       f.deg = s->deg; f.esrc = s->esrc; f.egeo = s->egeo; f.h = h_l; f.h_kstride = s->h_kstride; f.x = x_in;
@@ -1626,7 +1652,7 @@ SegPlan plan_segments(int cus, int ng, int n_k, int N, const std::vector<int2>& 
 extern "C" {
 
 const char* jamun_last_error(void) { return g_err.c_str(); }
-int jamun_version(void) { return 4; }
+int jamun_version(void) { return 5; }
 
 int jamun_model_create(const jamun_hparams* hp, const jamun_tensor* tensors, int32_t n_tensors, jamun_model** out) {
   return guarded([&] {
@@ -1659,6 +1685,7 @@ int jamun_sampler_create(const jamun_model* m, float sigma, const jamun_topology
     if (tuning) tn = *tuning;
     if (tn.dg_kgroups != 0 && tn.dg_kgroups != 1 && tn.dg_kgroups != 2 && tn.dg_kgroups != 4 && tn.dg_kgroups != 8)
       throw Err(JAMUN_ERR_INVALID, "jamun_tuning.dg_kgroups must be 0 (default), 1, 2, 4 or 8");
+    if (tn.reserved[0] != 0 || tn.reserved[1] != 0) throw Err(JAMUN_ERR_INVALID, "jamun_tuning.reserved must be zero");
     if (!(sigma > 0)) throw Err(JAMUN_ERR_INVALID, "sigma must be positive");
     if (topo->n_atoms < 1 || topo->n_graphs < 1) throw Err(JAMUN_ERR_INVALID, "empty walker batch");
     const jamun_hparams& hp = m->hp;
@@ -1715,7 +1742,8 @@ int jamun_sampler_create(const jamun_model* m, float sigma, const jamun_topology
     {
       const std::pair<const char*, int (*)()> lds_attr[] = {{"k_conv", conv_set_max_lds}, {"k_node_update", node_update_set_max_lds},
                                                             {"k_conv_init_v", conv_initv_set_max_lds}, {"k_conv_dg", conv_dg_set_max_lds},
-                                                            {"jamun_conv_mf.hip", conv_mf_set_max_lds}, {"jamun_sepconv.hip", sep_conv_set_max_lds}};
+                                                            {"jamun_conv_mf.hip", conv_mf_set_max_lds}, {"jamun_conv_ml.hip", conv_ml_set_max_lds},
+                                                            {"jamun_sepconv.hip", sep_conv_set_max_lds}};
       for (auto& f : lds_attr)
         if (f.second() != 0)
           throw Err(JAMUN_ERR_HIP, std::string("hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed for ") + f.first + ": " + hipGetErrorString(hipGetLastError()));
@@ -1908,6 +1936,32 @@ int jamun_sampler_create(const jamun_model* m, float sigma, const jamun_topology
             n_chunks = nc2; span_max = sm2; s->dg_row_blocks = false; s->dg_mode = 4;
           }
         }
+        // ... and for larger spans (molecules of 63 .. 167 atoms) the two-pass, block-sparse variant jamun_conv_ml.hip: whole molecules as
+        // spans of up to 167 rows; edge strides 33..40 (32 radial slots + bonded in-edges); f16x3 only
+        if ((s->dg_mode == 0 || s->dg_mode == 1 || s->dg_mode == 3) && s->dg_emu && !tn.no_mf && !tn.no_ml && s->layers.size() > 1 && s->layers[1].dg.wm &&
+            s->S >= 33 && s->S <= 40) {
+          std::vector<int2> a2, s2;
+          std::vector<int> c2;
+          int nc2 = 0, sm2 = 0;
+          bool rb2 = false;
+          plan_tiles(topo->ptr, graph_of, N, 167, a2, s2, c2, nc2, sm2, rb2);
+          int mult = 0, need = 0;
+          {
+            std::vector<std::pair<int64_t, int64_t>> bb;
+            for (int b = 0; b < topo->n_bonds; ++b) bb.push_back({topo->bond_src[b], topo->bond_dst[b]});
+            std::sort(bb.begin(), bb.end());
+            for (size_t i = 0, j = 0; i < bb.size(); i = j) {
+              while (j < bb.size() && bb[j] == bb[i]) ++j;
+              mult = std::max(mult, (int)(j - i));
+            }
+            for (auto& sp : s2) need = std::max(need, sp.y - (sp.x & ~1));
+          }
+          const int window = conv_ml_window(need);
+          if (!rb2 && window > 0 && mult <= 2 && (int64_t)(hp.edge_attr_dim + 1) * 32 * (((int64_t)N + 31 & ~31) + 64) * 4 < ((int64_t)1 << 40)) {
+            t_atoms.swap(a2); t_span.swap(s2); t_chunk.swap(c2);
+            n_chunks = nc2; span_max = sm2; s->dg_row_blocks = false; s->dg_mode = 5; s->ml_window = window;
+          }
+        }
         s->dg_RS = std::max((span_max + 3) & ~3, 16);  // (>= 16 rows: the segment-end staging tile of the forming waves aliases the source rows)
         s->dg_n_tiles = (int)t_atoms.size();
         // k-slices over XCD groups (jamun_tuning.dg_kgroups = 1, 2, 4, 8).  Measured on MI355X (cfg2, profiles/r2*): 1 slice 0.317 ms per
@@ -1964,7 +2018,11 @@ int jamun_sampler_create(const jamun_model* m, float sigma, const jamun_topology
         s->dg_atom_nslab = dev_upload(P.atom_nslab);
         s->dg_tile_atoms = dev_upload(t_atoms);
         s->dg_tile_span = dev_upload(t_span);
-        if (s->dg_mode == 4) {
+        if (s->dg_mode == 5) {
+          s->ml_count = dev_alloc<unsigned long long>(1);
+          HIPCHECK(hipMemset(s->ml_count, 0, sizeof(unsigned long long)));
+        }
+        if (s->dg_mode == 4 || s->dg_mode == 5) {
           int need = 0;  // rows of the window a tile's sources reach (the window starts at an even atom)
           for (size_t t = 0; t < t_span.size(); ++t)
             if (!is_tail[t]) need = std::max(need, t_span[t].y - (t_span[t].x & ~1));
@@ -1987,7 +2045,7 @@ int jamun_sampler_create(const jamun_model* m, float sigma, const jamun_topology
         if (!tn.no_init_v && !s->dg_row_blocks && s->layers[0].tt2 != nullptr && s->layers[0].p0.nt == 5 && s->dg_RS <= 170) {
           // (one buffer only for the large-molecule plan: measured on the ragged 17-57 atom batch the MFMA table kernel is 10 %
           // faster than the one-buffer variant, on 166-atom molecules — where it falls back to source row blocks — 2.1x slower)
-          for (int nbuf = 2; nbuf >= (s->dg_mode == 1 ? 1 : 2) && !s->initv_on; --nbuf)
+          for (int nbuf = 2; nbuf >= ((s->dg_mode == 1 || s->dg_mode == 5) ? 1 : 2) && !s->initv_on; --nbuf)
             if (conv_initv_lds_bytes(s->dg_RS, pmax, nbuf) <= JAMUN_MAX_DYN_LDS) { s->initv_on = true; s->initv_nbuf = nbuf; }
         }
         // ... or, on the tiles of k_conv_mf (spans within one K = 64 window) and with at most 32 distinct embedding rows, the same
@@ -2090,7 +2148,7 @@ int jamun_sampler_create(const jamun_model* m, float sigma, const jamun_topology
         // (32768 FLOP: 50 groups of 16 inputs x 3 products) + 72 v_mfma_f32_16x16x32_f16 (16384 FLOP); + 60 fp32 units per (32 atoms, k)
         // in the T pre-pass
         // (mode 4, jamun_conv_mf.hip: 414 v_mfma_f32_32x32x16_f16 per (tile, k): 228 forming + 186 contraction)
-        const int64_t per_tile_k = s->dg_mode == 4 ? (s->mf_nks == 3 ? 357LL : 414LL) * 32768 : s->dg_emu ? (150LL * 32768 + 72LL * 16384) : 476LL * 4096;
+        const int64_t per_tile_k = s->dg_mode == 5 ? (57LL * ((s->ml_window + 15) / 16) + 186) * 32768 : s->dg_mode == 4 ? (s->mf_nks == 3 ? 357LL : 414LL) * 32768 : s->dg_emu ? (150LL * 32768 + 72LL * 16384) : 476LL * 4096;
         s->conv_flop_exec_launch = (int64_t)(s->dg_n_tiles - s->n_tail_tiles) * per_tile_k * (hp.edge_attr_dim + 1);  // (tail tiles run in their own kernels)
         s->flop_exec += s->conv_flop_exec_launch + (int64_t)((s->n_atoms + 31) / 32) * (s->dg_emu ? 24LL * 32768 : 60LL * 4096) * (hp.edge_attr_dim + 1);
       }
@@ -2371,24 +2429,29 @@ int jamun_sampler_stats(jamun_sampler* s, jamun_stats* out, void* stream) {
     out->dg_row_blocks = s->dg_on && s->dg_row_blocks ? 1 : 0;
     out->dg_emu = s->dg_on ? s->dg_emu : -1;
     out->conv_flop_exec_launch = s->conv_flop_exec_launch;
+    if (s->dg_on && s->dg_mode == 5 && s->ml_count && s->ml_launches > 0) {  // (block-sparse forming: counted by the kernel; mean over its launches so far)
+      unsigned long long cnt = 0;
+      HIPCHECK(hipMemcpy(&cnt, s->ml_count, sizeof(cnt), hipMemcpyDeviceToHost));
+      out->conv_flop_exec_launch = (int64_t)((double)cnt / (double)s->ml_launches) * 32768;
+    }
     out->n_tail_tiles = s->n_tail_tiles;
     out->n_tail = s->n_tail;
     out->mf_nks = (s->dg_on && s->dg_mode == 4) ? s->mf_nks : 0;
-    out->reserved0 = 0;
+    out->ml_window = (s->dg_on && s->dg_mode == 5) ? s->ml_window : 0;
     out->conv_flop_useful_launch = 0;
     out->conv_bytes_alg_launch = 0;
     if (s->dg_on && s->layers.size() > 1) {
       const int64_t m0 = s->hp.mul0, m1 = s->hp.mul1, H1 = s->hp.edge_attr_dim + 1, N = s->n_atoms;
       const int64_t contraction = 2 * H1 * N * ((m0 + m1) * (m0 + m1) + 3 * m1 * (2 * m1));
       // per edge and k: x0 (m0), dot 3 m1, x1 3 m1, cross 6 m1, T term 3 m1 — on the matrix cores only in k_conv_mf (k_conv_dg forms on the vector ALUs)
-      const int64_t forming = s->dg_mode == 4 ? 2 * H1 * (int64_t)e * (m0 + 15 * m1) : 0;
+      const int64_t forming = (s->dg_mode == 4 || s->dg_mode == 5) ? 2 * H1 * (int64_t)e * (m0 + 15 * m1) : 0;
       out->conv_flop_useful_launch = (s->dg_emu ? 3 : 1) * (contraction + forming);
       const int64_t slots = (int64_t)s->h_kstride;
       out->conv_bytes_alg_launch = 4 * (H1 * slots          // h~ of the layer
                                         + H1 * 32 * N         // T
                                         + N * s->XS           // feature rows
                                         + (int64_t)s->dg_n_slabs * s->n_pad * 32 * (s->layers[1].p0.nt + 3 * s->layers[1].p1.nt)) +  // slabs
-                                   (s->dg_mode == 4 ? H1 * 124 * 64 * 16 : s->dg_emu ? H1 * 4 * 34 * 64 * 16 : H1 * (5 * 16 + 5 * 4 + 2 * 4) * 64 * 16);  // weights
+                                   ((s->dg_mode == 4 || s->dg_mode == 5) ? H1 * 124 * 64 * 16 : s->dg_emu ? H1 * 4 * 34 * 64 * 16 : H1 * (5 * 16 + 5 * 4 + 2 * 4) * 64 * 16);  // weights
     } else if (s->layers.size() > 1 && s->layers[1].sep.w2b) {
       // SeparableConv hidden layer (k_sep_fused + k_sep_linear): h~ of the layer, one feature row per edge, the per-destination sums written
       // and read once, the slab, W2~ and the Linear's weights once

@@ -38,9 +38,7 @@
 
 #include "jamun_internal.h"
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef _Float16 h8 __attribute__((ext_vector_type(8)));
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+#include "jamun_mf_dev.h"
 
 #define MF_THREADS 512
 #define MF_ROWB 144                      // bytes per row of a K = 64 plane of halves: 128 + 16 (rows 16 B apart mod 256: conflict-free b128 reads)
@@ -56,14 +54,6 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 #define MF_LDS_BYTES (MF_MISC + 144)
 #define MF_PL (32 * MF_ROWB)             // hi -> lo plane of a T / C tile
 
-#define MFMA32H(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8, (a)), __builtin_bit_cast(h8, (b)), (c), 0, 0, 0)
-#define M3(ACC, AH_, AL_, BH_, BL_)   \
-  ACC = MFMA32H(AL_, BH_, ACC);       \
-  ACC = MFMA32H(AH_, BL_, ACC);       \
-  ACC = MFMA32H(AH_, BH_, ACC)
-#define RFL(v) __builtin_amdgcn_readfirstlane(v)
-#define LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
-
 #ifdef MF_TRACE  // per-wave timeline of workgroup 7 (diagnostic builds): [wave][k-step][stamp]
 __device__ unsigned long long g_mftrace[8][40][8];
 #define MSTAMP(slot) do { if (blockIdx.x == 7 && trc < 40) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); g_mftrace[wave][trc][slot] = t_; } } while (0)
@@ -74,66 +64,6 @@ __device__ unsigned long long g_mfseg[8][4][8];  // [wave][segment][stamp]: segm
 #define SSTAMP(slot) do { } while (0)
 #endif
 
-namespace {
-
-__device__ __forceinline__ float4 lds_f4(int addr) {
-#if defined(__HIP_DEVICE_COMPILE__)
-  typedef float f32x4 __attribute__((ext_vector_type(4)));
-  const f32x4 v = *(const __attribute__((address_space(3))) f32x4*)(unsigned)addr;
-  return make_float4(v.x, v.y, v.z, v.w);
-#else
-  (void)addr;
-  return make_float4(0.f, 0.f, 0.f, 0.f);
-#endif
-}
-__device__ __forceinline__ int lds_addr(const void* p) {
-#if defined(__HIP_DEVICE_COMPILE__)
-  return (int)(unsigned)(uintptr_t)(const __attribute__((address_space(3))) char*)p;
-#else
-  (void)p;
-  return 0;
-#endif
-}
-__device__ __forceinline__ unsigned cvt_pk_f16(float a, float b) {
-  unsigned r;
-  asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-  return r;
-}
-__device__ __forceinline__ float resid_lo(float a, unsigned pk) {  // a - float(pk[15:0])
-  float r;
-  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r) : "v"(pk), "v"(a));
-  return r;
-}
-__device__ __forceinline__ float resid_hi(float a, unsigned pk) {  // a - float(pk[31:16])
-  float r;
-  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(pk), "v"(a));
-  return r;
-}
-// uniform loads through the constant address space: scalar loads into scalar registers
-__device__ __forceinline__ int4 ld_const(const int4* p) {
-#if defined(__HIP_DEVICE_COMPILE__)
-  typedef int i32x4 __attribute__((ext_vector_type(4)));
-  const i32x4 v = *(const __attribute__((address_space(4))) i32x4*)(uintptr_t)p;
-  return make_int4(v.x, v.y, v.z, v.w);
-#else
-  return *p;
-#endif
-}
-__device__ __forceinline__ int2 ld_const(const int2* p) {
-#if defined(__HIP_DEVICE_COMPILE__)
-  typedef int i32x2 __attribute__((ext_vector_type(2)));
-  const i32x2 v = *(const __attribute__((address_space(4))) i32x2*)(uintptr_t)p;
-  return make_int2(v.x, v.y);
-#else
-  return *p;
-#endif
-}
-__device__ __forceinline__ float pow2f(int e) { return __uint_as_float((unsigned)(e + 127) << 23); }
-__device__ __forceinline__ int exp_above(float v) { return (int)((__float_as_uint(v) >> 23) & 0xffu) - 126; }  // v < 2^exp_above(v)
-__device__ __forceinline__ int clamp40(int s) { return max(-40, min(40, s)); }
-__device__ __forceinline__ int clamp100(int s) { return max(-100, min(100, s)); }
-
-}  // namespace
 
 // SPD: the builder's lane layout.  32: edge strides up to 32 — four passes of 8 destinations x 32 slots over the 256 builder lanes;
 // 64: eight passes of 4 destinations x 64 slots; 40: edge strides 33..40 — the four passes of layout 32 plus ONE pass for slots 32..39 of
@@ -453,7 +383,6 @@ __global__ __launch_bounds__(MF_THREADS) void k_conv_mf(MfArgs a) {
       const int edeg = deg_lds[row] > 0 ? exp_above((float)deg_lds[row]) : 1;
       return pow2f(clamp100(14 + edeg - a.sB));
     };
-#define MF_SCHED() __builtin_amdgcn_sched_barrier(0)
 
     if (wave < 5) {
       // ---- scalar-output waves: 20 weight blocks per k ((hi, lo) per (output tile n, K-step s2)); ring: half a hidden unit ahead

@@ -121,6 +121,37 @@ struct MfArgs {
   int* err;          // device flag: bit 0 = more than three edges of one (source, destination) pair
 };
 
+// the matrix-formed conv for LARGE source spans (jamun_conv_ml.hip): two passes over the hidden units (vector channels, then scalar
+// channels), block-sparse forming over the occupied 16-row source blocks; weight stream, T buffer, scales and epilogue of k_conv_mf
+struct MlArgs {
+  const int* deg;
+  const int* epair;  // k_geom's pair table (MfArgs::epair)
+  const int* esrc;
+  const float4* egeo;
+  const float* h;  // [hidden unit k (65 rows)][h_kstride]
+  size_t h_kstride;
+  const float* x;  // [n_atoms][XS = 216]
+  int n_pad, S, XS, n_atoms;
+  const int2* tile_span;   // [n_tiles] {lo, hi} source atoms of the tile (hi - (lo & ~1) <= window)
+  const int2* tile_atoms;  // [n_tiles] {first destination atom, number of destination atoms (<= 32)}
+  const int4* segs;        // [grid][max_segs][2], as MfArgs
+  int max_segs, nt0;
+  int window;              // source rows of the instantiation: 96, 128 or 168 (conv_ml_window)
+  const float4* wm;        // MfArgs::wm
+  const float* Tt;         // MfArgs::Tt (read as global fp32, scaled and split in registers)
+  int t_stride;
+  int sB;
+  const float *gx, *cf0, *cf1;
+  int sC, sTw;
+  float* partial0;
+  float* partial1;
+  int* err;                // as MfArgs::err (bit 1: a source outside the window)
+  unsigned long long* mfma_count;  // += v_mfma_f32_32x32x16_f16 executed (depends on the occupied source blocks of every tile), or null
+};
+int launch_conv_ml(const MlArgs& a, int grid, hipStream_t st);
+int conv_ml_set_max_lds();
+int conv_ml_window(int rows_needed);
+
 // initial projector on the scheme of k_conv_mf (k_conv_mfi in jamun_conv_mf.hip): selector-formed coefficient sums per distinct
 // embedding row, contracted with the input-times-weight table
 struct MfiArgs {

@@ -201,11 +201,12 @@ def save_dcd(path: str, frames) -> None:
         tb = struct.pack("<i", len(titles)) + b"".join(titles)
         f.write(struct.pack("<i", len(tb)) + tb + struct.pack("<i", len(tb)))
         f.write(struct.pack("<3i", 4, natom, 4))
-        rec = struct.pack("<i", 4 * natom)
-        ang = np.ascontiguousarray(np.transpose(xyz * np.float32(10.0), (0, 2, 1)))  # [T, 3, n]
-        for t in range(nset):
-            for c in range(3):
-                f.write(rec + ang[t, c].astype("<f4").tobytes() + rec)
+        # one buffer for all frames: per frame three Fortran records (marker, natom float32, marker) — a structured view instead of 3 T small writes
+        ang = np.transpose(xyz * np.float32(10.0), (0, 2, 1))  # [T, 3, n]
+        recs = np.empty((nset, 3), dtype=np.dtype([("a", "<i4"), ("v", "<f4", (natom,)), ("b", "<i4")]))
+        recs["a"] = recs["b"] = 4 * natom
+        recs["v"] = ang
+        f.write(recs.tobytes())
 
 
 class PDBDataset:

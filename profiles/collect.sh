@@ -10,7 +10,7 @@ cfg=${2:-cfg2}
 extra=${3:-}
 out=gpurun_out/prof_$tag
 mkdir -p "$out"
-BENCH="python3 bench.py --config $cfg $extra --no-cpu-baseline --no-secondary --repeats 1"
+BENCH="python3 bench.py --config $cfg $extra --no-cpu-baseline --no-secondary --no-e2e --no-sweep --repeats 1"
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- $BENCH --steps 10 --warmup 2 > $out/bench_under_rocprof.log 2>&1
 f=$(find $out/trace -name "*kernel_stats.csv" | head -1)
 [ -n "$f" ] || { echo "no kernel_stats.csv produced; see $out/bench_under_rocprof.log" >&2; exit 1; }
@@ -42,6 +42,7 @@ for k,v in agg.items():
 PY
 done
 cat $out/pmc_summary.txt
+python3 bench.py --config $cfg $extra --no-cpu-baseline --signature > $out/signature.json
 python3 - $out <<'PY'
 import csv, glob, json, sys, collections
 out = sys.argv[1]
@@ -55,6 +56,7 @@ for name in ("FETCH_SIZE", "WRITE_SIZE"):
             tot[k] += float(r["Counter_Value"]); disp[k].add(r["Dispatch_Id"])
         for k, v in tot.items():
             res[k][name + "_KB_per_dispatch"] = v / max(len(disp[k]), 1)
+res["_build"] = json.load(open(f"{out}/signature.json"))  # bench.py quotes these counters only while the build and the kernel selection are the same
 json.dump(res, open(f"{out}/pmc_traffic.json", "w"), indent=1)
-print(json.dumps({k: v for k, v in res.items() if "conv" in k or "node" in k}, indent=1))
+print(json.dumps({k: v for k, v in res.items() if "conv" in k or "node" in k or k == "_build"}, indent=1))
 PY

@@ -28,7 +28,7 @@ def test_library_builds_loads_and_exports_all_symbols():
     lib = _lib.load()
     for name in _declared_symbols():
         assert hasattr(lib, name), name
-    assert lib.jamun_version() == _lib.ABI_VERSION == 4  # the binding refuses any other version (struct layouts)
+    assert lib.jamun_version() == _lib.ABI_VERSION == 5  # the binding refuses any other version (struct layouts)
 
 
 def test_num_frames_matches_reference_counts():

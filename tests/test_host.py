@@ -177,6 +177,7 @@ cb = SaveTrajectoryCallback([DS()], output_dir=os.path.join(sys.argv[2], "sample
 samples = [{"dataset_label": "m", "xhat_traj": torch.full((6, 4, 3), float(lo + w))} for w in range(local.num_graphs)]
 cb.on_after_sample_batch(samples, FakeSampler())
 cb.on_after_sample_batch(samples, FakeSampler())
+cb.flush()  # (files are written on a side thread; on_sample_end / flush wait for it)
 dist.barrier()
 if rank == 0:
     d = os.path.join(sys.argv[2], "sampler", "m", "predicted_samples", "npy")
@@ -474,6 +475,7 @@ def test_save_trajectory_true_samples_and_reference_npy_numbering(tmp_path):
     mk = lambda w: SampleGraph(dataset_label="uncapped_AG", atom_type_index=base["atom_type_index"], xhat_traj=base["pos"][:, None, :] + torch.full((10, 2, 3), float(w)))
     cb.on_after_sample_batch([mk(0), mk(1), mk(2)], FakeSampler())
     cb.on_after_sample_batch([mk(3), mk(4), mk(5)], FakeSampler())
+    cb.flush()
     root = os.path.join(out, "uncapped_AG")
     have = sorted(os.path.relpath(os.path.join(dp, f), root) for dp, _, fs in os.walk(root) for f in fs)
     want = (["topology.pdb", "true_samples/pdb/0.pdb", "true_samples/dcd/0.dcd"]
