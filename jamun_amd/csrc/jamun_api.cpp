@@ -2502,6 +2502,7 @@ int jamun_debug_stamps(unsigned long long* out8) {
     conv_dg_print_stamps();
     conv_initv_print_stamps();
     conv_mf_print_stamps();
+    conv_ml_print_stamps();
     for (int i = 0; i < 8; ++i) out8[i] = 0;
   });
 }

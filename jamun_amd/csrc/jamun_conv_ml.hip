@@ -27,6 +27,7 @@
 #include <algorithm>
 #include <stdint.h>
 #include <stdio.h>
+#include <type_traits>
 
 #include "jamun_internal.h"
 #include "jamun_mf_dev.h"
@@ -37,6 +38,16 @@
 constexpr int ml_dbg = ML_EXP;
 #else
 constexpr int ml_dbg = 0;
+#endif
+
+#ifdef ML_TRACE  // per-wave timeline of workgroup 7 (diagnostic builds): [wave][pass V, S][k-step][stamp], [wave][segment][stamp]
+__device__ unsigned long long g_mltrace[8][2][24][6];
+__device__ unsigned long long g_mlseg[8][3][10];
+#define MLSTAMP(pass, slot) do { if (blockIdx.x == 7 && sgi == 0 && it < 24) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); g_mltrace[wave][pass][it][slot] = t_; } } while (0)
+#define MLSEG(slot) do { if (blockIdx.x == 7 && sgi < 3) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); g_mlseg[wave][sgi][slot] = t_; } } while (0)
+#else
+#define MLSTAMP(pass, slot) do { } while (0)
+#define MLSEG(slot) do { } while (0)
 #endif
 
 namespace {
@@ -50,7 +61,8 @@ struct MlGeo {
   static constexpr int CC = 2 * PL;                          // one component
   // pass V: x1^T hi [3 m][32 u] | lo | coefficient tiles [DBV ? 2 : 1][4 components][hi, lo][32 i]
   static constexpr int V_X1H = 0, V_X1L = 96 * ROWX, V_C = 2 * 96 * ROWX, V_CB = 4 * CC;
-  static constexpr int V_END = V_C + (DBV ? 2 : 1) * V_CB;
+  static constexpr int V_HB = V_C + (DBV ? 2 : 1) * V_CB;  // hand-over of the split dot tile (wave 4 -> wave 0): [s2][hi, lo][64 lanes] x 16 B
+  static constexpr int V_END = V_HB + (DBV ? 2 : 1) * 4096;  // (double buffered: no barrier separates wave 0's read of unit k - 1 from wave 4's write of unit k)
   // pass S: x0^T hi [128 u] | lo | component 0 [2 buffers][hi, lo][32 i]
   static constexpr int S_X0H = 0, S_X0L = 128 * ROWX, S_C = 2 * 128 * ROWX, S_CB = CC;
   static constexpr int S_END = S_C + 2 * S_CB;
@@ -76,6 +88,7 @@ __global__ __launch_bounds__(ML_THREADS) void k_conv_ml(MlArgs a) {
   const int tid0 = threadIdx.x, lane0 = tid0 & 63;
   const int wave = RFL(tid0 >> 6);
   const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  const float m1 = opaque_minus_one();  // (jamun_mf_dev.h: the split primitives as compiler-visible instructions)
 
   for (int sgi = 0; sgi < a.max_segs; ++sgi) {
     const int4 sg0 = ld_const(a.segs + ((size_t)blockIdx.x * a.max_segs + sgi) * 2);
@@ -87,26 +100,27 @@ __global__ __launch_bounds__(ML_THREADS) void k_conv_ml(MlArgs a) {
     const int tid = wave * 64 + lane;
     const int slab = RFL(sg0.y), k_begin = RFL(sg0.z), k_run = RFL(sg0.w) - k_begin, k_extra = RFL(sg1.x);
     const int nk = k_run + (k_extra >= 0 ? 1 : 0);
-    auto k_of = [&](int kk) { kk = kk < 0 ? 0 : (kk < nk ? kk : nk - 1); return kk < k_run ? k_begin + kk : k_extra; };
+    auto k_of = [&](int kk) __attribute__((always_inline)) { kk = kk < 0 ? 0 : (kk < nk ? kk : nk - 1); return kk < k_run ? k_begin + kk : k_extra; };
     const int2 t_at = ld_const(a.tile_atoms + tile), span = ld_const(a.tile_span + tile);
     const int n0 = RFL(t_at.x), n_dst = RFL(t_at.y);
     const int s_lo = RFL(span.x), rows = RFL(span.y) - s_lo;
     const int s_base = s_lo & ~1, off = s_lo - s_base;  // window from an even atom (8-byte T loads, row pairs)
     const int r = lane & 31, hh = lane >> 5;
+    MLSEG(0);
 
     // ---- builder layout (both halves of the workgroup hold it: waves 0..3 build in pass V, waves 4..7 in pass S): four passes of 8
     // destinations x 32 slots over 256 lanes + ONE pass for slots 32..39 of all 32 destinations (k_geom caps the radial neighbours at 32: those
     // slots hold bonded edges only); lane = (q-th destination of this wave, slot - 32) keeps a destination's slots inside one wave
     constexpr int BT = 256, SPL = 32, LG = 5, DPP = BT / SPL, NPM = 32 / DPP, NP = NPM + 1, GPW = 64 / SPL;
     const int bt = tid & (BT - 1), bw = bt >> 6;
-    auto dst_of = [&](int p) { return p == NPM ? DPP * ((lane >> 3) / GPW) + GPW * bw + ((lane >> 3) % GPW) : (bt + BT * p) / SPL; };
-    auto slt_of = [&](int p) { return p == NPM ? SPL + (lane & 7) : (bt + BT * p) % SPL; };
+    auto dst_of = [&](int p) __attribute__((always_inline)) { return p == NPM ? DPP * ((lane >> 3) / GPW) + GPW * bw + ((lane >> 3) % GPW) : (bt + BT * p) / SPL; };
+    auto slt_of = [&](int p) __attribute__((always_inline)) { return p == NPM ? SPL + (lane & 7) : (bt + BT * p) % SPL; };
     const int slot0 = (n0 + dst_of(0)) * a.S + slt_of(0), pstride = DPP * a.S, slot_x = (n0 + dst_of(NPM)) * a.S + slt_of(NPM);
-    auto slot_of = [&](int p) { return p == NPM ? slot_x : slot0 + p * pstride; };
+    auto slot_of = [&](int p) __attribute__((always_inline)) { return p == NPM ? slot_x : slot0 + p * pstride; };
     int dgv = 0;
     if (tid < 32 && tid < n_dst) dgv = a.deg[n0 + tid];
     float hv[NP];
-    auto load_h = [&](int k) {  // h~ of this lane's edge slots of hidden unit k (lanes past the in-degree read a neighbouring slot: never used)
+    auto load_h = [&](int k) __attribute__((always_inline)) {  // h~ of this lane's edge slots of hidden unit k (lanes past the in-degree read a neighbouring slot: never used)
       const float* __restrict__ hk = a.h + (size_t)k * a.h_kstride;
 #pragma unroll
       for (int p = 0; p < NP; ++p) hv[p] = hk[slot_of(p)];
@@ -129,11 +143,19 @@ __global__ __launch_bounds__(ML_THREADS) void k_conv_ml(MlArgs a) {
     for (int idx = tid; idx < (DBV ? 2 : 1) * G::V_CB / 16; idx += ML_THREADS) reinterpret_cast<float4*>(lds + G::V_C)[idx] = make_float4(0.f, 0.f, 0.f, 0.f);
     if (tid == 0) { *xmax_lds = 0u; *mask_lds = 0u; }
     {
+      // thread = (float4 column c4 = tid % 54, row group tid / 54 of 9): the channel factors once per thread, five row loads in flight
       float mx = 0.f;
-      for (int idx = tid; idx < rows * 54; idx += ML_THREADS) {
-        const int j = idx / 54, c4 = idx - j * 54;
-        const float4 v = reinterpret_cast<const float4*>(a.x + (size_t)(s_lo + j) * a.XS)[c4], g4 = reinterpret_cast<const float4*>(a.gx)[c4];
-        mx = fmaxf(mx, fmaxf(fmaxf(fabsf(v.x * g4.x), fabsf(v.y * g4.y)), fmaxf(fabsf(v.z * g4.z), fabsf(v.w * g4.w))));
+      const int c4 = tid % 54, jg = tid / 54;
+      if (tid < 486) {
+        const float4 g4 = reinterpret_cast<const float4*>(a.gx)[c4];
+        const float4* __restrict__ px = reinterpret_cast<const float4*>(a.x + (size_t)s_lo * a.XS) + c4;
+        for (int j0 = jg; j0 < rows; j0 += 45) {
+          float4 v[5];
+#pragma unroll
+          for (int q = 0; q < 5; ++q) v[q] = j0 + 9 * q < rows ? px[(size_t)(j0 + 9 * q) * (a.XS / 4)] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+          for (int q = 0; q < 5; ++q) mx = fmaxf(mx, fmaxf(fmaxf(fabsf(v[q].x * g4.x), fabsf(v[q].y * g4.y)), fmaxf(fabsf(v[q].z * g4.z), fabsf(v[q].w * g4.w))));
+        }
       }
 #pragma unroll
       for (int o = 32; o >= 1; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
@@ -142,6 +164,7 @@ __global__ __launch_bounds__(ML_THREADS) void k_conv_ml(MlArgs a) {
     }
     if (tid < 32) deg_lds[tid] = dgv;
     LDS_BARRIER();
+    MLSEG(1);
     const float xm = __uint_as_float(*xmax_lds);
     const int sX = RFL(xm > 0.f ? clamp40(14 - exp_above(xm)) : 0);
 
@@ -159,7 +182,7 @@ __global__ __launch_bounds__(ML_THREADS) void k_conv_ml(MlArgs a) {
         const int ep = in ? epv[p] : 0;
         if (ep & JAMUN_EP_OVERFLOW) atomicOr(a.err, 1);
         const int pa = (ep & 127) - 1, pb = ((ep >> 7) & 127) - 1;  // slots of the pair's other edges (-1: none); always behind this one
-        auto ref = [&](int ps) {  // where this lane finds the h~ of slot ps of its destination: lane distance, or (| 64) a lane of the last pass
+        auto ref = [&](int ps) __attribute__((always_inline)) {  // where this lane finds the h~ of slot ps of its destination: lane distance, or (| 64) a lane of the last pass
           if (ps < 0) return 0;
           if (p < NPM && ps >= SPL) return (((GPW * p + (lane >> LG)) << 3) + (ps - SPL)) | 64;
           return ps - t;
@@ -175,7 +198,7 @@ __global__ __launch_bounds__(ML_THREADS) void k_conv_ml(MlArgs a) {
       if (lane == 0 && wave < 4) atomicOr(mask_lds, bm);
     }
     const float scC = pow2f(a.sC), scx = pow2f(sX), scT = pow2f(clamp100(sX + a.sTw));
-    auto coef = [&](int p) {  // h~ of pass p's entry: this lane's edge + the pair's other edges
+    auto coef = [&](int p) __attribute__((always_inline)) {  // h~ of pass p's entry: this lane's edge + the pair's other edges
       const int d0 = (ent[p] >> 14) & 63, d1 = (ent[p] >> 20) & 63;
       float t0 = __shfl(hv[p], lane + d0, 64), t1 = __shfl(hv[p], lane + d1, 64);
       bool u0 = d0 != 0, u1 = d1 != 0;
@@ -186,12 +209,28 @@ __global__ __launch_bounds__(ML_THREADS) void k_conv_ml(MlArgs a) {
       }
       return (hv[p] + (u0 ? t0 : 0.f)) + (u1 ? t1 : 0.f);
     };
-    auto build4 = [&](char* __restrict__ cbuf) {  // all four components (pass V)
+    // all four components (pass V), in two halves: prep4 computes the entries of the NEXT hidden unit into registers (coefficient x geometry, scaled,
+    // split: four packed words per builder pass) — vector work that runs beside the other waves' forming MFMAs, while the single coefficient
+    // buffer is still being read — and flush4 stores them behind the barrier that ends the forming phase: sixteen-bit LDS stores only, so the
+    // phase in which the matrix pipes idle is short ("double buffering in registers": two LDS buffers of four components do not fit)
+    unsigned stg[NP][4];
+    auto prep4 = [&]() __attribute__((always_inline)) {
+      float cc[NP];
+#pragma unroll
+      for (int p = 0; p < NP; ++p) cc[p] = coef(p) * scC;  // (all passes' lane shuffles in flight before the first is consumed)
 #pragma unroll
       for (int p = 0; p < NP; ++p) {
-        const float c0 = coef(p) * scC, c1 = c0 * evx[p], c2 = c0 * evy[p], c3 = c0 * evz[p];
-        const unsigned h01 = cvt_pk_f16(c0, c1), h23 = cvt_pk_f16(c2, c3);
-        const unsigned l01 = cvt_pk_f16(resid_lo(c0, h01), resid_hi(c1, h01)), l23 = cvt_pk_f16(resid_lo(c2, h23), resid_hi(c3, h23));
+        const float c0 = cc[p], c1 = c0 * evx[p], c2 = c0 * evy[p], c3 = c0 * evz[p];
+        const unsigned h01 = cvt_pk_f16_c(c0, c1), h23 = cvt_pk_f16_c(c2, c3);
+        stg[p][0] = h01; stg[p][1] = h23;
+        stg[p][2] = cvt_pk_f16_c(resid_lo_c(c0, h01, m1), resid_hi_c(c1, h01, m1));
+        stg[p][3] = cvt_pk_f16_c(resid_lo_c(c2, h23, m1), resid_hi_c(c3, h23, m1));
+      }
+    };
+    auto flush4 = [&](char* __restrict__ cbuf) __attribute__((always_inline)) {
+#pragma unroll
+      for (int p = 0; p < NP; ++p) {
+        const unsigned h01 = stg[p][0], h23 = stg[p][1], l01 = stg[p][2], l23 = stg[p][3];
         char* __restrict__ d = cbuf + (ent[p] & 0x3fff);
         *reinterpret_cast<unsigned short*>(d) = (unsigned short)(h01 & 0xffffu);
         *reinterpret_cast<unsigned short*>(d + PL) = (unsigned short)(l01 & 0xffffu);
@@ -203,12 +242,12 @@ __global__ __launch_bounds__(ML_THREADS) void k_conv_ml(MlArgs a) {
         *reinterpret_cast<unsigned short*>(d + 7 * PL) = (unsigned short)(l23 >> 16);
       }
     };
-    auto build1 = [&](char* __restrict__ cbuf) {  // component 0 only (pass S)
+    auto build1 = [&](char* __restrict__ cbuf) __attribute__((always_inline)) {  // component 0 only (pass S)
 #pragma unroll
       for (int p = 0; p < NP; ++p) {
         const float c0 = coef(p) * scC;
-        const unsigned h0 = cvt_pk_f16(c0, 0.f);
-        const unsigned l0 = cvt_pk_f16(resid_lo(c0, h0), 0.f);
+        const unsigned h0 = cvt_pk_f16_c(c0, 0.f);
+        const unsigned l0 = cvt_pk_f16_c(resid_lo_c(c0, h0, m1), 0.f);
         char* __restrict__ d = cbuf + (ent[p] & 0x3fff);
         *reinterpret_cast<unsigned short*>(d) = (unsigned short)(h0 & 0xffffu);
         *reinterpret_cast<unsigned short*>(d + PL) = (unsigned short)(l0 & 0xffffu);
@@ -216,22 +255,31 @@ __global__ __launch_bounds__(ML_THREADS) void k_conv_ml(MlArgs a) {
     };
     // ---- staging of the span's rows, transposed and split: lane = row pair (coalesced LDS words), one float4 column per (wave, round)
     //   first channel float4 column c0 (30: the vector block), NC columns, destination planes by the row of each channel
-    auto stage = [&](auto row_of, int c0, int NC, int lo_off) {
-      constexpr int NPAIR = RH / 2;
-      for (int cw = wave; cw < NC * ((NPAIR + 63) / 64); cw += 8) {
-        const int c4 = c0 + cw % NC, jp = 64 * (cw / NC) + lane;
-        if (jp < NPAIR) {
-          const int j0 = 2 * jp - off, j1 = j0 + 1;  // rows relative to the span
-          float4 va = make_float4(0.f, 0.f, 0.f, 0.f), vb = va;
-          if (j0 >= 0 && j0 < rows) va = reinterpret_cast<const float4*>(a.x + (size_t)(s_lo + j0) * a.XS)[c4];
-          if (j1 >= 0 && j1 < rows) vb = reinterpret_cast<const float4*>(a.x + (size_t)(s_lo + j1) * a.XS)[c4];
+    auto stage = [&](auto row_of, auto c0_, auto nc_, int lo_off) __attribute__((always_inline)) {
+      constexpr int c0 = decltype(c0_)::value, NC = decltype(nc_)::value;
+      constexpr int NPAIR = RH / 2, NR = (NPAIR + 63) / 64, NIT = (NC * NR + 7) / 8;
+      float4 va[NIT], vb[NIT];
+#pragma unroll
+      for (int q = 0; q < NIT; ++q) {  // (every round's rows requested before the first is split and stored)
+        const int cw = wave + 8 * q, c4 = c0 + cw % NC, jp = 64 * (cw / NC) + lane;
+        const int j0 = 2 * jp - off, j1 = j0 + 1;  // rows relative to the span
+        va[q] = vb[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (cw < NC * NR && jp < NPAIR) {
+          if (j0 >= 0 && j0 < rows) va[q] = reinterpret_cast<const float4*>(a.x + (size_t)(s_lo + j0) * a.XS)[c4];
+          if (j1 >= 0 && j1 < rows) vb[q] = reinterpret_cast<const float4*>(a.x + (size_t)(s_lo + j1) * a.XS)[c4];
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < NIT; ++q) {
+        const int cw = wave + 8 * q, c4 = c0 + cw % NC, jp = 64 * (cw / NC) + lane;
+        if (cw < NC * NR && jp < NPAIR) {
           const float4 g4 = reinterpret_cast<const float4*>(a.gx)[c4];
-          const float ea[4] = {va.x * g4.x, va.y * g4.y, va.z * g4.z, va.w * g4.w}, eb[4] = {vb.x * g4.x, vb.y * g4.y, vb.z * g4.z, vb.w * g4.w};
+          const float ea[4] = {va[q].x * g4.x, va[q].y * g4.y, va[q].z * g4.z, va[q].w * g4.w}, eb[4] = {vb[q].x * g4.x, vb[q].y * g4.y, vb[q].z * g4.z, vb[q].w * g4.w};
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             const int rowb = row_of(4 * c4 + e) * ROWX;
             const float a0 = ea[e] * scx, b0 = eb[e] * scx;
-            const unsigned ph = cvt_pk_f16(a0, b0), pl = cvt_pk_f16(resid_lo(a0, ph), resid_hi(b0, ph));
+            const unsigned ph = cvt_pk_f16_c(a0, b0), pl = cvt_pk_f16_c(resid_lo_c(a0, ph, m1), resid_hi_c(b0, ph, m1));
             *reinterpret_cast<unsigned*>(lds + rowb + 4 * jp) = ph;
             *reinterpret_cast<unsigned*>(lds + rowb + lo_off + 4 * jp) = pl;
           }
@@ -239,8 +287,10 @@ __global__ __launch_bounds__(ML_THREADS) void k_conv_ml(MlArgs a) {
       }
     };
     // pass V: vector element 120 + 3 u + m -> row (m, u) of the x1^T planes
-    stage([](int ch) { const int e1 = ch - 120, u = e1 / 3; return (e1 - 3 * u) * 32 + u; }, 30, 24, G::V_X1L - G::V_X1H);
+    stage([](int ch) { const int e1 = ch - 120, u = e1 / 3; return (e1 - 3 * u) * 32 + u; }, std::integral_constant<int, 30>{}, std::integral_constant<int, 24>{}, G::V_X1L - G::V_X1H);
+    MLSEG(2);
     LDS_BARRIER();  // mask, x1^T complete
+    MLSEG(3);
 
     // ---- the occupied source blocks of this tile: a list of 4-bit block indices in ONE 64-bit scalar (position i at bits 4 i ..); the forming
     // loops are run-time loops over the list (positions past the end clamp to the last entry: prefetches need no predicate)
@@ -255,7 +305,7 @@ __global__ __launch_bounds__(ML_THREADS) void k_conv_ml(MlArgs a) {
       }
       nb = RFL(nb);
     }
-    auto boff = [&](int i) {  // byte offset of list position i inside a row of halves
+    auto boff = [&](int i) __attribute__((always_inline)) {  // byte offset of list position i inside a row of halves
       const int ic = min(i, nb - 1);
       return nb > 0 ? (int)((blist >> (4 * ic)) & 15ull) << 5 : 0;
     };
@@ -267,19 +317,19 @@ __global__ __launch_bounds__(ML_THREADS) void k_conv_ml(MlArgs a) {
     const int fox = r * ROWX + 16 * hh + L0, foc = r * ROWC + 16 * hh + L0;  // this lane's fragment offsets inside a 32-row x^T / coefficient plane
     const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float4*>(a.wm), 0, 0x7fffffff, 0x00020000);
     const int wvo = lane * 16;
-    auto wload = [&](int so) { return __builtin_amdgcn_raw_buffer_load_b128(wrs, wvo, so, 0); };
+    auto wload = [&](int so) __attribute__((always_inline)) { return __builtin_amdgcn_raw_buffer_load_b128(wrs, wvo, so, 0); };
     struct Frag { float4 ah, al, bh, bl; };
-    auto ldf = [&](int xa, int xlo, int ca, int clo) -> Frag { return Frag{lds_f4(xa), lds_f4(xa + xlo), lds_f4(ca), lds_f4(ca + clo)}; };
-    auto mm = [&](f32x16& F, const Frag& f) { M3(F, f.ah, f.al, f.bh, f.bl); };
-    auto split16 = [&](const f32x16& F, float4 (&Ah)[2], float4 (&Al)[2]) {
+    auto ldf = [&](int xa, int xlo, int ca, int clo) __attribute__((always_inline)) -> Frag { return Frag{lds_f4(xa), lds_f4(xa + xlo), lds_f4(ca), lds_f4(ca + clo)}; };
+    auto mm = [&](f32x16& F, const Frag& f) __attribute__((always_inline)) { M3(F, f.ah, f.al, f.bh, f.bl); };
+    auto split16 = [&](const f32x16& F, float4 (&Ah)[2], float4 (&Al)[2]) __attribute__((always_inline)) {
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
         unsigned ph[4], pl[4];
 #pragma unroll
         for (int p2 = 0; p2 < 4; ++p2) {
           const float v0 = F[8 * s2 + 2 * p2] * rs, v1 = F[8 * s2 + 2 * p2 + 1] * rs;
-          ph[p2] = cvt_pk_f16(v0, v1);
-          pl[p2] = cvt_pk_f16(resid_lo(v0, ph[p2]), resid_hi(v1, ph[p2]));
+          ph[p2] = cvt_pk_f16_c(v0, v1);
+          pl[p2] = cvt_pk_f16_c(resid_lo_c(v0, ph[p2], m1), resid_hi_c(v1, ph[p2], m1));
         }
         Ah[s2] = make_float4(__uint_as_float(ph[0]), __uint_as_float(ph[1]), __uint_as_float(ph[2]), __uint_as_float(ph[3]));
         Al[s2] = make_float4(__uint_as_float(pl[0]), __uint_as_float(pl[1]), __uint_as_float(pl[2]), __uint_as_float(pl[3]));
@@ -289,7 +339,7 @@ __global__ __launch_bounds__(ML_THREADS) void k_conv_ml(MlArgs a) {
     // there too); the roles meet at the barriers only: V0 | per hidden unit of pass V: (A unless DBV) B | S0 S1 | per hidden unit of pass S: one
     constexpr int NB20 = 20, RD = 10;
     // scalar-output contraction of one formed tile: 20 weight blocks per k ((hi, lo) per (output tile n, K-step s2)), ring half a unit deep
-    auto contract5 = [&](f32x16 (&accS)[5], u32x4 (&RB)[RD], const float4 (&Ah)[2], const float4 (&Al)[2], int cur, int nxt) {
+    auto contract5 = [&](f32x16 (&accS)[5], u32x4 (&RB)[RD], const float4 (&Ah)[2], const float4 (&Al)[2], int cur, int nxt) __attribute__((always_inline)) {
 #pragma unroll
       for (int n = 0; n < 5; ++n)
 #pragma unroll
@@ -303,91 +353,23 @@ __global__ __launch_bounds__(ML_THREADS) void k_conv_ml(MlArgs a) {
     };
     // between the passes (all threads; every wave left pass V through its last barrier: nothing reads the x1^T planes or the coefficient
     // tiles any more): zero component 0's two buffers, stage x0^T
-    auto prep_S = [&]() {
+    auto prep_S = [&]() __attribute__((always_inline)) {
       for (int idx = tid; idx < 2 * G::S_CB / 16; idx += ML_THREADS) reinterpret_cast<float4*>(lds + G::S_C)[idx] = make_float4(0.f, 0.f, 0.f, 0.f);
       if (tid < 2 * 8 * (ROWX / 16)) {  // channel rows 120..127 of the scalar block (inputs of the last K-step that do not exist)
         const int pl = tid / (8 * (ROWX / 16)), q = tid - pl * 8 * (ROWX / 16);
         *reinterpret_cast<float4*>(lds + (pl ? G::S_X0L : G::S_X0H) + 120 * ROWX + 16 * q) = make_float4(0.f, 0.f, 0.f, 0.f);
       }
-      stage([](int ch) { return ch; }, 0, 30, G::S_X0L - G::S_X0H);
+      stage([](int ch) { return ch; }, std::integral_constant<int, 0>{}, std::integral_constant<int, 30>{}, G::S_X0L - G::S_X0H);
     };
     float* __restrict__ ST0 = reinterpret_cast<float*>(lds);                     // [5 waves][32][160] partial scalar-output tiles (segment end)
     float* __restrict__ ST1 = reinterpret_cast<float*>(lds + 5 * 32 * 160 * 4);  // [2][32][96] vector planes: contraction, T term
-    auto cbuf_rd = [&](int it) { return G::V_C + (DBV ? (it & 1) * G::V_CB : 0); };
-    auto cbuf_wr = [&](int it) { return G::V_C + (DBV ? ((it + 1) & 1) * G::V_CB : 0); };
+    auto cbuf_rd = [&](int it) __attribute__((always_inline)) { return G::V_C + (DBV ? (it & 1) * G::V_CB : 0); };
+    auto cbuf_wr = [&](int it) __attribute__((always_inline)) { return G::V_C + (DBV ? ((it + 1) & 1) * G::V_CB : 0); };
 
-    if (wave < 4) {
-      // =================================================================================================================
-      // waves 0..3.  Pass V: the T term of plane wave - 1 (waves 1..3), the coefficient tiles of the next hidden unit.
-      //              Pass S: scalar channels 32 wave .. -> the five scalar-output tiles.
-      // =================================================================================================================
-      const int vm = wave >= 1 ? wave - 1 : 0;
-      f32x16 accT = zero16;
-      {
-        // T_k rows of the span (fp32, global, transposed by the pre-pass: MfArgs::Tt): lane (w' = r, hh) needs T[j][w'], j = 16 b + 8 hh .. + 7, of
-        // every occupied block — two 16-byte buffer loads per block, a ring of four blocks in flight (the first four of a hidden unit are
-        // requested during the previous unit's build)
-        typedef float f32x4 __attribute__((ext_vector_type(4)));
-        const int tvo = (r * a.t_stride + s_base + 8 * hh) * 4;  // this lane's byte offset inside the [32 w'][t_stride] table of a hidden unit
-        f32x4 tq[4][2];
-        auto t_rsrc = [&](int k) { return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.Tt + (size_t)k * 32 * a.t_stride), 0, 0x7fffffff, 0x00020000); };
-        auto load_T = [&](f32x4 (&t)[2], __amdgpu_buffer_rsrc_t trs, int i) {
-          const int so = 2 * boff(i);
-          t[0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(trs, tvo, so, 0));
-          t[1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(trs, tvo + 16, so, 0));
-        };
-        auto load_T4 = [&](int k) {
-          const __amdgpu_buffer_rsrc_t trs = t_rsrc(k);
-#pragma unroll
-          for (int q = 0; q < 4; ++q) load_T(tq[q], trs, q);
-        };
-        build4(lds + G::V_C);
-        load_h(k_of(1));
-        if (wave >= 1) load_T4(k_of(0));
-        LDS_BARRIER();  // V0: C(k0) complete
-        for (int it = 0; it < ((ml_dbg & 16) ? 0 : nk); ++it) {
-          const int cb = cbuf_rd(it);
-          int foc_ = foc;
-          asm volatile("" : "+v"(foc_));  // (per-iteration copy: the block addresses are not hoisted out of the k loop and spilled)
-          if (wave >= 1 && !(ml_dbg & 1)) {
-            // out_m[i][w'] += sum_j C[v_m][i][j] T_k[j][w']: A = coefficient rows (LDS), B = T_k^T rows, scaled and split here
-            const __amdgpu_buffer_rsrc_t trs = t_rsrc(k_of(it));
-            auto tstep = [&](f32x4 (&t)[2], int i) {
-              const int ca = cb + (1 + vm) * CC + foc_ + boff(i);
-              const float4 ah = lds_f4(ca), al = lds_f4(ca + PL);
-              unsigned ph[4], pl[4];
-#pragma unroll
-              for (int q = 0; q < 4; ++q) {
-                const float t0 = t[q >> 1][2 * (q & 1)] * scT, t1 = t[q >> 1][2 * (q & 1) + 1] * scT;
-                ph[q] = cvt_pk_f16(t0, t1);
-                pl[q] = cvt_pk_f16(resid_lo(t0, ph[q]), resid_hi(t1, ph[q]));
-              }
-              const float4 bh = make_float4(__uint_as_float(ph[0]), __uint_as_float(ph[1]), __uint_as_float(ph[2]), __uint_as_float(ph[3]));
-              const float4 bl = make_float4(__uint_as_float(pl[0]), __uint_as_float(pl[1]), __uint_as_float(pl[2]), __uint_as_float(pl[3]));
-              M3(accT, ah, al, bh, bl);
-              if (i + 4 < nb) load_T(t, trs, i + 4);
-            };
-            for (int i = 0; i < nb; i += 4) {
-              tstep(tq[0], i);
-              if (i + 1 < nb) tstep(tq[1], i + 1);
-              if (i + 2 < nb) tstep(tq[2], i + 2);
-              if (i + 3 < nb) tstep(tq[3], i + 3);
-            }
-          }
-          if (!DBV) LDS_BARRIER();  // A: every read of C(k) done
-          if (wave >= 1) load_T4(k_of(it + 1));
-          if (!(ml_dbg & 2)) build4(lds + cbuf_wr(it));  // (on the last hidden unit: from clamped loads, never read)
-          load_h(k_of(it + 2));
-          MF_SCHED();
-          LDS_BARRIER();  // B: C(k + 1) complete (double buffered: and every read of C(k) done)
-        }
-      }
-      prep_S();
-      f32x16 accS[5];
-#pragma unroll
-      for (int n = 0; n < 5; ++n) accS[n] = zero16;
+    // pass S of a scalar wave (waves 0..3): channels 32 wave .. -> the five scalar-output tiles; barriers S0, S1, one per hidden unit
+    auto pass_S_scalar = [&](f32x16 (&accS)[5]) __attribute__((always_inline)) {
       u32x4 RB[RD];
-      auto wstreamS = [&](int k) { return (k * 124 + 20 * wave) * 1024; };
+      auto wstreamS = [&](int k) __attribute__((always_inline)) { return (k * 124 + 20 * wave) * 1024; };
       {
         const int c0 = wstreamS(k_of(0));
 #pragma unroll
@@ -395,13 +377,23 @@ __global__ __launch_bounds__(ML_THREADS) void k_conv_ml(MlArgs a) {
       }
       LDS_BARRIER();  // S0: x0^T complete, tiles zeroed
       LDS_BARRIER();  // S1: C0(k0) complete
+      MLSEG(5);
+      // the formed tile of hidden unit k is split behind its forming and CONTRACTED at the start of unit k + 1 (registers and weights only),
+      // behind that unit's first fragment reads: the contraction's MFMAs cover the LDS round trip the forming chain starts with
+      float4 sAh[2], sAl[2];
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) sAh[s2] = sAl[s2] = make_float4(0.f, 0.f, 0.f, 0.f);
       for (int it = 0; it < ((ml_dbg & 8) ? 0 : nk); ++it) {
         int fox_ = fox, foc_ = foc;
         asm volatile("" : "+v"(fox_), "+v"(foc_));
         const int cb = G::S_C + (it & 1) * G::S_CB + foc_, xa = G::S_X0H + 32 * wave * ROWX + fox_;
+        MLSTAMP(1, 0);
         f32x16 F = zero16;
-        auto fr = [&](int i) { const int bo = boff(i); return ldf(xa + bo, G::S_X0L - G::S_X0H, cb + bo, PL); };
+        auto fr = [&](int i) __attribute__((always_inline)) { const int bo = boff(i); return ldf(xa + bo, G::S_X0L - G::S_X0H, cb + bo, PL); };
         Frag fA = fr(0), fB = fr(1);
+        MF_SCHED();
+        if (it > 0 && !(ml_dbg & 32)) contract5(accS, RB, sAh, sAl, wstreamS(k_of(it - 1)), wstreamS(k_of(it)));
+        MLSTAMP(1, 1);
         for (int i = 0; i < nb; i += 2) {  // two blocks per round, the reads one round ahead
           MF_SCHED();
           if (!(ml_dbg & 4)) mm(F, fA);
@@ -412,67 +404,18 @@ __global__ __launch_bounds__(ML_THREADS) void k_conv_ml(MlArgs a) {
           MF_SCHED();
           fB = fr(i + 3);
         }
-        float4 Ah[2], Al[2];
-        split16(F, Ah, Al);
-        if (!(ml_dbg & 32)) contract5(accS, RB, Ah, Al, wstreamS(k_of(it)), wstreamS(k_of(it + 1)));
+        MLSTAMP(1, 2);
+        split16(F, sAh, sAl);
         MF_SCHED();
+        MLSTAMP(1, 3);
         LDS_BARRIER();
+        MLSTAMP(1, 4);
       }
-#pragma unroll
-      for (int q = 0; q < 16; ++q) {  // (raw accumulators: the power-of-two factors are applied to the SUM of the partial tiles below)
-        const int row = (q & 3) + 8 * (q >> 2) + 4 * hh;
-#pragma unroll
-        for (int n = 0; n < 5; ++n) ST0[(wave * 32 + row) * 160 + 32 * n + r] = accS[n][q];
-        if (wave >= 1) ST1[3072 + row * 96 + vm * 32 + r] = accT[q];
-      }
-    } else if (wave == 4) {
-      // =================================================================================================================
-      // wave 4.  Pass V: dot(x1, v) = sum_m x1[m] C[v_m] over the occupied blocks -> the five scalar-output tiles.  Pass S: builder.
-      // =================================================================================================================
-      f32x16 accS[5];
-#pragma unroll
-      for (int n = 0; n < 5; ++n) accS[n] = zero16;
-      {
-        u32x4 RB[RD];
-        auto wstreamV = [&](int k) { return (k * 124 + 80) * 1024; };
-        {
-          const int c0 = wstreamV(k_of(0));
-#pragma unroll
-          for (int p = 0; p < RD; ++p) RB[p] = wload(c0 + p * 1024);
-        }
-        LDS_BARRIER();  // V0
-        for (int it = 0; it < ((ml_dbg & 16) ? 0 : nk); ++it) {
-          const int cb = cbuf_rd(it);
-          int fox_ = fox, foc_ = foc;
-          asm volatile("" : "+v"(fox_), "+v"(foc_));
-          f32x16 F = zero16;
-          auto fr = [&](int bo, int m) { return ldf(G::V_X1H + m * 32 * ROWX + fox_ + bo, G::V_X1L - G::V_X1H, cb + (1 + m) * CC + foc_ + bo, PL); };
-          int bo = boff(0);
-          Frag f0 = fr(bo, 0), f1 = fr(bo, 1), f2;
-          for (int i = 0; i < nb; ++i) {  // (the reads run two products ahead of the MFMAs)
-            const int bn = boff(i + 1);
-            f2 = fr(bo, 2);
-            MF_SCHED();
-            if (!(ml_dbg & 4)) mm(F, f0);
-            MF_SCHED();
-            f0 = fr(bn, 0);
-            MF_SCHED();
-            if (!(ml_dbg & 4)) mm(F, f1);
-            MF_SCHED();
-            f1 = fr(bn, 1);
-            MF_SCHED();
-            if (!(ml_dbg & 4)) mm(F, f2);
-            MF_SCHED();
-            bo = bn;
-          }
-          if (!DBV) LDS_BARRIER();  // A
-          float4 Ah[2], Al[2];
-          split16(F, Ah, Al);
-          if (!(ml_dbg & 32)) contract5(accS, RB, Ah, Al, wstreamV(k_of(it)), wstreamV(k_of(it + 1)));
-          MF_SCHED();
-          LDS_BARRIER();  // B
-        }
-      }
+      if (!(ml_dbg & (8 | 32))) contract5(accS, RB, sAh, sAl, wstreamS(k_of(nk - 1)), wstreamS(k_of(nk - 1)));
+      MLSEG(6);
+    };
+    // pass S of a builder wave (waves 4..7)
+    auto pass_S_builder = [&]() __attribute__((always_inline)) {
       prep_S();
       load_h(k_of(0));
       LDS_BARRIER();  // S0
@@ -480,44 +423,253 @@ __global__ __launch_bounds__(ML_THREADS) void k_conv_ml(MlArgs a) {
       load_h(k_of(1));
       LDS_BARRIER();  // S1
       for (int it = 0; it < ((ml_dbg & 8) ? 0 : nk); ++it) {
+        MLSTAMP(1, 0);
         if (!(ml_dbg & 2)) build1(lds + G::S_C + ((it + 1) & 1) * G::S_CB);
         load_h(k_of(it + 2));
         MF_SCHED();
+        MLSTAMP(1, 3);
         LDS_BARRIER();
+        MLSTAMP(1, 4);
       }
+    };
+    const int hb = G::V_HB + 16 * lane + L0;  // this lane's slot of the hand-over buffer (+ 1024 per fragment: Ah[0], Al[0], Ah[1], Al[1])
+
+    if (wave == 0) {
+      // =================================================================================================================
+      // wave 0.  Pass V: contracts the dot(x1, v) tile wave 4 formed one hidden unit earlier (handed over split, through LDS) into ITS
+      //          five scalar-output tiles — partial sums of the same outputs as its own channels in pass S: one set of accumulators —
+      //          while the other waves form; then builds the next unit's coefficient tiles.  Pass S: scalar channels 0..31.
+      // =================================================================================================================
+      f32x16 accS[5];
+#pragma unroll
+      for (int n = 0; n < 5; ++n) accS[n] = zero16;
+      {
+        u32x4 RV[RD];  // the dot stream: the ring of contract5, half a hidden unit ahead
+        auto wstreamD = [&](int k) __attribute__((always_inline)) { return (k * 124 + 80) * 1024; };
+        auto contract_dot = [&](int cur, int nxt, int hbk) __attribute__((always_inline)) {
+          float4 Ah[2], Al[2];
+          Ah[0] = lds_f4(hbk); Al[0] = lds_f4(hbk + 1024); Ah[1] = lds_f4(hbk + 2048); Al[1] = lds_f4(hbk + 3072);
+          if (!(ml_dbg & 32)) contract5(accS, RV, Ah, Al, cur, nxt);
+        };
+        {
+          const int c0 = wstreamD(k_of(0));
+#pragma unroll
+          for (int p = 0; p < RD; ++p) RV[p] = wload(c0 + p * 1024);
+        }
+        prep4();
+        flush4(lds + G::V_C);
+        load_h(k_of(1));
+        LDS_BARRIER();  // V0: C(k0) complete
+        for (int it = 0; it < ((ml_dbg & 16) ? 0 : nk); ++it) {
+          MLSTAMP(0, 0);
+          if (it > 0) contract_dot(wstreamD(k_of(it - 1)), wstreamD(k_of(it)), hb + (DBV ? ((it - 1) & 1) * 4096 : 0));  // the tile of hidden unit it - 1; the ring moves on to unit it
+          if (!(ml_dbg & 2)) prep4();  // (on the last hidden unit: from clamped loads, never read)
+          MLSTAMP(0, 1);
+          if (!DBV) LDS_BARRIER();  // A: every read of C(k) done
+          MLSTAMP(0, 2);
+          if (!(ml_dbg & 2)) flush4(lds + cbuf_wr(it));
+          load_h(k_of(it + 2));
+          MF_SCHED();
+          MLSTAMP(0, 3);
+          LDS_BARRIER();  // B: C(k + 1) complete, the dot tile of unit k handed over
+          MLSTAMP(0, 4);
+        }
+        if (!(ml_dbg & 16)) contract_dot(wstreamD(k_of(nk - 1)), wstreamD(k_of(nk - 1)), hb + (DBV ? ((nk - 1) & 1) * 4096 : 0));  // the last unit's tile (the ring's reload is not used)
+        MLSEG(4);
+      }
+      prep_S();
+      pass_S_scalar(accS);
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {  // (raw accumulators: the power-of-two factors are applied to the SUM of the partial tiles below)
+        const int row = (q & 3) + 8 * (q >> 2) + 4 * hh;
+#pragma unroll
+        for (int n = 0; n < 5; ++n) {
+          ST0[(0 * 32 + row) * 160 + 32 * n + r] = accS[n][q];
+          ST0[(4 * 32 + row) * 160 + 32 * n + r] = 0.f;  // (the dot tile's slot of the five-way sum: already inside accS)
+        }
+      }
+    } else if (wave < 4) {
+      // =================================================================================================================
+      // waves 1..3.  Pass V: the T term of plane wave - 1, then the coefficient tiles of the next hidden unit.
+      //              Pass S: scalar channels 32 wave .. -> the five scalar-output tiles.
+      // =================================================================================================================
+      const int vm = wave - 1;
+      f32x16 accT = zero16;
+      {
+        // T_k rows of the span (fp32, global, transposed by the pre-pass: MfArgs::Tt): lane (w' = r, hh) needs T[j][w'], j = 16 b + 8 hh .. + 7, of
+        // every occupied block — two 16-byte buffer loads per block, a ring of four blocks in flight (the first four of a hidden unit are
+        // requested during the previous unit's build)
+        typedef float f32x4 __attribute__((ext_vector_type(4)));
+        const int tvo = (r * a.t_stride + s_base + 8 * hh) * 4;  // this lane's byte offset inside the [32 w'][t_stride] table of a hidden unit
+        constexpr int TD = NKS < 8 ? NKS : 8;  // blocks of T in flight: all of a hidden unit's up to eight occupied blocks, requested behind the previous unit's build
+        f32x4 tq[TD][2];
+        auto t_rsrc = [&](int k) __attribute__((always_inline)) { return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.Tt + (size_t)k * 32 * a.t_stride), 0, 0x7fffffff, 0x00020000); };
+        auto load_T = [&](f32x4 (&t)[2], __amdgpu_buffer_rsrc_t trs, int i) __attribute__((always_inline)) {
+          const int so = 2 * boff(i);
+          t[0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(trs, tvo, so, 0));
+          t[1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(trs, tvo + 16, so, 0));
+        };
+        auto load_TD = [&](int k) __attribute__((always_inline)) {
+          const __amdgpu_buffer_rsrc_t trs = t_rsrc(k);
+#pragma unroll
+          for (int q = 0; q < TD; ++q) load_T(tq[q], trs, q);
+        };
+        prep4();
+        flush4(lds + G::V_C);
+        load_h(k_of(1));
+        load_TD(k_of(0));
+        LDS_BARRIER();  // V0: C(k0) complete
+        for (int it = 0; it < ((ml_dbg & 16) ? 0 : nk); ++it) {
+          const int cb = cbuf_rd(it);
+          int foc_ = foc;
+          asm volatile("" : "+v"(foc_));  // (per-iteration copy: the block addresses are not hoisted out of the k loop and spilled)
+          MLSTAMP(0, 0);
+          if (!(ml_dbg & 1)) {
+            // out_m[i][w'] += sum_j C[v_m][i][j] T_k[j][w']: A = coefficient rows (LDS), B = T_k^T rows, scaled and split here
+            const __amdgpu_buffer_rsrc_t trs = t_rsrc(k_of(it));
+            auto tstep = [&](f32x4 (&t)[2], int i) __attribute__((always_inline)) {
+              const int ca = cb + (1 + vm) * CC + foc_ + boff(i);
+              const float4 ah = lds_f4(ca), al = lds_f4(ca + PL);
+              unsigned ph[4], pl[4];
+#pragma unroll
+              for (int q = 0; q < 4; ++q) {
+                const float t0 = t[q >> 1][2 * (q & 1)] * scT, t1 = t[q >> 1][2 * (q & 1) + 1] * scT;
+                ph[q] = cvt_pk_f16_c(t0, t1);
+                pl[q] = cvt_pk_f16_c(resid_lo_c(t0, ph[q], m1), resid_hi_c(t1, ph[q], m1));
+              }
+              const float4 bh = make_float4(__uint_as_float(ph[0]), __uint_as_float(ph[1]), __uint_as_float(ph[2]), __uint_as_float(ph[3]));
+              const float4 bl = make_float4(__uint_as_float(pl[0]), __uint_as_float(pl[1]), __uint_as_float(pl[2]), __uint_as_float(pl[3]));
+              M3(accT, ah, al, bh, bl);
+              if (NKS > TD && i + TD < nb) load_T(t, trs, i + TD);  // (more than eight occupied blocks: the ring refills as it drains)
+            };
+            for (int i = 0; i < nb; i += TD) {
+#pragma unroll
+              for (int q = 0; q < TD; ++q)
+                if (i + q < nb) tstep(tq[q], i + q);
+            }
+          }
+          if (!(ml_dbg & 2)) prep4();
+          MLSTAMP(0, 1);
+          if (!DBV) LDS_BARRIER();  // A: every read of C(k) done
+          MLSTAMP(0, 2);
+          if (!(ml_dbg & 2)) flush4(lds + cbuf_wr(it));
+          load_h(k_of(it + 2));
+          load_TD(k_of(it + 1));  // (behind the build and the h~ loads: by the time the next build waits for h~, these have long arrived)
+          MF_SCHED();
+          MLSTAMP(0, 3);
+          LDS_BARRIER();  // B: C(k + 1) complete (double buffered: and every read of C(k) done)
+          MLSTAMP(0, 4);
+        }
+        MLSEG(4);
+      }
+      prep_S();
+      f32x16 accS[5];
+#pragma unroll
+      for (int n = 0; n < 5; ++n) accS[n] = zero16;
+      pass_S_scalar(accS);
 #pragma unroll
       for (int q = 0; q < 16; ++q) {
         const int row = (q & 3) + 8 * (q >> 2) + 4 * hh;
 #pragma unroll
-        for (int n = 0; n < 5; ++n) ST0[(4 * 32 + row) * 160 + 32 * n + r] = accS[n][q];
+        for (int n = 0; n < 5; ++n) ST0[(wave * 32 + row) * 160 + 32 * n + r] = accS[n][q];
+        ST1[3072 + row * 96 + vm * 32 + r] = accT[q];
       }
+    } else if (wave == 4) {
+      // =================================================================================================================
+      // wave 4.  Pass V: forms dot(x1, v) = sum_m x1[m] C[v_m] over the occupied blocks, splits it and hands it to wave 0.  Pass S: builder.
+      // =================================================================================================================
+      LDS_BARRIER();  // V0
+      for (int it = 0; it < ((ml_dbg & 16) ? 0 : nk); ++it) {
+        const int cb = cbuf_rd(it);
+        int fox_ = fox, foc_ = foc;
+        asm volatile("" : "+v"(fox_), "+v"(foc_));
+        MLSTAMP(0, 0);
+        f32x16 F = zero16;
+        auto fr = [&](int bo, int m) __attribute__((always_inline)) { return ldf(G::V_X1H + m * 32 * ROWX + fox_ + bo, G::V_X1L - G::V_X1H, cb + (1 + m) * CC + foc_ + bo, PL); };
+        int bo = boff(0);
+        Frag f0 = fr(bo, 0), f1 = fr(bo, 1), f2;
+        for (int i = 0; i < nb; ++i) {  // (the reads run two products ahead of the MFMAs)
+          const int bn = boff(i + 1);
+          f2 = fr(bo, 2);
+          MF_SCHED();
+          if (!(ml_dbg & 4)) mm(F, f0);
+          MF_SCHED();
+          f0 = fr(bn, 0);
+          MF_SCHED();
+          if (!(ml_dbg & 4)) mm(F, f1);
+          MF_SCHED();
+          f1 = fr(bn, 1);
+          MF_SCHED();
+          if (!(ml_dbg & 4)) mm(F, f2);
+          MF_SCHED();
+          bo = bn;
+        }
+        MLSTAMP(0, 1);
+        if (!DBV) LDS_BARRIER();  // A
+        MLSTAMP(0, 2);
+        float4 Ah[2], Al[2];
+        split16(F, Ah, Al);
+        const int hbk = hb + (DBV ? (it & 1) * 4096 : 0);
+        lds_st4(hbk, Ah[0]); lds_st4(hbk + 1024, Al[0]); lds_st4(hbk + 2048, Ah[1]); lds_st4(hbk + 3072, Al[1]);
+        MLSTAMP(0, 3);
+        LDS_BARRIER();  // B
+        MLSTAMP(0, 4);
+      }
+      pass_S_builder();
     } else {
       // =================================================================================================================
-      // waves 5..7.  Pass V: vector plane vm: FA = x1[m] C[0];  F1 = x1[m+1] C[v_(m+2)], F2 = x1[m+2] C[v_(m+1)]  ((x1 x v)[m] = F1 - F2),
-      //              both contracted into the plane.  Pass S: builder.
+      // waves 5..7.  Pass V: vector plane vm: FA = x1[m] C[0];  F1 = x1[m+1] C[v_(m+2)], F2 = x1[m+2] C[v_(m+1)]  ((x1 x v)[m] = F1 - F2);
+      //              both tiles are split behind the forming barrier and contracted into the plane at the START of the next unit's forming
+      //              phase (registers and weights only), next to the first fragment reads.  Pass S: builder.
       // =================================================================================================================
       const int vm = wave - 5, m1 = (vm + 1) % 3, m2 = (vm + 2) % 3;
       f32x16 accP = zero16;
       {
         u32x4 RB[8];
-        auto wstreamV = [&](int k) { return (k * 124 + 100 + 8 * vm) * 1024; };
+        auto wstreamV = [&](int k) __attribute__((always_inline)) { return (k * 124 + 100 + 8 * vm) * 1024; };
         {
           const int c0 = wstreamV(k_of(0));
 #pragma unroll
           for (int p = 0; p < 8; ++p) RB[p] = wload(c0 + p * 1024);
         }
+        float4 sAh[2], sAl[2], sCh[2], sCl[2];  // the split tiles of the previous hidden unit: x1[m], cross
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) sAh[s2] = sAl[s2] = sCh[s2] = sCl[s2] = make_float4(0.f, 0.f, 0.f, 0.f);
+        auto contract_plane = [&](int nxt) __attribute__((always_inline)) {  // blocks 0..3: x1 inputs ((hi, lo) per K-step), 4..7: cross inputs; the ring moves on to the next unit
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const int s2 = g & 1, p = 2 * g;
+            if (!(ml_dbg & 32)) { M3(accP, (g < 2 ? sAh[s2] : sCh[s2]), (g < 2 ? sAl[s2] : sCl[s2]), RB[p], RB[p + 1]); }
+            RB[p] = wload(nxt + p * 1024);
+            RB[p + 1] = wload(nxt + (p + 1) * 1024);
+            MF_SCHED();
+          }
+        };
         LDS_BARRIER();  // V0
+        f32x16 FA = zero16, F1 = zero16, F2 = zero16;
+        auto split_plane = [&]() __attribute__((always_inline)) {
+          split16(FA, sAh, sAl);
+#pragma unroll
+          for (int q = 0; q < 16; ++q) F1[q] -= F2[q];
+          split16(F1, sCh, sCl);
+        };
         for (int it = 0; it < ((ml_dbg & 16) ? 0 : nk); ++it) {
           const int cb = cbuf_rd(it);
           int fox_ = fox, foc_ = foc;
           asm volatile("" : "+v"(fox_), "+v"(foc_));
-          f32x16 FA = zero16, F1 = zero16, F2 = zero16;
-          auto fr = [&](int bo, int g) {
+          MLSTAMP(0, 0);
+          auto fr = [&](int bo, int g) __attribute__((always_inline)) {
             const int xm_ = g == 0 ? vm : g == 1 ? m1 : m2, cc = g == 0 ? 0 : g == 1 ? 1 + m2 : 1 + m1;
             return ldf(G::V_X1H + xm_ * 32 * ROWX + fox_ + bo, G::V_X1L - G::V_X1H, cb + cc * CC + foc_ + bo, PL);
           };
           int bo = boff(0);
           Frag f0 = fr(bo, 0), f1 = fr(bo, 1), f2;
+          MF_SCHED();
+          if (it > 0) {  // hidden unit it - 1: split and contracted behind the first fragment reads of unit it (registers and weights only)
+            split_plane();
+            contract_plane(wstreamV(k_of(it)));
+          }
+          FA = zero16; F1 = zero16; F2 = zero16;
           for (int i = 0; i < nb; ++i) {
             const int bn = boff(i + 1);
             f2 = fr(bo, 2);
@@ -534,44 +686,17 @@ __global__ __launch_bounds__(ML_THREADS) void k_conv_ml(MlArgs a) {
             MF_SCHED();
             bo = bn;
           }
+          MLSTAMP(0, 1);
           if (!DBV) LDS_BARRIER();  // A
-          const int nxt = wstreamV(k_of(it + 1));
-          float4 Ah[2], Al[2];
-          split16(FA, Ah, Al);
-#pragma unroll
-          for (int s2 = 0; s2 < 2; ++s2) {  // x1 inputs: blocks 0..3 ((hi, lo) per K-step)
-            const int p = 2 * s2;
-            M3(accP, Ah[s2], Al[s2], RB[p], RB[p + 1]);
-            RB[p] = wload(nxt + p * 1024);
-            RB[p + 1] = wload(nxt + (p + 1) * 1024);
-            MF_SCHED();
-          }
-#pragma unroll
-          for (int q = 0; q < 16; ++q) F1[q] -= F2[q];
-          split16(F1, Ah, Al);
-#pragma unroll
-          for (int s2 = 0; s2 < 2; ++s2) {  // cross inputs: blocks 4..7
-            const int p = 4 + 2 * s2;
-            M3(accP, Ah[s2], Al[s2], RB[p], RB[p + 1]);
-            RB[p] = wload(nxt + p * 1024);
-            RB[p + 1] = wload(nxt + (p + 1) * 1024);
-            MF_SCHED();
-          }
+          MLSTAMP(0, 2);
+          MLSTAMP(0, 3);
           LDS_BARRIER();  // B
+          MLSTAMP(0, 4);
         }
+        if (!(ml_dbg & 16)) split_plane();
+        if (!(ml_dbg & 16)) contract_plane(wstreamV(k_of(nk - 1)));  // the last unit (the ring's reload is not used)
       }
-      prep_S();
-      load_h(k_of(0));
-      LDS_BARRIER();  // S0
-      build1(lds + G::S_C);
-      load_h(k_of(1));
-      LDS_BARRIER();  // S1
-      for (int it = 0; it < ((ml_dbg & 8) ? 0 : nk); ++it) {
-        if (!(ml_dbg & 2)) build1(lds + G::S_C + ((it + 1) & 1) * G::S_CB);
-        load_h(k_of(it + 2));
-        MF_SCHED();
-        LDS_BARRIER();
-      }
+      pass_S_builder();
 #pragma unroll
       for (int q = 0; q < 16; ++q) {
         const int row = (q & 3) + 8 * (q >> 2) + 4 * hh;
@@ -581,7 +706,7 @@ __global__ __launch_bounds__(ML_THREADS) void k_conv_ml(MlArgs a) {
 
     // ---- segment end: partial tiles -> LDS (raw accumulators), summed and scaled on the way to the slab (as k_conv_mf)
     const float i1 = pow2f(clamp100(-(sX + a.sC))), iT2 = pow2f(clamp100(-a.sTw));
-    auto i2_of = [&](int row) {
+    auto i2_of = [&](int row) __attribute__((always_inline)) {
       const int edeg = deg_lds[row] > 0 ? exp_above((float)deg_lds[row]) : 1;
       return pow2f(clamp100(14 + edeg - a.sB));
     };
@@ -613,8 +738,35 @@ __global__ __launch_bounds__(ML_THREADS) void k_conv_ml(MlArgs a) {
         if (row < n_dst) *reinterpret_cast<float4*>(p1 + row * 96 + 4 * c4) = v;
       }
     }
+    MLSEG(7);
     LDS_BARRIER();  // the next segment rewrites the tiles
   }
+}
+
+void conv_ml_print_stamps() {
+#ifdef ML_TRACE
+  static unsigned long long tr[8][2][24][6], sg[8][3][10];
+  if (hipMemcpyFromSymbol(tr, HIP_SYMBOL(g_mltrace), sizeof(tr)) != hipSuccess || hipMemcpyFromSymbol(sg, HIP_SYMBOL(g_mlseg), sizeof(sg)) != hipSuccess || sg[0][0][0] == 0) return;
+  const unsigned long long t0 = sg[0][0][0];
+  fprintf(stderr, "ml segments (workgroup 7): start / max barrier / staged V / loop V entered / loop V left / loop S entered / loop S left / slab stored\n");
+  for (int q = 0; q < 3; ++q)
+    for (int w = 0; w < 8; ++w) {
+      if (sg[w][q][0] == 0) continue;
+      fprintf(stderr, "  seg %d wave %d:", q, w);
+      for (int i = 0; i < 8; ++i) fprintf(stderr, " %8lld", (long long)(sg[w][q][i] - t0));
+      fprintf(stderr, "\n");
+    }
+  for (int ps = 0; ps < 2; ++ps) {
+    fprintf(stderr, "ml pass %s, first segment: per k-step and wave: top / formed / after barrier A / phase B done / after barrier B (cycles since segment start)\n", ps ? "S" : "V");
+    for (int st = 0; st < 24; ++st)
+      for (int w = 0; w < 8; ++w) {
+        if (tr[w][ps][st][0] == 0) continue;
+        fprintf(stderr, "  step %2d wave %d:", st, w);
+        for (int i = 0; i < 5; ++i) fprintf(stderr, " %8lld", tr[w][ps][st][i] ? (long long)(tr[w][ps][st][i] - t0) : -1LL);
+        fprintf(stderr, "\n");
+      }
+  }
+#endif
 }
 
 namespace {

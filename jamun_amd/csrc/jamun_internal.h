@@ -151,6 +151,7 @@ struct MlArgs {
 int launch_conv_ml(const MlArgs& a, int grid, hipStream_t st);
 int conv_ml_set_max_lds();
 int conv_ml_window(int rows_needed);
+void conv_ml_print_stamps();
 
 // initial projector on the scheme of k_conv_mf (k_conv_mfi in jamun_conv_mf.hip): selector-formed coefficient sums per distinct
 // embedding row, contracted with the input-times-weight table

@@ -30,6 +30,14 @@ __device__ __forceinline__ float4 lds_f4(int addr) {
   return make_float4(0.f, 0.f, 0.f, 0.f);
 #endif
 }
+__device__ __forceinline__ void lds_st4(int addr, const float4& v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  typedef float f32x4 __attribute__((ext_vector_type(4)));
+  *(__attribute__((address_space(3))) f32x4*)(unsigned)addr = f32x4{v.x, v.y, v.z, v.w};
+#else
+  (void)addr; (void)v;
+#endif
+}
 __device__ __forceinline__ int lds_addr(const void* p) {
 #if defined(__HIP_DEVICE_COMPILE__)
   return (int)(unsigned)(uintptr_t)(const __attribute__((address_space(3))) char*)p;
@@ -53,6 +61,22 @@ __device__ __forceinline__ float resid_hi(float a, unsigned pk) {  // a - float(
   asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(pk), "v"(a));
   return r;
 }
+// The same three primitives as COMPILER-VISIBLE instructions (jamun_conv_ml.hip).  An inline-asm statement is opaque to the hazard recogniser:
+// when the register allocator hands one of the asm's outputs a VGPR that an MFMA issued a few cycles earlier still reads as its A / B operand
+// (the multi-pass v_mfma_f32_32x32x16_f16 reads them over several passes), nothing inserts the wait states and the MFMA multiplies a
+// half-overwritten fragment — wrong AND non-reproducible results (measured: the T term of k_conv_ml<8>, 1e-4 per layer, gone with these).
+// With -1.0 held in a scalar register the compiler cannot fold fma(float(h), -1, a) into a subtraction and selects exactly the instructions
+// of the asm versions: v_cvt_pk_f16_f32, v_fma_mix_f32.
+typedef _Float16 mf_h2 __attribute__((ext_vector_type(2)));
+typedef float mf_f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float opaque_minus_one() {
+  float m1 = -1.0f;
+  asm volatile("" : "+s"(m1));
+  return m1;
+}
+__device__ __forceinline__ unsigned cvt_pk_f16_c(float a, float b) { return __builtin_bit_cast(unsigned, __builtin_convertvector(mf_f2{a, b}, mf_h2)); }
+__device__ __forceinline__ float resid_lo_c(float a, unsigned pk, float m1) { return __builtin_fmaf((float)__builtin_bit_cast(mf_h2, pk).x, m1, a); }  // a - float(pk[15:0])
+__device__ __forceinline__ float resid_hi_c(float a, unsigned pk, float m1) { return __builtin_fmaf((float)__builtin_bit_cast(mf_h2, pk).y, m1, a); }  // a - float(pk[31:16])
 // uniform loads through the constant address space: scalar loads into scalar registers
 __device__ __forceinline__ int4 ld_const(const int4* p) {
 #if defined(__HIP_DEVICE_COMPILE__)
