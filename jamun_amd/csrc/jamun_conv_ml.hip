@@ -213,13 +213,19 @@ __global__ __launch_bounds__(ML_THREADS) void k_conv_ml(MlArgs a) {
     // split: four packed words per builder pass) — vector work that runs beside the other waves' forming MFMAs, while the single coefficient
     // buffer is still being read — and flush4 stores them behind the barrier that ends the forming phase: sixteen-bit LDS stores only, so the
     // phase in which the matrix pipes idle is short ("double buffering in registers": two LDS buffers of four components do not fit)
+    // PM: the builder passes this wave computes and stores — both halves of the workgroup hold the same lane layout (waves w and w + 4), so
+    // the work is shared: waves 1..3, which also carry the T term, take passes 0, 1 and the extra pass; waves 5..7 take passes 2, 3 behind
+    // their forming; waves 0 and 4 take their share the same way
     unsigned stg[NP][4];
-    auto prep4 = [&]() __attribute__((always_inline)) {
+    auto prep4 = [&](auto pm_) __attribute__((always_inline)) {
+      constexpr int PM = decltype(pm_)::value;
       float cc[NP];
 #pragma unroll
-      for (int p = 0; p < NP; ++p) cc[p] = coef(p) * scC;  // (all passes' lane shuffles in flight before the first is consumed)
+      for (int p = 0; p < NP; ++p)
+        if ((PM >> p) & 1) cc[p] = coef(p) * scC;  // (all passes' lane shuffles in flight before the first is consumed)
 #pragma unroll
       for (int p = 0; p < NP; ++p) {
+        if (!((PM >> p) & 1)) continue;
         const float c0 = cc[p], c1 = c0 * evx[p], c2 = c0 * evy[p], c3 = c0 * evz[p];
         const unsigned h01 = cvt_pk_f16_c(c0, c1), h23 = cvt_pk_f16_c(c2, c3);
         stg[p][0] = h01; stg[p][1] = h23;
@@ -227,9 +233,11 @@ __global__ __launch_bounds__(ML_THREADS) void k_conv_ml(MlArgs a) {
         stg[p][3] = cvt_pk_f16_c(resid_lo_c(c2, h23, m1), resid_hi_c(c3, h23, m1));
       }
     };
-    auto flush4 = [&](char* __restrict__ cbuf) __attribute__((always_inline)) {
+    auto flush4 = [&](char* __restrict__ cbuf, auto pm_) __attribute__((always_inline)) {
+      constexpr int PM = decltype(pm_)::value;
 #pragma unroll
       for (int p = 0; p < NP; ++p) {
+        if (!((PM >> p) & 1)) continue;
         const unsigned h01 = stg[p][0], h23 = stg[p][1], l01 = stg[p][2], l23 = stg[p][3];
         char* __restrict__ d = cbuf + (ent[p] & 0x3fff);
         *reinterpret_cast<unsigned short*>(d) = (unsigned short)(h01 & 0xffffu);
@@ -242,6 +250,8 @@ __global__ __launch_bounds__(ML_THREADS) void k_conv_ml(MlArgs a) {
         *reinterpret_cast<unsigned short*>(d + 7 * PL) = (unsigned short)(l23 >> 16);
       }
     };
+    const std::integral_constant<int, 0x13> PM_LO{};  // passes 0, 1, 4
+    const std::integral_constant<int, 0x0c> PM_HI{};  // passes 2, 3
     auto build1 = [&](char* __restrict__ cbuf) __attribute__((always_inline)) {  // component 0 only (pass S)
 #pragma unroll
       for (int p = 0; p < NP; ++p) {
@@ -456,19 +466,19 @@ __global__ __launch_bounds__(ML_THREADS) void k_conv_ml(MlArgs a) {
 #pragma unroll
           for (int p = 0; p < RD; ++p) RV[p] = wload(c0 + p * 1024);
         }
-        prep4();
-        flush4(lds + G::V_C);
+        prep4(PM_LO);
+        flush4(lds + G::V_C, PM_LO);
         load_h(k_of(1));
         LDS_BARRIER();  // V0: C(k0) complete
         for (int it = 0; it < ((ml_dbg & 16) ? 0 : nk); ++it) {
           MLSTAMP(0, 0);
           if (it > 0) contract_dot(wstreamD(k_of(it - 1)), wstreamD(k_of(it)), hb + (DBV ? ((it - 1) & 1) * 4096 : 0));  // the tile of hidden unit it - 1; the ring moves on to unit it
-          if (!(ml_dbg & 2)) prep4();  // (on the last hidden unit: from clamped loads, never read)
+          if (!(ml_dbg & 2)) prep4(PM_LO);  // (on the last hidden unit: from clamped loads, never read)
+          load_h(k_of(it + 2));        // (behind the entries computed from unit it + 1's: the phase between the barriers is stores only)
           MLSTAMP(0, 1);
           if (!DBV) LDS_BARRIER();  // A: every read of C(k) done
           MLSTAMP(0, 2);
-          if (!(ml_dbg & 2)) flush4(lds + cbuf_wr(it));
-          load_h(k_of(it + 2));
+          if (!(ml_dbg & 2)) flush4(lds + cbuf_wr(it), PM_LO);
           MF_SCHED();
           MLSTAMP(0, 3);
           LDS_BARRIER();  // B: C(k + 1) complete, the dot tile of unit k handed over
@@ -514,8 +524,8 @@ __global__ __launch_bounds__(ML_THREADS) void k_conv_ml(MlArgs a) {
 #pragma unroll
           for (int q = 0; q < TD; ++q) load_T(tq[q], trs, q);
         };
-        prep4();
-        flush4(lds + G::V_C);
+        prep4(PM_LO);
+        flush4(lds + G::V_C, PM_LO);
         load_h(k_of(1));
         load_TD(k_of(0));
         LDS_BARRIER();  // V0: C(k0) complete
@@ -548,13 +558,13 @@ __global__ __launch_bounds__(ML_THREADS) void k_conv_ml(MlArgs a) {
                 if (i + q < nb) tstep(tq[q], i + q);
             }
           }
-          if (!(ml_dbg & 2)) prep4();
+          load_TD(k_of(it + 1));  // (the ring is drained: the next unit's T rows are requested before this unit's barrier, a whole phase ahead of their use)
+          if (!(ml_dbg & 2)) prep4(PM_LO);
+          load_h(k_of(it + 2));
           MLSTAMP(0, 1);
           if (!DBV) LDS_BARRIER();  // A: every read of C(k) done
           MLSTAMP(0, 2);
-          if (!(ml_dbg & 2)) flush4(lds + cbuf_wr(it));
-          load_h(k_of(it + 2));
-          load_TD(k_of(it + 1));  // (behind the build and the h~ loads: by the time the next build waits for h~, these have long arrived)
+          if (!(ml_dbg & 2)) flush4(lds + cbuf_wr(it), PM_LO);
           MF_SCHED();
           MLSTAMP(0, 3);
           LDS_BARRIER();  // B: C(k + 1) complete (double buffered: and every read of C(k) done)
@@ -578,6 +588,9 @@ __global__ __launch_bounds__(ML_THREADS) void k_conv_ml(MlArgs a) {
       // =================================================================================================================
       // wave 4.  Pass V: forms dot(x1, v) = sum_m x1[m] C[v_m] over the occupied blocks, splits it and hands it to wave 0.  Pass S: builder.
       // =================================================================================================================
+      prep4(PM_HI);
+      flush4(lds + G::V_C, PM_HI);
+      load_h(k_of(1));
       LDS_BARRIER();  // V0
       for (int it = 0; it < ((ml_dbg & 16) ? 0 : nk); ++it) {
         const int cb = cbuf_rd(it);
@@ -604,9 +617,12 @@ __global__ __launch_bounds__(ML_THREADS) void k_conv_ml(MlArgs a) {
           MF_SCHED();
           bo = bn;
         }
+        if (!(ml_dbg & 2)) prep4(PM_HI);
+        load_h(k_of(it + 2));
         MLSTAMP(0, 1);
         if (!DBV) LDS_BARRIER();  // A
         MLSTAMP(0, 2);
+        if (!(ml_dbg & 2)) flush4(lds + cbuf_wr(it), PM_HI);
         float4 Ah[2], Al[2];
         split16(F, Ah, Al);
         const int hbk = hb + (DBV ? (it & 1) * 4096 : 0);
@@ -645,6 +661,9 @@ __global__ __launch_bounds__(ML_THREADS) void k_conv_ml(MlArgs a) {
             MF_SCHED();
           }
         };
+        prep4(PM_HI);
+        flush4(lds + G::V_C, PM_HI);
+        load_h(k_of(1));
         LDS_BARRIER();  // V0
         f32x16 FA = zero16, F1 = zero16, F2 = zero16;
         auto split_plane = [&]() __attribute__((always_inline)) {
@@ -686,9 +705,12 @@ __global__ __launch_bounds__(ML_THREADS) void k_conv_ml(MlArgs a) {
             MF_SCHED();
             bo = bn;
           }
+          if (!(ml_dbg & 2)) prep4(PM_HI);
+          load_h(k_of(it + 2));
           MLSTAMP(0, 1);
           if (!DBV) LDS_BARRIER();  // A
           MLSTAMP(0, 2);
+          if (!(ml_dbg & 2)) flush4(lds + cbuf_wr(it), PM_HI);
           MLSTAMP(0, 3);
           LDS_BARRIER();  // B
           MLSTAMP(0, 4);
