@@ -253,7 +253,8 @@ typedef struct jamun_stats {
                              0 two phases per hidden unit with resident source rows, 1 two passes over the hidden units (molecules above
                              ~80 atoms), 2 single phase (spans up to ~52 atoms), 3 single phase with one Y tile (spans up to ~73 atoms);
                              -1: not in use */
-  int32_t init_path;      /* initial projector: 4 k_conv_mfx (jamun_conv_mf.hip: aggregated operand formed on the matrix cores from the embedding
+  int32_t init_path;      /* initial projector: 5 k_conv_mlx (jamun_conv_ml.hip: as 4 on the dg_mode 5 tiles — source spans of 63..167 atoms, block-sparse forming),
+                             4 k_conv_mfx (jamun_conv_mf.hip: aggregated operand formed on the matrix cores from the embedding
                              rows, as a hidden layer with 64 scalar channels; dg_mode 4 tiles, any number of distinct embedding rows),
                              3 k_conv_mfi (coefficient sums per distinct embedding row formed with a one-hot selector, contracted with the
                              input-times-weight table; dg_mode 4 tiles, <= 32 distinct rows),

@@ -360,6 +360,7 @@ struct jamun_sampler {
   bool init_tail = false;      // the initial projector sends the tail tiles through k_tail_form_init / k_tail_contract as well
   bool mfi_on = false;    // initial projector on k_conv_mfi (mode 4 tiles, at most 32 distinct embedding rows)
   bool mfx_on = false;    // ... or on k_conv_mfx (mode 4 tiles, any number of distinct rows: formed from the feature rows)
+  bool mlx_on = false;    // ... or, on the mode 5 tiles (large spans), k_conv_mlx
   int n_uniq = 0;         // distinct (noise-scaled) embedding rows of the batch
   int* mf_err = nullptr;  // device flag of k_conv_mf
   int* mf_err_host = nullptr;  // pinned copy, refreshed behind every entry point that ran a forward (mf_err_fetch / mf_err_check)
@@ -1212,7 +1213,7 @@ LayerDev build_layer(const jamun_model& m, const std::string& prefix, const std:
     for (size_t i = 0; i < N; ++i)
       for (int u = 0; u < C; ++u) xm = std::max(xm, std::fabs(std::ldexp((double)(*all_rows)[i * row_len + u], eu[u])));
     L.x_sX = 14 - pow2_above(xm);
-    const size_t n_pairs = (N + 1) / 2 + 40;  // a window reads 32 pairs from the pair of its first atom: zero rows behind the batch
+    const size_t n_pairs = (N + 1) / 2 + 96;  // a window reads up to 88 pairs (k_conv_mlx; k_conv_mfx: 32) from the pair of its first atom: zero rows behind the batch
     std::vector<unsigned> xph(n_pairs * 64, 0u), xpl(n_pairs * 64, 0u);
     for (size_t i = 0; i < N; ++i)
       for (int u = 0; u < C; ++u) {
@@ -1346,6 +1347,20 @@ void run_layer(jamun_sampler* s, size_t l, const float* x_in, int XSin, float* x
         ProfScope pt(s, JAMUN_PROF_CONV1_INIT, st);
         if (launch_conv_tail_init(t, st) != 0) throw Err(JAMUN_ERR_INVALID, "tail-tile conv launch failed (configuration not supported)");
       }
+    } else if (l == 0 && s->mlx_on) {
+      MlxArgs f{};
+      f.deg = s->deg; f.epair = s->epair; f.esrc = s->esrc; f.egeo = s->egeo; f.h = h_l; f.h_kstride = s->h_kstride;
+      f.n_pad = s->n_pad; f.S = s->S; f.nt0 = L.p0.nt; f.window = s->ml_window;
+      f.tile_span = s->dg_tile_span; f.tile_atoms = s->dg_tile_atoms; f.segs = s->dg_segs; f.max_segs = s->dg_max_segs;
+      f.xph = L.xph; f.xpl = L.xpl; f.wx = L.wx; f.sX = L.x_sX; f.cf0 = L.xcf0; f.cf1 = L.xcf1;
+      {
+        int e3 = 0;
+        std::frexp(1.5 * (double)L.dg.hmax2, &e3);
+        f.sC = std::max(-40, std::min(40, 14 - e3));
+      }
+      f.partial0 = s->partial0; f.partial1 = s->partial1; f.err = s->mf_err; f.mfma_count = nullptr;
+      ProfScope ps(s, JAMUN_PROF_CONV0_INIT, st);
+      if (launch_conv_mlx(f, s->dg_grid, st) != 0) throw Err(JAMUN_ERR_INVALID, "initial-projector conv launch failed (configuration not supported)");
     } else if (l == 0 && s->initv_on) {
       InitVArgs f{};
       f.deg = s->deg; f.esrc = s->esrc; f.egeo = s->egeo; f.h = h_l; f.h_kstride = s->h_kstride;
@@ -1452,7 +1467,7 @@ void run_layer(jamun_sampler* s, size_t l, const float* x_in, int XSin, float* x
     n.cL = s->hp.act_scalar_const; n.cS = s->hp.act_gate_const;
     n.n_atoms = s->n_atoms; n.n_pad = s->n_pad; n.n_slices = s->n_slices; n.nt0 = L.p0.nt; n.nt1 = L.p1.nt;
     n.mul0 = s->hp.mul0; n.mul1 = s->hp.mul1; n.in0 = L.in0; n.in1 = L.in1; n.XSin = XSin;
-    const bool dg_layer = (l > 0 && s->dg_on) || (l == 0 && (s->initv_on || s->mfi_on || s->mfx_on));  // (slabs of the dg tile plan)
+    const bool dg_layer = (l > 0 && s->dg_on) || (l == 0 && (s->initv_on || s->mfi_on || s->mfx_on || s->mlx_on));  // (slabs of the dg tile plan)
     const bool init_plan = l == 0 && dg_layer && s->init_segs != nullptr;  // (the initial projector keeps the tail tiles on its own segment lists)
     n.atom_nslab = dg_layer ? (init_plan ? s->init_atom_nslab : s->dg_atom_nslab) : nullptr;
     n.max_slabs = dg_layer ? (init_plan ? s->init_n_slabs : s->dg_n_slabs) : s->n_slices;
@@ -2055,7 +2070,8 @@ int jamun_sampler_create(const jamun_model* m, float sigma, const jamun_topology
           if (s->n_uniq <= 32 && s->layers[0].tabw != nullptr && s->atom_uid != nullptr && s->layers[0].tab_ut == 1) s->mfi_on = true;
           else if (s->layers[0].wx != nullptr) s->mfx_on = true;
         }
-        if (s->mfi_on || s->mfx_on) s->initv_on = false;
+        if (s->dg_mode == 5 && s->layers[0].p0.nt == 5 && !tn.no_mfi && s->layers[0].wx != nullptr) s->mlx_on = true;
+        if (s->mfi_on || s->mfx_on || s->mlx_on) s->initv_on = false;
       }
       if (!s->dg_on)
         for (auto& L : s->layers) free_dg(L.dg);
@@ -2425,7 +2441,7 @@ int jamun_sampler_stats(jamun_sampler* s, jamun_stats* out, void* stream) {
     out->n_slices = s->dg_on ? s->dg_n_slabs : s->n_slices;
     out->conv_path = s->dg_on ? 2 : 0;
     out->dg_mode = s->dg_on ? s->dg_mode : -1;
-    out->init_path = s->mfx_on ? 4 : s->mfi_on ? 3 : s->initv_on ? 2 : 0;
+    out->init_path = s->mlx_on ? 5 : s->mfx_on ? 4 : s->mfi_on ? 3 : s->initv_on ? 2 : 0;
     out->dg_row_blocks = s->dg_on && s->dg_row_blocks ? 1 : 0;
     out->dg_emu = s->dg_on ? s->dg_emu : -1;
     out->conv_flop_exec_launch = s->conv_flop_exec_launch;

@@ -765,6 +765,323 @@ __global__ __launch_bounds__(ML_THREADS) void k_conv_ml(MlArgs a) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------
+// k_conv_mlx — the INITIAL projector for the same large spans: k_conv_mfx (jamun_conv_mf.hip: the layer as a hidden layer with 64 scalar
+// input channels, formed from the host-split embedding rows) with the window, the block-sparse forming and the register-staged coefficient
+// entries of k_conv_ml.  One pass: x^T of 64 channels is 43 KB, the four coefficient components (single buffered) 94 KB.
+//   wave = 2 c + t: coefficient component c (0: scalar outputs, 1 + m: x0 (x) v_m -> vector plane m), channel tile t: forms its tile over
+//   the occupied blocks, splits it behind the forming barrier and contracts it at the start of the next hidden unit's forming phase
+//   (waves 0, 1 into the five scalar-output tiles, the others into their plane; K-split over t, summed at the segment end).
+//   All eight waves prepare the next unit's entries in registers during the forming phase and store them between the two barriers.
+template <int NKS, bool HALF>
+__global__ __launch_bounds__(ML_THREADS) void k_conv_mlx(MlxArgs a) {
+  constexpr int RH = 16 * NKS - (HALF ? 8 : 0);
+  constexpr int ROWX = HALF ? 32 * NKS - 16 : 32 * NKS + 16, ROWC = 32 * NKS + 16, PL = 32 * ROWC, CC = 2 * PL;
+  constexpr int X_H = 0, X_L = 64 * ROWX, X_C = 2 * 64 * ROWX, X_END = X_C + 4 * CC;
+  constexpr int EP_END = 2 * 32 * 160 * 4 + 2 * 32 * 96 * 4;
+  constexpr int MISC = ((X_END > EP_END ? X_END : EP_END) + 15) & ~15;
+  static_assert(MISC + 160 <= JAMUN_MAX_DYN_LDS, "k_conv_mlx: LDS budget");
+  extern __shared__ float4 lds4[];
+  char* __restrict__ lds = reinterpret_cast<char*>(lds4);
+  const int L0 = lds_addr(lds);
+  int* __restrict__ deg_lds = reinterpret_cast<int*>(lds + MISC);
+  unsigned* __restrict__ mask_lds = reinterpret_cast<unsigned*>(lds + MISC + 132);
+  const int tid0 = threadIdx.x, lane0 = tid0 & 63;
+  const int wave = RFL(tid0 >> 6);
+  const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  const float m1 = opaque_minus_one();
+
+  for (int sgi = 0; sgi < a.max_segs; ++sgi) {
+    const int4 sg0 = ld_const(a.segs + ((size_t)blockIdx.x * a.max_segs + sgi) * 2);
+    const int4 sg1 = ld_const(a.segs + ((size_t)blockIdx.x * a.max_segs + sgi) * 2 + 1);
+    const int tile = RFL(sg0.x);
+    if (tile < 0) break;
+    int lane = lane0;
+    asm volatile("" : "+v"(lane));
+    const int tid = wave * 64 + lane;
+    const int slab = RFL(sg0.y), k_begin = RFL(sg0.z), k_run = RFL(sg0.w) - k_begin, k_extra = RFL(sg1.x);
+    const int nk = k_run + (k_extra >= 0 ? 1 : 0);
+    auto k_of = [&](int kk) __attribute__((always_inline)) { kk = kk < 0 ? 0 : (kk < nk ? kk : nk - 1); return kk < k_run ? k_begin + kk : k_extra; };
+    const int2 t_at = ld_const(a.tile_atoms + tile), span = ld_const(a.tile_span + tile);
+    const int n0 = RFL(t_at.x), n_dst = RFL(t_at.y);
+    const int s_base = RFL(span.x) & ~1;  // window from an even atom (the rows are stored in pairs)
+    const int r = lane & 31, hh = lane >> 5;
+
+    // ---- builder layout: four passes of 8 destinations x 64 slots over the 512 lanes (a destination's slots inside one wave)
+    constexpr int NP = 4;
+    const int slot0 = (n0 + tid / 64) * a.S + (tid & 63), pstride = 8 * a.S;
+    int dgv = 0;
+    if (tid < 32 && tid < n_dst) dgv = a.deg[n0 + tid];
+    float hv[NP];
+    auto load_h = [&](int k) __attribute__((always_inline)) {
+      const float* __restrict__ hk = a.h + (size_t)k * a.h_kstride;
+#pragma unroll
+      for (int p = 0; p < NP; ++p) hv[p] = hk[slot0 + p * pstride];
+    };
+    load_h(k_of(0));
+    float evx[NP], evy[NP], evz[NP];
+    int sjv[NP], epv[NP], ent[NP];
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+      const int i = tid / 64 + 8 * p, t = tid & 63;
+      const bool in = i < n_dst && t < a.S;
+      sjv[p] = in ? a.esrc[slot0 + p * pstride] : 0;
+      epv[p] = in ? a.epair[slot0 + p * pstride] : 0;
+      float4 ge = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (in) ge = a.egeo[slot0 + p * pstride];
+      evx[p] = ge.x; evy[p] = ge.y; evz[p] = ge.z;
+    }
+    // ---- prologue: zero the coefficient tiles; the window's rows (already split, two atoms per word): a copy, transposed
+    for (int idx = tid; idx < 4 * CC / 16; idx += ML_THREADS) reinterpret_cast<float4*>(lds + X_C)[idx] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (tid == 0) *mask_lds = 0u;
+    {
+      const unsigned* __restrict__ ph = a.xph + (size_t)(s_base >> 1) * 64;
+      const unsigned* __restrict__ pl = a.xpl + (size_t)(s_base >> 1) * 64;
+      constexpr int NW = (RH / 2) * 64, NQ = (NW + ML_THREADS - 1) / ML_THREADS;
+      unsigned vh[NQ], vl[NQ];
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) {
+        const int idx = tid + ML_THREADS * q;
+        vh[q] = idx < NW ? ph[idx] : 0u;
+        vl[q] = idx < NW ? pl[idx] : 0u;
+      }
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) {
+        const int idx = tid + ML_THREADS * q, ch = idx & 63, jp = idx >> 6;
+        if (idx < NW) {
+          *reinterpret_cast<unsigned*>(lds + X_H + ch * ROWX + 4 * jp) = vh[q];
+          *reinterpret_cast<unsigned*>(lds + X_L + ch * ROWX + 4 * jp) = vl[q];
+        }
+      }
+    }
+    if (tid < 32) deg_lds[tid] = dgv;
+    LDS_BARRIER();
+    {
+      unsigned bm = 0u;
+#pragma unroll
+      for (int p = 0; p < NP; ++p) {
+        const int i = tid / 64 + 8 * p, t = tid & 63;
+        const int dg = deg_lds[i];
+        const bool in = t < dg && t < a.S;
+        const int jl = (sjv[p] & 0x7fffffff) - s_base;  // (bit 31: bonded)
+        const bool valid = in && jl >= 0 && jl < RH;
+        if (in && (jl < 0 || jl >= RH)) atomicOr(a.err, 2);
+        const int ep = in ? epv[p] : 0;
+        if (ep & JAMUN_EP_OVERFLOW) atomicOr(a.err, 1);
+        const int pa = (ep & 127) - 1, pb = ((ep >> 7) & 127) - 1;
+        const int d0 = pa >= 0 ? pa - t : 0, d1 = pb >= 0 ? pb - t : 0;  // lane distance to the pair's other edges (same lane group)
+        const bool active = valid && !((unsigned)ep & JAMUN_EP_OWNED);
+        ent[p] = active ? (i * ROWC + 2 * jl) | (d0 << 14) | (d1 << 20) : (ROWC - 16);
+        if (active) bm |= 1u << (jl >> 4);
+      }
+#pragma unroll
+      for (int o = 32; o >= 1; o >>= 1) bm |= (unsigned)__shfl_xor((int)bm, o, 64);
+      if (lane == 0) atomicOr(mask_lds, bm);
+    }
+    const float scC = pow2f(a.sC);
+    unsigned stg[NP][4];
+    auto prep = [&]() __attribute__((always_inline)) {
+      float cc[NP];
+#pragma unroll
+      for (int p = 0; p < NP; ++p) {
+        const int d0 = (ent[p] >> 14) & 63, d1 = (ent[p] >> 20) & 63;
+        const float t0 = __shfl(hv[p], lane + d0, 64), t1 = __shfl(hv[p], lane + d1, 64);
+        cc[p] = ((hv[p] + (d0 ? t0 : 0.f)) + (d1 ? t1 : 0.f)) * scC;
+      }
+#pragma unroll
+      for (int p = 0; p < NP; ++p) {
+        const float c0 = cc[p], c1 = c0 * evx[p], c2 = c0 * evy[p], c3 = c0 * evz[p];
+        const unsigned h01 = cvt_pk_f16_c(c0, c1), h23 = cvt_pk_f16_c(c2, c3);
+        stg[p][0] = h01; stg[p][1] = h23;
+        stg[p][2] = cvt_pk_f16_c(resid_lo_c(c0, h01, m1), resid_hi_c(c1, h01, m1));
+        stg[p][3] = cvt_pk_f16_c(resid_lo_c(c2, h23, m1), resid_hi_c(c3, h23, m1));
+      }
+    };
+    auto flush = [&]() __attribute__((always_inline)) {
+#pragma unroll
+      for (int p = 0; p < NP; ++p) {
+        const unsigned h01 = stg[p][0], h23 = stg[p][1], l01 = stg[p][2], l23 = stg[p][3];
+        char* __restrict__ d = lds + X_C + (ent[p] & 0x3fff);
+        *reinterpret_cast<unsigned short*>(d) = (unsigned short)(h01 & 0xffffu);
+        *reinterpret_cast<unsigned short*>(d + PL) = (unsigned short)(l01 & 0xffffu);
+        *reinterpret_cast<unsigned short*>(d + 2 * PL) = (unsigned short)(h01 >> 16);
+        *reinterpret_cast<unsigned short*>(d + 3 * PL) = (unsigned short)(l01 >> 16);
+        *reinterpret_cast<unsigned short*>(d + 4 * PL) = (unsigned short)(h23 & 0xffffu);
+        *reinterpret_cast<unsigned short*>(d + 5 * PL) = (unsigned short)(l23 & 0xffffu);
+        *reinterpret_cast<unsigned short*>(d + 6 * PL) = (unsigned short)(h23 >> 16);
+        *reinterpret_cast<unsigned short*>(d + 7 * PL) = (unsigned short)(l23 >> 16);
+      }
+    };
+    LDS_BARRIER();  // mask, x^T complete, tiles zeroed
+    unsigned long long blist = 0ull;
+    int nb = 0;
+    {
+      unsigned m = (unsigned)RFL((int)*mask_lds);
+      while (m) {
+        blist |= (unsigned long long)__builtin_ctz(m) << (4 * nb);
+        ++nb;
+        m &= m - 1u;
+      }
+      nb = RFL(nb);
+    }
+    auto boff = [&](int i) __attribute__((always_inline)) {
+      const int ic = min(i, nb - 1);
+      return nb > 0 ? (int)((blist >> (4 * ic)) & 15ull) << 5 : 0;
+    };
+    if (tid == 0 && a.mfma_count) atomicAdd(a.mfma_count, (unsigned long long)nk * (unsigned long long)(24 * nb + 96));
+
+    const int comp = wave >> 1, ct = wave & 1;
+    const int edeg_r = deg_lds[r] > 0 ? exp_above((float)deg_lds[r]) : 1;
+    const float rs = pow2f(-14 - edeg_r);  // formed values are below in-degree x 2^28 -> below 2^14
+    const int fox = r * ROWX + 16 * hh + L0 + X_H + 32 * ct * ROWX, foc = r * ROWC + 16 * hh + L0 + X_C + comp * CC;
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float4*>(a.wx), 0, 0x7fffffff, 0x00020000);
+    const int wvo = lane * 16;
+    auto wload = [&](int so) __attribute__((always_inline)) { return __builtin_amdgcn_raw_buffer_load_b128(wrs, wvo, so, 0); };
+    struct Frag { float4 ah, al, bh, bl; };
+    auto split16 = [&](const f32x16& F, float4 (&Ah)[2], float4 (&Al)[2]) __attribute__((always_inline)) {
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        unsigned ph[4], pl[4];
+#pragma unroll
+        for (int p2 = 0; p2 < 4; ++p2) {
+          const float v0 = F[8 * s2 + 2 * p2] * rs, v1 = F[8 * s2 + 2 * p2 + 1] * rs;
+          ph[p2] = cvt_pk_f16_c(v0, v1);
+          pl[p2] = cvt_pk_f16_c(resid_lo_c(v0, ph[p2], m1), resid_hi_c(v1, ph[p2], m1));
+        }
+        Ah[s2] = make_float4(__uint_as_float(ph[0]), __uint_as_float(ph[1]), __uint_as_float(ph[2]), __uint_as_float(ph[3]));
+        Al[s2] = make_float4(__uint_as_float(pl[0]), __uint_as_float(pl[1]), __uint_as_float(pl[2]), __uint_as_float(pl[3]));
+      }
+    };
+    float* __restrict__ ST0 = reinterpret_cast<float*>(lds);                     // [2 channel tiles][32][160]
+    float* __restrict__ ST1 = reinterpret_cast<float*>(lds + 2 * 32 * 160 * 4);  // [2][32][96]
+    float4 sAh[2], sAl[2];
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) sAh[s2] = sAl[s2] = make_float4(0.f, 0.f, 0.f, 0.f);
+    prep();
+    flush();
+    load_h(k_of(1));
+
+    auto k_loop = [&](auto contract) __attribute__((always_inline)) {
+      for (int it = 0; it < nk; ++it) {
+        int fox_ = fox, foc_ = foc;
+        asm volatile("" : "+v"(fox_), "+v"(foc_));
+        auto fr = [&](int i) __attribute__((always_inline)) { const int bo = boff(i); return Frag{lds_f4(fox_ + bo), lds_f4(fox_ + bo + (X_L - X_H)), lds_f4(foc_ + bo), lds_f4(foc_ + bo + PL)}; };
+        Frag fA = fr(0), fB = fr(1);
+        MF_SCHED();
+        if (it > 0) contract(it - 1);  // the previous unit's tile (registers and weights only), behind this unit's first fragment reads
+        f32x16 F = zero16;
+        for (int i = 0; i < nb; i += 2) {
+          MF_SCHED();
+          M3(F, fA.ah, fA.al, fA.bh, fA.bl);
+          MF_SCHED();
+          fA = fr(i + 2);
+          MF_SCHED();
+          if (i + 1 < nb) { M3(F, fB.ah, fB.al, fB.bh, fB.bl); }
+          MF_SCHED();
+          fB = fr(i + 3);
+        }
+        prep();  // (the entries of unit it + 1, in registers; on the last unit from clamped loads, never read)
+        load_h(k_of(it + 2));
+        LDS_BARRIER();  // A: every read of C(k) done
+        flush();
+        split16(F, sAh, sAl);
+        MF_SCHED();
+        LDS_BARRIER();  // B: C(k + 1) complete
+      }
+      contract(nk - 1);
+    };
+    if (comp == 0) {
+      // scalar outputs: 20 weight blocks per hidden unit ((hi, lo) per (output tile n, K-step s2)), ring of 10
+      constexpr int NB = 20, RD = 10;
+      f32x16 accS[5];
+#pragma unroll
+      for (int n = 0; n < 5; ++n) accS[n] = zero16;
+      auto wstream = [&](int k) __attribute__((always_inline)) { return (k * 48 + 20 * ct) * 1024; };
+      u32x4 RB[RD];
+      {
+        const int c0 = wstream(k_of(0));
+#pragma unroll
+        for (int p = 0; p < RD; ++p) RB[p] = wload(c0 + p * 1024);
+      }
+      LDS_BARRIER();  // C(k0) complete
+      k_loop([&](int u) __attribute__((always_inline)) {
+        const int cur = wstream(k_of(u)), nxt = wstream(k_of(u + 1));
+#pragma unroll
+        for (int n = 0; n < 5; ++n)
+#pragma unroll
+          for (int s2 = 0; s2 < 2; ++s2) {
+            const int p = 2 * (2 * n + s2);
+            M3(accS[n], sAh[s2], sAl[s2], RB[p % RD], RB[(p + 1) % RD]);
+#pragma unroll
+            for (int e = 0; e < 2; ++e) RB[(p + e) % RD] = (p + e + RD < NB) ? wload(cur + (p + e + RD) * 1024) : wload(nxt + (p + e + RD - NB) * 1024);
+            MF_SCHED();
+          }
+      });
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int row = (q & 3) + 8 * (q >> 2) + 4 * hh;
+#pragma unroll
+        for (int n = 0; n < 5; ++n) ST0[(ct * 32 + row) * 160 + 32 * n + r] = accS[n][q];
+      }
+    } else {
+      // vector plane comp - 1: 4 weight blocks per hidden unit ((hi, lo) per K-step), the next unit's requested as they are used
+      f32x16 accP = zero16;
+      auto wstream = [&](int k) __attribute__((always_inline)) { return (k * 48 + 40 + 4 * ct) * 1024; };
+      u32x4 RB[4];
+      {
+        const int c0 = wstream(k_of(0));
+#pragma unroll
+        for (int p = 0; p < 4; ++p) RB[p] = wload(c0 + p * 1024);
+      }
+      LDS_BARRIER();
+      k_loop([&](int u) __attribute__((always_inline)) {
+        const int nxt = wstream(k_of(u + 1));
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+          M3(accP, sAh[s2], sAl[s2], RB[2 * s2], RB[2 * s2 + 1]);
+          RB[2 * s2] = wload(nxt + (2 * s2) * 1024);
+          RB[2 * s2 + 1] = wload(nxt + (2 * s2 + 1) * 1024);
+          MF_SCHED();
+        }
+      });
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int row = (q & 3) + 8 * (q >> 2) + 4 * hh;
+        ST1[(ct * 32 + row) * 96 + (comp - 1) * 32 + r] = accP[q];
+      }
+    }
+    LDS_BARRIER();
+    {
+      const float i1 = pow2f(clamp100(-(a.sX + a.sC)));
+      auto i2_of = [&](int row) __attribute__((always_inline)) {
+        const int edeg = deg_lds[row] > 0 ? exp_above((float)deg_lds[row]) : 1;
+        return pow2f(14 + edeg);
+      };
+      float* __restrict__ p0 = a.partial0 + ((size_t)slab * a.n_pad + n0) * (size_t)(a.nt0 * 32);
+      float* __restrict__ p1 = a.partial1 + ((size_t)slab * a.n_pad + n0) * 96;
+      for (int idx = tid; idx < 32 * 40; idx += ML_THREADS) {
+        const int row = idx / 40, c4 = idx - row * 40;
+        const float4 a0 = *reinterpret_cast<const float4*>(ST0 + row * 160 + 4 * c4), a1 = *reinterpret_cast<const float4*>(ST0 + 5120 + row * 160 + 4 * c4);
+        const float4 cf = reinterpret_cast<const float4*>(a.cf0)[c4];
+        const float i2 = i2_of(row);
+        if (row < n_dst)
+          *reinterpret_cast<float4*>(p0 + row * 160 + 4 * c4) = make_float4((((a0.x + a1.x) * i1) * i2) * cf.x, (((a0.y + a1.y) * i1) * i2) * cf.y,
+                                                                             (((a0.z + a1.z) * i1) * i2) * cf.z, (((a0.w + a1.w) * i1) * i2) * cf.w);
+      }
+      for (int idx = tid; idx < 32 * 24; idx += ML_THREADS) {
+        const int row = idx / 24, c4 = idx - row * 24;
+        const float4 a0 = *reinterpret_cast<const float4*>(ST1 + row * 96 + 4 * c4), a1 = *reinterpret_cast<const float4*>(ST1 + 3072 + row * 96 + 4 * c4);
+        const float4 cf = reinterpret_cast<const float4*>(a.cf1)[c4 & 7];
+        const float i2 = i2_of(row);
+        if (row < n_dst)
+          *reinterpret_cast<float4*>(p1 + row * 96 + 4 * c4) = make_float4((((a0.x + a1.x) * i1) * i2) * cf.x, (((a0.y + a1.y) * i1) * i2) * cf.y,
+                                                                            (((a0.z + a1.z) * i1) * i2) * cf.z, (((a0.w + a1.w) * i1) * i2) * cf.w);
+      }
+    }
+    LDS_BARRIER();  // the next segment rewrites the tiles
+  }
+}
+
 void conv_ml_print_stamps() {
 #ifdef ML_TRACE
   static unsigned long long tr[8][2][24][6], sg[8][3][10];
@@ -823,7 +1140,31 @@ int launch_conv_ml(const MlArgs& a, int grid, hipStream_t st) {
   }
 }
 
+namespace {
+template <int NKS, bool HALF>
+int launch_mlx(const MlxArgs& a, int grid, hipStream_t st) {
+  constexpr int ROWX = HALF ? 32 * NKS - 16 : 32 * NKS + 16, ROWC = 32 * NKS + 16, X_END = 2 * 64 * ROWX + 4 * 2 * 32 * ROWC;
+  constexpr int EP_END = 2 * 32 * 160 * 4 + 2 * 32 * 96 * 4;
+  constexpr size_t smem = (((X_END > EP_END ? X_END : EP_END) + 15) & ~15) + 160;
+  hipLaunchKernelGGL((k_conv_mlx<NKS, HALF>), dim3(grid), dim3(ML_THREADS), smem, st, a);
+  return 0;
+}
+}  // namespace
+
+int launch_conv_mlx(const MlxArgs& a, int grid, hipStream_t st) {
+  if (a.nt0 != 5 || a.S > 64 || !a.epair) return -1;
+  switch (a.window) {
+    case 96: return launch_mlx<6, false>(a, grid, st);
+    case 128: return launch_mlx<8, false>(a, grid, st);
+    case 168: return launch_mlx<11, true>(a, grid, st);
+    default: return -1;
+  }
+}
+
 int conv_ml_set_max_lds() {
+  if (hipFuncSetAttribute((const void*)k_conv_mlx<6, false>, hipFuncAttributeMaxDynamicSharedMemorySize, JAMUN_MAX_DYN_LDS) != hipSuccess) return -1;
+  if (hipFuncSetAttribute((const void*)k_conv_mlx<8, false>, hipFuncAttributeMaxDynamicSharedMemorySize, JAMUN_MAX_DYN_LDS) != hipSuccess) return -1;
+  if (hipFuncSetAttribute((const void*)k_conv_mlx<11, true>, hipFuncAttributeMaxDynamicSharedMemorySize, JAMUN_MAX_DYN_LDS) != hipSuccess) return -1;
   if (set_lds<6, false, true>() != 0) return -1;
   if (set_lds<8, false, false>() != 0) return -1;
   if (set_lds<11, true, false>() != 0) return -1;

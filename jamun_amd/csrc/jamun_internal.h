@@ -148,6 +148,31 @@ struct MlArgs {
   int* err;                // as MfArgs::err (bit 1: a source outside the window)
   unsigned long long* mfma_count;  // += v_mfma_f32_32x32x16_f16 executed (depends on the occupied source blocks of every tile), or null
 };
+// the initial projector on the same spans (k_conv_mlx in jamun_conv_ml.hip): MfxArgs + the window
+struct MlxArgs {
+  const int* deg;
+  const int* epair;
+  const int* esrc;
+  const float4* egeo;
+  const float* h;
+  size_t h_kstride;
+  int n_pad, S;
+  const int2* tile_span;
+  const int2* tile_atoms;
+  const int4* segs;
+  int max_segs, nt0;
+  int window;  // as MlArgs
+  const unsigned* xph;  // MfxArgs::xph / xpl (zero rows behind the batch: a window reads window / 2 pairs from the pair of its first atom)
+  const unsigned* xpl;
+  const float4* wx;     // MfxArgs::wx
+  int sX, sC;
+  const float *cf0, *cf1;
+  float* partial0;
+  float* partial1;
+  int* err;
+  unsigned long long* mfma_count;
+};
+int launch_conv_mlx(const MlxArgs& a, int grid, hipStream_t st);
 int launch_conv_ml(const MlArgs& a, int grid, hipStream_t st);
 int conv_ml_set_max_lds();
 int conv_ml_window(int rows_needed);
