@@ -61,6 +61,10 @@ def molecules(kind):
 
         rng = random.Random(1234)
         return [synth.random_chain(rng.randint(17, 57), seed=100 + i) for i in range(8)]
+    # large molecules of mixed sizes in one batch (5AA-like peptides with hydrogens, 63..120 atoms; analysis/sampling_times/JAMUN.csv:6) next to
+    # small ones: tile spans of one and of two molecules, windows starting at odd atoms — the tile plan of jamun_conv_ml.hip
+    if kind == "large_mix":
+        return [synth.random_chain(n, seed=40 + i) for i, n in enumerate([63, 9, 101, 64, 120, 3, 77])]
     raise KeyError(kind)
 
 
@@ -168,8 +172,11 @@ CASES = {
     "oracle_forward_h64x16_ragged": lambda **kw: forward_case("ragged", True, variant="h64x16"),
     "oracle_forward_trained_chain17x6": lambda **kw: forward_case("chain17x6", True, variant="trained"),
     "oracle_forward_trained_ragged": lambda **kw: forward_case("ragged", True, variant="trained"),
+    "oracle_forward_trained_chig93x2": lambda **kw: forward_case("chig93x2", True, variant="trained"),
+    "oracle_forward_large_mix": lambda **kw: forward_case("large_mix", True),
     "oracle_forward_sep_trained_ragged": lambda **kw: forward_case("ragged", True, variant="sep_trained"),
     "oracle_walk_baoab_trained_ag4_12": lambda max_steps=None, **kw: walk_case("ag4", "baoab", 12, "stable", max_steps, variant="trained"),
+    "oracle_walk_baoab_trained_chig93_6": lambda max_steps=None, **kw: walk_case("chig93x2", "baoab", 6, "stable", max_steps, variant="trained"),
     "oracle_walk_baoab_chig93_6": lambda max_steps=None, **kw: walk_case("chig93x2", "baoab", 6, "stable", max_steps),
     "oracle_walk_baoab_chig166_4": lambda max_steps=None, **kw: walk_case("chig166x2", "baoab", 4, "stable", max_steps),
     "oracle_walk_baoab_ag4_50_mid": lambda max_steps=None, **kw: walk_case("ag4", "baoab", 50, "mid", max_steps),

@@ -59,6 +59,8 @@ def _mols(kind):
         return [synth.random_chain(93, seed=5)] * 2
     if kind == "chig166x2":
         return [synth.random_chain(166, seed=5)] * 2
+    if kind == "large_mix":  # (tests/golden/make_oracle_fixtures.py: molecules of 63..120 atoms next to small ones)
+        return [synth.random_chain(n, seed=40 + i) for i, n in enumerate([63, 9, 101, 64, 120, 3, 77])]
     raise KeyError(kind)
 
 
@@ -251,7 +253,7 @@ def _ckpt(preset):
     return synth.synthetic_checkpoint(output_gain={"strong": 0.5, "stable": 0.05, "mid": 0.1, "g02": 0.2}[preset])
 
 
-@pytest.mark.parametrize("kind", ["ag4", "chain17x6", "ragged", "dense70", "chig93x2", "chig166x2"])
+@pytest.mark.parametrize("kind", ["ag4", "chain17x6", "ragged", "dense70", "chig93x2", "chig166x2", "large_mix"])
 def test_forward_matches_oracle(dev, golden_dir, kind):
     """One denoiser forward vs the cached CPU-oracle outputs (tests/golden/make_oracle_fixtures.py): edge structure
     exactly, node features after every block, network output, xhat (<= 1e-5 nm RMSD) and score."""
@@ -328,10 +330,14 @@ def test_conv_kernel_variants_agree(dev, golden_dir, kind, monkeypatch):
     # VALU-forming kernel for everything larger, has four variants chosen by the span of the tiles: single phase (2), single phase
     # with one Y tile (3), two phases with resident source rows (0), two passes (large molecules, 1).  Each variant that can take
     # this batch is switched on in turn and must give the same features.
-    expect = {"ag4": 4, "chain17x6": 4, "ragged_small": 4, "ragged": 4, "dense70": 3, "chig93x2": 1, "chig166x2": 1}[kind]
+    # Molecules of 63..167 atoms take jamun_conv_ml.hip (dg_mode 5: matrix-core forming for large spans, two passes over the hidden units,
+    # block-sparse forming); with it switched off (no_ml) the VALU-forming variants take over.
+    expect = {"ag4": 4, "chain17x6": 4, "ragged_small": 4, "ragged": 4, "dense70": 5, "chig93x2": 5, "chig166x2": 5}[kind]
     assert mode == expect, (kind, mode)
     small = kind in ("ag4", "chain17x6", "ragged_small")  # spans within the single-phase budget of jamun_conv_dg.hip (~52 rows)
-    variants = {4: [("no_mf",)], 1: [("dg_no_alt",)], 2: [], 3: []}[mode]
+    variants = {4: [("no_mf",)], 5: [("no_ml",)], 1: [("dg_no_alt",)], 2: [], 3: []}[mode]
+    if mode == 5:
+        variants.append(("no_ml", "dg_no_sph") if kind == "dense70" else ("no_ml", "dg_no_alt"))
     if mode == 4:
         variants.append(("no_mf", "dg_no_sp") if small else ("no_mf", "dg_no_sph"))
         if small:
@@ -347,13 +353,13 @@ def test_conv_kernel_variants_agree(dev, golden_dir, kind, monkeypatch):
         for l in range(6):
             a2, b2 = other.debug_read(0, l).cpu(), general.debug_read(0, l).cpu()
             assert (a2 - b2).abs().max().item() <= 2e-5 * max(b2.abs().max().item(), 1e-6), (envs, l)
-    assert seen == {"ag4": {4, 2, 3, 0}, "chain17x6": {4, 2, 3, 0}, "ragged_small": {4, 2, 3, 0}, "ragged": {4, 3, 0}, "dense70": {3, 0},
-                    "chig93x2": {1, 0}, "chig166x2": {1, 0}}[kind], seen
+    assert seen == {"ag4": {4, 2, 3, 0}, "chain17x6": {4, 2, 3, 0}, "ragged_small": {4, 2, 3, 0}, "ragged": {4, 3, 0}, "dense70": {5, 3, 0},
+                    "chig93x2": {5, 1, 0}, "chig166x2": {5, 1, 0}}[kind], seen
     # The initial projector of the default path: on the tiles of k_conv_mf (spans up to 62 rows) k_conv_mfi (up to 32 distinct
     # embedding rows: one-hot selector, init_path 3) or k_conv_mfx (formed from the embedding rows, 4); on the tiles of the dg kernel
-    # k_conv_init_v (edge by edge on the vector ALUs, 2).  Each is switched off in turn: same features; with all of them off the
-    # general kernel takes the layer (0).
-    expect_init = {"ag4": 3, "chain17x6": 3, "ragged_small": 4, "ragged": 4, "dense70": 2, "chig93x2": 2, "chig166x2": 2}[kind]
+    # k_conv_init_v (edge by edge on the vector ALUs, 2); on the large-span tiles of jamun_conv_ml.hip k_conv_mlx (5).  Each is switched off in
+    # turn: same features; with all of them off the general kernel takes the layer (0).
+    expect_init = {"ag4": 3, "chain17x6": 3, "ragged_small": 4, "ragged": 4, "dense70": 5, "chig93x2": 5, "chig166x2": 5}[kind]
     assert dg.stats()["init_path"] == expect_init, (kind, dg.stats()["init_path"])
     a1 = dg.debug_read(0, 0).cpu()
     if expect_init >= 3:
@@ -627,7 +633,79 @@ def test_matrix_formed_conv_edge_cases(dev, case, monkeypatch):
         assert NativeSampler(model._native, 0.04, big, dev).stats()["dg_mode"] != 4
 
 
-@pytest.mark.parametrize("atoms,walkers,dg_mode,init_path", [(17, 64, 4, 3), (33, 64, 4, 3), (57, 32, 4, 4), (70, 16, 3, 2), (166, 4, 1, 2)])
+@pytest.mark.parametrize("case", ["w96", "w128", "w168", "mixed", "odd_starts", "double_bonds", "stretched", "empty_and_single"])
+def test_large_span_matrix_formed_conv(dev, case, monkeypatch):
+    """jamun_conv_ml.hip (k_conv_ml: hidden layers, k_conv_mlx: initial projector; dg_mode 5 / init_path 5) against the general kernel and the
+    VALU-forming kernels it replaces, on what stresses its bookkeeping: each window instantiation (96, 128 and 168 source rows, the last with
+    the half block), spans of two molecules of different sizes, windows starting at odd atoms, every bond listed twice in both directions
+    (three edges of one pair share a coefficient entry), a stretched chain whose tiles touch few 16-row source blocks (the block-sparse forming
+    skips the others), a batch with 1- and 2-atom walkers between large ones.  Bit-reproducible (host-built segment lists, slabs summed in order;
+    every split primitive a compiler-visible instruction: jamun_mf_dev.h on why inline asm beside MFMAs is not)."""
+    from jamun_amd import synth
+    from jamun_amd.data import WalkerBatch
+    from jamun_amd.model import Denoiser
+    from jamun_amd.native import NativeSampler
+
+    model = Denoiser.from_checkpoint_dict(_ckpt("strong")).to(dev)
+    window = None
+    if case == "w96":
+        mols, window = [synth.random_chain(93, seed=1)] * 3 + [synth.random_chain(80, seed=2)], 96
+    elif case == "w128":
+        mols, window = [synth.random_chain(120, seed=3)] * 2 + [synth.random_chain(128, seed=4)], 128
+    elif case == "w168":
+        mols, window = [synth.random_chain(166, seed=5), synth.random_chain(167, seed=6), synth.random_chain(150, seed=7)], 168
+    elif case == "mixed":
+        mols, window = [synth.random_chain(n, seed=50 + i) for i, n in enumerate([63, 70, 9, 101, 64, 33, 120, 77, 17])], 168
+    elif case == "odd_starts":
+        mols, window = [synth.random_chain(n, seed=60 + i) for i, n in enumerate([1, 93, 3, 95, 7, 65, 5, 91])], 168  # (a span of 95 + 7 + 65 atoms)
+    elif case == "double_bonds":
+        mols = []
+        for i, n in enumerate([70, 93]):
+            m = synth.random_chain(n, seed=70 + i)
+            b = m["bonds"]
+            m["bonds"] = torch.cat([b, b.flip(0)], dim=1)  # every bond a second time, reversed: with both directions present, each ordered pair twice
+            mols.append(m)
+    elif case == "stretched":
+        m = synth.random_chain(160, seed=24)
+        pos = m["pos"].clone()
+        pos[:, 0] = 0.14 * torch.arange(160, dtype=pos.dtype)
+        pos[:, 1:] *= 0.05
+        mols, window = [dict(m, pos=pos)] * 2, 168
+    else:
+        mols = [synth.random_chain(n, seed=80 + i) for i, n in enumerate([1, 2, 100, 1, 64, 2])]
+    batch = WalkerBatch.from_molecules(mols).to(dev)
+    torch.manual_seed(13)
+    y = batch.pos + 0.04 * torch.randn(batch.pos.shape).to(dev)
+    ml = NativeSampler(model._native, 0.04, batch, dev)
+    x = ml.xhat(y)
+    st = ml.stats()
+    assert (st["conv_path"], st["dg_mode"], st["init_path"]) == (2, 5, 5), st
+    if window is not None:
+        assert st["ml_window"] == window, st
+    assert torch.isfinite(x).all() and torch.equal(ml.xhat(y), x)
+    # the block-sparse forming executes 57 MFMAs per occupied 16-row source block + 186 per (tile, hidden unit): on the stretched chain a tile's
+    # sources lie in two or three of the window's eleven blocks
+    if case == "stretched":
+        dense = 10 * 65 * (57 * 11 + 186) * 32768  # 2 x 5 tiles
+        assert 10 * 65 * 186 * 32768 < st["conv_flop_exec_launch"] < 0.55 * dense, (st["conv_flop_exec_launch"], dense)
+    valu = NativeSampler(model._native, 0.04, batch, dev, tuning={"no_ml": 1})
+    assert valu.stats()["dg_mode"] in (0, 1, 3) and valu.stats()["init_path"] == 2
+    monkeypatch.setitem(native.TUNING, "no_dg", 1)
+    general = NativeSampler(model._native, 0.04, batch, dev)
+    monkeypatch.delitem(native.TUNING, "no_dg", raising=False)
+    assert general.stats()["conv_path"] == 0
+    xv, xg = valu.xhat(y), general.xhat(y)
+    assert rmsd(x, xg) <= RMSD_TOL_NM and rmsd(xv, xg) <= RMSD_TOL_NM, (rmsd(x, xg), rmsd(xv, xg))
+    for l in range(6):
+        a, b = ml.debug_read(0, l).cpu(), general.debug_read(0, l).cpu()
+        assert (a - b).abs().max().item() <= 2e-5 * max(b.abs().max().item(), 1e-6), (case, l)
+    # the initial projector alone against k_conv_init_v on the same tiles
+    half = NativeSampler(model._native, 0.04, batch, dev, tuning={"no_mfi": 1})
+    assert half.stats()["dg_mode"] == 5 and half.stats()["init_path"] == 2
+    assert rmsd(half.xhat(y), x) <= RMSD_TOL_NM
+
+
+@pytest.mark.parametrize("atoms,walkers,dg_mode,init_path", [(17, 64, 4, 3), (33, 64, 4, 3), (57, 32, 4, 4), (70, 16, 5, 5), (93, 8, 5, 5), (166, 4, 5, 5)])
 def test_kernel_variants_chosen_for_the_baseline_shapes(dev, atoms, walkers, dg_mode, init_path):
     """BASELINE configs[1..4] shapes (fewer walkers): which variant of the hidden-layer conv kernel (jamun_stats.dg_mode) and of
     the initial projector (init_path) the sampler picks, and that the forward through them is finite and rotation-equivariant."""
@@ -712,7 +790,7 @@ def test_full_size_batches_of_the_multi_gpu_configs_match_the_oracle(dev, golden
         slots, expect_modes = [32 * i for i in range(8)], (4,)
     else:
         fixture, mols = "chig166x2", [synth.random_chain(166, seed=5)] * 64
-        slots, expect_modes = [0, 1], (1,)
+        slots, expect_modes = [0, 1], (5,)
     ref = _golden(golden_dir, f"oracle_forward_{fixture}")
     big = WalkerBatch.from_molecules(mols).to(dev)
     smp = NativeSampler(model._native, 0.04, big, dev)

@@ -43,6 +43,7 @@ CASES = [
     ("h64x16", "ragged", dict()),
     ("trained", "chain17x6", dict(dg_mode=4, init_path=3, dg_emu=1)),
     ("trained", "ragged", dict(dg_mode=4, init_path=4, dg_emu=1)),
+    ("trained", "chig93x2", dict(dg_mode=5, init_path=5, dg_emu=1, ml_window=96)),  # the reference's chignolin shape (93 heavy atoms) on k_conv_ml / k_conv_mlx
     ("sep_trained", "ragged", dict()),
     # the default point on BASELINE configs[1] as the reference runs it: 48 DISTINCT dipeptides (real topology, 143 distinct embedding rows)
     ("default", "dipep48", dict(dg_mode=4, dg_emu=1, init_path=4)),
@@ -132,6 +133,30 @@ def test_walk_with_trained_like_weights_matches_oracle():
     batch = WalkerBatch.from_molecules(mk.molecules("ag4")).to(dev)
     smp = model.sampler_for(batch, 0.04)
     steps = 12
+    noise = ref["noise"]
+    y, v = ref["y0"].to(dev).clone(), noise[1].to(dev).clone()
+    params = native.make_mcmc_params(steps, 0.04, 1.0, 1.0, 1.0, 100.0)
+    y_traj, score_traj, xhat_traj, xhat = smp.walk("baoab", y, v, params, noise[2 : steps + 1].to(dev).contiguous(), 0, True)
+    worst = max(rmsd(xhat_traj[t], ref["xhat_traj"][t]) for t in range(steps))
+    assert worst <= RMSD_TOL_NM, worst
+
+
+def test_walk_at_the_reference_chignolin_shape_with_trained_like_weights_matches_oracle():
+    """93 heavy atoms (what the reference feeds the model for chignolin: data/_mdtraj.py:60,218) x 2 walkers, trained-like weights, six BAOAB
+    walk-jump frames on k_conv_ml / k_conv_mlx against the oracle: every frame within 1e-5 nm."""
+    from jamun_amd import native
+    from jamun_amd.data import WalkerBatch
+    from jamun_amd.model import Denoiser
+
+    mk = _mk()
+    dev = torch.device("cuda", 0)
+    ref = _golden("oracle_walk_baoab_trained_chig93_6")
+    model = Denoiser.from_checkpoint_dict(mk.variant_checkpoint("trained", mk.GAINS["stable"])).to(dev)
+    batch = WalkerBatch.from_molecules(mk.molecules("chig93x2")).to(dev)
+    smp = model.sampler_for(batch, 0.04)
+    st = smp.stats()
+    assert (st["dg_mode"], st["init_path"], st["ml_window"]) == (5, 5, 96), st
+    steps = 6
     noise = ref["noise"]
     y, v = ref["y0"].to(dev).clone(), noise[1].to(dev).clone()
     params = native.make_mcmc_params(steps, 0.04, 1.0, 1.0, 1.0, 100.0)
