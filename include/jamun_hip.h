@@ -102,7 +102,9 @@ typedef struct jamun_tuning {
   int32_t no_tail;      /* k_conv_mf: tiles with few destinations stay whole tiles (no k_tail_form / k_tail_contract)                 */
   int32_t no_short_k;   /* k_conv_mf: always four forming K-steps (64 source rows), also when every tile's sources fit the first 48      */
   int32_t no_ml;        /* hidden layers: not k_conv_ml (matrix-core forming for source spans of 63..167 atoms); k_conv_dg there              */
-  int32_t reserved[2];  /* must be zero                                                                                              */
+  int32_t seg_cost_tenths; /* work lists of the destination-grouped kernels: cost of a segment's prologue + epilogue in tenths of a (tile, hidden unit)
+                              item when the lists are cut (0: the kernel's measured default — k_conv_mf 3.6, k_conv_ml 5.8 items —, -1: none)        */
+  int32_t reserved[1];  /* must be zero                                                                                              */
 } jamun_tuning;
 
 typedef struct jamun_model jamun_model;     /* raw checkpoint tensors kept on the host          */

@@ -1597,7 +1597,8 @@ struct SegPlan {
 };
 template <typename WeightFn>
 SegPlan plan_segments(int cus, int ng, int n_k, int N, const std::vector<int2>& t_atoms, const std::vector<int>& t_chunk, int n_chunks,
-                      WeightFn weight, const std::vector<char>* skip = nullptr) {  // skip[t]: tile t is not on this plan (its atoms get 0 slabs)
+                      WeightFn weight, const std::vector<char>* skip = nullptr,  // skip[t]: tile t is not on this plan (its atoms get 0 slabs)
+                      double seg_cost = 0.0) {                                   // cost of a segment's prologue + epilogue, in items
   SegPlan P;
   const int ncx_all = cus / ng;
   std::vector<std::vector<int>> wg_of(ng);  // workgroups of k-slice x, in launch order
@@ -1620,6 +1621,7 @@ SegPlan plan_segments(int cus, int ng, int n_k, int N, const std::vector<int2>& 
     if (w_max < 0) continue;  // (no tile on this plan)
     const bool uniform = 4 * (w_max - w_min) < w_max;
     auto weight_of = [&](int t) -> int64_t { return uniform ? 1 : weight(t); };
+    const double unit = uniform ? 1.0 : 1.0 / (double)std::max<int64_t>(w_min, 1);
     int64_t Lx = 0, Wx = 0;
     for (int t = 0; t < n_tiles; ++t) {
       if (skipped(t)) continue;
@@ -1630,25 +1632,48 @@ SegPlan plan_segments(int cus, int ng, int n_k, int N, const std::vector<int2>& 
     // small batches: do not cut the list finer than 8 items per workgroup (a tile's partial slabs are summed by the node
     // update; one slab per hidden unit would make that kernel the bottleneck)
     const int ncx = (int)std::max<int64_t>(1, std::min<int64_t>(ncx_all, Lx / 8));
-    int64_t off_w = 0;
-    for (int t = 0; t < n_tiles; ++t) {
-      if (skipped(t)) continue;
-      const int ex = extra_of(t), cnt = base + (ex >= 0 ? 1 : 0);
-      const int64_t w = weight_of(t);
-      auto wg_of_item = [&](int i) { return (int)std::min<int64_t>(ncx - 1, ((off_w + i * w + w / 2) * ncx) / Wx); };
-      int i0 = 0;
-      while (i0 < cnt) {
-        const int c = wg_of_item(i0);
-        int i1 = i0 + 1;
-        while (i1 < cnt && wg_of_item(i1) == c) ++i1;
-        const int kb = x * base + std::min(i0, base), ke = x * base + std::min(i1, base);
-        auto& v = wg_segs[wg_of[x][c]];
-        v.push_back(make_int4(t, nslab[t_chunk[t]]++, kb, ke));
-        v.push_back(make_int4(i1 > base ? ex : -1, 0, 0, 0));
-        i0 = i1;
+    // Every segment costs its workgroup a prologue and an epilogue (staging the span's rows, the edge records, the partial slab): `seg_cost`
+    // items' worth (measured with the kernels' segment stamps: k_conv_mf 17 k cycles against 4.75 k per item, k_conv_ml 49 k against 8.5 k).  A
+    // workgroup whose share of the list crosses a tile boundary runs two segments, one that does not runs one: the list is cut so that
+    // items x weight + segments x seg_cost is level — the smallest per-workgroup budget for which a greedy walk over the list fits ncx workgroups.
+    auto walk = [&](double budget, std::vector<std::vector<int4>>* out) {
+      int c = 0;
+      double acc = 0;
+      for (int t = 0; t < n_tiles; ++t) {
+        if (skipped(t)) continue;
+        const int ex = extra_of(t), cnt = base + (ex >= 0 ? 1 : 0);
+        const double w = (double)weight_of(t) * unit;
+        int i0 = 0;
+        while (i0 < cnt) {
+          int take = (int)std::floor((budget - acc - seg_cost) / w + 1e-9);
+          if (take < 1 && acc > 0) { ++c; acc = 0; continue; }  // (no room for a segment with one item: next workgroup)
+          take = std::max(1, std::min(take, cnt - i0));
+          if (c >= ncx) return false;
+          if (out) {
+            const int i1 = i0 + take;
+            const int kb = x * base + std::min(i0, base), ke = x * base + std::min(i1, base);
+            auto& v = (*out)[wg_of[x][c]];
+            v.push_back(make_int4(t, nslab[t_chunk[t]]++, kb, ke));
+            v.push_back(make_int4(i1 > base ? ex : -1, 0, 0, 0));
+          }
+          acc += seg_cost + take * w;
+          i0 += take;
+        }
       }
-      off_w += cnt * w;
+      return c < ncx;
+    };
+    double lo = 0, hi = 0;
+    {
+      // unit: items are counted in units of the lightest tile's weight
+      for (int t = 0; t < n_tiles; ++t)
+        if (!skipped(t)) hi += (base + (extra_of(t) >= 0 ? 1 : 0)) * (double)weight_of(t) * unit + seg_cost;
+      lo = hi / ncx * 0.5;
     }
+    for (int iter = 0; iter < 60; ++iter) {
+      const double mid = 0.5 * (lo + hi);
+      if (walk(mid, nullptr)) hi = mid; else lo = mid;
+    }
+    walk(hi, &wg_segs);
   }
   size_t ms = 1;
   for (auto& v : wg_segs) ms = std::max(ms, v.size() / 2 + 1);
@@ -1700,7 +1725,8 @@ int jamun_sampler_create(const jamun_model* m, float sigma, const jamun_topology
     if (tuning) tn = *tuning;
     if (tn.dg_kgroups != 0 && tn.dg_kgroups != 1 && tn.dg_kgroups != 2 && tn.dg_kgroups != 4 && tn.dg_kgroups != 8)
       throw Err(JAMUN_ERR_INVALID, "jamun_tuning.dg_kgroups must be 0 (default), 1, 2, 4 or 8");
-    if (tn.reserved[0] != 0 || tn.reserved[1] != 0) throw Err(JAMUN_ERR_INVALID, "jamun_tuning.reserved must be zero");
+    if (tn.reserved[0] != 0) throw Err(JAMUN_ERR_INVALID, "jamun_tuning.reserved must be zero");
+    if (tn.seg_cost_tenths < -1 || tn.seg_cost_tenths > 1000) throw Err(JAMUN_ERR_INVALID, "jamun_tuning.seg_cost_tenths must be -1 (no segment cost), 0 (default) or 1..1000");
     if (!(sigma > 0)) throw Err(JAMUN_ERR_INVALID, "sigma must be positive");
     if (topo->n_atoms < 1 || topo->n_graphs < 1) throw Err(JAMUN_ERR_INVALID, "empty walker batch");
     const jamun_hparams& hp = m->hp;
@@ -2011,7 +2037,9 @@ int jamun_sampler_create(const jamun_model* m, float sigma, const jamun_topology
             s->tail_P = dev_alloc<float4>(p_bytes / 16);
           }
         }
-        SegPlan P = plan_segments(cus, ng, n_k, N, t_atoms, t_chunk, n_chunks, weight, s->n_tail_tiles ? &is_tail : nullptr);
+        // (a segment's prologue + epilogue in items of its k loop, from the kernels' segment stamps; jamun_tuning.seg_cost_tenths overrides)
+        const double seg_cost = tn.seg_cost_tenths < 0 ? 0.0 : tn.seg_cost_tenths > 0 ? 0.1 * tn.seg_cost_tenths : s->dg_mode == 4 ? 3.6 : s->dg_mode == 5 ? 5.8 : 0.0;
+        SegPlan P = plan_segments(cus, ng, n_k, N, t_atoms, t_chunk, n_chunks, weight, s->n_tail_tiles ? &is_tail : nullptr, seg_cost);
         if (s->n_tail_tiles) {
           for (size_t t = 0; t < t_atoms.size(); ++t)
             if (is_tail[t])
@@ -2019,7 +2047,7 @@ int jamun_sampler_create(const jamun_model* m, float sigma, const jamun_topology
           P.n_slabs = std::max(P.n_slabs, s->tail_runs);
           s->init_tail = s->layers[0].wx != nullptr && s->layers[0].p0.nt == 5 && !tn.no_mfi;
           if (!s->init_tail) {  // the initial projector keeps every tile on segment lists of its own
-            SegPlan PI = plan_segments(cus, ng, n_k, N, t_atoms, t_chunk, n_chunks, weight);
+            SegPlan PI = plan_segments(cus, ng, n_k, N, t_atoms, t_chunk, n_chunks, weight, nullptr, seg_cost);
             s->init_segs = dev_upload(PI.segs);
             s->init_atom_nslab = dev_upload(PI.atom_nslab);
             s->init_max_segs = PI.max_segs;

@@ -61,12 +61,15 @@ __device__ __forceinline__ float resid_hi(float a, unsigned pk) {  // a - float(
   asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(pk), "v"(a));
   return r;
 }
-// The same three primitives as COMPILER-VISIBLE instructions (jamun_conv_ml.hip).  An inline-asm statement is opaque to the hazard recogniser:
-// when the register allocator hands one of the asm's outputs a VGPR that an MFMA issued a few cycles earlier still reads as its A / B operand
-// (the multi-pass v_mfma_f32_32x32x16_f16 reads them over several passes), nothing inserts the wait states and the MFMA multiplies a
-// half-overwritten fragment — wrong AND non-reproducible results (measured: the T term of k_conv_ml<8>, 1e-4 per layer, gone with these).
-// With -1.0 held in a scalar register the compiler cannot fold fma(float(h), -1, a) into a subtraction and selects exactly the instructions
-// of the asm versions: v_cvt_pk_f16_f32, v_fma_mix_f32.
+// The same three primitives as COMPILER-VISIBLE instructions, for jamun_conv_ml.hip.  With -1.0 held in a scalar register the optimiser
+// cannot see through, fma(float(h), -1, a) is not folded into a subtraction and the back end selects exactly the instructions of the asm
+// versions (v_cvt_pk_f16_f32, v_fma_mix_f32) — as instructions it schedules and whose hazards it tracks.
+// Why two forms (round 5, measured; the cause is not established, so each kernel keeps the form it was validated with):
+//  * k_conv_ml<8> with the INLINE-ASM splits in its T term gave wrong AND irreproducible features (1e-4 per layer, different from run to run;
+//    extra wait counts and nops did not help); with these it is exact to 5e-7 and bit-reproducible (tests/test_gpu_parity.py:
+//    test_large_span_matrix_formed_conv).  An asm statement is opaque to the hazard recogniser and to the scheduler.
+//  * k_conv_mf with THESE in the split of its plane waves (and only there: staging, builder and the scalar waves' split convert cleanly)
+//    gives wrong vector rows — and runs 5 % faster, which is the lower power of wrong data, not a gain (profiles/EXPERIMENTS.md).
 typedef _Float16 mf_h2 __attribute__((ext_vector_type(2)));
 typedef float mf_f2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ float opaque_minus_one() {
