@@ -280,6 +280,11 @@ typedef struct jamun_stats {
 } jamun_stats;
 /* Synchronises `stream`. */
 int jamun_sampler_stats(jamun_sampler* s, jamun_stats* out, void* stream);
+/* Synchronises `stream` and returns JAMUN_ERR_INVALID if a matrix-formed conv kernel flagged, in any forward enqueued so far, an edge table
+ * its coefficient tiles cannot represent (more than three edges of one ordered pair; a source outside the tile's window: host plan and kernel
+ * disagree).  The flag also surfaces, unsynchronised, at the next entry point after its copy landed; call this where the results are about to
+ * be consumed (jamun_amd.sampling.Sampler does, once per batch). */
+int jamun_sampler_check(jamun_sampler* s, void* stream);
 
 /* Per-kernel-class timing with HIP events recorded on the launch stream around each launch of the forward
  * (bench.py's roofline leg).  enable(1) starts collecting; read() synchronises `stream`, returns the summed

@@ -124,6 +124,7 @@ SYMBOLS = {
     "jamun_build_edges": (C.c_int, [_P, _P, _P]),
     "jamun_conv_block": (C.c_int, [_P, C.c_int32, _P, _P, _P]),
     "jamun_sampler_stats": (C.c_int, [_P, C.POINTER(jamun_stats), _P]),
+    "jamun_sampler_check": (C.c_int, [_P, _P]),
     "jamun_profile_enable": (C.c_int, [_P, C.c_int32]),
     "jamun_profile_sample": (C.c_int, [_P, C.c_int32]),
     "jamun_profile_read": (C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(C.c_int64), _P]),

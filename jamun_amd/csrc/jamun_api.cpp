@@ -2506,6 +2506,16 @@ int jamun_sampler_stats(jamun_sampler* s, jamun_stats* out, void* stream) {
   });
 }
 
+int jamun_sampler_check(jamun_sampler* s, void* stream) {
+  return guarded([&] {
+    if (!s) throw Err(JAMUN_ERR_INVALID, "null argument");
+    hipStream_t st = (hipStream_t)stream;
+    mf_err_fetch(s, st);
+    HIPCHECK(hipStreamSynchronize(st));
+    mf_err_check(s);
+  });
+}
+
 int jamun_profile_enable(jamun_sampler* s, int32_t on) {
   return guarded([&] {
     if (!s) throw Err(JAMUN_ERR_INVALID, "null argument");

@@ -221,6 +221,11 @@ class NativeSampler:
                           _ptr(y_traj), _ptr(score_traj), _ptr(xhat_traj), _ptr(xhat), _stream()))
         return y_traj, score_traj, xhat_traj, xhat
 
+    def check(self) -> None:
+        """Synchronise and raise if a conv kernel flagged an edge table it cannot represent (``jamun_sampler_check``)."""
+        with torch.cuda.device(self.device):
+            _lib.check(self._lib.jamun_sampler_check(self._h, _stream()))
+
     def stats(self) -> dict:
         st = _lib.jamun_stats()
         with torch.cuda.device(self.device):

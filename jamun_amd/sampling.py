@@ -426,6 +426,8 @@ class Sampler:
             for batch_idx in range(num_batches):
                 self.global_step = batch_idx
                 out = batch_sampler.sample(model=model_wrapped, y_init=y_init, v_init=v_init)
+                # (the batch is about to be consumed: synchronise once and surface a conv kernel's error flag HERE, not at some later call)
+                model_wrapped.native_sampler(batch_sampler.sigma).check()
                 samples = model_wrapped.unbatch_samples(out)
                 if continue_chain:
                     y_init = out["y"].to(model_wrapped.device)

@@ -1274,3 +1274,43 @@ def test_long_walks_are_bit_reproducible(dev, shape):
     assert torch.isfinite(runs[0][0]).all()
     for a, b in zip(runs[0], runs[1]):
         assert torch.equal(a, b)
+
+
+def test_a_twenty_thousand_step_batch_through_the_sampler_is_bit_reproducible(dev):
+    """The reference's shipped batch length (num_sampling_steps_per_batch = 20 000: configs/experiment/sample_uncapped_2AA.yaml:16-17) at the
+    BASELINE configs[1] shape, through Sampler.sample / SingleMeasurementSampler / BAOAB as jamun_sample runs it: 3 x 1 GB of frames per batch,
+    per-walker [n, T, 3] views for the callbacks.  Twice from the same seed: every frame of every walker bit-identical, the last frame finite."""
+    from jamun_amd import synth
+    from jamun_amd.data import WalkerBatch
+    from jamun_amd.model import Denoiser
+    from jamun_amd.sampling import BAOAB, Sampler, SingleMeasurementSampler
+
+    steps = 20000
+    mols = [dict(synth.random_chain(17, seed=0), dataset_label="m")] * 256
+    batch = WalkerBatch.from_molecules(mols)
+    model = Denoiser.from_checkpoint_dict(synth.synthetic_checkpoint(output_gain=0.05)).to(dev)
+
+    class Keep:
+        def __init__(self):
+            self.first, self.last, self.frames = None, None, 0
+
+        def on_after_sample_batch(self, sample, sampler):
+            assert len(sample) == 256 and tuple(sample[0]["xhat_traj"].shape) == (17, steps, 3)
+            self.frames = sample[0]["xhat_traj"].shape[1]
+            # (checksums on the device: the batch's frames are views of one [T, N, 3] tensor)
+            full = torch.stack([s["xhat_traj"] for s in sample[:4]])
+            self.first = full.clone()
+            self.last = torch.stack([s["xhat_traj"][:, -1] for s in sample]).clone()
+            self.sum = torch.stack([s["y_traj"].double().sum() for s in sample]).clone()
+
+    outs = []
+    for _ in range(2):
+        keep = Keep()
+        mcmc = BAOAB(steps=steps, save_trajectory=True, save_every_n_steps=1, v_init="gaussian", delta=0.04, friction=1.0, M=1.0,
+                     inverse_temperature=1.0, score_fn_clip=100.0)
+        torch.manual_seed(123)
+        Sampler(callbacks=[keep]).sample(model, SingleMeasurementSampler(mcmc=mcmc, sigma=0.04), num_batches=1, init_graphs=batch)
+        torch.cuda.synchronize()
+        outs.append(keep)
+    assert outs[0].frames == steps and torch.isfinite(outs[0].last).all()
+    assert torch.equal(outs[0].first, outs[1].first) and torch.equal(outs[0].last, outs[1].last) and torch.equal(outs[0].sum, outs[1].sum)
