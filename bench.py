@@ -572,7 +572,7 @@ def main():
             "higher_is_better": True,
             "scaling": "strong" if args.strong else "weak",
             "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": "f32" if stats.get("dg_emu", 0) != 2 else "f16x1 (opt-in reduced-precision conv, JAMUN_TUNING=f16x1: NOT the metric's precision)",
             "data": "synthetic",
             "timed_repeats": len(per_rep),
             "timed_total_s": sum(per_rep),
@@ -611,7 +611,8 @@ def main():
             flop = stats["conv0_flop_alg"] + (stats["conv1_flop_alg"] if fused else 0)
             kname = ("k_conv_mf" if stats.get("dg_mode") == 4 else "k_conv_ml" if stats.get("dg_mode") == 5 else f"k_conv_dg<mode {stats.get('dg_mode')}>") if stats["conv_path"] == 2 else \
                 {1: "k_conv_fused"}.get(stats["conv_path"], "k_conv")
-            f16x3 = stats.get("dg_emu", -1) == 1 and fused and stats.get("conv_flop_exec_launch", 0) > 0
+            f16x3 = stats.get("dg_emu", -1) in (1, 2) and fused and stats.get("conv_flop_exec_launch", 0) > 0  # (2: the opt-in f16x1 mode)
+            f16x1 = stats.get("dg_emu", -1) == 2
             if f16x3 or (fused and stats.get("conv_flop_exec_launch", 0) > 0):
                 # The roof is the one of the instructions the kernel issues: dense f16 MFMA (2.5 PFLOP/s) for the f16x3 scheme — every
                 # fp32 product is three v_mfma_f32_32x32x16_f16 on operands split hi + lo, fp32 accumulate — or the
@@ -626,7 +627,8 @@ def main():
                               + ("; A operand formed on the matrix cores" if stats.get("dg_mode") in (4, 5) else "; A operand formed on the vector ALUs")
                               + ("; two passes over the hidden units, block-sparse forming over the occupied 16-row source blocks" if stats.get("dg_mode") == 5 else "") + ")",
                     "bound": "mfma",
-                    "mfma_dtype": "f16 (f16x3 emulation of fp32: operands split hi + lo, 3 MFMAs per product, fp32 accumulate)" if f16x3 else "f32",
+                    "mfma_dtype": "f16 (opt-in f16x1: operands rounded to f16, 1 MFMA per product, fp32 accumulate)" if f16x1 else
+                                  "f16 (f16x3 emulation of fp32: operands split hi + lo, 3 MFMAs per product, fp32 accumulate)" if f16x3 else "f32",
                     "achieved": ex,
                     "peak": peak,
                     "unit": "TFLOP/s",

@@ -104,7 +104,10 @@ typedef struct jamun_tuning {
   int32_t no_ml;        /* hidden layers: not k_conv_ml (matrix-core forming for source spans of 63..167 atoms); k_conv_dg there              */
   int32_t seg_cost_tenths; /* work lists of the destination-grouped kernels: cost of a segment's prologue + epilogue in tenths of a (tile, hidden unit)
                               item when the lists are cut (0: the kernel's measured default — k_conv_mf 3.6, k_conv_ml 5.8 items —, -1: none)        */
-  int32_t reserved[1];  /* must be zero                                                                                              */
+  int32_t f16x1;        /* OPT-IN reduced precision of the hidden-layer conv (k_conv_mf / k_conv_ml): each fp32 product as ONE f16 MFMA (operands
+                           rounded to 11 bits, fp32 accumulation) instead of the three of the f16x3 scheme; state, integrator, radial MLPs, initial
+                           projector, node update and head stay as they are.  Never the default; x-hat then differs from the fp32 path at the 1e-4 nm
+                           level (the level of the reference's TF32 GPU path).  jamun_stats.dg_emu reports 2.  Ignored by the other conv kernels.   */
 } jamun_tuning;
 
 typedef struct jamun_model jamun_model;     /* raw checkpoint tensors kept on the host          */
@@ -263,7 +266,7 @@ typedef struct jamun_stats {
                              2 edge-by-edge VALU kernel on the tiles of jamun_conv_dg.hip (jamun_conv_initv.hip),
                              0 the general kernel k_conv  (1 was the table kernel jamun_conv_init.hip, retired in round 4) */
   int32_t dg_row_blocks;  /* jamun_conv_dg.hip: 1 when some molecule exceeds the span budget and its sources are cut into row blocks */
-  int32_t dg_emu;         /* jamun_conv_dg.hip contraction: 1 f16x3 (three v_mfma_f32_*_f16 per fp32 product, operands split hi + lo),
+  int32_t dg_emu;         /* hidden-layer conv arithmetic: 2 f16x1 (jamun_tuning.f16x1: one f16 MFMA per product; k_conv_mf / k_conv_ml only), 1 f16x3 (three v_mfma_f32_*_f16 per fp32 product, operands split hi + lo),
                              0 v_mfma_f32_32x32x2_f32 (jamun_tuning.dg_fp32); -1: not in use */
   int64_t conv_flop_exec_launch; /* matrix-core FLOPs EXECUTED by ONE launch of the hidden-layer conv kernel (k_conv_mf / k_conv_dg; padding,
                              structural zeros of the forming GEMMs and the three products of the f16x3 scheme included; the T pre-pass is

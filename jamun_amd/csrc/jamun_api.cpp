@@ -334,7 +334,7 @@ struct jamun_sampler {
   // destination-grouped VALU-forming conv kernel (jamun_conv_dg.hip; hidden layers): own tile plan (larger source spans)
   bool dg_on = false, dg_row_blocks = false;
   int dg_mode = 0;  // 0 two-phase resident, 1 alternating residency, 2 single phase (see jamun_sampler_create)
-  int dg_emu = 1;   // 1: f16x3 contraction (three f16 MFMAs per fp32 product); 0 (JAMUN_DG_FP32=1): v_mfma_f32_32x32x2_f32
+  int dg_emu = 1;   // 1: f16x3 contraction (three f16 MFMAs per fp32 product); 0 (jamun_tuning.dg_fp32): v_mfma_f32_32x32x2_f32; stats report 2 for the opt-in f16x1 mode (s->x1)
   int dg_RS = 0, dg_grid = 0, dg_max_segs = 0, dg_n_slabs = 0, dg_n_tiles = 0;
   int2 *dg_tile_atoms = nullptr, *dg_tile_span = nullptr;
   int4* dg_segs = nullptr;
@@ -347,6 +347,7 @@ struct jamun_sampler {
   // destinations at a time (k_tail_form / k_tail_contract) instead of as whole tiles of k_conv_mf; the initial projector keeps them as tiles
   int n_tail_tiles = 0, n_tail = 0, tail_runs = 0;
   int mf_nks = 4;  // forming K-steps of k_conv_mf (3: every whole tile's sources lie in the first 48 rows of its window)
+  int x1 = 0;         // 1: reduced-precision hidden-layer conv (jamun_tuning.f16x1) — honoured by k_conv_mf / k_conv_ml (dg_mode 4 / 5) only
   int ml_window = 0;  // mode 5 (jamun_conv_ml.hip): source rows of the instantiation (96, 128, 168)
   unsigned long long* ml_count = nullptr;  // device: v_mfma_f32_32x32x16_f16 executed by k_conv_ml since create (depends on the occupied source blocks)
   int64_t ml_launches = 0;                 // ... over this many launches
@@ -1383,7 +1384,7 @@ void run_layer(jamun_sampler* s, size_t l, const float* x_in, int XSin, float* x
         std::frexp(1.5 * (double)L.dg.hmax2, &e3);  // 3 max|h~| < 2^e3
         f.sC = std::max(-40, std::min(40, 14 - e3));
       }
-      f.partial0 = s->partial0; f.partial1 = s->partial1; f.err = s->mf_err;
+      f.partial0 = s->partial0; f.partial1 = s->partial1; f.err = s->mf_err; f.x1 = s->x1;
       {
         ProfScope pt(s, JAMUN_PROF_TPROD, st);
         launch_tprod(x_in, XSin, s->n_atoms, s->hp.edge_attr_dim + 1, L.dg.wt, L.dg.wth, L.dg.gT, L.dg.cfT, s->dg_T, s->dg_tstride, st);
@@ -1416,7 +1417,7 @@ void run_layer(jamun_sampler* s, size_t l, const float* x_in, int XSin, float* x
         std::frexp(1.5 * (double)L.dg.hmax2, &e3);  // 3 max|h~| < 2^e3
         f.sC = std::max(-40, std::min(40, 14 - e3));
       }
-      f.partial0 = s->partial0; f.partial1 = s->partial1; f.err = s->mf_err; f.mfma_count = s->ml_count;
+      f.partial0 = s->partial0; f.partial1 = s->partial1; f.err = s->mf_err; f.mfma_count = s->ml_count; f.x1 = s->x1;
       {
         ProfScope pt(s, JAMUN_PROF_TPROD, st);
         launch_tprod(x_in, XSin, s->n_atoms, s->hp.edge_attr_dim + 1, L.dg.wt, L.dg.wth, L.dg.gT, L.dg.cfT, s->dg_T, s->dg_tstride, st);
@@ -1725,7 +1726,7 @@ int jamun_sampler_create(const jamun_model* m, float sigma, const jamun_topology
     if (tuning) tn = *tuning;
     if (tn.dg_kgroups != 0 && tn.dg_kgroups != 1 && tn.dg_kgroups != 2 && tn.dg_kgroups != 4 && tn.dg_kgroups != 8)
       throw Err(JAMUN_ERR_INVALID, "jamun_tuning.dg_kgroups must be 0 (default), 1, 2, 4 or 8");
-    if (tn.reserved[0] != 0) throw Err(JAMUN_ERR_INVALID, "jamun_tuning.reserved must be zero");
+    if (tn.f16x1 != 0 && tn.f16x1 != 1) throw Err(JAMUN_ERR_INVALID, "jamun_tuning.f16x1 must be 0 or 1");
     if (tn.seg_cost_tenths < -1 || tn.seg_cost_tenths > 1000) throw Err(JAMUN_ERR_INVALID, "jamun_tuning.seg_cost_tenths must be -1 (no segment cost), 0 (default) or 1..1000");
     if (!(sigma > 0)) throw Err(JAMUN_ERR_INVALID, "sigma must be positive");
     if (topo->n_atoms < 1 || topo->n_graphs < 1) throw Err(JAMUN_ERR_INVALID, "empty walker batch");
@@ -2081,6 +2082,7 @@ int jamun_sampler_create(const jamun_model* m, float sigma, const jamun_topology
           s->dg_T = dev_alloc<float>((size_t)n_k * N * 32);
         }
         s->dg_on = true;
+        s->x1 = (tn.f16x1 && (s->dg_mode == 4 || s->dg_mode == 5) && s->dg_emu) ? 1 : 0;
         // initial projector on the same tiles: two LDS buffers of table rows when they fit (spans up to ~90 rows), else one
         // (up to ~170 rows)
         // (mid-size ragged batches keep the MFMA table kernel: on 17-57 atom molecules, mean in-degree 11, it takes 0.283 ms
@@ -2471,8 +2473,8 @@ int jamun_sampler_stats(jamun_sampler* s, jamun_stats* out, void* stream) {
     out->dg_mode = s->dg_on ? s->dg_mode : -1;
     out->init_path = s->mlx_on ? 5 : s->mfx_on ? 4 : s->mfi_on ? 3 : s->initv_on ? 2 : 0;
     out->dg_row_blocks = s->dg_on && s->dg_row_blocks ? 1 : 0;
-    out->dg_emu = s->dg_on ? s->dg_emu : -1;
-    out->conv_flop_exec_launch = s->conv_flop_exec_launch;
+    out->dg_emu = s->dg_on ? (s->x1 ? 2 : s->dg_emu) : -1;
+    out->conv_flop_exec_launch = (s->x1 && s->dg_mode == 4) ? s->conv_flop_exec_launch / 3 : s->conv_flop_exec_launch;
     if (s->dg_on && s->dg_mode == 5 && s->ml_count && s->ml_launches > 0) {  // (block-sparse forming: counted by the kernel; mean over its launches so far)
       unsigned long long cnt = 0;
       HIPCHECK(hipMemcpy(&cnt, s->ml_count, sizeof(cnt), hipMemcpyDeviceToHost));
@@ -2489,7 +2491,7 @@ int jamun_sampler_stats(jamun_sampler* s, jamun_stats* out, void* stream) {
       const int64_t contraction = 2 * H1 * N * ((m0 + m1) * (m0 + m1) + 3 * m1 * (2 * m1));
       // per edge and k: x0 (m0), dot 3 m1, x1 3 m1, cross 6 m1, T term 3 m1 — on the matrix cores only in k_conv_mf (k_conv_dg forms on the vector ALUs)
       const int64_t forming = (s->dg_mode == 4 || s->dg_mode == 5) ? 2 * H1 * (int64_t)e * (m0 + 15 * m1) : 0;
-      out->conv_flop_useful_launch = (s->dg_emu ? 3 : 1) * (contraction + forming);
+      out->conv_flop_useful_launch = (s->x1 ? 1 : s->dg_emu ? 3 : 1) * (contraction + forming);
       const int64_t slots = (int64_t)s->h_kstride;
       out->conv_bytes_alg_launch = 4 * (H1 * slots          // h~ of the layer
                                         + H1 * 32 * N         // T

@@ -72,7 +72,8 @@ __device__ unsigned long long g_mfseg[8][4][8];  // [wave][segment][stamp]: segm
 // NKS: K-steps of 16 source rows per forming product (4 = the whole 64-row window; 3 when EVERY tile of the launch has its sources
 // in the window's first 48 rows — one 33-atom molecule per tile: 57 instead of 76 forming products per hidden unit; chosen by the host,
 // MfArgs::nks: a per-step branch on the span breaks the pinned schedule, a compile-time count does not)
-template <int SPD, int NKS>
+// X1: the opt-in reduced-precision mode (jamun_tuning.f16x1): every product is its hi hi MFMA alone (operands rounded to 11 bits, fp32 accumulation)
+template <int SPD, int NKS, bool X1>
 __global__ __launch_bounds__(MF_THREADS) void k_conv_mf(MfArgs a) {
   extern __shared__ float4 lds4[];
   char* __restrict__ lds = reinterpret_cast<char*>(lds4);
@@ -356,7 +357,7 @@ __global__ __launch_bounds__(MF_THREADS) void k_conv_mf(MfArgs a) {
       return Frag{lds_f4(xa), lds_f4(xa + xlo), lds_f4(ca), lds_f4(ca + MF_PL)};
     };
     auto mm = [&](f32x16& F, const Frag& f) {
-      if constexpr (!(dbg & 2)) { M3(F, f.ah, f.al, f.bh, f.bl); }
+      if constexpr (!(dbg & 2)) { MX(F, f.ah, f.al, f.bh, f.bl); }
       else { F[0] += f.ah.x + f.al.x + f.bh.x + f.bl.x; }
     };
     auto split = [&](const f32x16& F, float4 (&Ah)[2], float4 (&Al)[2]) {
@@ -401,7 +402,7 @@ __global__ __launch_bounds__(MF_THREADS) void k_conv_mf(MfArgs a) {
 #pragma unroll
           for (int s2 = 0; s2 < 2; ++s2) {
             const int p = 2 * (2 * n + s2);
-            if constexpr (!(dbg & 4)) { M3(accS[n], Ah[s2], Al[s2], RB[p % RD], RB[(p + 1) % RD]); }
+            if constexpr (!(dbg & 4)) { MX(accS[n], Ah[s2], Al[s2], RB[p % RD], RB[(p + 1) % RD]); }
             if constexpr (!(dbg & 1)) {
 #pragma unroll
               for (int e = 0; e < 2; ++e) RB[(p + e) % RD] = (p + e + RD < NB) ? wload(cur + (p + e + RD) * 1024) : wload(nxt + (p + e + RD - NB) * 1024);
@@ -517,11 +518,11 @@ __global__ __launch_bounds__(MF_THREADS) void k_conv_mf(MfArgs a) {
 #pragma unroll
               for (int s2 = 0; s2 < 2; ++s2) {
                 const int g = 2 * n + s2, p = 2 * g;
-                if constexpr (!(dbg & 4)) accS[n] = MFMA32H(Al[s2], RB[p % R], accS[n]);
+                if constexpr (!(dbg & 4) && !X1) accS[n] = MFMA32H(Al[s2], RB[p % R], accS[n]);
                 MF_SCHED();
                 bslot(3 * g);
                 MF_SCHED();
-                if constexpr (!(dbg & 4)) accS[n] = MFMA32H(Ah[s2], RB[(p + 1) % R], accS[n]);
+                if constexpr (!(dbg & 4) && !X1) accS[n] = MFMA32H(Ah[s2], RB[(p + 1) % R], accS[n]);
                 MF_SCHED();
                 bslot(3 * g + 1);
                 MF_SCHED();
@@ -671,11 +672,11 @@ __global__ __launch_bounds__(MF_THREADS) void k_conv_mf(MfArgs a) {
           MF_SCHED();
           const Frag& f = fq[st % 3];
           const int e = 3 * (st - 3 * NKS);
-          if constexpr (!(dbg & 2)) accT = MFMA32H(f.al, f.bh, accT);
+          if constexpr (!(dbg & 2) && !X1) accT = MFMA32H(f.al, f.bh, accT);
           MF_SCHED();
           ride(e);
           MF_SCHED();
-          if constexpr (!(dbg & 2)) accT = MFMA32H(f.ah, f.bl, accT);
+          if constexpr (!(dbg & 2) && !X1) accT = MFMA32H(f.ah, f.bl, accT);
           MF_SCHED();
           ride(e + 1);
           MF_SCHED();
@@ -693,7 +694,7 @@ __global__ __launch_bounds__(MF_THREADS) void k_conv_mf(MfArgs a) {
         for (int g = 0; g < 4; ++g) {  // x1 inputs (blocks 0..3), then cross inputs (4..7): (hi, lo) per K-step
           const int s2 = g & 1, p = 2 * g;
           const float4 Ah_ = g < 2 ? f4(ahA[s2]) : f4(ahC[s2]), Al_ = g < 2 ? f4(alA[s2]) : f4(alC[s2]);
-          if constexpr (!(dbg & 4)) { M3(accP, Ah_, Al_, RB[p % R], RB[(p + 1) % R]); }
+          if constexpr (!(dbg & 4)) { MX(accP, Ah_, Al_, RB[p % R], RB[(p + 1) % R]); }
           if constexpr (!(dbg & 1)) {
 #pragma unroll
             for (int e = 0; e < 2; ++e) RB[(p + e) % R] = (p + e + R < NB) ? wload(cur + (p + e + R) * 1024) : wload(nxt + (p + e + R - NB) * 1024);
@@ -1716,21 +1717,28 @@ void conv_mf_print_stamps() {
 
 size_t conv_mf_lds_bytes() { return MF_LDS_BYTES; }
 
+namespace {
+template <bool X1>
+int launch_mf(const MfArgs& a, int grid, hipStream_t st) {
+  if (a.S <= 32) {
+    if (a.nks == 3) hipLaunchKernelGGL((k_conv_mf<32, 3, X1>), dim3(grid), dim3(MF_THREADS), MF_LDS_BYTES, st, a);
+    else hipLaunchKernelGGL((k_conv_mf<32, 4, X1>), dim3(grid), dim3(MF_THREADS), MF_LDS_BYTES, st, a);
+  } else if (a.S <= 40) {
+    if (a.nks == 3) hipLaunchKernelGGL((k_conv_mf<40, 3, X1>), dim3(grid), dim3(MF_THREADS), MF_LDS_BYTES, st, a);
+    else hipLaunchKernelGGL((k_conv_mf<40, 4, X1>), dim3(grid), dim3(MF_THREADS), MF_LDS_BYTES, st, a);
+  } else {
+    if (a.nks == 3) hipLaunchKernelGGL((k_conv_mf<64, 3, X1>), dim3(grid), dim3(MF_THREADS), MF_LDS_BYTES, st, a);
+    else hipLaunchKernelGGL((k_conv_mf<64, 4, X1>), dim3(grid), dim3(MF_THREADS), MF_LDS_BYTES, st, a);
+  }
+  return 0;
+}
+}  // namespace
+
 int launch_conv_mf(const MfArgs& a, int grid, hipStream_t st) {
   if (a.XS != 216 || a.nt0 != 5 || a.S > 64 || (a.t_stride & 1)) return -1;
   if (a.nks != 3 && a.nks != 4) return -1;
   if (!a.epair) return -1;
-  if (a.S <= 32) {
-    if (a.nks == 3) hipLaunchKernelGGL((k_conv_mf<32, 3>), dim3(grid), dim3(MF_THREADS), MF_LDS_BYTES, st, a);
-    else hipLaunchKernelGGL((k_conv_mf<32, 4>), dim3(grid), dim3(MF_THREADS), MF_LDS_BYTES, st, a);
-  } else if (a.S <= 40) {
-    if (a.nks == 3) hipLaunchKernelGGL((k_conv_mf<40, 3>), dim3(grid), dim3(MF_THREADS), MF_LDS_BYTES, st, a);
-    else hipLaunchKernelGGL((k_conv_mf<40, 4>), dim3(grid), dim3(MF_THREADS), MF_LDS_BYTES, st, a);
-  } else {
-    if (a.nks == 3) hipLaunchKernelGGL((k_conv_mf<64, 3>), dim3(grid), dim3(MF_THREADS), MF_LDS_BYTES, st, a);
-    else hipLaunchKernelGGL((k_conv_mf<64, 4>), dim3(grid), dim3(MF_THREADS), MF_LDS_BYTES, st, a);
-  }
-  return 0;
+  return a.x1 ? launch_mf<true>(a, grid, st) : launch_mf<false>(a, grid, st);
 }
 
 int launch_conv_mfi(const MfiArgs& a, int grid, hipStream_t st) {
@@ -1767,8 +1775,10 @@ int conv_mf_set_max_lds() {
                        (const void*)k_conv_mfi<32, 4>, (const void*)k_conv_mfi<64, 4>};
   for (const void* f : fi)
     if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, JAMUN_MAX_DYN_LDS) != hipSuccess) return -1;
-  const void* fns[6] = {(const void*)k_conv_mf<32, 4>, (const void*)k_conv_mf<64, 4>, (const void*)k_conv_mf<32, 3>, (const void*)k_conv_mf<64, 3>,
-                        (const void*)k_conv_mf<40, 4>, (const void*)k_conv_mf<40, 3>};
+  const void* fns[12] = {(const void*)k_conv_mf<32, 4, false>, (const void*)k_conv_mf<64, 4, false>, (const void*)k_conv_mf<32, 3, false>,
+                         (const void*)k_conv_mf<64, 3, false>, (const void*)k_conv_mf<40, 4, false>, (const void*)k_conv_mf<40, 3, false>,
+                         (const void*)k_conv_mf<32, 4, true>,  (const void*)k_conv_mf<64, 4, true>,  (const void*)k_conv_mf<32, 3, true>,
+                         (const void*)k_conv_mf<64, 3, true>,  (const void*)k_conv_mf<40, 4, true>,  (const void*)k_conv_mf<40, 3, true>};
   for (const void* f : fns)
     if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, JAMUN_MAX_DYN_LDS) != hipSuccess) return -1;
   return 0;

@@ -74,7 +74,8 @@ struct MlGeo {
 
 }  // namespace
 
-template <int NKS, bool HALF, bool DBV>
+// X1: the opt-in reduced-precision mode (jamun_tuning.f16x1): every product is its hi hi MFMA alone
+template <int NKS, bool HALF, bool DBV, bool X1>
 __global__ __launch_bounds__(ML_THREADS) void k_conv_ml(MlArgs a) {
   using G = MlGeo<NKS, HALF, DBV>;
   constexpr int ROWX = G::ROWX, ROWC = G::ROWC, PL = G::PL, CC = G::CC, RH = G::RH;
@@ -319,7 +320,7 @@ __global__ __launch_bounds__(ML_THREADS) void k_conv_ml(MlArgs a) {
       const int ic = min(i, nb - 1);
       return nb > 0 ? (int)((blist >> (4 * ic)) & 15ull) << 5 : 0;
     };
-    if (tid == 0 && a.mfma_count) atomicAdd(a.mfma_count, (unsigned long long)nk * (unsigned long long)(57 * nb + 186));
+    if (tid == 0 && a.mfma_count) atomicAdd(a.mfma_count, (unsigned long long)nk * (unsigned long long)((X1 ? 1 : 3) * (19 * nb + 62)));
 
     // ---- common matrix-wave pieces
     const int edeg_r = deg_lds[r] > 0 ? exp_above((float)deg_lds[r]) : 1;
@@ -330,7 +331,7 @@ __global__ __launch_bounds__(ML_THREADS) void k_conv_ml(MlArgs a) {
     auto wload = [&](int so) __attribute__((always_inline)) { return __builtin_amdgcn_raw_buffer_load_b128(wrs, wvo, so, 0); };
     struct Frag { float4 ah, al, bh, bl; };
     auto ldf = [&](int xa, int xlo, int ca, int clo) __attribute__((always_inline)) -> Frag { return Frag{lds_f4(xa), lds_f4(xa + xlo), lds_f4(ca), lds_f4(ca + clo)}; };
-    auto mm = [&](f32x16& F, const Frag& f) __attribute__((always_inline)) { M3(F, f.ah, f.al, f.bh, f.bl); };
+    auto mm = [&](f32x16& F, const Frag& f) __attribute__((always_inline)) { MX(F, f.ah, f.al, f.bh, f.bl); };
     auto split16 = [&](const f32x16& F, float4 (&Ah)[2], float4 (&Al)[2]) __attribute__((always_inline)) {
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
@@ -355,7 +356,7 @@ __global__ __launch_bounds__(ML_THREADS) void k_conv_ml(MlArgs a) {
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {
           const int p = 2 * (2 * n + s2);
-          M3(accS[n], Ah[s2], Al[s2], RB[p % RD], RB[(p + 1) % RD]);
+          MX(accS[n], Ah[s2], Al[s2], RB[p % RD], RB[(p + 1) % RD]);
 #pragma unroll
           for (int e = 0; e < 2; ++e) RB[(p + e) % RD] = (p + e + RD < NB20) ? wload(cur + (p + e + RD) * 1024) : wload(nxt + (p + e + RD - NB20) * 1024);
           MF_SCHED();  // (pins the ring: left alone, the scheduler sinks each load to just before its use)
@@ -549,7 +550,7 @@ __global__ __launch_bounds__(ML_THREADS) void k_conv_ml(MlArgs a) {
               }
               const float4 bh = make_float4(__uint_as_float(ph[0]), __uint_as_float(ph[1]), __uint_as_float(ph[2]), __uint_as_float(ph[3]));
               const float4 bl = make_float4(__uint_as_float(pl[0]), __uint_as_float(pl[1]), __uint_as_float(pl[2]), __uint_as_float(pl[3]));
-              M3(accT, ah, al, bh, bl);
+              MX(accT, ah, al, bh, bl);
               if (NKS > TD && i + TD < nb) load_T(t, trs, i + TD);  // (more than eight occupied blocks: the ring refills as it drains)
             };
             for (int i = 0; i < nb; i += TD) {
@@ -655,7 +656,7 @@ __global__ __launch_bounds__(ML_THREADS) void k_conv_ml(MlArgs a) {
 #pragma unroll
           for (int g = 0; g < 4; ++g) {
             const int s2 = g & 1, p = 2 * g;
-            if (!(ml_dbg & 32)) { M3(accP, (g < 2 ? sAh[s2] : sCh[s2]), (g < 2 ? sAl[s2] : sCl[s2]), RB[p], RB[p + 1]); }
+            if (!(ml_dbg & 32)) { MX(accP, (g < 2 ? sAh[s2] : sCh[s2]), (g < 2 ? sAl[s2] : sCl[s2]), RB[p], RB[p + 1]); }
             RB[p] = wload(nxt + p * 1024);
             RB[p + 1] = wload(nxt + (p + 1) * 1024);
             MF_SCHED();
@@ -1113,12 +1114,14 @@ template <int NKS, bool HALF, bool DBV>
 int launch_ml(const MlArgs& a, int grid, hipStream_t st) {
   static_assert(MlGeo<NKS, HALF, DBV>::LDS_BYTES <= JAMUN_MAX_DYN_LDS, "k_conv_ml: LDS budget");
   constexpr size_t smem = MlGeo<NKS, HALF, DBV>::LDS_BYTES;
-  hipLaunchKernelGGL((k_conv_ml<NKS, HALF, DBV>), dim3(grid), dim3(ML_THREADS), smem, st, a);
+  if (a.x1) hipLaunchKernelGGL((k_conv_ml<NKS, HALF, DBV, true>), dim3(grid), dim3(ML_THREADS), smem, st, a);
+  else hipLaunchKernelGGL((k_conv_ml<NKS, HALF, DBV, false>), dim3(grid), dim3(ML_THREADS), smem, st, a);
   return 0;
 }
 template <int NKS, bool HALF, bool DBV>
 int set_lds() {
-  return hipFuncSetAttribute((const void*)k_conv_ml<NKS, HALF, DBV>, hipFuncAttributeMaxDynamicSharedMemorySize, JAMUN_MAX_DYN_LDS) == hipSuccess ? 0 : -1;
+  if (hipFuncSetAttribute((const void*)k_conv_ml<NKS, HALF, DBV, true>, hipFuncAttributeMaxDynamicSharedMemorySize, JAMUN_MAX_DYN_LDS) != hipSuccess) return -1;
+  return hipFuncSetAttribute((const void*)k_conv_ml<NKS, HALF, DBV, false>, hipFuncAttributeMaxDynamicSharedMemorySize, JAMUN_MAX_DYN_LDS) == hipSuccess ? 0 : -1;
 }
 }  // namespace
 

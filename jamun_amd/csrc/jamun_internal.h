@@ -119,6 +119,7 @@ struct MfArgs {
   float* partial0;   // [slab][n_pad][nt0*32]
   float* partial1;   // [slab][n_pad][3][32]
   int* err;          // device flag: bit 0 = more than three edges of one (source, destination) pair
+  int x1;            // 1: the reduced-precision instantiation (f16x1: hi hi products only; jamun_tuning.f16x1)
 };
 
 // the matrix-formed conv for LARGE source spans (jamun_conv_ml.hip): two passes over the hidden units (vector channels, then scalar
@@ -147,6 +148,7 @@ struct MlArgs {
   float* partial1;
   int* err;                // as MfArgs::err (bit 1: a source outside the window)
   unsigned long long* mfma_count;  // += v_mfma_f32_32x32x16_f16 executed (depends on the occupied source blocks of every tile), or null
+  int x1;                  // as MfArgs::x1
 };
 // the initial projector on the same spans (k_conv_mlx in jamun_conv_ml.hip): MfxArgs + the window
 struct MlxArgs {

@@ -14,6 +14,13 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
   ACC = MFMA32H(AL_, BH_, ACC);       \
   ACC = MFMA32H(AH_, BL_, ACC);       \
   ACC = MFMA32H(AH_, BH_, ACC)
+// ... or, in the opt-in reduced-precision mode (X1 in scope: "f16x1"), the hi hi product alone: operands rounded to 11 bits, fp32 accumulation — the
+// loads, splits and conversions that only feed the dropped products are dead code for the compiler
+#define MX(ACC, AH_, AL_, BH_, BL_)                              \
+  do {                                                           \
+    if constexpr (X1) { ACC = MFMA32H(AH_, BH_, ACC); }          \
+    else { M3(ACC, AH_, AL_, BH_, BL_); }                        \
+  } while (0)
 #define RFL(v) __builtin_amdgcn_readfirstlane(v)
 #define LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 #define MF_SCHED() __builtin_amdgcn_sched_barrier(0)

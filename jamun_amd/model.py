@@ -61,7 +61,10 @@ class Denoiser:
         self.state_dict_ = {k: v.detach().to("cpu") for k, v in state_dict.items()}
         self._native = NativeModel(self.state_dict_, self.arch, self.max_radius, self.average_squared_distance, self.mean_center)
         self._device = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu")
-        self._samplers: Dict[Tuple[float, int, str], NativeSampler] = {}
+        self._samplers: Dict[Tuple[float, int, str, bool], NativeSampler] = {}
+        # Opt-in reduced precision of the hidden-layer conv (``jamun_tuning.f16x1``: one f16 MFMA per product instead of three; everything else
+        # stays fp32).  Set by ``Sampler(precision="bf16-true" | "16-true")``; never the default — x-hat then sits ~1e-4 nm from the fp32 path.
+        self.reduced_precision = False
 
     # ---- construction ---------------------------------------------------------------------------------------
     @classmethod
@@ -118,10 +121,10 @@ class Denoiser:
     # ---- forward ----------------------------------------------------------------------------------------------
     def sampler_for(self, graph: WalkerBatch, sigma: float) -> NativeSampler:
         dev = graph.pos.device
-        key = (float(sigma), graph.topology_id, str(dev))
+        key = (float(sigma), graph.topology_id, str(dev), bool(self.reduced_precision))
         s = self._samplers.get(key)
         if s is None:
-            s = NativeSampler(self._native, float(sigma), graph, dev)
+            s = NativeSampler(self._native, float(sigma), graph, dev, tuning={"f16x1": 1} if self.reduced_precision else None)
             if len(self._samplers) >= 4:  # a sampling run uses one sigma and one batch
                 self._samplers.pop(next(iter(self._samplers)))
             self._samplers[key] = s

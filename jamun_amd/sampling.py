@@ -357,9 +357,17 @@ class Sampler:
     def __init__(self, accelerator: str = "auto", strategy: str = "auto", devices: Any = "auto", num_nodes: int = 1,
                  precision: Union[str, int] = "32-true", plugins: Any = None, callbacks: Optional[Iterable[Any]] = None,
                  loggers: Any = None, shard_walkers: bool = False, rng: str = "philox"):
-        if str(precision) not in ("32-true", "32"):
-            # the reference's Fabric wrapper is discarded (_sampler.py:62), so its mixed modes have no numerical effect
-            raise NotImplementedError(f"precision={precision!r}: only 32-true is defined for sampling (SURVEY.md Appendix C.12)")
+        # "32-true" (the reference's sampling default, hydra_config/sample.yaml:27-28) is fp32-accurate arithmetic (f16x3).  The 16-bit names select
+        # the OPT-IN reduced mode of the hidden-layer conv (one f16 MFMA per product, fp32 state / accumulation / integrator / node update):
+        # x-hat ~1e-4 nm from the fp32 path — the level of the reference's own TF32 GPU path (float32_matmul_precision: high), not its bf16
+        # autocast, whose effect on sampling is undefined (the Fabric wrapper is discarded, _sampler.py:62).
+        p = str(precision)
+        if p in ("32-true", "32"):
+            self.reduced_precision = False
+        elif p in ("bf16-true", "16-true", "bf16-mixed", "16-mixed", "bf16", "16"):
+            self.reduced_precision = True
+        else:
+            raise NotImplementedError(f"precision={precision!r}: 32-true (default) or a 16-bit name (opt-in reduced-precision conv) are defined for sampling")
         if accelerator == "cpu":
             raise RuntimeError("jamun_amd has no CPU path: sampler.accelerator must be gpu/cuda/auto")
         from . import dist
@@ -398,6 +406,8 @@ class Sampler:
 
         model.to(self.device)
         model.eval()
+        if hasattr(model, "reduced_precision"):
+            model.reduced_precision = self.reduced_precision
         if self.shard_walkers and self.world_size > 1:
             # contiguous blocks of walkers, balanced by modelled cost = atoms x capped in-degree: equal
             # walkers give the even split, ragged batches (MDGen-4AA-like) are cut where the work is
@@ -427,7 +437,8 @@ class Sampler:
                 self.global_step = batch_idx
                 out = batch_sampler.sample(model=model_wrapped, y_init=y_init, v_init=v_init)
                 # (the batch is about to be consumed: synchronise once and surface a conv kernel's error flag HERE, not at some later call)
-                model_wrapped.native_sampler(batch_sampler.sigma).check()
+                if hasattr(model, "sampler_for"):
+                    model_wrapped.native_sampler(batch_sampler.sigma).check()
                 samples = model_wrapped.unbatch_samples(out)
                 if continue_chain:
                     y_init = out["y"].to(model_wrapped.device)

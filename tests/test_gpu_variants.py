@@ -163,3 +163,40 @@ def test_walk_at_the_reference_chignolin_shape_with_trained_like_weights_matches
     y_traj, score_traj, xhat_traj, xhat = smp.walk("baoab", y, v, params, noise[2 : steps + 1].to(dev).contiguous(), 0, True)
     worst = max(rmsd(xhat_traj[t], ref["xhat_traj"][t]) for t in range(steps))
     assert worst <= RMSD_TOL_NM, worst
+
+
+@pytest.mark.parametrize("kind", ["chain17x6", "ragged", "chig93x2", "chig166x2"])
+def test_opt_in_reduced_precision_conv_is_bounded_and_never_the_default(kind):
+    """``jamun_tuning.f16x1`` / ``Sampler(precision="bf16-true")``: the hidden-layer conv (k_conv_mf, k_conv_ml) with ONE f16 MFMA per fp32
+    product (operands rounded to 11 bits, fp32 accumulation) instead of the three of the f16x3 scheme.  The default stays f16x3 (dg_emu 1) and
+    meets 1e-5 nm; the opt-in mode reports dg_emu 2 and must stay within 1e-3 nm RMSD of the oracle's x-hat (measured 5e-5 .. 3e-4 nm with the
+    strongly non-linear test checkpoint: the level of the reference's own TF32 GPU path, float32_matmul_precision = high)
+    and clearly above the fp32 path's error — i.e. it really is the reduced arithmetic that ran."""
+    from jamun_amd.data import WalkerBatch
+    from jamun_amd.model import Denoiser
+    from jamun_amd.native import NativeSampler
+    from jamun_amd.sampling import Sampler
+
+    mk = _mk()
+    dev = torch.device("cuda", 0)
+    ref = _golden(f"oracle_forward_{kind}")
+    from jamun_amd import synth
+
+    model = Denoiser.from_checkpoint_dict(synth.synthetic_checkpoint(output_gain=0.5)).to(dev)
+    batch = WalkerBatch.from_molecules(mk.molecules(kind)).to(dev)
+    y = ref["y"].to(dev)
+    full = NativeSampler(model._native, 0.04, batch, dev)
+    fast = NativeSampler(model._native, 0.04, batch, dev, tuning={"f16x1": 1})
+    assert full.stats()["dg_emu"] == 1 and fast.stats()["dg_emu"] == 2 and fast.stats()["dg_mode"] == full.stats()["dg_mode"]
+    e_full, e_fast = rmsd(full.xhat(y), ref["xhat"]), rmsd(fast.xhat(y), ref["xhat"])
+    print(f"f16x1 {kind}: x-hat RMSD vs oracle {e_fast:.2e} nm (f16x3: {e_full:.2e})")
+    assert e_full <= RMSD_TOL_NM and 10 * e_full < e_fast <= 1e-3, (e_full, e_fast)
+    assert torch.equal(fast.xhat(y), fast.xhat(y))
+    # the Python switch: Sampler(precision=...) sets it on the model, the default does not; other names still raise
+    assert Sampler().reduced_precision is False and Sampler(precision="bf16-true").reduced_precision is True
+    with pytest.raises(NotImplementedError):
+        Sampler(precision="64-true")
+    model.reduced_precision = True
+    assert model.sampler_for(batch, 0.04).stats()["dg_emu"] == 2
+    model.reduced_precision = False
+    assert model.sampler_for(batch, 0.04).stats()["dg_emu"] == 1
