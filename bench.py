@@ -129,6 +129,16 @@ def cpu_baseline(cfg: str, sample_walkers=8, frames=8, cfg1_exact=True):
 
     cores = _cpu_threads()
     mols = workload_molecules(cfg, sample_walkers)
+    # bounded by ATOMS as well (measured: 136 atoms x 8 frames = 28 s; 1328 atoms of the 166-atom workload x 8 frames took 453 s): the
+    # first walkers up to ~140 atoms in total — at least one — and 4 frames when that one walker alone is larger
+    n_keep, tot = 0, 0
+    for m in mols:
+        if n_keep and tot + m["pos"].shape[0] > 140:
+            break
+        n_keep, tot = n_keep + 1, tot + m["pos"].shape[0]
+    mols, sample_walkers = mols[:n_keep], n_keep
+    if tot > 140:
+        frames = min(frames, 4)
     dt = _cpu_walk(mols, frames)
     out = {
         "value": sample_walkers * frames / dt,

@@ -615,7 +615,9 @@ LayerDev build_layer_separable(const jamun_model& m, const std::string& prefix, 
   // B fragments of the f16x3 weight GEMM of k_sep_fused: column tiles A 0..3 (x0 -> 0e, channel u at column 32 ct + c), B 4..7, C 8, D 9,
   // E 10; every column balanced by its own power of two (the depth-wise weights inherit the spread of the channels they multiply),
   // split hi + lo; the bias row (hidden unit H: the radial MLP's output bias) is added in fp32 after the product
-  if (H != 64 || n0 > 128 || n1 > 32) throw Err(JAMUN_ERR_INVALID, "SeparableConv: unsupported irreps / radial MLP width");
+  // (the envelope of k_sep_fused / k_sep_linear, with the reason: the same texts as sep_conv_unsupported, which sees the edge stride too)
+  if (n0 > 128 || n1 > 32) throw Err(JAMUN_ERR_INVALID, "SeparableConv: input irreps wider than 128x0e + 32x1e");
+  if (H != 64) throw Err(JAMUN_ERR_INVALID, "SeparableConv: radial MLP with other than 64 hidden units");
   (void)n_ct;
   std::vector<float> cfw(352, 0.f), bias(352, 0.f);
   std::vector<float4> w2b((size_t)4 * 11 * 2 * 64, make_float4(0.f, 0.f, 0.f, 0.f));
@@ -1653,7 +1655,7 @@ SegPlan plan_segments(int cus, int ng, int n_k, int N, const std::vector<int2>& 
           if (out) {
             const int i1 = i0 + take;
             const int kb = x * base + std::min(i0, base), ke = x * base + std::min(i1, base);
-            auto& v = (*out)[wg_of[x][c]];
+            auto& v = (*out)[c];
             v.push_back(make_int4(t, nslab[t_chunk[t]]++, kb, ke));
             v.push_back(make_int4(i1 > base ? ex : -1, 0, 0, 0));
           }
@@ -1674,7 +1676,37 @@ SegPlan plan_segments(int cus, int ng, int n_k, int N, const std::vector<int2>& 
       const double mid = 0.5 * (lo + hi);
       if (walk(mid, nullptr)) hi = mid; else lo = mid;
     }
-    walk(hi, &wg_segs);
+    // Which workgroup runs which share.  Workgroup g runs on XCD g % 8 (round-robin dispatch), every XCD has its own 4 MB L2, and every
+    // workgroup streams the layer's weights (127 KB per hidden unit) at the pace of its k loop: a block is served by the L2 a second
+    // time only to a workgroup of the SAME XCD that reaches the same hidden unit within a few steps (32 streams x 127 KB = the whole L2
+    // per step).  The shares are therefore dealt to the XCDs by the PHASE of their k loop — the hidden unit their first segment starts
+    // at; a share continues with k = 0 of the next tile when it crosses a tile boundary —: the 32 workgroups of an XCD then walk a
+    // window of ~65 / 8 hidden units together, ~1 MB of weights, and every XCD fetches the stream once (cfg2: FETCH_SIZE of k_conv_mf
+    // 291 -> 90 MB per launch, +2.3 % conformations/s; cfg5 +1.5 %; in launch order the phases of an XCD's workgroups were spread over
+    // all 65 units — profiles/EXPERIMENTS.md).
+    std::vector<std::vector<int4>> share((size_t)ncx);
+    walk(hi, &share);
+    std::vector<int> order;
+    for (int c = 0; c < ncx; ++c)
+      if (!share[c].empty()) order.push_back(c);
+    const int kspan = std::max(1, base + (rem ? 1 : 0));
+    auto phase = [&](int c) { return ((share[c][0].z - x * base) % kspan + kspan) % kspan; };
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return phase(a) < phase(b); });
+    std::vector<std::vector<int>> by_xcd(8);
+    for (int g : wg_of[x]) by_xcd[g % 8].push_back(g);
+    std::vector<int> xcds;
+    for (int q = 0; q < 8; ++q)
+      if (!by_xcd[q].empty()) xcds.push_back(q);
+    // (equal counts per XCD, the remainder to the first ones — the shares are level, so are the XCDs)
+    size_t pos = 0;
+    for (size_t qi = 0; qi < xcds.size(); ++qi) {
+      const size_t n_q = order.size() / xcds.size() + (qi < order.size() % xcds.size() ? 1 : 0);
+      auto& ids = by_xcd[xcds[qi]];
+      for (size_t j = 0; j < n_q && pos < order.size(); ++j, ++pos) {
+        if (j >= ids.size()) throw Err(JAMUN_ERR_INVALID, "plan_segments: more shares than workgroups on an XCD");
+        wg_segs[ids[j]] = share[order[pos]];
+      }
+    }
   }
   size_t ms = 1;
   for (auto& v : wg_segs) ms = std::max(ms, v.size() / 2 + 1);
@@ -2488,9 +2520,12 @@ int jamun_sampler_stats(jamun_sampler* s, jamun_stats* out, void* stream) {
     out->conv_bytes_alg_launch = 0;
     if (s->dg_on && s->layers.size() > 1) {
       const int64_t m0 = s->hp.mul0, m1 = s->hp.mul1, H1 = s->hp.edge_attr_dim + 1, N = s->n_atoms;
-      const int64_t contraction = 2 * H1 * N * ((m0 + m1) * (m0 + m1) + 3 * m1 * (2 * m1));
+      // (the launch these figures describe is the main conv kernel: destinations that go through the tail kernels are not its work — their
+      // edges are taken as the batch's mean in-degree, the slab and h~ bytes below stay whole: every slot is read, every slab row written)
+      const int64_t Nm = N - ((s->dg_mode == 4 && s->n_tail_tiles > 0) ? s->n_tail : 0), em = N > 0 ? (int64_t)((double)e * (double)Nm / (double)N) : 0;
+      const int64_t contraction = 2 * H1 * Nm * ((m0 + m1) * (m0 + m1) + 3 * m1 * (2 * m1));
       // per edge and k: x0 (m0), dot 3 m1, x1 3 m1, cross 6 m1, T term 3 m1 — on the matrix cores only in k_conv_mf (k_conv_dg forms on the vector ALUs)
-      const int64_t forming = (s->dg_mode == 4 || s->dg_mode == 5) ? 2 * H1 * (int64_t)e * (m0 + 15 * m1) : 0;
+      const int64_t forming = (s->dg_mode == 4 || s->dg_mode == 5) ? 2 * H1 * em * (m0 + 15 * m1) : 0;
       out->conv_flop_useful_launch = (s->x1 ? 1 : s->dg_emu ? 3 : 1) * (contraction + forming);
       const int64_t slots = (int64_t)s->h_kstride;
       out->conv_bytes_alg_launch = 4 * (H1 * slots          // h~ of the layer

@@ -200,3 +200,25 @@ def test_opt_in_reduced_precision_conv_is_bounded_and_never_the_default(kind):
     assert model.sampler_for(batch, 0.04).stats()["dg_emu"] == 2
     model.reduced_precision = False
     assert model.sampler_for(batch, 0.04).stats()["dg_emu"] == 1
+
+
+@pytest.mark.parametrize("over,msg", [
+    (dict(irreps_hidden="136x0e + 16x1e"), "SeparableConv: input irreps wider than 128x0e + 32x1e"),
+    (dict(edge_attr_dim=32), "only edge_attr_dim = 64 is supported"),
+])
+def test_separable_conv_outside_its_envelope_is_refused_at_create_with_the_reason(over, msg):
+    """``k_sep_fused`` / ``k_sep_linear`` cover the shipped ``e3conv_separable.yaml`` and its neighbourhood (<= 128 scalar /
+    32 vector input channels, <= 64 edge slots, 64 radial hidden units); anything else fails in ``jamun_sampler_create`` with the reason in
+    the message — there is no slower path to fall back to, and none is taken silently."""
+    from jamun_amd import synth
+    from jamun_amd.data import WalkerBatch
+    from jamun_amd.model import Denoiser
+
+    mk = _mk()
+    dev = torch.device("cuda", 0)
+    batch = WalkerBatch.from_molecules(mk.molecules("ag4")).to(dev)
+    import re
+
+    with pytest.raises(RuntimeError, match=re.escape(msg)):
+        model = Denoiser.from_checkpoint_dict(synth.synthetic_checkpoint(arch=synth.default_arch(**over), separable=True)).to(dev)
+        model.sampler_for(batch, 0.04)
