@@ -11,7 +11,7 @@ extra=${3:-}
 out=gpurun_out/prof_$tag
 mkdir -p "$out"
 BENCH="python3 bench.py --config $cfg $extra --no-cpu-baseline --no-secondary --no-e2e --no-sweep --repeats 1"
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- $BENCH --steps 10 --warmup 2 > $out/bench_under_rocprof.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- $BENCH --steps 200 --warmup 40 > $out/bench_under_rocprof.log 2>&1
 f=$(find $out/trace -name "*kernel_stats.csv" | head -1)
 [ -n "$f" ] || { echo "no kernel_stats.csv produced; see $out/bench_under_rocprof.log" >&2; exit 1; }
 python3 - "$f" "$out/kernel_stats_summary.csv" <<'PY'

@@ -742,6 +742,37 @@ def test_docs_cite_profile_files_that_exist():
     assert not missing, missing
 
 
+def test_quoted_counter_summaries_were_collected_from_this_build():
+    """Every `profiles/*_pmc_traffic.json` that DESIGN.md or README.md names — the files `bench.py` takes `roofline.traffic` from — carries
+    the digest of the library sources as they are NOW (`_build.source_digest`, written by `profiles/collect.sh` from
+    `bench.py --signature`): an edit of any kernel after the counters were collected fails here until they are collected again, and
+    `bench.py` itself refuses such a file (`traffic_stale`)."""
+    import json
+    import re
+
+    from jamun_amd.csrc import build
+
+    want = build._digest()
+    cited = set()
+    for doc in ("DESIGN.md", "README.md"):
+        cited |= set(re.findall(r"profiles/([A-Za-z0-9_]+_pmc_traffic\.json)", open(os.path.join(ROOT, doc)).read()))
+    assert cited, "DESIGN.md section 7 names the counter summaries its traffic figures come from"
+    for name in sorted(cited):
+        d = json.load(open(os.path.join(ROOT, "profiles", name)))
+        assert d.get("_build", {}).get("source_digest") == want, f"{name} was collected from another build of the library"
+    # and bench.py's reader applies the same rule: a summary with a foreign digest is reported as stale, never quoted
+    import bench
+
+    real = bench.build_signature
+
+    try:
+        bench.build_signature = lambda stats=None: {"source_digest": "0" * 64}
+        r = bench._pmc_traffic("k_conv_mf<", "cfg2", "", None)
+        assert r is None or r[0] is None
+    finally:
+        bench.build_signature = real
+
+
 def test_parse_datasets_from_directory(tmp_path):
     """data/_utils.py:36-116 over a Timewarp-style tree (`<code>-traj-arrays.npz` + `<code>-traj-state0.pdb`): code = group 1 of
     the anchored regular expression, datasets sorted by code, filter -> offset -> max in the reference's order, dataset kwargs
