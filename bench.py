@@ -137,7 +137,7 @@ def cpu_baseline(cfg: str, sample_walkers=8, frames=8, cfg1_exact=True):
             break
         n_keep, tot = n_keep + 1, tot + m["pos"].shape[0]
     mols, sample_walkers = mols[:n_keep], n_keep
-    if tot > 140:
+    if tot > 140 or (n_keep == 1 and tot > 80):
         frames = min(frames, 4)
     dt = _cpu_walk(mols, frames)
     out = {
