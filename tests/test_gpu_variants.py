@@ -222,3 +222,30 @@ def test_separable_conv_outside_its_envelope_is_refused_at_create_with_the_reaso
     with pytest.raises(RuntimeError, match=re.escape(msg)):
         model = Denoiser.from_checkpoint_dict(synth.synthetic_checkpoint(arch=synth.default_arch(**over), separable=True)).to(dev)
         model.sampler_for(batch, 0.04)
+
+
+def test_reduced_precision_walks_stay_near_the_fp32_oracle_on_contractive_checkpoints():
+    """The opt-in f16x1 conv over whole BAOAB walks (trained-like weights, contractive gain): 12 frames on the AG batch (k_conv_mf) and six on
+    the 93-atom batch (k_conv_ml) against the fp32 oracle's trajectories — every frame within 1e-3 nm (measured 1e-5 .. 1e-4), none within the
+    fp32 path's 1e-5 nm on every frame by accident of the test (the mode really ran)."""
+    from jamun_amd import native
+    from jamun_amd.data import WalkerBatch
+    from jamun_amd.model import Denoiser
+    from jamun_amd.native import NativeSampler
+
+    mk = _mk()
+    dev = torch.device("cuda", 0)
+    model = Denoiser.from_checkpoint_dict(mk.variant_checkpoint("trained", mk.GAINS["stable"])).to(dev)
+    for fixture, kind, steps in (("oracle_walk_baoab_trained_ag4_12", "ag4", 12), ("oracle_walk_baoab_trained_chig93_6", "chig93x2", 6)):
+        ref = _golden(fixture)
+        batch = WalkerBatch.from_molecules(mk.molecules(kind)).to(dev)
+        smp = NativeSampler(model._native, 0.04, batch, dev, tuning={"f16x1": 1})
+        assert smp.stats()["dg_emu"] == 2
+        noise = ref["noise"]
+        y, v = ref["y0"].to(dev).clone(), noise[1].to(dev).clone()
+        params = native.make_mcmc_params(steps, 0.04, 1.0, 1.0, 1.0, 100.0)
+        _, _, xhat_traj, _ = smp.walk("baoab", y, v, params, noise[2 : steps + 1].to(dev).contiguous(), 0, True)
+        errs = [rmsd(xhat_traj[t], ref["xhat_traj"][t]) for t in range(steps)]
+        print(f"f16x1 walk {kind}: x-hat RMSD per frame {min(errs):.2e} .. {max(errs):.2e} nm")
+        assert max(errs) <= 1e-3, errs
+        assert max(errs) > 1e-7, errs
