@@ -322,6 +322,7 @@ __global__ __launch_bounds__(256) void k_edge_h16(const int* __restrict__ deg, c
     bonded = esrc[slot] < 0 ? 1 : 0;
   }
   float4 Rh[2], Rl[2];  // B fragments: lane (slot, hh), halves p <-> basis 16 s2 + 8 hh + p
+  const float inv_step = 1.f / step;
 #pragma unroll
   for (int s2 = 0; s2 < 2; ++s2) {
     unsigned ph[4], pl[4];
@@ -330,8 +331,10 @@ __global__ __launch_bounds__(256) void k_edge_h16(const int* __restrict__ deg, c
       float v[2];
 #pragma unroll
       for (int e = 0; e < 2; ++e) {
-        const float diff = FSUB(d, mu[16 * s2 + 8 * hh + 2 * p2 + e]) / step;
-        v[e] = (expf(-FMUL(diff, diff)) / 1.12f) * 16384.f;
+        // (reciprocal step, hardware exponential, one constant for / 1.12 * 2^14: the IEEE divisions and expf were 45 % of this kernel's
+        // vector instructions; the value is split into two f16 terms just below — 2^-22 of it — and these forms are within 1e-7 absolute)
+        const float diff = FSUB(d, mu[16 * s2 + 8 * hh + 2 * p2 + e]) * inv_step;
+        v[e] = __expf(-FMUL(diff, diff)) * (float)(16384.0 / 1.12);
       }
       asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(ph[p2]) : "v"(v[0]), "v"(v[1]));
       float r0, r1;
@@ -355,7 +358,8 @@ __global__ __launch_bounds__(256) void k_edge_h16(const int* __restrict__ deg, c
     for (int b = 0; b < 4; ++b) an[b] = w1h[((size_t)jn * 4 + b) * 64 + lane];
     const float* __restrict__ c = cmask_all + (size_t)l * 128 + bonded * 64 + 4 * hh;  // c_mask[mask of this lane's slot][k]
     const float isc = isc_all[l];
-    float* __restrict__ h = h_all + (size_t)l * h_layer_stride + slot;
+    // (this lane's row 32 mt + 4 hh; the rows of its 16 accumulator registers then lie at wave-uniform distances: one 64-bit add per store)
+    float* __restrict__ h = h_all + (size_t)l * h_layer_stride + slot + (size_t)(32 * mt + 4 * hh) * h_kstride;
     eh_f32x16 acc;
 #pragma unroll
     for (int q = 0; q < 16; ++q) acc[q] = 0.f;
@@ -367,12 +371,12 @@ __global__ __launch_bounds__(256) void k_edge_h16(const int* __restrict__ deg, c
     }
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
-      const int k = 32 * mt + (q & 3) + 8 * (q >> 2) + 4 * hh;
       const float pre = fmaf(acc[q], isc, c[32 * mt + (q & 3) + 8 * (q >> 2)]);
-      const float hv = pre * __frcp_rn(1.f + __expf(-pre));
-      if (valid) h[(size_t)k * h_kstride] = hv;
+      // (v_rcp_f32, 1 ulp: __frcp_rn is the correctly rounded reciprocal — a ten-instruction IEEE division per output)
+      const float hv = pre * __builtin_amdgcn_rcpf(1.f + __expf(-pre));
+      if (valid) h[(size_t)((q & 3) + 8 * (q >> 2)) * h_kstride] = hv;
     }
-    if (mt == 1 && valid && hh == 0) h[(size_t)64 * h_kstride] = 1.f;  // bias row of the second radial-MLP layer
+    if (mt == 1 && valid && hh == 0) h[(size_t)32 * h_kstride] = 1.f;  // bias row (64) of the second radial-MLP layer
 #pragma unroll
     for (int b = 0; b < 4; ++b) av[b] = an[b];
   }

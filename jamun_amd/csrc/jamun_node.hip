@@ -95,6 +95,9 @@ __global__ __launch_bounds__(NH_T, LR ? 4 : 2) void k_node_update_h(NodeArgs a) 
   const int ns_max = a.atom_nslab ? a.max_slabs : a.n_slices;
   const int dgi = ok ? a.deg[i] : 1;
   const float degf = (float)(dgi < 1 ? 1 : dgi);
+  // mean over the in-edges as a product with 1 / deg, sigmoid with v_exp_f32 / v_rcp_f32 (each within 1 ulp of the IEEE forms the fp32
+  // kernel k_node_update keeps; the results are split into 22-bit operands a few lines below): 32 ten-instruction divisions per thread less
+  const float rdeg = 1.f / degf;
   const int w0 = a.nt0 * 32, G0 = a.mul0 + a.mul1;
   const size_t slab0 = (size_t)a.n_pad * w0, slab1 = (size_t)a.n_pad * 96;
   const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -215,14 +218,14 @@ __global__ __launch_bounds__(NH_T, LR ? 4 : 2) void k_node_update_h(NodeArgs a) 
 #pragma unroll
   for (int q = 0; q < 3; ++q) {
     const int c = 4 * (c16 + 16 * q);
-    float e[4] = {ms[q].x / degf, ms[q].y / degf, ms[q].z / degf, ms[q].w / degf};
+    float e[4] = {ms[q].x * rdeg, ms[q].y * rdeg, ms[q].z * rdeg, ms[q].w * rdeg};
     const float4 k4 = LR ? ld_kg0(q) : kg0[LR ? 0 : q];
     const float kg[4] = {k4.x, k4.y, k4.z, k4.w};  // (a piece is all activated scalars or all gate pre-activations: mul0 % 4 == 0)
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
       const int w = c + t;
       if (w < a.mul0) { e[t] = (a.cL * (e[t] > 0.f ? e[t] : 0.01f * e[t])) * kg[t]; mxS = fmaxf(mxS, fabsf(e[t])); }
-      else if (w < G0) s_gate[il * 32 + (w - a.mul0)] = a.cS / (1.f + expf(-e[t]));
+      else if (w < G0) s_gate[il * 32 + (w - a.mul0)] = a.cS * __builtin_amdgcn_rcpf(1.f + __expf(-e[t]));
     }
     ms[q] = make_float4(e[0], e[1], e[2], e[3]);
   }
@@ -263,7 +266,7 @@ __global__ __launch_bounds__(NH_T, LR ? 4 : 2) void k_node_update_h(NodeArgs a) 
 #pragma unroll
   for (int q = 0; q < 2; ++q) {
     const int j = c16 + 16 * q, c = 4 * (j & 7);  // piece j: plane j / 8, channels c .. c + 3
-    const float e[4] = {mv[q].x / degf, mv[q].y / degf, mv[q].z / degf, mv[q].w / degf};
+    const float e[4] = {mv[q].x * rdeg, mv[q].y * rdeg, mv[q].z * rdeg, mv[q].w * rdeg};
     const float4 k4 = LR ? ld_kg1(q) : kg1[LR ? 0 : q];
     const float kg[4] = {k4.x, k4.y, k4.z, k4.w};
 #pragma unroll
