@@ -34,6 +34,8 @@ GAINS = {"strong": 0.5, "stable": 0.05, "mid": 0.1, "g02": 0.2}
 def molecules(kind):
     if kind == "ag4":
         return [synth.ag_dipeptide()] * 4
+    if kind == "ag32":
+        return [synth.ag_dipeptide()] * 32
     if kind == "chain17x6":
         return [synth.random_chain(17, seed=0)] * 6
     if kind == "ragged":
@@ -183,6 +185,9 @@ CASES = {
     "oracle_walk_baoab_ag4_50_g02": lambda max_steps=None, **kw: walk_case("ag4", "baoab", 50, "g02", max_steps),
     "oracle_walk_baoab_ag4_50": lambda max_steps=None, **kw: walk_case("ag4", "baoab", 50, "stable", max_steps),
     "oracle_walk_baoab_ag4_20_strong": lambda max_steps=None, **kw: walk_case("ag4", "baoab", 20, "strong", max_steps),
+    # a LONG walk with the strongly non-linear checkpoint (the bench checkpoint's gain): single trajectories leave the oracle's after ~40
+    # steps — what must still agree is the ENSEMBLE (tests/test_gpu_variants.py: statistics of frames 40..80)
+    "oracle_walk_baoab_ag32_80_strong": lambda max_steps=None, **kw: walk_case("ag32", "baoab", 80, "strong", max_steps),
     "oracle_walk_baoab_ragged_12": lambda max_steps=None, **kw: walk_case("ragged", "baoab", 12, "stable", max_steps),
     "oracle_walk_aboba_ag4_20": lambda max_steps=None, **kw: walk_case("ag4", "aboba", 20, "stable", max_steps),
     "oracle_sampler_cc1": lambda max_batches=None, **kw: sampler_case(True, max_batches=max_batches),
