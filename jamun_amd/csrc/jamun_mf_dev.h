@@ -84,9 +84,15 @@ __device__ __forceinline__ float opaque_minus_one() {
   asm volatile("" : "+s"(m1));
   return m1;
 }
+#ifdef ML_SPLIT_ASM  // (experiment: k_conv_ml with the inline-asm forms)
+__device__ __forceinline__ unsigned cvt_pk_f16_c(float a, float b) { return cvt_pk_f16(a, b); }
+__device__ __forceinline__ float resid_lo_c(float a, unsigned pk, float) { return resid_lo(a, pk); }
+__device__ __forceinline__ float resid_hi_c(float a, unsigned pk, float) { return resid_hi(a, pk); }
+#else
 __device__ __forceinline__ unsigned cvt_pk_f16_c(float a, float b) { return __builtin_bit_cast(unsigned, __builtin_convertvector(mf_f2{a, b}, mf_h2)); }
 __device__ __forceinline__ float resid_lo_c(float a, unsigned pk, float m1) { return __builtin_fmaf((float)__builtin_bit_cast(mf_h2, pk).x, m1, a); }  // a - float(pk[15:0])
 __device__ __forceinline__ float resid_hi_c(float a, unsigned pk, float m1) { return __builtin_fmaf((float)__builtin_bit_cast(mf_h2, pk).y, m1, a); }  // a - float(pk[31:16])
+#endif
 // uniform loads through the constant address space: scalar loads into scalar registers
 __device__ __forceinline__ int4 ld_const(const int4* p) {
 #if defined(__HIP_DEVICE_COMPILE__)

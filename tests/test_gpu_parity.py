@@ -284,6 +284,57 @@ def test_forward_matches_oracle(dev, golden_dir, kind):
     assert rmsd(s, ref["score"]) <= RMSD_TOL_NM / sigma**2  # score = (xhat - y)/sigma^2 amplifies by 625
 
 
+def test_forward_matches_reference_fixtures(dev, golden_dir):
+    """GPU twin of tests/test_oracle.py::test_oracle_matches_reference_fixtures: the HIP forward against `reference_forward_*.npz`, the
+    outputs of the reference's own `Denoiser` (tests/golden/make_reference_fixtures.py — the pin kit for SURVEY section 8 rows a7-a18).
+    Skips while no such fixture exists (they need e3nn / torch_cluster / torch_scatter, absent from this image).  A fixture whose radius
+    graph came from torch_cluster's CPU kd-tree AND has an atom at the 32-neighbour cap is not compared: above the cap the CPU build keeps
+    other neighbours than the CUDA build whose rule this path implements; its `_cuda` twin, when present, is."""
+    import glob
+    import importlib.util
+
+    from jamun_amd import synth
+    from jamun_amd.data import WalkerBatch
+    from jamun_amd.model import Denoiser
+
+    files = sorted(glob.glob(os.path.join(golden_dir, "reference_forward_*.npz")))
+    if not files:
+        pytest.skip("no tests/golden/reference_forward_*.npz (tests/golden/make_reference_fixtures.py needs e3nn / torch_cluster / torch_scatter)")
+    spec = importlib.util.spec_from_file_location("make_oracle_fixtures", os.path.join(golden_dir, "make_oracle_fixtures.py"))
+    mk = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mk)
+    cases = {"ag4": ("ag4", None), "chain17x6": ("chain17x6", None), "ragged": ("ragged", None), "chig93x2": ("chig93x2", None),
+             "dipep48": ("dipep48", None), "sep_ag4": ("ag4", "sep"), "trained_ragged": ("ragged", "trained"), "nl2_ragged": ("ragged", "nl2")}
+    compared = 0
+    for f in files:
+        name = os.path.basename(f)[len("reference_forward_"):-len(".npz")]
+        cuda = name.endswith("_cuda")
+        kind, variant = cases[name[:-5] if cuda else name]
+        ref = {k: torch.tensor(v) for k, v in np.load(f).items() if v.dtype.kind in "fiu"}
+        mols = mk.molecules(kind)
+        if variant == "sep":
+            ck, sigma = synth.synthetic_checkpoint(output_gain=mk.GAINS["strong"], separable=True), mk.SIGMA
+        elif variant is not None:
+            ck, sigma = mk.variant_checkpoint(variant), mk.VARIANTS[variant]["sigma"]
+        else:
+            ck, sigma = synth.synthetic_checkpoint(output_gain=mk.GAINS["strong"]), mk.SIGMA
+        bonds_in = max(int(torch.bincount(m["bonds"][1], minlength=m["pos"].shape[0]).max()) if m["bonds"].numel() else 0 for m in mols)
+        if not cuda and int(ref["deg"].max()) >= 32 + bonds_in:
+            continue
+        smp = Denoiser.from_checkpoint_dict(ck).to(dev).sampler_for(WalkerBatch.from_molecules(mols).to(dev), sigma)
+        x = smp.xhat(ref["y"].to(dev))
+        assert torch.equal(smp.debug_read(1).cpu().flatten().long(), ref["deg"]), name
+        l = 0
+        while f"x{l}" in ref:
+            xl, r = smp.debug_read(0, l).cpu(), ref[f"x{l}"]
+            assert (xl - r).abs().max().item() <= 2e-5 * max(r.abs().max().item(), 1e-6), (name, l)
+            l += 1
+        assert rmsd(x, ref["xhat"]) <= RMSD_TOL_NM, (name, rmsd(x, ref["xhat"]))
+        assert rmsd(smp.score(ref["y"].to(dev)), ref["score"]) <= RMSD_TOL_NM / sigma**2, name
+        compared += 1
+    assert compared > 0
+
+
 @pytest.mark.parametrize("kind", ["ag4", "chain17x6", "ragged_small", "ragged", "dense70", "chig93x2", "chig166x2"])
 def test_conv_kernel_variants_agree(dev, golden_dir, kind, monkeypatch):
     """The conv kernels — jamun_conv_mf (A operand formed on the matrix cores), the four modes of jamun_conv_dg (formed on the vector
