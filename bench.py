@@ -148,9 +148,12 @@ def cpu_baseline(cfg: str, sample_walkers=8, frames=8, cfg1_exact=True):
         "sample": f"{sample_walkers} walkers x {frames} walk-jump frames of the {cfg} workload ({sum(m['pos'].shape[0] for m in mols)} atoms), fp32, {dt:.1f} s",
     }
     if cfg1_exact:
-        dt1 = _cpu_walk([synth.ag_dipeptide()] * 4, 50)
-        out["cfg1_exact"] = {"value": 4 * 50 / dt1, "unit": "conformations/s", "cores": cores, "kind": "port",
-                             "sample": f"BASELINE configs[0] exactly: AG dipeptide, 4 walkers x 50 walk-jump steps, fp32, {dt1:.1f} s"}
+        n1 = 50 if os.environ.get("JAMUN_BENCH_CFG1_FULL") else 20
+        dt1 = _cpu_walk([synth.ag_dipeptide()] * 4, n1)
+        out["cfg1_exact"] = {"value": 4 * n1 / dt1, "unit": "conformations/s", "cores": cores, "kind": "port",
+                             "sample": f"BASELINE configs[0]: AG dipeptide, 4 walkers x {n1} walk-jump steps"
+                                       + (" (the configuration exactly)" if n1 == 50 else " (the first 20 of its 50 steps — every step costs the same two forwards; JAMUN_BENCH_CFG1_FULL=1 runs all 50)")
+                                       + f", fp32, {dt1:.1f} s"}
     return out
 
 
@@ -361,6 +364,156 @@ def batch_sweep(model, cfg, atoms, dev, rank, walker_counts=(256, 512, 1024, 204
     return out
 
 
+def also_legs(model, dev, rank, steps=20, target_s=2.0):
+    """The shapes the reference actually runs, in the driver's line (N = 1): 20-step fused walks, >= `target_s` of timed work each, same
+    timing as the headline (median repeat, synchronised on both sides) with HIP events around every 7th launch of the dominant conv kernel:
+      cfg2r       configs[1] as sample_uncapped_2AA.yaml:8-19 runs it: one walker per DISTINCT dipeptide (k_conv_mfx initial projector)
+      cfg5h       configs[4] as data/_mdtraj.py:60,218 feeds it: 93 heavy atoms x 128 walkers (k_conv_ml<96>)
+      cfg2_f16x1  the headline shape with the OPT-IN reduced-precision conv (Sampler(precision="bf16-true")): configs[1] says "bf16"
+    """
+    import torch
+
+    from jamun_amd import native
+    from jamun_amd.data import WalkerBatch
+    from jamun_amd.native import NativeSampler
+
+    out = {}
+    for name, cfg, tuning in (("cfg2r", "cfg2r", None), ("cfg5h", "cfg5h", None), ("cfg2_f16x1", "cfg2", {"f16x1": 1})):
+        mols = workload_molecules(cfg, CONFIGS[cfg]["walkers"], None, rank)
+        batch = WalkerBatch.from_molecules(mols).to(dev)
+        smp = NativeSampler(model._native, SIGMA, batch, dev, tuning=tuning)
+        torch.manual_seed(42 + rank)
+        y = batch.pos + SIGMA * torch.randn_like(batch.pos)
+        v = torch.randn_like(y)
+        params = native.make_mcmc_params(steps, **MCMC)
+        run = lambda: smp.walk("baoab", y, v, params, None, seed=1234 + rank, save_trajectory=True)
+        run()
+        torch.cuda.synchronize()
+        smp.profile_enable(True, classes=["conv0", "conv1"], every=PROF_EVERY)
+        dts, t_all = [], time.perf_counter()
+        while time.perf_counter() - t_all < target_s or len(dts) < 3:
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            o = run()
+            torch.cuda.synchronize()
+            dts.append(time.perf_counter() - t0)
+        prof = smp.profile_read()
+        smp.profile_enable(False)
+        assert torch.isfinite(o[2]).all()
+        st = smp.stats()
+        dt = statistics.median(dts)
+        ms0, c0 = prof["conv0"]
+        kname = "k_conv_mf" if st.get("dg_mode") == 4 else "k_conv_ml" if st.get("dg_mode") == 5 else f"k_conv_dg<{st.get('dg_mode')}>"
+        out[name] = {"workload": f"{CONFIGS[cfg]['baseline']}: {CONFIGS[cfg]['desc']}, {batch.num_graphs} walkers" + (" — opt-in f16x1 conv, NOT the metric's precision" if tuning else ""),
+                     "value": batch.num_graphs * steps / dt, "unit": "conformations/s", "ms_per_step": 1e3 * dt / steps, "timed_repeats": len(dts), "timed_total_s": sum(dts),
+                     "dtype": "f16x1" if st.get("dg_emu") == 2 else "f32", "dominant_kernel": kname, "avg_launch_ms": ms0 / max(c0, 1), "launches_timed": c0,
+                     "frac": (st.get("conv_flop_exec_launch", 0) / (ms0 / max(c0, 1) * 1e-3) / 1e12 / F16_MFMA_PEAK_TFLOPS) if c0 else None,
+                     "init_path": st.get("init_path"), "atoms_total": batch.num_nodes}
+        del smp, batch, y, v, o
+    return out
+
+
+class _StubModel:
+    """--dry-run: what Sampler.sample touches of a model, without kernels (the rank plumbing, the sharding, the callback's gather and the
+    writer are the REAL code; only the walk is replaced by a constant trajectory)."""
+
+    def __init__(self, dev):
+        self.device = dev
+
+    def to(self, d):
+        return self
+
+    def eval(self):
+        return self
+
+
+class _StubBatchSampler:
+    sigma = SIGMA
+
+    def __init__(self, steps):
+        import types
+
+        self.steps, self.mcmc = steps, types.SimpleNamespace(rng="philox")
+
+    def sample(self, model, y_init, v_init):
+        import torch
+
+        T = self.steps
+        xt = y_init[None].expand(T, -1, -1).clone()
+        return {"xhat": y_init, "y": y_init, "v": torch.zeros_like(y_init), "sample": y_init, "xhat_traj": xt, "y_traj": xt, "score_traj": xt, "t_traj": torch.ones(T)}
+
+
+def e2e_sharded(model, cfg, dev, world, rank, steps=1000, num_batches=2, walkers_total=None, stub=False):
+    """north_star's ONE collective inside a timed interval: `Sampler.sample(shard_walkers=True, num_batches=2)` over all ranks with
+    `SaveTrajectoryCallback` — the walker batch is sharded (contiguous, cost balanced), every rank walks its share, and after each batch the
+    per-rank `[chains, n, T, 3]` blocks go to rank 0 (`dist.gather_ragged_to_host`: one block at a time through one device receive buffer
+    and one pinned staging buffer; RCCL send / recv on GPUs), which writes the files on its side thread.  Wall time is bracketed by barriers
+    and taken as the MAX over ranks; `gather_s` is rank 0's time inside the exchange (metadata + receives + host copies; it includes
+    waiting for the slowest rank to arrive), `gather_bytes` the payload that crossed ranks.  The reference's counterpart is torchmetrics'
+    all-gather of the trajectories (metrics/_utils.py:40)."""
+    import shutil
+    import tempfile
+
+    import torch
+
+    from jamun_amd import dist
+    from jamun_amd.callbacks import SaveTrajectoryCallback
+    from jamun_amd.data import WalkerBatch
+    from jamun_amd.sampling import BAOAB, Sampler, SingleMeasurementSampler
+
+    label = "bench"
+    total = walkers_total if walkers_total is not None else CONFIGS[cfg]["walkers"] * world
+    mols = workload_molecules(cfg, total, None, 0)  # the WHOLE batch on every rank (as get_initial_graphs builds it); sample() takes this rank's share
+    batch = WalkerBatch.from_molecules([dict(m, dataset_label=label) for m in mols])
+    tmp = tempfile.mkdtemp(prefix="jamun_bench_sharded_") if rank == 0 else None
+    cb = SaveTrajectoryCallback([_BenchDataset(mols[0], label)], output_dir=tmp if rank == 0 else os.path.join(tempfile.gettempdir(), "unused"), write_pdb=False)
+    sampler = Sampler(callbacks=[cb], shard_walkers=True)
+    if stub:
+        bs = _StubBatchSampler(steps)
+    else:
+        bs = SingleMeasurementSampler(mcmc=BAOAB(steps=steps, save_trajectory=True, save_every_n_steps=1, v_init="gaussian", **MCMC), sigma=SIGMA)
+    torch.manual_seed(42 + rank)  # seed + rank (cmdline/sample.py:86-88)
+    sync = torch.cuda.synchronize if dev.type == "cuda" else (lambda: None)
+    sync()
+    dist.barrier()
+    t0 = time.perf_counter()
+    sampler.sample(model, bs, num_batches=num_batches, init_graphs=batch, continue_chain=True)
+    sync()
+    dist.barrier()
+    dt = time.perf_counter() - t0
+    t = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+    out = None
+    if rank == 0:
+        wall = float(t.item())
+        n_files = sum(len(f) for _, _, f in os.walk(tmp))
+        joined = os.path.join(tmp, label, "predicted_samples", "npy", "joined.npy")
+        import numpy as np
+
+        shape = list(np.load(joined, mmap_mode="r").shape) if os.path.exists(joined) else None
+        out = {"steps_per_batch": steps, "num_batches": num_batches, "walkers_total": total, "wall_s": wall,
+               "conformations_per_s": total * steps * num_batches / wall, "gather_s": cb.gather_timings.get("gather_s", 0.0),
+               "gather_bytes": int(cb.gather_timings.get("gather_bytes", 0)), "gather_share_of_wall": cb.gather_timings.get("gather_s", 0.0) / wall,
+               "writer_wait_s": cb.wait_s, "files_written": n_files, "joined_shape": shape,
+               "note": "Sampler.sample(shard_walkers=True) + SaveTrajectoryCallback over all ranks; MAX-over-ranks wall time between two barriers; "
+                       "gather_s includes waiting for the slowest rank" + ("; DRY RUN: constant trajectories, no kernels" if stub else "")}
+        shutil.rmtree(tmp, ignore_errors=True)
+    return out
+
+
+def rccl_record(dev, world):
+    """Proof of the ranks behind an N > 1 line: backend name, world size and an all-reduce of ones over the group."""
+    import torch
+
+    if not (torch.distributed.is_available() and torch.distributed.is_initialized()):
+        return {"backend": None, "world": 1, "ranks_seen": 1}
+    ones = torch.ones(1, dtype=torch.float64, device=dev)
+    torch.distributed.all_reduce(ones)
+    return {"backend": torch.distributed.get_backend() + (" (RCCL)" if torch.distributed.get_backend() == "nccl" else ""),
+            "world": world, "ranks_seen": int(round(float(ones.item())))}
+
+
 # ---- self-launch ---------------------------------------------------------------------------------------------------------
 
 
@@ -440,6 +593,7 @@ def main():
     ap.add_argument("--dry-run", action="store_true", help="rank plumbing only (gloo, no kernels): used by the CPU test of the self-launch")
     ap.add_argument("--dry-run-fail-rank", type=int, default=-1, help="with --dry-run: this rank exits with an error before the rendezvous (tests the supervision of the self-launch)")
     ap.add_argument("--no-e2e", action="store_true", help="skip the Sampler.sample wall-time legs (1000 / 20000 steps per batch, with and without the trajectory writer)")
+    ap.add_argument("--no-also", action="store_true", help="skip the 20-step walks of cfg2r / cfg5h / cfg2 f16x1 added to the cfg2 line")
     ap.add_argument("--no-sweep", action="store_true", help="skip the one-GPU walker-count sweep (256 / 512 / 1024 / 2048 walkers)")
     ap.add_argument("--signature", action="store_true", help="print the build signature of this config (source digest + kernel selection) as JSON and exit (profiles/collect.sh)")
     ap.add_argument("--strong", action="store_true", help="strong scaling: the config's walker count x 8 (2048 for cfg2/3/4) is the TOTAL, split over the ranks")
@@ -459,8 +613,12 @@ def main():
         t = torch.tensor([float(rank + 1)], dtype=torch.float64)
         if world > 1:
             torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        cpu = torch.device("cpu")
+        sharded = e2e_sharded(_StubModel(cpu), args.config, cpu, world, rank, steps=8, num_batches=2, walkers_total=3 * world + 1, stub=True)
+        rec = rccl_record(cpu, world)
         if rank == 0:
-            print(json.dumps({"metric": "dry-run", "value": 0.0, "n_gpus": world, "ranks_seen": int(t.item()), "steps": args.steps, "warmup": args.warmup}), flush=True)
+            print(json.dumps({"metric": "dry-run", "value": 0.0, "n_gpus": world, "ranks_seen": int(t.item()), "steps": args.steps, "warmup": args.warmup,
+                              "e2e_sharded": sharded, "rccl": rec}), flush=True)
         if world > 1:
             torch.distributed.destroy_process_group()
         return
@@ -567,6 +725,14 @@ def main():
     if world > 1:
         torch.distributed.all_reduce(tot_walkers)
         torch.distributed.all_reduce(tot_atoms)
+
+    rccl = rccl_record(dev, world)
+    sharded = None
+    if world > 1 and not args.no_e2e and args.walkers is None and args.atoms is None:
+        del y_traj, score_traj, xhat_traj
+        # (every rank takes part; 1000 steps per batch: 0.85 s of walking per batch at cfg2, 13 MB per rank and batch to rank 0)
+        sharded = e2e_sharded(model, args.config, dev, world, rank, steps=1000, num_batches=2,
+                              walkers_total=total_walkers if args.strong else None)
 
     if rank == 0:
         total_conf = int(tot_walkers.item()) * args.steps
@@ -689,8 +855,13 @@ def main():
             out["config"]["ref_association_tflops_equiv"] = stats["flop_ref_assoc"] * args.steps / dt_med / 1e12
             if stats.get("n_tail_tiles"):
                 out["config"]["tail_tiles"] = f"{stats['n_tail_tiles']} tiles / {stats['n_tail']} destinations through k_tail_form + k_tail_contract (kernel class conv1)"
+        out["rccl"] = rccl
+        if sharded is not None:
+            out["e2e_sharded"] = sharded
         if world == 1:
             del y_traj, score_traj, xhat_traj
+        if not args.no_also and world == 1 and args.config == "cfg2" and args.walkers is None and args.atoms is None and not args.strong and not args.separable:
+            out["also"] = also_legs(model, dev, rank)
         if not args.no_e2e and world == 1 and args.config in ("cfg2", "cfg2r") and args.walkers is None and args.atoms is None and not args.strong:
             # (the metric's config only: two 20 000-step batches of cfg2 are 35 s of GPU time per leg; other shapes take minutes)
             out["e2e"] = e2e_legs(model, mols, dev)

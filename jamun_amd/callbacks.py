@@ -79,6 +79,10 @@ class SaveTrajectoryCallback:
         self._pool = None
         self._pending: list = []
         self.wait_s = 0.0
+        from . import dist
+
+        self._stager = dist.HostStager()  # one pinned + one device staging buffer for the whole run (dist.gather_ragged_to_host)
+        self.gather_timings: Dict[str, float] = {}  # gather_s / gather_bytes accumulated over batches and labels (bench.py: e2e_sharded)
 
     def _dir(self, label: str, ext: str) -> str:
         d = os.path.join(self.output_dir, label, "predicted_samples", ext)
@@ -130,7 +134,18 @@ class SaveTrajectoryCallback:
         if self.write_dcd:
             save_dcd(self.filename_pred(label, index, "dcd"), frames)
 
+    def _raise_finished_writer_errors(self) -> None:
+        """A writer failure (disk full, permission, bad shape) must stop the run at the NEXT batch, not after the last one."""
+        still = []
+        for fut in self._pending:
+            if fut.done():
+                fut.result()
+            else:
+                still.append(fut)
+        self._pending = still
+
     def on_after_sample_batch(self, sample: Sequence[dict], sampler):
+        self._raise_finished_writer_errors()
         for s in sample:
             if s.get("dataset_label") not in self.datasets:
                 raise KeyError(f"sample dataset label {s.get('dataset_label')!r} has no dataset")
@@ -142,23 +157,14 @@ class SaveTrajectoryCallback:
                     raise ValueError(f"Invalid sample shape: {tuple(s[self.sample_key].shape)}, expected (num_atoms, num_frames, 3).")
             # a rank without walkers of this label contributes nothing; gather_ragged agrees on the trailing shape first
             block = torch.stack([s[self.sample_key] for s in mine]).contiguous() if mine else None  # [chains_local, n, T, 3]
-            gathered = dist.gather_ragged(block, dst=0, device=sampler.device)
-            if gathered is None:
+            # one block at a time through ONE reusable device receive buffer and ONE reusable pinned staging buffer; what the writer
+            # thread (and self.chains) keep are pageable copies
+            blocks = dist.gather_ragged_to_host(block, dst=0, device=sampler.device, stager=self._stager, timings=self.gather_timings)
+            if blocks is None:
                 continue
-            blocks = [self._to_host(g) for g in gathered]  # (pinned staging: one contiguous D2H copy per block)
             start = self.num_chains_seen[label]
             self.num_chains_seen[label] = start + sum(int(b.shape[0]) for b in blocks)
             self._submit(self._write_batch, label, blocks, start)
-
-    @staticmethod
-    def _to_host(t: torch.Tensor) -> np.ndarray:
-        t = t.detach()
-        if t.is_cuda:
-            buf = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
-            buf.copy_(t, non_blocking=True)
-            torch.cuda.current_stream(t.device).synchronize()
-            return buf.numpy()
-        return t.contiguous().numpy()
 
     def _write_batch(self, label: str, blocks: List[np.ndarray], start: int) -> None:
         new = [c for b in blocks for c in b]
@@ -187,7 +193,14 @@ class SaveTrajectoryCallback:
         self.wait_s += time.perf_counter() - t0
 
     def on_sample_end(self, sampler):
-        self.flush()  # (the reference only uploads the joined files to wandb here, _save_trajectory.py:64-76: out of scope)
+        try:
+            self.flush()  # (the reference only uploads the joined files to wandb here, _save_trajectory.py:64-76: out of scope)
+        finally:
+            self.close()
+
+    def close(self) -> None:
+        """Stop the writer thread (also called by Sampler.sample when the loop raises: pending writes finish, their errors are not re-raised
+        over the original one)."""
         if self._pool is not None:
             self._pool.shutdown(wait=True)
             self._pool = None

@@ -1684,8 +1684,23 @@ SegPlan plan_segments(int cus, int ng, int n_k, int N, const std::vector<int2>& 
     // window of ~65 / 8 hidden units together, ~1 MB of weights, and every XCD fetches the stream once (cfg2: FETCH_SIZE of k_conv_mf
     // 291 -> 90 MB per launch, +2.3 % conformations/s; cfg5 +1.5 %; in launch order the phases of an XCD's workgroups were spread over
     // all 65 units — profiles/EXPERIMENTS.md).
+    // (the greedy walk is not strictly monotone in the budget: the bisection's `hi` is verified, and widened if need be, BEFORE the walk that
+    // numbers the slabs — the first budget tried above, the whole list in one share, always fits)
+    for (int grow = 0; grow < 64 && !walk(hi, nullptr); ++grow) hi *= 1.05;
     std::vector<std::vector<int4>> share((size_t)ncx);
-    walk(hi, &share);
+    if (!walk(hi, &share)) throw Err(JAMUN_ERR_INVALID, "plan_segments: no feasible cut of the work list");
+    {  // every (tile, hidden unit) of this plan exactly once
+      std::vector<int> covered((size_t)n_tiles, 0), extra_seen((size_t)n_tiles, 0);
+      for (auto& v : share)
+        for (size_t q = 0; q + 1 < v.size(); q += 2) {
+          covered[v[q].x] += v[q].w - v[q].z;
+          if (v[q + 1].x >= 0) ++extra_seen[v[q].x];
+        }
+      for (int t = 0; t < n_tiles; ++t) {
+        if (skipped(t)) continue;
+        if (covered[t] != base || extra_seen[t] != (extra_of(t) >= 0 ? 1 : 0)) throw Err(JAMUN_ERR_INVALID, "plan_segments: a tile's hidden units are not covered exactly once");
+      }
+    }
     std::vector<int> order;
     for (int c = 0; c < ncx; ++c)
       if (!share[c].empty()) order.push_back(c);
@@ -2512,6 +2527,8 @@ int jamun_sampler_stats(jamun_sampler* s, jamun_stats* out, void* stream) {
       HIPCHECK(hipMemcpy(&cnt, s->ml_count, sizeof(cnt), hipMemcpyDeviceToHost));
       out->conv_flop_exec_launch = (int64_t)((double)cnt / (double)s->ml_launches) * 32768;
     }
+    if (s->dg_on && s->layers.size() > 1)  // one basis for both figures: the hidden layers' share of flop_executed follows the per-launch figure reported above (f16x1: a third; k_conv_ml: kernel-counted)
+      out->flop_executed += (int64_t)(s->layers.size() - 1) * (out->conv_flop_exec_launch - s->conv_flop_exec_launch);
     out->n_tail_tiles = s->n_tail_tiles;
     out->n_tail = s->n_tail;
     out->mf_nks = (s->dg_on && s->dg_mode == 4) ? s->mf_nks : 0;

@@ -84,15 +84,38 @@ __device__ __forceinline__ float opaque_minus_one() {
   asm volatile("" : "+s"(m1));
   return m1;
 }
-#ifdef ML_SPLIT_ASM  // (experiment: k_conv_ml with the inline-asm forms)
-__device__ __forceinline__ unsigned cvt_pk_f16_c(float a, float b) { return cvt_pk_f16(a, b); }
-__device__ __forceinline__ float resid_lo_c(float a, unsigned pk, float) { return resid_lo(a, pk); }
-__device__ __forceinline__ float resid_hi_c(float a, unsigned pk, float) { return resid_hi(a, pk); }
-#else
 __device__ __forceinline__ unsigned cvt_pk_f16_c(float a, float b) { return __builtin_bit_cast(unsigned, __builtin_convertvector(mf_f2{a, b}, mf_h2)); }
 __device__ __forceinline__ float resid_lo_c(float a, unsigned pk, float m1) { return __builtin_fmaf((float)__builtin_bit_cast(mf_h2, pk).x, m1, a); }  // a - float(pk[15:0])
 __device__ __forceinline__ float resid_hi_c(float a, unsigned pk, float m1) { return __builtin_fmaf((float)__builtin_bit_cast(mf_h2, pk).y, m1, a); }  // a - float(pk[31:16])
+// experiment switch (-DML_SPLIT_ASM=bits: the inline-asm forms at single sites of jamun_conv_ml.hip; 1 T term, 2 split16, 4 prep4, 8 build1, 16 stage, 32 k_conv_mlx)
+#ifndef ML_SPLIT_ASM
+#define ML_SPLIT_ASM 0
 #endif
+// (-DML_T_VARIANT=n narrows the asm form further: 1 cvt only, 2 residuals only, 3 "s_nop 1" behind every asm instruction, 4 asm volatile, 5 early-clobber outputs)
+#ifndef ML_T_VARIANT
+#define ML_T_VARIANT 0
+#endif
+__device__ __forceinline__ unsigned cvt_pk_f16_v(float a, float b) {
+  unsigned r;
+  if constexpr (ML_T_VARIANT == 2) return cvt_pk_f16_c(a, b);
+  else if constexpr (ML_T_VARIANT == 3) asm("v_cvt_pk_f16_f32 %0, %1, %2\n\ts_nop 1" : "=v"(r) : "v"(a), "v"(b));
+  else if constexpr (ML_T_VARIANT == 4) asm volatile("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  else if constexpr (ML_T_VARIANT == 5) asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=&v"(r) : "v"(a), "v"(b));
+  else asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+template <bool HI> __device__ __forceinline__ float resid_v(float a, unsigned pk, float m1) {
+  float r;
+  if constexpr (ML_T_VARIANT == 1) return HI ? resid_hi_c(a, pk, m1) : resid_lo_c(a, pk, m1);
+  else if constexpr (ML_T_VARIANT == 3) { if constexpr (HI) asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\ts_nop 1" : "=v"(r) : "v"(pk), "v"(a)); else asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]\n\ts_nop 1" : "=v"(r) : "v"(pk), "v"(a)); }
+  else if constexpr (ML_T_VARIANT == 4) { if constexpr (HI) asm volatile("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(pk), "v"(a)); else asm volatile("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r) : "v"(pk), "v"(a)); }
+  else if constexpr (ML_T_VARIANT == 5) { if constexpr (HI) asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=&v"(r) : "v"(pk), "v"(a)); else asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=&v"(r) : "v"(pk), "v"(a)); }
+  else { if constexpr (HI) asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(pk), "v"(a)); else asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r) : "v"(pk), "v"(a)); }
+  return r;
+}
+template <int SITE> __device__ __forceinline__ unsigned cvt_pk_f16_s(float a, float b) { if constexpr ((ML_SPLIT_ASM & SITE) != 0) return cvt_pk_f16_v(a, b); else return cvt_pk_f16_c(a, b); }
+template <int SITE> __device__ __forceinline__ float resid_lo_s(float a, unsigned pk, float m1) { if constexpr ((ML_SPLIT_ASM & SITE) != 0) return resid_v<false>(a, pk, m1); else return resid_lo_c(a, pk, m1); }
+template <int SITE> __device__ __forceinline__ float resid_hi_s(float a, unsigned pk, float m1) { if constexpr ((ML_SPLIT_ASM & SITE) != 0) return resid_v<true>(a, pk, m1); else return resid_hi_c(a, pk, m1); }
 // uniform loads through the constant address space: scalar loads into scalar registers
 __device__ __forceinline__ int4 ld_const(const int4* p) {
 #if defined(__HIP_DEVICE_COMPILE__)

@@ -63,7 +63,7 @@ class Denoiser:
         self._device = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu")
         self._samplers: Dict[Tuple[float, int, str, bool], NativeSampler] = {}
         # Opt-in reduced precision of the hidden-layer conv (``jamun_tuning.f16x1``: one f16 MFMA per product instead of three; everything else
-        # stays fp32).  Set by ``Sampler(precision="bf16-true" | "16-true")``; never the default — x-hat then sits ~1e-4 nm from the fp32 path.
+        # stays fp32).  Set by ``Sampler(precision="bf16-true" | "16-true")``; never the default — x-hat then sits 2.5e-5 .. 7.6e-5 nm from the fp32 path on the test batches (asserted <= 1e-3 nm).
         self.reduced_precision = False
 
     # ---- construction ---------------------------------------------------------------------------------------

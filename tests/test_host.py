@@ -163,6 +163,18 @@ if rank == 0:
     assert [g.shape[0] for g in got] == [2, 3] and float(got[1].mean()) == 1.0
 else:
     assert got is None
+# the trajectory form of the gather: numpy arrays on rank 0, received one block at a time through ONE reusable staging object; what
+# comes back are pageable copies (a second gather through the same stager must not change the first result)
+stg, tm = dist.HostStager(), {}
+got1 = dist.gather_ragged_to_host(blk, dst=0, stager=stg, timings=tm)
+got2 = dist.gather_ragged_to_host(blk + 10.0, dst=0, stager=stg, timings=tm)
+if rank == 0:
+    assert [type(g).__name__ for g in got1] == ["ndarray", "ndarray"] and [g.shape for g in got1] == [(2, 3, 2), (3, 3, 2)]
+    assert float(got1[1].mean()) == 1.0 and float(got2[1].mean()) == 11.0 and float(got1[0].mean()) == 0.0
+    assert tm["gather_bytes"] == 2 * 3 * 3 * 2 * 4 and tm["gather_s"] > 0.0
+else:
+    assert got1 is None and got2 is None and tm["gather_bytes"] == 0
+assert (dist.gather_ragged_to_host(None, dst=0) == []) if rank == 0 else (dist.gather_ragged_to_host(None, dst=0) is None)
 # walker sharding + trajectory gather through the callback: 5 walkers of one molecule -> ranks get 3 and 2
 mol = synth.random_chain(6, seed=0)
 class DS:
@@ -594,6 +606,14 @@ def test_bench_self_launches_ranks(tmp_path):
     assert len(lines) == 1, lines
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["ranks_seen"] == 2 and d["steps"] == 4
+    # the N > 1 line proves its ranks (an all-reduce of ones over the group) and times north_star's one collective: Sampler.sample(
+    # shard_walkers=True) + SaveTrajectoryCallback over both ranks — here with constant trajectories, the gather and the writer are real
+    assert d["rccl"] == {"backend": "gloo", "world": 2, "ranks_seen": 2}
+    sh = d["e2e_sharded"]
+    assert sh["walkers_total"] == 7 and sh["num_batches"] == 2 and sh["steps_per_batch"] == 8
+    assert sh["joined_shape"] == [17, 7 * 2 * 8, 3]  # every walker of both ranks, both batches, in the joined file on rank 0
+    assert sh["gather_bytes"] == 2 * 3 * 17 * 8 * 3 * 4  # rank 1's three walkers crossed ranks, once per batch
+    assert 0.0 < sh["gather_s"] <= sh["wall_s"] and sh["conformations_per_s"] > 0 and sh["files_written"] >= 2 * 8
     # under a launcher (WORLD_SIZE set) the script must NOT spawn again: a single rank with WORLD_SIZE=1 just runs
     r1 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--dry-run"], env=dict(env, WORLD_SIZE="1", RANK="0"),
                         capture_output=True, text=True, timeout=240)
