@@ -54,7 +54,7 @@ class jamun_topology(C.Structure):
 
 class jamun_tuning(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("no_dg", "no_mf", "dg_fp32", "dg_no_alt", "dg_no_sp", "dg_no_sph", "no_mfi", "no_init_v", "node_fp32",
-                                         "edge_h_fp32", "dg_kgroups", "no_tail", "no_short_k", "no_ml", "seg_cost_tenths", "f16x1")]
+                                         "edge_h_fp32", "dg_kgroups", "no_tail", "no_short_k", "no_ml", "seg_cost_tenths", "f16x1", "selfcheck")]
 
 
 class jamun_mcmc_params(C.Structure):
@@ -134,7 +134,7 @@ SYMBOLS = {
 
 PROF_CLASSES = ["geom", "edge_h", "conv0_init", "conv1_init", "conv0", "conv1", "node_update", "head_finalize", "tprod"]
 
-ABI_VERSION = 5  # jamun_version() of the library this binding was written for (struct layouts and signatures above)
+ABI_VERSION = 6  # jamun_version() of the library this binding was written for (struct layouts and signatures above)
 
 _lib: Optional[C.CDLL] = None
 

@@ -21,7 +21,7 @@ OUT = os.path.join(PKG, "libjamun_hip.so")
 OBJ_DIR = os.path.join(HERE, "build")
 SOURCES = ["jamun_kernels.hip", "jamun_conv.hip", "jamun_conv_initv.hip", "jamun_conv_dg.hip", "jamun_conv_mf.hip", "jamun_conv_ml.hip", "jamun_node.hip", "jamun_sepconv.hip",
            "jamun_api.cpp"]
-HEADERS = ["jamun_internal.h", "jamun_mf_dev.h", os.path.join(ROOT, "include", "jamun_hip.h")]
+HEADERS = ["jamun_internal.h", "jamun_mf_dev.h", "jamun_split.h", os.path.join(ROOT, "include", "jamun_hip.h")]
 DEPS = SOURCES + HEADERS
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 CFLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-x", "hip", "-ffp-contract=off", "-fno-slp-vectorize",

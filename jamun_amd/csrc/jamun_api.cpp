@@ -1740,7 +1740,7 @@ SegPlan plan_segments(int cus, int ng, int n_k, int N, const std::vector<int2>& 
 extern "C" {
 
 const char* jamun_last_error(void) { return g_err.c_str(); }
-int jamun_version(void) { return 5; }
+int jamun_version(void) { return 6; }
 
 int jamun_model_create(const jamun_hparams* hp, const jamun_tensor* tensors, int32_t n_tensors, jamun_model** out) {
   return guarded([&] {
@@ -1766,9 +1766,23 @@ int jamun_model_create(const jamun_hparams* hp, const jamun_tensor* tensors, int
 }
 void jamun_model_destroy(jamun_model* m) { delete m; }
 
+static void sampler_create_impl(const jamun_model* m, float sigma, const jamun_topology* topo, const jamun_tuning* tuning, jamun_sampler** out);
+static void sampler_self_check(const jamun_model* m, float sigma, const jamun_topology* topo, jamun_sampler* s);
+
 int jamun_sampler_create(const jamun_model* m, float sigma, const jamun_topology* topo, const jamun_tuning* tuning, jamun_sampler** out) {
   return guarded([&] {
     if (!m || !topo || !out) throw Err(JAMUN_ERR_INVALID, "null argument");
+    if (tuning && (tuning->selfcheck < -1 || tuning->selfcheck > 2)) throw Err(JAMUN_ERR_INVALID, "jamun_tuning.selfcheck must be -1 (off), 0 (default: on), 1 (on) or 2 (on, with an injected fault)");
+    jamun_sampler* s = nullptr;
+    sampler_create_impl(m, sigma, topo, tuning, &s);
+    std::unique_ptr<jamun_sampler> hold(s);
+    if (!tuning || tuning->selfcheck >= 0) sampler_self_check(m, sigma, topo, s);
+    *out = hold.release();
+  });
+}
+
+static void sampler_create_impl(const jamun_model* m, float sigma, const jamun_topology* topo, const jamun_tuning* tuning, jamun_sampler** out) {
+  {
     jamun_tuning tn{};
     if (tuning) tn = *tuning;
     if (tn.dg_kgroups != 0 && tn.dg_kgroups != 1 && tn.dg_kgroups != 2 && tn.dg_kgroups != 4 && tn.dg_kgroups != 8)
@@ -2250,7 +2264,83 @@ int jamun_sampler_create(const jamun_model* m, float sigma, const jamun_topology
     }
     HIPCHECK(hipDeviceSynchronize());
     *out = s.release();
-  });
+  }
+}
+
+// Create-time self-check: a build whose specialised kernels compute something else than the general ones must not sample.
+// The sampler's FIRST forward — on synthetic positions: one random-walk chain per walker, 0.15 nm steps, so that neighbourhoods are as dense
+// as a peptide's and the 32-neighbour cap binds on large molecules — is run twice: through the kernels this sampler selected (matrix-formed /
+// destination-grouped conv, table or matrix-formed initial projector, f16x3 node update and radial MLP) and through a second, temporary
+// sampler restricted to the general kernels (k_conv, k_node_update, k_edge_h: fp32 MFMAs / vector ALUs, no host-planned tiles).  Node
+// features after every block and the network output must agree to 2e-5 of the block's largest feature (the parity tests' bound; the f16x3
+// kernels sit at 1e-6).  The opt-in reduced-precision mode (f16x1) is checked against its own bound, 2e-2.  SeparableConv has one
+// implementation and is not checked.  Cost: one general-kernel forward + the packing of its weights (cfg2: 0.3 s, once per sampler).
+static void sampler_self_check(const jamun_model* m, float sigma, const jamun_topology* topo, jamun_sampler* s) {
+  const bool special = s->dg_on || s->mfi_on || s->mfx_on || s->mlx_on || s->initv_on;
+  if (!special) return;
+  for (auto& L : s->layers)
+    if (L.sep.w2b) return;
+  jamun_tuning rt{};
+  rt.no_dg = rt.no_mf = rt.no_mfi = rt.no_init_v = rt.no_ml = rt.no_tail = 1;
+  rt.node_fp32 = rt.edge_h_fp32 = 1;
+  rt.selfcheck = -1;
+  jamun_sampler* rp = nullptr;
+  sampler_create_impl(m, sigma, topo, &rt, &rp);
+  std::unique_ptr<jamun_sampler> r(rp);
+  const int N = s->n_atoms;
+  std::vector<float> y((size_t)N * 3);
+  {
+    uint64_t z = 0x9e3779b97f4a7c15ull;
+    auto u = [&]() { z = z * 6364136223846793005ull + 1442695040888963407ull; return (float)((z >> 40) & 0xffffff) / 8388608.0f - 1.0f; };  // (-1, 1)
+    for (int g = 0; g < topo->n_graphs; ++g) {
+      float px = 0.f, py = 0.f, pz = 0.f;
+      for (int a = topo->ptr[g]; a < topo->ptr[g + 1]; ++a) {
+        float dx, dy, dz, n2;
+        do { dx = u(); dy = u(); dz = u(); n2 = dx * dx + dy * dy + dz * dz; } while (n2 < 0.05f || n2 > 1.f);
+        const float inv = 0.15f / sqrtf(n2);
+        px += dx * inv; py += dy * inv; pz += dz * inv;
+        y[(size_t)a * 3] = px; y[(size_t)a * 3 + 1] = py; y[(size_t)a * 3 + 2] = pz;
+      }
+    }
+  }
+  float* y_dev = dev_upload(y);
+  struct Free { float* p; ~Free() { hipFree(p); } } free_y{y_dev};
+  if (s->tune.selfcheck == 2 && s->layers.size() > 1) {
+    // fault injection (tests): 4 KB of the first hidden layer's weight stream of the SELECTED kernel read as zeros from here on
+    float4* w = s->layers[1].dg.wm ? s->layers[1].dg.wm : s->layers[1].dg.wxh ? s->layers[1].dg.wxh : s->layers[1].dg.wx;
+    if (w) HIPCHECK(hipMemset(reinterpret_cast<char*>(w) + 64 * 1024, 0, 4096));
+  }
+  hipStream_t st = nullptr;
+  forward(s, y_dev, s->xhat_buf, nullptr, st);
+  forward(r.get(), y_dev, r->xhat_buf, nullptr, st);
+  HIPCHECK(hipStreamSynchronize(st));
+  mf_err_fetch(s, st);
+  HIPCHECK(hipStreamSynchronize(st));
+  mf_err_check(s);
+  const int n_cmp = std::min(N, 16384);  // (rows compared per block: the first 512 tiles — every tile runs the same code)
+  std::vector<float> a((size_t)n_cmp * s->XS), b((size_t)n_cmp * s->XS);
+  const double tol = s->x1 ? 2e-2 : 2e-5;
+  auto compare = [&](const float* da, const float* db, size_t n, const char* what, int layer) {
+    HIPCHECK(hipMemcpy(a.data(), da, n * sizeof(float), hipMemcpyDeviceToHost));
+    HIPCHECK(hipMemcpy(b.data(), db, n * sizeof(float), hipMemcpyDeviceToHost));
+    double mx = 0, dv = 0;
+    bool finite = true;
+    for (size_t i = 0; i < n; ++i) {
+      finite = finite && std::isfinite(a[i]) && std::isfinite(b[i]);
+      mx = std::max(mx, (double)std::fabs(b[i]));
+      dv = std::max(dv, (double)std::fabs(a[i] - b[i]));
+    }
+    if (!finite || dv > tol * std::max(mx, 1e-6)) {
+      char msg[320];
+      snprintf(msg, sizeof msg, "create-time self-check failed: %s%d of the selected kernels (conv path %d, mode %d, initial projector %d) deviates from the general kernels by %.3g of its largest value (bound %.0e)%s — this build must not sample",
+               what, layer, s->dg_on ? 2 : 0, s->dg_on ? s->dg_mode : -1, s->mlx_on ? 5 : s->mfx_on ? 4 : s->mfi_on ? 3 : s->initv_on ? 2 : 0, finite ? dv / std::max(mx, 1e-6) : NAN, tol, finite ? "" : " (non-finite values)");
+      throw Err(JAMUN_ERR_INVALID, msg);
+    }
+  };
+  for (size_t l = 0; l < s->layers.size(); ++l) compare(s->x[l], r->x[l], (size_t)n_cmp * s->XS, "node features after block ", (int)l);
+  compare(s->g, r->g, (size_t)n_cmp * 3, "network output g, block ", (int)s->layers.size());
+  if (s->ml_count) { HIPCHECK(hipMemset(s->ml_count, 0, sizeof(unsigned long long))); s->ml_launches = 0; }  // (the check's launches are not the run's)
+  s->edges_built = false;
 }
 void jamun_sampler_destroy(jamun_sampler* s) { delete s; }
 

@@ -40,6 +40,7 @@
 #include <stdio.h>
 
 #include "jamun_internal.h"
+#include "jamun_split.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -114,21 +115,6 @@ __device__ __forceinline__ int lds_address(const void* p) {
 
 // f16x3 split helpers: (a, b) -> packed halves with round-to-nearest-even; residual of a value against one half of a packed pair
 // (v_fma_mix_f32: fma with per-operand f16 / f32 selection; a - hi is exact: hi holds the leading 11 bits of a)
-__device__ __forceinline__ unsigned cvt_pk_f16(float a, float b) {
-  unsigned r;
-  asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-  return r;
-}
-__device__ __forceinline__ float resid_lo(float a, unsigned pk) {  // a - float(pk[15:0])
-  float r;
-  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r) : "v"(pk), "v"(a));
-  return r;
-}
-__device__ __forceinline__ float resid_hi(float a, unsigned pk) {  // a - float(pk[31:16])
-  float r;
-  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(pk), "v"(a));
-  return r;
-}
 __device__ __forceinline__ float pow2f(int e) { return __uint_as_float((unsigned)(e + 127) << 23); }  // 2^e, -126 <= e <= 127
 
 __host__ __device__ constexpr int dg_xs0(bool h) { return h ? DG_XS0H : DG_XS0; }

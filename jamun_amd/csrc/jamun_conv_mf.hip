@@ -649,20 +649,6 @@ __global__ __launch_bounds__(MF_THREADS) void k_conv_mf(MfArgs a) {
         auto split_pair = [&](int i) {  // i = 0..7: x1[m] tile, 8..15: cross-product tile; pair (s2, p2) of the tile
           const int s2 = (i >> 2) & 1, p2 = i & 3, q = 8 * s2 + 2 * p2;
           if constexpr ((dbg & 16) != 0) { ahA[s2][p2] = alA[s2][p2] = ahC[s2][p2] = alC[s2][p2] = 0u; return; }
-#ifdef MF_SPLIT_C  // (experiment: the plane waves' split as compiler-visible instructions)
-          const float m1c = opaque_minus_one();
-          if (i < 8) {
-            const float v0 = FA[q] * rs, v1 = FA[q + 1] * rs;
-            const unsigned ph = cvt_pk_f16_c(v0, v1);
-            ahA[s2][p2] = ph;
-            alA[s2][p2] = cvt_pk_f16_c(resid_lo_c(v0, ph, m1c), resid_hi_c(v1, ph, m1c));
-          } else {
-            const float v0 = (F1[q] - F2[q]) * rs, v1 = (F1[q + 1] - F2[q + 1]) * rs;
-            const unsigned ph = cvt_pk_f16_c(v0, v1);
-            ahC[s2][p2] = ph;
-            alC[s2][p2] = cvt_pk_f16_c(resid_lo_c(v0, ph, m1c), resid_hi_c(v1, ph, m1c));
-          }
-#else
           if (i < 8) {
             const float v0 = FA[q] * rs, v1 = FA[q + 1] * rs;
             const unsigned ph = cvt_pk_f16(v0, v1);
@@ -674,7 +660,6 @@ __global__ __launch_bounds__(MF_THREADS) void k_conv_mf(MfArgs a) {
             ahC[s2][p2] = ph;
             alC[s2][p2] = cvt_pk_f16(resid_lo(v0, ph), resid_hi(v1, ph));
           }
-#endif
         };
         // (MFMA slot i of the 3 NKS carries pairs [16 i / (3 NKS), 16 (i + 1) / (3 NKS)): 1 + 1 + 2 per step for four steps)
         auto ride = [&](int slot) {

@@ -228,10 +228,10 @@ __global__ __launch_bounds__(ML_THREADS) void k_conv_ml(MlArgs a) {
       for (int p = 0; p < NP; ++p) {
         if (!((PM >> p) & 1)) continue;
         const float c0 = cc[p], c1 = c0 * evx[p], c2 = c0 * evy[p], c3 = c0 * evz[p];
-        const unsigned h01 = cvt_pk_f16_s<4>(c0, c1), h23 = cvt_pk_f16_s<4>(c2, c3);
+        const unsigned h01 = cvt_pk_f16_c(c0, c1), h23 = cvt_pk_f16_c(c2, c3);
         stg[p][0] = h01; stg[p][1] = h23;
-        stg[p][2] = cvt_pk_f16_s<4>(resid_lo_s<4>(c0, h01, m1), resid_hi_s<4>(c1, h01, m1));
-        stg[p][3] = cvt_pk_f16_s<4>(resid_lo_s<4>(c2, h23, m1), resid_hi_s<4>(c3, h23, m1));
+        stg[p][2] = cvt_pk_f16_c(resid_lo_c(c0, h01, m1), resid_hi_c(c1, h01, m1));
+        stg[p][3] = cvt_pk_f16_c(resid_lo_c(c2, h23, m1), resid_hi_c(c3, h23, m1));
       }
     };
     auto flush4 = [&](char* __restrict__ cbuf, auto pm_) __attribute__((always_inline)) {
@@ -257,8 +257,8 @@ __global__ __launch_bounds__(ML_THREADS) void k_conv_ml(MlArgs a) {
 #pragma unroll
       for (int p = 0; p < NP; ++p) {
         const float c0 = coef(p) * scC;
-        const unsigned h0 = cvt_pk_f16_s<8>(c0, 0.f);
-        const unsigned l0 = cvt_pk_f16_s<8>(resid_lo_s<8>(c0, h0, m1), 0.f);
+        const unsigned h0 = cvt_pk_f16_c(c0, 0.f);
+        const unsigned l0 = cvt_pk_f16_c(resid_lo_c(c0, h0, m1), 0.f);
         char* __restrict__ d = cbuf + (ent[p] & 0x3fff);
         *reinterpret_cast<unsigned short*>(d) = (unsigned short)(h0 & 0xffffu);
         *reinterpret_cast<unsigned short*>(d + PL) = (unsigned short)(l0 & 0xffffu);
@@ -290,7 +290,7 @@ __global__ __launch_bounds__(ML_THREADS) void k_conv_ml(MlArgs a) {
           for (int e = 0; e < 4; ++e) {
             const int rowb = row_of(4 * c4 + e) * ROWX;
             const float a0 = ea[e] * scx, b0 = eb[e] * scx;
-            const unsigned ph = cvt_pk_f16_s<16>(a0, b0), pl = cvt_pk_f16_s<16>(resid_lo_s<16>(a0, ph, m1), resid_hi_s<16>(b0, ph, m1));
+            const unsigned ph = cvt_pk_f16_c(a0, b0), pl = cvt_pk_f16_c(resid_lo_c(a0, ph, m1), resid_hi_c(b0, ph, m1));
             *reinterpret_cast<unsigned*>(lds + rowb + 4 * jp) = ph;
             *reinterpret_cast<unsigned*>(lds + rowb + lo_off + 4 * jp) = pl;
           }
@@ -339,8 +339,8 @@ __global__ __launch_bounds__(ML_THREADS) void k_conv_ml(MlArgs a) {
 #pragma unroll
         for (int p2 = 0; p2 < 4; ++p2) {
           const float v0 = F[8 * s2 + 2 * p2] * rs, v1 = F[8 * s2 + 2 * p2 + 1] * rs;
-          ph[p2] = cvt_pk_f16_s<2>(v0, v1);
-          pl[p2] = cvt_pk_f16_s<2>(resid_lo_s<2>(v0, ph[p2], m1), resid_hi_s<2>(v1, ph[p2], m1));
+          ph[p2] = cvt_pk_f16_c(v0, v1);
+          pl[p2] = cvt_pk_f16_c(resid_lo_c(v0, ph[p2], m1), resid_hi_c(v1, ph[p2], m1));
         }
         Ah[s2] = make_float4(__uint_as_float(ph[0]), __uint_as_float(ph[1]), __uint_as_float(ph[2]), __uint_as_float(ph[3]));
         Al[s2] = make_float4(__uint_as_float(pl[0]), __uint_as_float(pl[1]), __uint_as_float(pl[2]), __uint_as_float(pl[3]));
@@ -545,8 +545,8 @@ __global__ __launch_bounds__(ML_THREADS) void k_conv_ml(MlArgs a) {
 #pragma unroll
               for (int q = 0; q < 4; ++q) {
                 const float t0 = t[q >> 1][2 * (q & 1)] * scT, t1 = t[q >> 1][2 * (q & 1) + 1] * scT;
-                ph[q] = cvt_pk_f16_s<1>(t0, t1);
-                pl[q] = cvt_pk_f16_s<1>(resid_lo_s<1>(t0, ph[q], m1), resid_hi_s<1>(t1, ph[q], m1));
+                ph[q] = cvt_pk_f16_c(t0, t1);
+                pl[q] = cvt_pk_f16_c(resid_lo_c(t0, ph[q], m1), resid_hi_c(t1, ph[q], m1));
               }
               const float4 bh = make_float4(__uint_as_float(ph[0]), __uint_as_float(ph[1]), __uint_as_float(ph[2]), __uint_as_float(ph[3]));
               const float4 bl = make_float4(__uint_as_float(pl[0]), __uint_as_float(pl[1]), __uint_as_float(pl[2]), __uint_as_float(pl[3]));
@@ -892,10 +892,10 @@ __global__ __launch_bounds__(ML_THREADS) void k_conv_mlx(MlxArgs a) {
 #pragma unroll
       for (int p = 0; p < NP; ++p) {
         const float c0 = cc[p], c1 = c0 * evx[p], c2 = c0 * evy[p], c3 = c0 * evz[p];
-        const unsigned h01 = cvt_pk_f16_s<32>(c0, c1), h23 = cvt_pk_f16_s<32>(c2, c3);
+        const unsigned h01 = cvt_pk_f16_c(c0, c1), h23 = cvt_pk_f16_c(c2, c3);
         stg[p][0] = h01; stg[p][1] = h23;
-        stg[p][2] = cvt_pk_f16_s<32>(resid_lo_s<32>(c0, h01, m1), resid_hi_s<32>(c1, h01, m1));
-        stg[p][3] = cvt_pk_f16_s<32>(resid_lo_s<32>(c2, h23, m1), resid_hi_s<32>(c3, h23, m1));
+        stg[p][2] = cvt_pk_f16_c(resid_lo_c(c0, h01, m1), resid_hi_c(c1, h01, m1));
+        stg[p][3] = cvt_pk_f16_c(resid_lo_c(c2, h23, m1), resid_hi_c(c3, h23, m1));
       }
     };
     auto flush = [&]() __attribute__((always_inline)) {
@@ -946,8 +946,8 @@ __global__ __launch_bounds__(ML_THREADS) void k_conv_mlx(MlxArgs a) {
 #pragma unroll
         for (int p2 = 0; p2 < 4; ++p2) {
           const float v0 = F[8 * s2 + 2 * p2] * rs, v1 = F[8 * s2 + 2 * p2 + 1] * rs;
-          ph[p2] = cvt_pk_f16_s<32>(v0, v1);
-          pl[p2] = cvt_pk_f16_s<32>(resid_lo_s<32>(v0, ph[p2], m1), resid_hi_s<32>(v1, ph[p2], m1));
+          ph[p2] = cvt_pk_f16_c(v0, v1);
+          pl[p2] = cvt_pk_f16_c(resid_lo_c(v0, ph[p2], m1), resid_hi_c(v1, ph[p2], m1));
         }
         Ah[s2] = make_float4(__uint_as_float(ph[0]), __uint_as_float(ph[1]), __uint_as_float(ph[2]), __uint_as_float(ph[3]));
         Al[s2] = make_float4(__uint_as_float(pl[0]), __uint_as_float(pl[1]), __uint_as_float(pl[2]), __uint_as_float(pl[3]));

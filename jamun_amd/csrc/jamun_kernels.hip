@@ -15,6 +15,7 @@
 #include <stdint.h>
 
 #include "jamun_internal.h"
+#include "jamun_split.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -336,11 +337,8 @@ __global__ __launch_bounds__(256) void k_edge_h16(const int* __restrict__ deg, c
         const float diff = FSUB(d, mu[16 * s2 + 8 * hh + 2 * p2 + e]) * inv_step;
         v[e] = __expf(-FMUL(diff, diff)) * (float)(16384.0 / 1.12);
       }
-      asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(ph[p2]) : "v"(v[0]), "v"(v[1]));
-      float r0, r1;
-      asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r0) : "v"(ph[p2]), "v"(v[0]));
-      asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r1) : "v"(ph[p2]), "v"(v[1]));
-      asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(pl[p2]) : "v"(r0), "v"(r1));
+      ph[p2] = cvt_pk_f16(v[0], v[1]);  // (jamun_split.h: compiler-visible instructions, never inline asm in front of an MFMA)
+      pl[p2] = cvt_pk_f16(resid_lo(v[0], ph[p2]), resid_hi(v[1], ph[p2]));
     }
     Rh[s2] = make_float4(__uint_as_float(ph[0]), __uint_as_float(ph[1]), __uint_as_float(ph[2]), __uint_as_float(ph[3]));
     Rl[s2] = make_float4(__uint_as_float(pl[0]), __uint_as_float(pl[1]), __uint_as_float(pl[2]), __uint_as_float(pl[3]));

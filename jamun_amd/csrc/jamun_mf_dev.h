@@ -4,6 +4,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "jamun_split.h"
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
@@ -53,69 +55,6 @@ __device__ __forceinline__ int lds_addr(const void* p) {
   return 0;
 #endif
 }
-__device__ __forceinline__ unsigned cvt_pk_f16(float a, float b) {
-  unsigned r;
-  asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-  return r;
-}
-__device__ __forceinline__ float resid_lo(float a, unsigned pk) {  // a - float(pk[15:0])
-  float r;
-  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r) : "v"(pk), "v"(a));
-  return r;
-}
-__device__ __forceinline__ float resid_hi(float a, unsigned pk) {  // a - float(pk[31:16])
-  float r;
-  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(pk), "v"(a));
-  return r;
-}
-// The same three primitives as COMPILER-VISIBLE instructions, for jamun_conv_ml.hip.  With -1.0 held in a scalar register the optimiser
-// cannot see through, fma(float(h), -1, a) is not folded into a subtraction and the back end selects exactly the instructions of the asm
-// versions (v_cvt_pk_f16_f32, v_fma_mix_f32) — as instructions it schedules and whose hazards it tracks.
-// Why two forms (round 5, measured; the cause is not established, so each kernel keeps the form it was validated with):
-//  * k_conv_ml<8> with the INLINE-ASM splits in its T term gave wrong AND irreproducible features (1e-4 per layer, different from run to run;
-//    extra wait counts and nops did not help); with these it is exact to 5e-7 and bit-reproducible (tests/test_gpu_parity.py:
-//    test_large_span_matrix_formed_conv).  An asm statement is opaque to the hazard recogniser and to the scheduler.
-//  * k_conv_mf with THESE in the split of its plane waves (and only there: staging, builder and the scalar waves' split convert cleanly)
-//    gives wrong vector rows — and runs 5 % faster, which is the lower power of wrong data, not a gain (profiles/EXPERIMENTS.md).
-typedef _Float16 mf_h2 __attribute__((ext_vector_type(2)));
-typedef float mf_f2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ float opaque_minus_one() {
-  float m1 = -1.0f;
-  asm volatile("" : "+s"(m1));
-  return m1;
-}
-__device__ __forceinline__ unsigned cvt_pk_f16_c(float a, float b) { return __builtin_bit_cast(unsigned, __builtin_convertvector(mf_f2{a, b}, mf_h2)); }
-__device__ __forceinline__ float resid_lo_c(float a, unsigned pk, float m1) { return __builtin_fmaf((float)__builtin_bit_cast(mf_h2, pk).x, m1, a); }  // a - float(pk[15:0])
-__device__ __forceinline__ float resid_hi_c(float a, unsigned pk, float m1) { return __builtin_fmaf((float)__builtin_bit_cast(mf_h2, pk).y, m1, a); }  // a - float(pk[31:16])
-// experiment switch (-DML_SPLIT_ASM=bits: the inline-asm forms at single sites of jamun_conv_ml.hip; 1 T term, 2 split16, 4 prep4, 8 build1, 16 stage, 32 k_conv_mlx)
-#ifndef ML_SPLIT_ASM
-#define ML_SPLIT_ASM 0
-#endif
-// (-DML_T_VARIANT=n narrows the asm form further: 1 cvt only, 2 residuals only, 3 "s_nop 1" behind every asm instruction, 4 asm volatile, 5 early-clobber outputs)
-#ifndef ML_T_VARIANT
-#define ML_T_VARIANT 0
-#endif
-__device__ __forceinline__ unsigned cvt_pk_f16_v(float a, float b) {
-  unsigned r;
-  if constexpr (ML_T_VARIANT == 2) return cvt_pk_f16_c(a, b);
-  else if constexpr (ML_T_VARIANT == 3) asm("v_cvt_pk_f16_f32 %0, %1, %2\n\ts_nop 1" : "=v"(r) : "v"(a), "v"(b));
-  else if constexpr (ML_T_VARIANT == 4) asm volatile("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-  else if constexpr (ML_T_VARIANT == 5) asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=&v"(r) : "v"(a), "v"(b));
-  else asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-  return r;
-}
-template <bool HI> __device__ __forceinline__ float resid_v(float a, unsigned pk, float m1) {
-  float r;
-  if constexpr (ML_T_VARIANT == 1) return HI ? resid_hi_c(a, pk, m1) : resid_lo_c(a, pk, m1);
-  else if constexpr (ML_T_VARIANT == 3) { if constexpr (HI) asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\ts_nop 1" : "=v"(r) : "v"(pk), "v"(a)); else asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]\n\ts_nop 1" : "=v"(r) : "v"(pk), "v"(a)); }
-  else if constexpr (ML_T_VARIANT == 4) { if constexpr (HI) asm volatile("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(pk), "v"(a)); else asm volatile("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r) : "v"(pk), "v"(a)); }
-  else if constexpr (ML_T_VARIANT == 5) { if constexpr (HI) asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=&v"(r) : "v"(pk), "v"(a)); else asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=&v"(r) : "v"(pk), "v"(a)); }
-  else { if constexpr (HI) asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(pk), "v"(a)); else asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r) : "v"(pk), "v"(a)); }
-  return r;
-}
-template <int SITE> __device__ __forceinline__ unsigned cvt_pk_f16_s(float a, float b) { if constexpr ((ML_SPLIT_ASM & SITE) != 0) return cvt_pk_f16_v(a, b); else return cvt_pk_f16_c(a, b); }
-template <int SITE> __device__ __forceinline__ float resid_lo_s(float a, unsigned pk, float m1) { if constexpr ((ML_SPLIT_ASM & SITE) != 0) return resid_v<false>(a, pk, m1); else return resid_lo_c(a, pk, m1); }
-template <int SITE> __device__ __forceinline__ float resid_hi_s(float a, unsigned pk, float m1) { if constexpr ((ML_SPLIT_ASM & SITE) != 0) return resid_v<true>(a, pk, m1); else return resid_hi_c(a, pk, m1); }
 // uniform loads through the constant address space: scalar loads into scalar registers
 __device__ __forceinline__ int4 ld_const(const int4* p) {
 #if defined(__HIP_DEVICE_COMPILE__)

@@ -17,6 +17,7 @@
 #include <stdint.h>
 
 #include "jamun_internal.h"
+#include "jamun_split.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
@@ -29,21 +30,6 @@ typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 
 namespace {
 
-__device__ __forceinline__ unsigned cvt_pk_f16(float a, float b) {
-  unsigned r;
-  asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-  return r;
-}
-__device__ __forceinline__ float resid_lo(float a, unsigned pk) {  // a - float(pk[15:0])
-  float r;
-  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r) : "v"(pk), "v"(a));
-  return r;
-}
-__device__ __forceinline__ float resid_hi(float a, unsigned pk) {  // a - float(pk[31:16])
-  float r;
-  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(pk), "v"(a));
-  return r;
-}
 __device__ __forceinline__ float pow2f(int e) { return __uint_as_float((unsigned)(e + 127) << 23); }
 __device__ __forceinline__ int scale_of(float mx) {  // largest magnitude -> [2^13, 2^14)
   int s = 0;

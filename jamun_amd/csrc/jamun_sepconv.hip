@@ -24,6 +24,7 @@
 #include <algorithm>
 
 #include "jamun_internal.h"
+#include "jamun_split.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
@@ -40,21 +41,6 @@ typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 #define SF_LDS_BYTES (SF_W2_BYTES + 8 * 64 * 16 + 2 * 352 * 4)  // + slot records [8 waves][64] float4 + column factors and biases [2][352]
 
 namespace {
-__device__ __forceinline__ unsigned cvt_pk_f16(float a, float b) {
-  unsigned r;
-  asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-  return r;
-}
-__device__ __forceinline__ float resid_lo(float a, unsigned pk) {
-  float r;
-  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r) : "v"(pk), "v"(a));
-  return r;
-}
-__device__ __forceinline__ float resid_hi(float a, unsigned pk) {
-  float r;
-  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(pk), "v"(a));
-  return r;
-}
 __device__ __forceinline__ float pow2f(int e) { return __uint_as_float((unsigned)(e + 127) << 23); }
 }  // namespace
 

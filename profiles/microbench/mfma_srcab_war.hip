@@ -63,6 +63,25 @@ DEF_MODE(depB, VICTIM_DEP, OVW_B)
 DEF_MODE(depMix, VICTIM_DEP, OVW_MIX)
 DEF_MODE(indA, VICTIM_IND, OVW_A)
 
+// The rule that DID bite (round 6): a VGPR written by a vector-ALU instruction and read by the MFMA behind it as SrcB, N wait states later.
+// v104 (B.x) holds the OLD value from LOAD_TUPLES; the probe overwrites it with v_cvt_pk_f16_f32 of two new values and multiplies.
+#define DEF_V2M(NAME, NOPS)                                                                                                             \
+  __global__ __launch_bounds__(256) void NAME(const f32x4* __restrict__ in, float* __restrict__ out, int reps) {                        \
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;                                                                                \
+    const f32x4 a = in[3 * t], a2 = in[3 * t + 1], b = in[3 * t + 2];                                                                   \
+    f32x16 acc, acc2;                                                                                                                   \
+    for (int q = 0; q < 16; ++q) acc[q] = acc2[q] = 0.f;                                                                                \
+    for (int r = 0; r < reps; ++r) {                                                                                                    \
+      const float junk = 0.25f + 0.001f * r; /* the two NEW halves of B.x: cvt_pk(junk, junk) */                                        \
+      asm volatile(LOAD_TUPLES "v_cvt_pk_f16_f32 v104, %[junk], %[junk]\n" NOPS VICTIM_IND DRAIN                                         \
+                   : [acc] "+v"(acc), [acc2] "+v"(acc2) : OPS : CLOB);                                                                  \
+    }                                                                                                                                   \
+    float s = 0.f;                                                                                                                      \
+    for (int q = 0; q < 16; ++q) s += acc[q] + acc2[q];                                                                                 \
+    out[t] = s;                                                                                                                         \
+  }
+DEF_V2M(k_v2m_0, N0) DEF_V2M(k_v2m_1, N1) DEF_V2M(k_v2m_2, N2) DEF_V2M(k_v2m_4, N4) DEF_V2M(k_v2m_8, N8) DEF_V2M(k_v2m_40, N40)
+
 typedef void (*kern_t)(const f32x4*, float*, int);
 static void run(kern_t k, const f32x4* d_in, float* d_out, std::vector<float>& h, int nthreads) {
   hipLaunchKernelGGL(k, dim3(nthreads / 256), dim3(256), 0, 0, d_in, d_out, 50);
@@ -97,5 +116,7 @@ int main() {
   sweep("dependent victim, v_mov to SrcB", depB, d_in, d_out, nthreads);
   sweep("dependent victim, v_fma_mix_f32 (op_sel) to SrcA", depMix, d_in, d_out, nthreads);
   sweep("INDEPENDENT victim (own accumulator), v_mov to SrcA", indA, d_in, d_out, nthreads);
+  const kern_t v2m[6] = {k_v2m_0, k_v2m_1, k_v2m_2, k_v2m_4, k_v2m_8, k_v2m_40};
+  sweep("v_cvt_pk_f16_f32 writes B.x, the MFMA N wait states behind it reads B", v2m, d_in, d_out, nthreads);
   return 0;
 }

@@ -8,11 +8,14 @@ recogniser inserts `s_nop`s.  It does so for instructions it can see.  The body 
 `getWaitStatesSince` counts an INLINEASM as zero wait states), so a `v_cvt_pk_f16_f32` / `v_fma_mix_f32` written as inline asm
 that reads an accumulator too early reads whatever the register held — data dependent AND timing dependent.
 
-Rules checked (wait states = instructions issued by the wave between the two, `s_nop N` = N + 1; P = passes of the MFMA,
-8 for v_mfma_f32_32x32x16_{f16,bf16} / 16x16x32 on gfx950 as modelled here — LLVM 'GFX940_XDL_N_Pass...' tables, +1 on gfx950):
+Rules checked (wait states = instructions issued by the wave between the two, `s_nop N` = N + 1; P = passes of the MFMA: PASSES below,
+8 for v_mfma_f32_32x32x16_f16 — LLVM 'GFX940_XDL_N_Pass...' tables, +1 on gfx950; --passes is the default for opcodes not listed):
   RAW  MFMA writes vDst -> VALU / LDS / VMEM reads it          P + 3 + 1  (12)
   WAW  MFMA writes vDst -> VALU writes it                       P + 1 + 1  (10)
   WAR  MFMA reads SrcC  -> VALU writes it                       {2: 1, 4: 3, 8: 7, 16: 13}[P]
+  V2M  VALU writes a VGPR -> MFMA reads it (SrcA / SrcB / SrcC) 2      (hipcc -S of `x = f(..); mfma(x, ..)` shows the compiler keeping two wait
+       states there on gfx942 and gfx950; behind an inline-asm definition it keeps ONE — its generic rule for an asm that defines a VGPR — which
+       is what made k_conv_ml<8> with the asm `v_cvt_pk_f16_f32` irreproducible: profiles/EXPERIMENTS.md, round 6)
   (MFMA -> MFMA dependencies are all compiler-visible and not checked here.)
 
 Usage:  mfma_hazard_scan.py file.s [--kernel SUBSTR] [--passes 8] [--all]
@@ -40,8 +43,13 @@ NO_DST = ("ds_write", "ds_store", "global_store", "buffer_store", "flat_store", 
 SGPR_DST = ("v_cmp", "v_readfirstlane", "v_readlane")
 
 
+# passes (4 cycles each) of the MFMA opcodes this library issues, gfx950 (LLVM SISchedule: 32x32x16 f16 8, 16x16x32 f16 4, 32x32x2 f32 16, 16x16x4 f32 8)
+PASSES = {"v_mfma_f32_32x32x16_f16": 8, "v_mfma_f32_32x32x16_bf16": 8, "v_mfma_f32_16x16x32_f16": 4, "v_mfma_f32_16x16x32_bf16": 4,
+          "v_mfma_f32_32x32x2_f32": 16, "v_mfma_f32_16x16x4_f32": 8}
+
+
 class Ins:
-    __slots__ = ("line", "text", "op", "dst", "src", "asm", "ws", "mfma", "srcc")
+    __slots__ = ("line", "text", "op", "dst", "src", "asm", "ws", "mfma", "srcc", "passes")
 
     def __init__(self, line, text, asm):
         self.line, self.text, self.asm = line, text, asm
@@ -49,6 +57,7 @@ class Ins:
         self.op = parts[0]
         ops = [o.strip() for o in parts[1].split(",")] if len(parts) > 1 else []
         self.mfma = self.op.startswith("v_mfma") or self.op.startswith("v_smfmac")
+        self.passes = PASSES.get(self.op.split("_e64")[0], None)
         self.ws = 1
         if self.op == "s_nop":
             self.ws = int(ops[0], 0) + 1
@@ -95,8 +104,13 @@ def parse(lines):
 
 def check(ins, labels, passes, want_all):
     """Backward walk over the control-flow graph (fall-through + branch edges) from every candidate consumer."""
-    raw_ws, waw_ws, war_ws = passes + 4, passes + 2, {2: 1, 4: 3, 8: 7, 16: 13}[passes]
-    horizon = raw_ws
+    def need(p):  # (RAW, WAW, WAR) wait states behind MFMA p
+        n = p.passes or passes
+        if p.op.count("f32") == 2:  # fp32-input MFMAs are not XDL ops on gfx940+: LLVM's SMFMA tables (N + 2, N + 2)
+            return n + 2, n + 2, {2: 1, 4: 3, 8: 7, 16: 13}[n]
+        return n + 4, n + 2, {2: 1, 4: 3, 8: 7, 16: 13}[n]
+
+    horizon = 20
     jump_preds = {}
     for j, c in enumerate(ins):
         if c.op.startswith("s_cbranch") or c.op == "s_branch":
@@ -112,6 +126,23 @@ def check(ins, labels, passes, want_all):
         return out
 
     out = []
+    # V2M: the consumer is the (compiler-visible) MFMA, the producer a vector ALU instruction — inline asm or not
+    for j, c in enumerate(ins):
+        if not c.mfma:
+            continue
+        stack, seen = [(i, 0, i != j - 1) for i in preds(j)], set()
+        while stack:
+            i, ws, jumped = stack.pop()
+            if (i, ws) in seen:
+                continue
+            seen.add((i, ws))
+            p = ins[i]
+            if p.op.startswith("v_") and not p.mfma and (p.dst & c.src) and (p.asm or want_all) and ws < 2:
+                out.append(("V2M", ws, 2, p, c, " (path through a branch edge)" if jumped else ""))
+            ws += 0 if p.asm else p.ws
+            if ws < 2:
+                for q in preds(i):
+                    stack.append((q, ws, jumped or q != i - 1))
     for j, c in enumerate(ins):
         if c.mfma or c.op.startswith("s_") or not (c.asm or want_all) or not (c.dst or c.src):
             continue
@@ -124,6 +155,7 @@ def check(ins, labels, passes, want_all):
             p = ins[i]
             if p.mfma:
                 tag = " (path through a branch edge)" if jumped else ""
+                raw_ws, waw_ws, war_ws = need(p)
                 if ws < raw_ws and (c.src & p.dst):
                     out.append(("RAW", ws, raw_ws, p, c, tag))
                 if ws < waw_ws and (c.dst & p.dst):
@@ -162,10 +194,10 @@ def main():
     a = ap.parse_args()
     bad = 0
     for name, (n, nm, na, out) in scan(a.file, a.kernel, a.passes, a.all).items():
-        n_asm = sum(1 for v in out if v[4].asm)
+        n_asm = sum(1 for v in out if (v[3].asm if v[0] == "V2M" else v[4].asm))
         print(f"{name}: {n} instructions, {nm} MFMA, {na} inline-asm; violations: {n_asm} inline-asm, {len(out) - n_asm} compiler-visible")
         for kind, ws, need, p, c, tag in out:
-            print(f"   {kind} {ws}/{need} wait states{tag}: line {p.line}: {p.text}\n        -> line {c.line}{' [asm]' if c.asm else ''}: {c.text}")
+            print(f"   {kind} {ws}/{need} wait states{tag}: line {p.line}{' [asm]' if p.asm else ''}: {p.text}\n        -> line {c.line}{' [asm]' if c.asm else ''}: {c.text}")
         bad += n_asm
     sys.exit(1 if bad else 0)
 

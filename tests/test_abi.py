@@ -28,7 +28,7 @@ def test_library_builds_loads_and_exports_all_symbols():
     lib = _lib.load()
     for name in _declared_symbols():
         assert hasattr(lib, name), name
-    assert lib.jamun_version() == _lib.ABI_VERSION == 5  # the binding refuses any other version (struct layouts)
+    assert lib.jamun_version() == _lib.ABI_VERSION == 6  # the binding refuses any other version (struct layouts)
 
 
 def test_num_frames_matches_reference_counts():
@@ -90,3 +90,53 @@ def test_library_reads_no_environment_and_tuning_is_validated():
     body = hdr[hdr.index("typedef struct jamun_tuning {") : hdr.index("} jamun_tuning;")]
     fields = re.findall(r"int32_t\s+(\w+)", body)
     assert fields == [n for n, _ in _lib.jamun_tuning._fields_]  # the binding mirrors the header field for field
+
+
+def _device_isa(src: str) -> str:
+    """gfx950 ISA text of one kernel source with the library's own flags (hipcc -S --cuda-device-only), cached under csrc/build/ by the same
+    digest as the objects (source + shared headers + flags)."""
+    import subprocess
+
+    from jamun_amd.csrc import build as b
+
+    os.makedirs(b.OBJ_DIR, exist_ok=True)
+    out = os.path.join(b.OBJ_DIR, f"{os.path.splitext(src)[0]}.{b._obj_digest(src)}.s")
+    if not os.path.exists(out):
+        for old in os.listdir(b.OBJ_DIR):
+            if old.startswith(os.path.splitext(src)[0] + ".") and old.endswith(".s"):
+                os.unlink(os.path.join(b.OBJ_DIR, old))
+        tmp = out + f".tmp{os.getpid()}"
+        subprocess.run([b.HIPCC] + b.CFLAGS + b.EXTRA + ["-S", "--cuda-device-only", os.path.join(b.HERE, src), "-o", tmp], check=True, capture_output=True)
+        os.replace(tmp, out)
+    return out
+
+
+def test_no_vector_instruction_sits_inside_an_mfma_hazard_window_of_the_shipped_build():
+    """The tripwire behind jamun_split.h.  On gfx950 the dependencies between a v_mfma and the vector instructions around it are software
+    managed (wait states); hipcc inserts them for instructions it selects and NOT for the body of an inline-asm statement.  Round 5 shipped
+    asm `v_cvt_pk_f16_f32` results read by an MFMA one wait state later (two are needed): right by luck in three kernels, irreproducible in a
+    fourth.  profiles/tools/mfma_hazard_scan.py re-derives the rules (RAW / WAW / WAR behind an MFMA, VALU -> MFMA) and walks the ISA of
+    every kernel: no instruction, compiler-selected or asm, may violate them — and the split primitives must not be asm again."""
+    import importlib.util
+    from concurrent.futures import ThreadPoolExecutor
+
+    from jamun_amd.csrc import build as b
+
+    spec = importlib.util.spec_from_file_location("mfma_hazard_scan", os.path.join(ROOT, "profiles", "tools", "mfma_hazard_scan.py"))
+    scan = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(scan)
+    assert "JAMUN_SPLIT_ASM_REPRO" not in " ".join(b.CFLAGS + b.EXTRA)
+    hips = [s for s in b.SOURCES if s.endswith(".hip")]
+    with ThreadPoolExecutor(max_workers=min(len(hips), os.cpu_count() or 4)) as ex:
+        isas = list(ex.map(_device_isa, hips))
+    n_kernels = n_mfma = 0
+    for src, isa in zip(hips, isas):
+        for name, (n_ins, n_m, n_asm, violations) in scan.scan(isa, want_all=True).items():
+            n_kernels += 1
+            n_mfma += n_m
+            assert not violations, (src, name, [(k, ws, need, p.text, c.text) for k, ws, need, p, c, _ in violations[:4]])
+    assert n_kernels >= 60 and n_mfma >= 3000  # (the scan saw the library: ~80 kernels, ~4800 MFMA instructions)
+    for f in os.listdir(b.HERE):  # one split implementation: no kernel source carries its own asm v_cvt_pk / v_fma_mix
+        if f.endswith((".hip", ".h")) and f != "jamun_split.h":
+            txt = open(os.path.join(b.HERE, f)).read()
+            assert not re.search(r'asm[^;]*"v_(cvt_pk_f16_f32|fma_mix_f32)', txt), f

@@ -297,3 +297,30 @@ def test_long_chaotic_walk_agrees_with_the_oracle_as_an_ensemble():
         print(f"ensemble {name}: HIP {ga.mean().item():.6f} oracle {gb.mean().item():.6f} nm, |diff| {d:.2e}, standard error {se:.2e}")
         assert d <= 5 * se + 1e-6, (name, d, se)
     print(f"single trajectories: x-hat RMSD vs oracle {errs[7]:.1e} nm at frame 7, {errs[39]:.1e} at 39, {errs[79]:.1e} at 79")
+
+
+@pytest.mark.parametrize("kind", ["chain17x6", "chain33x4", "chig93x2"])
+def test_create_time_self_check_passes_on_this_build_and_fires_on_a_corrupted_kernel(kind):
+    """jamun_sampler_create runs the sampler's first forward (synthetic positions) through the kernels it selected AND through the general
+    kernels and refuses to hand out a sampler whose node features differ by more than 2e-5 (jamun_api.cpp: sampler_self_check): a build whose
+    matrix-formed kernels compute something else — the round-5 inline-asm hazard was such a build — must not sample.  Here: the default
+    build passes (k_conv_mf + k_conv_mfi, + tail tiles, k_conv_ml + k_conv_mlx); with `selfcheck = 2` 4 KB of the selected conv kernel's
+    weight stream are zeroed before the check, and create must fail with the reason; `selfcheck = -1` switches the check off."""
+    from jamun_amd import synth
+    from jamun_amd.data import WalkerBatch
+    from jamun_amd.model import Denoiser
+    from jamun_amd.native import NativeSampler
+
+    mk = _mk()
+    dev = torch.device("cuda", 0)
+    model = Denoiser.from_checkpoint_dict(synth.synthetic_checkpoint(output_gain=0.5)).to(dev)
+    batch = WalkerBatch.from_molecules(mk.molecules(kind)).to(dev)
+    ok = NativeSampler(model._native, 0.04, batch, dev)  # (default: check on)
+    assert ok.stats()["conv_path"] == 2 and ok.stats()["dg_mode"] in (4, 5)
+    with pytest.raises(RuntimeError, match="self-check failed.*must not sample"):
+        NativeSampler(model._native, 0.04, batch, dev, tuning={"selfcheck": 2})
+    off = NativeSampler(model._native, 0.04, batch, dev, tuning={"selfcheck": -1})
+    ref = _golden(f"oracle_forward_{kind}")
+    assert torch.equal(off.xhat(ref["y"].to(dev)), ok.xhat(ref["y"].to(dev)))  # the check leaves no trace in the sampler it passed
+    with pytest.raises(RuntimeError, match="selfcheck"):
+        NativeSampler(model._native, 0.04, batch, dev, tuning={"selfcheck": 7})
