@@ -719,6 +719,14 @@ __global__ __launch_bounds__(MF_THREADS) void k_conv_mf(MfArgs a) {
     // ---- all threads: sum of the five K-partial tiles -> partial slab of this segment, coalesced 16-byte stores
     sg0 = nsg0; sg1 = nsg1;
     if (RFL(sg0.x) >= 0) { t_at = ld_const(a.tile_atoms + RFL(sg0.x)); span = ld_const(a.tile_span + RFL(sg0.x)); }
+    // (the inverse column scales of this thread's slab pieces: requested in FRONT of the barrier — as loads at their points of use they were a
+    // global round trip of ~2 k cycles inside every segment's epilogue, round 6)
+    constexpr int NE0 = (32 * 40 + MF_THREADS - 1) / MF_THREADS, NE1 = (32 * 24 + MF_THREADS - 1) / MF_THREADS;
+    float4 cfa[NE0], cfb[NE1];
+#pragma unroll
+    for (int j = 0; j < NE0; ++j) cfa[j] = reinterpret_cast<const float4*>(a.cf0)[(tid + j * MF_THREADS) % 40];
+#pragma unroll
+    for (int j = 0; j < NE1; ++j) cfb[j] = reinterpret_cast<const float4*>(a.cf1)[((tid + j * MF_THREADS) % 24) & 7];
     LDS_BARRIER();
     SSTAMP(6);
     {
@@ -726,23 +734,29 @@ __global__ __launch_bounds__(MF_THREADS) void k_conv_mf(MfArgs a) {
       const float* __restrict__ ST1 = reinterpret_cast<const float*>(lds + 5 * 32 * 160 * 4);
       float* __restrict__ p0 = a.partial0 + ((size_t)slab * a.n_pad + n0) * (size_t)(a.nt0 * 32);
       float* __restrict__ p1 = a.partial1 + ((size_t)slab * a.n_pad + n0) * 96;
-      for (int idx = tid; idx < 32 * 40; idx += MF_THREADS) {
+#pragma unroll
+      for (int j = 0; j < NE0; ++j) {
+        const int idx = tid + j * MF_THREADS;
+        if (idx >= 32 * 40) break;
         const int row = idx / 40, c4 = idx - row * 40;
         const float* __restrict__ q0 = ST0 + row * 160 + 4 * c4;
         const float4 a0 = *reinterpret_cast<const float4*>(q0), a1 = *reinterpret_cast<const float4*>(q0 + 5120),
                      a2 = *reinterpret_cast<const float4*>(q0 + 10240), a3 = *reinterpret_cast<const float4*>(q0 + 15360),
                      a4 = *reinterpret_cast<const float4*>(q0 + 20480);
         const float i2 = i2_of(row);
-        const float4 cf = reinterpret_cast<const float4*>(a.cf0)[c4];
+        const float4 cf = cfa[j];
         const float4 v = make_float4(((((((a0.x + a1.x) + a2.x) + a3.x) + a4.x) * i1) * i2) * cf.x, ((((((a0.y + a1.y) + a2.y) + a3.y) + a4.y) * i1) * i2) * cf.y,
                                      ((((((a0.z + a1.z) + a2.z) + a3.z) + a4.z) * i1) * i2) * cf.z, ((((((a0.w + a1.w) + a2.w) + a3.w) + a4.w) * i1) * i2) * cf.w);
         if (row < n_dst) *reinterpret_cast<float4*>(p0 + row * 160 + 4 * c4) = v;
       }
-      for (int idx = tid; idx < 32 * 24; idx += MF_THREADS) {
+#pragma unroll
+      for (int j = 0; j < NE1; ++j) {
+        const int idx = tid + j * MF_THREADS;
+        if (idx >= 32 * 24) break;
         const int row = idx / 24, c4 = idx - row * 24;
         const float i2 = i2_of(row);
         const float4 c = *reinterpret_cast<const float4*>(ST1 + row * 96 + 4 * c4), t = *reinterpret_cast<const float4*>(ST1 + 3072 + row * 96 + 4 * c4);
-        const float4 cf = reinterpret_cast<const float4*>(a.cf1)[c4 & 7];  // (column 4 (c4 % 8) .. of plane c4 / 8)
+        const float4 cf = cfb[j];  // (column 4 (c4 % 8) .. of plane c4 / 8)
         const float4 v = make_float4(((c.x * i1) * i2) * cf.x + (t.x * i1) * iT2, ((c.y * i1) * i2) * cf.y + (t.y * i1) * iT2, ((c.z * i1) * i2) * cf.z + (t.z * i1) * iT2,
                                      ((c.w * i1) * i2) * cf.w + (t.w * i1) * iT2);
         if (row < n_dst) *reinterpret_cast<float4*>(p1 + row * 96 + 4 * c4) = v;
