@@ -472,6 +472,9 @@ def e2e_sharded(model, cfg, dev, world, rank, steps=1000, num_batches=2, walkers
         bs = _StubBatchSampler(steps)
     else:
         bs = SingleMeasurementSampler(mcmc=BAOAB(steps=steps, save_trajectory=True, save_every_n_steps=1, v_init="gaussian", **MCMC), sigma=SIGMA)
+    if not stub:  # untimed: the native sampler of this rank's shard (weights packed, work lists planned, create-time self-check) is built and cached
+        Sampler(shard_walkers=True).sample(model, SingleMeasurementSampler(mcmc=BAOAB(steps=2, save_trajectory=True, save_every_n_steps=1, v_init="gaussian", **MCMC), sigma=SIGMA),
+                                           num_batches=1, init_graphs=batch)
     torch.manual_seed(42 + rank)  # seed + rank (cmdline/sample.py:86-88)
     sync = torch.cuda.synchronize if dev.type == "cuda" else (lambda: None)
     sync()
@@ -593,6 +596,7 @@ def main():
     ap.add_argument("--dry-run", action="store_true", help="rank plumbing only (gloo, no kernels): used by the CPU test of the self-launch")
     ap.add_argument("--dry-run-fail-rank", type=int, default=-1, help="with --dry-run: this rank exits with an error before the rendezvous (tests the supervision of the self-launch)")
     ap.add_argument("--no-e2e", action="store_true", help="skip the Sampler.sample wall-time legs (1000 / 20000 steps per batch, with and without the trajectory writer)")
+    ap.add_argument("--sharded-leg", action="store_true", help="run the e2e_sharded leg also at world size 1 when a process group exists (torch.distributed.run --nproc-per-node 1): the RCCL path on one GPU")
     ap.add_argument("--no-also", action="store_true", help="skip the 20-step walks of cfg2r / cfg5h / cfg2 f16x1 added to the cfg2 line")
     ap.add_argument("--no-sweep", action="store_true", help="skip the one-GPU walker-count sweep (256 / 512 / 1024 / 2048 walkers)")
     ap.add_argument("--signature", action="store_true", help="print the build signature of this config (source digest + kernel selection) as JSON and exit (profiles/collect.sh)")
@@ -628,7 +632,7 @@ def main():
     from jamun_amd.model import Denoiser
     from jamun_amd import synth
 
-    rank, world = dist.init_process_group()
+    rank, world = dist.init_process_group(force=args.sharded_leg)
     if args.gpus != world:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     assert torch.cuda.is_available(), "bench.py needs a GPU (jamun_amd has no CPU path)"
@@ -728,8 +732,9 @@ def main():
 
     rccl = rccl_record(dev, world)
     sharded = None
-    if world > 1 and not args.no_e2e and args.walkers is None and args.atoms is None:
-        del y_traj, score_traj, xhat_traj
+    grouped = torch.distributed.is_available() and torch.distributed.is_initialized()  # (under a launcher even one rank has a group: the RCCL path runs)
+    if (world > 1 or (grouped and args.sharded_leg)) and not args.no_e2e and args.walkers is None and args.atoms is None:
+        y_traj = score_traj = xhat_traj = None  # (free the headline walk's frames)
         # (every rank takes part; 1000 steps per batch: 0.85 s of walking per batch at cfg2, 13 MB per rank and batch to rank 0)
         sharded = e2e_sharded(model, args.config, dev, world, rank, steps=1000, num_batches=2,
                               walkers_total=total_walkers if args.strong else None)

@@ -108,6 +108,7 @@ typedef struct jamun_tuning {
                            rounded to 11 bits, fp32 accumulation) instead of the three of the f16x3 scheme; state, integrator, radial MLPs, initial
                            projector, node update and head stay as they are.  Never the default; x-hat then sits 2.5e-5 .. 7.6e-5 nm from the fp32
                            path on the test batches (asserted <= 1e-3 nm; the level of the reference's TF32 GPU path).  jamun_stats.dg_emu reports 2.  Ignored by the other conv kernels.   */
+  int32_t no_fuse_geom; /* walks: k_finalize of an iteration and k_geom of the next as two launches instead of one (k_finalize_geom, round 6); A/B aid */
   int32_t selfcheck;    /* create-time self-check of the selected kernels against the general ones (one forward on synthetic positions through both;
                            node features after every block within 2e-5, else jamun_sampler_create returns JAMUN_ERR_INVALID): 0 / 1 on (default),
                            -1 off, 2 on with an injected fault in the selected conv kernel's weight stream (tests: the check must fire)   */

@@ -1262,8 +1262,8 @@ struct ProfScope {
 // Geometry of one forward: centring, radius graph + bonded edges, unit vectors and distances (k_geom; `pre`: the first half of a
 // BAOAB iteration fused in front of it), and — when the buffer holds all layers — the radial MLPs' hidden activations of every
 // layer (k_edge_h; they depend on the geometry only).
-void build_edges(jamun_sampler* s, float* y, hipStream_t st, const LangevinPre& pre = LangevinPre()) {
-  {
+void build_edges(jamun_sampler* s, float* y, hipStream_t st, const LangevinPre& pre = LangevinPre(), bool geom_done = false) {
+  if (!geom_done) {  // (geom_done: the previous walk iteration's last launch, k_finalize_geom, already advanced y and built the edge table)
     ProfScope ps(s, JAMUN_PROF_GEOM, st);
     launch_geom(y, s->ptr, s->n_graphs, s->c_in, s->r2, s->S, s->bond_in_ptr, s->bond_in_src, s->hp.mean_center, s->yc,
                 s->deg, s->esrc, s->egeo, s->epair, pre, st);
@@ -1502,8 +1502,8 @@ void mf_err_fetch(jamun_sampler* s, hipStream_t st) {
 // One denoiser forward.  `pre` / `post`: the two halves of a BAOAB iteration fused into the first and the last kernel of the
 // forward (y is then advanced in place before the geometry is built).
 void forward(jamun_sampler* s, float* y, float* xhat, float* score, hipStream_t st, const LangevinPre& pre = LangevinPre(),
-             const LangevinPost& post = LangevinPost()) {
-  build_edges(s, y, st, pre);
+             const LangevinPost& post = LangevinPost(), const LangevinPre* next_pre = nullptr, bool geom_done = false) {
+  build_edges(s, y, st, pre, geom_done);
   const float* x_in = s->x_emb;
   int XSin = s->n_emb;
   for (size_t l = 0; l < s->layers.size(); ++l) {
@@ -1517,8 +1517,12 @@ void forward(jamun_sampler* s, float* y, float* xhat, float* score, hipStream_t 
   {
     ProfScope ps(s, JAMUN_PROF_HEAD, st);
     launch_head(hd, st);
-    launch_finalize(y, s->yc, s->g, s->ptr, s->n_graphs, s->c_skip, s->c_out, s->sigma * s->sigma, s->hp.mean_center,
-                    s->tmp, xhat, score, post, st);
+    if (next_pre)  // walk: this iteration's finalize and the next iteration's geometry in one launch
+      launch_finalize_geom(y, s->yc, s->g, s->ptr, s->n_graphs, s->c_skip, s->c_out, s->sigma * s->sigma, s->hp.mean_center, s->tmp, xhat, score, post,
+                           s->c_in, s->r2, s->S, s->bond_in_ptr, s->bond_in_src, s->deg, s->esrc, s->egeo, s->epair, *next_pre, st);
+    else
+      launch_finalize(y, s->yc, s->g, s->ptr, s->n_graphs, s->c_skip, s->c_out, s->sigma * s->sigma, s->hp.mean_center,
+                      s->tmp, xhat, score, post, st);
   }
   HIPCHECK(hipGetLastError());
 }
@@ -2384,7 +2388,15 @@ int jamun_walk_baoab(jamun_sampler* s, float* y, float* v, const jamun_mcmc_para
     const size_t fr = (size_t)n * 3;
     int fy = 0, fs = 0;
     // The two halves of an iteration run inside the first and the last kernel of the forward (k_geom, k_finalize): one step =
-    // the forward's launches and nothing else.  i = 0: initial frame + initial score (_splitting.py:136-155)
+    // the forward's launches and nothing else — and (round 6) the last kernel of iteration i IS the first of iteration i + 1
+    // (k_finalize_geom: 20 launches per step instead of 21; jamun_tuning.no_fuse_geom: the two separate kernels).
+    // i = 0: initial frame + initial score (_splitting.py:136-155)
+    const bool fuse = !s->tune.no_fuse_geom;
+    auto make_pre = [&](int i) {
+      LangevinPre pre;
+      pre.v = v; pre.psi = s->psi; pre.noise = noise ? noise + fr * (size_t)(i - 1) : nullptr; pre.seed = seed; pre.iter = (uint32_t)i; pre.k = k;
+      return pre;
+    };
     {
       const bool sv = saves(p, 0);
       LangevinPost post;
@@ -2392,13 +2404,13 @@ int jamun_walk_baoab(jamun_sampler* s, float* y, float* v, const jamun_mcmc_para
       post.y_frame = (y_traj && sv) ? y_traj + fr * fy : nullptr;
       post.xhat_frame = (xhat_traj && sv) ? xhat_traj + fr * fy : nullptr;
       post.score_frame = score_traj ? score_traj + fr * fs : nullptr;
-      forward(s, y, s->xhat_buf, s->score_buf, st, LangevinPre(), post);
+      const LangevinPre pre1 = make_pre(1);
+      forward(s, y, s->xhat_buf, s->score_buf, st, LangevinPre(), post, (fuse && p->steps > 1) ? &pre1 : nullptr);
       if (sv) ++fy;
       ++fs;
     }
     for (int i = 1; i < p->steps; ++i) {
-      LangevinPre pre;
-      pre.v = v; pre.psi = s->psi; pre.noise = noise ? noise + fr * (size_t)(i - 1) : nullptr; pre.seed = seed; pre.iter = (uint32_t)i; pre.k = k;
+      const LangevinPre pre = make_pre(i), pre_next = make_pre(i + 1);
       const bool sv = saves(p, i);
       LangevinPost post;
       post.psi_out = s->psi; post.v = v; post.update_v = 1; post.k = k;
@@ -2407,7 +2419,7 @@ int jamun_walk_baoab(jamun_sampler* s, float* y, float* v, const jamun_mcmc_para
       // scores after the initial one are kept only together with the trajectory (_splitting.py:168-170): without y_traj
       // the caller's score_traj holds ONE frame
       post.score_frame = (score_traj && y_traj && sv) ? score_traj + fr * fs : nullptr;
-      forward(s, y, s->xhat_buf, s->score_buf, st, pre, post);
+      forward(s, y, s->xhat_buf, s->score_buf, st, pre, post, (fuse && i + 1 < p->steps) ? &pre_next : nullptr, /*geom_done=*/fuse);
       if (sv) { ++fy; ++fs; }
     }
     if (xhat_out) launch_copy(s->xhat_buf, xhat_out, n * 3, st);  // last forward was evaluated at the final y

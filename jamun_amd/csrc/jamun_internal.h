@@ -394,6 +394,9 @@ struct LangevinPost {
 void launch_mean_center(const float* pos, const int* ptr, int n_graphs, float* out, hipStream_t st);
 void launch_radius_graph(const float* pos, const int* ptr, int n_graphs, float r2, int stride, int* nbr, int* deg,
                          hipStream_t st);
+void launch_finalize_geom(float* y, float* yc, const float* g, const int* ptr, int n_graphs, float c_skip, float c_out, float sigma2, int mean_center,
+                          float* tmp, float* xhat, float* score, const LangevinPost& post, float c_in, float r2, int S, const int* bip, const int* bis,
+                          int* deg, int* esrc, float4* egeo, int* epair, const LangevinPre& pre, hipStream_t st);
 void launch_geom(float* y, const int* ptr, int n_graphs, float c_in, float r2, int S, const int* bip,
                  const int* bis, int mean_center, float* yc, int* deg, int* esrc, float4* egeo, int* epair, const LangevinPre& pre,
                  hipStream_t st);

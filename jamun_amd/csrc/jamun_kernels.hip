@@ -73,15 +73,26 @@ __device__ __forceinline__ void philox_normal3(uint64_t seed, uint32_t iter, uin
 // Optional BAOAB first half (B, A, O, A) fused in front of the geometry: the walker's workgroup first advances its own atoms
 //   v += u(d/2) psi ; y += (d/2) v ; vhat = a v + z R ; y += (d/2) vhat ; v <- vhat      (functional/_splitting.py:158-163)
 // with exactly the arithmetic of k_baoab_pre, then centres and builds the edge table from the new y.
-__global__ void k_geom(float* __restrict__ y, const int* __restrict__ ptr, float c_in, float r2, int S,
-                       const int* __restrict__ bond_in_ptr, const int* __restrict__ bond_in_src, int mean_center,
-                       float* __restrict__ yc, int* __restrict__ deg, int* __restrict__ esrc,
-                       float4* __restrict__ egeo, int* __restrict__ epair, LangevinPre pre) {
-  __shared__ float cen[3];
+struct GeomArgs {
+  float* y;
+  const int* ptr;
+  float c_in, r2;
+  int S;
+  const int *bond_in_ptr, *bond_in_src;
+  int mean_center;
+  float* yc;
+  int *deg, *esrc;
+  float4* egeo;
+  int* epair;
+};
+// (cen [3] and s_pos [3 GEOM_LDS_ATOMS]: the workgroup's shared arrays)
+__device__ __forceinline__ void geom_body(float* __restrict__ y, const int* __restrict__ ptr, float c_in, float r2, int S,
+                                          const int* __restrict__ bond_in_ptr, const int* __restrict__ bond_in_src, int mean_center,
+                                          float* __restrict__ yc, int* __restrict__ deg, int* __restrict__ esrc,
+                                          float4* __restrict__ egeo, int* __restrict__ epair, const LangevinPre& pre, float* cen, float* s_pos) {
   // The walker's coordinates through LDS (molecules up to GEOM_LDS_ATOMS): the centre is a sum in atom order by three threads and the
   // neighbour search reads every atom of the molecule per thread — as global loads both are chains of dependent round trips (a
   // 166-atom molecule: 50 us of a launch that computes almost nothing).  Same values, same operations, same order: bit-identical.
-  __shared__ float s_pos[3 * GEOM_LDS_ATOMS];
   const int g = blockIdx.x;
   const int lo = ptr[g], hi = ptr[g + 1];
   const bool in_lds = hi - lo <= GEOM_LDS_ATOMS;
@@ -219,6 +230,14 @@ __global__ void k_geom(float* __restrict__ y, const int* __restrict__ ptr, float
   };
   if (in_lds) atoms([&](int k) { return s_pos[k - lo * 3]; });
   else atoms([&](int k) { return yc[k]; });
+}
+__global__ void k_geom(float* __restrict__ y, const int* __restrict__ ptr, float c_in, float r2, int S,
+                       const int* __restrict__ bond_in_ptr, const int* __restrict__ bond_in_src, int mean_center,
+                       float* __restrict__ yc, int* __restrict__ deg, int* __restrict__ esrc,
+                       float4* __restrict__ egeo, int* __restrict__ epair, LangevinPre pre) {
+  __shared__ float cen[3];
+  __shared__ float s_pos[3 * GEOM_LDS_ATOMS];
+  geom_body(y, ptr, c_in, r2, S, bond_in_ptr, bond_in_src, mean_center, yc, deg, esrc, egeo, epair, pre, cen, s_pos);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -672,11 +691,10 @@ __device__ __forceinline__ void process_score(const float s[3], const LangevinCo
 
 // Optional BAOAB second half fused behind it:  psi = clip(score) * beta ; v = vhat + (d/2) psi (no u, _splitting.py:166) ; the
 // saved frame (y, score, xhat) — exactly the arithmetic of k_baoab_post.
-__global__ void k_finalize(const float* __restrict__ y, const float* __restrict__ yc, const float* __restrict__ g,
-                           const int* __restrict__ ptr, float c_skip, float c_out, float sigma2, int mean_center,
-                           float* __restrict__ tmp, float* __restrict__ xhat, float* __restrict__ score, LangevinPost post) {
-  __shared__ float cen[3];
-  __shared__ float s_tmp[3 * GEOM_LDS_ATOMS];  // (as k_geom: the centre is a sum in atom order by three threads)
+__device__ __forceinline__ void finalize_body(const float* __restrict__ y, const float* __restrict__ yc, const float* __restrict__ g,
+                                              const int* __restrict__ ptr, float c_skip, float c_out, float sigma2, int mean_center,
+                                              float* __restrict__ tmp, float* __restrict__ xhat, float* __restrict__ score, const LangevinPost& post,
+                                              float* cen, float* s_tmp) {  // (s_tmp [3 GEOM_LDS_ATOMS], as k_geom: the centre is a sum in atom order by three threads)
   const int gi = blockIdx.x;
   const int lo = ptr[gi], hi = ptr[gi + 1];
   const bool in_lds = hi - lo <= GEOM_LDS_ATOMS;
@@ -723,6 +741,27 @@ __global__ void k_finalize(const float* __restrict__ y, const float* __restrict_
   };
   if (in_lds) atoms([&](int k) { return s_tmp[k - lo * 3]; });
   else atoms([&](int k) { return tmp[k]; });
+}
+__global__ void k_finalize(const float* __restrict__ y, const float* __restrict__ yc, const float* __restrict__ g,
+                           const int* __restrict__ ptr, float c_skip, float c_out, float sigma2, int mean_center,
+                           float* __restrict__ tmp, float* __restrict__ xhat, float* __restrict__ score, LangevinPost post) {
+  __shared__ float cen[3];
+  __shared__ float s_tmp[3 * GEOM_LDS_ATOMS];
+  finalize_body(y, yc, g, ptr, c_skip, c_out, sigma2, mean_center, tmp, xhat, score, post, cen, s_tmp);
+}
+// The LAST kernel of walk iteration i and the FIRST of iteration i + 1 in one launch (round 6): both are one workgroup per walker, and
+// everything the geometry of the next iteration reads — v, psi, y of this walker — was written by this workgroup a moment ago (by the same
+// threads: both loops deal the walker's atoms to the threads the same way; the barrier and fence below make that independent of the layout).
+// Same arithmetic in the same order as k_finalize followed by k_geom: bit-identical trajectories, one launch boundary less per step.
+__global__ void k_finalize_geom(const float* __restrict__ yc_in, const float* __restrict__ g, float c_skip, float c_out, float sigma2,
+                                float* __restrict__ tmp, float* __restrict__ xhat, float* __restrict__ score, LangevinPost post, GeomArgs ga,
+                                LangevinPre pre) {
+  __shared__ float cen[3];
+  __shared__ float s_buf[3 * GEOM_LDS_ATOMS];
+  finalize_body(ga.y, yc_in, g, ga.ptr, c_skip, c_out, sigma2, ga.mean_center, tmp, xhat, score, post, cen, s_buf);
+  __threadfence_block();
+  __syncthreads();  // every read of y / yc / cen / s_buf of the finalize half is done; its v and psi are visible to the workgroup
+  geom_body(ga.y, ga.ptr, ga.c_in, ga.r2, ga.S, ga.bond_in_ptr, ga.bond_in_src, ga.mean_center, ga.yc, ga.deg, ga.esrc, ga.egeo, ga.epair, pre, cen, s_buf);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -989,6 +1028,12 @@ void launch_finalize(const float* y, const float* yc, const float* g, const int*
                      const LangevinPost& post, hipStream_t st) {
   hipLaunchKernelGGL(k_finalize, dim3(n_graphs), dim3(128), 0, st, y, yc, g, ptr, c_skip, c_out, sigma2, mean_center,
                      tmp, xhat, score, post);
+}
+void launch_finalize_geom(float* y, float* yc, const float* g, const int* ptr, int n_graphs, float c_skip, float c_out, float sigma2, int mean_center,
+                          float* tmp, float* xhat, float* score, const LangevinPost& post, float c_in, float r2, int S, const int* bip, const int* bis,
+                          int* deg, int* esrc, float4* egeo, int* epair, const LangevinPre& pre, hipStream_t st) {
+  GeomArgs ga{y, ptr, c_in, r2, S, bip, bis, mean_center, yc, deg, esrc, egeo, epair};
+  hipLaunchKernelGGL(k_finalize_geom, dim3(n_graphs), dim3(128), 0, st, yc, g, c_skip, c_out, sigma2, tmp, xhat, score, post, ga, pre);
 }
 void launch_baoab_pre(float* y, float* v, const float* psi, const float* noise, uint64_t seed, uint32_t iter, int n,
                       const LangevinConsts& k, hipStream_t st) {

@@ -29,10 +29,13 @@ def local_device() -> torch.device:
     return torch.device("cpu")
 
 
-def init_process_group(backend: Optional[str] = None) -> Tuple[int, int]:
-    """Initialise from the torchrun environment (RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT).  No-op for 1 rank."""
+def init_process_group(backend: Optional[str] = None, force: bool = False) -> Tuple[int, int]:
+    """Initialise from the torchrun environment (RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT).  No-op for 1 rank unless ``force``
+    (a one-rank group exercises the backend's code path — RCCL on a single GPU — with nobody to talk to)."""
     world = int(os.environ.get("WORLD_SIZE", 1))
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or force) and not dist.is_initialized():
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:

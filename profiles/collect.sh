@@ -10,7 +10,7 @@ cfg=${2:-cfg2}
 extra=${3:-}
 out=gpurun_out/prof_$tag
 mkdir -p "$out"
-BENCH="python3 bench.py --config $cfg $extra --no-cpu-baseline --no-secondary --no-e2e --no-sweep --repeats 1"
+BENCH="python3 bench.py --config $cfg $extra --no-cpu-baseline --no-secondary --no-e2e --no-sweep --no-also --repeats 1"
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- $BENCH --steps 200 --warmup 40 > $out/bench_under_rocprof.log 2>&1
 f=$(find $out/trace -name "*kernel_stats.csv" | head -1)
 [ -n "$f" ] || { echo "no kernel_stats.csv produced; see $out/bench_under_rocprof.log" >&2; exit 1; }
@@ -60,3 +60,7 @@ res["_build"] = json.load(open(f"{out}/signature.json"))  # bench.py quotes thes
 json.dump(res, open(f"{out}/pmc_traffic.json", "w"), indent=1)
 print(json.dumps({k: v for k, v in res.items() if "conv" in k or "node" in k or k == "_build"}, indent=1))
 PY
+# the raw rocprofv3 outputs stay on the box: gpurun merges at most 64 MiB back, and three configs' traces exceed that (round 6: a whole call's results
+# were dropped); the summaries above are what gets committed
+rm -rf "$out/trace" "$out"/pmc_*/
+du -sh "$out" >&2

@@ -179,3 +179,28 @@ def test_bench_line_contract_and_roofline_invariants():
     assert 0.0 < rf["frac_useful"] < rf["frac"] and rf["flop_useful_per_launch"] < rf["flop_executed_per_launch"]
     assert rf["flop_executed_per_launch"] == 136 * 65 * 414 * 32768  # tiles x hidden units x MFMAs per (tile, unit) x FLOP per v_mfma_f32_32x32x16_f16
     assert rf["bytes_algorithmic_per_launch"] > 5e7 and (rf["traffic"] is None or rf["traffic_ratio"] > 1.0)
+    # the shapes the reference actually runs ride in the same line: distinct dipeptides, the 93-heavy-atom chignolin shape, the opt-in f16x1 mode
+    assert set(d["also"]) == {"cfg2r", "cfg5h", "cfg2_f16x1"}
+    for name, leg in d["also"].items():
+        assert leg["value"] > 0 and leg["timed_total_s"] >= 2.0 and leg["avg_launch_ms"] > 0, (name, leg)
+    assert d["also"]["cfg2r"]["dominant_kernel"] == "k_conv_mf" and d["also"]["cfg2r"]["init_path"] == 4 and d["also"]["cfg5h"]["dominant_kernel"] == "k_conv_ml"
+    assert d["also"]["cfg2_f16x1"]["dtype"] == "f16x1" and d["also"]["cfg2_f16x1"]["value"] > d["value"] and d["also"]["cfg2r"]["dtype"] == "f32"
+    assert d["rccl"] == {"backend": None, "world": 1, "ranks_seen": 1}  # (no launcher: no process group)
+
+
+def test_bench_sharded_leg_on_a_one_rank_rccl_group():
+    """`bench.py --sharded-leg` creates a one-rank RCCL group and runs the leg every N > 1 line carries: Sampler.sample(shard_walkers=True) +
+    SaveTrajectoryCallback with the trajectory gather (here: nobody to receive from, the own block through the pinned staging buffer), the
+    all-reduce that proves the ranks, and the keys the 8-GPU line will have."""
+    import subprocess
+    import sys
+
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--sharded-leg", "--steps", "4", "--warmup", "1", "--repeats", "2", "--no-cpu-baseline",
+                        "--no-secondary", "--no-sweep", "--no-also"], env=dict(env, MASTER_ADDR="127.0.0.1", MASTER_PORT="29577"), capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["rccl"]["backend"].startswith("nccl") and d["rccl"]["world"] == 1 and d["rccl"]["ranks_seen"] == 1
+    sh = d["e2e_sharded"]
+    assert sh["walkers_total"] == 256 and sh["steps_per_batch"] == 1000 and sh["num_batches"] == 2 and sh["joined_shape"] == [17, 256 * 2 * 1000, 3]
+    assert sh["gather_bytes"] == 0 and 0 < sh["gather_s"] < sh["wall_s"] and sh["conformations_per_s"] > 1e5

@@ -1325,6 +1325,24 @@ def test_long_walks_are_bit_reproducible(dev, shape):
     assert torch.isfinite(runs[0][0]).all()
     for a, b in zip(runs[0], runs[1]):
         assert torch.equal(a, b)
+    # the last kernel of an iteration and the first of the next as ONE launch (k_finalize_geom, the default) or as two (k_finalize, k_geom):
+    # the same arithmetic in the same order, so every frame, the final state and the host-noise variant agree bit for bit
+    from jamun_amd.native import NativeSampler
+
+    two = NativeSampler(model._native, 0.04, batch, dev, tuning={"no_fuse_geom": 1})
+    y, v = y0.clone(), torch.zeros_like(y0)
+    y_traj, score_traj, xhat_traj, xh = two.walk("baoab", y, v, params, None, seed=77, save_trajectory=True)
+    for a, b in zip(runs[0], (xhat_traj, y_traj, score_traj)):
+        assert torch.equal(a, b)
+    short = native.make_mcmc_params(7, delta=0.04, friction=1.0, M=1.0, inverse_temperature=1.0, score_fn_clip=100.0)
+    noise = torch.randn(6, *y0.shape, device=dev)
+    outs = []
+    for s_ in (smp, two):
+        y, v = y0.clone(), torch.ones_like(y0) * 0.1
+        o = s_.walk("baoab", y, v, short, noise, 0, True)
+        outs.append((o[0].clone(), o[1].clone(), o[2].clone(), o[3].clone(), y.clone(), v.clone()))
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
 
 
 def test_a_twenty_thousand_step_batch_through_the_sampler_is_bit_reproducible(dev):
