@@ -691,7 +691,7 @@ def test_large_span_matrix_formed_conv(dev, case, monkeypatch):
     the half block), spans of two molecules of different sizes, windows starting at odd atoms, every bond listed twice in both directions
     (three edges of one pair share a coefficient entry), a stretched chain whose tiles touch few 16-row source blocks (the block-sparse forming
     skips the others), a batch with 1- and 2-atom walkers between large ones.  Bit-reproducible (host-built segment lists, slabs summed in order;
-    every split primitive a compiler-visible instruction: jamun_mf_dev.h on why inline asm beside MFMAs is not)."""
+    every split primitive a compiler-visible instruction: jamun_split.h on why inline asm in front of MFMAs is not)."""
     from jamun_amd import synth
     from jamun_amd.data import WalkerBatch
     from jamun_amd.model import Denoiser
