@@ -733,7 +733,7 @@ def main():
     rccl = rccl_record(dev, world)
     sharded = None
     grouped = torch.distributed.is_available() and torch.distributed.is_initialized()  # (under a launcher even one rank has a group: the RCCL path runs)
-    if (world > 1 or (grouped and args.sharded_leg)) and not args.no_e2e and args.walkers is None and args.atoms is None:
+    if ((world > 1 and not args.no_e2e) or (grouped and args.sharded_leg)) and args.walkers is None and args.atoms is None:
         y_traj = score_traj = xhat_traj = None  # (free the headline walk's frames)
         # (every rank takes part; 1000 steps per batch: 0.85 s of walking per batch at cfg2, 13 MB per rank and batch to rank 0)
         sharded = e2e_sharded(model, args.config, dev, world, rank, steps=1000, num_batches=2,
