@@ -140,3 +140,38 @@ def test_no_vector_instruction_sits_inside_an_mfma_hazard_window_of_the_shipped_
         if f.endswith((".hip", ".h")) and f != "jamun_split.h":
             txt = open(os.path.join(b.HERE, f)).read()
             assert not re.search(r'asm[^;]*"v_(cvt_pk_f16_f32|fma_mix_f32)', txt), f
+
+
+def test_hazard_scanner_flags_the_round5_pattern_and_accepts_the_compiler_forms(tmp_path):
+    """The tripwire itself: on hand-written ISA the scanner must flag (a) an inline-asm v_cvt_pk_f16_f32 one wait state in front of the MFMA
+    that reads it (the round-5 bug: `s_nop 0` is all hipcc puts behind an asm definition), (b) a vector read of an MFMA's destination inside
+    its latency, (c) a vector write to an in-flight MFMA's SrcC — and accept the same sequences at the distances hipcc keeps for visible
+    instructions, across a branch edge too."""
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("mfma_hazard_scan", os.path.join(ROOT, "profiles", "tools", "mfma_hazard_scan.py"))
+    scan = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(scan)
+
+    def run(body):
+        f = tmp_path / "k.s"
+        f.write_text("_Z1kv:\n" + body + "\n\ts_endpgm\n.Lfunc_end0:\n")
+        (name, (n, n_mfma, n_asm, viol)), = scan.scan(str(f), want_all=True).items()
+        return [(k, ws, need) for k, ws, need, p, c, tag in viol]
+
+    mfma = "\tv_mfma_f32_32x32x16_f16 v[0:15], v[16:19], v[20:23], v[0:15]\n"
+    asm_cvt = "\t;;#ASMSTART\n\tv_cvt_pk_f16_f32 v20, v30, v31\n\t;;#ASMEND\n"
+    assert run(asm_cvt + "\ts_nop 0\n" + mfma) == [("V2M", 1, 2)]                      # the bug as shipped
+    assert run(asm_cvt + "\ts_nop 1\n" + mfma) == []                                  # two wait states: fine
+    assert run("\tv_cvt_pk_f16_f32 v20, v30, v31\n\ts_nop 0\n" + mfma) == [("V2M", 1, 2)]  # a visible instruction that close would be a compiler bug
+    assert run("\tv_cvt_pk_f16_f32 v20, v30, v31\n\ts_waitcnt lgkmcnt(0)\n\ts_nop 0\n" + mfma) == []
+    assert run(mfma + "\ts_nop 7\n\tv_mul_f32_e32 v40, v0, v41\n") == [("RAW", 8, 12)]  # 8-pass MFMA result read after 8 wait states (12 needed)
+    assert run(mfma + "\ts_nop 11\n\tv_mul_f32_e32 v40, v0, v41\n") == []
+    assert ("WAR", 3, 7) in run(mfma + "\ts_nop 2\n\tv_mov_b32_e32 v5, 0\n")          # write to SrcC (= vDst) of an MFMA in flight
+    assert run(mfma + "\tv_mov_b32_e32 v16, 0\n") == []                               # SrcA / SrcB: safe against write-after-read (microbenchmark)
+    # through a back edge: the MFMA at the bottom of a loop, its consumer at the top
+    loop = ".LBB0_1:\n\tv_mul_f32_e32 v40, v0, v41\n\ts_nop 3\n" + mfma + "\ts_cbranch_scc1 .LBB0_1\n"
+    assert ("RAW", 1, 12) in run(loop)
+    # the 4-pass and the fp32-input (non-XDL) opcodes have their own distances
+    assert run("\tv_mfma_f32_16x16x32_f16 v[0:3], v[16:19], v[20:23], v[0:3]\n\ts_nop 6\n\tv_mul_f32_e32 v40, v0, v41\n") == [("RAW", 7, 8)]
+    assert run("\tv_mfma_f32_32x32x2_f32 v[0:15], v16, v20, v[0:15]\n\ts_nop 15\n\ts_nop 1\n\tv_mul_f32_e32 v40, v0, v41\n") == []
