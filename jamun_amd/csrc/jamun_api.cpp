@@ -2105,6 +2105,17 @@ static void sampler_create_impl(const jamun_model* m, float sigma, const jamun_t
         }
         // (a segment's prologue + epilogue in items of its k loop, from the kernels' segment stamps; jamun_tuning.seg_cost_tenths overrides)
         const double seg_cost = tn.seg_cost_tenths < 0 ? 0.0 : tn.seg_cost_tenths > 0 ? 0.1 * tn.seg_cost_tenths : s->dg_mode == 4 ? 3.6 : s->dg_mode == 5 ? 5.8 : 0.0;
+        // (round 6) every segment record carries its tile's descriptor — {k_extra, first destination, destinations | source rows << 8, first source row} —
+        // so that a kernel's first prologue is ONE round trip behind the segment list instead of two (list -> tile tables -> loads)
+        auto embed = [&](std::vector<int4>& segs) {
+          for (size_t i = 0; i + 1 < segs.size(); i += 2) {
+            const int t = segs[i].x;
+            if (t < 0) continue;
+            segs[i + 1].y = t_atoms[t].x;
+            segs[i + 1].z = t_atoms[t].y | ((t_span[t].y - t_span[t].x) << 8);
+            segs[i + 1].w = t_span[t].x;
+          }
+        };
         SegPlan P = plan_segments(cus, ng, n_k, N, t_atoms, t_chunk, n_chunks, weight, s->n_tail_tiles ? &is_tail : nullptr, seg_cost);
         if (s->n_tail_tiles) {
           for (size_t t = 0; t < t_atoms.size(); ++t)
@@ -2114,6 +2125,7 @@ static void sampler_create_impl(const jamun_model* m, float sigma, const jamun_t
           s->init_tail = s->layers[0].wx != nullptr && s->layers[0].p0.nt == 5 && !tn.no_mfi;
           if (!s->init_tail) {  // the initial projector keeps every tile on segment lists of its own
             SegPlan PI = plan_segments(cus, ng, n_k, N, t_atoms, t_chunk, n_chunks, weight, nullptr, seg_cost);
+            embed(PI.segs);
             s->init_segs = dev_upload(PI.segs);
             s->init_atom_nslab = dev_upload(PI.atom_nslab);
             s->init_max_segs = PI.max_segs;
@@ -2122,6 +2134,7 @@ static void sampler_create_impl(const jamun_model* m, float sigma, const jamun_t
         }
         s->dg_grid = cus;
         s->dg_max_segs = P.max_segs;
+        embed(P.segs);
         s->dg_segs = dev_upload(P.segs);
         s->dg_n_slabs = P.n_slabs;
         s->dg_atom_nslab = dev_upload(P.atom_nslab);

@@ -97,8 +97,8 @@ __global__ __launch_bounds__(MF_THREADS) void k_conv_mf(MfArgs a) {
   // global round trips off the critical path of every segment but the first)
   const int4* __restrict__ my_segs = a.segs + (size_t)blockIdx.x * a.max_segs * 2;
   int4 sg0 = ld_const(my_segs), sg1 = ld_const(my_segs + 1);
-  int2 t_at = make_int2(0, 0), span = make_int2(0, 0);
-  if (RFL(sg0.x) >= 0) { t_at = ld_const(a.tile_atoms + RFL(sg0.x)); span = ld_const(a.tile_span + RFL(sg0.x)); }
+  // (the record carries its tile's descriptor, jamun_api.cpp: embed — no second, dependent trip to the tile tables)
+  int2 t_at = make_int2(sg1.y, sg1.z & 255), span = make_int2(sg1.w, sg1.w + (sg1.z >> 8));
   for (int sgi = 0; sgi < a.max_segs; ++sgi) {
     const int tile = RFL(sg0.x);
     if (tile < 0) break;
@@ -718,7 +718,7 @@ __global__ __launch_bounds__(MF_THREADS) void k_conv_mf(MfArgs a) {
     }
     // ---- all threads: sum of the five K-partial tiles -> partial slab of this segment, coalesced 16-byte stores
     sg0 = nsg0; sg1 = nsg1;
-    if (RFL(sg0.x) >= 0) { t_at = ld_const(a.tile_atoms + RFL(sg0.x)); span = ld_const(a.tile_span + RFL(sg0.x)); }
+    t_at = make_int2(sg1.y, sg1.z & 255); span = make_int2(sg1.w, sg1.w + (sg1.z >> 8));
     // (the inverse column scales of this thread's slab pieces: requested in FRONT of the barrier — as loads at their points of use they were a
     // global round trip of ~2 k cycles inside every segment's epilogue, round 6)
     constexpr int NE0 = (32 * 40 + MF_THREADS - 1) / MF_THREADS, NE1 = (32 * 24 + MF_THREADS - 1) / MF_THREADS;
@@ -799,9 +799,9 @@ __global__ __launch_bounds__(MF_THREADS) void k_conv_mfi(MfiArgs a) {
     const int slab = RFL(sg0.y), k_begin = RFL(sg0.z), k_run = RFL(sg0.w) - k_begin, k_extra = RFL(sg1.x);
     const int nk = k_run + (k_extra >= 0 ? 1 : 0);
     auto k_of = [&](int kk) { kk = kk < 0 ? 0 : (kk < nk ? kk : nk - 1); return kk < k_run ? k_begin + kk : k_extra; };
-    const int2 t_at = a.tile_atoms[tile];
+    const int2 t_at = make_int2(sg1.y, sg1.z & 255);  // (the record carries its tile's descriptor, jamun_api.cpp: embed — one dependent round trip less per segment)
     const int n0 = RFL(t_at.x), n_dst = RFL(t_at.y);
-    const int2 span = a.tile_span[tile];
+    const int2 span = make_int2(sg1.w, sg1.w + (sg1.z >> 8));
     const int s_lo = RFL(span.x), rows = RFL(span.y) - s_lo;
     const int s_base = s_lo;
 
@@ -1009,9 +1009,9 @@ __global__ __launch_bounds__(MF_THREADS) void k_conv_mfx(MfxArgs a) {
     const int slab = RFL(sg0.y), k_begin = RFL(sg0.z), k_run = RFL(sg0.w) - k_begin, k_extra = RFL(sg1.x);
     const int nk = k_run + (k_extra >= 0 ? 1 : 0);
     auto k_of = [&](int kk) { kk = kk < 0 ? 0 : (kk < nk ? kk : nk - 1); return kk < k_run ? k_begin + kk : k_extra; };
-    const int2 t_at = a.tile_atoms[tile];
+    const int2 t_at = make_int2(sg1.y, sg1.z & 255);  // (as k_conv_mfi: descriptor inside the segment record)
     const int n0 = RFL(t_at.x), n_dst = RFL(t_at.y);
-    const int2 span = a.tile_span[tile];
+    const int2 span = make_int2(sg1.w, sg1.w + (sg1.z >> 8));
     const int s_base = RFL(span.x) & ~1;  // window of 64 source rows from an even atom (the rows are stored in pairs)
 
     // ---- loads first: in-degrees, h~ of the first hidden unit, the edge records of all passes (as k_conv_mfi)

@@ -102,7 +102,7 @@ __global__ __launch_bounds__(ML_THREADS) void k_conv_ml(MlArgs a) {
     const int slab = RFL(sg0.y), k_begin = RFL(sg0.z), k_run = RFL(sg0.w) - k_begin, k_extra = RFL(sg1.x);
     const int nk = k_run + (k_extra >= 0 ? 1 : 0);
     auto k_of = [&](int kk) __attribute__((always_inline)) { kk = kk < 0 ? 0 : (kk < nk ? kk : nk - 1); return kk < k_run ? k_begin + kk : k_extra; };
-    const int2 t_at = ld_const(a.tile_atoms + tile), span = ld_const(a.tile_span + tile);
+    const int2 t_at = make_int2(sg1.y, sg1.z & 255), span = make_int2(sg1.w, sg1.w + (sg1.z >> 8));  // (descriptor inside the segment record, jamun_api.cpp: embed)
     const int n0 = RFL(t_at.x), n_dst = RFL(t_at.y);
     const int s_lo = RFL(span.x), rows = RFL(span.y) - s_lo;
     const int s_base = s_lo & ~1, off = s_lo - s_base;  // window from an even atom (8-byte T loads, row pairs)
@@ -816,7 +816,7 @@ __global__ __launch_bounds__(ML_THREADS) void k_conv_mlx(MlxArgs a) {
     const int slab = RFL(sg0.y), k_begin = RFL(sg0.z), k_run = RFL(sg0.w) - k_begin, k_extra = RFL(sg1.x);
     const int nk = k_run + (k_extra >= 0 ? 1 : 0);
     auto k_of = [&](int kk) __attribute__((always_inline)) { kk = kk < 0 ? 0 : (kk < nk ? kk : nk - 1); return kk < k_run ? k_begin + kk : k_extra; };
-    const int2 t_at = ld_const(a.tile_atoms + tile), span = ld_const(a.tile_span + tile);
+    const int2 t_at = make_int2(sg1.y, sg1.z & 255), span = make_int2(sg1.w, sg1.w + (sg1.z >> 8));  // (descriptor inside the segment record, jamun_api.cpp: embed)
     const int n0 = RFL(t_at.x), n_dst = RFL(t_at.y);
     const int s_base = RFL(span.x) & ~1;  // window from an even atom (the rows are stored in pairs)
     const int r = lane & 31, hh = lane >> 5;
