@@ -112,6 +112,8 @@ typedef struct jamun_tuning {
   int32_t selfcheck;    /* create-time self-check of the selected kernels against the general ones (one forward on synthetic positions through both;
                            node features after every block within 2e-5, else jamun_sampler_create returns JAMUN_ERR_INVALID): 0 / 1 on (default),
                            -1 off, 2 on with an injected fault in the selected conv kernel's weight stream (tests: the check must fire)   */
+  int32_t no_tprod_t;   /* T pre-pass of k_conv_mf / k_conv_ml with k_tprod_h instead of k_tprod_t (round 6: weights through LDS, rows fetched whole,
+                           transposed T stored as whole lines; bit-identical T); A/B aid                                                   */
 } jamun_tuning;
 
 typedef struct jamun_model jamun_model;     /* raw checkpoint tensors kept on the host          */

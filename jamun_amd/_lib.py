@@ -54,7 +54,7 @@ class jamun_topology(C.Structure):
 
 class jamun_tuning(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("no_dg", "no_mf", "dg_fp32", "dg_no_alt", "dg_no_sp", "dg_no_sph", "no_mfi", "no_init_v", "node_fp32",
-                                         "edge_h_fp32", "dg_kgroups", "no_tail", "no_short_k", "no_ml", "seg_cost_tenths", "f16x1", "no_fuse_geom", "selfcheck")]
+                                         "edge_h_fp32", "dg_kgroups", "no_tail", "no_short_k", "no_ml", "seg_cost_tenths", "f16x1", "no_fuse_geom", "selfcheck", "no_tprod_t")]
 
 
 class jamun_mcmc_params(C.Structure):

@@ -1389,7 +1389,7 @@ void run_layer(jamun_sampler* s, size_t l, const float* x_in, int XSin, float* x
       f.partial0 = s->partial0; f.partial1 = s->partial1; f.err = s->mf_err; f.x1 = s->x1;
       {
         ProfScope pt(s, JAMUN_PROF_TPROD, st);
-        launch_tprod(x_in, XSin, s->n_atoms, s->hp.edge_attr_dim + 1, L.dg.wt, L.dg.wth, L.dg.gT, L.dg.cfT, s->dg_T, s->dg_tstride, st);
+        launch_tprod(x_in, XSin, s->n_atoms, s->hp.edge_attr_dim + 1, L.dg.wt, L.dg.wth, L.dg.gT, L.dg.cfT, s->dg_T, s->dg_tstride, st, s->tune.no_tprod_t != 0);
       }
       {
         ProfScope ps(s, JAMUN_PROF_CONV0, st);
@@ -1422,7 +1422,7 @@ void run_layer(jamun_sampler* s, size_t l, const float* x_in, int XSin, float* x
       f.partial0 = s->partial0; f.partial1 = s->partial1; f.err = s->mf_err; f.mfma_count = s->ml_count; f.x1 = s->x1;
       {
         ProfScope pt(s, JAMUN_PROF_TPROD, st);
-        launch_tprod(x_in, XSin, s->n_atoms, s->hp.edge_attr_dim + 1, L.dg.wt, L.dg.wth, L.dg.gT, L.dg.cfT, s->dg_T, s->dg_tstride, st);
+        launch_tprod(x_in, XSin, s->n_atoms, s->hp.edge_attr_dim + 1, L.dg.wt, L.dg.wth, L.dg.gT, L.dg.cfT, s->dg_T, s->dg_tstride, st, s->tune.no_tprod_t != 0);
       }
       {
         ProfScope ps(s, JAMUN_PROF_CONV0, st);
@@ -2090,7 +2090,13 @@ static void sampler_create_impl(const jamun_model* m, float sigma, const jamun_t
             }
           const size_t p_bytes = (size_t)((tatom.size() + 31) / 32) * 32 * (size_t)n_k * TAIL_NFT * 8 * 16;
           if (tt.size() >= 4 && 100 * tt.size() >= 3 * t_atoms.size() && tt.size() < t_atoms.size() && p_bytes <= ((size_t)2 << 30)) {
-            for (auto& e : tt) is_tail[e.x] = 1;
+            for (auto& e : tt) {
+              is_tail[e.x] = 1;
+              // (the record carries its tile's descriptor — {first tail destination, first atom, atoms | source rows << 8, first source row} —
+              // so that the tail kernels do not start with a second, dependent trip to the tile tables; as the segment records of k_conv_mf)
+              const int t = e.x;
+              e = make_int4(e.y, t_atoms[t].x, t_atoms[t].y | ((t_span[t].y - t_span[t].x) << 8), t_span[t].x);
+            }
             s->n_tail_tiles = (int)tt.size();
             s->n_tail = (int)tatom.size();
             const int n_ct = (s->n_tail + 31) / 32;
@@ -2726,6 +2732,7 @@ int jamun_debug_stamps(unsigned long long* out8) {
     conv_initv_print_stamps();
     conv_mf_print_stamps();
     conv_ml_print_stamps();
+    node_print_stamps();
     for (int i = 0; i < 8; ++i) out8[i] = 0;
   });
 }

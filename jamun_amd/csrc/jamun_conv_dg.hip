@@ -37,6 +37,7 @@
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <stdint.h>
+#include <type_traits>
 #include <stdio.h>
 
 #include "jamun_internal.h"
@@ -1353,7 +1354,34 @@ __global__ __launch_bounds__(DG_THREADS) void k_conv_dg(DgArgs a) {
 #endif
 }
 
+#ifdef TP_TRACE
+__device__ unsigned long long g_tptrace[1024][16];
+#endif
 void conv_dg_print_stamps() {
+#ifdef TP_TRACE
+  {
+    static unsigned long long tp[1024][16];
+    if (hipMemcpyFromSymbol(tp, HIP_SYMBOL(g_tptrace), sizeof(tp)) == hipSuccess) {
+      unsigned long long rt0 = ~0ull, rt1 = 0;
+      int nw = 0;
+      for (int g = 0; g < 1024; ++g)
+        if (tp[g][0]) { rt0 = std::min(rt0, tp[g][0]); rt1 = std::max(rt1, tp[g][14]); ++nw; }
+      fprintf(stderr, "tprod trace: %d waves; first entry -> last exit %llu ticks of s_memrealtime (100 MHz)\n", nw, rt1 - rt0);
+      fprintf(stderr, "  wave: entry (rt ticks after first) | cycles after entry: rows arrived, split done, units..., exit | exit (rt ticks after first entry)\n");
+      for (int g = 0; g < 1024; ++g) {
+        if (!tp[g][0] || !(g % 37 == 0 || g >= 945)) continue;
+        fprintf(stderr, "  %4d: %4llu |", g, tp[g][0] - rt0);
+        fprintf(stderr, " %6lld %6lld |", (long long)(tp[g][15] - tp[g][1]), (long long)(tp[g][2] - tp[g][1]));
+        for (int i = 3; i < 13; ++i) fprintf(stderr, " %6lld", tp[g][i] ? (long long)(tp[g][i] - tp[g][1]) : 0ll);
+        fprintf(stderr, " | %6lld | %4llu\n", (long long)(tp[g][13] - tp[g][1]), tp[g][14] - rt0);
+      }
+      // distribution of entry and exit times
+      unsigned long long emax = 0, xmin = ~0ull; double esum = 0, xsum = 0, dsum = 0;
+      for (int g = 0; g < 1024; ++g) if (tp[g][0]) { emax = std::max(emax, tp[g][0] - rt0); xmin = std::min(xmin, tp[g][14] - rt0); esum += tp[g][0] - rt0; xsum += tp[g][14] - rt0; dsum += tp[g][13] - tp[g][1]; }
+      fprintf(stderr, "  entry: mean %.1f max %llu ticks; exit: min %llu mean %.1f ticks; mean cycles per wave %.0f\n", esum / nw, emax, xmin, xsum / nw, dsum / nw);
+    }
+  }
+#endif
 #ifdef JAMUN_STAMP
   unsigned long long v[2][8], z[2][8] = {};
   if (hipMemcpyFromSymbol(v, HIP_SYMBOL(g_dgstamp), sizeof(v)) != hipSuccess) return;
@@ -1445,6 +1473,15 @@ __global__ __launch_bounds__(64 * TP_WAVES) __attribute__((amdgpu_waves_per_eu(2
 // v_mfma_f32_32x32x16_f16 (lane (atom, hh): inputs 16 g + 8 hh + j); per hidden unit the 16 weight blocks (8 groups x hi, lo; split
 // on the host after scaling by 2^sBt) stream through a double buffer and 24 MFMAs of 32 cycles replace 60 of 64.  The kernel turns
 // from MFMA-bound to bound by its weight stream (16 KB per wave and hidden unit from L2).
+#ifdef TP_TRACE
+#define TSTAMP(slot) do { if (gid < 1024) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); if (lane == 0) g_tptrace[gid][slot] = t_; } } while (0)
+#define TSTAMP_RT(slot) do { if (gid < 1024) { unsigned long long t_; asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); if (lane == 0) g_tptrace[gid][slot] = t_; } } while (0)
+#define TSTAMP_V(slot, v) do { if (gid < 1024) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_), "+v"(v) :: "memory"); if (lane == 0) g_tptrace[gid][slot] = t_; } } while (0)
+#else
+#define TSTAMP(slot) do { } while (0)
+#define TSTAMP_RT(slot) do { } while (0)
+#define TSTAMP_V(slot, v) do { } while (0)
+#endif
 __global__ __launch_bounds__(64 * TP_WAVES) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_tprod_h(
     const float* __restrict__ x, int XS, int n_atoms, int n_k, int kg, const float4* __restrict__ wth, const float* __restrict__ gT, const float* __restrict__ cfT,
     float* __restrict__ T, int t_stride) {
@@ -1457,6 +1494,8 @@ __global__ __launch_bounds__(64 * TP_WAVES) __attribute__((amdgpu_waves_per_eu(2
   const int k_lo = RFL((g * n_k) / kg), k_hi = RFL(((g + 1) * n_k) / kg);
   if (k_lo >= k_hi) return;
   const int row = min(a0 + r, n_atoms - 1);
+  TSTAMP_RT(0);
+  TSTAMP(1);
   float4 xh[8], xl[8], w0[16], w1[16];
   float isc;
   auto load_w = [&](float4 (&wv)[16], int k) {
@@ -1481,6 +1520,7 @@ __global__ __launch_bounds__(64 * TP_WAVES) __attribute__((amdgpu_waves_per_eu(2
         mx = fmaxf(mx, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
       }
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));  // both input halves of the atom
+    TSTAMP_V(15, mx);
     if (t_stride > 0) {  // transposed output: one scale for the wave's 32 atoms (a register of the accumulator then holds four ATOMS)
 #pragma unroll
       for (int o = 16; o >= 1; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
@@ -1504,6 +1544,7 @@ __global__ __launch_bounds__(64 * TP_WAVES) __attribute__((amdgpu_waves_per_eu(2
       xl[q] = make_float4(__uint_as_float(pl[0]), __uint_as_float(pl[1]), __uint_as_float(pl[2]), __uint_as_float(pl[3]));
     }
   }
+  { float v_ = xl[7].w; TSTAMP_V(2, v_); xl[7].w = v_; }
   __shared__ float tp_tile[TP_WAVES][32 * TP_LD];
   float* __restrict__ tt = tp_tile[wave];
   // (inverse column scales of the weights: transposed output — lane = output channel r: one factor; else register 4 g4 + i = channel 8 g4 + 4 hh + i)
@@ -1558,20 +1599,220 @@ __global__ __launch_bounds__(64 * TP_WAVES) __attribute__((amdgpu_waves_per_eu(2
   for (int k = k_lo; k < k_hi; k += 2) {
     load_w(w1, k + 1);
     step(w0, k);
+    if (k - k_lo < 10) TSTAMP(3 + k - k_lo);
     if (k + 1 < k_hi) {
       load_w(w0, k + 2);
       step(w1, k + 1);
+      if (k + 1 - k_lo < 10) TSTAMP(3 + k + 1 - k_lo);
     }
   }
+  TSTAMP(13);
+  TSTAMP_RT(14);
+}
+
+// k_tprod_t — the transposed pre-pass ([k][w'][atom], what k_conv_mf / k_conv_ml stage) as a kernel of its own (round 6).
+// Per-wave timeline of k_tprod_h on cfg2 (-DTP_TRACE, profiles/r6_cfg2_tprod_node_trace.txt): ~3.4 us until the feature rows have arrived
+// (every lane fetches ITS row in sixteen 16-byte pieces: 32 cache lines per load instruction, seven k-groups fetch every tile), 0.45 us of
+// split, then 9-10 hidden units of ~1750 cycles each around a chain of 24 MFMAs (768 cycles).  What holds a unit is the CU's vector-memory
+// path: four waves x (16 KB of weight blocks + 4 KB of stores) per unit is ~47 B/clk of its 64 — a first rewrite with two tiles per wave
+// and the stores between the MFMAs (24 KB per wave and unit) ran at the same rate per byte.  Here the weights go through LDS:
+//   * a workgroup = 4 waves x 64 atoms walking the SAME run of hidden units; a unit's 16 weight blocks are fetched ONCE per workgroup (each
+//     wave a quarter, a unit ahead, through registers into the other half of a 2 x 16 KB LDS buffer; one barrier per unit) and read from
+//     LDS as A fragments, each read feeding six MFMAs (two 32-atom tiles x f16x3);
+//   * the rows are fetched whole (a load instruction = two rows of 512 bytes), scaled by the tile's power of two, split once, transposed
+//     through LDS ([plane][2 q + hh][atom] x 16 bytes, blocks 528 bytes apart: the 8-byte writes of a row and the 16-byte reads of a
+//     fragment are conflict-free) and then HELD IN REGISTERS as B fragments (128 of them);
+//   * the weights are the A operand, so a lane of the accumulator is an ATOM and a register a channel: a row of T is 32 consecutive lanes —
+//     two whole 128-byte lines per dword store, no staging tile; the stores of a finished unit (32 products with the column factors, 32
+//     dword stores) are placed between the MFMAs of the next one, two sets of accumulators taking turns.
+// Per CU and unit: 16 KB of loads + 32 KB of stores (was 64 + 16) against 48 x 4 MFMAs.
+// Same products in the same order as k_tprod_h's transposed branch (operand roles swapped: each output element sums the same K sequence);
+// all scale factors are powers of two: T is bit-identical.
+#define TT_WAVES 4
+#define TT_BLK 528                      // bytes of a fragment block: 32 lanes x 16 + 16
+#define TT_PLANE (16 * TT_BLK)          // hi -> lo
+#define TT_TILE (2 * TT_PLANE)          // 32 atoms: a wave's staging area
+#define TT_WBUF (16 * 1024)             // a unit's weight blocks
+#define TT_LDS_BYTES (TT_WAVES * TT_TILE + 2 * TT_WBUF)
+__global__ __launch_bounds__(64 * TT_WAVES) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_tprod_t(
+    const float* __restrict__ x, int XS, int n_atoms, int n_k, int kg, const float4* __restrict__ wth, const float* __restrict__ gT, const float* __restrict__ cfT,
+    float* __restrict__ T, int t_stride) {
+  extern __shared__ float4 tt_lds4[];
+  const int lane = threadIdx.x & 63, wave = RFL(threadIdx.x >> 6);
+  const int r = lane & 31, hh = lane >> 5;
+  const int rowg = RFL((int)blockIdx.x / kg), g = RFL((int)blockIdx.x - rowg * kg);
+  const int a0 = (rowg * TT_WAVES + wave) * 64;
+  const bool active = a0 < n_atoms;  // wave-uniform; a wave without atoms still fetches its share of the weights and joins the barriers
+  const int k_lo = RFL((g * n_k) / kg), k_hi = RFL(((g + 1) * n_k) / kg);
+  if (k_lo >= k_hi) return;  // (workgroup-uniform)
+  char* __restrict__ xs = reinterpret_cast<char*>(tt_lds4) + wave * TT_TILE;
+  char* __restrict__ wl = reinterpret_cast<char*>(tt_lds4) + TT_WAVES * TT_TILE;  // [2][16 blocks][64 lanes] x 16 bytes
+#ifdef TP_TRACE
+  const int gid = blockIdx.x * TT_WAVES + wave;
+#endif
+  TSTAMP_RT(0);
+  TSTAMP(1);
+  // this wave's quarter of a unit's weight blocks: 4 wave .. 4 wave + 3
+  struct Quarter { float4 b0, b1, b2, b3; };
+  auto load_w = [&](int k) {
+    const float4* __restrict__ wk = wth + ((size_t)min(k, n_k - 1) * 16 + 4 * wave) * 64 + lane;
+    return Quarter{wk[0], wk[64], wk[128], wk[192]};
+  };
+  auto put_w = [&](int buf, const Quarter& w) {
+    char* __restrict__ d = wl + buf * TT_WBUF + 4 * wave * 1024 + 16 * lane;
+    *reinterpret_cast<float4*>(d) = w.b0;
+    *reinterpret_cast<float4*>(d + 1024) = w.b1;
+    *reinterpret_cast<float4*>(d + 2048) = w.b2;
+    *reinterpret_cast<float4*>(d + 3072) = w.b3;
+  };
+  const Quarter wfirst = load_w(k_lo);  // (requested with the rows)
+  // column factors of this lane's sixteen accumulator registers (register 4 g4 + i <-> channel 8 g4 + 4 hh + i)
+  float cf[16];
+#pragma unroll
+  for (int g4 = 0; g4 < 4; ++g4) {
+    const float4 c = *reinterpret_cast<const float4*>(cfT + 8 * g4 + 4 * hh);
+    cf[4 * g4] = c.x; cf[4 * g4 + 1] = c.y; cf[4 * g4 + 2] = c.z; cf[4 * g4 + 3] = c.w;
+  }
+  float isc[2] = {0.f, 0.f};
+  float4 xh[2][8], xl[2][8];  // B fragments of the two tiles: lane (atom r, hh), halves <-> inputs 16 q + 8 hh + j
+  if (active) {
+    // rows: load instruction n of tile t = rows 2n, 2n + 1 (lanes 0..31 / 32..63), inputs 4 r .. 4 r + 3 (120..127: beyond the scalar block -> zeros)
+    // 2^e_u of the input channels (the host took it out of their weight rows); zero for the lanes beyond the scalar block (a select on the
+    // loaded value instead would be compiled into a branch around the load: sixteen serialised round trips)
+    float4 gv = *reinterpret_cast<const float4*>(gT + min(4 * r, 116));
+    const float km = 4 * r < 120 ? 1.f : 0.f;
+    gv = make_float4(gv.x * km, gv.y * km, gv.z * km, gv.w * km);
+    const int wofs = (r >> 1) * TT_BLK + 8 * (r & 1);  // block 2 q + hh of this lane's inputs (q = r / 4, hh = (r / 2) & 1), first or second half of its 16 bytes
+    const float m1 = opaque_minus_one();
+    float4 xa[2][16];  // (all 32 requests of the wave's 64 rows in flight together)
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int n = 0; n < 16; ++n) {
+        // (rows past the last atom repeat it: the tile's maximum is unchanged; their columns of T land in the slack of the rows, as k_tprod_h's)
+        const int row = min(a0 + 32 * t + 2 * n + hh, n_atoms - 1);
+        xa[t][n] = *reinterpret_cast<const float4*>(x + (size_t)row * XS + min(4 * r, 116));
+      }
+    __builtin_amdgcn_sched_barrier(0);  // (left alone, the scheduler sinks the second tile's requests behind the first tile's split: a second round trip)
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      float4 xf[16];
+      float mx = 0.f;
+#pragma unroll
+      for (int n = 0; n < 16; ++n) {
+        float4 v = xa[t][n];
+        v = make_float4(v.x * gv.x, v.y * gv.y, v.z * gv.z, v.w * gv.w);
+        xf[n] = v;
+        mx = fmaxf(mx, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
+      }
+#pragma unroll
+      for (int o = 32; o >= 1; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));  // one scale for the tile's 32 atoms
+      if (t == 0) TSTAMP_V(15, mx);
+      int sA = 0;
+      if (mx > 0.f) sA = 14 - ((int)((__float_as_uint(mx) >> 23) & 0xffu) - 126);
+      sA = max(-60, min(60, sA));
+      const float sc = pow2f(sA);
+      isc[t] = pow2f(-sA);
+#pragma unroll
+      for (int n = 0; n < 16; ++n) {
+        const float e0 = xf[n].x * sc, e1 = xf[n].y * sc, e2 = xf[n].z * sc, e3 = xf[n].w * sc;
+        const unsigned p0 = cvt_pk_f16_c(e0, e1), p1 = cvt_pk_f16_c(e2, e3);
+        const unsigned q0 = cvt_pk_f16_c(resid_lo_c(e0, p0, m1), resid_hi_c(e1, p0, m1)), q1 = cvt_pk_f16_c(resid_lo_c(e2, p1, m1), resid_hi_c(e3, p1, m1));
+        *reinterpret_cast<uint2*>(xs + wofs + 16 * (2 * n + hh)) = make_uint2(p0, p1);
+        *reinterpret_cast<uint2*>(xs + wofs + TT_PLANE + 16 * (2 * n + hh)) = make_uint2(q0, q1);
+      }
+      // (the staging area is this wave's own: its LDS writes and reads are ordered by the counters, no barrier)
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        xh[t][q] = *reinterpret_cast<const float4*>(xs + (2 * q + hh) * TT_BLK + 16 * r);
+        xl[t][q] = *reinterpret_cast<const float4*>(xs + TT_PLANE + (2 * q + hh) * TT_BLK + 16 * r);
+      }
+    }
+  }
+  // (consumed here once: first used inside the loop, the compiler's wait for these loads would sit at the loop's top and drain the
+  // requests and stores in flight there in EVERY iteration — vmcnt counts in order)
+#pragma unroll
+  for (int i_ = 0; i_ < 16; ++i_) asm volatile("" : "+v"(cf[i_]));
+  put_w(0, wfirst);
+  TSTAMP(2);
+  const unsigned lofs = (unsigned)(4 * hh * t_stride + a0 + r);  // T[(32 k + 8 g4 + 4 hh + i) t_stride + atom]: a wave-uniform row base + this lane's 32-bit offset
+  const char* __restrict__ wr = wl + 16 * lane;
+  auto store2 = [&](const f32x16& p0, const f32x16& p1, int kp, int i_) {  // register i_ of a finished unit's two tiles
+    float* __restrict__ tp_ = T + ((size_t)kp * 32 + 8 * (i_ >> 2) + (i_ & 3)) * t_stride;
+    tp_[lofs] = (p0[i_] * isc[0]) * cf[i_];
+    (tp_ + 32)[lofs] = (p1[i_] * isc[1]) * cf[i_];
+  };
+  // one unit: barrier (its weights are in buffer `buf`, the other buffer is free), request the next unit's quarter, 8 x (one pair of A
+  // fragments -> six MFMAs; two registers of the unit before stored), write the quarter into the other buffer
+  auto unit = [&](f32x16& c0, f32x16& c1, const f32x16& p0, const f32x16& p1, auto have_pend, int k, int buf) {
+    __syncthreads();
+    const Quarter wn = load_w(k + 1);
+    if (active) {
+      const char* __restrict__ wb = wr + buf * TT_WBUF;
+      float4 a0f = *reinterpret_cast<const float4*>(wb), a1f = *reinterpret_cast<const float4*>(wb + 1024);
+#pragma unroll
+      for (int q_ = 0; q_ < 16; ++q_) { c0[q_] = 0.f; c1[q_] = 0.f; }
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        float4 n0f = a0f, n1f = a1f;
+        if (q + 1 < 8) {
+          n0f = *reinterpret_cast<const float4*>(wb + (2 * q + 2) * 1024);
+          n1f = *reinterpret_cast<const float4*>(wb + (2 * q + 3) * 1024);
+        }
+        c0 = MFMA32H(a1f, xh[0][q], c0);
+        c1 = MFMA32H(a1f, xh[1][q], c1);
+        c0 = MFMA32H(a0f, xl[0][q], c0);
+        c1 = MFMA32H(a0f, xl[1][q], c1);
+        c0 = MFMA32H(a0f, xh[0][q], c0);
+        c1 = MFMA32H(a0f, xh[1][q], c1);
+        if constexpr (decltype(have_pend)::value) {
+          store2(p0, p1, k - 1, 2 * q);
+          store2(p0, p1, k - 1, 2 * q + 1);
+        }
+        a0f = n0f; a1f = n1f;
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    put_w(buf ^ 1, wn);
+  };
+  f32x16 A0, A1, B0, B1;
+  int k = k_lo;
+  unit(A0, A1, B0, B1, std::false_type{}, k, 0);
+  if (k_lo == k_hi - 1) TSTAMP(3);
+  for (++k; k + 1 < k_hi; k += 2) {
+    unit(B0, B1, A0, A1, std::true_type{}, k, 1);
+    if (k - k_lo < 10) TSTAMP(3 + k - k_lo);
+    unit(A0, A1, B0, B1, std::true_type{}, k + 1, 0);
+    if (k + 1 - k_lo < 10) TSTAMP(3 + k + 1 - k_lo);
+  }
+  if (k < k_hi) {
+    unit(B0, B1, A0, A1, std::true_type{}, k, 1);
+    if (active) {
+#pragma unroll
+      for (int i_ = 0; i_ < 16; ++i_) store2(B0, B1, k, i_);
+    }
+  } else if (active) {
+#pragma unroll
+    for (int i_ = 0; i_ < 16; ++i_) store2(A0, A1, k - 1, i_);
+  }
+  TSTAMP(13);
+  TSTAMP_RT(14);
 }
 
 void launch_tprod(const float* x, int XS, int n_atoms, int n_k, const float4* wt, const float4* wth, const float* gT, const float* cfT, float* T, int t_stride,
-                  hipStream_t st) {
+                  hipStream_t st, bool no_tprod_t) {
   const int tiles = (n_atoms + 31) / 32;
   // waves = tiles x kg runs of hidden units.  One wave per SIMD (1024 waves) is best while a wave's run stays below ~10 hidden units
   // (136 tiles: 18.0 us against 20.0 with 2048 waves); a wave walks its units one after the other behind a one-unit weight prefetch, so
   // with more tiles the runs are cut to ~9 units again, up to two waves per SIMD — the register budget of the kernel (33 x 256 atoms,
   // 264 tiles: 36.7 -> 29.7 us; 296 tiles: 29.8 -> 27.4)
+  if (wth && t_stride > 0 && !no_tprod_t) {  // k_tprod_t: workgroups of 4 waves x 64 atoms, one per CU; the shortest runs of hidden units that fit
+    const int rows = (n_atoms + 64 * TT_WAVES - 1) / (64 * TT_WAVES);
+    const int kg_max = std::min(n_k, std::max(1, 256 / rows));
+    const int units = (n_k + kg_max - 1) / kg_max, kg_t = (n_k + units - 1) / units;
+    hipLaunchKernelGGL(k_tprod_t, dim3(rows * kg_t), dim3(64 * TT_WAVES), TT_LDS_BYTES, st, x, XS, n_atoms, n_k, kg_t, wth, gT, cfT, T, t_stride);
+    return;
+  }
   const int kg = std::min(n_k, std::max(1, std::min(std::max(1024 / tiles, 7), 2048 / tiles)));
   if (wth)
     hipLaunchKernelGGL(k_tprod_h, dim3((tiles * kg + TP_WAVES - 1) / TP_WAVES), dim3(64 * TP_WAVES), 0, st, x, XS, n_atoms, n_k, kg, wth, gT, cfT, T, t_stride);
@@ -1604,5 +1845,6 @@ int conv_dg_set_max_lds() {
                         (const void*)k_conv_dg<0, true>,  (const void*)k_conv_dg<1, true>,  (const void*)k_conv_dg<2, true>,  (const void*)k_conv_dg<3, true>};
   for (const void* f : fns)
     if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, JAMUN_MAX_DYN_LDS) != hipSuccess) return -1;
+  if (hipFuncSetAttribute((const void*)k_tprod_t, hipFuncAttributeMaxDynamicSharedMemorySize, TT_LDS_BYTES) != hipSuccess) return -1;
   return 0;
 }

@@ -1267,11 +1267,9 @@ __global__ __launch_bounds__(MF_THREADS) void k_tail_form(TailArgs a) {
   int* __restrict__ deg_lds = reinterpret_cast<int*>(lds + MF_MISC);
   unsigned* __restrict__ xmax_lds = reinterpret_cast<unsigned*>(lds + MF_MISC + 128);
   const int tid = threadIdx.x, lane = tid & 63, wave = RFL(tid >> 6);
-  const int4 tt = a.tail_tiles[blockIdx.x];  // {tile index, first tail-destination index, 0, 0}
-  const int tile = RFL(tt.x), td0 = RFL(tt.y);
-  const int2 t_at = a.tile_atoms[tile], span = a.tile_span[tile];
-  const int n0 = RFL(t_at.x), n_dst = RFL(t_at.y);
-  const int s_lo = RFL(span.x), rows = RFL(span.y) - s_lo;
+  const int4 tt = a.tail_tiles[blockIdx.x];  // {first tail-destination index, first atom, atoms | source rows << 8, first source row}
+  const int td0 = RFL(tt.x), n0 = RFL(tt.y), n_dst = RFL(tt.z & 255);
+  const int s_lo = RFL(tt.w), rows = RFL(tt.z >> 8);
   const int s_base = s_lo & ~1, off = s_lo - s_base;
   const int ndp = n_dst <= 1 ? 1 : (n_dst <= 2 ? 2 : (n_dst <= 4 ? 4 : 8));
   const int KB = 32 / ndp, kb_sh = ndp == 1 ? 5 : (ndp == 2 ? 4 : (ndp == 4 ? 3 : 2));  // hidden units per step = 1 << kb_sh
@@ -1288,15 +1286,27 @@ __global__ __launch_bounds__(MF_THREADS) void k_tail_form(TailArgs a) {
   if (tid < 32) deg_lds[tid] = tid < n_dst ? a.deg[n0 + tid] : 0;
   float4 va[4], vb[4];
   float mx = 0.f;
+  {
+    // (every request unconditional, at a clamped address, the channel factors zeroed where the row or the channel group does not exist:
+    // as loads under `if (row in the span)` each of the eight was a branch, a request and an `s_waitcnt vmcnt(0)` — eight serialised round
+    // trips in front of a kernel of three steps, round 6)
+    float4 ra[4], rb[4], ga[4], gb[4];
 #pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const int item = tid + MF_THREADS * q, jp = item & 31, c4 = item >> 5;
-    va[q] = vb[q] = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (c4 < 54) {
+    for (int q = 0; q < 4; ++q) {
+      const int item = tid + MF_THREADS * q, jp = item & 31, c4 = item >> 5, c4c = min(c4, 53);
       const int j0 = 2 * jp - off, j1 = j0 + 1;
-      const float4 g4 = reinterpret_cast<const float4*>(a.gx)[c4];
-      if (j0 >= 0 && j0 < rows) { const float4 v = reinterpret_cast<const float4*>(a.x + (size_t)(s_lo + j0) * a.XS)[c4]; va[q] = make_float4(v.x * g4.x, v.y * g4.y, v.z * g4.z, v.w * g4.w); }
-      if (j1 >= 0 && j1 < rows) { const float4 v = reinterpret_cast<const float4*>(a.x + (size_t)(s_lo + j1) * a.XS)[c4]; vb[q] = make_float4(v.x * g4.x, v.y * g4.y, v.z * g4.z, v.w * g4.w); }
+      const float4 g4 = reinterpret_cast<const float4*>(a.gx)[c4c];
+      const float k0 = (c4 < 54 && j0 >= 0 && j0 < rows) ? 1.f : 0.f, k1 = (c4 < 54 && j1 >= 0 && j1 < rows) ? 1.f : 0.f;
+      ga[q] = make_float4(g4.x * k0, g4.y * k0, g4.z * k0, g4.w * k0);
+      gb[q] = make_float4(g4.x * k1, g4.y * k1, g4.z * k1, g4.w * k1);
+      ra[q] = reinterpret_cast<const float4*>(a.x + (size_t)(s_lo + max(0, min(j0, rows - 1))) * a.XS)[c4c];
+      rb[q] = reinterpret_cast<const float4*>(a.x + (size_t)(s_lo + max(0, min(j1, rows - 1))) * a.XS)[c4c];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      va[q] = make_float4(ra[q].x * ga[q].x, ra[q].y * ga[q].y, ra[q].z * ga[q].z, ra[q].w * ga[q].w);
+      vb[q] = make_float4(rb[q].x * gb[q].x, rb[q].y * gb[q].y, rb[q].z * gb[q].z, rb[q].w * gb[q].w);
       mx = fmaxf(mx, fmaxf(fmaxf(fabsf(va[q].x), fabsf(va[q].y)), fmaxf(fabsf(va[q].z), fabsf(va[q].w))));
       mx = fmaxf(mx, fmaxf(fmaxf(fabsf(vb[q].x), fabsf(vb[q].y)), fmaxf(fabsf(vb[q].z), fabsf(vb[q].w))));
     }
@@ -1342,10 +1352,13 @@ __global__ __launch_bounds__(MF_THREADS) void k_tail_form(TailArgs a) {
     const bool in = d < n_dst && t < dg && t < a.S;
     const int slot = (n0 + (d < n_dst ? d : 0)) * a.S + (t < a.S ? t : 0);
     slotv[p] = slot;
-    const int sj = in ? a.esrc[slot] : 0, ep = in ? a.epair[slot] : 0;
-    float4 ge = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (in) ge = a.egeo[slot];
-    evx[p] = ge.x; evy[p] = ge.y; evz[p] = ge.z;
+    // (the slot is clamped: unconditional requests, all passes' in flight together, masked after — under `in ? .. : 0` each was a branch, a
+    // request and a wait of its own)
+    const int sjv = a.esrc[slot], epv = a.epair[slot];
+    const float4 gev = a.egeo[slot];
+    const int sj = in ? sjv : 0, ep = in ? epv : 0;
+    const float kin = in ? 1.f : 0.f;
+    evx[p] = gev.x * kin; evy[p] = gev.y * kin; evz[p] = gev.z * kin;
     const int jl = (sj & 0x7fffffff) - s_base;  // (bit 31: bonded)
     const bool valid = in && jl >= 0 && jl < 64;
     // (edges of one ordered pair share one entry: matched by k_geom — MfArgs::epair, JAMUN_EP_* — as in k_conv_mf)
@@ -1360,7 +1373,7 @@ __global__ __launch_bounds__(MF_THREADS) void k_tail_form(TailArgs a) {
     for (int p = 0; p < NP; ++p) {
       const int g = tid + BT * p, i = g / SPD;
       const int k = (st << kb_sh) + (i & (KB - 1));
-      hv[p] = (st < nsteps && k < n_k) ? a.h[(size_t)k * a.h_kstride + slotv[p]] : 0.f;
+      hv[p] = a.h[(size_t)min(k, n_k - 1) * a.h_kstride + slotv[p]] * ((st < nsteps && k < n_k) ? 1.f : 0.f);  // (unconditional request, clamped)
     }
   };
   const float scC = pow2f(a.sC);
@@ -1475,11 +1488,9 @@ __global__ __launch_bounds__(MF_THREADS) void k_tail_form_init(TailArgs a) {
   constexpr int X_H = 0, X_L = 64 * MF_ROWB, X_C = 2 * 64 * MF_ROWB, X_MISC = X_C + 2 * MF_CB;
   int* __restrict__ deg_lds = reinterpret_cast<int*>(lds + X_MISC);
   const int tid = threadIdx.x, lane = tid & 63, wave = RFL(tid >> 6);
-  const int4 tt = a.tail_tiles[blockIdx.x];
-  const int tile = RFL(tt.x), td0 = RFL(tt.y);
-  const int2 t_at = a.tile_atoms[tile], span = a.tile_span[tile];
-  const int n0 = RFL(t_at.x), n_dst = RFL(t_at.y);
-  const int s_base = RFL(span.x) & ~1;
+  const int4 tt = a.tail_tiles[blockIdx.x];  // (the tile's descriptor: see k_tail_form)
+  const int td0 = RFL(tt.x), n0 = RFL(tt.y), n_dst = RFL(tt.z & 255);
+  const int s_base = RFL(tt.w) & ~1;
   const int ndp = n_dst <= 1 ? 1 : (n_dst <= 2 ? 2 : (n_dst <= 4 ? 4 : 8));
   const int KB = 32 / ndp, kb_sh = ndp == 1 ? 5 : (ndp == 2 ? 4 : (ndp == 4 ? 3 : 2));
   const int n_k = a.n_k, nsteps = (n_k + KB - 1) / KB;
@@ -1507,10 +1518,13 @@ __global__ __launch_bounds__(MF_THREADS) void k_tail_form_init(TailArgs a) {
     const bool in = d < n_dst && t < dg && t < a.S;
     const int slot = (n0 + (d < n_dst ? d : 0)) * a.S + (t < a.S ? t : 0);
     slotv[p] = slot;
-    const int sj = in ? a.esrc[slot] : 0, ep = in ? a.epair[slot] : 0;
-    float4 ge = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (in) ge = a.egeo[slot];
-    evx[p] = ge.x; evy[p] = ge.y; evz[p] = ge.z;
+    // (the slot is clamped: unconditional requests, all passes' in flight together, masked after — under `in ? .. : 0` each was a branch, a
+    // request and a wait of its own)
+    const int sjv = a.esrc[slot], epv = a.epair[slot];
+    const float4 gev = a.egeo[slot];
+    const int sj = in ? sjv : 0, ep = in ? epv : 0;
+    const float kin = in ? 1.f : 0.f;
+    evx[p] = gev.x * kin; evy[p] = gev.y * kin; evz[p] = gev.z * kin;
     const int jl = (sj & 0x7fffffff) - s_base;  // (bit 31: bonded)
     const bool valid = in && jl >= 0 && jl < 64;
     // (edges of one ordered pair share one entry: matched by k_geom — MfArgs::epair, JAMUN_EP_* — as in k_conv_mf)
@@ -1525,7 +1539,7 @@ __global__ __launch_bounds__(MF_THREADS) void k_tail_form_init(TailArgs a) {
     for (int p = 0; p < NP; ++p) {
       const int g = tid + BT * p, i = g / SPD;
       const int k = (st << kb_sh) + (i & (KB - 1));
-      hv[p] = (st < nsteps && k < n_k) ? a.h[(size_t)k * a.h_kstride + slotv[p]] : 0.f;
+      hv[p] = a.h[(size_t)min(k, n_k - 1) * a.h_kstride + slotv[p]] * ((st < nsteps && k < n_k) ? 1.f : 0.f);  // (unconditional request, clamped)
     }
   };
   const float scC = pow2f(a.sC);
@@ -1606,7 +1620,10 @@ __global__ __launch_bounds__(MF_THREADS) void k_tail_form_init(TailArgs a) {
 // with all loads of a hidden unit in flight at once; the eight partial tiles are summed through LDS in wave order: one partial slab per
 // run for the node update.
 template <bool INIT>  // INIT: the initial projector (formed tiles 2 c + t of k_tail_form_init, weight stream of k_conv_mfx)
-#define TC_WAVES 16  // hidden units of a run in flight at once (one per wave; a wave's units run one after the other: 48 loads each)
+#define TC_WAVES 8   // hidden units of a run in flight at once (one per wave; a wave's units run one after the other: 40-48 loads each,
+                     // ALL requested before the first MFMA — two waves per SIMD leave the 200 registers that takes.  With 16 waves (128
+                     // registers) the compiler kept 60 and issued the loads next to their uses: `3 loads, s_waitcnt vmcnt(0), 1 MFMA, 1 load,
+                     // s_waitcnt vmcnt(0), 2 MFMAs, ...` — twenty serialised round trips per hidden unit, 31 us per launch on cfg3)
 __global__ __launch_bounds__(64 * TC_WAVES) void k_tail_contract(TailArgs a) {
   __shared__ float red[TC_WAVES][32][33];
   constexpr int NFT = INIT ? TAIL_NFT_INIT : TAIL_NFT;
@@ -1634,8 +1651,10 @@ __global__ __launch_bounds__(64 * TC_WAVES) void k_tail_contract(TailArgs a) {
         const int blk = job < 5 ? 20 * t + 2 * (2 * job + s2) : 40 + 4 * t + 2 * s2;
         bh[i] = wk[blk * 64]; bl[i] = wk[(blk + 1) * 64];
       }
+      __builtin_amdgcn_sched_barrier(0);  // (the requests of a unit stay in front of its MFMAs)
 #pragma unroll
       for (int i = 0; i < 4; ++i) { M3(acc, ah[i], al[i], bh[i], bl[i]); }
+      __builtin_amdgcn_sched_barrier(0);
     }
   } else if (job < 5) {
     const int n = job;
@@ -1648,8 +1667,10 @@ __global__ __launch_bounds__(64 * TC_WAVES) void k_tail_contract(TailArgs a) {
         ah[i] = p[0]; al[i] = p[1];
         bh[i] = wk[(20 * (i >> 1) + 2 * (2 * n + (i & 1))) * 64]; bl[i] = wk[(20 * (i >> 1) + 2 * (2 * n + (i & 1)) + 1) * 64];
       }
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int i = 0; i < 10; ++i) { M3(acc, ah[i], al[i], bh[i], bl[i]); }
+      __builtin_amdgcn_sched_barrier(0);
     }
   } else {
     const int m = job - 5;
@@ -1663,8 +1684,10 @@ __global__ __launch_bounds__(64 * TC_WAVES) void k_tail_contract(TailArgs a) {
         ah[i] = p[0]; al[i] = p[1];
         bh[i] = wk[(4 * g + 2 * (i & 1)) * 64]; bl[i] = wk[(4 * g + 2 * (i & 1) + 1) * 64];
       }
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int i = 0; i < 12; ++i) { M3(acc, ah[i], al[i], bh[i], bl[i]); }
+      __builtin_amdgcn_sched_barrier(0);
     }
   }
 #pragma unroll

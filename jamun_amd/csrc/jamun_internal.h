@@ -222,7 +222,7 @@ struct TailArgs {
   int n_pad, S, XS, n_k, nt0;
   const int2* tile_span;   // the tile arrays of k_conv_mf
   const int2* tile_atoms;
-  const int4* tail_tiles;  // [n_tail_tiles] {tile, index of its first tail destination, 0, 0}
+  const int4* tail_tiles;  // [n_tail_tiles] {index of its first tail destination, first atom, atoms | source rows << 8, first source row}
   int n_tail_tiles, n_tail, n_runs;  // tail tiles, tail destinations, runs of hidden units (= partial slabs) of the contraction
   const int* tail_atom;    // [n_tail] atom of each tail destination
   float* tail_scale;       // [n_tail] 2^-(sX + sC) of the destination's forming (work buffer)
@@ -409,11 +409,12 @@ int conv_set_max_lds();
 int launch_conv_dg(const DgArgs& a, int grid, hipStream_t st);
 int conv_dg_set_max_lds();
 void conv_dg_print_stamps();
+void node_print_stamps();  // (-DNH_TRACE builds: per-wave timeline of k_node_update_h)
 void conv_initv_print_stamps();
 void conv_mf_print_stamps();
 size_t conv_dg_lds_bytes(int rs, int pmax, int mode, int emu);
 void launch_tprod(const float* x, int XS, int n_atoms, int n_k, const float4* wt, const float4* wth, const float* gT, const float* cfT, float* T, int t_stride,
-                  hipStream_t st);
+                  hipStream_t st, bool no_tprod_t = false);  // (t_stride > 0 and f16x3 weights: k_tprod_t unless no_tprod_t)
 int launch_conv_mf(const MfArgs& a, int grid, hipStream_t st);
 int launch_conv_mfi(const MfiArgs& a, int grid, hipStream_t st);
 int launch_conv_mfx(const MfxArgs& a, int grid, hipStream_t st);

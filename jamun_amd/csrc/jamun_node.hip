@@ -15,6 +15,8 @@
 // Measured on MI355X (cfg2, 4352 atoms, 3 slabs): k_node_update 24.4 us = 13.8 phase 1 + 10.6 phase 2; see DESIGN.md 3.4 for this kernel.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
+#include <stdio.h>
 
 #include "jamun_internal.h"
 #include "jamun_split.h"
@@ -27,6 +29,17 @@ typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 #define NH_W 8  // K-steps of weight blocks in flight per wave (the first NH_W are requested before phase 1)
 #define MFMA32H(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8, (a)), __builtin_bit_cast(h8, (b)), (c), 0, 0, 0)
 #define RFL(v) __builtin_amdgcn_readfirstlane(v)
+
+#ifdef NH_TRACE  // per-wave timeline of every workgroup (diagnostic builds): [workgroup * 8 + wave][stamp]
+__device__ unsigned long long g_nhtrace[2400][8];
+#define NSTAMP(slot) do { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); if (lane == 0 && blockIdx.x < 300) g_nhtrace[blockIdx.x * 8 + wave][slot] = t_; } while (0)
+#define NSTAMP_RT(slot) do { unsigned long long t_; asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); if (lane == 0 && blockIdx.x < 300) g_nhtrace[blockIdx.x * 8 + wave][slot] = t_; } while (0)
+#define NSTAMP_V(slot, v) do { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_), "+v"(v) :: "memory"); if (lane == 0 && blockIdx.x < 300) g_nhtrace[blockIdx.x * 8 + wave][slot] = t_; } while (0)
+#else
+#define NSTAMP(slot) do { } while (0)
+#define NSTAMP_RT(slot) do { } while (0)
+#define NSTAMP_V(slot, v) do { } while (0)
+#endif
 
 namespace {
 
@@ -60,7 +73,10 @@ __device__ __forceinline__ void put1(char* hi_row, int lo_off, int k, float v, f
 // LR = the low-register variant (<= 128 registers: two workgroups per CU; chosen by the launcher when the grid exceeds the CUs, where a
 // second round of a few workgroups would double the launch: 33 x 256 atoms = 264 workgroups took 36 us against 21 for 256): nothing of
 // phase 2 is requested before phase 1 — the other workgroup of the CU covers those round trips — and the weight ring is 4 steps deep.
-template <bool LR>
+// FX = the contraction depths are the standard ones (K0h = 240, K1h = 64: 15 and 4 K-steps): phase 2 is unrolled with compile-time slots of
+// the weight ring.  (With run-time depths the compiler rotates the ring through register COPIES behind `s_waitcnt vmcnt(0)` — every K-step
+// waited for the request it had just issued, ~500 cycles each, 6-9 k cycles for the 45 MFMAs of a scalar tile: profiles/r6_cfg2_tprod_node_trace.txt.)
+template <bool LR, bool FX>
 __global__ __launch_bounds__(NH_T, LR ? 4 : 2) void k_node_update_h(NodeArgs a) {
   constexpr int NW = LR ? 4 : NH_W;
   extern __shared__ float4 nh_lds[];
@@ -76,6 +92,8 @@ __global__ __launch_bounds__(NH_T, LR ? 4 : 2) void k_node_update_h(NodeArgs a) 
   const int tid = threadIdx.x, lane = tid & 63, wave = RFL(tid >> 6);
   const int il = tid >> 4, c16 = tid & 15;
   const int i = n0 + il;
+  NSTAMP_RT(0);
+  NSTAMP(1);
   const bool ok = i < a.n_atoms;
   const int ns = ok ? (a.atom_nslab ? a.atom_nslab[i] : a.n_slices) : 0;
   const int ns_max = a.atom_nslab ? a.max_slabs : a.n_slices;
@@ -148,21 +166,6 @@ __global__ __launch_bounds__(NH_T, LR ? 4 : 2) void k_node_update_h(NodeArgs a) 
       xv[q] = *reinterpret_cast<const float4*>(a.x_in + (size_t)min(i, a.n_atoms - 1) * a.XSin + min(4 * j, a.XSin - 4));
     }
     // (the loads above do not wait for this atom's slab count: slab indices are clamped to the batch's maximum, results masked here)
-    // phase 2's operands that do not depend on phase 1 — the first NH_W K-steps of this wave's weight blocks and the x_old values of its
-    // output tile — are requested now, behind the slab loads: their round trips run during phase 1 instead of after its barrier
-    if constexpr (!LR) {
-#pragma unroll
-      for (int t = 0; t < NW; ++t) {
-        const int sw = t < nst_j ? t : nst_j - 1;
-        wh[t] = wp_j[(2 * sw) * 64];  // (a wave without a job reads the blocks of plane 0: valid addresses, results unused)
-        wl[t] = wp_j[(2 * sw + 1) * 64];
-      }
-#pragma unroll
-      for (int q = 0; q < 16; ++q) {
-        const int rl = (q & 3) + 8 * (q >> 2) + 4 * hh_j, ii = n0 + rl;
-        xo[q] = (a.mix && col_ok_j && ii < a.n_atoms) ? a.x_in[(size_t)ii * a.XSin + o_j] : 0.f;
-      }
-    }
 #pragma unroll
     for (int q = 0; q < 3; ++q) {
       const bool in = 4 * (c16 + 16 * q) < w0;
@@ -199,6 +202,27 @@ __global__ __launch_bounds__(NH_T, LR ? 4 : 2) void k_node_update_h(NodeArgs a) 
 #if defined(NH_EXP) && (NH_EXP & 2)
   if (a.mix) { if (ms[0].x + ms[1].x + ms[2].x + mv[0].x + mv[1].x + xv[0].x + xv[1].x + xv[2].x + xv[3].x == 1.2345f) a.x_out[0] = 0.f; return; }
 #endif
+  // phase 2's operands that do not depend on phase 1 — the first NH_W K-steps of this wave's weight blocks and the x_old values of its
+  // output tile — are requested here, once the slabs have ARRIVED: their round trips run during phase 1 instead of after its barrier.
+  // (Requested together with the slabs they delayed them: a CU's eight waves move 126 KB of slabs and 160 KB of weights / x_old through
+  // one 64 B/clk vector-memory path, and waves 4..7's slabs queued behind waves 0..3's weights — slabs at ~10 k cycles, the barrier waiting
+  // for the late half: profiles/r6_cfg2_tprod_node_trace.txt)
+  __builtin_amdgcn_sched_barrier(0);
+  if constexpr (!LR) {
+#pragma unroll
+    for (int t = 0; t < NW; ++t) {
+      const int sw = t < nst_j ? t : nst_j - 1;
+      wh[t] = wp_j[(2 * sw) * 64];  // (a wave without a job reads the blocks of plane 0: valid addresses, results unused)
+      wl[t] = wp_j[(2 * sw + 1) * 64];
+    }
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int rl = (q & 3) + 8 * (q >> 2) + 4 * hh_j, ii = n0 + rl;
+      xo[q] = (a.mix && col_ok_j && ii < a.n_atoms) ? a.x_in[(size_t)ii * a.XSin + o_j] : 0.f;
+    }
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  NSTAMP_V(2, ms[0].x);
   // ---- phase 1a: mean over in-edges, activation (scalar K range) / gate; the scalar channels of x_in extend the scalar K range
   float mxS = 0.f;
 #pragma unroll
@@ -245,7 +269,20 @@ __global__ __launch_bounds__(NH_T, LR ? 4 : 2) void k_node_update_h(NodeArgs a) 
     for (int k = a.mul0 + a.in0 + 4 * c16; k < a.K0h; k += 64) put4(row, L0, k, z4, 1.f);  // pad rows of the K range
     if (c16 == 0) isc0[il] = pow2f(-sS);
   }
+  NSTAMP(3);
   __syncthreads();  // gates
+  // (standard depths: the K-steps of a scalar tile beyond the ring are requested here — the slab registers are free — and arrive during phase 1b)
+  float4 wh2[(FX && !LR) ? 7 : 1], wl2[(FX && !LR) ? 7 : 1];
+  if constexpr (FX && !LR) {
+    if (scalar_j) {
+#pragma unroll
+      for (int t = 0; t < 7; ++t) {
+        wh2[t] = wp_j[(2 * (NW + t)) * 64];
+        wl2[t] = wp_j[(2 * (NW + t) + 1) * 64];
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
 
   // ---- phase 1b: gated vectors and the vector channels of x_in (K range of a plane: [gate * m1 (mul1) | x_in vectors (in1) | pad])
   float gv[2][4];
@@ -290,6 +327,14 @@ __global__ __launch_bounds__(NH_T, LR ? 4 : 2) void k_node_update_h(NodeArgs a) 
     if (c16 == 0) isc1[il] = pow2f(-sV);
   }
   __syncthreads();
+  NSTAMP(4);
+  // (the operands requested in front of phase 1 are consumed here once: first used inside the epilogue's predicated stores, the compiler's
+  // wait for them is `s_waitcnt vmcnt(0)` in front of EVERY store block — sixteen serialised store round trips, ~5 k cycles)
+  if constexpr (!LR) {
+#pragma unroll
+    for (int q = 0; q < 16; ++q) asm volatile("" : "+v"(xo[q]));
+    asm volatile("" : "+v"(mw_j), "+v"(cinv_j));
+  }
 
   // ---- phase 2: one job per wave: scalar-output tile (32 columns, K0h / 16 steps) or vector plane (K1h / 16 steps); weight blocks of
   // 64 lanes x 8 halves, (hi, lo) per step, NH_W steps in flight (the first NH_W requested before phase 1)
@@ -314,6 +359,37 @@ __global__ __launch_bounds__(NH_T, LR ? 4 : 2) void k_node_update_h(NodeArgs a) 
         wl[t] = wp[(2 * sw + 1) * 64];
       }
     }
+    if constexpr (FX) {
+      auto run = [&](auto nst_c) {
+        constexpr int NST = decltype(nst_c)::value;
+        float4 ah = *reinterpret_cast<const float4*>(ap), al = *reinterpret_cast<const float4*>(ap + lo);
+#pragma unroll
+        for (int s_ = 0; s_ < NST; ++s_) {
+          float4 nah = ah, nal = al;
+          if (s_ + 1 < NST) {
+            nah = *reinterpret_cast<const float4*>(ap + 32 * (s_ + 1));
+            nal = *reinterpret_cast<const float4*>(ap + lo + 32 * (s_ + 1));
+          }
+          float4 bh = wh[s_ % NW], bl = wl[s_ % NW];
+          if constexpr (!LR) {
+            if (s_ >= NW) { bh = wh2[s_ >= NW ? s_ - NW : 0]; bl = wl2[s_ >= NW ? s_ - NW : 0]; }
+          }
+          acc = MFMA32H(al, bh, acc);
+          acc = MFMA32H(ah, bl, acc);
+          acc = MFMA32H(ah, bh, acc);
+          if constexpr (LR) {
+            if (s_ + NW < NST) {  // (compile-time slot: no copies)
+              wh[s_ % NW] = wp[(2 * (s_ + NW)) * 64];
+              wl[s_ % NW] = wp[(2 * (s_ + NW) + 1) * 64];
+            }
+          }
+          ah = nah; al = nal;
+          __builtin_amdgcn_sched_barrier(0);  // (left alone, the scheduler sinks every reload to just in front of its use)
+        }
+      };
+      if (scalar) run(std::integral_constant<int, 15>{});
+      else run(std::integral_constant<int, 4>{});
+    } else
     for (int s0 = 0; s0 < nst; s0 += NW) {
 #pragma unroll
       for (int t = 0; t < NW; ++t) {
@@ -330,18 +406,63 @@ __global__ __launch_bounds__(NH_T, LR ? 4 : 2) void k_node_update_h(NodeArgs a) 
         }
       }
     }
-    const float mw = LR ? ld_mw() : mw_j, cinv = LR ? ld_cinv() : cinv_j;
+    NSTAMP_V(5, acc[0]);
+    float mw = LR ? ld_mw() : mw_j, cinv = LR ? ld_cinv() : cinv_j;
     const float* __restrict__ isc = scalar ? isc0 : isc1;
+    // x_old of this lane's sixteen outputs and the tile's row scales, all requested before the first predicated store (inside the store
+    // blocks every one of them was a round trip of its own: the compiler's wait in a predicated block is vmcnt(0), stores included)
+    float xold[16], iscr[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int rl = (q & 3) + 8 * (q >> 2) + 4 * hh;
+      iscr[q] = isc[rl];
+      if constexpr (LR) xold[q] = a.x_in[(size_t)min(n0 + rl, a.n_atoms - 1) * a.XSin + ((a.mix && col_ok_j) ? o_j : 0)];  // (unconditional, clamped)
+      else xold[q] = xo[LR ? 0 : q];
+    }
+    if constexpr (LR) {
+#pragma unroll
+      for (int q = 0; q < 16; ++q) asm volatile("" : "+v"(xold[q]));
+      asm volatile("" : "+v"(mw), "+v"(cinv));
+    }
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
       const int rl = (q & 3) + 8 * (q >> 2) + 4 * hh, ii = n0 + rl;
       if (col_ok_j && ii < a.n_atoms) {
-        float v = (acc[q] * isc[rl]) * cinv;
-        if (a.mix) v = mw * (LR ? a.x_in[(size_t)ii * a.XSin + o_j] : xo[LR ? 0 : q]) + (1.f - mw) * v;  // hidden layers: XSin == XSo, x_in is x_old
+        float v = (acc[q] * iscr[q]) * cinv;
+        if (a.mix) v = mw * xold[q] + (1.f - mw) * v;  // hidden layers: XSin == XSo, x_in is x_old
         a.x_out[(size_t)ii * XSo + o_j] = v;
       }
     }
   }
+  NSTAMP(6);
+  NSTAMP_RT(7);
+}
+
+void node_print_stamps() {
+#ifdef NH_TRACE
+  static unsigned long long tr[2400][8];
+  if (hipMemcpyFromSymbol(tr, HIP_SYMBOL(g_nhtrace), sizeof(tr)) != hipSuccess) return;
+  unsigned long long rt0 = ~0ull, rt1 = 0;
+  int nw = 0;
+  for (int g = 0; g < 2400; ++g)
+    if (tr[g][0]) { rt0 = rt0 < tr[g][0] ? rt0 : tr[g][0]; rt1 = rt1 > tr[g][7] ? rt1 : tr[g][7]; ++nw; }
+  if (!nw) return;
+  fprintf(stderr, "node update trace: %d waves; first entry -> last exit %llu ticks of s_memrealtime (100 MHz)\n", nw, rt1 - rt0);
+  fprintf(stderr, "  wg.wave: entry (ticks after first) | cycles after entry: loads arrived, phase 1a done, phase 1 done (2nd barrier passed), MFMAs done, exit | exit (ticks)\n");
+  double sum[8] = {};
+  for (int g = 0; g < 2400; ++g) {
+    if (!tr[g][0]) continue;
+    for (int i = 2; i < 7; ++i) sum[i] += (double)(tr[g][i] - tr[g][1]);
+    sum[0] += (double)(tr[g][0] - rt0); sum[7] += (double)(tr[g][7] - rt0);
+    if ((g >> 3) % 23 != 0) continue;
+    fprintf(stderr, "  %3d.%d: %4llu |", g >> 3, g & 7, tr[g][0] - rt0);
+    for (int i = 2; i < 7; ++i) fprintf(stderr, " %6lld", tr[g][i] ? (long long)(tr[g][i] - tr[g][1]) : 0ll);
+    fprintf(stderr, " | %4llu\n", tr[g][7] - rt0);
+  }
+  fprintf(stderr, "  means: entry %.1f ticks |", sum[0] / nw);
+  for (int i = 2; i < 7; ++i) fprintf(stderr, " %.0f", sum[i] / nw);
+  fprintf(stderr, " | exit %.1f ticks\n", sum[7] / nw);
+#endif
 }
 
 size_t node_update_h_lds_bytes(const NodeArgs& a) {
@@ -354,8 +475,10 @@ bool node_update_h_supported(const NodeArgs& a) {
 }
 void launch_node_update_h(const NodeArgs& a, int cus, hipStream_t st) {
   const int grid = a.n_pad / 32;
-  if (grid > cus && 2 * node_update_h_lds_bytes(a) <= 150 * 1024)
-    hipLaunchKernelGGL(k_node_update_h<true>, dim3(grid), dim3(NH_T), node_update_h_lds_bytes(a), st, a);
-  else
-    hipLaunchKernelGGL(k_node_update_h<false>, dim3(grid), dim3(NH_T), node_update_h_lds_bytes(a), st, a);
+  const bool lr = grid > cus && 2 * node_update_h_lds_bytes(a) <= 150 * 1024, fx = a.K0h == 240 && a.K1h == 64;
+  const size_t lds = node_update_h_lds_bytes(a);
+  if (lr && fx) hipLaunchKernelGGL((k_node_update_h<true, true>), dim3(grid), dim3(NH_T), lds, st, a);
+  else if (lr) hipLaunchKernelGGL((k_node_update_h<true, false>), dim3(grid), dim3(NH_T), lds, st, a);
+  else if (fx) hipLaunchKernelGGL((k_node_update_h<false, true>), dim3(grid), dim3(NH_T), lds, st, a);
+  else hipLaunchKernelGGL((k_node_update_h<false, false>), dim3(grid), dim3(NH_T), lds, st, a);
 }

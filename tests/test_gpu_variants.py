@@ -326,3 +326,27 @@ def test_create_time_self_check_passes_on_this_build_and_fires_on_a_corrupted_ke
     assert torch.equal(off.xhat(ref["y"].to(dev)), ok.xhat(ref["y"].to(dev)))  # the check leaves no trace in the sampler it passed
     with pytest.raises(RuntimeError, match="selfcheck"):
         NativeSampler(model._native, 0.04, batch, dev, tuning={"selfcheck": 7})
+
+
+@pytest.mark.parametrize("kind", ["ag4", "chain17x6", "chain33x4", "ragged", "chig93x2", "chig166x2"])
+def test_transposed_pre_pass_kernels_agree_bit_for_bit(kind):
+    """k_tprod_t (round 6: a workgroup's four waves share a hidden unit's weight blocks through LDS, the rows are fetched whole and held as B
+    fragments, T rows are stored as whole 128-byte lines) forms the same products in the same order as k_tprod_h's transposed branch
+    (`jamun_tuning.no_tprod_t`), with powers of two for every scale: x-hat and score are bit-identical — also where the last workgroup's waves
+    have fewer than 64 atoms or none (102, 132, .. atoms) and where the hidden units do not divide into the workgroups' runs."""
+    from jamun_amd import synth
+    from jamun_amd.data import WalkerBatch
+    from jamun_amd.model import Denoiser
+    from jamun_amd.native import NativeSampler
+
+    mk = _mk()
+    dev = torch.device("cuda", 0)
+    model = Denoiser.from_checkpoint_dict(synth.synthetic_checkpoint(output_gain=0.5)).to(dev)
+    batch = WalkerBatch.from_molecules(mk.molecules(kind)).to(dev)
+    new = NativeSampler(model._native, 0.04, batch, dev)
+    old = NativeSampler(model._native, 0.04, batch, dev, tuning={"no_tprod_t": 1})
+    if new.stats()["dg_mode"] not in (4, 5):
+        pytest.skip("this shape does not take the transposed pre-pass")
+    y = _golden(f"oracle_forward_{kind}")["y"].to(dev)
+    assert torch.equal(new.xhat(y), old.xhat(y))
+    assert torch.equal(new.score(y), old.score(y))
