@@ -269,11 +269,14 @@ __global__ __launch_bounds__(ML_THREADS) void k_conv_ml(MlArgs a) {
     auto stage = [&](auto row_of, auto c0_, auto nc_, int lo_off) __attribute__((always_inline)) {
       constexpr int c0 = decltype(c0_)::value, NC = decltype(nc_)::value;
       constexpr int NPAIR = RH / 2, NR = (NPAIR + 63) / 64, NIT = (NC * NR + 7) / 8;
-      float4 va[NIT], vb[NIT];
+      float4 va[NIT], vb[NIT], gq[NIT];
 #pragma unroll
       for (int q = 0; q < NIT; ++q) {  // (every round's rows requested before the first is split and stored)
         const int cw = wave + 8 * q, c4 = c0 + cw % NC, jp = 64 * (cw / NC) + lane;
         const int j0 = 2 * jp - off, j1 = j0 + 1;  // rows relative to the span
+        // (the channel factors with the rows: as loads at their use, under the round's predicate, each was a request and an `s_waitcnt vmcnt(0)` of
+        // its own — up to four serialised round trips per staging pass, round 6)
+        gq[q] = reinterpret_cast<const float4*>(a.gx)[c4];
         va[q] = vb[q] = make_float4(0.f, 0.f, 0.f, 0.f);
         if (cw < NC * NR && jp < NPAIR) {
           if (j0 >= 0 && j0 < rows) va[q] = reinterpret_cast<const float4*>(a.x + (size_t)(s_lo + j0) * a.XS)[c4];
@@ -284,7 +287,7 @@ __global__ __launch_bounds__(ML_THREADS) void k_conv_ml(MlArgs a) {
       for (int q = 0; q < NIT; ++q) {
         const int cw = wave + 8 * q, c4 = c0 + cw % NC, jp = 64 * (cw / NC) + lane;
         if (cw < NC * NR && jp < NPAIR) {
-          const float4 g4 = reinterpret_cast<const float4*>(a.gx)[c4];
+          const float4 g4 = gq[q];
           const float ea[4] = {va[q].x * g4.x, va[q].y * g4.y, va[q].z * g4.z, va[q].w * g4.w}, eb[4] = {vb[q].x * g4.x, vb[q].y * g4.y, vb[q].z * g4.z, vb[q].w * g4.w};
 #pragma unroll
           for (int e = 0; e < 4; ++e) {

@@ -98,13 +98,18 @@ __device__ __forceinline__ void geom_body(float* __restrict__ y, const int* __re
   const bool in_lds = hi - lo <= GEOM_LDS_ATOMS;
   if (pre.v) {
     for (int i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+      // (the atom's nine inputs requested before its first store: pre.v / pre.psi may alias y for all the compiler knows, and between the stores
+      // every load was a round trip of its own)
+      float v0[3], p0[3], y0[3];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) { v0[c] = pre.v[i * 3 + c]; p0[c] = pre.psi[i * 3 + c]; y0[c] = y[i * 3 + c]; }
       float R[3];
       if (pre.noise) { R[0] = pre.noise[i * 3]; R[1] = pre.noise[i * 3 + 1]; R[2] = pre.noise[i * 3 + 2]; }
       else philox_normal3(pre.seed, pre.iter, (uint32_t)i, R);
 #pragma unroll
       for (int c = 0; c < 3; ++c) {
-        float vv = FADD(pre.v[i * 3 + c], FMUL(pre.k.u_half_delta, pre.psi[i * 3 + c]));
-        float yy = FADD(y[i * 3 + c], FMUL(pre.k.half_delta, vv));
+        float vv = FADD(v0[c], FMUL(pre.k.u_half_delta, p0[c]));
+        float yy = FADD(y0[c], FMUL(pre.k.half_delta, vv));
         float vh = FADD(FMUL(pre.k.exp_mg, vv), FMUL(pre.k.zeta_sqrt_u, R[c]));
         yy = FADD(yy, FMUL(pre.k.half_delta, vh));
         pre.v[i * 3 + c] = vh;
@@ -637,10 +642,16 @@ __global__ __launch_bounds__(256) void k_head(HeadArgs a) {
 #pragma unroll
       for (int q = 0; q < HQ; ++q) {
         const int idx = base + threadIdx.x + 256 * q;
-        v[q] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (idx < n_wg4) v[q] = g4[idx];
-        else if (idx < n_wg4 + n_wv4) v[q] = v4[idx - n_wg4];
-        else if (idx < n_all && (size_t)blockIdx.x * n_x4 + (idx - n_wg4 - n_wv4) < x4_total) v[q] = x4[idx - n_wg4 - n_wv4];
+        // (ONE unconditional request per piece, from a selected address — as three loads under an if / else chain each piece was a branch and,
+        // for the feature rows, a wait of its own; pieces past the end read the first weight piece and are not stored, rows past the last atom
+        // are multiplied by zero)
+        const int ix = idx - n_wg4 - n_wv4;
+        const bool is_g = idx < n_wg4, is_v = idx < n_wg4 + n_wv4;
+        const bool x_ok = idx < n_all && (size_t)blockIdx.x * n_x4 + (size_t)(ix < 0 ? 0 : ix) < x4_total;
+        const float4* __restrict__ src = is_g ? g4 + idx : (is_v ? v4 + (idx - n_wg4) : (x_ok ? x4 + ix : g4));
+        const float km = (is_v || x_ok) ? 1.f : 0.f;
+        const float4 t = *src;
+        v[q] = make_float4(t.x * km, t.y * km, t.z * km, t.w * km);
       }
 #pragma unroll
       for (int q = 0; q < HQ; ++q) {
@@ -717,11 +728,23 @@ __device__ __forceinline__ void finalize_body(const float* __restrict__ y, const
   __syncthreads();
   auto atoms = [&](auto rd) {  // (once per address space, as k_geom)
   for (int i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+    // (everything the atom reads is requested before its first store: between the stores — the output pointers of LangevinPost may alias for all
+    // the compiler knows — every load was a round trip of its own, seven per atom in a kernel that is nothing but latency)
+    float yv[3], vv[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < 3; ++c) yv[c] = y[i * 3 + c];
+    if (post.psi_out && post.update_v) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) vv[c] = post.v[i * 3 + c];
+    }
     float xh[3], sc[3];
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
       xh[c] = FSUB(rd(i * 3 + c), cen[c]);
-      sc[c] = FSUB(xh[c], y[i * 3 + c]) / sigma2;
+      sc[c] = FSUB(xh[c], yv[c]) / sigma2;
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
       if (xhat) xhat[i * 3 + c] = xh[c];
       if (score) score[i * 3 + c] = sc[c];
     }
@@ -731,8 +754,8 @@ __device__ __forceinline__ void finalize_body(const float* __restrict__ y, const
 #pragma unroll
       for (int c = 0; c < 3; ++c) {
         post.psi_out[i * 3 + c] = p[c];
-        if (post.update_v) post.v[i * 3 + c] = FADD(post.v[i * 3 + c], FMUL(post.k.half_delta, p[c]));
-        if (post.y_frame) post.y_frame[i * 3 + c] = y[i * 3 + c];
+        if (post.update_v) post.v[i * 3 + c] = FADD(vv[c], FMUL(post.k.half_delta, p[c]));
+        if (post.y_frame) post.y_frame[i * 3 + c] = yv[c];
         if (post.score_frame) post.score_frame[i * 3 + c] = sc[c];
         if (post.xhat_frame) post.xhat_frame[i * 3 + c] = xh[c];
       }
