@@ -788,11 +788,14 @@ __global__ __launch_bounds__(MF_THREADS) void k_conv_mfi(MfiArgs a) {
   int* __restrict__ deg_lds = reinterpret_cast<int*>(lds + I_MISC);
   const int tid0 = threadIdx.x, lane0 = tid0 & 63;
   const int wave = RFL(tid0 >> 6);
+  // (the record of segment s + 1 is requested during segment s, as in k_conv_mf: one dependent round trip less per segment but the first)
+  const int4* __restrict__ my_segs = a.segs + (size_t)blockIdx.x * a.max_segs * 2;
+  int4 sg0 = ld_const(my_segs), sg1 = ld_const(my_segs + 1);
   for (int sgi = 0; sgi < a.max_segs; ++sgi) {
-    const int4 sg0 = a.segs[((size_t)blockIdx.x * a.max_segs + sgi) * 2];
-    const int4 sg1 = a.segs[((size_t)blockIdx.x * a.max_segs + sgi) * 2 + 1];
     const int tile = RFL(sg0.x);
     if (tile < 0) break;
+    int4 nsg0 = make_int4(-1, 0, 0, 0), nsg1 = make_int4(-1, 0, 0, 0);
+    if (sgi + 1 < a.max_segs) { nsg0 = ld_const(my_segs + 2 * (sgi + 1)); nsg1 = ld_const(my_segs + 2 * (sgi + 1) + 1); }
     int lane = lane0;
     asm volatile("" : "+v"(lane));
     const int tid = wave * 64 + lane;
@@ -807,12 +810,16 @@ __global__ __launch_bounds__(MF_THREADS) void k_conv_mfi(MfiArgs a) {
 
     // ---- everything the builder needs from global memory is requested first (in-degrees, h~ of the first hidden unit, the edge records
     // of all passes without the degree predicate — slots past it hold stale records and are masked below), so that these round trips
-    // and the selector's overlap instead of following one another
-    int dgv = 0;
-    if (tid < 32 && tid < n_dst) dgv = a.deg[n0 + tid];
+    // and the selector's overlap instead of following one another.  Every request is UNCONDITIONAL at a clamped address and masked after
+    // (round 6: as `in ? a.esrc[slot] : 0` each load was a branch, and the compiler put `s_waitcnt vmcnt(0)` into some of the branches —
+    // five serialised round trips in front of every tile of this kernel)
+    const int dgl = a.deg[n0 + min(tid & 31, n_dst - 1)];
+    const int dgv = dgl * ((tid < 32 && tid < n_dst) ? 1 : 0);  // (a product, not a select: a select's load is sunk into a branch, with a wait of its own)
     constexpr int BT = MF_THREADS, DPP = BT / SPD, NP = 32 / DPP;
     int ent[NP];
     const int slot0 = (n0 + tid / SPD) * a.S + tid % SPD, pstride = DPP * a.S;
+    const int tcl = min(tid % SPD, a.S - 1);  // (clamped slot of the records: a destination of the tile, a slot below the stride)
+    auto slot_c = [&](int p) { return (n0 + min((tid + BT * p) / SPD, n_dst - 1)) * a.S + tcl; };
     float hv[NP];
     // (every lane loads the h~ of its OWN slot; the owner of a coefficient entry fetches the pair's other edges by lane shuffle, as in k_conv_mf)
     auto load_k = [&](int k) {
@@ -827,19 +834,23 @@ __global__ __launch_bounds__(MF_THREADS) void k_conv_mfi(MfiArgs a) {
     for (int p = 0; p < NP; ++p) {
       const int g = tid + BT * p, i = g / SPD, t = g % SPD;
       const bool in = i < n_dst && t < a.S;
-      sjv[p] = in ? a.esrc[slot0 + p * pstride] : 0;
-      epv[p] = in ? a.epair[slot0 + p * pstride] : 0;
-      float4 ge = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (in) ge = a.egeo[slot0 + p * pstride];
-      evx[p] = ge.x; evy[p] = ge.y; evz[p] = ge.z;
+      const int sc_ = slot_c(p);
+      const int sj_ = a.esrc[sc_], ep_ = a.epair[sc_];
+      const float4 ge = a.egeo[sc_];
+      const float kin = in ? 1.f : 0.f;
+      sjv[p] = in ? sj_ : 0;
+      epv[p] = in ? ep_ : 0;
+      evx[p] = ge.x * kin; evy[p] = ge.y * kin; evz[p] = ge.z * kin;
     }
+    // (the embedding-row ids of the span: a thread's pair of source rows is the same in every round of the selector loop below)
+    const int jp_u = tid & 31;
+    const int uu0 = a.atom_uid[s_lo + min(2 * jp_u, rows - 1)], uu1 = a.atom_uid[s_lo + min(2 * jp_u + 1, rows - 1)];
+    const int u0 = 2 * jp_u < rows ? uu0 : -1, u1 = 2 * jp_u + 1 < rows ? uu1 : -1;
 
     // ---- segment prologue: zero the coefficient tiles, the selector
     for (int idx = tid; idx < 2 * MF_CB / 16; idx += MF_THREADS) reinterpret_cast<float4*>(lds + I_C)[idx] = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int idx = tid; idx < UT * 32 * 32; idx += MF_THREADS) {  // (uid, pair of source rows)
+    for (int idx = tid; idx < UT * 32 * 32; idx += MF_THREADS) {  // (uid, pair of source rows; idx & 31 == tid & 31: MF_THREADS is a multiple of 32)
       const int uid = idx >> 5, jp = idx & 31;
-      const int j0 = 2 * jp, j1 = j0 + 1;
-      const int u0 = j0 < rows ? a.atom_uid[s_lo + j0] : -1, u1 = j1 < rows ? a.atom_uid[s_lo + j1] : -1;
       *reinterpret_cast<unsigned*>(lds + I_S + uid * MF_ROWB + 4 * jp) = (u0 == uid ? 0x3c00u : 0u) | (u1 == uid ? 0x3c000000u : 0u);
     }
     if (tid < 32) deg_lds[tid] = dgv;
@@ -974,6 +985,7 @@ __global__ __launch_bounds__(MF_THREADS) void k_conv_mfi(MfiArgs a) {
       }
     }
     LDS_BARRIER();  // the next segment rewrites the tiles
+    sg0 = nsg0; sg1 = nsg1;
   }
 }
 
@@ -998,11 +1010,13 @@ __global__ __launch_bounds__(MF_THREADS) void k_conv_mfx(MfxArgs a) {
   int* __restrict__ deg_lds = reinterpret_cast<int*>(lds + X_MISC);
   const int tid0 = threadIdx.x, lane0 = tid0 & 63;
   const int wave = RFL(tid0 >> 6);
+  const int4* __restrict__ my_segs = a.segs + (size_t)blockIdx.x * a.max_segs * 2;  // (next record requested during this segment, as k_conv_mfi)
+  int4 sg0 = ld_const(my_segs), sg1 = ld_const(my_segs + 1);
   for (int sgi = 0; sgi < a.max_segs; ++sgi) {
-    const int4 sg0 = a.segs[((size_t)blockIdx.x * a.max_segs + sgi) * 2];
-    const int4 sg1 = a.segs[((size_t)blockIdx.x * a.max_segs + sgi) * 2 + 1];
     const int tile = RFL(sg0.x);
     if (tile < 0) break;
+    int4 nsg0 = make_int4(-1, 0, 0, 0), nsg1 = make_int4(-1, 0, 0, 0);
+    if (sgi + 1 < a.max_segs) { nsg0 = ld_const(my_segs + 2 * (sgi + 1)); nsg1 = ld_const(my_segs + 2 * (sgi + 1) + 1); }
     int lane = lane0;
     asm volatile("" : "+v"(lane));
     const int tid = wave * 64 + lane;
@@ -1014,12 +1028,14 @@ __global__ __launch_bounds__(MF_THREADS) void k_conv_mfx(MfxArgs a) {
     const int2 span = make_int2(sg1.w, sg1.w + (sg1.z >> 8));
     const int s_base = RFL(span.x) & ~1;  // window of 64 source rows from an even atom (the rows are stored in pairs)
 
-    // ---- loads first: in-degrees, h~ of the first hidden unit, the edge records of all passes (as k_conv_mfi)
-    int dgv = 0;
-    if (tid < 32 && tid < n_dst) dgv = a.deg[n0 + tid];
+    // ---- loads first: in-degrees, h~ of the first hidden unit, the edge records of all passes (as k_conv_mfi: unconditional, clamped, masked)
+    const int dgl = a.deg[n0 + min(tid & 31, n_dst - 1)];
+    const int dgv = dgl * ((tid < 32 && tid < n_dst) ? 1 : 0);
     constexpr int BT = MF_THREADS, DPP = BT / SPD, NP = 32 / DPP;
     int ent[NP];
     const int slot0 = (n0 + tid / SPD) * a.S + tid % SPD, pstride = DPP * a.S;
+    const int tcl = min(tid % SPD, a.S - 1);
+    auto slot_c = [&](int p) { return (n0 + min((tid + BT * p) / SPD, n_dst - 1)) * a.S + tcl; };
     float hv[NP];
     auto load_k = [&](int k) {
       const float* __restrict__ hk = a.h + (size_t)k * a.h_kstride;
@@ -1033,11 +1049,13 @@ __global__ __launch_bounds__(MF_THREADS) void k_conv_mfx(MfxArgs a) {
     for (int p = 0; p < NP; ++p) {
       const int g = tid + BT * p, i = g / SPD, t = g % SPD;
       const bool in = i < n_dst && t < a.S;
-      sjv[p] = in ? a.esrc[slot0 + p * pstride] : 0;
-      epv[p] = in ? a.epair[slot0 + p * pstride] : 0;
-      float4 ge = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (in) ge = a.egeo[slot0 + p * pstride];
-      evx[p] = ge.x; evy[p] = ge.y; evz[p] = ge.z;
+      const int sc_ = slot_c(p);
+      const int sj_ = a.esrc[sc_], ep_ = a.epair[sc_];
+      const float4 ge = a.egeo[sc_];
+      const float kin = in ? 1.f : 0.f;
+      sjv[p] = in ? sj_ : 0;
+      epv[p] = in ? ep_ : 0;
+      evx[p] = ge.x * kin; evy[p] = ge.y * kin; evz[p] = ge.z * kin;
     }
     // ---- segment prologue: zero the coefficient tiles; the window's rows (already split, two atoms per word): a copy, transposed
     for (int idx = tid; idx < 2 * MF_CB / 16; idx += MF_THREADS) reinterpret_cast<float4*>(lds + X_C)[idx] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -1211,6 +1229,13 @@ __global__ __launch_bounds__(MF_THREADS) void k_conv_mfx(MfxArgs a) {
         ST1[(ct * 32 + row) * 96 + (comp - 1) * 32 + r] = accP[q];
       }
     }
+    // (the column factors of this thread's pieces of the slab, requested in front of the barrier: as loads at their points of use every
+    // round of the two loops below was a round trip of its own — five per segment; as k_conv_mf's cfa / cfb)
+    float4 cfa[3], cfb[2];
+#pragma unroll
+    for (int n = 0; n < 3; ++n) cfa[n] = reinterpret_cast<const float4*>(a.cf0)[(tid + MF_THREADS * n) % 40];
+#pragma unroll
+    for (int n = 0; n < 2; ++n) cfb[n] = reinterpret_cast<const float4*>(a.cf1)[((tid + MF_THREADS * n) % 24) & 7];
     // (the staging tiles alias the x^T rows and the first coefficient buffer: every wave left the loop through its last barrier, after
     // which nothing reads those; the stores above of a fast wave may precede a slow wave's last barrier only by program order of ITS
     // OWN reads, all finished — the k loop ends with a barrier on every path)
@@ -1223,19 +1248,25 @@ __global__ __launch_bounds__(MF_THREADS) void k_conv_mfx(MfxArgs a) {
       };
       float* __restrict__ p0 = a.partial0 + ((size_t)slab * a.n_pad + n0) * (size_t)(a.nt0 * 32);
       float* __restrict__ p1 = a.partial1 + ((size_t)slab * a.n_pad + n0) * 96;
-      for (int idx = tid; idx < 32 * 40; idx += MF_THREADS) {
+#pragma unroll
+      for (int n = 0; n < 3; ++n) {
+        const int idx = tid + MF_THREADS * n;
+        if (idx >= 32 * 40) break;
         const int row = idx / 40, c4 = idx - row * 40;
         const float4 a0 = *reinterpret_cast<const float4*>(ST0 + row * 160 + 4 * c4), a1 = *reinterpret_cast<const float4*>(ST0 + 5120 + row * 160 + 4 * c4);
-        const float4 cf = reinterpret_cast<const float4*>(a.cf0)[c4];
+        const float4 cf = cfa[n];
         const float i2 = i2_of(row);
         if (row < n_dst)
           *reinterpret_cast<float4*>(p0 + row * 160 + 4 * c4) = make_float4((((a0.x + a1.x) * i1) * i2) * cf.x, (((a0.y + a1.y) * i1) * i2) * cf.y,
                                                                              (((a0.z + a1.z) * i1) * i2) * cf.z, (((a0.w + a1.w) * i1) * i2) * cf.w);
       }
-      for (int idx = tid; idx < 32 * 24; idx += MF_THREADS) {
+#pragma unroll
+      for (int n = 0; n < 2; ++n) {
+        const int idx = tid + MF_THREADS * n;
+        if (idx >= 32 * 24) break;
         const int row = idx / 24, c4 = idx - row * 24;
         const float4 a0 = *reinterpret_cast<const float4*>(ST1 + row * 96 + 4 * c4), a1 = *reinterpret_cast<const float4*>(ST1 + 3072 + row * 96 + 4 * c4);
-        const float4 cf = reinterpret_cast<const float4*>(a.cf1)[c4 & 7];
+        const float4 cf = cfb[n];
         const float i2 = i2_of(row);
         if (row < n_dst)
           *reinterpret_cast<float4*>(p1 + row * 96 + 4 * c4) = make_float4((((a0.x + a1.x) * i1) * i2) * cf.x, (((a0.y + a1.y) * i1) * i2) * cf.y,
@@ -1243,6 +1274,7 @@ __global__ __launch_bounds__(MF_THREADS) void k_conv_mfx(MfxArgs a) {
       }
     }
     LDS_BARRIER();  // the next segment rewrites the tiles
+    sg0 = nsg0; sg1 = nsg1;
   }
 }
 

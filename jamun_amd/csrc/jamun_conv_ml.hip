@@ -118,8 +118,8 @@ __global__ __launch_bounds__(ML_THREADS) void k_conv_ml(MlArgs a) {
     auto slt_of = [&](int p) __attribute__((always_inline)) { return p == NPM ? SPL + (lane & 7) : (bt + BT * p) % SPL; };
     const int slot0 = (n0 + dst_of(0)) * a.S + slt_of(0), pstride = DPP * a.S, slot_x = (n0 + dst_of(NPM)) * a.S + slt_of(NPM);
     auto slot_of = [&](int p) __attribute__((always_inline)) { return p == NPM ? slot_x : slot0 + p * pstride; };
-    int dgv = 0;
-    if (tid < 32 && tid < n_dst) dgv = a.deg[n0 + tid];
+    const int dgl = a.deg[n0 + min(tid & 31, n_dst - 1)];
+    const int dgv = dgl * ((tid < 32 && tid < n_dst) ? 1 : 0);  // (a product, not a select: a select's load is sunk into a branch)
     float hv[NP];
     auto load_h = [&](int k) __attribute__((always_inline)) {  // h~ of this lane's edge slots of hidden unit k (lanes past the in-degree read a neighbouring slot: never used)
       const float* __restrict__ hk = a.h + (size_t)k * a.h_kstride;
@@ -131,13 +131,17 @@ __global__ __launch_bounds__(ML_THREADS) void k_conv_ml(MlArgs a) {
     int sjv[NP], epv[NP], ent[NP];
 #pragma unroll
     for (int p = 0; p < NP; ++p) {
-      const int i = dst_of(p), t = slt_of(p), slot = slot_of(p);
+      const int i = dst_of(p), t = slt_of(p);
       const bool in = i < n_dst && t < a.S;
-      sjv[p] = in ? a.esrc[slot] : 0;
-      epv[p] = in ? a.epair[slot] : 0;
-      float4 ge = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (in) ge = a.egeo[slot];
-      evx[p] = ge.x; evy[p] = ge.y; evz[p] = ge.z;
+      // (unconditional requests at a clamped slot — a destination of the tile, a slot below the stride — masked after: as `in ? a.esrc[slot] : 0`
+      // every load was a branch and some of the branches carried an `s_waitcnt vmcnt(0)`, round 6)
+      const int sc_ = (n0 + min(i, n_dst - 1)) * a.S + min(t, a.S - 1);
+      const int sj_ = a.esrc[sc_], ep_ = a.epair[sc_];
+      const float4 ge = a.egeo[sc_];
+      const float kin = in ? 1.f : 0.f;
+      sjv[p] = in ? sj_ : 0;
+      epv[p] = in ? ep_ : 0;
+      evx[p] = ge.x * kin; evy[p] = ge.y * kin; evz[p] = ge.z * kin;
     }
 
     // ---- prologue 1: zero the coefficient tiles of pass V; largest |x g| over the span's rows (all 216 channels: ONE scale 2^sX for both passes)
@@ -153,7 +157,7 @@ __global__ __launch_bounds__(ML_THREADS) void k_conv_ml(MlArgs a) {
         for (int j0 = jg; j0 < rows; j0 += 45) {
           float4 v[5];
 #pragma unroll
-          for (int q = 0; q < 5; ++q) v[q] = j0 + 9 * q < rows ? px[(size_t)(j0 + 9 * q) * (a.XS / 4)] : make_float4(0.f, 0.f, 0.f, 0.f);
+          for (int q = 0; q < 5; ++q) v[q] = px[(size_t)min(j0 + 9 * q, rows - 1) * (a.XS / 4)];  // (clamped: a repeated row does not change the maximum; unconditional requests)
 #pragma unroll
           for (int q = 0; q < 5; ++q) mx = fmaxf(mx, fmaxf(fmaxf(fabsf(v[q].x * g4.x), fabsf(v[q].y * g4.y)), fmaxf(fabsf(v[q].z * g4.z), fabsf(v[q].w * g4.w))));
         }
@@ -827,8 +831,8 @@ __global__ __launch_bounds__(ML_THREADS) void k_conv_mlx(MlxArgs a) {
     // ---- builder layout: four passes of 8 destinations x 64 slots over the 512 lanes (a destination's slots inside one wave)
     constexpr int NP = 4;
     const int slot0 = (n0 + tid / 64) * a.S + (tid & 63), pstride = 8 * a.S;
-    int dgv = 0;
-    if (tid < 32 && tid < n_dst) dgv = a.deg[n0 + tid];
+    const int dgl = a.deg[n0 + min(tid & 31, n_dst - 1)];
+    const int dgv = dgl * ((tid < 32 && tid < n_dst) ? 1 : 0);
     float hv[NP];
     auto load_h = [&](int k) __attribute__((always_inline)) {
       const float* __restrict__ hk = a.h + (size_t)k * a.h_kstride;
@@ -842,11 +846,13 @@ __global__ __launch_bounds__(ML_THREADS) void k_conv_mlx(MlxArgs a) {
     for (int p = 0; p < NP; ++p) {
       const int i = tid / 64 + 8 * p, t = tid & 63;
       const bool in = i < n_dst && t < a.S;
-      sjv[p] = in ? a.esrc[slot0 + p * pstride] : 0;
-      epv[p] = in ? a.epair[slot0 + p * pstride] : 0;
-      float4 ge = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (in) ge = a.egeo[slot0 + p * pstride];
-      evx[p] = ge.x; evy[p] = ge.y; evz[p] = ge.z;
+      const int sc_ = (n0 + min(i, n_dst - 1)) * a.S + min(t, a.S - 1);  // (unconditional, clamped, masked: as k_conv_ml)
+      const int sj_ = a.esrc[sc_], ep_ = a.epair[sc_];
+      const float4 ge = a.egeo[sc_];
+      const float kin = in ? 1.f : 0.f;
+      sjv[p] = in ? sj_ : 0;
+      epv[p] = in ? ep_ : 0;
+      evx[p] = ge.x * kin; evy[p] = ge.y * kin; evz[p] = ge.z * kin;
     }
     // ---- prologue: zero the coefficient tiles; the window's rows (already split, two atoms per word): a copy, transposed
     for (int idx = tid; idx < 4 * CC / 16; idx += ML_THREADS) reinterpret_cast<float4*>(lds + X_C)[idx] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -859,8 +865,8 @@ __global__ __launch_bounds__(ML_THREADS) void k_conv_mlx(MlxArgs a) {
 #pragma unroll
       for (int q = 0; q < NQ; ++q) {
         const int idx = tid + ML_THREADS * q;
-        vh[q] = idx < NW ? ph[idx] : 0u;
-        vl[q] = idx < NW ? pl[idx] : 0u;
+        vh[q] = ph[min(idx, NW - 1)];  // (unconditional, clamped; pieces past the end are not stored)
+        vl[q] = pl[min(idx, NW - 1)];
       }
 #pragma unroll
       for (int q = 0; q < NQ; ++q) {
