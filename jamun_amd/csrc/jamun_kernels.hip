@@ -96,6 +96,16 @@ __device__ __forceinline__ void geom_body(float* __restrict__ y, const int* __re
   const int g = blockIdx.x;
   const int lo = ptr[g], hi = ptr[g + 1];
   const bool in_lds = hi - lo <= GEOM_LDS_ATOMS;
+  // (the bond list of this thread's first atom — topology, independent of the positions — is requested here, with the integrator's inputs:
+  // at its point of use, behind three barriers, it was two more dependent round trips of a kernel that is a chain of them)
+  const int i_first = lo + (int)threadIdx.x;
+  int pf_b0 = 0, pf_b1 = 0, pf_src[4] = {-1, -1, -1, -1};
+  if (i_first < hi) {
+    pf_b0 = bond_in_ptr[i_first];
+    pf_b1 = bond_in_ptr[i_first + 1];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) pf_src[q] = q < pf_b1 - pf_b0 ? bond_in_src[pf_b0 + q] : -1;
+  }
   if (pre.v) {
     for (int i = lo + threadIdx.x; i < hi; i += blockDim.x) {
       // (the atom's nine inputs requested before its first store: pre.v / pre.psi may alias y for all the compiler knows, and between the stores
@@ -152,11 +162,12 @@ __device__ __forceinline__ void geom_body(float* __restrict__ y, const int* __re
     const size_t base = (size_t)i * S;
     // pair table (jamun_internal.h: JAMUN_EP_*): the radial slot of each bonded neighbour is noted while the radial edges are written
     // (atoms with up to four bonds; more: a scan over the slots below)
-    const int bnd0 = bond_in_ptr[i], n_bnd = bond_in_ptr[i + 1] - bnd0;
+    const bool pf = i == i_first;  // (always, for molecules up to the workgroup's 128 threads)
+    const int bnd0 = pf ? pf_b0 : bond_in_ptr[i], n_bnd = (pf ? pf_b1 : bond_in_ptr[i + 1]) - bnd0;
     const bool ep_fast = epair != nullptr && n_bnd <= 4;
     int bsrc[4], twin[4];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) { bsrc[q] = (ep_fast && q < n_bnd) ? bond_in_src[bnd0 + q] : -1; twin[q] = -1; }
+    for (int q = 0; q < 4; ++q) { bsrc[q] = (ep_fast && q < n_bnd) ? (pf ? pf_src[q] : bond_in_src[bnd0 + q]) : -1; twin[q] = -1; }
     for (int j = lo; j < hi; ++j) {
       const float qx = rd(j * 3), qy = rd(j * 3 + 1), qz = rd(j * 3 + 2);
       float dx = FSUB(qx, px), dy = FSUB(qy, py), dz = FSUB(qz, pz);
@@ -179,8 +190,15 @@ __device__ __forceinline__ void geom_body(float* __restrict__ y, const int* __re
       }
     }
     const int nr_rad = nr;
-    for (int b = bond_in_ptr[i]; b < bond_in_ptr[i + 1]; ++b) {
-      const int j = bond_in_src[b];
+    for (int b = bnd0; b < bnd0 + n_bnd; ++b) {
+      int j = -1;
+      if (pf && b - bnd0 < 4) {  // (a compare per element: a run-time index would put the array into scratch)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          if (q == b - bnd0) j = pf_src[q];
+      } else {
+        j = bond_in_src[b];
+      }
       const float qx = rd(j * 3), qy = rd(j * 3 + 1), qz = rd(j * 3 + 2);  // (bonds stay inside the walker's molecule)
       float ex = FSUB(FMUL(qx, c_in), sx), ey = FSUB(FMUL(qy, c_in), sy), ez = FSUB(FMUL(qz, c_in), sz);
       float d = sqrtf(fmaf(ez, ez, fmaf(ey, ey, FMUL(ex, ex))));
@@ -338,14 +356,14 @@ __global__ __launch_bounds__(256) void k_edge_h16(const int* __restrict__ deg, c
   const long slot = ((long)blockIdx.x * 4 + wave) * 32 + e_l;
   const int i = slot < n_slots ? (int)(slot / S) : 0;
   const int t = (int)(slot - (long)i * S);
+  // (the slot's record requested with the in-degree, not behind it: unconditional at a clamped slot, masked by `valid` — one dependent round trip less)
+  const long slot_c = slot < n_slots ? slot : n_slots - 1;
+  const float d_raw = egeo[slot_c].w;
+  const int src_raw = esrc[slot_c];
   const bool valid = slot < n_slots && t < deg[i];
   if (__ballot(valid) == 0) return;  // wave-uniform: no edge in these 32 slots
-  float d = 0.f;
-  int bonded = 0;
-  if (valid) {
-    d = egeo[slot].w;
-    bonded = esrc[slot] < 0 ? 1 : 0;
-  }
+  const float d = valid ? d_raw : 0.f;
+  const int bonded = (valid && src_raw < 0) ? 1 : 0;
   float4 Rh[2], Rl[2];  // B fragments: lane (slot, hh), halves p <-> basis 16 s2 + 8 hh + p
   const float inv_step = 1.f / step;
 #pragma unroll
