@@ -175,3 +175,38 @@ def test_hazard_scanner_flags_the_round5_pattern_and_accepts_the_compiler_forms(
     # the 4-pass and the fp32-input (non-XDL) opcodes have their own distances
     assert run("\tv_mfma_f32_16x16x32_f16 v[0:3], v[16:19], v[20:23], v[0:3]\n\ts_nop 6\n\tv_mul_f32_e32 v40, v0, v41\n") == [("RAW", 7, 8)]
     assert run("\tv_mfma_f32_32x32x2_f32 v[0:15], v16, v20, v[0:15]\n\ts_nop 15\n\ts_nop 1\n\tv_mul_f32_e32 v40, v0, v41\n") == []
+
+
+def test_wait_scan_counts_requests_that_are_waited_for_at_once(tmp_path):
+    """profiles/tools/wait_scan.py: a request followed by `s_waitcnt vmcnt(0)` within a few instructions is one serialised
+    round trip; requests that are issued together and waited for once are not."""
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("wait_scan", os.path.join(ROOT, "profiles", "tools", "wait_scan.py"))
+    ws = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ws)
+    text = "\n".join([
+        "_Z4k_ab:",
+        "\tglobal_load_dword v0, v[2:3], off",
+        "\ts_waitcnt vmcnt(0)",
+        "\tv_add_f32 v1, v0, v0",
+        "\tglobal_load_dword v4, v[2:3], off",
+        "\ts_waitcnt vmcnt(0)",
+        "\t.size\t_Z4k_ab, .Lfunc_end0-_Z4k_ab",
+        "_Z4k_ok:",
+        "\tglobal_load_dword v0, v[2:3], off",
+        "\tglobal_load_dword v4, v[2:3], off",
+    ] + ["\tv_mov_b32 v9, v9"] * 20 + [
+        "\ts_waitcnt vmcnt(0)",
+        "\t.size\t_Z4k_ok, .Lfunc_end1-_Z4k_ok",
+    ])
+    f = tmp_path / "k.s"
+    f.write_text(text)
+    ks = ws.kernels(str(f))
+    assert set(ks) == {"_Z4k_ab", "_Z4k_ok"}
+
+    def tight(name):
+        ins = ws.instrs(ks[name])
+        return sum(1 for i, x in enumerate(ins) if ws.is_load(x) and any(y.startswith("s_waitcnt") and "vmcnt(0)" in y for y in ins[i + 1 : i + ws.W]))
+
+    assert tight("_Z4k_ab") == 2 and tight("_Z4k_ok") == 0
