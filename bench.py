@@ -443,6 +443,32 @@ class _StubBatchSampler:
         return {"xhat": y_init, "y": y_init, "v": torch.zeros_like(y_init), "sample": y_init, "xhat_traj": xt, "y_traj": xt, "score_traj": xt, "t_traj": torch.ones(T)}
 
 
+def _guarded_sharded_leg(out, rank, leg, timeout_s=240.0):
+    """Runs the trajectory-exchange leg so that it can never cost the line its headline: the send / receive pairs between GPUs have only ever
+    run on gloo and on a one-rank RCCL group (no multi-GPU node was available to the builder), so an exception becomes
+    `{"error": ...}` in the line, and an exchange that does not return within `timeout_s` makes rank 0 print the line it has — the walk's
+    numbers are final before this leg starts — and every rank leave without a barrier."""
+    import threading
+
+    done = threading.Event()
+
+    def watchdog():
+        if done.wait(timeout_s):
+            return
+        if rank == 0 and out is not None:
+            out["e2e_sharded"] = {"error": f"the sharded leg did not return within {timeout_s:.0f} s (exchange not completed); the timed walk above is unaffected"}
+            print(json.dumps(out), flush=True)
+        os._exit(0)
+
+    threading.Thread(target=watchdog, daemon=True).start()
+    try:
+        res = leg()
+    except Exception as e:  # noqa: BLE001 — reported in the line
+        res = {"error": f"{type(e).__name__}: {e}"[:400]}
+    done.set()
+    return res
+
+
 def e2e_sharded(model, cfg, dev, world, rank, steps=1000, num_batches=2, walkers_total=None, stub=False):
     """north_star's ONE collective inside a timed interval: `Sampler.sample(shard_walkers=True, num_batches=2)` over all ranks with
     `SaveTrajectoryCallback` — the walker batch is sharded (contiguous, cost balanced), every rank walks its share, and after each batch the
@@ -733,11 +759,10 @@ def main():
     rccl = rccl_record(dev, world)
     sharded = None
     grouped = torch.distributed.is_available() and torch.distributed.is_initialized()  # (under a launcher even one rank has a group: the RCCL path runs)
-    if ((world > 1 and not args.no_e2e) or (grouped and args.sharded_leg)) and args.walkers is None and args.atoms is None:
+    # (the leg itself runs at the very end, when rank 0's line is complete but for it: `_guarded_sharded_leg`)
+    sharded_wanted = ((world > 1 and not args.no_e2e) or (grouped and args.sharded_leg)) and args.walkers is None and args.atoms is None
+    if sharded_wanted:
         y_traj = score_traj = xhat_traj = None  # (free the headline walk's frames)
-        # (every rank takes part; 1000 steps per batch: 0.85 s of walking per batch at cfg2, 13 MB per rank and batch to rank 0)
-        sharded = e2e_sharded(model, args.config, dev, world, rank, steps=1000, num_batches=2,
-                              walkers_total=total_walkers if args.strong else None)
 
     if rank == 0:
         total_conf = int(tot_walkers.item()) * args.steps
@@ -861,8 +886,6 @@ def main():
             if stats.get("n_tail_tiles"):
                 out["config"]["tail_tiles"] = f"{stats['n_tail_tiles']} tiles / {stats['n_tail']} destinations through k_tail_form + k_tail_contract (kernel class conv1)"
         out["rccl"] = rccl
-        if sharded is not None:
-            out["e2e_sharded"] = sharded
         if world == 1:
             del y_traj, score_traj, xhat_traj
         if not args.no_also and world == 1 and args.config == "cfg2" and args.walkers is None and args.atoms is None and not args.strong and not args.separable:
@@ -879,7 +902,18 @@ def main():
             out["secondary_rooflines"] = secondary_rooflines(dev)
         if cpu_line is not None:
             out["cpu_baseline"] = cpu_line
+    else:
+        out = None
+    if sharded_wanted:
+        # every rank takes part; 1000 steps per batch: 0.85 s of walking per batch at cfg2, 13 MB per rank and batch to rank 0
+        sharded = _guarded_sharded_leg(out, rank, lambda: e2e_sharded(model, args.config, dev, world, rank, steps=1000, num_batches=2,
+                                                                      walkers_total=total_walkers if args.strong else None))
+        if rank == 0:
+            out["e2e_sharded"] = sharded
+    if rank == 0:
         print(json.dumps(out), flush=True)
+    if sharded_wanted and isinstance(sharded, dict) and "error" in sharded:
+        os._exit(0)  # (an exchange that failed on this rank leaves the group in an unknown state: no barrier, no orderly shutdown)
     if world > 1:
         dist.barrier()  # (names the device under nccl)
         torch.distributed.destroy_process_group()

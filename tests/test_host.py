@@ -855,3 +855,27 @@ def test_parse_datasets_from_directory(tmp_path):
             "pdb_pattern": "^(.*)-traj-state0.pdb", "subsample": 1, "max_datasets": 3}
     ds = C.instantiate(node)
     assert [d.label() for d in ds] == ["AG", "FY", "GA"] and len(ds[0]) == 5
+
+
+def test_bench_sharded_leg_cannot_cost_the_line_its_headline():
+    """`bench._guarded_sharded_leg`: the exchange between GPUs has never run on a multi-GPU node, so an exception inside the leg becomes an
+    `error` entry of the line, and a leg that does not return makes rank 0 print the line it has and every rank leave."""
+    import subprocess
+    import sys
+
+    import bench
+
+    out = {"metric": "m", "value": 1.0}
+    res = bench._guarded_sharded_leg(out, 0, lambda: (_ for _ in ()).throw(RuntimeError("recv failed")))
+    assert res == {"error": "RuntimeError: recv failed"}
+    assert bench._guarded_sharded_leg(out, 0, lambda: {"wall_s": 1.0}) == {"wall_s": 1.0}
+    code = (
+        "import json, time, sys; sys.path.insert(0, %r); import bench\n"
+        "out = {'metric': 'm', 'value': 2.5}\n"
+        "bench._guarded_sharded_leg(out, 0, lambda: time.sleep(60), timeout_s=0.5)\n"
+        "print('not reached')\n" % ROOT
+    )
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "not reached" not in r.stdout
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["value"] == 2.5 and "did not return" in line["e2e_sharded"]["error"]
